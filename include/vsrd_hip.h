@@ -1,0 +1,137 @@
+/*
+ * libvsrd_hip -- C ABI of the MI355X (gfx950) implementation of VSRD's instance-aware
+ * volumetric silhouette renderer and the geometry around it.
+ *
+ * The reference (skmhrk1209/VSRD) is pure Python on PyTorch and defines no FFI; the
+ * boundary it offers is the Python call surface of vsrd.rendering / vsrd.operations as
+ * used by scripts/main.py.  Every entry point below names the
+ * reference function it replaces (file:line under the reference checkout).  The Python
+ * package vsrd_amd/ binds these symbols with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers to fp32 (or the stated type), caller-owned;
+ *   - per-sample tensors are ray-major: [R, D] (the reference's sample-major [D, R, 1]
+ *     is a permuted view of the same buffer);
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), touches no
+ *     global state and is re-entrant;
+ *   - return value: 0 on success, a negative VSRD_E_* code otherwise (never throws);
+ *     vsrd_error_string() describes a code.
+ */
+#ifndef VSRD_HIP_H
+#define VSRD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSRD_ABI_VERSION 1
+
+#define VSRD_OK 0
+#define VSRD_E_INVALID_ARGUMENT (-1) /* null pointer, non-positive size, unsupported N / S */
+#define VSRD_E_UNSUPPORTED (-2)      /* valid request this build does not implement        */
+#define VSRD_E_LAUNCH (-3)           /* hipGetLastError() != hipSuccess after the launch   */
+#define VSRD_E_WORKSPACE (-4)        /* workspace too small (see vsrd_workspace_bytes)     */
+
+#define VSRD_MAX_INSTANCES 64  /* N, instances per soft-min union                         */
+#define VSRD_MAX_SAMPLES 256   /* S, num_samples of hierarchical_volumetric_rendering      */
+#define VSRD_INSTANCE_STRIDE 16 /* floats per packed instance: t[3] R[9] (row-major) dim[3] pad */
+#define VSRD_MLP_WEIGHTS 1617  /* per-instance residual MLP, hyper_distance_field.py:18-25 */
+
+/* Field = temperature soft-min union of N oriented boxes (+ optional residual MLP).
+ * Replaces the closure tree scripts/main.py:525-618 builds from
+ *   vsrd/rendering/sdfs.py:9-37 (box, rotation, translation),
+ *   scripts/main.py:433-492     (residual field/composition, instance_field, soft_union). */
+typedef struct vsrd_field {
+    int32_t num_instances;      /* N, 1..VSRD_MAX_INSTANCES                                */
+    float temperature;          /* sdf_union_temperature, main.py:423-426                  */
+    const float* instances;     /* [N, 16] packed: location, rotation matrix, half extents */
+    const float* mlp_weights;   /* [N, 1617] or NULL (box-only)                            */
+} vsrd_field;
+
+/* Scalars of vsrd.rendering.hierarchical_volumetric_rendering (renderers.py:177-188). */
+typedef struct vsrd_render_config {
+    int32_t num_rays;           /* R                                                        */
+    int32_t num_samples;        /* S ("num_samples"); pass 1 renders S-1, pass 2 2S-1 points */
+    float distance_near;        /* distance_range[0]                                        */
+    float distance_far;         /* distance_range[1]                                        */
+    float sdf_std_deviation;    /* NeuS logistic std                                        */
+    float cosine_ratio;         /* cos anneal ratio, renderers.py:234-239                   */
+    float epsilon;              /* opacity denominator guard, default 1e-6                  */
+    int32_t origin_stride;      /* floats between ray origins: 3, or 0 for one shared origin */
+    uint64_t seed;              /* Philox key when uniforms are generated in-kernel         */
+    uint64_t stream_offset;     /* Philox counter offset (step index)                       */
+    uint32_t flags;             /* VSRD_FLAG_*                                              */
+} vsrd_render_config;
+
+#define VSRD_FLAG_FINE_UNIFORMS_SORTED 1u /* u_fine is already sorted ascending per ray     */
+#define VSRD_FLAG_SKIP_EXACT_MISSES 2u    /* rays whose coarse weights are all exactly 0 skip pass 2:
+                                             labels = 0 (exact); distances/gradients/weights of such
+                                             rays are NOT produced (fused-loss mode only)        */
+
+int32_t vsrd_abi_version(void);
+const char* vsrd_error_string(int32_t code);
+
+/* Bytes of scratch vsrd_render_backward needs for a field of N instances. */
+size_t vsrd_workspace_bytes(int32_t num_instances);
+
+/* vsrd.rendering.ray_casting (vsrd/rendering/utils.py:5-18), the per-pixel part:
+ * directions[v,y,x,:] = normalize(inverse_projection[v] @ (x, y, 1)), integer pixel centres.
+ * inverse_projection [V,9] = inv(E)[:3,:3] @ inv(K) (row-major), computed by the caller. */
+int32_t vsrd_ray_directions(const float* inverse_projection, int32_t num_views, int32_t height, int32_t width,
+                            float* directions /* [V,H,W,3] */, void* stream);
+
+/* Evaluate the field at arbitrary points: what calling the distance_field closure does
+ * (scripts/main.py:477-492) plus the autograd normal of renderers.py:76-113 / :218-228.
+ * Any of distances [P], gradients [P,3], labels [P,N] may be NULL.
+ * hard_union != 0 selects the arg-min union of scripts/main.py:494-509 (distances only). */
+int32_t vsrd_field_eval(const vsrd_field* field, const float* positions /* [P,3] */, int64_t num_points,
+                        float* distances, float* gradients, float* labels, int32_t hard_union, void* stream);
+
+/* samplers.quadrature_sampler over linspace bins (renderers.py:191-194, samplers.py:5-8).
+ * u_coarse [R,S] in [0,1) -> distances [R,S]. */
+int32_t vsrd_sample_stratified(const vsrd_render_config* config, const float* u_coarse, float* distances, void* stream);
+
+/* Pass-2 distances: cat(coarse, inverse_transform_sampler(coarse, weights)) sorted
+ * (renderers.py:198-210, samplers.py:11-36).  coarse_distances [R,S], coarse_weights [R,S-1],
+ * u_fine [R,S] (raw draws, or sorted with VSRD_FLAG_FINE_UNIFORMS_SORTED) -> merged [R,2S]. */
+int32_t vsrd_sample_importance(const vsrd_render_config* config, const float* coarse_distances,
+                               const float* coarse_weights, const float* u_fine, float* merged, void* stream);
+
+/* renderers.py:212-270 for given sorted distances [R,D]: evaluates the field and its normal at
+ * the D-1 interval mid-points, converts to opacities, composites front to back.
+ * Outputs: labels [R,N]; gradients [R,D-1,3] (may be NULL); weights [R,D-1] (may be NULL). */
+int32_t vsrd_render_forward(const vsrd_field* field, const vsrd_render_config* config,
+                            const float* origins, const float* directions,
+                            const float* distances, int32_t num_distances,
+                            float* labels, float* gradients, float* weights, void* stream);
+
+/* Adjoint of vsrd_render_forward w.r.t. the packed instances (what autograd, including the
+ * double-backward through the SDF normal, produces in the reference -- renderers.py:218-228).
+ * grad_labels [R,N]; grad_gradients [R,D-1,3] or NULL; grad_weights [R,D-1] or NULL.
+ * grad_instances [N,16] is OVERWRITTEN (pad column = 0).  workspace: vsrd_workspace_bytes(N). */
+int32_t vsrd_render_backward(const vsrd_field* field, const vsrd_render_config* config,
+                             const float* origins, const float* directions,
+                             const float* distances, int32_t num_distances,
+                             const float* grad_labels, const float* grad_gradients, const float* grad_weights,
+                             void* workspace, size_t workspace_bytes,
+                             float* grad_instances, void* stream);
+
+/* The two-pass wrapper scripts/main.py:511-523 around renderers.py:177-270 in ONE launch:
+ * pass 1 (stratified, no grad) -> importance sampling -> merge -> pass 2.
+ * u_coarse / u_fine [R,S]: recorded uniforms, or NULL -> Philox4x32-10 keyed by (seed, stream_offset, ray).
+ * Outputs: labels [R,N]; distances [R,2S] (needed by vsrd_render_backward; may be NULL for
+ * inference); gradients [R,2S-1,3] / weights [R,2S-1] may be NULL;
+ * u_coarse_out / u_fine_out [R,S] (may be NULL) export the uniforms actually used. */
+int32_t vsrd_render_hierarchical_forward(const vsrd_field* field, const vsrd_render_config* config,
+                                         const float* origins, const float* directions,
+                                         const float* u_coarse, const float* u_fine,
+                                         float* labels, float* distances, float* gradients, float* weights,
+                                         float* u_coarse_out, float* u_fine_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSRD_HIP_H */

@@ -1,0 +1,283 @@
+"""Parity of the HIP render path (through the C ABI) against the CPU oracle and the committed golden
+vectors.  Needs a real MI355X: run with ``-m gpu``."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, RENDER_CASES
+from oracle import fields as ofields, rendering as orendering, geometry as ogeometry, losses as olosses
+
+pytestmark = pytest.mark.gpu
+
+LABEL_TOL = 1.0e-4   # BASELINE.json north_star: silhouettes within 1e-4 max-abs of the reference
+GRAD_TOL = 5.0e-3    # parameter gradients, relative to the largest entry of each tensor
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    import __graft_entry__
+    __graft_entry__.build()
+    return torch.device("cuda:0")
+
+
+def hip_union(g, dev, requires_grad=False, temperature=None):
+    from vsrd_amd import fields, rendering
+    loc = g["locations"].to(dev).requires_grad_(requires_grad)
+    dim = g["dimensions"].to(dev).requires_grad_(requires_grad)
+    rot = g["orientations"].to(dev).requires_grad_(requires_grad)
+    N = loc.shape[0]
+    T = float(g["temperature"]) if temperature is None else temperature
+    union = fields.soft_union([
+        rendering.sdfs.translation(rendering.sdfs.rotation(fields.instance_field(rendering.sdfs.box(dim[i]), i, N), rot[i]), loc[i])
+        for i in range(N)], T)
+    return union, (loc, dim, rot)
+
+
+def cpu_union(g, requires_grad=False, dtype=torch.float32):
+    loc = g["locations"].to(dtype).clone().requires_grad_(requires_grad)
+    dim = g["dimensions"].to(dtype).clone().requires_grad_(requires_grad)
+    rot = g["orientations"].to(dtype).clone().requires_grad_(requires_grad)
+    return ofields.InstanceUnion(loc, rot, dim, float(g["temperature"])), (loc, dim, rot)
+
+
+def test_wave_primitives(dev):
+    import ctypes
+    from vsrd_amd import _lib
+    lib = _lib.load()
+    fn = lib.vsrd_selftest_wave
+    fn.restype, fn.argtypes = ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    v = torch.randn(64, generator=torch.Generator().manual_seed(1))
+    out = torch.zeros(512, device=dev)
+    _lib.check(fn(_lib.ptr(v.to(dev)), _lib.ptr(out), _lib.stream()))
+    out = out.cpu()
+    v64 = v.double()
+    torch.testing.assert_close(out[0:64], v64.sum().float().expand(64), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out[64:128], torch.cumsum(v64, 0).float(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out[128:192], torch.cumprod(1 + 0.01 * v64, 0).float(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(out[192:256], v.max().expand(64))
+    assert torch.equal(out[256:320], v.flip(0))
+    assert torch.equal(out[320:384], torch.cat([torch.tensor([-7.0]), v[:-1]]))
+    u = out[384:448]
+    assert torch.all((u >= 0) & (u < 1)) and u.unique().numel() > 60
+    assert torch.equal(out[448:512], torch.linspace(0.0, 100.0, 65)[:64])
+
+
+def test_ray_casting_g1(dev):
+    from vsrd_amd import rendering
+    g = load_golden("g1_ray_casting")
+    for tag in ("small", "mid"):
+        h, w = (int(v) for v in g[f"{tag}_hw"])
+        cam, dirs = rendering.ray_casting((h, w), g[f"{tag}_K"].to(dev), g[f"{tag}_E"].to(dev))
+        torch.testing.assert_close(cam.cpu(), g[f"{tag}_camera_positions"], rtol=0, atol=1e-6)
+        torch.testing.assert_close(dirs.cpu(), g[f"{tag}_ray_directions"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("temperature,tag", [(1.0, "T1"), (0.1, "T0p1")])
+def test_field_eval_g3(dev, temperature, tag):
+    from vsrd_amd import rendering
+    g = load_golden("g2_g3_sdf_union")
+    union, _ = hip_union(g, dev, temperature=temperature)
+    u, w, grad = rendering.evaluate_field(union, g["points"].to(dev), with_gradients=True)
+    torch.testing.assert_close(u.cpu(), g[f"union_{tag}_distances"], rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(w.cpu(), g[f"union_{tag}_labels"], rtol=1e-4, atol=2e-6)
+    torch.testing.assert_close(grad.cpu(), g[f"union_{tag}_gradients"], rtol=1e-4, atol=5e-5)
+    # a single translated/rotated box called directly, and the hard union
+    from vsrd_amd import fields
+    single = union.distance_fields[2]
+    d = rendering.evaluate_field(single, g["points"].to(dev))
+    torch.testing.assert_close(d.cpu(), g["instance_distances"][2], rtol=1e-6, atol=3e-6)
+    hard = rendering.evaluate_field(fields.hard_union(union.distance_fields), g["points"].to(dev))
+    torch.testing.assert_close(hard.cpu(), g["instance_distances"].min(0).values, rtol=1e-6, atol=3e-6)
+
+
+@pytest.mark.parametrize("name", RENDER_CASES)
+def test_render_at_golden_distances(dev, name):
+    """Entry (i) of SURVEY §8c: given the reference's own sorted distances -> labels / gradients / weights."""
+    from vsrd_amd import rendering
+    g = load_golden(name)
+    union, _ = hip_union(g, dev)
+    std, ratio = float(g["sdf_std_deviation"]), float(g["cosine_ratio"])
+    for prefix in ("coarse", "fine"):
+        dist = g[f"{prefix}_distances"].t().contiguous().to(dev)
+        labels, grads, weights = rendering.render_at_distances(union, g["origins"].to(dev), g["directions"].to(dev), dist, std, ratio)
+        assert (labels.cpu() - g[f"{prefix}_labels"]).abs().max() < LABEL_TOL
+        assert (weights.cpu() - g[f"{prefix}_weights"].t()).abs().max() < LABEL_TOL
+        conditioned = g["coarse_weights"].sum(0) > 0 if prefix == "fine" else torch.ones(dist.shape[0], dtype=torch.bool)
+        torch.testing.assert_close(grads.cpu()[conditioned], g[f"{prefix}_gradients"].transpose(0, 1)[conditioned], rtol=2e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("name", RENDER_CASES)
+def test_importance_merge_golden(dev, name):
+    from vsrd_amd import rendering
+    g = load_golden(name)
+    merged = rendering.importance_merge(g["coarse_distances"].t().contiguous().to(dev), g["coarse_weights"].t().contiguous().to(dev),
+                                        uniforms=g["u_fine"].to(dev), sorted_uniforms=False).cpu()
+    ref = g["fine_distances"].t()
+    assert torch.all(merged[:, 1:] >= merged[:, :-1])
+    miss = g["coarse_weights"].sum(0) == 0
+    torch.testing.assert_close(merged[~miss], ref[~miss], rtol=1e-4, atol=5e-3)
+    torch.testing.assert_close(merged[miss], ref[miss], rtol=1e-5, atol=1e-3)
+    # pre-sorted uniforms give the same result
+    merged2 = rendering.importance_merge(g["coarse_distances"].t().contiguous().to(dev), g["coarse_weights"].t().contiguous().to(dev),
+                                         uniforms=torch.sort(g["u_fine"], -1).values.to(dev), sorted_uniforms=True).cpu()
+    assert torch.equal(merged, merged2)
+
+
+@pytest.mark.parametrize("name", RENDER_CASES)
+def test_fused_hierarchical_golden(dev, name):
+    """Fused two-pass kernel with the recorded uniforms against the reference's pass-2 outputs and gradients."""
+    from vsrd_amd import rendering
+    g = load_golden(name)
+    S = int(g["num_samples"])
+    union, params = hip_union(g, dev, requires_grad=True)
+    std, ratio = float(g["sdf_std_deviation"]), float(g["cosine_ratio"])
+    out = rendering.render_hierarchical(union, g["origins"].to(dev), g["directions"].to(dev), (0.0, 100.0), S, std, ratio,
+                                        u_coarse=g["u_coarse"].to(dev), u_fine=g["u_fine"].to(dev),
+                                        return_gradients=True, return_weights=True)
+    labels = out["labels"]
+    assert (labels.detach().cpu() - g["fine_labels"]).abs().max() < LABEL_TOL
+    assert (out["weights"].detach().cpu() - g["fine_weights"].t()).abs().max() < LABEL_TOL
+    miss = g["coarse_weights"].sum(0) == 0
+    torch.testing.assert_close(out["distances"].cpu()[~miss], g["fine_distances"].t()[~miss], rtol=1e-4, atol=5e-3)
+    # loss exactly as the golden generator assembled it (BCE + w * eikonal over well-conditioned rays)
+    bce = olosses.silhouette_loss(labels, g["targets"].to(dev))
+    eik = olosses.eikonal_loss(out["gradients"][(~miss).to(dev)])
+    torch.testing.assert_close(bce.detach().cpu(), g["bce"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(eik.detach().cpu(), g["eikonal_conditioned"], rtol=2e-3, atol=1e-6)
+    loss = bce + float(g["eikonal_weight"]) * eik
+    grads = torch.autograd.grad(loss, params)
+    for got, key in zip(grads, ("grad_locations", "grad_dimensions", "grad_orientations")):
+        scale = max(float(g[key].abs().max()), 1e-6)
+        err = (got.cpu() - g[key]).abs().max().item() / scale
+        assert err < GRAD_TOL, f"{key}: relative error {err:.3e}"
+
+
+@pytest.mark.parametrize("name", ["g4_render_n4_s32_mid", "g4_render_n16_s64_mid"])
+def test_api_two_pass_wrapper(dev, name):
+    """The reference call surface driven exactly like scripts/main.py:511-523 (torch RNG on the device);
+    checked against the oracle fed with the same draws."""
+    from vsrd_amd import rendering
+    g = load_golden(name)
+    S = int(g["num_samples"])
+    union, params = hip_union(g, dev, requires_grad=True)
+    std, ratio = float(g["sdf_std_deviation"]), float(g["cosine_ratio"])
+    kwargs = dict(distance_field=union, ray_positions=g["origins"].to(dev), ray_directions=g["directions"].to(dev),
+                  distance_range=[0.0, 100.0], num_samples=S, sdf_std_deviation=std, cosine_ratio=ratio)
+    torch.manual_seed(1234)
+    with torch.no_grad():
+        *_, cd, cw = rendering.hierarchical_volumetric_rendering(**kwargs)
+    labels, grads, fd, fw = rendering.hierarchical_volumetric_rendering(**kwargs, sampled_distances=cd, sampled_weights=cw)
+    R = g["origins"].shape[0]
+    assert cd.shape == (S, R, 1) and cw.shape == (S - 1, R, 1)
+    assert labels.shape == (R, g["locations"].shape[0]) and grads.shape == (2 * S - 1, R, 3)
+    assert fd.shape == (2 * S, R, 1) and fw.shape == (2 * S - 1, R, 1)
+    # replay the device RNG stream for the oracle
+    torch.manual_seed(1234)
+    u_coarse = torch.rand(R, 1, S, device=dev)[:, 0].cpu()
+    u_fine = torch.rand(R, 1, S, device=dev)[:, 0].cpu()
+    ounion, oparams = cpu_union(g, requires_grad=True)
+    fine = orendering.hierarchical_render(ounion, g["origins"], g["directions"], (0.0, 100.0), S, std, ratio, u_coarse, u_fine)
+    assert (labels.detach().cpu() - fine.labels.detach()).abs().max() < LABEL_TOL
+    loss = olosses.silhouette_loss(labels, g["targets"].to(dev))
+    oloss = olosses.silhouette_loss(fine.labels, g["targets"])
+    for got, want in zip(torch.autograd.grad(loss, params), torch.autograd.grad(oloss, oparams)):
+        err = (got.cpu() - want).abs().max().item() / max(want.abs().max().item(), 1e-6)
+        assert err < GRAD_TOL
+
+
+def test_philox_mode_matches_oracle_on_exported_uniforms(dev):
+    from vsrd_amd import rendering
+    g = load_golden("g4_render_n4_s32_mid")
+    S = int(g["num_samples"])
+    union, _ = hip_union(g, dev)
+    std, ratio = float(g["sdf_std_deviation"]), float(g["cosine_ratio"])
+    args = (union, g["origins"].to(dev), g["directions"].to(dev), (0.0, 100.0), S, std, ratio)
+    a = rendering.render_hierarchical(*args, seed=7, stream_offset=3, return_uniforms=True)
+    b = rendering.render_hierarchical(*args, seed=7, stream_offset=3, return_uniforms=True)
+    c = rendering.render_hierarchical(*args, seed=8, stream_offset=3, return_uniforms=True)
+    assert torch.equal(a["labels"], b["labels"]) and torch.equal(a["u_fine"], b["u_fine"])      # deterministic
+    assert not torch.equal(a["u_coarse"], c["u_coarse"])
+    u = torch.cat([a["u_coarse"].flatten(), a["u_fine"].flatten()]).cpu()
+    assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.01 and abs(u.var() - 1 / 12) < 0.005
+    ounion, _ = cpu_union(g)
+    fine = orendering.hierarchical_render(ounion, g["origins"], g["directions"], (0.0, 100.0), S, std, ratio,
+                                          a["u_coarse"].cpu(), a["u_fine"].cpu())
+    assert (a["labels"].cpu() - fine.labels).abs().max() < LABEL_TOL
+
+
+def test_skip_exact_misses_is_exact(dev):
+    from vsrd_amd import rendering
+    g = load_golden("g4_render_n4_s32_late")
+    S = int(g["num_samples"])
+    union, params = hip_union(g, dev, requires_grad=True)
+    std, ratio = float(g["sdf_std_deviation"]), float(g["cosine_ratio"])
+    kw = dict(u_coarse=g["u_coarse"].to(dev), u_fine=g["u_fine"].to(dev))
+    args = (union, g["origins"].to(dev), g["directions"].to(dev), (0.0, 100.0), S, std, ratio)
+    full = rendering.render_hierarchical(*args, **kw)["labels"]
+    fast = rendering.render_hierarchical(*args, skip_exact_misses=True, **kw)["labels"]
+    assert torch.equal(full, fast)
+    assert int((g["coarse_weights"].sum(0) == 0).sum()) > 0
+    lam = torch.randn(full.shape, generator=torch.Generator().manual_seed(3)).to(dev)
+    for a, b in zip(torch.autograd.grad((full * lam).sum(), params), torch.autograd.grad((fast * lam).sum(), params)):
+        assert torch.equal(a, b)
+
+
+def test_single_origin_and_leading_dims(dev):
+    """main.py:1011-1026 renders image rows with a [3] camera position and [W,3] directions."""
+    from vsrd_amd import rendering
+    g = load_golden("g4_render_n4_s32_mid")
+    union, _ = hip_union(g, dev)
+    dist = g["fine_distances"].t().contiguous().to(dev)
+    a = rendering.render_at_distances(union, g["origins"].to(dev), g["directions"].to(dev), dist, 0.5, 0.5)[0]
+    b = rendering.render_at_distances(union, g["origins"][0].to(dev), g["directions"].to(dev), dist, 0.5, 0.5)[0]
+    assert torch.equal(a, b)
+    torch.manual_seed(5)
+    out = rendering.hierarchical_volumetric_rendering(union, g["origins"][0].to(dev), g["directions"].reshape(12, 20, 3).to(dev),
+                                                      [0.0, 100.0], 32, 0.5, 0.5)
+    assert out[0].shape == (12, 20, 4) and out[1].shape == (31, 12, 20, 3) and out[2].shape == (32, 12, 20, 1) and out[3].shape == (31, 12, 20, 1)
+
+
+def test_backward_linearity_and_determinism(dev):
+    from vsrd_amd import rendering
+    g = load_golden("g4_render_n16_s64_mid")
+    union, params = hip_union(g, dev, requires_grad=True)
+    dist = g["fine_distances"].t().contiguous().to(dev)
+    labels, grads, weights = rendering.render_at_distances(union, g["origins"].to(dev), g["directions"].to(dev), dist, 0.55, 0.5)
+    gen = torch.Generator().manual_seed(0)
+    lam = torch.randn(labels.shape, generator=gen).to(dev)
+    gam = (torch.randn(grads.shape, generator=gen) * 0.1).to(dev)
+    om = (torch.randn(weights.shape, generator=gen) * 0.1).to(dev)
+    def vjp(l, g_, o):
+        return torch.autograd.grad([labels, grads, weights], params, [l, g_, o], retain_graph=True)
+    base = vjp(lam, gam, om)
+    again = vjp(lam, gam, om)
+    for a, b in zip(base, again):
+        assert torch.equal(a, b)                                  # deterministic two-stage reduction
+    double = vjp(2 * lam, 2 * gam, 2 * om)
+    for a, b in zip(base, double):
+        torch.testing.assert_close(2 * a, b, rtol=1e-5, atol=1e-6)
+    # against float64 autograd through the oracle
+    loc, dim, rot = (g[k].double().requires_grad_(True) for k in ("locations", "dimensions", "orientations"))
+    ou = ofields.InstanceUnion(loc, rot, dim, float(g["temperature"]))
+    o = orendering.render_given_distances(ou, g["origins"].double(), g["directions"].double(), dist.cpu().double(), 0.55, 0.5)
+    want = torch.autograd.grad([o.labels, o.gradients, o.weights], [loc, dim, rot], [lam.cpu().double(), gam.cpu().double(), om.cpu().double()])
+    for got, ref in zip(base, want):
+        err = (got.cpu().double() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-9)
+        assert err < 2e-3, err
+
+
+def test_argument_validation(dev):
+    from vsrd_amd import rendering, fields, _lib
+    g = load_golden("g4_render_n4_s32_mid")
+    union, _ = hip_union(g, dev)
+    with pytest.raises(_lib.VsrdHipError):
+        rendering.render_at_distances(union, g["origins"], g["directions"].to(dev), g["fine_distances"].t().contiguous().to(dev), 0.5)
+    with pytest.raises(fields.UnsupportedFieldError):
+        rendering.render_at_distances(lambda p: p.norm(dim=-1, keepdim=True), g["origins"].to(dev), g["directions"].to(dev),
+                                      g["fine_distances"].t().contiguous().to(dev), 0.5)
+    with pytest.raises(_lib.VsrdHipError):   # std must be positive
+        rendering.render_at_distances(union, g["origins"].to(dev), g["directions"].to(dev), g["fine_distances"].t().contiguous().to(dev), 0.0)
+    empty = rendering.render_at_distances(union, g["origins"][:0].to(dev), g["directions"][:0].to(dev),
+                                          g["fine_distances"].t()[:0].contiguous().to(dev), 0.5)
+    assert empty[0].shape == (0, 4)

@@ -1,0 +1,130 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every declared symbol, the
+ctypes structs match the header, the field recogniser flattens both our combinator objects and the
+closure tree an unchanged scripts/main.py builds, and nothing in the product imports the oracle."""
+import ctypes
+import functools
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__
+    __graft_entry__.build()
+    from vsrd_amd import _lib
+    return _lib.load()
+
+
+def test_header_symbols_are_exported(lib):
+    header = open(os.path.join(ROOT, "include", "vsrd_hip.h")).read()
+    declared = set(re.findall(r"^(?:int32_t|size_t|const char\*)\s+(vsrd_\w+)\s*\(", header, flags=re.M))
+    assert {"vsrd_render_forward", "vsrd_render_backward", "vsrd_render_hierarchical_forward", "vsrd_field_eval",
+            "vsrd_ray_directions", "vsrd_sample_stratified", "vsrd_sample_importance"} <= declared
+    from vsrd_amd import _lib
+    assert declared == set(_lib.SIGNATURES), "ctypes binding and header disagree"
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.vsrd_abi_version() == 1
+    assert lib.vsrd_workspace_bytes(16) == 2048 * 4 * 16 * 16 * 4
+    assert lib.vsrd_workspace_bytes(0) == 0 and lib.vsrd_workspace_bytes(65) == 0
+    assert lib.vsrd_error_string(-1) == b"invalid argument"
+
+
+def test_struct_layout_matches_header():
+    from vsrd_amd import _lib
+    assert ctypes.sizeof(_lib.Field) == 24                      # int32, float, 2 pointers
+    assert _lib.Field.instances.offset == 8 and _lib.Field.mlp_weights.offset == 16
+    assert ctypes.sizeof(_lib.RenderConfig) == 56
+    assert _lib.RenderConfig.seed.offset == 32 and _lib.RenderConfig.stream_offset.offset == 40 and _lib.RenderConfig.flags.offset == 48
+
+
+def test_cpu_tensors_are_rejected_not_emulated(lib):
+    from vsrd_amd import _lib
+    with pytest.raises(_lib.VsrdHipError):
+        _lib.ptr(torch.zeros(3))
+
+
+def _main_py_style_field(loc, dim, rot, temperature, mlp=None, hyper=None):
+    """Closures written like scripts/main.py:433-509 (nested ``wrapper`` functions), around OUR sdfs objects."""
+    from vsrd_amd import rendering
+
+    def residual_distance_field(distance_field):
+        def wrapper(positions):
+            return torch.sigmoid(distance_field(positions) - 1.0)     # never evaluated: the recogniser reads the closure
+        return wrapper
+
+    def residual_composition(distance_field, residual_distance_field):
+        def wrapper(positions):
+            return distance_field(positions) + residual_distance_field(positions)
+        return wrapper
+
+    def instance_field(distance_field, instance_label):
+        def wrapper(positions):
+            return distance_field(positions), instance_label
+        return wrapper
+
+    def soft_union(distance_fields, temperature):
+        def wrapper(positions):
+            return [f(positions) for f in distance_fields], temperature
+        return wrapper
+
+    members = []
+    for i in range(loc.shape[0]):
+        base = rendering.sdfs.box(dim[i])
+        if mlp is not None:
+            base = residual_composition(distance_field=base, residual_distance_field=residual_distance_field(
+                distance_field=functools.partial(hyper, mlp[i])))
+        members.append(rendering.sdfs.translation(rendering.sdfs.rotation(
+            instance_field(distance_field=base, instance_label=dim.new_tensor(i, dtype=torch.long)), rot[i]), loc[i]))
+    return soft_union(distance_fields=members, temperature=temperature)
+
+
+def test_recogniser_flattens_main_py_closures():
+    from vsrd_amd import fields
+    g = torch.Generator().manual_seed(0)
+    loc = torch.randn(5, 3, generator=g).requires_grad_(True)
+    dim = (torch.rand(5, 3, generator=g) + 0.5).requires_grad_(True)
+    rot = torch.randn(5, 3, 3, generator=g).requires_grad_(True)
+    block = fields.flatten(_main_py_style_field(loc, dim, rot, 0.37))
+    assert block.instances.shape == (5, 16) and block.temperature == pytest.approx(0.37)
+    assert block.mlp_weights is None and block.label_indices is None and not block.hard
+    assert torch.equal(block.instances[:, 0:3], loc) and torch.equal(block.instances[:, 3:12], rot.reshape(5, 9))
+    assert torch.equal(block.instances[:, 12:15], dim) and torch.all(block.instances[:, 15] == 0)
+    # autograd reaches the original tensors through the packing
+    gl, gd, gr = torch.autograd.grad(block.instances.sum(), [loc, dim, rot])
+    assert torch.all(gl == 1) and torch.all(gd == 1) and torch.all(gr == 1)
+    # residual variant: weights travel through functools.partial (main.py:541-544)
+    mlp = torch.randn(5, 1617, generator=g)
+    block = fields.flatten(_main_py_style_field(loc, dim, rot, 1.0, mlp=mlp, hyper=lambda w, x: x))
+    assert torch.equal(block.mlp_weights, mlp)
+
+
+def test_recogniser_objects_labels_and_rejections():
+    from vsrd_amd import fields, rendering
+    loc, dim, rot = torch.zeros(3, 3), torch.ones(3, 3), torch.eye(3).repeat(3, 1, 1)
+    members = [rendering.sdfs.translation(rendering.sdfs.rotation(fields.instance_field(rendering.sdfs.box(dim[i]), lab, 3), rot[i]), loc[i])
+               for i, lab in enumerate([2, 0, 1])]
+    block = fields.flatten(fields.soft_union(members, 0.5))
+    assert block.label_indices.tolist() == [2, 0, 1]
+    assert fields.flatten(fields.hard_union(members)).hard
+    assert fields.flatten(rendering.sdfs.box(dim[0])).instances.shape == (1, 16)       # identity pose filled in
+    with pytest.raises(fields.UnsupportedFieldError):
+        fields.flatten(lambda p: p)
+    with pytest.raises(fields.UnsupportedFieldError):                                   # rotation(translation(.)) is a different map
+        fields.flatten(fields.soft_union([rendering.sdfs.rotation(rendering.sdfs.translation(rendering.sdfs.box(dim[0]), loc[0]), rot[0])], 1.0))
+    with pytest.raises(fields.UnsupportedFieldError):
+        fields.flatten(fields.soft_union([rendering.sdfs.box(dim[0])] * 65, 1.0))
+
+
+def test_product_never_imports_the_oracle():
+    for base, _, files in os.walk(os.path.join(ROOT, "vsrd_amd")):
+        for name in files:
+            if name.endswith((".py", ".h", ".hip")):
+                text = open(os.path.join(base, name)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"{name} imports the oracle"
+                assert "/root/reference" not in text

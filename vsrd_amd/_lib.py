@@ -1,0 +1,133 @@
+"""ctypes binding of libvsrd_hip.so (include/vsrd_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There is no CPU
+fallback: if the shared object is missing, or a tensor is not on a HIP device, every entry
+point raises.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBRARY_PATH = os.path.join(_HERE, "lib", "libvsrd_hip.so")
+
+ABI_VERSION = 1
+MAX_INSTANCES = 64
+MAX_SAMPLES = 256
+INSTANCE_STRIDE = 16
+MLP_WEIGHTS = 1617
+FLAG_FINE_UNIFORMS_SORTED = 1
+FLAG_SKIP_EXACT_MISSES = 2
+
+c_float_p = ctypes.c_void_p  # device pointers travel as integers
+
+
+class Field(ctypes.Structure):
+    _fields_ = [
+        ("num_instances", ctypes.c_int32),
+        ("temperature", ctypes.c_float),
+        ("instances", ctypes.c_void_p),
+        ("mlp_weights", ctypes.c_void_p),
+    ]
+
+
+class RenderConfig(ctypes.Structure):
+    _fields_ = [
+        ("num_rays", ctypes.c_int32),
+        ("num_samples", ctypes.c_int32),
+        ("distance_near", ctypes.c_float),
+        ("distance_far", ctypes.c_float),
+        ("sdf_std_deviation", ctypes.c_float),
+        ("cosine_ratio", ctypes.c_float),
+        ("epsilon", ctypes.c_float),
+        ("origin_stride", ctypes.c_int32),
+        ("seed", ctypes.c_uint64),
+        ("stream_offset", ctypes.c_uint64),
+        ("flags", ctypes.c_uint32),
+    ]
+
+
+# symbol -> (restype, argtypes); mirrors include/vsrd_hip.h one to one
+SIGNATURES = {
+    "vsrd_abi_version": (ctypes.c_int32, []),
+    "vsrd_error_string": (ctypes.c_char_p, [ctypes.c_int32]),
+    "vsrd_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32]),
+    "vsrd_ray_directions": (ctypes.c_int32, [c_float_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_float_p, ctypes.c_void_p]),
+    "vsrd_field_eval": (ctypes.c_int32, [ctypes.POINTER(Field), c_float_p, ctypes.c_int64, c_float_p, c_float_p, c_float_p,
+                                         ctypes.c_int32, ctypes.c_void_p]),
+    "vsrd_sample_stratified": (ctypes.c_int32, [ctypes.POINTER(RenderConfig), c_float_p, c_float_p, ctypes.c_void_p]),
+    "vsrd_sample_importance": (ctypes.c_int32, [ctypes.POINTER(RenderConfig), c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
+    "vsrd_render_forward": (ctypes.c_int32, [ctypes.POINTER(Field), ctypes.POINTER(RenderConfig), c_float_p, c_float_p, c_float_p,
+                                             ctypes.c_int32, c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
+    "vsrd_render_backward": (ctypes.c_int32, [ctypes.POINTER(Field), ctypes.POINTER(RenderConfig), c_float_p, c_float_p, c_float_p,
+                                              ctypes.c_int32, c_float_p, c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_size_t,
+                                              c_float_p, ctypes.c_void_p]),
+    "vsrd_render_hierarchical_forward": (ctypes.c_int32, [ctypes.POINTER(Field), ctypes.POINTER(RenderConfig), c_float_p, c_float_p,
+                                                          c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
+                                                          c_float_p, c_float_p, ctypes.c_void_p]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class VsrdHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises if the HIP library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIBRARY_PATH):
+                raise VsrdHipError(
+                    f"{LIBRARY_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(hipcc --offload-arch=gfx950).  vsrd_amd has no CPU fallback.")
+            lib = ctypes.CDLL(LIBRARY_PATH)
+            for name, (restype, argtypes) in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = restype
+                fn.argtypes = argtypes
+            if lib.vsrd_abi_version() != ABI_VERSION:
+                raise VsrdHipError(f"ABI mismatch: library {lib.vsrd_abi_version()} vs binding {ABI_VERSION}")
+            _lib = lib
+    return _lib
+
+
+def check(code):
+    if code != 0:
+        raise VsrdHipError(f"libvsrd_hip: {load().vsrd_error_string(code).decode()} (code {code})")
+
+
+def ptr(tensor):
+    """Device pointer of a contiguous fp32 HIP tensor (None -> NULL)."""
+    if tensor is None:
+        return None
+    if not tensor.is_cuda:
+        raise VsrdHipError("vsrd_amd operates on HIP device tensors only (got a CPU tensor); there is no CPU fallback")
+    if tensor.dtype != torch.float32:
+        raise VsrdHipError(f"expected float32, got {tensor.dtype}")
+    if not tensor.is_contiguous():
+        raise VsrdHipError("internal error: non-contiguous tensor handed to the C ABI")
+    return ctypes.c_void_p(tensor.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_field(instances, temperature, mlp_weights=None):
+    return Field(int(instances.shape[0]), float(temperature), ptr(instances).value,
+                 None if mlp_weights is None else ptr(mlp_weights).value)
+
+
+def make_config(num_rays, num_samples, distance_range, sdf_std_deviation, cosine_ratio, epsilon, origin_stride,
+                seed=0, stream_offset=0, flags=0):
+    return RenderConfig(int(num_rays), int(num_samples), float(distance_range[0]), float(distance_range[1]),
+                        float(sdf_std_deviation), float(cosine_ratio), float(epsilon), int(origin_stride),
+                        int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_offset) & 0xFFFFFFFFFFFFFFFF, int(flags))

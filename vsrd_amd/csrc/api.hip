@@ -1,0 +1,279 @@
+// C ABI of libvsrd_hip (include/vsrd_hip.h): argument validation, launch geometry, dispatch on the
+// number of 64-sample rounds.  No torch types, no global state, no allocation.
+#include "../../include/vsrd_hip.h"
+#include "aux_kernels.h"
+
+namespace {
+
+using namespace vsrd;
+
+constexpr int kMaxBlocks = 2048;             // 256 CUs x 8 workgroups: persistent-ish grid
+constexpr size_t kLdsLimit = 160 * 1024;     // gfx950 LDS per CU
+constexpr size_t kLdsDefault = 64 * 1024;    // dynamic LDS without opting in
+
+struct Geometry {
+    int blocks;
+    int threads;
+    size_t lds_bytes;
+};
+
+// Pick the number of waves per workgroup so the wave-private LDS partitions fit.
+bool plan(int num_rays, size_t floats_per_wave, Geometry* g) {
+    const size_t per_wave = floats_per_wave * sizeof(float);
+    if (per_wave > kLdsLimit) return false;
+    int waves = kMaxWavesPerBlock;
+    while (waves > 1 && per_wave * waves > kLdsDefault) waves >>= 1;
+    g->threads = waves * kWave;
+    g->lds_bytes = per_wave * waves;
+    const long long want = (static_cast<long long>(num_rays) + waves - 1) / waves;
+    g->blocks = static_cast<int>(want < 1 ? 1 : (want > kMaxBlocks ? kMaxBlocks : want));
+    return true;
+}
+
+template <typename Kernel>
+int opt_in_lds(Kernel kernel, size_t bytes) {
+    if (bytes <= kLdsDefault) return VSRD_OK;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(bytes)) == hipSuccess ? VSRD_OK : VSRD_E_LAUNCH;
+}
+
+int launch_status() { return hipGetLastError() == hipSuccess ? VSRD_OK : VSRD_E_LAUNCH; }
+
+bool valid_field(const vsrd_field* f) {
+    return f != nullptr && f->instances != nullptr && f->num_instances >= 1 && f->num_instances <= VSRD_MAX_INSTANCES &&
+           f->temperature > 0.0f;
+}
+
+bool valid_config(const vsrd_render_config* c) {
+    return c != nullptr && c->num_rays >= 0 && c->num_samples >= 2 && c->num_samples <= VSRD_MAX_SAMPLES &&
+           c->sdf_std_deviation > 0.0f && (c->origin_stride == 0 || c->origin_stride == 3);
+}
+
+FieldArgs field_args(const vsrd_field* f) {
+    FieldArgs a;
+    a.instances = f->instances;
+    a.mlp_weights = f->mlp_weights;
+    a.num_instances = f->num_instances;
+    a.inv_t = 1.0f / f->temperature;
+    return a;
+}
+
+RenderArgs render_args(const vsrd_render_config* c) {
+    RenderArgs a;
+    a.num_rays = c->num_rays;
+    a.num_samples = c->num_samples;
+    a.near = c->distance_near;
+    a.far = c->distance_far;
+    a.sh.inv_t = 0.0f;  // filled from the field
+    a.sh.std = c->sdf_std_deviation;
+    a.sh.ratio = c->cosine_ratio;
+    a.sh.eps = c->epsilon;
+    a.origin_stride = c->origin_stride;
+    a.seed = c->seed;
+    a.stream_offset = c->stream_offset;
+    a.flags = c->flags;
+    return a;
+}
+
+// rounds of 64 lanes needed for `points` sample points, rounded up to the instantiated {1,2,4,8}
+int rounds_for(int points) {
+    const int need = (points + kWave - 1) / kWave;
+    if (need <= 1) return 1;
+    if (need <= 2) return 2;
+    if (need <= 4) return 4;
+    if (need <= 8) return 8;
+    return 0;
+}
+
+size_t partial_floats(int num_instances) {
+    return static_cast<size_t>(kMaxBlocks) * kMaxWavesPerBlock * num_instances * kGradStride;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t vsrd_abi_version(void) { return VSRD_ABI_VERSION; }
+
+const char* vsrd_error_string(int32_t code) {
+    switch (code) {
+        case VSRD_OK: return "ok";
+        case VSRD_E_INVALID_ARGUMENT: return "invalid argument";
+        case VSRD_E_UNSUPPORTED: return "unsupported configuration";
+        case VSRD_E_LAUNCH: return "HIP launch failed";
+        case VSRD_E_WORKSPACE: return "workspace too small";
+        default: return "unknown error";
+    }
+}
+
+size_t vsrd_workspace_bytes(int32_t num_instances) {
+    if (num_instances < 1 || num_instances > VSRD_MAX_INSTANCES) return 0;
+    return partial_floats(num_instances) * sizeof(float);
+}
+
+int32_t vsrd_ray_directions(const float* inverse_projection, int32_t num_views, int32_t height, int32_t width,
+                            float* directions, void* stream) {
+    if (!inverse_projection || !directions || num_views < 1 || height < 1 || width < 1) return VSRD_E_INVALID_ARGUMENT;
+    const size_t total = static_cast<size_t>(num_views) * height * width;
+    const int blocks = static_cast<int>(std::min<size_t>((total + 255) / 256, 8192));
+    hipLaunchKernelGGL(ray_directions_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       inverse_projection, num_views, height, width, directions);
+    return launch_status();
+}
+
+int32_t vsrd_field_eval(const vsrd_field* field, const float* positions, int64_t num_points,
+                        float* distances, float* gradients, float* labels, int32_t hard_union, void* stream) {
+    if (!valid_field(field) || (!positions && num_points > 0) || num_points < 0) return VSRD_E_INVALID_ARGUMENT;
+    if (field->mlp_weights != nullptr) return VSRD_E_UNSUPPORTED;
+    if (hard_union && labels) return VSRD_E_INVALID_ARGUMENT;
+    if (num_points == 0) return VSRD_OK;
+    const int blocks = static_cast<int>(std::min<int64_t>((num_points + 255) / 256, 8192));
+    hipLaunchKernelGGL(field_eval_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       field_args(field), positions, static_cast<long long>(num_points), distances, gradients, labels, hard_union);
+    return launch_status();
+}
+
+int32_t vsrd_sample_stratified(const vsrd_render_config* config, const float* u_coarse, float* distances, void* stream) {
+    if (!valid_config(config) || !u_coarse || !distances) return VSRD_E_INVALID_ARGUMENT;
+    if (config->num_rays == 0) return VSRD_OK;
+    const size_t total = static_cast<size_t>(config->num_rays) * config->num_samples;
+    const int blocks = static_cast<int>(std::min<size_t>((total + 255) / 256, 8192));
+    hipLaunchKernelGGL(sample_stratified_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       render_args(config), u_coarse, distances);
+    return launch_status();
+}
+
+int32_t vsrd_sample_importance(const vsrd_render_config* config, const float* coarse_distances,
+                               const float* coarse_weights, const float* u_fine, float* merged, void* stream) {
+    if (!valid_config(config) || !coarse_distances || !coarse_weights || !u_fine || !merged) return VSRD_E_INVALID_ARGUMENT;
+    if (config->num_rays == 0) return VSRD_OK;
+    Geometry g;
+    if (!plan(config->num_rays, wave_lds_floats(config->num_samples, 0), &g)) return VSRD_E_UNSUPPORTED;
+    const RenderArgs c = render_args(config);
+    const hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rounds = rounds_for(config->num_samples);
+#define VSRD_LAUNCH(K)                                                                                                  \
+    hipLaunchKernelGGL(sample_importance_kernel<K>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, c, coarse_distances, \
+                       coarse_weights, u_fine, merged)
+    switch (rounds) {
+        case 1: VSRD_LAUNCH(1); break;
+        case 2: VSRD_LAUNCH(2); break;
+        case 4: VSRD_LAUNCH(4); break;
+        default: return VSRD_E_UNSUPPORTED;
+    }
+#undef VSRD_LAUNCH
+    return launch_status();
+}
+
+int32_t vsrd_render_forward(const vsrd_field* field, const vsrd_render_config* config,
+                            const float* origins, const float* directions,
+                            const float* distances, int32_t num_distances,
+                            float* labels, float* gradients, float* weights, void* stream) {
+    if (!valid_field(field) || !valid_config(config) || !origins || !directions || !distances || !labels ||
+        num_distances < 2 || num_distances > 2 * VSRD_MAX_SAMPLES)
+        return VSRD_E_INVALID_ARGUMENT;
+    if (field->mlp_weights != nullptr) return VSRD_E_UNSUPPORTED;
+    if (config->num_rays == 0) return VSRD_OK;
+    Geometry g;
+    if (!plan(config->num_rays, static_cast<size_t>(num_distances) + field->num_instances * kWave, &g)) return VSRD_E_UNSUPPORTED;
+    const FieldArgs f = field_args(field);
+    RenderArgs c = render_args(config);
+    c.sh.inv_t = f.inv_t;
+    const hipStream_t s = static_cast<hipStream_t>(stream);
+#define VSRD_LAUNCH(K)                                                                                                       \
+    do {                                                                                                                       \
+        if (opt_in_lds(render_forward_kernel<K>, g.lds_bytes) != VSRD_OK) return VSRD_E_LAUNCH;                              \
+        hipLaunchKernelGGL(render_forward_kernel<K>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, c, origins,           \
+                           directions, distances, num_distances, labels, gradients, weights);                                \
+    } while (0)
+    switch (rounds_for(num_distances - 1)) {
+        case 1: VSRD_LAUNCH(1); break;
+        case 2: VSRD_LAUNCH(2); break;
+        case 4: VSRD_LAUNCH(4); break;
+        case 8: VSRD_LAUNCH(8); break;
+        default: return VSRD_E_UNSUPPORTED;
+    }
+#undef VSRD_LAUNCH
+    return launch_status();
+}
+
+int32_t vsrd_render_backward(const vsrd_field* field, const vsrd_render_config* config,
+                             const float* origins, const float* directions,
+                             const float* distances, int32_t num_distances,
+                             const float* grad_labels, const float* grad_gradients, const float* grad_weights,
+                             void* workspace, size_t workspace_bytes,
+                             float* grad_instances, void* stream) {
+    if (!valid_field(field) || !valid_config(config) || !origins || !directions || !distances || !grad_labels ||
+        !grad_instances || !workspace || num_distances < 2 || num_distances > 2 * VSRD_MAX_SAMPLES)
+        return VSRD_E_INVALID_ARGUMENT;
+    if (field->mlp_weights != nullptr) return VSRD_E_UNSUPPORTED;
+    const int N = field->num_instances;
+    if (workspace_bytes < vsrd_workspace_bytes(N)) return VSRD_E_WORKSPACE;
+    const hipStream_t s = static_cast<hipStream_t>(stream);
+    const int row = N * kGradStride;
+    if (config->num_rays == 0) {
+        return hipMemsetAsync(grad_instances, 0, row * sizeof(float), s) == hipSuccess ? VSRD_OK : VSRD_E_LAUNCH;
+    }
+    Geometry g;
+    if (!plan(config->num_rays, static_cast<size_t>(num_distances) + N + row, &g)) return VSRD_E_UNSUPPORTED;
+    const FieldArgs f = field_args(field);
+    RenderArgs c = render_args(config);
+    c.sh.inv_t = f.inv_t;
+    float* partials = static_cast<float*>(workspace);
+#define VSRD_LAUNCH(K)                                                                                                       \
+    hipLaunchKernelGGL(render_backward_kernel<K>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, c, origins, directions, \
+                       distances, num_distances, grad_labels, grad_gradients, grad_weights, partials)
+    switch (rounds_for(num_distances - 1)) {
+        case 1: VSRD_LAUNCH(1); break;
+        case 2: VSRD_LAUNCH(2); break;
+        case 4: VSRD_LAUNCH(4); break;
+        default: return VSRD_E_UNSUPPORTED;
+    }
+#undef VSRD_LAUNCH
+    if (launch_status() != VSRD_OK) return VSRD_E_LAUNCH;
+    const int num_waves = g.blocks * (g.threads / kWave);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(row), dim3(256), 0, s, partials, num_waves, row, grad_instances);
+    return launch_status();
+}
+
+int32_t vsrd_render_hierarchical_forward(const vsrd_field* field, const vsrd_render_config* config,
+                                         const float* origins, const float* directions,
+                                         const float* u_coarse, const float* u_fine,
+                                         float* labels, float* distances, float* gradients, float* weights,
+                                         float* u_coarse_out, float* u_fine_out, void* stream) {
+    if (!valid_field(field) || !valid_config(config) || !origins || !directions || !labels) return VSRD_E_INVALID_ARGUMENT;
+    if (field->mlp_weights != nullptr) return VSRD_E_UNSUPPORTED;
+    if ((config->flags & VSRD_FLAG_SKIP_EXACT_MISSES) && (gradients || weights)) return VSRD_E_INVALID_ARGUMENT;
+    if (config->num_rays == 0) return VSRD_OK;
+    const int S = config->num_samples;
+    Geometry g;
+    if (!plan(config->num_rays, wave_lds_floats(S, field->num_instances), &g)) return VSRD_E_UNSUPPORTED;
+    const FieldArgs f = field_args(field);
+    RenderArgs c = render_args(config);
+    c.sh.inv_t = f.inv_t;
+    const hipStream_t s = static_cast<hipStream_t>(stream);
+#define VSRD_LAUNCH(K)                                                                                                       \
+    do {                                                                                                                       \
+        if (opt_in_lds(render_hierarchical_kernel<K>, g.lds_bytes) != VSRD_OK) return VSRD_E_LAUNCH;                         \
+        hipLaunchKernelGGL(render_hierarchical_kernel<K>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, c, origins,      \
+                           directions, u_coarse, u_fine, labels, distances, gradients, weights, u_coarse_out, u_fine_out);   \
+    } while (0)
+    switch (rounds_for(2 * S - 1)) {
+        case 1: VSRD_LAUNCH(1); break;
+        case 2: VSRD_LAUNCH(2); break;
+        case 4: VSRD_LAUNCH(4); break;
+        case 8: VSRD_LAUNCH(8); break;
+        default: return VSRD_E_UNSUPPORTED;
+    }
+#undef VSRD_LAUNCH
+    return launch_status();
+}
+
+// Not part of the public header: exercised by tests/test_hip_wave.py.
+int32_t vsrd_selftest_wave(const float* in64, float* out512, void* stream) {
+    if (!in64 || !out512) return VSRD_E_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(wave_selftest_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), in64, out512);
+    return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,131 @@
+// Kernels around the render path: per-pixel ray directions, field evaluation at arbitrary points,
+// and the two samplers as stand-alone launches (the API-faithful two-call path).
+#pragma once
+#include "render_kernels.h"
+
+namespace vsrd {
+
+// vsrd/rendering/utils.py:5-18: dir = normalize(M @ (x, y, 1)), M = inv(E)[:3,:3] @ inv(K).
+// One thread per pixel; a wave writes 768 contiguous bytes.
+__global__ __launch_bounds__(256) void ray_directions_kernel(const float* __restrict__ inverse_projection, int num_views,
+                                                             int height, int width, float* __restrict__ directions) {
+    const size_t pixels = static_cast<size_t>(height) * width;
+    const size_t total = pixels * num_views;
+    for (size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+         idx += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const int view = static_cast<int>(idx / pixels);
+        const size_t pixel = idx - static_cast<size_t>(view) * pixels;
+        const float py = static_cast<float>(pixel / width);
+        const float px = static_cast<float>(pixel % width);
+        const float* m = inverse_projection + view * 9;
+        const float dx = m[0] * px + m[1] * py + m[2];
+        const float dy = m[3] * px + m[4] * py + m[5];
+        const float dz = m[6] * px + m[7] * py + m[8];
+        const float inv = 1.0f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1.0e-12f);
+        directions[idx * 3 + 0] = dx * inv;
+        directions[idx * 3 + 1] = dy * inv;
+        directions[idx * 3 + 2] = dz * inv;
+    }
+}
+
+// The distance_field closure evaluated at arbitrary points (main.py:477-509) plus its analytic normal.
+// One thread per point; the instance loop is still wave-uniform (scalar parameter loads).
+__global__ __launch_bounds__(256) void field_eval_kernel(FieldArgs f, const float* __restrict__ positions, long long num_points,
+                                                         float* __restrict__ distances, float* __restrict__ gradients,
+                                                         float* __restrict__ labels, int hard_union) {
+    for (long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; idx < num_points;
+         idx += static_cast<long long>(gridDim.x) * blockDim.x) {
+        const float x = positions[idx * 3 + 0], y = positions[idx * 3 + 1], z = positions[idx * 3 + 2];
+        if (hard_union) {
+            float best = 3.0e38f, bx = 0.0f, by = 0.0f, bz = 0.0f;
+            for (int i = 0; i < f.num_instances; ++i) {
+                const BoxEval e = eval_box(load_instance(f.instances, i), x, y, z);
+                if (e.d < best) { best = e.d; bx = e.gwx; by = e.gwy; bz = e.gwz; }   // argmin: first minimum
+            }
+            if (distances) distances[idx] = best;
+            if (gradients) { gradients[idx * 3 + 0] = bx; gradients[idx * 3 + 1] = by; gradients[idx * 3 + 2] = bz; }
+            continue;
+        }
+        UnionSums sums = union_init();
+        for (int i = 0; i < f.num_instances; ++i) {
+            const BoxEval e = eval_box(load_instance(f.instances, i), x, y, z);
+            union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, 0.0f, f.inv_t);
+        }
+        const UnionValue v = union_finish(sums, f.inv_t);
+        if (distances) distances[idx] = v.u;
+        if (gradients) { gradients[idx * 3 + 0] = v.gx; gradients[idx * 3 + 1] = v.gy; gradients[idx * 3 + 2] = v.gz; }
+        if (labels) {
+            for (int i = 0; i < f.num_instances; ++i) {
+                const BoxEval e = eval_box(load_instance(f.instances, i), x, y, z);
+                labels[idx * f.num_instances + i] = expf(-(e.d - v.m) * f.inv_t) * v.inv_z;
+            }
+        }
+    }
+}
+
+// renderers.py:191-194 + samplers.py:5-8, one thread per (ray, bin).
+__global__ __launch_bounds__(256) void sample_stratified_kernel(RenderArgs c, const float* __restrict__ u_coarse, float* __restrict__ distances) {
+    const size_t total = static_cast<size_t>(c.num_rays) * c.num_samples;
+    for (size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+         idx += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const int k = static_cast<int>(idx % c.num_samples);
+        const float lo = torch_linspace(c.near, c.far, c.num_samples + 1, k);
+        const float hi = torch_linspace(c.near, c.far, c.num_samples + 1, k + 1);
+        distances[idx] = torch_lerp(lo, hi, u_coarse[idx]);
+    }
+}
+
+// samplers.py:11-36 + renderers.py:198-210 as its own launch (wave per ray).
+template <int kRoundsS>
+__global__ __launch_bounds__(kBlockThreads) void sample_importance_kernel(
+    RenderArgs c, const float* __restrict__ coarse_distances, const float* __restrict__ coarse_weights,
+    const float* __restrict__ u_fine, float* __restrict__ merged) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = wave_in_block();
+    const int lane = lane_id();
+    const int S = c.num_samples;
+    const WaveLds l = carve_lds(lds + wave * wave_lds_floats(S, 0), S);
+    const bool sorted_input = (c.flags & 1u) != 0;
+    const int stride = static_cast<int>(gridDim.x) * waves_per_block();
+    for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
+        const size_t row = static_cast<size_t>(ray) * S;
+        float w1[kRoundsS];
+#pragma unroll
+        for (int k = 0; k < kRoundsS; ++k) {
+            const int idx = k * kWave + lane;
+            w1[k] = 0.0f;
+            if (idx < S) {
+                l.coarse[idx] = coarse_distances[row + idx];
+                (sorted_input ? l.usorted : l.uraw)[idx] = u_fine[row + idx];
+                if (idx < S - 1) w1[k] = coarse_weights[static_cast<size_t>(ray) * (S - 1) + idx];
+            }
+        }
+        wave_lds_sync();
+        if (!sorted_input) {
+            rank_sort<kRoundsS>(l.uraw, l.usorted, S);
+            wave_lds_sync();
+        }
+        importance_merge<kRoundsS>(l, S, w1);
+        float* dst = merged + static_cast<size_t>(ray) * 2 * S;
+        for (int idx = lane; idx < 2 * S; idx += kWave) dst[idx] = l.merged[idx];
+        wave_lds_sync();
+    }
+}
+
+// Self-test of the wave primitives (tests/test_hip_wave.py): out[0..63] sum, [64..127] inclusive sum,
+// [128..191] inclusive product, [192..255] max, [256..319] reverse, [320..383] shift-up.
+__global__ void wave_selftest_kernel(const float* __restrict__ in, float* __restrict__ out) {
+    const int lane = lane_id();
+    const float v = in[lane];
+    out[lane] = wave_sum(v);
+    out[64 + lane] = wave_inclusive_sum(v);
+    out[128 + lane] = wave_inclusive_product(1.0f + 0.01f * v);
+    out[192 + lane] = wave_max(v);
+    out[256 + lane] = wave_reverse(v, lane);
+    out[320 + lane] = wave_shift_up(v, -7.0f, lane);
+    const Philox4 r = philox4x32_10(static_cast<uint32_t>(lane), 1u, 2u, 3u, 0xdeadbeefu, 0x12345678u);
+    out[384 + lane] = uniform_from_bits(r.x);
+    out[448 + lane] = torch_linspace(0.0f, 100.0f, 65, lane);
+}
+
+}  // namespace vsrd

@@ -1,0 +1,138 @@
+// Per-instance oriented-box SDF, its analytic gradient, and the online temperature soft-min union.
+//
+// Reference semantics (see oracle/fields.py for the CPU restatement):
+//   box / rotation / translation           vsrd/rendering/sdfs.py:5-37
+//   instance_field + soft_union            scripts/main.py:460-492
+//   grad = autograd.grad(sdf, positions)   vsrd/rendering/renderers.py:218-228  (analytic here)
+//
+// Mapping: the instance loop is WAVE-UNIFORM (every lane evaluates instance i at its own sample),
+// so the 16 packed floats of instance i are fetched with scalar loads and used as SGPR operands.
+#pragma once
+#include "wave.h"
+
+namespace vsrd {
+
+constexpr int kInstanceStride = 16;  // VSRD_INSTANCE_STRIDE
+constexpr float kNormEpsilon = 1.0e-6f;  // sdfs.py:5
+
+struct Instance {
+    float tx, ty, tz;
+    float r00, r01, r02, r10, r11, r12, r20, r21, r22;
+    float dx, dy, dz;
+};
+
+__device__ __forceinline__ Instance load_instance(const float* __restrict__ instances, int i) {
+    const float* p = instances + i * kInstanceStride;  // uniform address -> s_load_dwordx16
+    Instance v;
+    v.tx = p[0]; v.ty = p[1]; v.tz = p[2];
+    v.r00 = p[3]; v.r01 = p[4]; v.r02 = p[5];
+    v.r10 = p[6]; v.r11 = p[7]; v.r12 = p[8];
+    v.r20 = p[9]; v.r21 = p[10]; v.r22 = p[11];
+    v.dx = p[12]; v.dy = p[13]; v.dz = p[14];
+    return v;
+}
+
+// Everything phase B of the backward needs about one (sample, instance) pair.
+struct BoxEval {
+    float relx, rely, relz;   // x - t
+    float px, py, pz;         // local position  p = (x - t) @ R
+    float qx, qy, qz;         // |p| - half extents
+    float hx, hy, hz;         // d d / d q
+    float nrm;                // sqrt(sum relu(q)^2 + 1e-6)
+    float d;                  // signed distance
+    float glx, gly, glz;      // local gradient  sign(p) * h
+    float gwx, gwy, gwz;      // world gradient  R @ gl
+};
+
+__device__ __forceinline__ float sign_of(float v) { return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); }
+
+__device__ __forceinline__ BoxEval eval_box(const Instance& in, float x, float y, float z) {
+    BoxEval e;
+    e.relx = x - in.tx; e.rely = y - in.ty; e.relz = z - in.tz;
+    // row vector times R (sdfs.py:34): p_j = sum_k rel_k R_kj
+    e.px = e.relx * in.r00 + e.rely * in.r10 + e.relz * in.r20;
+    e.py = e.relx * in.r01 + e.rely * in.r11 + e.relz * in.r21;
+    e.pz = e.relx * in.r02 + e.rely * in.r12 + e.relz * in.r22;
+    e.qx = fabsf(e.px) - in.dx; e.qy = fabsf(e.py) - in.dy; e.qz = fabsf(e.pz) - in.dz;
+    const float ax = fmaxf(e.qx, 0.0f), ay = fmaxf(e.qy, 0.0f), az = fmaxf(e.qz, 0.0f);
+    e.nrm = sqrtf(ax * ax + ay * ay + az * az + kNormEpsilon);
+    // torch.max returns the first maximal index; its backward routes to that index.
+    float qmax = e.qx; int arg = 0;
+    if (e.qy > qmax) { qmax = e.qy; arg = 1; }
+    if (e.qz > qmax) { qmax = e.qz; arg = 2; }
+    e.d = e.nrm - fmaxf(-qmax, 0.0f);
+    const float inv = 1.0f / e.nrm;
+    const float inside = (qmax < 0.0f) ? 1.0f : 0.0f;
+    e.hx = ax * inv + ((arg == 0) ? inside : 0.0f);
+    e.hy = ay * inv + ((arg == 1) ? inside : 0.0f);
+    e.hz = az * inv + ((arg == 2) ? inside : 0.0f);
+    e.glx = sign_of(e.px) * e.hx; e.gly = sign_of(e.py) * e.hy; e.glz = sign_of(e.pz) * e.hz;
+    // gw_k = sum_j R_kj gl_j
+    e.gwx = in.r00 * e.glx + in.r01 * e.gly + in.r02 * e.glz;
+    e.gwy = in.r10 * e.glx + in.r11 * e.gly + in.r12 * e.glz;
+    e.gwz = in.r20 * e.glx + in.r21 * e.gly + in.r22 * e.glz;
+    return e;
+}
+
+// Online soft-min over the instances, with the running minimum as the shift so that neither the
+// exponentials nor the (d_i - u)/T factor of the union gradient lose digits at small temperature.
+//   e_i = exp(-(d_i - m)/T), Z = sum e_i, S1 = sum e_i (d_i - m),
+//   G0 = sum e_i gw_i, G1 = sum e_i (d_i - m) gw_i, L = sum e_i lambda_i (backward only)
+struct UnionSums {
+    float m, Z, S1;
+    float g0x, g0y, g0z, g1x, g1y, g1z;
+    float L;
+};
+
+__device__ __forceinline__ UnionSums union_init() {
+    UnionSums s;
+    s.m = 3.0e38f;  // finite: the first instance rescales the (all-zero) sums by exp(-3e38/T) = 0, no inf*0
+    s.Z = 0.0f; s.S1 = 0.0f;
+    s.g0x = s.g0y = s.g0z = 0.0f; s.g1x = s.g1y = s.g1z = 0.0f; s.L = 0.0f;
+    return s;
+}
+
+__device__ __forceinline__ void union_accumulate(UnionSums& s, float d, float gwx, float gwy, float gwz, float lambda, float inv_t) {
+    // One exponential per instance: either the old sums are rescaled (new minimum) or the new term is.
+    const bool lower = d < s.m;
+    const float gap = lower ? (s.m - d) : (d - s.m);           // >= 0
+    const float ex = expf(-gap * inv_t);
+    const float scale = lower ? ex : 1.0f;                      // multiplies the old sums
+    const float e = lower ? 1.0f : ex;                          // weight of the new term
+    const float shift = lower ? gap : 0.0f;                     // old (d_j - m) grow by the drop of m
+    const float dd = lower ? 0.0f : gap;                        // new term's (d_i - m)
+    s.g1x = scale * (s.g1x + shift * s.g0x) + e * dd * gwx;
+    s.g1y = scale * (s.g1y + shift * s.g0y) + e * dd * gwy;
+    s.g1z = scale * (s.g1z + shift * s.g0z) + e * dd * gwz;
+    s.S1 = scale * (s.S1 + shift * s.Z) + e * dd;
+    s.g0x = scale * s.g0x + e * gwx;
+    s.g0y = scale * s.g0y + e * gwy;
+    s.g0z = scale * s.g0z + e * gwz;
+    s.L = scale * s.L + e * lambda;
+    s.Z = scale * s.Z + e;
+    s.m = lower ? d : s.m;
+}
+
+struct UnionValue {
+    float u;            // union distance  sum_i w_i d_i
+    float gx, gy, gz;   // its gradient    sum_i w_i (1 - (d_i - u)/T) grad d_i
+    float m, inv_z;     // soft-min shift and 1/Z:  w_i = exp(-(d_i - m)/T) * inv_z
+    float us;           // u - m  (>= 0)
+    float b0x, b0y, b0z;  // sum_i w_i grad d_i
+};
+
+__device__ __forceinline__ UnionValue union_finish(const UnionSums& s, float inv_t) {
+    UnionValue v;
+    v.m = s.m;
+    v.inv_z = 1.0f / s.Z;
+    v.us = s.S1 * v.inv_z;
+    v.u = s.m + v.us;
+    v.b0x = s.g0x * v.inv_z; v.b0y = s.g0y * v.inv_z; v.b0z = s.g0z * v.inv_z;
+    const float k = 1.0f + v.us * inv_t;
+    v.gx = k * v.b0x - inv_t * (s.g1x * v.inv_z);
+    v.gy = k * v.b0y - inv_t * (s.g1y * v.inv_z);
+    v.gz = k * v.b0z - inv_t * (s.g1z * v.inv_z);
+    return v;
+}
+
+}  // namespace vsrd

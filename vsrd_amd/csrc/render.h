@@ -1,0 +1,252 @@
+// Wave-per-ray rendering core: one wavefront = one ray, one lane = one sample point.
+//
+// Reference semantics (CPU restatement: oracle/rendering.py):
+//   stratified + inverse-transform sampling   vsrd/rendering/samplers.py:5-36
+//   hierarchical_volumetric_rendering         vsrd/rendering/renderers.py:177-270
+//   two-pass wrapper (pass 1 without grad)    scripts/main.py:511-523
+//
+// Per-ray state lives in registers (one or a few samples per lane) and in a small wave-private
+// LDS partition (sorted distances, cdf, per-instance distance cache); nothing per-sample ever
+// goes to HBM unless the caller asks for the API-faithful outputs.
+#pragma once
+#include "field.h"
+
+namespace vsrd {
+
+struct Ray { float ox, oy, oz, rx, ry, rz; };
+
+struct Shading {
+    float inv_t;    // 1 / soft-union temperature
+    float std;      // sdf_std_deviation
+    float ratio;    // cosine_ratio
+    float eps;      // epsilon (opacity denominator)
+};
+
+// torch.lerp(a, b, w): two-sided formula of ATen's lerp kernel.
+__device__ __forceinline__ float torch_lerp(float a, float b, float w) {
+    const float diff = b - a;
+    return (fabsf(w) < 0.5f) ? (a + w * diff) : (b - diff * (1.0f - w));
+}
+
+// torch.linspace(start, end, steps)[i] (ATen: symmetric evaluation from both ends).
+__device__ __forceinline__ float torch_linspace(float start, float end, int steps, int i) {
+    const float step = (end - start) / static_cast<float>(steps - 1);
+    return (i < steps / 2) ? (start + step * static_cast<float>(i)) : (end - step * static_cast<float>(steps - i - 1));
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// NeuS section-point opacity, renderers.py:228-248, with every intermediate the adjoint needs.
+struct Opacity {
+    float inv_gn;           // 1 / max(|g|, 1e-12)
+    float nx, ny, nz;       // normal
+    float cosine;           // r . n
+    float cprime;           // annealed, negated cosine
+    float phi_p, phi_n;     // logistic cdf at the previous / next section point
+    float xx;               // (phi_p - phi_n) / (phi_p + eps)
+    float alpha;            // relu(xx)
+};
+
+__device__ __forceinline__ Opacity opacity_of(const UnionValue& v, const Ray& ray, float delta, const Shading& sh) {
+    Opacity o;
+    const float gn = sqrtf(v.gx * v.gx + v.gy * v.gy + v.gz * v.gz);
+    o.inv_gn = 1.0f / fmaxf(gn, 1.0e-12f);                       // F.normalize eps
+    o.nx = v.gx * o.inv_gn; o.ny = v.gy * o.inv_gn; o.nz = v.gz * o.inv_gn;
+    o.cosine = ray.rx * o.nx + ray.ry * o.ny + ray.rz * o.nz;
+    const float a = fmaxf(-o.cosine * 0.5f + 0.5f, 0.0f);
+    const float b = fmaxf(-o.cosine, 0.0f);
+    o.cprime = -torch_lerp(a, b, sh.ratio);
+    const float half = o.cprime * delta / 2.0f;
+    o.phi_p = sigmoidf((v.u - half) / sh.std);
+    o.phi_n = sigmoidf((v.u + half) / sh.std);
+    o.xx = (o.phi_p - o.phi_n) / (o.phi_p + sh.eps);
+    o.alpha = fmaxf(o.xx, 0.0f);
+    return o;
+}
+
+// Evaluate the union at one point: a uniform loop over the instances with scalar parameter loads.
+template <bool kCacheDistances>
+__device__ __forceinline__ UnionValue eval_union(const float* __restrict__ instances, int num_instances, float inv_t,
+                                                 float x, float y, float z, float* dcache, int lane) {
+    UnionSums sums = union_init();
+    for (int i = 0; i < num_instances; ++i) {
+        const Instance in = load_instance(instances, i);
+        const BoxEval e = eval_box(in, x, y, z);
+        if (kCacheDistances) dcache[i * kWave + lane] = e.d;
+        union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, 0.0f, inv_t);
+    }
+    return union_finish(sums, inv_t);
+}
+
+// Render the D-1 interval mid-points of the sorted distances `dist` (LDS, wave-private).
+//   weights[k]  <- compositing weight of sample (k*64 + lane)         (0 for padding lanes)
+//   return      <- lane i holds label i (sum_s w_s * softmin weight)  when kLabels
+//   grad_out / weight_out: this ray's [D-1,3] / [D-1] rows in HBM, or nullptr.
+template <int kRounds, bool kLabels>
+__device__ __forceinline__ float render_pass(const float* __restrict__ instances, int num_instances, const Shading& sh,
+                                             const Ray& ray, const float* dist, int num_distances, float* dcache,
+                                             float (&weights)[kRounds], float* grad_out, float* weight_out) {
+    const int lane = lane_id();
+    const int num_points = num_distances - 1;
+    float carry = 1.0f;       // transmittance entering this round (wave-uniform)
+    float label_acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kRounds; ++k) {
+        weights[k] = 0.0f;
+        if (k * kWave >= num_points) continue;                       // wave-uniform
+        const int s = k * kWave + lane;
+        const bool valid = s < num_points;
+        const int s0 = valid ? s : (num_points - 1);
+        const float d0 = dist[s0], d1 = dist[s0 + 1];
+        const float delta = d1 - d0;
+        const float mid = (d0 + d1) / 2.0f;
+        const float x = ray.ox + ray.rx * mid, y = ray.oy + ray.ry * mid, z = ray.oz + ray.rz * mid;
+        const UnionValue v = eval_union<kLabels>(instances, num_instances, sh.inv_t, x, y, z, dcache, lane);
+        const Opacity op = opacity_of(v, ray, delta, sh);
+        const float alpha = valid ? op.alpha : 0.0f;
+        const float inclusive = wave_inclusive_product(1.0f - alpha);
+        const float trans = carry * wave_shift_up(inclusive, 1.0f, lane);
+        const float w = trans * alpha;
+        carry *= read_lane(inclusive, kWave - 1);
+        weights[k] = w;
+        if (grad_out != nullptr && valid) {
+            grad_out[s * 3 + 0] = v.gx; grad_out[s * 3 + 1] = v.gy; grad_out[s * 3 + 2] = v.gz;
+        }
+        if (weight_out != nullptr && valid) weight_out[s] = w;
+        if (kLabels) {
+            const float scale = w * v.inv_z;
+            for (int i = 0; i < num_instances; ++i) {
+                const float e = expf(-(dcache[i * kWave + lane] - v.m) * sh.inv_t) * scale;
+                const float total = wave_sum(e);
+                label_acc = (lane == i) ? (label_acc + total) : label_acc;
+            }
+        }
+    }
+    return label_acc;
+}
+
+// Number of elements of the sorted LDS array a[0..n) that are  < v  (kStrict) or <= v.
+template <bool kStrict>
+__device__ __forceinline__ int count_below(const float* a, int n, float v, int iterations) {
+    int lo = 0, hi = n;
+    for (int it = 0; it < iterations; ++it) {
+        const bool open = lo < hi;
+        const int mid = (lo + hi) >> 1;
+        const float probe = a[open ? mid : 0];
+        const bool below = kStrict ? (probe < v) : (probe <= v);
+        lo = (open && below) ? (mid + 1) : lo;
+        hi = (open && !below) ? mid : hi;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ int search_iterations(int n) { return 33 - __builtin_clz(static_cast<unsigned>(n)); }
+
+// Per-wave LDS partition, in floats.
+struct WaveLds {
+    float* coarse;    // [S]   pass-1 distances
+    float* cdf;       // [S]   cdf[0] = 0, cdf[k+1] = cumsum pdf
+    float* uraw;      // [S]   raw fine uniforms
+    float* usorted;   // [S]   sorted fine uniforms
+    float* fine;      // [S]   importance samples
+    float* merged;    // [2S]  sorted union
+    float* dcache;    // [N,64] per-instance distances of the current round
+};
+
+__host__ __device__ inline int wave_lds_floats(int num_samples, int num_instances) {
+    return 7 * num_samples + num_instances * kWave;
+}
+
+__device__ __forceinline__ WaveLds carve_lds(float* base, int num_samples) {
+    WaveLds l;
+    l.coarse = base; l.cdf = base + num_samples; l.uraw = base + 2 * num_samples; l.usorted = base + 3 * num_samples;
+    l.fine = base + 4 * num_samples; l.merged = base + 5 * num_samples; l.dcache = base + 7 * num_samples;
+    return l;
+}
+
+// Sort S uniforms (one per lane and round) by ranking: rank = #{smaller} + #{equal with lower index}.
+template <int kRounds>
+__device__ __forceinline__ void rank_sort(const float* raw, float* sorted, int n) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int k = 0; k < kRounds; ++k) {
+        if (k * kWave >= n) continue;
+        const int idx = k * kWave + lane;
+        const bool valid = idx < n;
+        const float v = raw[valid ? idx : 0];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {                                // LDS broadcast reads
+            const float o = raw[j];
+            rank += ((o < v) || (o == v && j < idx)) ? 1 : 0;
+        }
+        if (valid) sorted[rank] = v;
+    }
+}
+
+// samplers.py:11-36 + renderers.py:198-210: importance samples from (coarse, weights), merged with
+// the coarse distances into l.merged[0..2S).  weights[k] holds w of sample k*64+lane (0 when >= S-1).
+// l.usorted must hold the sorted uniforms.
+template <int kRoundsS>
+__device__ __forceinline__ void importance_merge(const WaveLds& l, int S, const float (&weights)[kRoundsS]) {
+    const int lane = lane_id();
+    // pdf = w / max(sum |w|, 1e-12); cdf = cumsum
+    float total = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kRoundsS; ++k) total += wave_sum(fabsf(weights[k]));
+    const float denom = fmaxf(total, 1.0e-12f);
+    float running = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kRoundsS; ++k) {
+        if (k * kWave >= S - 1) continue;
+        const int idx = k * kWave + lane;
+        const float inclusive = wave_inclusive_sum(weights[k] / denom) + running;
+        if (idx < S - 1) l.cdf[idx + 1] = inclusive;
+        running = read_lane(inclusive, kWave - 1);
+    }
+    if (lane == 0) l.cdf[0] = 0.0f;
+    wave_lds_sync();
+    // inverse transform
+    const int iters = search_iterations(S);
+    float fine_max = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < kRoundsS; ++k) {
+        if (k * kWave >= S) continue;
+        const int j = k * kWave + lane;
+        const bool valid = j < S;
+        const float u = l.usorted[valid ? j : (S - 1)];
+        int upper = count_below<true>(l.cdf, S, u, iters);          // searchsorted(right=False)
+        upper = min(max(upper, 1), S - 1);
+        const float c_lo = l.cdf[upper - 1], c_hi = l.cdf[upper];
+        const float b_lo = l.coarse[upper - 1], b_hi = l.coarse[upper];
+        const float t = (u - c_lo) / (c_hi - c_lo + 1.0e-6f);
+        float sample = torch_lerp(b_lo, b_hi, t);
+        // The samples are non-decreasing in exact arithmetic; a running maximum removes one-ulp
+        // inversions of the two-sided lerp so that the rank merge below is a valid permutation.
+        float scan = valid ? sample : -3.0e38f;
+        scan = fmaxf(scan, dpp_move<kDppRowShr1>(scan, scan));
+        scan = fmaxf(scan, dpp_move<kDppRowShr2>(scan, scan));
+        scan = fmaxf(scan, dpp_move<kDppRowShr4>(scan, scan));
+        scan = fmaxf(scan, dpp_move<kDppRowShr8>(scan, scan));
+        scan = fmaxf(scan, dpp_move<kDppRowBcast15, 0xa>(scan, scan));
+        scan = fmaxf(scan, dpp_move<kDppRowBcast31, 0xc>(scan, scan));
+        sample = fmaxf(scan, fine_max);
+        fine_max = fmaxf(fine_max, read_lane(scan, kWave - 1));
+        if (valid) l.fine[j] = sample;
+    }
+    wave_lds_sync();
+    // merge by rank (ties: coarse first)
+#pragma unroll
+    for (int k = 0; k < kRoundsS; ++k) {
+        if (k * kWave >= S) continue;
+        const int j = k * kWave + lane;
+        const bool valid = j < S;
+        const int jj = valid ? j : (S - 1);
+        const float a = l.coarse[jj], b = l.fine[jj];
+        const int rank_a = jj + count_below<true>(l.fine, S, a, iters);
+        const int rank_b = jj + count_below<false>(l.coarse, S, b, iters);
+        if (valid) { l.merged[rank_a] = a; l.merged[rank_b] = b; }
+    }
+    wave_lds_sync();
+}
+
+}  // namespace vsrd

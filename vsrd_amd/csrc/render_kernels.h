@@ -1,0 +1,350 @@
+// __global__ kernels of the render path (forward, fused hierarchical forward, backward).
+// Grid: persistent-ish; 256-thread workgroups = 4 independent waves, each looping over rays.
+#pragma once
+#include "render.h"
+
+namespace vsrd {
+
+constexpr int kMaxWavesPerBlock = 4;
+constexpr int kBlockThreads = kMaxWavesPerBlock * kWave;   // launch bound; the host may launch fewer waves
+
+__device__ __forceinline__ int waves_per_block() { return static_cast<int>(blockDim.x) >> 6; }
+constexpr int kGradStride = kInstanceStride;   // grad_instances rows are [t(3) R(9) dim(3) pad]
+
+struct FieldArgs {
+    const float* __restrict__ instances;   // [N,16]
+    const float* __restrict__ mlp_weights; // [N,1617] or nullptr
+    int num_instances;
+    float inv_t;
+};
+
+struct RenderArgs {
+    int num_rays;
+    int num_samples;
+    float near, far;
+    Shading sh;
+    int origin_stride;
+    unsigned long long seed, stream_offset;
+    unsigned flags;
+};
+
+__device__ __forceinline__ Ray load_ray(const float* __restrict__ origins, const float* __restrict__ directions,
+                                        int origin_stride, int ray) {
+    const float* o = origins + static_cast<size_t>(ray) * origin_stride;
+    const float* d = directions + static_cast<size_t>(ray) * 3;
+    Ray r;
+    r.ox = uniform(o[0]); r.oy = uniform(o[1]); r.oz = uniform(o[2]);
+    r.rx = uniform(d[0]); r.ry = uniform(d[1]); r.rz = uniform(d[2]);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// renderers.py:212-270 at given sorted distances [R,D]
+// ---------------------------------------------------------------------------------------------------
+template <int kRounds>
+__global__ __launch_bounds__(kBlockThreads) void render_forward_kernel(
+    FieldArgs f, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
+    const float* __restrict__ distances, int num_distances,
+    float* __restrict__ labels, float* __restrict__ gradients, float* __restrict__ weights) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = wave_in_block();
+    const int lane = lane_id();
+    const int per_wave = num_distances + f.num_instances * kWave;
+    float* dist = lds + wave * per_wave;
+    float* dcache = dist + num_distances;
+    const int stride = static_cast<int>(gridDim.x) * waves_per_block();
+    for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
+        const Ray r = load_ray(origins, directions, c.origin_stride, ray);
+        const float* src = distances + static_cast<size_t>(ray) * num_distances;
+        for (int idx = lane; idx < num_distances; idx += kWave) dist[idx] = src[idx];
+        wave_lds_sync();
+        float w[kRounds];
+        float* g_out = gradients ? gradients + static_cast<size_t>(ray) * (num_distances - 1) * 3 : nullptr;
+        float* w_out = weights ? weights + static_cast<size_t>(ray) * (num_distances - 1) : nullptr;
+        const float label = render_pass<kRounds, true>(f.instances, f.num_instances, c.sh, r, dist, num_distances, dcache, w, g_out, w_out);
+        if (lane < f.num_instances) labels[static_cast<size_t>(ray) * f.num_instances + lane] = label;
+        wave_lds_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// scripts/main.py:511-523 (two-pass wrapper) in one launch
+// ---------------------------------------------------------------------------------------------------
+template <int kRounds>
+__global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
+    FieldArgs f, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
+    const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
+    float* __restrict__ labels, float* __restrict__ distances, float* __restrict__ gradients, float* __restrict__ weights,
+    float* __restrict__ u_coarse_out, float* __restrict__ u_fine_out) {
+    constexpr int kRoundsS = (kRounds + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = wave_in_block();
+    const int lane = lane_id();
+    const int S = c.num_samples;
+    const WaveLds l = carve_lds(lds + wave * wave_lds_floats(S, f.num_instances), S);
+    const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
+    const int stride = static_cast<int>(gridDim.x) * waves_per_block();
+    for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
+        const Ray r = load_ray(origins, directions, c.origin_stride, ray);
+        const size_t row = static_cast<size_t>(ray) * S;
+        // ---- stratified distances (samplers.py:5-8) and the fine uniforms -------------------------
+#pragma unroll
+        for (int k = 0; k < kRoundsS; ++k) {
+            const int idx = k * kWave + lane;
+            if (idx < S) {
+                float uc, uf;
+                if (u_coarse == nullptr || u_fine == nullptr) {
+                    const Philox4 rnd = philox4x32_10(static_cast<uint32_t>(ray), static_cast<uint32_t>(idx),
+                                                      static_cast<uint32_t>(c.stream_offset), static_cast<uint32_t>(c.stream_offset >> 32),
+                                                      static_cast<uint32_t>(c.seed), static_cast<uint32_t>(c.seed >> 32));
+                    uc = uniform_from_bits(rnd.x);
+                    uf = uniform_from_bits(rnd.y);
+                }
+                if (u_coarse != nullptr) uc = u_coarse[row + idx];
+                if (u_fine != nullptr) uf = u_fine[row + idx];
+                const float lo = torch_linspace(c.near, c.far, S + 1, idx);
+                const float hi = torch_linspace(c.near, c.far, S + 1, idx + 1);
+                l.coarse[idx] = torch_lerp(lo, hi, uc);
+                (sorted_input ? l.usorted : l.uraw)[idx] = uf;
+                if (u_coarse_out != nullptr) u_coarse_out[row + idx] = uc;
+                if (u_fine_out != nullptr) u_fine_out[row + idx] = uf;
+            }
+        }
+        wave_lds_sync();
+        if (!sorted_input) {
+            rank_sort<kRoundsS>(l.uraw, l.usorted, S);
+            wave_lds_sync();
+        }
+        // ---- pass 1: coarse weights only (no labels, no outputs) ----------------------------------
+        float w1[kRoundsS];
+        render_pass<kRoundsS, false>(f.instances, f.num_instances, c.sh, r, l.coarse, S, l.dcache, w1, nullptr, nullptr);
+        if (c.flags & 2u) {
+            float total = 0.0f;
+#pragma unroll
+            for (int k = 0; k < kRoundsS; ++k) total += wave_sum(w1[k]);
+            if (total == 0.0f) {                                    // wave-uniform: exact miss
+                if (lane < f.num_instances) labels[static_cast<size_t>(ray) * f.num_instances + lane] = 0.0f;
+                // sentinel row: the backward skips it (the exact adjoint of an exact miss is zero)
+                if (distances != nullptr && lane == 0) distances[static_cast<size_t>(ray) * 2 * S] = __builtin_nanf("");
+                wave_lds_sync();
+                continue;
+            }
+        }
+        // ---- importance sampling + merge (samplers.py:11-36, renderers.py:198-210) ---------------
+        importance_merge<kRoundsS>(l, S, w1);
+        // ---- pass 2 ----------------------------------------------------------------------------------
+        float w2[kRounds];
+        const int D = 2 * S;
+        float* g_out = gradients ? gradients + static_cast<size_t>(ray) * (D - 1) * 3 : nullptr;
+        float* w_out = weights ? weights + static_cast<size_t>(ray) * (D - 1) : nullptr;
+        const float label = render_pass<kRounds, true>(f.instances, f.num_instances, c.sh, r, l.merged, D, l.dcache, w2, g_out, w_out);
+        if (lane < f.num_instances) labels[static_cast<size_t>(ray) * f.num_instances + lane] = label;
+        if (distances != nullptr) {
+            float* dst = distances + static_cast<size_t>(ray) * D;
+            for (int idx = lane; idx < D; idx += kWave) dst[idx] = l.merged[idx];
+        }
+        wave_lds_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Adjoint of render_forward w.r.t. the packed instances.  Derivation: DESIGN.md "Backward";
+// float64 blueprint: oracle/analytic.py (phase A / phase B).
+// ---------------------------------------------------------------------------------------------------
+struct SampleAdjoint {
+    float x, y, z;        // sample position
+    float m, inv_z, us;   // soft-min shift, 1/Z, u - m
+    float wgt;            // compositing weight
+    float lam_z;          // sum_n lambda_n w_n
+    float u_bar;          // dL/du
+    float gbx, gby, gbz;  // dL/dg
+    float A, B;           // g_bar . g,  g_bar . sum_i w_i grad d_i
+};
+
+template <int kRounds>
+__global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
+    FieldArgs f, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
+    const float* __restrict__ distances, int num_distances,
+    const float* __restrict__ grad_labels, const float* __restrict__ grad_gradients, const float* __restrict__ grad_weights,
+    float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = wave_in_block();
+    const int lane = lane_id();
+    const int N = f.num_instances;
+    const int num_points = num_distances - 1;
+    const int per_wave = num_distances + N + N * kGradStride;
+    float* dist = lds + wave * per_wave;
+    float* lam = dist + num_distances;
+    float* G = lam + N;
+    for (int idx = lane; idx < N * kGradStride; idx += kWave) G[idx] = 0.0f;
+    const float inv_t = f.inv_t;
+    const Shading sh = c.sh;
+    const int stride = static_cast<int>(gridDim.x) * waves_per_block();
+    for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
+        wave_lds_sync();
+        const float lam_lane = (lane < N) ? grad_labels[static_cast<size_t>(ray) * N + lane] : 0.0f;
+        if (grad_gradients == nullptr && grad_weights == nullptr && wave_max(fabsf(lam_lane)) == 0.0f) continue;  // nothing flows back
+        const Ray r = load_ray(origins, directions, c.origin_stride, ray);
+        const float* src = distances + static_cast<size_t>(ray) * num_distances;
+        for (int idx = lane; idx < num_distances; idx += kWave) dist[idx] = src[idx];
+        if (lane < N) lam[lane] = lam_lane;
+        wave_lds_sync();
+        if (dist[0] != dist[0]) continue;                            // NaN sentinel: ray skipped by the forward
+
+        // ---- phase A, forward sweep: union sums, opacity, transmittance -----------------------------
+        SampleAdjoint sa[kRounds];
+        Opacity op[kRounds];
+        float gx[kRounds], gy[kRounds], gz[kRounds], trans[kRounds], delta[kRounds];
+        float carry = 1.0f;
+#pragma unroll
+        for (int k = 0; k < kRounds; ++k) {
+            const int s = k * kWave + lane;
+            const bool valid = s < num_points;
+            const int s0 = valid ? s : (num_points - 1);
+            const float d0 = dist[s0], d1 = dist[s0 + 1];
+            delta[k] = d1 - d0;
+            const float mid = (d0 + d1) / 2.0f;
+            sa[k].x = r.ox + r.rx * mid; sa[k].y = r.oy + r.ry * mid; sa[k].z = r.oz + r.rz * mid;
+            UnionSums sums = union_init();
+            for (int i = 0; i < N; ++i) {
+                const Instance in = load_instance(f.instances, i);
+                const BoxEval e = eval_box(in, sa[k].x, sa[k].y, sa[k].z);
+                union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lam[i], inv_t);
+            }
+            const UnionValue v = union_finish(sums, inv_t);
+            op[k] = opacity_of(v, r, delta[k], sh);
+            const float alpha = valid ? op[k].alpha : 0.0f;
+            op[k].alpha = alpha;
+            const float inclusive = wave_inclusive_product(1.0f - alpha);
+            trans[k] = carry * wave_shift_up(inclusive, 1.0f, lane);
+            carry *= read_lane(inclusive, kWave - 1);
+            sa[k].m = v.m; sa[k].inv_z = v.inv_z; sa[k].us = v.us;
+            sa[k].wgt = trans[k] * alpha;
+            sa[k].lam_z = sums.L * v.inv_z;
+            gx[k] = v.gx; gy[k] = v.gy; gz[k] = v.gz;
+            // B needs sum_i w_i grad d_i: stash it in (gbx,gby,gbz) until the reverse sweep
+            sa[k].gbx = v.b0x; sa[k].gby = v.b0y; sa[k].gbz = v.b0z;
+        }
+        // ---- phase A, reverse sweep: labels -> weights -> opacity -> (u_bar, g_bar) -----------------
+        float suffix_carry = 0.0f;
+        bool any_flow = false;
+#pragma unroll
+        for (int k = kRounds - 1; k >= 0; --k) {
+            const int s = k * kWave + lane;
+            const bool valid = s < num_points;
+            float w_bar = sa[k].lam_z;
+            if (grad_weights != nullptr && valid) w_bar += grad_weights[static_cast<size_t>(ray) * num_points + s];
+            const float contrib = valid ? w_bar * sa[k].wgt : 0.0f;
+            const float rev_inclusive = wave_inclusive_sum(wave_reverse(contrib, lane));
+            const float suffix_inclusive = wave_reverse(rev_inclusive, lane);
+            const float Q = suffix_inclusive - contrib + suffix_carry;          // sum over later samples
+            suffix_carry += read_lane(rev_inclusive, kWave - 1);
+            const float alpha = op[k].alpha;
+            const float alpha_bar = w_bar * trans[k] - Q / (1.0f - alpha);
+            const float x_bar = (valid && op[k].xx > 0.0f) ? alpha_bar : 0.0f;
+            const float pe = op[k].phi_p + sh.eps;
+            const float phi_p_bar = x_bar * (op[k].phi_n + sh.eps) / (pe * pe);
+            const float phi_n_bar = -x_bar / pe;
+            const float sp_bar = phi_p_bar * op[k].phi_p * (1.0f - op[k].phi_p) / sh.std;
+            const float sn_bar = phi_n_bar * op[k].phi_n * (1.0f - op[k].phi_n) / sh.std;
+            const float u_bar = sp_bar + sn_bar;
+            const float cprime_bar = (sn_bar - sp_bar) * delta[k] / 2.0f;
+            const float slope = (1.0f - sh.ratio) * ((0.5f - 0.5f * op[k].cosine > 0.0f) ? 0.5f : 0.0f)
+                              + sh.ratio * ((-op[k].cosine > 0.0f) ? 1.0f : 0.0f);
+            const float cos_bar = cprime_bar * slope;
+            const float nbx = cos_bar * r.rx, nby = cos_bar * r.ry, nbz = cos_bar * r.rz;
+            const float n_dot = op[k].nx * nbx + op[k].ny * nby + op[k].nz * nbz;
+            float gbx = (nbx - op[k].nx * n_dot) * op[k].inv_gn;
+            float gby = (nby - op[k].ny * n_dot) * op[k].inv_gn;
+            float gbz = (nbz - op[k].nz * n_dot) * op[k].inv_gn;
+            if (grad_gradients != nullptr && valid) {
+                const float* gg = grad_gradients + (static_cast<size_t>(ray) * num_points + s) * 3;
+                gbx += gg[0]; gby += gg[1]; gbz += gg[2];
+            }
+            if (!valid) { gbx = 0.0f; gby = 0.0f; gbz = 0.0f; }
+            sa[k].B = gbx * sa[k].gbx + gby * sa[k].gby + gbz * sa[k].gbz;
+            sa[k].A = gbx * gx[k] + gby * gy[k] + gbz * gz[k];
+            sa[k].gbx = gbx; sa[k].gby = gby; sa[k].gbz = gbz;
+            sa[k].u_bar = valid ? u_bar : 0.0f;
+            if (!valid) { sa[k].wgt = 0.0f; sa[k].lam_z = 0.0f; }
+            any_flow = any_flow || (sa[k].u_bar != 0.0f) || (gbx != 0.0f) || (gby != 0.0f) || (gbz != 0.0f) || (sa[k].wgt != 0.0f);
+        }
+        if (__ballot(any_flow) == 0ull) continue;                                  // wave-uniform: exact zero adjoint
+
+        // ---- phase B: per instance, adjoint of (d_i, grad d_i) w.r.t. (t, R, dim) -------------------
+        for (int i = 0; i < N; ++i) {
+            const Instance in = load_instance(f.instances, i);
+            const float lam_i = lam[i];
+            float at0 = 0, at1 = 0, at2 = 0, ad0 = 0, ad1 = 0, ad2 = 0;
+            float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
+#pragma unroll
+            for (int k = 0; k < kRounds; ++k) {
+                if (k * kWave >= num_points) continue;
+                const BoxEval e = eval_box(in, sa[k].x, sa[k].y, sa[k].z);
+                const float ds = e.d - sa[k].m;
+                const float w = expf(-ds * inv_t) * sa[k].inv_z;
+                const float cc = w * (1.0f - (ds - sa[k].us) * inv_t);
+                const float beta = sa[k].gbx * e.gwx + sa[k].gby * e.gwy + sa[k].gbz * e.gwz;
+                const float d_bar = sa[k].u_bar * cc
+                                  + inv_t * (-beta * cc + w * sa[k].A - beta * w + cc * sa[k].B)
+                                  - inv_t * w * sa[k].wgt * (lam_i - sa[k].lam_z);
+                const float gwbx = cc * sa[k].gbx, gwby = cc * sa[k].gby, gwbz = cc * sa[k].gbz;
+                // gl_bar_j = sum_k R_kj gw_bar_k
+                const float glbx = in.r00 * gwbx + in.r10 * gwby + in.r20 * gwbz;
+                const float glby = in.r01 * gwbx + in.r11 * gwby + in.r21 * gwbz;
+                const float glbz = in.r02 * gwbx + in.r12 * gwby + in.r22 * gwbz;
+                const float sx = sign_of(e.px), sy = sign_of(e.py), sz = sign_of(e.pz);
+                const float vx = sx * glbx, vy = sy * glby, vz = sz * glbz;
+                const float inv_n = 1.0f / e.nrm;
+                const float hx = fmaxf(e.qx, 0.0f) * inv_n, hy = fmaxf(e.qy, 0.0f) * inv_n, hz = fmaxf(e.qz, 0.0f) * inv_n;
+                const float hv = hx * vx + hy * vy + hz * vz;
+                const float qbx = d_bar * e.hx + ((e.qx > 0.0f) ? (vx - hx * hv) * inv_n : 0.0f);
+                const float qby = d_bar * e.hy + ((e.qy > 0.0f) ? (vy - hy * hv) * inv_n : 0.0f);
+                const float qbz = d_bar * e.hz + ((e.qz > 0.0f) ? (vz - hz * hv) * inv_n : 0.0f);
+                const float pbx = sx * qbx, pby = sy * qby, pbz = sz * qbz;
+                ad0 -= qbx; ad1 -= qby; ad2 -= qbz;
+                r00 += e.relx * pbx + gwbx * e.glx; r01 += e.relx * pby + gwbx * e.gly; r02 += e.relx * pbz + gwbx * e.glz;
+                r10 += e.rely * pbx + gwby * e.glx; r11 += e.rely * pby + gwby * e.gly; r12 += e.rely * pbz + gwby * e.glz;
+                r20 += e.relz * pbx + gwbz * e.glx; r21 += e.relz * pby + gwbz * e.gly; r22 += e.relz * pbz + gwbz * e.glz;
+                at0 -= in.r00 * pbx + in.r01 * pby + in.r02 * pbz;
+                at1 -= in.r10 * pbx + in.r11 * pby + in.r12 * pbz;
+                at2 -= in.r20 * pbx + in.r21 * pby + in.r22 * pbz;
+            }
+            // 15 wave reductions; lane j (< 15) keeps parameter j of instance i in its LDS slot
+            const float t0 = wave_sum(at0), t1 = wave_sum(at1), t2 = wave_sum(at2);
+            const float m0 = wave_sum(r00), m1 = wave_sum(r01), m2 = wave_sum(r02);
+            const float m3 = wave_sum(r10), m4 = wave_sum(r11), m5 = wave_sum(r12);
+            const float m6 = wave_sum(r20), m7 = wave_sum(r21), m8 = wave_sum(r22);
+            const float e0 = wave_sum(ad0), e1 = wave_sum(ad1), e2 = wave_sum(ad2);
+            float mine = 0.0f;
+            mine = (lane == 0) ? t0 : mine; mine = (lane == 1) ? t1 : mine; mine = (lane == 2) ? t2 : mine;
+            mine = (lane == 3) ? m0 : mine; mine = (lane == 4) ? m1 : mine; mine = (lane == 5) ? m2 : mine;
+            mine = (lane == 6) ? m3 : mine; mine = (lane == 7) ? m4 : mine; mine = (lane == 8) ? m5 : mine;
+            mine = (lane == 9) ? m6 : mine; mine = (lane == 10) ? m7 : mine; mine = (lane == 11) ? m8 : mine;
+            mine = (lane == 12) ? e0 : mine; mine = (lane == 13) ? e1 : mine; mine = (lane == 14) ? e2 : mine;
+            if (lane < kGradStride) G[i * kGradStride + lane] += mine;
+        }
+    }
+    wave_lds_sync();
+    const size_t wave_global = static_cast<size_t>(blockIdx.x) * waves_per_block() + wave;
+    float* out = partials + wave_global * (N * kGradStride);
+    for (int idx = lane; idx < N * kGradStride; idx += kWave) out[idx] = G[idx];
+}
+
+// Deterministic second stage: grad[idx] = sum over waves of partials[wave][idx].
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int num_waves, int row, float* __restrict__ out) {
+    __shared__ float scratch[256 / kWave];
+    const int idx = blockIdx.x;
+    float acc = 0.0f;
+    for (int w = threadIdx.x; w < num_waves; w += blockDim.x) acc += partials[static_cast<size_t>(w) * row + idx];
+    acc = wave_sum(acc);
+    if (lane_id() == 0) scratch[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float total = 0.0f;
+        for (int k = 0; k < 256 / kWave; ++k) total += scratch[k];
+        out[idx] = total;
+    }
+}
+
+}  // namespace vsrd

@@ -1,0 +1,117 @@
+// Wave64 primitives for gfx950: one wavefront renders one ray, one lane owns one sample.
+// Everything here is wave-local: no workgroup barrier is ever needed on the render path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vsrd {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & (kWave - 1); }
+
+// Wave index inside the workgroup as a *scalar* (SGPR) value so that everything indexed by it
+// (LDS partitions, ray ids, per-instance parameter loads) stays on the scalar unit.
+__device__ __forceinline__ int wave_in_block() {
+    return __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+}
+
+__device__ __forceinline__ float uniform(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+__device__ __forceinline__ float read_lane(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// LDS written by some lanes of this wave and read by others: DS operations of one wave execute in
+// order, so only the compiler has to be stopped from reordering; the workgroup-scope fence also
+// drains lgkmcnt, which is cheap and keeps this robust against scheduling changes.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// ---- DPP building blocks (gfx9 family: row_shr, row_bcast15/31 are available on gfx950) ----------
+template <int kCtrl, int kRowMask = 0xf, int kBankMask = 0xf>
+__device__ __forceinline__ float dpp_move(float identity, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v),
+                                                                 kCtrl, kRowMask, kBankMask, false));
+}
+constexpr int kDppQuadXor1 = 0xB1;       // quad_perm:[1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4E;       // quad_perm:[2,3,0,1]
+constexpr int kDppRowHalfMirror = 0x141;
+constexpr int kDppRowMirror = 0x140;
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
+constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
+
+// Sum over the 64 lanes; the result is returned as a wave-uniform value.
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_move<kDppQuadXor1>(0.0f, v);
+    v += dpp_move<kDppQuadXor2>(0.0f, v);
+    v += dpp_move<kDppRowHalfMirror>(0.0f, v);
+    v += dpp_move<kDppRowMirror>(0.0f, v);                 // every lane: sum of its row of 16
+    v += dpp_move<kDppRowBcast15, 0xa>(0.0f, v);           // rows 1,3 += row 0,2
+    v += dpp_move<kDppRowBcast31, 0xc>(0.0f, v);           // rows 2,3 += rows 0+1
+    return read_lane(v, 63);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_move<kDppQuadXor1>(v, v));
+    v = fmaxf(v, dpp_move<kDppQuadXor2>(v, v));
+    v = fmaxf(v, dpp_move<kDppRowHalfMirror>(v, v));
+    v = fmaxf(v, dpp_move<kDppRowMirror>(v, v));
+    v = fmaxf(v, dpp_move<kDppRowBcast15, 0xa>(v, v));
+    v = fmaxf(v, dpp_move<kDppRowBcast31, 0xc>(v, v));
+    return read_lane(v, 63);
+}
+
+// Inclusive prefix sum / product over the lanes (lane 0 first).
+__device__ __forceinline__ float wave_inclusive_sum(float v) {
+    v += dpp_move<kDppRowShr1>(0.0f, v);
+    v += dpp_move<kDppRowShr2>(0.0f, v);
+    v += dpp_move<kDppRowShr4>(0.0f, v);
+    v += dpp_move<kDppRowShr8>(0.0f, v);                   // scan inside each row of 16
+    v += dpp_move<kDppRowBcast15, 0xa>(0.0f, v);
+    v += dpp_move<kDppRowBcast31, 0xc>(0.0f, v);
+    return v;
+}
+
+__device__ __forceinline__ float wave_inclusive_product(float v) {
+    v *= dpp_move<kDppRowShr1>(1.0f, v);
+    v *= dpp_move<kDppRowShr2>(1.0f, v);
+    v *= dpp_move<kDppRowShr4>(1.0f, v);
+    v *= dpp_move<kDppRowShr8>(1.0f, v);
+    v *= dpp_move<kDppRowBcast15, 0xa>(1.0f, v);
+    v *= dpp_move<kDppRowBcast31, 0xc>(1.0f, v);
+    return v;
+}
+
+// Value of lane (l-1), `first` for lane 0 / value of lane (l+1), `last` for lane 63.
+__device__ __forceinline__ float wave_shift_up(float v, float first, int lane) {
+    const float t = __shfl_up(v, 1, kWave);
+    return lane == 0 ? first : t;
+}
+__device__ __forceinline__ float wave_reverse(float v, int lane) { return __shfl(v, kWave - 1 - lane, kWave); }
+
+// ---- Philox4x32-10 (counter-based; the same generator family torch uses on device) --------------
+struct Philox4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+    constexpr uint32_t kM0 = 0xD2511F53u, kM1 = 0xCD9E8D57u, kW0 = 0x9E3779B9u, kW1 = 0xBB67AE85u;
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        const uint32_t hi0 = __umulhi(kM0, c0), lo0 = kM0 * c0;
+        const uint32_t hi1 = __umulhi(kM1, c2), lo1 = kM1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += kW0; k1 += kW1;
+    }
+    return {c0, c1, c2, c3};
+}
+
+// 24 random bits -> [0, 1) exactly as torch's uniform transformation for float.
+__device__ __forceinline__ float uniform_from_bits(uint32_t bits) { return static_cast<float>(bits >> 8) * 5.9604644775390625e-08f; }
+
+}  // namespace vsrd

@@ -1,0 +1,275 @@
+"""vsrd.rendering renderers on the HIP library (reference: vsrd/rendering/renderers.py:177-270,
+scripts/main.py:511-523).
+
+Two ways in:
+
+* ``hierarchical_volumetric_rendering`` -- the reference's signature and return tuple, one call per
+  pass exactly as ``scripts/main.py``'s ``hierarchical_wrapper`` drives it.  Random draws come from
+  the torch generator in the reference's order (``rand_like`` for the stratified pass, ``rand`` +
+  ``sort`` for the importance pass), so a seeded run consumes the same stream as the reference
+  would on the same device.
+* ``render_hierarchical`` -- both passes in ONE kernel launch (pass 1, importance sampling, merge,
+  pass 2), uniforms from in-kernel Philox or supplied, only ``labels`` (and what the backward needs)
+  written to HBM.  This is the production / benchmark path.
+
+Gradients reach the field parameters through ``torch.autograd.Function``s whose backward is the
+hand-derived adjoint kernel (``vsrd_render_backward``); there is no PyTorch-op fallback.
+"""
+import torch
+
+from .. import _lib
+from ..fields import FieldBlock, SoftUnion, flatten, _closure_vars
+
+_workspaces = {}
+
+
+def _workspace(device, num_instances):
+    key = (device, num_instances)
+    buf = _workspaces.get(key)
+    if buf is None:
+        nbytes = _lib.load().vsrd_workspace_bytes(num_instances)
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def _prepare_rays(ray_positions, ray_directions):
+    lead = ray_directions.shape[:-1]
+    directions = ray_directions.reshape(-1, 3).to(torch.float32).contiguous()
+    if ray_positions.dim() == 1:
+        origins, stride = ray_positions.to(torch.float32).contiguous(), 0
+    else:
+        origins = ray_positions.expand(*lead, 3).reshape(-1, 3).to(torch.float32).contiguous()
+        stride = 3
+    return origins, directions, stride, lead
+
+
+class _RenderAtDistances(torch.autograd.Function):
+    """renderers.py:212-270 at given sorted distances (ray-major [R,D])."""
+
+    @staticmethod
+    def forward(ctx, instances, origins, directions, distances, temperature, scalars, origin_stride):
+        lib = _lib.load()
+        std, ratio, eps, near, far, num_samples = scalars
+        R, D = distances.shape
+        N = instances.shape[0]
+        instances = instances.detach().contiguous()
+        labels = torch.empty(R, N, dtype=torch.float32, device=distances.device)
+        gradients = torch.empty(R, D - 1, 3, dtype=torch.float32, device=distances.device)
+        weights = torch.empty(R, D - 1, dtype=torch.float32, device=distances.device)
+        field = _lib.make_field(instances, temperature)
+        config = _lib.make_config(R, num_samples, (near, far), std, ratio, eps, origin_stride)
+        _lib.check(lib.vsrd_render_forward(field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(distances), D,
+                                           _lib.ptr(labels), _lib.ptr(gradients), _lib.ptr(weights), _lib.stream()))
+        ctx.save_for_backward(instances, origins, directions, distances)
+        ctx.meta = (temperature, scalars, origin_stride)
+        ctx.set_materialize_grads(False)   # unused outputs arrive as None, not as zero tensors
+        return labels, gradients, weights
+
+    @staticmethod
+    def backward(ctx, grad_labels, grad_gradients, grad_weights):
+        instances, origins, directions, distances = ctx.saved_tensors
+        temperature, scalars, origin_stride = ctx.meta
+        return (_backward(instances, origins, directions, distances, temperature, scalars, origin_stride,
+                          grad_labels, grad_gradients, grad_weights), None, None, None, None, None, None)
+
+
+def _backward(instances, origins, directions, distances, temperature, scalars, origin_stride,
+              grad_labels, grad_gradients, grad_weights):
+    lib = _lib.load()
+    std, ratio, eps, near, far, num_samples = scalars
+    R, D = distances.shape
+    N = instances.shape[0]
+    grad_labels = torch.zeros(R, N, dtype=torch.float32, device=distances.device) if grad_labels is None \
+        else grad_labels.to(torch.float32).contiguous()
+    grad_gradients = None if grad_gradients is None else grad_gradients.to(torch.float32).contiguous()
+    grad_weights = None if grad_weights is None else grad_weights.to(torch.float32).contiguous()
+    grad_instances = torch.empty_like(instances)
+    workspace = _workspace(distances.device, N)
+    field = _lib.make_field(instances, temperature)
+    config = _lib.make_config(R, num_samples, (near, far), std, ratio, eps, origin_stride)
+    _lib.check(lib.vsrd_render_backward(field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(distances), D,
+                                        _lib.ptr(grad_labels), _lib.ptr(grad_gradients), _lib.ptr(grad_weights),
+                                        workspace.data_ptr(), workspace.numel(), _lib.ptr(grad_instances), _lib.stream()))
+    return grad_instances
+
+
+class _RenderHierarchical(torch.autograd.Function):
+    """scripts/main.py:511-523 around renderers.py:177-270, both passes in one launch."""
+
+    @staticmethod
+    def forward(ctx, instances, origins, directions, u_coarse, u_fine, temperature, scalars, origin_stride,
+                seed, stream_offset, flags, want_gradients, want_weights, want_uniforms):
+        lib = _lib.load()
+        std, ratio, eps, near, far, S = scalars
+        R = directions.shape[0]
+        N = instances.shape[0]
+        dev = directions.device
+        instances = instances.detach().contiguous()
+        labels = torch.empty(R, N, dtype=torch.float32, device=dev)
+        distances = torch.empty(R, 2 * S, dtype=torch.float32, device=dev)
+        gradients = torch.empty(R, 2 * S - 1, 3, dtype=torch.float32, device=dev) if want_gradients else None
+        weights = torch.empty(R, 2 * S - 1, dtype=torch.float32, device=dev) if want_weights else None
+        uc_out = torch.empty(R, S, dtype=torch.float32, device=dev) if want_uniforms else None
+        uf_out = torch.empty(R, S, dtype=torch.float32, device=dev) if want_uniforms else None
+        field = _lib.make_field(instances, temperature)
+        config = _lib.make_config(R, S, (near, far), std, ratio, eps, origin_stride, seed, stream_offset, flags)
+        _lib.check(lib.vsrd_render_hierarchical_forward(
+            field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(u_coarse), _lib.ptr(u_fine),
+            _lib.ptr(labels), _lib.ptr(distances), _lib.ptr(gradients), _lib.ptr(weights),
+            _lib.ptr(uc_out), _lib.ptr(uf_out), _lib.stream()))
+        ctx.save_for_backward(instances, origins, directions, distances)
+        ctx.meta = (temperature, scalars, origin_stride)
+        ctx.set_materialize_grads(False)
+        outs = (labels, gradients if want_gradients else labels.new_empty(0), weights if want_weights else labels.new_empty(0),
+                distances, uc_out if want_uniforms else labels.new_empty(0), uf_out if want_uniforms else labels.new_empty(0))
+        ctx.mark_non_differentiable(outs[3], outs[4], outs[5])
+        return outs
+
+    @staticmethod
+    def backward(ctx, grad_labels, grad_gradients, grad_weights, _gd, _gu1, _gu2):
+        instances, origins, directions, distances = ctx.saved_tensors
+        temperature, scalars, origin_stride = ctx.meta
+        if grad_gradients is not None and grad_gradients.numel() == 0:
+            grad_gradients = None
+        if grad_weights is not None and grad_weights.numel() == 0:
+            grad_weights = None
+        grad = _backward(instances, origins, directions, distances, temperature, scalars, origin_stride,
+                         grad_labels, grad_gradients, grad_weights)
+        return (grad,) + (None,) * 13
+
+
+def _scatter_labels(labels, block: FieldBlock):
+    """One-hot features are indexed by instance_label (main.py:470); identity unless labels were permuted."""
+    if block.label_indices is None:
+        return labels
+    out = torch.zeros_like(labels)
+    return out.index_add(-1, block.label_indices, labels)
+
+
+def render_at_distances(distance_field, ray_positions, ray_directions, distances, sdf_std_deviation,
+                        cosine_ratio=1.0, epsilon=1.0e-6):
+    """Ray-major core: distances [R,D] sorted -> (labels [R,N], gradients [R,D-1,3], weights [R,D-1])."""
+    block = flatten(distance_field)
+    if block.mlp_weights is not None:
+        raise NotImplementedError("residual-MLP fields are not implemented in this round (SURVEY.md §8 row a9-a11)")
+    origins, directions, stride, _ = _prepare_rays(ray_positions, ray_directions)
+    distances = distances.to(torch.float32).contiguous()
+    scalars = (float(sdf_std_deviation), float(cosine_ratio), float(epsilon), 0.0, 1.0, max(2, (distances.shape[1] + 1) // 2))
+    labels, gradients, weights = _RenderAtDistances.apply(block.instances, origins, directions, distances,
+                                                          block.temperature, scalars, stride)
+    return _scatter_labels(labels, block), gradients, weights
+
+
+def render_hierarchical(distance_field, ray_positions, ray_directions, distance_range, num_samples, sdf_std_deviation,
+                        cosine_ratio=1.0, epsilon=1.0e-6, u_coarse=None, u_fine=None, seed=0, stream_offset=0,
+                        return_gradients=False, return_weights=False, return_uniforms=False, skip_exact_misses=False):
+    """Fused two-pass render.  Returns a dict: labels [R,N], distances [R,2S], optionally gradients
+    [R,2S-1,3], weights [R,2S-1], u_coarse/u_fine [R,S] (the uniforms actually used)."""
+    block = flatten(distance_field)
+    if block.mlp_weights is not None:
+        raise NotImplementedError("residual-MLP fields are not implemented in this round (SURVEY.md §8 row a9-a11)")
+    origins, directions, stride, _ = _prepare_rays(ray_positions, ray_directions)
+    if (u_coarse is None) != (u_fine is None):
+        raise ValueError("pass both u_coarse and u_fine, or neither (in-kernel Philox)")
+    if u_coarse is not None:
+        u_coarse = u_coarse.reshape(-1, num_samples).to(torch.float32).contiguous()
+        u_fine = u_fine.reshape(-1, num_samples).to(torch.float32).contiguous()
+    flags = _lib.FLAG_SKIP_EXACT_MISSES if skip_exact_misses else 0
+    scalars = (float(sdf_std_deviation), float(cosine_ratio), float(epsilon), float(distance_range[0]),
+               float(distance_range[1]), int(num_samples))
+    labels, gradients, weights, distances, uc, uf = _RenderHierarchical.apply(
+        block.instances, origins, directions, u_coarse, u_fine, block.temperature, scalars, stride,
+        int(seed), int(stream_offset), flags, bool(return_gradients), bool(return_weights), bool(return_uniforms))
+    out = dict(labels=_scatter_labels(labels, block), distances=distances)
+    if return_gradients:
+        out["gradients"] = gradients
+    if return_weights:
+        out["weights"] = weights
+    if return_uniforms:
+        out["u_coarse"], out["u_fine"] = uc, uf
+    return out
+
+
+def hierarchical_volumetric_rendering(
+    distance_field,
+    ray_positions,
+    ray_directions,
+    distance_range,
+    num_samples,
+    sdf_std_deviation,
+    cosine_ratio=1.0,
+    epsilon=1e-6,
+    sampled_distances=None,
+    sampled_weights=None,
+):
+    """Drop-in for vsrd.rendering.hierarchical_volumetric_rendering (renderers.py:177-270).
+
+    Returns ``(labels [...,N], sampled_gradients [S',...,3], sampled_distances [D,...,1],
+    sampled_weights [S',...,1])`` with the reference's sample-major shapes (permuted views of the
+    ray-major device buffers, just as the reference returns permuted views).
+    """
+    lib = _lib.load()
+    block = flatten(distance_field)
+    if block.mlp_weights is not None:
+        raise NotImplementedError("residual-MLP fields are not implemented in this round (SURVEY.md §8 row a9-a11)")
+    origins, directions, stride, lead = _prepare_rays(ray_positions, ray_directions)
+    R = directions.shape[0]
+    dev = directions.device
+    with torch.no_grad():
+        if sampled_distances is None:
+            # renderers.py:191-194 + samplers.py:5-8 (rand_like over [..., 1, S])
+            u_coarse = torch.rand(*lead, 1, num_samples, device=dev).reshape(R, num_samples)
+            distances = torch.empty(R, num_samples, dtype=torch.float32, device=dev)
+            config = _lib.make_config(R, num_samples, distance_range, sdf_std_deviation, cosine_ratio, epsilon, stride)
+            _lib.check(lib.vsrd_sample_stratified(config, _lib.ptr(u_coarse), _lib.ptr(distances), _lib.stream()))
+        else:
+            # renderers.py:198-210 + samplers.py:11-36 (rand over [..., 1, S], sorted)
+            coarse = sampled_distances.reshape(sampled_distances.shape[0], R).t().to(torch.float32).contiguous()
+            cweights = sampled_weights.reshape(sampled_weights.shape[0], R).t().to(torch.float32).contiguous()
+            if coarse.shape[1] != num_samples or cweights.shape[1] != num_samples - 1:
+                raise NotImplementedError("the importance pass expects num_samples coarse distances and num_samples-1 weights")
+            u_fine = torch.sort(torch.rand(*lead, 1, num_samples, device=dev), dim=-1).values.reshape(R, num_samples).contiguous()
+            distances = torch.empty(R, 2 * num_samples, dtype=torch.float32, device=dev)
+            config = _lib.make_config(R, num_samples, distance_range, sdf_std_deviation, cosine_ratio, epsilon, stride,
+                                      flags=_lib.FLAG_FINE_UNIFORMS_SORTED)
+            _lib.check(lib.vsrd_sample_importance(config, _lib.ptr(coarse), _lib.ptr(cweights), _lib.ptr(u_fine),
+                                                  _lib.ptr(distances), _lib.stream()))
+    scalars = (float(sdf_std_deviation), float(cosine_ratio), float(epsilon), float(distance_range[0]),
+               float(distance_range[1]), int(num_samples))
+    labels, gradients, weights = _RenderAtDistances.apply(block.instances, origins, directions, distances,
+                                                          block.temperature, scalars, stride)
+    labels = _scatter_labels(labels, block)
+    D = distances.shape[1]
+    return (
+        labels.reshape(*lead, -1),
+        gradients.reshape(*lead, D - 1, 3).movedim(-2, 0),
+        distances.reshape(*lead, D).movedim(-1, 0).unsqueeze(-1),
+        weights.reshape(*lead, D - 1).movedim(-1, 0).unsqueeze(-1),
+    )
+
+
+def evaluate_field(distance_field, positions, with_gradients=False, with_labels=None):
+    """What calling the reference closure does (main.py:477-509): soft union -> (distances [...,1], labels [...,N]);
+    hard union / plain sdfs -> distances [...,1].  ``with_gradients`` adds the analytic normal [...,3]."""
+    lib = _lib.load()
+    block = flatten(distance_field)
+    if block.mlp_weights is not None:
+        raise NotImplementedError("residual-MLP fields are not implemented in this round")
+    if with_labels is None:  # the soft union returns (distances, features); plain sdfs / hard unions distances only
+        with_labels = (not block.hard) and (isinstance(distance_field, SoftUnion) or "distance_fields" in _closure_vars(distance_field))
+    lead = positions.shape[:-1]
+    pts = positions.reshape(-1, 3).to(torch.float32).contiguous()
+    P, N = pts.shape[0], block.num_instances
+    distances = torch.empty(P, dtype=torch.float32, device=pts.device)
+    gradients = torch.empty(P, 3, dtype=torch.float32, device=pts.device) if with_gradients else None
+    labels = torch.empty(P, N, dtype=torch.float32, device=pts.device) if with_labels else None
+    field = _lib.make_field(block.instances.detach().contiguous(), block.temperature)
+    _lib.check(lib.vsrd_field_eval(field, _lib.ptr(pts), P, _lib.ptr(distances), _lib.ptr(gradients), _lib.ptr(labels),
+                                   1 if block.hard else 0, _lib.stream()))
+    out = [distances.reshape(*lead, 1)]
+    if with_labels:
+        out.append(_scatter_labels(labels, block).reshape(*lead, N))
+    if with_gradients:
+        out.append(gradients.reshape(*lead, 3))
+    return out[0] if len(out) == 1 else tuple(out)

@@ -1,0 +1,43 @@
+"""vsrd.rendering samplers (reference: vsrd/rendering/samplers.py:5-36) on the HIP library.
+
+The renderer does not call these (sampling is fused into the render kernels); they exist so the
+``vsrd.rendering`` call surface is complete and so the samplers can be tested in isolation.
+"""
+import torch
+
+from .. import _lib
+
+
+def quadrature_sampler(bins, deterministic=False):
+    """Stratified samples inside consecutive bins [..., S+1] -> [..., S].  Bins must be the linspace the
+    renderer uses (renderers.py:191-192): the kernel regenerates it from its two end points."""
+    lib = _lib.load()
+    S = bins.shape[-1] - 1
+    flat = bins.reshape(-1, S + 1)
+    near, far = float(flat[0, 0]), float(flat[0, -1])
+    expected = torch.linspace(near, far, S + 1, device=bins.device)
+    if not torch.equal(flat, expected.expand_as(flat)):
+        raise NotImplementedError("quadrature_sampler: only the renderer's linspace bins are supported")
+    u = torch.full(bins[..., :-1].shape, 0.5, device=bins.device) if deterministic else torch.rand_like(bins[..., :-1])
+    u = u.reshape(-1, S).to(torch.float32).contiguous()
+    out = torch.empty_like(u)
+    config = _lib.make_config(u.shape[0], S, (near, far), 1.0, 1.0, 1.0e-6, 3)
+    _lib.check(lib.vsrd_sample_stratified(config, _lib.ptr(u), _lib.ptr(out), _lib.stream()))
+    return out.reshape(bins[..., :-1].shape)
+
+
+def importance_merge(bins, weights, uniforms=None, sorted_uniforms=False):
+    """cat(bins, inverse_transform_sampler(bins, weights, S)) sorted (renderers.py:198-210): [...,S] -> [...,2S]."""
+    lib = _lib.load()
+    S = bins.shape[-1]
+    lead = bins.shape[:-1]
+    b = bins.reshape(-1, S).to(torch.float32).contiguous()
+    w = weights.reshape(-1, S - 1).to(torch.float32).contiguous()
+    if uniforms is None:
+        uniforms, sorted_uniforms = torch.sort(torch.rand(*lead, S, device=bins.device), dim=-1).values, True
+    u = uniforms.reshape(-1, S).to(torch.float32).contiguous()
+    out = torch.empty(b.shape[0], 2 * S, dtype=torch.float32, device=bins.device)
+    config = _lib.make_config(b.shape[0], S, (0.0, 1.0), 1.0, 1.0, 1.0e-6, 3,
+                              flags=_lib.FLAG_FINE_UNIFORMS_SORTED if sorted_uniforms else 0)
+    _lib.check(lib.vsrd_sample_importance(config, _lib.ptr(b), _lib.ptr(w), _lib.ptr(u), _lib.ptr(out), _lib.stream()))
+    return out.reshape(*lead, 2 * S)
