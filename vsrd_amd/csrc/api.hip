@@ -134,8 +134,9 @@ int32_t vsrd_field_eval(const vsrd_field* field, const float* positions, int64_t
 }
 
 int32_t vsrd_sample_stratified(const vsrd_render_config* config, const float* u_coarse, float* distances, void* stream) {
-    if (!valid_config(config) || !u_coarse || !distances) return VSRD_E_INVALID_ARGUMENT;
+    if (!valid_config(config)) return VSRD_E_INVALID_ARGUMENT;
     if (config->num_rays == 0) return VSRD_OK;
+    if (!u_coarse || !distances) return VSRD_E_INVALID_ARGUMENT;
     const size_t total = static_cast<size_t>(config->num_rays) * config->num_samples;
     const int blocks = static_cast<int>(std::min<size_t>((total + 255) / 256, 8192));
     hipLaunchKernelGGL(sample_stratified_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
@@ -145,8 +146,9 @@ int32_t vsrd_sample_stratified(const vsrd_render_config* config, const float* u_
 
 int32_t vsrd_sample_importance(const vsrd_render_config* config, const float* coarse_distances,
                                const float* coarse_weights, const float* u_fine, float* merged, void* stream) {
-    if (!valid_config(config) || !coarse_distances || !coarse_weights || !u_fine || !merged) return VSRD_E_INVALID_ARGUMENT;
+    if (!valid_config(config)) return VSRD_E_INVALID_ARGUMENT;
     if (config->num_rays == 0) return VSRD_OK;
+    if (!coarse_distances || !coarse_weights || !u_fine || !merged) return VSRD_E_INVALID_ARGUMENT;
     Geometry g;
     if (!plan(config->num_rays, wave_lds_floats(config->num_samples, 0), &g)) return VSRD_E_UNSUPPORTED;
     const RenderArgs c = render_args(config);
@@ -169,11 +171,11 @@ int32_t vsrd_render_forward(const vsrd_field* field, const vsrd_render_config* c
                             const float* origins, const float* directions,
                             const float* distances, int32_t num_distances,
                             float* labels, float* gradients, float* weights, void* stream) {
-    if (!valid_field(field) || !valid_config(config) || !origins || !directions || !distances || !labels ||
-        num_distances < 2 || num_distances > 2 * VSRD_MAX_SAMPLES)
+    if (!valid_field(field) || !valid_config(config) || num_distances < 2 || num_distances > 2 * VSRD_MAX_SAMPLES)
         return VSRD_E_INVALID_ARGUMENT;
+    if (config->num_rays == 0) return VSRD_OK;   // empty batch: buffers may be null
+    if (!origins || !directions || !distances || !labels) return VSRD_E_INVALID_ARGUMENT;
     if (field->mlp_weights != nullptr) return VSRD_E_UNSUPPORTED;
-    if (config->num_rays == 0) return VSRD_OK;
     Geometry g;
     if (!plan(config->num_rays, static_cast<size_t>(num_distances) + field->num_instances * kWave, &g)) return VSRD_E_UNSUPPORTED;
     const FieldArgs f = field_args(field);
@@ -203,9 +205,10 @@ int32_t vsrd_render_backward(const vsrd_field* field, const vsrd_render_config* 
                              const float* grad_labels, const float* grad_gradients, const float* grad_weights,
                              void* workspace, size_t workspace_bytes,
                              float* grad_instances, void* stream) {
-    if (!valid_field(field) || !valid_config(config) || !origins || !directions || !distances || !grad_labels ||
-        !grad_instances || !workspace || num_distances < 2 || num_distances > 2 * VSRD_MAX_SAMPLES)
+    if (!valid_field(field) || !valid_config(config) || !grad_instances || !workspace || num_distances < 2 ||
+        num_distances > 2 * VSRD_MAX_SAMPLES)
         return VSRD_E_INVALID_ARGUMENT;
+    if (config->num_rays > 0 && (!origins || !directions || !distances || !grad_labels)) return VSRD_E_INVALID_ARGUMENT;
     if (field->mlp_weights != nullptr) return VSRD_E_UNSUPPORTED;
     const int N = field->num_instances;
     if (workspace_bytes < vsrd_workspace_bytes(N)) return VSRD_E_WORKSPACE;
@@ -241,10 +244,11 @@ int32_t vsrd_render_hierarchical_forward(const vsrd_field* field, const vsrd_ren
                                          const float* u_coarse, const float* u_fine,
                                          float* labels, float* distances, float* gradients, float* weights,
                                          float* u_coarse_out, float* u_fine_out, void* stream) {
-    if (!valid_field(field) || !valid_config(config) || !origins || !directions || !labels) return VSRD_E_INVALID_ARGUMENT;
+    if (!valid_field(field) || !valid_config(config)) return VSRD_E_INVALID_ARGUMENT;
+    if (config->num_rays == 0) return VSRD_OK;   // empty batch: buffers may be null
+    if (!origins || !directions || !labels) return VSRD_E_INVALID_ARGUMENT;
     if (field->mlp_weights != nullptr) return VSRD_E_UNSUPPORTED;
     if ((config->flags & VSRD_FLAG_SKIP_EXACT_MISSES) && (gradients || weights)) return VSRD_E_INVALID_ARGUMENT;
-    if (config->num_rays == 0) return VSRD_OK;
     const int S = config->num_samples;
     Geometry g;
     if (!plan(config->num_rays, wave_lds_floats(S, field->num_instances), &g)) return VSRD_E_UNSUPPORTED;

@@ -17,7 +17,7 @@ hand-derived adjoint kernel (``vsrd_render_backward``); there is no PyTorch-op f
 """
 import torch
 
-from .. import _lib
+from .. import _lib, profiling
 from ..fields import FieldBlock, SoftUnion, flatten, _closure_vars
 
 _workspaces = {}
@@ -59,8 +59,9 @@ class _RenderAtDistances(torch.autograd.Function):
         weights = torch.empty(R, D - 1, dtype=torch.float32, device=distances.device)
         field = _lib.make_field(instances, temperature)
         config = _lib.make_config(R, num_samples, (near, far), std, ratio, eps, origin_stride)
-        _lib.check(lib.vsrd_render_forward(field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(distances), D,
-                                           _lib.ptr(labels), _lib.ptr(gradients), _lib.ptr(weights), _lib.stream()))
+        with profiling.timed("vsrd_render_forward"):
+            _lib.check(lib.vsrd_render_forward(field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(distances), D,
+                                               _lib.ptr(labels), _lib.ptr(gradients), _lib.ptr(weights), _lib.stream()))
         ctx.save_for_backward(instances, origins, directions, distances)
         ctx.meta = (temperature, scalars, origin_stride)
         ctx.set_materialize_grads(False)   # unused outputs arrive as None, not as zero tensors
@@ -88,9 +89,10 @@ def _backward(instances, origins, directions, distances, temperature, scalars, o
     workspace = _workspace(distances.device, N)
     field = _lib.make_field(instances, temperature)
     config = _lib.make_config(R, num_samples, (near, far), std, ratio, eps, origin_stride)
-    _lib.check(lib.vsrd_render_backward(field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(distances), D,
-                                        _lib.ptr(grad_labels), _lib.ptr(grad_gradients), _lib.ptr(grad_weights),
-                                        workspace.data_ptr(), workspace.numel(), _lib.ptr(grad_instances), _lib.stream()))
+    with profiling.timed("vsrd_render_backward"):
+        _lib.check(lib.vsrd_render_backward(field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(distances), D,
+                                            _lib.ptr(grad_labels), _lib.ptr(grad_gradients), _lib.ptr(grad_weights),
+                                            workspace.data_ptr(), workspace.numel(), _lib.ptr(grad_instances), _lib.stream()))
     return grad_instances
 
 
@@ -114,10 +116,11 @@ class _RenderHierarchical(torch.autograd.Function):
         uf_out = torch.empty(R, S, dtype=torch.float32, device=dev) if want_uniforms else None
         field = _lib.make_field(instances, temperature)
         config = _lib.make_config(R, S, (near, far), std, ratio, eps, origin_stride, seed, stream_offset, flags)
-        _lib.check(lib.vsrd_render_hierarchical_forward(
-            field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(u_coarse), _lib.ptr(u_fine),
-            _lib.ptr(labels), _lib.ptr(distances), _lib.ptr(gradients), _lib.ptr(weights),
-            _lib.ptr(uc_out), _lib.ptr(uf_out), _lib.stream()))
+        with profiling.timed("vsrd_render_hierarchical_forward"):
+            _lib.check(lib.vsrd_render_hierarchical_forward(
+                field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(u_coarse), _lib.ptr(u_fine),
+                _lib.ptr(labels), _lib.ptr(distances), _lib.ptr(gradients), _lib.ptr(weights),
+                _lib.ptr(uc_out), _lib.ptr(uf_out), _lib.stream()))
         ctx.save_for_backward(instances, origins, directions, distances)
         ctx.meta = (temperature, scalars, origin_stride)
         ctx.set_materialize_grads(False)
