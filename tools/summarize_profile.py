@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_bench.sh output directory into small text summaries for profiles/.
+
+  python tools/summarize_profile.py gpurun_out/prof_r01 profiles/r01
+"""
+import csv
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name.split("(")[0][:90]
+
+
+def kernel_stats(path, out):
+    with open(path) as f:
+        rows = list(csv.DictReader(f))
+    out.write(f"{'kernel':92s} {'calls':>6s} {'avg_ms':>10s} {'total_ms':>10s} {'pct':>7s}\n")
+    for r in rows[:12]:
+        out.write(f"{short(r['Name']):92s} {r['Calls']:>6s} {float(r['AverageNs']) / 1e6:10.3f} "
+                  f"{float(r['TotalDurationNs']) / 1e6:10.3f} {float(r['Percentage']):7.2f}\n")
+
+
+def counters(path, out, only=("render_", "sample_", "field_eval", "ray_directions", "reduce_partials", "project_")):
+    acc = defaultdict(lambda: defaultdict(list))
+    meta = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            name = short(r["Kernel_Name"])
+            if not any(k in name for k in only):
+                continue
+            acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta[name] = (r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"])
+    for name, cs in acc.items():
+        grid, wg, lds, vgpr, agpr, sgpr = meta[name]
+        out.write(f"{name}\n  grid={grid} workgroup={wg} lds_bytes={lds} vgpr={vgpr} agpr={agpr} sgpr={sgpr}\n")
+        for counter, values in sorted(cs.items()):
+            out.write(f"  {counter:28s} dispatches={len(values):3d} mean={sum(values) / len(values):.6g} last={values[-1]:.6g}\n")
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    os.makedirs(dst, exist_ok=True)
+    with open(os.path.join(dst, "kernel_stats.txt"), "w") as out:
+        out.write("# rocprofv3 --kernel-trace --stats (top kernels by total time)\n")
+        kernel_stats(os.path.join(src, "trace", "bench_kernel_stats.csv"), out)
+        log = os.path.join(src, "trace_stdout.log")
+        if os.path.exists(log):
+            for line in open(log):
+                if line.startswith("{\"metric\""):
+                    out.write("\n# bench.py line of the same run\n" + line)
+    with open(os.path.join(dst, "pmc_counters.txt"), "w") as out:
+        out.write("# rocprofv3 --pmc passes (one counter group per pass); values are per dispatch, summed over the chip.\n"
+                  "# FETCH_SIZE / WRITE_SIZE are in KiB (rocprofv3 derived metrics); MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half\n"
+                  "# the bytes of a wide coalesced read stream (uncalibrated for narrow accesses) -- treat as a lower bound.\n")
+        for sub in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write"):
+            path = os.path.join(src, sub, "bench_counter_collection.csv")
+            if os.path.exists(path):
+                out.write(f"\n## {sub}\n")
+                counters(path, out)
+
+
+if __name__ == "__main__":
+    main()

@@ -51,8 +51,6 @@ bool valid_config(const vsrd_render_config* c) {
 
 FieldArgs field_args(const vsrd_field* f) {
     FieldArgs a;
-    a.instances = f->instances;
-    a.mlp_weights = f->mlp_weights;
     a.num_instances = f->num_instances;
     a.inv_t = 1.0f / f->temperature;
     return a;
@@ -66,6 +64,7 @@ RenderArgs render_args(const vsrd_render_config* c) {
     a.far = c->distance_far;
     a.sh.inv_t = 0.0f;  // filled from the field
     a.sh.std = c->sdf_std_deviation;
+    a.sh.inv_std = 1.0f / c->sdf_std_deviation;
     a.sh.ratio = c->cosine_ratio;
     a.sh.eps = c->epsilon;
     a.origin_stride = c->origin_stride;
@@ -129,7 +128,7 @@ int32_t vsrd_field_eval(const vsrd_field* field, const float* positions, int64_t
     if (num_points == 0) return VSRD_OK;
     const int blocks = static_cast<int>(std::min<int64_t>((num_points + 255) / 256, 8192));
     hipLaunchKernelGGL(field_eval_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       field_args(field), positions, static_cast<long long>(num_points), distances, gradients, labels, hard_union);
+                       field_args(field), field->instances, positions, static_cast<long long>(num_points), distances, gradients, labels, hard_union);
     return launch_status();
 }
 
@@ -185,7 +184,7 @@ int32_t vsrd_render_forward(const vsrd_field* field, const vsrd_render_config* c
 #define VSRD_LAUNCH(K)                                                                                                       \
     do {                                                                                                                       \
         if (opt_in_lds(render_forward_kernel<K>, g.lds_bytes) != VSRD_OK) return VSRD_E_LAUNCH;                              \
-        hipLaunchKernelGGL(render_forward_kernel<K>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, c, origins,           \
+        hipLaunchKernelGGL(render_forward_kernel<K>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins,           \
                            directions, distances, num_distances, labels, gradients, weights);                                \
     } while (0)
     switch (rounds_for(num_distances - 1)) {
@@ -224,7 +223,7 @@ int32_t vsrd_render_backward(const vsrd_field* field, const vsrd_render_config* 
     c.sh.inv_t = f.inv_t;
     float* partials = static_cast<float*>(workspace);
 #define VSRD_LAUNCH(K)                                                                                                       \
-    hipLaunchKernelGGL(render_backward_kernel<K>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, c, origins, directions, \
+    hipLaunchKernelGGL(render_backward_kernel<K>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins, directions, \
                        distances, num_distances, grad_labels, grad_gradients, grad_weights, partials)
     switch (rounds_for(num_distances - 1)) {
         case 1: VSRD_LAUNCH(1); break;
@@ -259,7 +258,7 @@ int32_t vsrd_render_hierarchical_forward(const vsrd_field* field, const vsrd_ren
 #define VSRD_LAUNCH(K)                                                                                                       \
     do {                                                                                                                       \
         if (opt_in_lds(render_hierarchical_kernel<K>, g.lds_bytes) != VSRD_OK) return VSRD_E_LAUNCH;                         \
-        hipLaunchKernelGGL(render_hierarchical_kernel<K>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, c, origins,      \
+        hipLaunchKernelGGL(render_hierarchical_kernel<K>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins,      \
                            directions, u_coarse, u_fine, labels, distances, gradients, weights, u_coarse_out, u_fine_out);   \
     } while (0)
     switch (rounds_for(2 * S - 1)) {

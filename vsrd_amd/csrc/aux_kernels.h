@@ -30,7 +30,8 @@ __global__ __launch_bounds__(256) void ray_directions_kernel(const float* __rest
 
 // The distance_field closure evaluated at arbitrary points (main.py:477-509) plus its analytic normal.
 // One thread per point; the instance loop is still wave-uniform (scalar parameter loads).
-__global__ __launch_bounds__(256) void field_eval_kernel(FieldArgs f, const float* __restrict__ positions, long long num_points,
+__global__ __launch_bounds__(256) void field_eval_kernel(FieldArgs f, const float* __restrict__ instances,
+                                                         const float* __restrict__ positions, long long num_points,
                                                          float* __restrict__ distances, float* __restrict__ gradients,
                                                          float* __restrict__ labels, int hard_union) {
     for (long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; idx < num_points;
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void field_eval_kernel(FieldArgs f, const floa
         if (hard_union) {
             float best = 3.0e38f, bx = 0.0f, by = 0.0f, bz = 0.0f;
             for (int i = 0; i < f.num_instances; ++i) {
-                const BoxEval e = eval_box(load_instance(f.instances, i), x, y, z);
+                const BoxEval e = eval_box(load_instance(instances, i), x, y, z);
                 if (e.d < best) { best = e.d; bx = e.gwx; by = e.gwy; bz = e.gwz; }   // argmin: first minimum
             }
             if (distances) distances[idx] = best;
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void field_eval_kernel(FieldArgs f, const floa
         }
         UnionSums sums = union_init();
         for (int i = 0; i < f.num_instances; ++i) {
-            const BoxEval e = eval_box(load_instance(f.instances, i), x, y, z);
+            const BoxEval e = eval_box(load_instance(instances, i), x, y, z);
             union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, 0.0f, f.inv_t);
         }
         const UnionValue v = union_finish(sums, f.inv_t);
@@ -56,8 +57,8 @@ __global__ __launch_bounds__(256) void field_eval_kernel(FieldArgs f, const floa
         if (gradients) { gradients[idx * 3 + 0] = v.gx; gradients[idx * 3 + 1] = v.gy; gradients[idx * 3 + 2] = v.gz; }
         if (labels) {
             for (int i = 0; i < f.num_instances; ++i) {
-                const BoxEval e = eval_box(load_instance(f.instances, i), x, y, z);
-                labels[idx * f.num_instances + i] = expf(-(e.d - v.m) * f.inv_t) * v.inv_z;
+                const BoxEval e = eval_box(load_instance(instances, i), x, y, z);
+                labels[idx * f.num_instances + i] = fast_exp(-(e.d - v.m) * f.inv_t) * v.inv_z;
             }
         }
     }

@@ -55,13 +55,13 @@ __device__ __forceinline__ BoxEval eval_box(const Instance& in, float x, float y
     e.pz = e.relx * in.r02 + e.rely * in.r12 + e.relz * in.r22;
     e.qx = fabsf(e.px) - in.dx; e.qy = fabsf(e.py) - in.dy; e.qz = fabsf(e.pz) - in.dz;
     const float ax = fmaxf(e.qx, 0.0f), ay = fmaxf(e.qy, 0.0f), az = fmaxf(e.qz, 0.0f);
-    e.nrm = sqrtf(ax * ax + ay * ay + az * az + kNormEpsilon);
+    e.nrm = fast_sqrt(ax * ax + ay * ay + az * az + kNormEpsilon);
     // torch.max returns the first maximal index; its backward routes to that index.
     float qmax = e.qx; int arg = 0;
     if (e.qy > qmax) { qmax = e.qy; arg = 1; }
     if (e.qz > qmax) { qmax = e.qz; arg = 2; }
     e.d = e.nrm - fmaxf(-qmax, 0.0f);
-    const float inv = 1.0f / e.nrm;
+    const float inv = fast_rcp(e.nrm);
     const float inside = (qmax < 0.0f) ? 1.0f : 0.0f;
     e.hx = ax * inv + ((arg == 0) ? inside : 0.0f);
     e.hy = ay * inv + ((arg == 1) ? inside : 0.0f);
@@ -96,7 +96,7 @@ __device__ __forceinline__ void union_accumulate(UnionSums& s, float d, float gw
     // One exponential per instance: either the old sums are rescaled (new minimum) or the new term is.
     const bool lower = d < s.m;
     const float gap = lower ? (s.m - d) : (d - s.m);           // >= 0
-    const float ex = expf(-gap * inv_t);
+    const float ex = fast_exp(-gap * inv_t);
     const float scale = lower ? ex : 1.0f;                      // multiplies the old sums
     const float e = lower ? 1.0f : ex;                          // weight of the new term
     const float shift = lower ? gap : 0.0f;                     // old (d_j - m) grow by the drop of m
@@ -124,7 +124,7 @@ struct UnionValue {
 __device__ __forceinline__ UnionValue union_finish(const UnionSums& s, float inv_t) {
     UnionValue v;
     v.m = s.m;
-    v.inv_z = 1.0f / s.Z;
+    v.inv_z = fast_rcp(s.Z);
     v.us = s.S1 * v.inv_z;
     v.u = s.m + v.us;
     v.b0x = s.g0x * v.inv_z; v.b0y = s.g0y * v.inv_z; v.b0z = s.g0z * v.inv_z;

@@ -18,6 +18,7 @@ struct Ray { float ox, oy, oz, rx, ry, rz; };
 struct Shading {
     float inv_t;    // 1 / soft-union temperature
     float std;      // sdf_std_deviation
+    float inv_std;  // 1 / sdf_std_deviation
     float ratio;    // cosine_ratio
     float eps;      // epsilon (opacity denominator)
 };
@@ -34,7 +35,7 @@ __device__ __forceinline__ float torch_linspace(float start, float end, int step
     return (i < steps / 2) ? (start + step * static_cast<float>(i)) : (end - step * static_cast<float>(steps - i - 1));
 }
 
-__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sigmoidf(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
 
 // NeuS section-point opacity, renderers.py:228-248, with every intermediate the adjoint needs.
 struct Opacity {
@@ -49,17 +50,17 @@ struct Opacity {
 
 __device__ __forceinline__ Opacity opacity_of(const UnionValue& v, const Ray& ray, float delta, const Shading& sh) {
     Opacity o;
-    const float gn = sqrtf(v.gx * v.gx + v.gy * v.gy + v.gz * v.gz);
-    o.inv_gn = 1.0f / fmaxf(gn, 1.0e-12f);                       // F.normalize eps
+    const float gn = fast_sqrt(v.gx * v.gx + v.gy * v.gy + v.gz * v.gz);
+    o.inv_gn = fast_rcp(fmaxf(gn, 1.0e-12f));                       // F.normalize eps
     o.nx = v.gx * o.inv_gn; o.ny = v.gy * o.inv_gn; o.nz = v.gz * o.inv_gn;
     o.cosine = ray.rx * o.nx + ray.ry * o.ny + ray.rz * o.nz;
     const float a = fmaxf(-o.cosine * 0.5f + 0.5f, 0.0f);
     const float b = fmaxf(-o.cosine, 0.0f);
     o.cprime = -torch_lerp(a, b, sh.ratio);
     const float half = o.cprime * delta / 2.0f;
-    o.phi_p = sigmoidf((v.u - half) / sh.std);
-    o.phi_n = sigmoidf((v.u + half) / sh.std);
-    o.xx = (o.phi_p - o.phi_n) / (o.phi_p + sh.eps);
+    o.phi_p = sigmoidf((v.u - half) * sh.inv_std);
+    o.phi_n = sigmoidf((v.u + half) * sh.inv_std);
+    o.xx = (o.phi_p - o.phi_n) * fast_rcp(o.phi_p + sh.eps);
     o.alpha = fmaxf(o.xx, 0.0f);
     return o;
 }
@@ -116,7 +117,7 @@ __device__ __forceinline__ float render_pass(const float* __restrict__ instances
         if (kLabels) {
             const float scale = w * v.inv_z;
             for (int i = 0; i < num_instances; ++i) {
-                const float e = expf(-(dcache[i * kWave + lane] - v.m) * sh.inv_t) * scale;
+                const float e = fast_exp(-(dcache[i * kWave + lane] - v.m) * sh.inv_t) * scale;
                 const float total = wave_sum(e);
                 label_acc = (lane == i) ? (label_acc + total) : label_acc;
             }

@@ -11,9 +11,10 @@ constexpr int kBlockThreads = kMaxWavesPerBlock * kWave;   // launch bound; the 
 __device__ __forceinline__ int waves_per_block() { return static_cast<int>(blockDim.x) >> 6; }
 constexpr int kGradStride = kInstanceStride;   // grad_instances rows are [t(3) R(9) dim(3) pad]
 
+// The instance block [N,16] travels as its own `const float* __restrict__` kernel argument (not inside this
+// struct): only then does the compiler prove the uniform loads in the instance loops are not clobbered by the
+// kernel's stores and select SMEM (s_load_dwordx8/x4) instead of VMEM for them.
 struct FieldArgs {
-    const float* __restrict__ instances;   // [N,16]
-    const float* __restrict__ mlp_weights; // [N,1617] or nullptr
     int num_instances;
     float inv_t;
 };
@@ -43,7 +44,7 @@ __device__ __forceinline__ Ray load_ray(const float* __restrict__ origins, const
 // ---------------------------------------------------------------------------------------------------
 template <int kRounds>
 __global__ __launch_bounds__(kBlockThreads) void render_forward_kernel(
-    FieldArgs f, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
+    FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
     const float* __restrict__ distances, int num_distances,
     float* __restrict__ labels, float* __restrict__ gradients, float* __restrict__ weights) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_forward_kernel(
         float w[kRounds];
         float* g_out = gradients ? gradients + static_cast<size_t>(ray) * (num_distances - 1) * 3 : nullptr;
         float* w_out = weights ? weights + static_cast<size_t>(ray) * (num_distances - 1) : nullptr;
-        const float label = render_pass<kRounds, true>(f.instances, f.num_instances, c.sh, r, dist, num_distances, dcache, w, g_out, w_out);
+        const float label = render_pass<kRounds, true>(instances, f.num_instances, c.sh, r, dist, num_distances, dcache, w, g_out, w_out);
         if (lane < f.num_instances) labels[static_cast<size_t>(ray) * f.num_instances + lane] = label;
         wave_lds_sync();
     }
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_forward_kernel(
 // ---------------------------------------------------------------------------------------------------
 template <int kRounds>
 __global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
-    FieldArgs f, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
+    FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
     const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
     float* __restrict__ labels, float* __restrict__ distances, float* __restrict__ gradients, float* __restrict__ weights,
     float* __restrict__ u_coarse_out, float* __restrict__ u_fine_out) {
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
         }
         // ---- pass 1: coarse weights only (no labels, no outputs) ----------------------------------
         float w1[kRoundsS];
-        render_pass<kRoundsS, false>(f.instances, f.num_instances, c.sh, r, l.coarse, S, l.dcache, w1, nullptr, nullptr);
+        render_pass<kRoundsS, false>(instances, f.num_instances, c.sh, r, l.coarse, S, l.dcache, w1, nullptr, nullptr);
         if (c.flags & 2u) {
             float total = 0.0f;
 #pragma unroll
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
         const int D = 2 * S;
         float* g_out = gradients ? gradients + static_cast<size_t>(ray) * (D - 1) * 3 : nullptr;
         float* w_out = weights ? weights + static_cast<size_t>(ray) * (D - 1) : nullptr;
-        const float label = render_pass<kRounds, true>(f.instances, f.num_instances, c.sh, r, l.merged, D, l.dcache, w2, g_out, w_out);
+        const float label = render_pass<kRounds, true>(instances, f.num_instances, c.sh, r, l.merged, D, l.dcache, w2, g_out, w_out);
         if (lane < f.num_instances) labels[static_cast<size_t>(ray) * f.num_instances + lane] = label;
         if (distances != nullptr) {
             float* dst = distances + static_cast<size_t>(ray) * D;
@@ -163,7 +164,7 @@ struct SampleAdjoint {
 
 template <int kRounds>
 __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
-    FieldArgs f, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
+    FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
     const float* __restrict__ distances, int num_distances,
     const float* __restrict__ grad_labels, const float* __restrict__ grad_gradients, const float* __restrict__ grad_weights,
     float* __restrict__ partials) {
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
             sa[k].x = r.ox + r.rx * mid; sa[k].y = r.oy + r.ry * mid; sa[k].z = r.oz + r.rz * mid;
             UnionSums sums = union_init();
             for (int i = 0; i < N; ++i) {
-                const Instance in = load_instance(f.instances, i);
+                const Instance in = load_instance(instances, i);
                 const BoxEval e = eval_box(in, sa[k].x, sa[k].y, sa[k].z);
                 union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lam[i], inv_t);
             }
@@ -240,13 +241,13 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
             const float Q = suffix_inclusive - contrib + suffix_carry;          // sum over later samples
             suffix_carry += read_lane(rev_inclusive, kWave - 1);
             const float alpha = op[k].alpha;
-            const float alpha_bar = w_bar * trans[k] - Q / (1.0f - alpha);
+            const float alpha_bar = w_bar * trans[k] - Q * fast_rcp(1.0f - alpha);
             const float x_bar = (valid && op[k].xx > 0.0f) ? alpha_bar : 0.0f;
-            const float pe = op[k].phi_p + sh.eps;
-            const float phi_p_bar = x_bar * (op[k].phi_n + sh.eps) / (pe * pe);
-            const float phi_n_bar = -x_bar / pe;
-            const float sp_bar = phi_p_bar * op[k].phi_p * (1.0f - op[k].phi_p) / sh.std;
-            const float sn_bar = phi_n_bar * op[k].phi_n * (1.0f - op[k].phi_n) / sh.std;
+            const float inv_pe = fast_rcp(op[k].phi_p + sh.eps);
+            const float phi_p_bar = x_bar * (op[k].phi_n + sh.eps) * inv_pe * inv_pe;
+            const float phi_n_bar = -x_bar * inv_pe;
+            const float sp_bar = phi_p_bar * op[k].phi_p * (1.0f - op[k].phi_p) * sh.inv_std;
+            const float sn_bar = phi_n_bar * op[k].phi_n * (1.0f - op[k].phi_n) * sh.inv_std;
             const float u_bar = sp_bar + sn_bar;
             const float cprime_bar = (sn_bar - sp_bar) * delta[k] / 2.0f;
             const float slope = (1.0f - sh.ratio) * ((0.5f - 0.5f * op[k].cosine > 0.0f) ? 0.5f : 0.0f)
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
 
         // ---- phase B: per instance, adjoint of (d_i, grad d_i) w.r.t. (t, R, dim) -------------------
         for (int i = 0; i < N; ++i) {
-            const Instance in = load_instance(f.instances, i);
+            const Instance in = load_instance(instances, i);
             const float lam_i = lam[i];
             float at0 = 0, at1 = 0, at2 = 0, ad0 = 0, ad1 = 0, ad2 = 0;
             float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
                 if (k * kWave >= num_points) continue;
                 const BoxEval e = eval_box(in, sa[k].x, sa[k].y, sa[k].z);
                 const float ds = e.d - sa[k].m;
-                const float w = expf(-ds * inv_t) * sa[k].inv_z;
+                const float w = fast_exp(-ds * inv_t) * sa[k].inv_z;
                 const float cc = w * (1.0f - (ds - sa[k].us) * inv_t);
                 const float beta = sa[k].gbx * e.gwx + sa[k].gby * e.gwy + sa[k].gbz * e.gwz;
                 const float d_bar = sa[k].u_bar * cc
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
                 const float glbz = in.r02 * gwbx + in.r12 * gwby + in.r22 * gwbz;
                 const float sx = sign_of(e.px), sy = sign_of(e.py), sz = sign_of(e.pz);
                 const float vx = sx * glbx, vy = sy * glby, vz = sz * glbz;
-                const float inv_n = 1.0f / e.nrm;
+                const float inv_n = fast_rcp(e.nrm);
                 const float hx = fmaxf(e.qx, 0.0f) * inv_n, hy = fmaxf(e.qy, 0.0f) * inv_n, hz = fmaxf(e.qz, 0.0f) * inv_n;
                 const float hv = hx * vx + hy * vy + hz * vz;
                 const float qbx = d_bar * e.hx + ((e.qx > 0.0f) ? (vx - hx * hv) * inv_n : 0.0f);

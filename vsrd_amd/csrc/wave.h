@@ -95,6 +95,21 @@ __device__ __forceinline__ float wave_shift_up(float v, float first, int lane) {
 }
 __device__ __forceinline__ float wave_reverse(float v, int lane) { return __shfl(v, kWave - 1 - lane, kWave); }
 
+// ---- fast fp32 math -----------------------------------------------------------------------------------
+// One hardware transcendental each (v_rcp_f32 / v_sqrt_f32 / v_exp_f32, <= 1 ulp) instead of the
+// correctly-rounded expansions (~10 instructions for a division).  The reference tolerance is 1e-4 on the
+// silhouettes (BASELINE.json), five orders of magnitude above what these change; VSRD_PRECISE_MATH=1
+// restores the IEEE sequences for A/B runs.
+#ifndef VSRD_PRECISE_MATH
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+#else
+__device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
+__device__ __forceinline__ float fast_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ float fast_exp(float x) { return expf(x); }
+#endif
+
 // ---- Philox4x32-10 (counter-based; the same generator family torch uses on device) --------------
 struct Philox4 { uint32_t x, y, z, w; };
 
