@@ -71,6 +71,9 @@ typedef struct vsrd_render_config {
                                              labels = 0 (exact); distances/gradients/weights of such
                                              rays are NOT produced (fused-loss mode only)        */
 
+#define VSRD_FLAG_NO_CULLING 4u           /* evaluate every instance at every sample (A/B switch for the
+                                             conservative soft-min culling described in DESIGN.md)        */
+
 int32_t vsrd_abi_version(void);
 const char* vsrd_error_string(int32_t code);
 

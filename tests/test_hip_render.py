@@ -58,7 +58,7 @@ def test_wave_primitives(dev):
     fn = lib.vsrd_selftest_wave
     fn.restype, fn.argtypes = ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     v = torch.randn(64, generator=torch.Generator().manual_seed(1))
-    out = torch.zeros(512, device=dev)
+    out = torch.zeros(576, device=dev)
     _lib.check(fn(_lib.ptr(v.to(dev)), _lib.ptr(out), _lib.stream()))
     out = out.cpu()
     v64 = v.double()
@@ -71,6 +71,8 @@ def test_wave_primitives(dev):
     u = out[384:448]
     assert torch.all((u >= 0) & (u < 1)) and u.unique().numel() > 60
     assert torch.equal(out[448:512], torch.linspace(0.0, 100.0, 65)[:64])
+    j = torch.arange(64) % 16
+    torch.testing.assert_close(out[512:576], (v64.sum() * (j + 1) + 64.0 * j).float(), rtol=1e-5, atol=1e-4)
 
 
 def test_ray_casting_g1(dev):
@@ -232,6 +234,33 @@ def test_skip_exact_misses_is_exact(dev):
     lam = torch.randn(full.shape, generator=torch.Generator().manual_seed(3)).to(dev)
     for a, b in zip(torch.autograd.grad((full * lam).sum(), params), torch.autograd.grad((fast * lam).sum(), params)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["g4_render_n16_s64_mid", "g4_render_n4_s32_late", "g4_render_n4_s32_step0"])
+def test_culling_is_invisible(dev, name):
+    """Conservative soft-min culling (weights < exp(-18) skipped wave-uniformly) against evaluating every instance."""
+    from vsrd_amd import rendering
+    from vsrd_amd.rendering import renderers
+    g = load_golden(name)
+    S = int(g["num_samples"])
+    std, ratio = float(g["sdf_std_deviation"]), float(g["cosine_ratio"])
+    results = {}
+    for culling in (True, False):
+        renderers.CULLING = culling
+        try:
+            union, params = hip_union(g, dev, requires_grad=True)
+            out = rendering.render_hierarchical(union, g["origins"].to(dev), g["directions"].to(dev), (0.0, 100.0), S, std, ratio,
+                                                u_coarse=g["u_coarse"].to(dev), u_fine=g["u_fine"].to(dev), return_gradients=True)
+            lam = torch.randn(out["labels"].shape, generator=torch.Generator().manual_seed(2)).to(dev)
+            gam = (torch.randn(out["gradients"].shape, generator=torch.Generator().manual_seed(3)) * 0.01).to(dev)
+            hit = (g["coarse_weights"].sum(0) > 0).to(dev)
+            loss = (out["labels"] * lam).sum() + (out["gradients"][hit] * gam[hit]).sum()
+            results[culling] = (out["labels"].detach(), torch.autograd.grad(loss, params))
+        finally:
+            renderers.CULLING = True
+    assert (results[True][0] - results[False][0]).abs().max() < 1e-6
+    for a, b in zip(results[True][1], results[False][1]):
+        assert (a - b).abs().max() <= 1e-4 * max(float(b.abs().max()), 1e-6)
 
 
 def test_single_origin_and_leading_dims(dev):

@@ -20,6 +20,7 @@ INSTANCE_STRIDE = 16
 MLP_WEIGHTS = 1617
 FLAG_FINE_UNIFORMS_SORTED = 1
 FLAG_SKIP_EXACT_MISSES = 2
+FLAG_NO_CULLING = 4
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 

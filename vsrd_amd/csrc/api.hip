@@ -63,6 +63,7 @@ RenderArgs render_args(const vsrd_render_config* c) {
     a.near = c->distance_near;
     a.far = c->distance_far;
     a.sh.inv_t = 0.0f;  // filled from the field
+    a.sh.cull = 0.0f;   // computed in-kernel (field.h: cull_margin)
     a.sh.std = c->sdf_std_deviation;
     a.sh.inv_std = 1.0f / c->sdf_std_deviation;
     a.sh.ratio = c->cosine_ratio;
@@ -275,7 +276,7 @@ int32_t vsrd_render_hierarchical_forward(const vsrd_field* field, const vsrd_ren
 // Not part of the public header: exercised by tests/test_hip_wave.py.
 int32_t vsrd_selftest_wave(const float* in64, float* out512, void* stream) {
     if (!in64 || !out512) return VSRD_E_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(wave_selftest_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), in64, out512);
+    hipLaunchKernelGGL(wave_selftest_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), in64, out512);  // writes 576 floats
     return launch_status();
 }
 

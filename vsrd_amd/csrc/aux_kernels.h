@@ -127,6 +127,10 @@ __global__ void wave_selftest_kernel(const float* __restrict__ in, float* __rest
     const Philox4 r = philox4x32_10(static_cast<uint32_t>(lane), 1u, 2u, 3u, 0xdeadbeefu, 0x12345678u);
     out[384 + lane] = uniform_from_bits(r.x);
     out[448 + lane] = torch_linspace(0.0f, 100.0f, 65, lane);
+    float many[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) many[j] = v * static_cast<float>(j + 1) + static_cast<float>(j);
+    out[512 + lane] = wave_reduce16_scatter(many, lane);   // lane l: sum over lanes of many[l & 15]
 }
 
 }  // namespace vsrd

@@ -74,6 +74,35 @@ __device__ __forceinline__ BoxEval eval_box(const Instance& in, float x, float y
     return e;
 }
 
+// ---- conservative instance culling -------------------------------------------------------------------
+// For a sample x, instance i's soft-min weight relative to the best instance is at most
+//   exp(-(LB_i - UB) / T),  LB_i = |x - t_i| (1 - k) - |dim_i|  <=  d_i(x),   UB = min_j |x - t_j| (1 + k) + 1e-3  >=  min_j d_j(x)
+// (a box lies inside its circumscribed sphere and contains its centre; k = 2e-4 absorbs rotation matrices that are
+// orthonormal only to ~1e-4).  When LB_i - UB > tau T on EVERY lane of the wave the instance is skipped for that round:
+// with tau = 18 its weight is below exp(-18) = 1.5e-8 < 2^-24, i.e. below half an ulp of the soft-min normaliser.
+// The decision is wave-uniform (one ballot), so a skipped instance costs ~14 instructions instead of ~120.
+constexpr float kCullTau = 18.0f;
+constexpr float kCullSlack = 2.0e-4f;
+
+__device__ __forceinline__ float centre_distance(const Instance& in, float x, float y, float z) {
+    const float rx = x - in.tx, ry = y - in.ty, rz = z - in.tz;
+    return fast_sqrt(rx * rx + ry * ry + rz * rz);
+}
+__device__ __forceinline__ float bounding_radius(const Instance& in) { return fast_sqrt(in.dx * in.dx + in.dy * in.dy + in.dz * in.dz); }
+
+// tau * T + slack, or +huge (culling off) when some rotation matrix is not orthonormal to 1e-4.
+__device__ __forceinline__ float cull_margin(const float* __restrict__ instances, int num_instances, float inv_t) {
+    float worst = 0.0f;
+    for (int i = 0; i < num_instances; ++i) {
+        const Instance in = load_instance(instances, i);
+        const float g00 = in.r00 * in.r00 + in.r10 * in.r10 + in.r20 * in.r20, g11 = in.r01 * in.r01 + in.r11 * in.r11 + in.r21 * in.r21;
+        const float g22 = in.r02 * in.r02 + in.r12 * in.r12 + in.r22 * in.r22, g01 = in.r00 * in.r01 + in.r10 * in.r11 + in.r20 * in.r21;
+        const float g02 = in.r00 * in.r02 + in.r10 * in.r12 + in.r20 * in.r22, g12 = in.r01 * in.r02 + in.r11 * in.r12 + in.r21 * in.r22;
+        worst = fmaxf(worst, fmaxf(fmaxf(fabsf(g00 - 1.0f), fabsf(g11 - 1.0f)), fmaxf(fabsf(g22 - 1.0f), fmaxf(fabsf(g01), fmaxf(fabsf(g02), fabsf(g12))))));
+    }
+    return (worst < 1.0e-4f) ? (kCullTau / inv_t + 2.0e-3f) : 3.0e38f;
+}
+
 // Online soft-min over the instances, with the running minimum as the shift so that neither the
 // exponentials nor the (d_i - u)/T factor of the union gradient lose digits at small temperature.
 //   e_i = exp(-(d_i - m)/T), Z = sum e_i, S1 = sum e_i (d_i - m),

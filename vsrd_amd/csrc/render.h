@@ -17,6 +17,7 @@ struct Ray { float ox, oy, oz, rx, ry, rz; };
 
 struct Shading {
     float inv_t;    // 1 / soft-union temperature
+    float cull;     // culling margin (field.h), wave-uniform; +huge disables culling
     float std;      // sdf_std_deviation
     float inv_std;  // 1 / sdf_std_deviation
     float ratio;    // cosine_ratio
@@ -65,18 +66,42 @@ __device__ __forceinline__ Opacity opacity_of(const UnionValue& v, const Ray& ra
     return o;
 }
 
+// Culling pre-pass (field.h): writes the per-instance lower bounds into dcache[i][lane] and returns this lane's
+// threshold; instance i is negligible for the whole round iff  dcache[i][lane] > threshold  on every lane.
+__device__ __forceinline__ float cull_prepass(const float* __restrict__ instances, int num_instances, float margin,
+                                              float x, float y, float z, float* dcache, int lane) {
+    float nearest = 3.0e38f;
+    for (int i = 0; i < num_instances; ++i) {
+        const Instance in = load_instance(instances, i);
+        const float dist = centre_distance(in, x, y, z);
+        dcache[i * kWave + lane] = dist * (1.0f - kCullSlack) - bounding_radius(in);
+        nearest = fminf(nearest, dist);
+    }
+    return nearest * (1.0f + kCullSlack) + margin;
+}
+
+__device__ __forceinline__ bool wave_any(bool pred) { return __ballot(pred) != 0ull; }
+
 // Evaluate the union at one point: a uniform loop over the instances with scalar parameter loads.
+// `lam` (LDS, or nullptr) are the per-instance label adjoints accumulated into sums.L by the backward.
+// On return dcache[i][lane] holds d_i for evaluated instances (a value > threshold on all lanes marks a culled one).
 template <bool kCacheDistances>
-__device__ __forceinline__ UnionValue eval_union(const float* __restrict__ instances, int num_instances, float inv_t,
-                                                 float x, float y, float z, float* dcache, int lane) {
+__device__ __forceinline__ UnionValue eval_union(const float* __restrict__ instances, int num_instances, const Shading& sh,
+                                                 float x, float y, float z, float* dcache, int lane, const float* lam,
+                                                 float* threshold_out, float* lam_z_out) {
+    const float threshold = cull_prepass(instances, num_instances, sh.cull, x, y, z, dcache, lane);
     UnionSums sums = union_init();
     for (int i = 0; i < num_instances; ++i) {
+        if (!wave_any(dcache[i * kWave + lane] <= threshold)) continue;        // wave-uniform skip
         const Instance in = load_instance(instances, i);
         const BoxEval e = eval_box(in, x, y, z);
         if (kCacheDistances) dcache[i * kWave + lane] = e.d;
-        union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, 0.0f, inv_t);
+        union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, sh.inv_t);
     }
-    return union_finish(sums, inv_t);
+    const UnionValue v = union_finish(sums, sh.inv_t);
+    if (threshold_out) *threshold_out = threshold;
+    if (lam_z_out) *lam_z_out = sums.L * v.inv_z;
+    return v;
 }
 
 // Render the D-1 interval mid-points of the sorted distances `dist` (LDS, wave-private).
@@ -102,7 +127,8 @@ __device__ __forceinline__ float render_pass(const float* __restrict__ instances
         const float delta = d1 - d0;
         const float mid = (d0 + d1) / 2.0f;
         const float x = ray.ox + ray.rx * mid, y = ray.oy + ray.ry * mid, z = ray.oz + ray.rz * mid;
-        const UnionValue v = eval_union<kLabels>(instances, num_instances, sh.inv_t, x, y, z, dcache, lane);
+        float threshold;
+        const UnionValue v = eval_union<kLabels>(instances, num_instances, sh, x, y, z, dcache, lane, nullptr, &threshold, nullptr);
         const Opacity op = opacity_of(v, ray, delta, sh);
         const float alpha = valid ? op.alpha : 0.0f;
         const float inclusive = wave_inclusive_product(1.0f - alpha);
@@ -117,7 +143,9 @@ __device__ __forceinline__ float render_pass(const float* __restrict__ instances
         if (kLabels) {
             const float scale = w * v.inv_z;
             for (int i = 0; i < num_instances; ++i) {
-                const float e = fast_exp(-(dcache[i * kWave + lane] - v.m) * sh.inv_t) * scale;
+                const float di = dcache[i * kWave + lane];
+                if (!wave_any(di <= threshold)) continue;                       // culled: weight < exp(-18)
+                const float e = fast_exp(-(di - v.m) * sh.inv_t) * scale;
                 const float total = wave_sum(e);
                 label_acc = (lane == i) ? (label_acc + total) : label_acc;
             }

@@ -53,6 +53,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_forward_kernel(
     const int per_wave = num_distances + f.num_instances * kWave;
     float* dist = lds + wave * per_wave;
     float* dcache = dist + num_distances;
+    Shading sh = c.sh;
+    sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, f.num_instances, f.inv_t);
     const int stride = static_cast<int>(gridDim.x) * waves_per_block();
     for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
         const Ray r = load_ray(origins, directions, c.origin_stride, ray);
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_forward_kernel(
         float w[kRounds];
         float* g_out = gradients ? gradients + static_cast<size_t>(ray) * (num_distances - 1) * 3 : nullptr;
         float* w_out = weights ? weights + static_cast<size_t>(ray) * (num_distances - 1) : nullptr;
-        const float label = render_pass<kRounds, true>(instances, f.num_instances, c.sh, r, dist, num_distances, dcache, w, g_out, w_out);
+        const float label = render_pass<kRounds, true>(instances, f.num_instances, sh, r, dist, num_distances, dcache, w, g_out, w_out);
         if (lane < f.num_instances) labels[static_cast<size_t>(ray) * f.num_instances + lane] = label;
         wave_lds_sync();
     }
@@ -84,6 +86,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
     const int S = c.num_samples;
     const WaveLds l = carve_lds(lds + wave * wave_lds_floats(S, f.num_instances), S);
     const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
+    Shading sh = c.sh;
+    sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, f.num_instances, f.inv_t);
     const int stride = static_cast<int>(gridDim.x) * waves_per_block();
     for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
         const Ray r = load_ray(origins, directions, c.origin_stride, ray);
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
         }
         // ---- pass 1: coarse weights only (no labels, no outputs) ----------------------------------
         float w1[kRoundsS];
-        render_pass<kRoundsS, false>(instances, f.num_instances, c.sh, r, l.coarse, S, l.dcache, w1, nullptr, nullptr);
+        render_pass<kRoundsS, false>(instances, f.num_instances, sh, r, l.coarse, S, l.dcache, w1, nullptr, nullptr);
         if (c.flags & 2u) {
             float total = 0.0f;
 #pragma unroll
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
         const int D = 2 * S;
         float* g_out = gradients ? gradients + static_cast<size_t>(ray) * (D - 1) * 3 : nullptr;
         float* w_out = weights ? weights + static_cast<size_t>(ray) * (D - 1) : nullptr;
-        const float label = render_pass<kRounds, true>(instances, f.num_instances, c.sh, r, l.merged, D, l.dcache, w2, g_out, w_out);
+        const float label = render_pass<kRounds, true>(instances, f.num_instances, sh, r, l.merged, D, l.dcache, w2, g_out, w_out);
         if (lane < f.num_instances) labels[static_cast<size_t>(ray) * f.num_instances + lane] = label;
         if (distances != nullptr) {
             float* dst = distances + static_cast<size_t>(ray) * D;
@@ -179,7 +183,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
     float* G = lam + N;
     for (int idx = lane; idx < N * kGradStride; idx += kWave) G[idx] = 0.0f;
     const float inv_t = f.inv_t;
-    const Shading sh = c.sh;
+    Shading sh = c.sh;
+    sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, N, inv_t);
     const int stride = static_cast<int>(gridDim.x) * waves_per_block();
     for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
         wave_lds_sync();
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
         // ---- phase A, forward sweep: union sums, opacity, transmittance -----------------------------
         SampleAdjoint sa[kRounds];
         Opacity op[kRounds];
-        float gx[kRounds], gy[kRounds], gz[kRounds], trans[kRounds], delta[kRounds];
+        float gx[kRounds], gy[kRounds], gz[kRounds], trans[kRounds], delta[kRounds], thr[kRounds];
         float carry = 1.0f;
 #pragma unroll
         for (int k = 0; k < kRounds; ++k) {
@@ -206,9 +211,15 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
             delta[k] = d1 - d0;
             const float mid = (d0 + d1) / 2.0f;
             sa[k].x = r.ox + r.rx * mid; sa[k].y = r.oy + r.ry * mid; sa[k].z = r.oz + r.rz * mid;
+            // culling (field.h): nearest centre first, then one ballot per instance
+            float nearest = 3.0e38f;
+            for (int i = 0; i < N; ++i) nearest = fminf(nearest, centre_distance(load_instance(instances, i), sa[k].x, sa[k].y, sa[k].z));
+            thr[k] = nearest * (1.0f + kCullSlack) + sh.cull;
             UnionSums sums = union_init();
             for (int i = 0; i < N; ++i) {
                 const Instance in = load_instance(instances, i);
+                const float lb = centre_distance(in, sa[k].x, sa[k].y, sa[k].z) * (1.0f - kCullSlack) - bounding_radius(in);
+                if (!wave_any(lb <= thr[k])) continue;
                 const BoxEval e = eval_box(in, sa[k].x, sa[k].y, sa[k].z);
                 union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lam[i], inv_t);
             }
@@ -276,11 +287,21 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
         for (int i = 0; i < N; ++i) {
             const Instance in = load_instance(instances, i);
             const float lam_i = lam[i];
+            const float rho = bounding_radius(in);
+            bool active[kRounds];
+            bool any_active = false;
+#pragma unroll
+            for (int k = 0; k < kRounds; ++k) {
+                const float lb = centre_distance(in, sa[k].x, sa[k].y, sa[k].z) * (1.0f - kCullSlack) - rho;
+                active[k] = (k * kWave < num_points) && wave_any(lb <= thr[k]);
+                any_active = any_active || active[k];
+            }
+            if (!any_active) continue;                                            // negligible for this ray (field.h culling)
             float at0 = 0, at1 = 0, at2 = 0, ad0 = 0, ad1 = 0, ad2 = 0;
             float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
 #pragma unroll
             for (int k = 0; k < kRounds; ++k) {
-                if (k * kWave >= num_points) continue;
+                if (!active[k]) continue;
                 const BoxEval e = eval_box(in, sa[k].x, sa[k].y, sa[k].z);
                 const float ds = e.d - sa[k].m;
                 const float w = fast_exp(-ds * inv_t) * sa[k].inv_z;
@@ -311,18 +332,9 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
                 at1 -= in.r10 * pbx + in.r11 * pby + in.r12 * pbz;
                 at2 -= in.r20 * pbx + in.r21 * pby + in.r22 * pbz;
             }
-            // 15 wave reductions; lane j (< 15) keeps parameter j of instance i in its LDS slot
-            const float t0 = wave_sum(at0), t1 = wave_sum(at1), t2 = wave_sum(at2);
-            const float m0 = wave_sum(r00), m1 = wave_sum(r01), m2 = wave_sum(r02);
-            const float m3 = wave_sum(r10), m4 = wave_sum(r11), m5 = wave_sum(r12);
-            const float m6 = wave_sum(r20), m7 = wave_sum(r21), m8 = wave_sum(r22);
-            const float e0 = wave_sum(ad0), e1 = wave_sum(ad1), e2 = wave_sum(ad2);
-            float mine = 0.0f;
-            mine = (lane == 0) ? t0 : mine; mine = (lane == 1) ? t1 : mine; mine = (lane == 2) ? t2 : mine;
-            mine = (lane == 3) ? m0 : mine; mine = (lane == 4) ? m1 : mine; mine = (lane == 5) ? m2 : mine;
-            mine = (lane == 6) ? m3 : mine; mine = (lane == 7) ? m4 : mine; mine = (lane == 8) ? m5 : mine;
-            mine = (lane == 9) ? m6 : mine; mine = (lane == 10) ? m7 : mine; mine = (lane == 11) ? m8 : mine;
-            mine = (lane == 12) ? e0 : mine; mine = (lane == 13) ? e1 : mine; mine = (lane == 14) ? e2 : mine;
+            // one reduce-scatter butterfly: lane j (< 16) receives parameter j of instance i and keeps it in its LDS slot
+            const float packed[16] = {at0, at1, at2, r00, r01, r02, r10, r11, r12, r20, r21, r22, ad0, ad1, ad2, 0.0f};
+            const float mine = wave_reduce16_scatter(packed, lane);
             if (lane < kGradStride) G[i * kGradStride + lane] += mine;
         }
     }

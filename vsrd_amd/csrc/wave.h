@@ -88,6 +88,54 @@ __device__ __forceinline__ float wave_inclusive_product(float v) {
     return v;
 }
 
+// lane ^ 16 / lane ^ 32 exchange sums with the gfx950 row-swap instructions (v_permlane16_swap / v_permlane32_swap):
+// swapping a register with itself leaves {even rows duplicated, odd rows duplicated}, whose sum is the xor butterfly.
+// (inline asm: with hipcc 7.2 the second result of __builtin_amdgcn_permlane{16,32}_swap is assigned the first
+//  result's register; the two wait states LLVM's hazard rule "VALU write -> v_permlane read" needs are in the string)
+__device__ __forceinline__ float add_xor16(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float add_xor32(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
+// Reduce 16 values per lane over the whole wave with a reduce-scatter butterfly: after the call EVERY lane l holds
+// the sum over the 64 lanes of v[l & 15].  ~50 VALU ops instead of 16 x (6 DPP + readlane): each stage pairs the
+// lanes of a row through a DPP permutation (mirror, half-mirror, quad xor 2, quad xor 1) and halves the number of
+// live values, so lane i of a row ends up owning value i; two row swaps then fold the four rows.
+__device__ __forceinline__ float wave_reduce16_scatter(const float (&v)[16], int lane) {
+    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+    float a[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const float keep = b3 ? v[8 + m] : v[m];
+        const float send = b3 ? v[m] : v[8 + m];
+        a[m] = keep + dpp_move<kDppRowMirror>(0.0f, send);
+    }
+    float b[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const float keep = b2 ? a[4 + m] : a[m];
+        const float send = b2 ? a[m] : a[4 + m];
+        b[m] = keep + dpp_move<kDppRowHalfMirror>(0.0f, send);
+    }
+    float c[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const float keep = b1 ? b[2 + m] : b[m];
+        const float send = b1 ? b[m] : b[2 + m];
+        c[m] = keep + dpp_move<kDppQuadXor2>(0.0f, send);
+    }
+    const float keep = b0 ? c[1] : c[0];
+    const float send = b0 ? c[0] : c[1];
+    const float r = keep + dpp_move<kDppQuadXor1>(0.0f, send);   // lane i of each row: row-sum of value i
+    return add_xor32(add_xor16(r));
+}
+
 // Value of lane (l-1), `first` for lane 0 / value of lane (l+1), `last` for lane 63.
 __device__ __forceinline__ float wave_shift_up(float v, float first, int lane) {
     const float t = __shfl_up(v, 1, kWave);

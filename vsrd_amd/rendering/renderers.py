@@ -22,6 +22,14 @@ from ..fields import FieldBlock, SoftUnion, flatten, _closure_vars
 
 _workspaces = {}
 
+# A/B switch for the conservative soft-min instance culling (DESIGN.md "Culling"): False sets VSRD_FLAG_NO_CULLING on
+# every launch so that each instance is evaluated at each sample, exactly like the reference's closure loop.
+CULLING = True
+
+
+def _base_flags():
+    return 0 if CULLING else _lib.FLAG_NO_CULLING
+
 
 def _workspace(device, num_instances):
     key = (device, num_instances)
@@ -58,7 +66,7 @@ class _RenderAtDistances(torch.autograd.Function):
         gradients = torch.empty(R, D - 1, 3, dtype=torch.float32, device=distances.device)
         weights = torch.empty(R, D - 1, dtype=torch.float32, device=distances.device)
         field = _lib.make_field(instances, temperature)
-        config = _lib.make_config(R, num_samples, (near, far), std, ratio, eps, origin_stride)
+        config = _lib.make_config(R, num_samples, (near, far), std, ratio, eps, origin_stride, flags=_base_flags())
         with profiling.timed("vsrd_render_forward"):
             _lib.check(lib.vsrd_render_forward(field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(distances), D,
                                                _lib.ptr(labels), _lib.ptr(gradients), _lib.ptr(weights), _lib.stream()))
@@ -88,7 +96,7 @@ def _backward(instances, origins, directions, distances, temperature, scalars, o
     grad_instances = torch.empty_like(instances)
     workspace = _workspace(distances.device, N)
     field = _lib.make_field(instances, temperature)
-    config = _lib.make_config(R, num_samples, (near, far), std, ratio, eps, origin_stride)
+    config = _lib.make_config(R, num_samples, (near, far), std, ratio, eps, origin_stride, flags=_base_flags())
     with profiling.timed("vsrd_render_backward"):
         _lib.check(lib.vsrd_render_backward(field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(distances), D,
                                             _lib.ptr(grad_labels), _lib.ptr(grad_gradients), _lib.ptr(grad_weights),
@@ -178,7 +186,7 @@ def render_hierarchical(distance_field, ray_positions, ray_directions, distance_
     if u_coarse is not None:
         u_coarse = u_coarse.reshape(-1, num_samples).to(torch.float32).contiguous()
         u_fine = u_fine.reshape(-1, num_samples).to(torch.float32).contiguous()
-    flags = _lib.FLAG_SKIP_EXACT_MISSES if skip_exact_misses else 0
+    flags = (_lib.FLAG_SKIP_EXACT_MISSES if skip_exact_misses else 0) | _base_flags()
     scalars = (float(sdf_std_deviation), float(cosine_ratio), float(epsilon), float(distance_range[0]),
                float(distance_range[1]), int(num_samples))
     labels, gradients, weights, distances, uc, uf = _RenderHierarchical.apply(
