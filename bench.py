@@ -108,6 +108,21 @@ def cpu_baseline(args, sched, frame, cores):
                 sample=f"{args.cpu_rows} image rows x {W} rays (fwd+bwd, N={N}, S={S}), oracle/ on host CPU, best of 2")
 
 
+def measured_traffic(kernel_symbol):
+    """HBM bytes per launch of `kernel_symbol` from the newest committed rocprofv3 PMC summary (profiles/rNN/traffic.json,
+    written by tools/summarize_profile.py from separate FETCH_SIZE / WRITE_SIZE passes of this same command), or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
+        try:
+            kernels = json.load(open(path))["kernels"]
+        except (OSError, ValueError, KeyError):
+            continue
+        for name, entry in kernels.items():
+            if kernel_symbol in name and "FETCH_SIZE_bytes" in entry and "WRITE_SIZE_bytes" in entry:
+                return entry["FETCH_SIZE_bytes"] + entry["WRITE_SIZE_bytes"], os.path.relpath(path, ROOT)
+    return None, None
+
+
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
@@ -204,8 +219,9 @@ def main():
         bwd_n, bwd_ms = kernels["vsrd_render_backward"]
         # Algorithmic bytes per ray (B_api = 24 + 12 N for fwd+bwd with per-ray origins excluded):
         #   forward launch : direction 12 + labels out 4N ; backward launch: direction re-read 12 + grad_labels in 4N
-        dominant, dom_ms, dom_bytes = ("vsrd_render_backward", bwd_ms, 12 + 4 * N) if bwd_ms >= fwd_ms else \
-                                      ("vsrd_render_hierarchical_forward", fwd_ms, 12 + 4 * N)
+        dominant, dom_ms, dom_bytes, symbol = ("vsrd_render_backward", bwd_ms, 12 + 4 * N, "render_backward_kernel") if bwd_ms >= fwd_ms else \
+                                              ("vsrd_render_hierarchical_forward", fwd_ms, 12 + 4 * N, "render_hierarchical_kernel")
+        traffic, traffic_source = measured_traffic(symbol)
         achieved_gbs = R * dom_bytes / (dom_ms * 1e-3) / 1e9
         flop_per_ray = 3.5 * (3 * S - 2) * (63 * N + 45)           # SURVEY.md §8d box-only model, fwd+bwd
         valu_tf = R * flop_per_ray / ((fwd_ms + bwd_ms) * 1e-3) / 1e12
@@ -223,7 +239,7 @@ def main():
                        "loss": "silhouette BCE (torch elementwise) + Adam on raw box parameters",
                        "final_loss": float(loss.detach()), "target_empty_fraction": miss},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_ray": dom_bytes, "launch_ms": dom_ms,
                          "note": "the fused path is fp32-VALU/transcendental bound, not HBM bound (SURVEY.md §8d); see roofline_valu"},
             "roofline_valu": {"bound": "fp32-valu", "achieved": valu_tf, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",

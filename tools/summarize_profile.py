@@ -60,6 +60,29 @@ def main():
             if os.path.exists(path):
                 out.write(f"\n## {sub}\n")
                 counters(path, out)
+    traffic(src, dst)
+
+
+def traffic(src, dst):
+    """profiles/<tag>/traffic.json: per-kernel HBM traffic of one launch from the FETCH_SIZE / WRITE_SIZE passes (bytes)."""
+    import json
+    out = defaultdict(dict)
+    for sub, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        path = os.path.join(src, sub, "bench_counter_collection.csv")
+        if not os.path.exists(path):
+            continue
+        per = defaultdict(list)
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                if r["Counter_Name"] == key and "vsrd::" in r["Kernel_Name"]:
+                    per[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        for name, values in per.items():
+            out[name][key + "_bytes"] = values[-1] * 1024.0          # rocprofv3 reports KiB; last dispatch = a timed step
+    with open(os.path.join(dst, "traffic.json"), "w") as f:
+        json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), last dispatch of each kernel, KiB*1024, uncorrected. "
+                           "Calibration: WRITE_SIZE of ray_directions_kernel = algorithmic 12 B x pixels exactly; the x2 gfx950 FETCH correction of "
+                           "MI355X_MICROARCH.md is for 16 B/lane streams and is NOT applied to these 4 B/lane reads.",
+                   "kernels": out}, f, indent=1)
 
 
 if __name__ == "__main__":
