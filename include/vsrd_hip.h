@@ -134,6 +134,24 @@ int32_t vsrd_render_hierarchical_forward(const vsrd_field* field, const vsrd_ren
                                          float* labels, float* distances, float* gradients, float* weights,
                                          float* u_coarse_out, float* u_fine_out, void* stream);
 
+/* Multi-view projection of N boxes (8 corners each, world frame) into V cameras and reduction to clipped 2-D boxes:
+ * scripts/main.py:339-362 = einsum with E + divide by w, vsrd.operations.project_box_3d / clip_lines_to_front
+ * (geometric_operations.py:343-389) per box, torchvision.ops.clip_boxes_to_image.  One launch for all V*N boxes.
+ * world_corners [N,8,3]; extrinsics [V,16]; intrinsics [V,9] (row-major); edges [E,2] corner indices (E <= 32).
+ * height/width <= 0 skips the image clamp (plain project_box_3d).
+ * Outputs: boxes_2d [V,N,4] = (x1,y1,x2,y2); camera_corners [V,N,8,3] or NULL; selection [V,N,4] (int32: which edge end
+ * point attained each extreme, -1 = no gradient) -- consumed by the backward. */
+int32_t vsrd_project_boxes_forward(const float* world_corners, const float* extrinsics, const float* intrinsics,
+                                   const int32_t* edges, int32_t num_edges, int32_t num_views, int32_t num_boxes,
+                                   int32_t height, int32_t width, float epsilon,
+                                   float* boxes_2d, float* camera_corners, int32_t* selection, void* stream);
+
+/* Adjoint of the above (torch min/max/clamp/where backward semantics): grad_boxes_2d [V,N,4] ->
+ * grad_world_per_view [V,N,8,3]; the caller sums over V (fixed order: deterministic). */
+int32_t vsrd_project_boxes_backward(const float* world_corners, const float* extrinsics, const float* intrinsics,
+                                    const int32_t* edges, int32_t num_edges, int32_t num_views, int32_t num_boxes, float epsilon,
+                                    const float* grad_boxes_2d, const int32_t* selection, float* grad_world_per_view, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

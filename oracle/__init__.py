@@ -28,4 +28,4 @@ Layout convention: per-sample tensors are *ray-major* ``[R, S']`` here (the HIP
 library's native layout); ``oracle.rendering.to_reference_layout`` converts to
 the reference's sample-major ``[S', R, 1]``.
 """
-from . import fields, rendering, geometry, losses  # noqa: F401
+from . import fields, rendering, geometry, losses, step  # noqa: F401

@@ -6,9 +6,9 @@ The sub-packages mirror the part of the reference's ``vsrd`` package that ``scri
 its hot path: ``rendering``, ``operations``, plus ``fields`` (the closures of ``main.py:433-523`` as
 importable objects) and ``models`` (the optimised parameters).
 """
-from . import _lib, fields, rendering
+from . import _lib, fields, rendering, operations, models
 
-__all__ = ["fields", "rendering", "install_as_vsrd"]
+__all__ = ["fields", "rendering", "operations", "models", "install_as_vsrd"]
 
 
 def install_as_vsrd():
@@ -18,3 +18,5 @@ def install_as_vsrd():
     sys.modules.setdefault("vsrd", sys.modules[__name__])
     sys.modules.setdefault("vsrd.rendering", rendering)
     sys.modules.setdefault("vsrd.rendering.sdfs", rendering.sdfs)
+    sys.modules.setdefault("vsrd.operations", operations)
+    sys.modules.setdefault("vsrd.models", models)

@@ -68,6 +68,12 @@ SIGNATURES = {
     "vsrd_render_hierarchical_forward": (ctypes.c_int32, [ctypes.POINTER(Field), ctypes.POINTER(RenderConfig), c_float_p, c_float_p,
                                                           c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
                                                           c_float_p, c_float_p, ctypes.c_void_p]),
+    "vsrd_project_boxes_forward": (ctypes.c_int32, [c_float_p, c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                                    ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
+                                                    c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "vsrd_project_boxes_backward": (ctypes.c_int32, [c_float_p, c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                                     ctypes.c_int32, ctypes.c_float, c_float_p, ctypes.c_void_p, c_float_p,
+                                                     ctypes.c_void_p]),
 }
 
 _lock = threading.Lock()
@@ -115,6 +121,13 @@ def ptr(tensor):
         raise VsrdHipError(f"expected float32, got {tensor.dtype}")
     if not tensor.is_contiguous():
         raise VsrdHipError("internal error: non-contiguous tensor handed to the C ABI")
+    return ctypes.c_void_p(tensor.data_ptr())
+
+
+def iptr(tensor):
+    """Device pointer of a contiguous int32 HIP tensor."""
+    if not tensor.is_cuda or tensor.dtype != torch.int32 or not tensor.is_contiguous():
+        raise VsrdHipError("expected a contiguous int32 HIP tensor")
     return ctypes.c_void_p(tensor.data_ptr())
 
 

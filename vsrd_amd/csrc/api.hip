@@ -2,6 +2,7 @@
 // number of 64-sample rounds.  No torch types, no global state, no allocation.
 #include "../../include/vsrd_hip.h"
 #include "aux_kernels.h"
+#include "projection.h"
 
 namespace {
 
@@ -270,6 +271,34 @@ int32_t vsrd_render_hierarchical_forward(const vsrd_field* field, const vsrd_ren
         default: return VSRD_E_UNSUPPORTED;
     }
 #undef VSRD_LAUNCH
+    return launch_status();
+}
+
+int32_t vsrd_project_boxes_forward(const float* world_corners, const float* extrinsics, const float* intrinsics,
+                                   const int32_t* edges, int32_t num_edges, int32_t num_views, int32_t num_boxes,
+                                   int32_t height, int32_t width, float epsilon,
+                                   float* boxes_2d, float* camera_corners, int32_t* selection, void* stream) {
+    if (num_views < 0 || num_boxes < 0 || num_edges < 1 || num_edges > kMaxEdges) return VSRD_E_INVALID_ARGUMENT;
+    if (num_views == 0 || num_boxes == 0) return VSRD_OK;
+    if (!world_corners || !extrinsics || !intrinsics || !edges || !boxes_2d || !selection) return VSRD_E_INVALID_ARGUMENT;
+    const int total = num_views * num_boxes;
+    hipLaunchKernelGGL(project_boxes_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       world_corners, extrinsics, intrinsics, edges, num_edges, num_views, num_boxes,
+                       static_cast<float>(height), static_cast<float>(width), epsilon, boxes_2d, camera_corners, selection);
+    return launch_status();
+}
+
+int32_t vsrd_project_boxes_backward(const float* world_corners, const float* extrinsics, const float* intrinsics,
+                                    const int32_t* edges, int32_t num_edges, int32_t num_views, int32_t num_boxes, float epsilon,
+                                    const float* grad_boxes_2d, const int32_t* selection, float* grad_world_per_view, void* stream) {
+    if (num_views < 0 || num_boxes < 0 || num_edges < 1 || num_edges > kMaxEdges) return VSRD_E_INVALID_ARGUMENT;
+    if (num_views == 0 || num_boxes == 0) return VSRD_OK;
+    if (!world_corners || !extrinsics || !intrinsics || !edges || !grad_boxes_2d || !selection || !grad_world_per_view)
+        return VSRD_E_INVALID_ARGUMENT;
+    const int total = num_views * num_boxes;
+    hipLaunchKernelGGL(project_boxes_backward_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       world_corners, extrinsics, intrinsics, edges, num_views, num_boxes, epsilon, grad_boxes_2d, selection,
+                       grad_world_per_view);
     return launch_status();
 }
 

@@ -1,0 +1,85 @@
+"""vsrd.operations geometry on the HIP library (reference: vsrd/operations/geometric_operations.py).
+
+``project_boxes_multi_view`` is the batched form of the per-box Python loop of scripts/main.py:339-362;
+``project_box_3d`` keeps the reference's single-box signature on top of the same kernel.
+"""
+import torch
+
+from .. import _lib
+
+# scripts/main.py:26-30
+LINE_INDICES = [[0, 1], [1, 2], [2, 3], [3, 0], [4, 5], [5, 6], [6, 7], [7, 4], [0, 4], [1, 5], [2, 6], [3, 7]]
+
+_edge_cache = {}
+
+
+def _edges(line_indices, device):
+    key = (tuple(map(tuple, line_indices)), device)
+    cached = _edge_cache.get(key)
+    if cached is None:
+        cached = torch.tensor(line_indices, dtype=torch.int32, device=device).contiguous()
+        _edge_cache[key] = cached
+    return cached
+
+
+class _ProjectBoxes(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, world_corners, extrinsics, intrinsics, edges, height, width, epsilon):
+        lib = _lib.load()
+        N, V = world_corners.shape[0], extrinsics.shape[0]
+        corners = world_corners.detach().to(torch.float32).contiguous()
+        E = extrinsics.detach().to(torch.float32).reshape(V, 16).contiguous()
+        K = intrinsics.detach().to(torch.float32).reshape(V, 9).contiguous()
+        boxes = torch.empty(V, N, 4, dtype=torch.float32, device=corners.device)
+        camera = torch.empty(V, N, 8, 3, dtype=torch.float32, device=corners.device)
+        selection = torch.empty(V, N, 4, dtype=torch.int32, device=corners.device)
+        _lib.check(lib.vsrd_project_boxes_forward(_lib.ptr(corners), _lib.ptr(E), _lib.ptr(K), _lib.iptr(edges), edges.shape[0], V, N,
+                                                  int(height), int(width), float(epsilon), _lib.ptr(boxes), _lib.ptr(camera),
+                                                  _lib.iptr(selection), _lib.stream()))
+        ctx.save_for_backward(corners, E, K, edges, selection)
+        ctx.epsilon = float(epsilon)
+        ctx.mark_non_differentiable(camera)
+        return boxes, camera
+
+    @staticmethod
+    def backward(ctx, grad_boxes, _grad_camera):
+        lib = _lib.load()
+        corners, E, K, edges, selection = ctx.saved_tensors
+        V, N = selection.shape[0], selection.shape[1]
+        per_view = torch.empty(V, N, 8, 3, dtype=torch.float32, device=corners.device)
+        _lib.check(lib.vsrd_project_boxes_backward(_lib.ptr(corners), _lib.ptr(E), _lib.ptr(K), _lib.iptr(edges), edges.shape[0], V, N,
+                                                   ctx.epsilon, _lib.ptr(grad_boxes.to(torch.float32).contiguous()), _lib.iptr(selection),
+                                                   _lib.ptr(per_view), _lib.stream()))
+        return per_view.sum(0), None, None, None, None, None, None
+
+
+def project_boxes_multi_view(world_boxes_3d, extrinsic_matrices, intrinsic_matrices, image_size, line_indices=LINE_INDICES, epsilon=1e-6):
+    """world corners [N,8,3], E [V,4,4], K [V,3,3] -> (boxes_2d [V,N,2,2] clipped to the image, camera corners [V,N,8,3])."""
+    height, width = int(image_size[0]), int(image_size[1])
+    boxes, camera = _ProjectBoxes.apply(world_boxes_3d, extrinsic_matrices, intrinsic_matrices,
+                                        _edges(line_indices, world_boxes_3d.device), height, width, epsilon)
+    return boxes.unflatten(-1, (2, 2)), camera
+
+
+def project_box_3d(box_3d, line_indices, intrinsic_matrix, epsilon=1e-6):
+    """Reference signature (geometric_operations.py:368-389): camera-frame corners [...,8,3] -> [...,2,2], not clipped to an image."""
+    lead = box_3d.shape[:-2]
+    corners = box_3d.reshape(-1, 8, 3)
+    eye = torch.eye(4, device=box_3d.device).unsqueeze(0)
+    boxes, _ = _ProjectBoxes.apply(corners, eye, intrinsic_matrix.reshape(1, 3, 3), _edges(line_indices, box_3d.device),
+                                   0, 0, epsilon)      # height = width = 0: no image clamp
+    return boxes[0].reshape(*lead, 2, 2)
+
+
+def rotation_matrix_x(angles):
+    """geometric_operations.py:30-40."""
+    cos, sin = torch.cos(angles), torch.sin(angles)
+    one, zero = torch.ones_like(angles), torch.zeros_like(angles)
+    return torch.stack([torch.stack([one, zero, zero], -1), torch.stack([zero, cos, -sin], -1), torch.stack([zero, sin, cos], -1)], -2)
+
+
+def expand_to_4x4(matrices):
+    """geometric_operations.py:10-15."""
+    out = torch.eye(4).to(matrices).repeat(*matrices.shape[:-2], 1, 1)
+    out[..., :matrices.shape[-2], :matrices.shape[-1]] = matrices
+    return out

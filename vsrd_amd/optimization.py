@@ -1,0 +1,113 @@
+"""One target frame's optimisation loop: the hot path of scripts/main.py:323-865 assembled from the device pieces.
+
+    detector() -> multi-view projection (HIP) -> Hungarian matching (host, as the reference) -> projection losses
+    -> schedules -> field block -> ray sampling -> fused two-pass render (HIP) -> silhouette (+ eikonal) loss
+    -> backward (HIP adjoint kernels + torch for the tiny decode) -> Adam -> ExponentialLR
+
+Frames are independent problems (README.md:128): multi-GPU runs shard *frames* over ranks (vsrd_amd/launcher.py) and
+never exchange gradients.
+"""
+from dataclasses import dataclass, field as dataclass_field
+from typing import Optional, Sequence
+
+import torch
+
+from . import fields, losses, models, operations, rendering
+
+
+@dataclass
+class FrameInputs:
+    """What scripts/main.py:106-316 prepares for one target frame; view 0 is the target view."""
+    image_size: Sequence[int]               # (H, W)
+    intrinsic_matrices: torch.Tensor        # [V,3,3]
+    extrinsic_matrices: torch.Tensor        # [V,4,4] (target-camera frame -> view camera frame)
+    soft_masks: torch.Tensor                # [V,H,W,N] re-indexed to the target's instance order (main.py:204-265)
+    boxes_2d: torch.Tensor                  # [V,N,2,2] ground-truth 2-D boxes, zeros where invisible
+    visible_masks: torch.Tensor             # [V,N] bool
+
+
+@dataclass
+class OptimizationConfig:
+    """configs/kitti_360/vsrd/*/config.json:120-127,166-238."""
+    num_steps: int = 3000
+    warmup_steps: int = 1000
+    num_rays: int = 1000
+    num_samples: int = 100
+    distance_range: Sequence[float] = (0.0, 100.0)
+    max_sdf_union_temperature: float = 1.0
+    min_sdf_union_temperature: float = 0.1
+    max_sdf_std_deviation: float = 1.0
+    min_sdf_std_deviation: float = 0.1
+    learning_rate: float = 1.0e-2
+    lr_gamma: float = 0.01 ** (1.0 / 3000.0)
+    loss_weights: dict = dataclass_field(default_factory=lambda: dict(losses.LOSS_WEIGHTS))
+    seed: int = 0
+    skip_exact_misses: bool = True
+
+
+class FrameOptimizer:
+    def __init__(self, inputs: FrameInputs, config: OptimizationConfig, device):
+        self.inputs, self.config, self.device = inputs, config, torch.device(device)
+        V, H, W, N = inputs.soft_masks.shape
+        self.num_views, self.num_instances = V, N
+        self.detector = models.BoxParameters3D(1, N).to(self.device)
+        groups = [dict(params=[p], lr=config.learning_rate) for p in (self.detector.locations, self.detector.dimensions, self.detector.orientations)]
+        self.optimizer = torch.optim.Adam(groups, lr=config.learning_rate)
+        self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=config.lr_gamma)
+        # rays of every view, once per frame (main.py:267-296)
+        cam, dirs = rendering.ray_casting((H, W), inputs.intrinsic_matrices, inputs.extrinsic_matrices)
+        self.camera_positions = cam                                         # [V,3]
+        self.ray_directions = dirs.reshape(-1, 3).contiguous()              # [V*H*W,3]
+        self.flat_masks = inputs.soft_masks.reshape(-1, N)
+        self.sampling_weights = self.flat_masks.max(dim=-1).values          # main.py:620-624
+        self.pixels_per_view = H * W
+        self.step_index = 0
+
+    # ------------------------------------------------------------------------------------------------
+    def sample_rays(self):
+        """main.py:620-627: importance-sample rays by the strongest soft mask (torch.multinomial, no replacement)."""
+        return torch.multinomial(self.sampling_weights, self.config.num_rays, replacement=False)
+
+    def field_block(self, outputs, temperature):
+        return fields.FieldBlock(fields.pack_instances(outputs["locations"][0], outputs["orientations"][0], outputs["dimensions"][0]),
+                                 float(temperature), None, None)
+
+    def step(self, ray_indices: Optional[torch.Tensor] = None, u_coarse=None, u_fine=None):
+        """One optimisation step (box-only phase).  ray_indices / uniforms may be supplied for reproducible parity runs."""
+        cfg, inp = self.config, self.inputs
+        step = self.step_index
+        if step >= cfg.warmup_steps:
+            raise NotImplementedError("residual-MLP phase (step >= warmup_steps) is not implemented in this round")
+        self.optimizer.zero_grad(set_to_none=True)
+        outputs = self.detector()
+        # ---- multi-view projection, matching, projection losses (main.py:339-415) --------------------
+        pd_boxes_2d, _ = operations.project_boxes_multi_view(outputs["boxes_3d"][0], inp.extrinsic_matrices, inp.intrinsic_matrices, inp.image_size)
+        pd_idx, gt_idx = losses.match_instances(pd_boxes_2d[0], inp.boxes_2d[0])
+        iou_loss, l1_loss = losses.projection_losses(pd_boxes_2d, inp.boxes_2d, inp.visible_masks, pd_idx, gt_idx)
+        # ---- instance loss (main.py:420-671) ---------------------------------------------------------
+        ratio, temperature, std = losses.schedules(step, cfg.num_steps, cfg.max_sdf_union_temperature, cfg.min_sdf_union_temperature,
+                                                   cfg.max_sdf_std_deviation, cfg.min_sdf_std_deviation)
+        block = self.field_block(outputs, temperature)
+        if ray_indices is None:
+            ray_indices = self.sample_rays()
+        origins = self.camera_positions[ray_indices // self.pixels_per_view]
+        directions = self.ray_directions[ray_indices]
+        out = rendering.render_hierarchical(block, origins, directions, cfg.distance_range, cfg.num_samples, std, ratio,
+                                            u_coarse=u_coarse, u_fine=u_fine, seed=cfg.seed, stream_offset=step,
+                                            skip_exact_misses=cfg.skip_exact_misses)
+        silhouette = losses.silhouette_loss(out["labels"], self.flat_masks[ray_indices], pd_idx, gt_idx)
+        terms = dict(iou_projection_loss=iou_loss, l1_projection_loss=l1_loss, silhouette_loss=silhouette)
+        total = sum(cfg.loss_weights[name] * value for name, value in terms.items())   # main.py:855
+        total.backward()
+        raw_gradients = [p.grad.detach().clone() for p in (self.detector.locations, self.detector.dimensions, self.detector.orientations)]
+        self.optimizer.step()
+        self.scheduler.step()
+        self.step_index += 1
+        terms["loss"] = total
+        result = {name: value.detach() for name, value in terms.items()}
+        result["raw_gradients"] = raw_gradients
+        return result
+
+    def boxes(self):
+        with torch.no_grad():
+            return self.detector()
