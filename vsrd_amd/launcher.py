@@ -1,0 +1,80 @@
+"""Frame-sharded multi-GPU launcher: one process per GPU, frames split across ranks, no data-path collective.
+
+Reference behaviour (scripts/main.py:45-57, vsrd/distributed/loader.py:4-9, README.md:128): ``torch.distributed`` is
+initialised, ranks print in order between barriers, a ``DistributedSampler`` hands every rank its share of the target
+frames, and each rank optimises its frames alone -- gradients are never averaged.  The only traffic is the start-up
+barrier; here additionally rank 0 broadcasts the run manifest so every rank agrees on the frame list.  On ROCm the
+``nccl`` backend is RCCL (xGMI carries latency-only messages; nothing bandwidth-bound exists on this path).
+"""
+import os
+import random
+from typing import Callable, List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def init_process_group(backend=None):
+    """env:// rendezvous as with torchrun (main.py:49).  Returns (rank, world_size, device)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_gpu = torch.cuda.is_available()
+    device = torch.device("cuda", local % max(torch.cuda.device_count(), 1)) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend or ("nccl" if use_gpu else "gloo"), rank=rank, world_size=world)
+    return rank, world, device
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def ordered(action: Callable[[int], None]):
+    """Run ``action(rank)`` rank by rank between barriers (the ordered start-up print of main.py:53-57)."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    for turn in range(world):
+        if turn == rank:
+            action(rank)
+        barrier()
+
+
+def broadcast_manifest(manifest=None):
+    """Rank 0's manifest (any picklable object) to every rank."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return manifest
+    box = [manifest if dist.get_rank() == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+def shard_frames(frames: Sequence, rank: int, world_size: int, seed: int = 0) -> List:
+    """Seeded permutation, then frame j of the permutation goes to rank j mod world_size.
+
+    Unlike ``DistributedSampler`` (loader.py:8) no frame is duplicated to pad the shards: the reference relies on its
+    "skip if the final checkpoint exists" guard (main.py:134-136) to make the padded duplicates harmless; here they never exist.
+    """
+    order = list(range(len(frames)))
+    random.Random(seed).shuffle(order)
+    return [frames[j] for position, j in enumerate(order) if position % world_size == rank]
+
+
+def run_frames(frames: Sequence, optimise: Callable, checkpoint_path: Callable[[object], str] = None):
+    """Optimise this rank's frames one after the other; a frame whose final checkpoint exists is skipped (main.py:134-136)."""
+    done = []
+    for frame in frames:
+        path = checkpoint_path(frame) if checkpoint_path else None
+        if path and os.path.exists(path):
+            continue
+        result = optimise(frame)
+        if path:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            torch.save(result, path)          # utils.Saver.save == torch.save(dict) (vsrd/utils.py:191-198)
+        done.append(frame)
+    return done
