@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, RENDER_CASES
+from conftest import load_golden, RENDER_CASES, RESIDUAL_CASES
 from oracle import fields as ofields, rendering as orendering, geometry as ogeometry, losses as olosses
 
 pytestmark = pytest.mark.gpu
@@ -197,6 +197,48 @@ def test_api_two_pass_wrapper(dev, name):
     for got, want in zip(torch.autograd.grad(loss, params), torch.autograd.grad(oloss, oparams)):
         err = (got.cpu() - want).abs().max().item() / max(want.abs().max().item(), 1e-6)
         assert err < GRAD_TOL
+
+
+def hip_residual_union(g, dev):
+    from vsrd_amd import fields, rendering
+    N = g["locations"].shape[0]
+    loc, dim, rot, mlp = (g[k].to(dev) for k in ("locations", "dimensions", "orientations", "mlp_weights"))
+    return fields.soft_union([
+        rendering.sdfs.translation(rendering.sdfs.rotation(fields.instance_field(
+            fields.residual_composition(rendering.sdfs.box(dim[i]), fields.ResidualField(mlp[i])), i, N), rot[i]), loc[i])
+        for i in range(N)], float(g["temperature"]))
+
+
+@pytest.mark.parametrize("name", RESIDUAL_CASES)
+def test_residual_field_forward_golden(dev, name):
+    """Config-3 field (box + per-instance residual MLP): forward parity against the reference's outputs (G10) and G6."""
+    from vsrd_amd import rendering
+    g = load_golden(name)
+    S = int(g["num_samples"])
+    union = hip_residual_union(g, dev)
+    std, ratio = float(g["sdf_std_deviation"]), float(g["cosine_ratio"])
+    # given the reference's own distances
+    for prefix in ("coarse", "fine"):
+        dist = g[f"{prefix}_distances"].t().contiguous().to(dev)
+        labels, grads, weights = rendering.render_at_distances(union, g["origins"].to(dev), g["directions"].to(dev), dist, std, ratio)
+        assert (labels.cpu() - g[f"{prefix}_labels"]).abs().max() < LABEL_TOL
+        assert (weights.cpu() - g[f"{prefix}_weights"].t()).abs().max() < LABEL_TOL
+        conditioned = g["coarse_weights"].sum(0) > 0 if prefix == "fine" else torch.ones(dist.shape[0], dtype=torch.bool)
+        torch.testing.assert_close(grads.cpu()[conditioned], g[f"{prefix}_gradients"].transpose(0, 1)[conditioned], rtol=5e-3, atol=5e-4)
+    # fused two-pass kernel with the recorded uniforms
+    out = rendering.render_hierarchical(union, g["origins"].to(dev), g["directions"].to(dev), (0.0, 100.0), S, std, ratio,
+                                        u_coarse=g["u_coarse"].to(dev), u_fine=g["u_fine"].to(dev))
+    assert (out["labels"].cpu() - g["fine_labels"]).abs().max() < LABEL_TOL
+    # closure call: union distance / labels / analytic normal at the sample points of a few rays, against the CPU oracle
+    ounion = ofields.InstanceUnion(g["locations"], g["orientations"], g["dimensions"], float(g["temperature"]), g["mlp_weights"])
+    rays = torch.nonzero(g["coarse_weights"].sum(0) > 0)[:8, 0]       # well-conditioned rays (no 1e6 m extrapolation)
+    mid = (g["fine_distances"][:-1, rays] + g["fine_distances"][1:, rays]).t() / 2
+    pts = g["origins"][rays, None, :] + g["directions"][rays, None, :] * mid[..., None]
+    u, w, grad = rendering.evaluate_field(union, pts.to(dev), with_gradients=True)
+    ou, ow, og = ounion.evaluate(pts)
+    torch.testing.assert_close(u.cpu()[..., 0], ou, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(w.cpu(), ow, rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(grad.cpu(), og, rtol=5e-3, atol=5e-4)
 
 
 def test_philox_mode_matches_oracle_on_exported_uniforms(dev):

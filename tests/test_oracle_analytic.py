@@ -37,3 +37,24 @@ def test_backward_ray_matches_autograd(name, ratio):
         for a, b in ((at, gt), (aR, gR), (ad, gd)):
             scale = max(float(b.abs().max()), 1e-9)
             np.testing.assert_allclose(a, b.numpy(), rtol=1e-7, atol=1e-9 * scale + 1e-12)
+
+
+def test_residual_mlp_jet_adjoint_matches_autograd():
+    """oracle/analytic_mlp.py (blueprint of the residual-MLP kernels) against autograd through the closed-form oracle."""
+    from oracle import analytic_mlp
+    rng = np.random.default_rng(3)
+    for trial in range(6):
+        p = rng.standard_normal(3) * np.array([2.0, 1.0, 3.0])
+        w = rng.standard_normal(1617) * 0.3
+        res_bar, gres_bar = rng.standard_normal(), rng.standard_normal(3)
+        pt = torch.tensor(p, dtype=torch.float64, requires_grad=True)
+        wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+        res, gres = fields.residual_distance_and_gradient(pt[None], wt[None])
+        a_res, a_gres, _ = analytic_mlp.forward(p, w)
+        np.testing.assert_allclose(a_res, res.item(), rtol=1e-12)
+        np.testing.assert_allclose(a_gres, gres[0].detach().numpy(), rtol=1e-10, atol=1e-14)
+        loss = res[0] * res_bar + (gres[0] * torch.tensor(gres_bar)).sum()
+        gp, gw = torch.autograd.grad(loss, [pt, wt])
+        a_p, a_w = analytic_mlp.backward(p, w, res_bar, gres_bar)
+        np.testing.assert_allclose(a_p, gp.numpy(), rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(a_w, gw.numpy(), rtol=1e-8, atol=1e-12 * max(1.0, float(gw.abs().max())))

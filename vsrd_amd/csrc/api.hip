@@ -125,12 +125,15 @@ int32_t vsrd_ray_directions(const float* inverse_projection, int32_t num_views, 
 int32_t vsrd_field_eval(const vsrd_field* field, const float* positions, int64_t num_points,
                         float* distances, float* gradients, float* labels, int32_t hard_union, void* stream) {
     if (!valid_field(field) || (!positions && num_points > 0) || num_points < 0) return VSRD_E_INVALID_ARGUMENT;
-    if (field->mlp_weights != nullptr) return VSRD_E_UNSUPPORTED;
     if (hard_union && labels) return VSRD_E_INVALID_ARGUMENT;
     if (num_points == 0) return VSRD_OK;
     const int blocks = static_cast<int>(std::min<int64_t>((num_points + 255) / 256, 8192));
-    hipLaunchKernelGGL(field_eval_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       field_args(field), field->instances, positions, static_cast<long long>(num_points), distances, gradients, labels, hard_union);
+    if (field->mlp_weights != nullptr)
+        hipLaunchKernelGGL(field_eval_kernel<true>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), field_args(field),
+                           field->instances, field->mlp_weights, positions, static_cast<long long>(num_points), distances, gradients, labels, hard_union);
+    else
+        hipLaunchKernelGGL(field_eval_kernel<false>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), field_args(field),
+                           field->instances, field->mlp_weights, positions, static_cast<long long>(num_points), distances, gradients, labels, hard_union);
     return launch_status();
 }
 
@@ -176,25 +179,35 @@ int32_t vsrd_render_forward(const vsrd_field* field, const vsrd_render_config* c
         return VSRD_E_INVALID_ARGUMENT;
     if (config->num_rays == 0) return VSRD_OK;   // empty batch: buffers may be null
     if (!origins || !directions || !distances || !labels) return VSRD_E_INVALID_ARGUMENT;
-    if (field->mlp_weights != nullptr) return VSRD_E_UNSUPPORTED;
+    const bool residual = field->mlp_weights != nullptr;
     Geometry g;
     if (!plan(config->num_rays, static_cast<size_t>(num_distances) + field->num_instances * kWave, &g)) return VSRD_E_UNSUPPORTED;
     const FieldArgs f = field_args(field);
     RenderArgs c = render_args(config);
     c.sh.inv_t = f.inv_t;
     const hipStream_t s = static_cast<hipStream_t>(stream);
-#define VSRD_LAUNCH(K)                                                                                                       \
+#define VSRD_LAUNCH(K, RES)                                                                                                  \
     do {                                                                                                                       \
-        if (opt_in_lds(render_forward_kernel<K>, g.lds_bytes) != VSRD_OK) return VSRD_E_LAUNCH;                              \
-        hipLaunchKernelGGL(render_forward_kernel<K>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins,           \
-                           directions, distances, num_distances, labels, gradients, weights);                                \
+        if (opt_in_lds(render_forward_kernel<K, RES>, g.lds_bytes) != VSRD_OK) return VSRD_E_LAUNCH;                         \
+        hipLaunchKernelGGL((render_forward_kernel<K, RES>), dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, \
+                           field->mlp_weights, c, origins, directions, distances, num_distances, labels, gradients, weights);   \
     } while (0)
-    switch (rounds_for(num_distances - 1)) {
-        case 1: VSRD_LAUNCH(1); break;
-        case 2: VSRD_LAUNCH(2); break;
-        case 4: VSRD_LAUNCH(4); break;
-        case 8: VSRD_LAUNCH(8); break;
-        default: return VSRD_E_UNSUPPORTED;
+    const int rounds = rounds_for(num_distances - 1);
+    if (residual) {
+        switch (rounds) {
+            case 1: VSRD_LAUNCH(1, true); break;
+            case 2: VSRD_LAUNCH(2, true); break;
+            case 4: VSRD_LAUNCH(4, true); break;
+            default: return VSRD_E_UNSUPPORTED;
+        }
+    } else {
+        switch (rounds) {
+            case 1: VSRD_LAUNCH(1, false); break;
+            case 2: VSRD_LAUNCH(2, false); break;
+            case 4: VSRD_LAUNCH(4, false); break;
+            case 8: VSRD_LAUNCH(8, false); break;
+            default: return VSRD_E_UNSUPPORTED;
+        }
     }
 #undef VSRD_LAUNCH
     return launch_status();
@@ -248,7 +261,7 @@ int32_t vsrd_render_hierarchical_forward(const vsrd_field* field, const vsrd_ren
     if (!valid_field(field) || !valid_config(config)) return VSRD_E_INVALID_ARGUMENT;
     if (config->num_rays == 0) return VSRD_OK;   // empty batch: buffers may be null
     if (!origins || !directions || !labels) return VSRD_E_INVALID_ARGUMENT;
-    if (field->mlp_weights != nullptr) return VSRD_E_UNSUPPORTED;
+    const bool residual = field->mlp_weights != nullptr;
     if ((config->flags & VSRD_FLAG_SKIP_EXACT_MISSES) && (gradients || weights)) return VSRD_E_INVALID_ARGUMENT;
     const int S = config->num_samples;
     Geometry g;
@@ -257,18 +270,29 @@ int32_t vsrd_render_hierarchical_forward(const vsrd_field* field, const vsrd_ren
     RenderArgs c = render_args(config);
     c.sh.inv_t = f.inv_t;
     const hipStream_t s = static_cast<hipStream_t>(stream);
-#define VSRD_LAUNCH(K)                                                                                                       \
+#define VSRD_LAUNCH(K, RES)                                                                                                  \
     do {                                                                                                                       \
-        if (opt_in_lds(render_hierarchical_kernel<K>, g.lds_bytes) != VSRD_OK) return VSRD_E_LAUNCH;                         \
-        hipLaunchKernelGGL(render_hierarchical_kernel<K>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins,      \
-                           directions, u_coarse, u_fine, labels, distances, gradients, weights, u_coarse_out, u_fine_out);   \
+        if (opt_in_lds(render_hierarchical_kernel<K, RES>, g.lds_bytes) != VSRD_OK) return VSRD_E_LAUNCH;                    \
+        hipLaunchKernelGGL((render_hierarchical_kernel<K, RES>), dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f,            \
+                           field->instances, field->mlp_weights, c, origins, directions, u_coarse, u_fine, labels, distances,   \
+                           gradients, weights, u_coarse_out, u_fine_out);                                                     \
     } while (0)
-    switch (rounds_for(2 * S - 1)) {
-        case 1: VSRD_LAUNCH(1); break;
-        case 2: VSRD_LAUNCH(2); break;
-        case 4: VSRD_LAUNCH(4); break;
-        case 8: VSRD_LAUNCH(8); break;
-        default: return VSRD_E_UNSUPPORTED;
+    const int rounds = rounds_for(2 * S - 1);
+    if (residual) {
+        switch (rounds) {
+            case 1: VSRD_LAUNCH(1, true); break;
+            case 2: VSRD_LAUNCH(2, true); break;
+            case 4: VSRD_LAUNCH(4, true); break;
+            default: return VSRD_E_UNSUPPORTED;
+        }
+    } else {
+        switch (rounds) {
+            case 1: VSRD_LAUNCH(1, false); break;
+            case 2: VSRD_LAUNCH(2, false); break;
+            case 4: VSRD_LAUNCH(4, false); break;
+            case 8: VSRD_LAUNCH(8, false); break;
+            default: return VSRD_E_UNSUPPORTED;
+        }
     }
 #undef VSRD_LAUNCH
     return launch_status();

@@ -30,7 +30,8 @@ __global__ __launch_bounds__(256) void ray_directions_kernel(const float* __rest
 
 // The distance_field closure evaluated at arbitrary points (main.py:477-509) plus its analytic normal.
 // One thread per point; the instance loop is still wave-uniform (scalar parameter loads).
-__global__ __launch_bounds__(256) void field_eval_kernel(FieldArgs f, const float* __restrict__ instances,
+template <bool kResidual>
+__global__ __launch_bounds__(256) void field_eval_kernel(FieldArgs f, const float* __restrict__ instances, const float* __restrict__ mlp,
                                                          const float* __restrict__ positions, long long num_points,
                                                          float* __restrict__ distances, float* __restrict__ gradients,
                                                          float* __restrict__ labels, int hard_union) {
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256) void field_eval_kernel(FieldArgs f, const floa
         if (hard_union) {
             float best = 3.0e38f, bx = 0.0f, by = 0.0f, bz = 0.0f;
             for (int i = 0; i < f.num_instances; ++i) {
-                const BoxEval e = eval_box(load_instance(instances, i), x, y, z);
+                const BoxEval e = eval_instance<kResidual>(load_instance(instances, i), kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z);
                 if (e.d < best) { best = e.d; bx = e.gwx; by = e.gwy; bz = e.gwz; }   // argmin: first minimum
             }
             if (distances) distances[idx] = best;
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void field_eval_kernel(FieldArgs f, const floa
         }
         UnionSums sums = union_init();
         for (int i = 0; i < f.num_instances; ++i) {
-            const BoxEval e = eval_box(load_instance(instances, i), x, y, z);
+            const BoxEval e = eval_instance<kResidual>(load_instance(instances, i), kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z);
             union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, 0.0f, f.inv_t);
         }
         const UnionValue v = union_finish(sums, f.inv_t);
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void field_eval_kernel(FieldArgs f, const floa
         if (gradients) { gradients[idx * 3 + 0] = v.gx; gradients[idx * 3 + 1] = v.gy; gradients[idx * 3 + 2] = v.gz; }
         if (labels) {
             for (int i = 0; i < f.num_instances; ++i) {
-                const BoxEval e = eval_box(load_instance(instances, i), x, y, z);
+                const BoxEval e = eval_instance<kResidual>(load_instance(instances, i), kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z);
                 labels[idx * f.num_instances + i] = fast_exp(-(e.d - v.m) * f.inv_t) * v.inv_z;
             }
         }

@@ -9,6 +9,7 @@
 // so the 16 packed floats of instance i are fetched with scalar loads and used as SGPR operands.
 #pragma once
 #include "wave.h"
+#include "residual.h"
 
 namespace vsrd {
 
@@ -74,6 +75,22 @@ __device__ __forceinline__ BoxEval eval_box(const Instance& in, float x, float y
     return e;
 }
 
+// Box (+ optional residual MLP) evaluation of instance i: d_i = box(p) + residual(p), local gradient likewise
+// (scripts/main.py:451-458).  `mlp` is the wave-uniform weight row of the instance.
+template <bool kResidual>
+__device__ __forceinline__ BoxEval eval_instance(const Instance& in, const float* __restrict__ mlp, float x, float y, float z) {
+    BoxEval e = eval_box(in, x, y, z);
+    if (kResidual) {
+        const Residual r = residual_forward(mlp, e.px, e.py, e.pz);
+        e.d += r.value;
+        e.glx += r.gx; e.gly += r.gy; e.glz += r.gz;
+        e.gwx = in.r00 * e.glx + in.r01 * e.gly + in.r02 * e.glz;
+        e.gwy = in.r10 * e.glx + in.r11 * e.gly + in.r12 * e.glz;
+        e.gwz = in.r20 * e.glx + in.r21 * e.gly + in.r22 * e.glz;
+    }
+    return e;
+}
+
 // ---- conservative instance culling -------------------------------------------------------------------
 // For a sample x, instance i's soft-min weight relative to the best instance is at most
 //   exp(-(LB_i - UB) / T),  LB_i = |x - t_i| (1 - k) - |dim_i|  <=  d_i(x),   UB = min_j |x - t_j| (1 + k) + 1e-3  >=  min_j d_j(x)
@@ -100,7 +117,7 @@ __device__ __forceinline__ float cull_margin(const float* __restrict__ instances
         const float g02 = in.r00 * in.r02 + in.r10 * in.r12 + in.r20 * in.r22, g12 = in.r01 * in.r02 + in.r11 * in.r12 + in.r21 * in.r22;
         worst = fmaxf(worst, fmaxf(fmaxf(fabsf(g00 - 1.0f), fabsf(g11 - 1.0f)), fmaxf(fabsf(g22 - 1.0f), fmaxf(fabsf(g01), fmaxf(fabsf(g02), fabsf(g12))))));
     }
-    return (worst < 1.0e-4f) ? (kCullTau / inv_t + 2.0e-3f) : 3.0e38f;
+    return (worst < 1.0e-4f) ? (kCullTau / inv_t + 2.0e-3f) : 3.0e38f;   // (+1 for residual fields: added by the kernels)
 }
 
 // Online soft-min over the instances, with the running minimum as the shift so that neither the

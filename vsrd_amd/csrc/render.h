@@ -85,16 +85,16 @@ __device__ __forceinline__ bool wave_any(bool pred) { return __ballot(pred) != 0
 // Evaluate the union at one point: a uniform loop over the instances with scalar parameter loads.
 // `lam` (LDS, or nullptr) are the per-instance label adjoints accumulated into sums.L by the backward.
 // On return dcache[i][lane] holds d_i for evaluated instances (a value > threshold on all lanes marks a culled one).
-template <bool kCacheDistances>
-__device__ __forceinline__ UnionValue eval_union(const float* __restrict__ instances, int num_instances, const Shading& sh,
-                                                 float x, float y, float z, float* dcache, int lane, const float* lam,
+template <bool kCacheDistances, bool kResidual>
+__device__ __forceinline__ UnionValue eval_union(const float* __restrict__ instances, const float* __restrict__ mlp, int num_instances,
+                                                 const Shading& sh, float x, float y, float z, float* dcache, int lane, const float* lam,
                                                  float* threshold_out, float* lam_z_out) {
     const float threshold = cull_prepass(instances, num_instances, sh.cull, x, y, z, dcache, lane);
     UnionSums sums = union_init();
     for (int i = 0; i < num_instances; ++i) {
         if (!wave_any(dcache[i * kWave + lane] <= threshold)) continue;        // wave-uniform skip
         const Instance in = load_instance(instances, i);
-        const BoxEval e = eval_box(in, x, y, z);
+        const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z);
         if (kCacheDistances) dcache[i * kWave + lane] = e.d;
         union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, sh.inv_t);
     }
@@ -108,8 +108,8 @@ __device__ __forceinline__ UnionValue eval_union(const float* __restrict__ insta
 //   weights[k]  <- compositing weight of sample (k*64 + lane)         (0 for padding lanes)
 //   return      <- lane i holds label i (sum_s w_s * softmin weight)  when kLabels
 //   grad_out / weight_out: this ray's [D-1,3] / [D-1] rows in HBM, or nullptr.
-template <int kRounds, bool kLabels>
-__device__ __forceinline__ float render_pass(const float* __restrict__ instances, int num_instances, const Shading& sh,
+template <int kRounds, bool kLabels, bool kResidual>
+__device__ __forceinline__ float render_pass(const float* __restrict__ instances, const float* __restrict__ mlp, int num_instances, const Shading& sh,
                                              const Ray& ray, const float* dist, int num_distances, float* dcache,
                                              float (&weights)[kRounds], float* grad_out, float* weight_out) {
     const int lane = lane_id();
@@ -128,7 +128,7 @@ __device__ __forceinline__ float render_pass(const float* __restrict__ instances
         const float mid = (d0 + d1) / 2.0f;
         const float x = ray.ox + ray.rx * mid, y = ray.oy + ray.ry * mid, z = ray.oz + ray.rz * mid;
         float threshold;
-        const UnionValue v = eval_union<kLabels>(instances, num_instances, sh, x, y, z, dcache, lane, nullptr, &threshold, nullptr);
+        const UnionValue v = eval_union<kLabels, kResidual>(instances, mlp, num_instances, sh, x, y, z, dcache, lane, nullptr, &threshold, nullptr);
         const Opacity op = opacity_of(v, ray, delta, sh);
         const float alpha = valid ? op.alpha : 0.0f;
         const float inclusive = wave_inclusive_product(1.0f - alpha);

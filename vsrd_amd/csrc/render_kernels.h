@@ -42,9 +42,9 @@ __device__ __forceinline__ Ray load_ray(const float* __restrict__ origins, const
 // ---------------------------------------------------------------------------------------------------
 // renderers.py:212-270 at given sorted distances [R,D]
 // ---------------------------------------------------------------------------------------------------
-template <int kRounds>
+template <int kRounds, bool kResidual>
 __global__ __launch_bounds__(kBlockThreads) void render_forward_kernel(
-    FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
+    FieldArgs f, const float* __restrict__ instances, const float* __restrict__ mlp, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
     const float* __restrict__ distances, int num_distances,
     float* __restrict__ labels, float* __restrict__ gradients, float* __restrict__ weights) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_forward_kernel(
     float* dist = lds + wave * per_wave;
     float* dcache = dist + num_distances;
     Shading sh = c.sh;
-    sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, f.num_instances, f.inv_t);
+    sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, f.num_instances, f.inv_t) + (kResidual ? 1.0f : 0.0f);
     const int stride = static_cast<int>(gridDim.x) * waves_per_block();
     for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
         const Ray r = load_ray(origins, directions, c.origin_stride, ray);
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_forward_kernel(
         float w[kRounds];
         float* g_out = gradients ? gradients + static_cast<size_t>(ray) * (num_distances - 1) * 3 : nullptr;
         float* w_out = weights ? weights + static_cast<size_t>(ray) * (num_distances - 1) : nullptr;
-        const float label = render_pass<kRounds, true>(instances, f.num_instances, sh, r, dist, num_distances, dcache, w, g_out, w_out);
+        const float label = render_pass<kRounds, true, kResidual>(instances, mlp, f.num_instances, sh, r, dist, num_distances, dcache, w, g_out, w_out);
         if (lane < f.num_instances) labels[static_cast<size_t>(ray) * f.num_instances + lane] = label;
         wave_lds_sync();
     }
@@ -73,9 +73,9 @@ __global__ __launch_bounds__(kBlockThreads) void render_forward_kernel(
 // ---------------------------------------------------------------------------------------------------
 // scripts/main.py:511-523 (two-pass wrapper) in one launch
 // ---------------------------------------------------------------------------------------------------
-template <int kRounds>
+template <int kRounds, bool kResidual>
 __global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
-    FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
+    FieldArgs f, const float* __restrict__ instances, const float* __restrict__ mlp, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
     const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
     float* __restrict__ labels, float* __restrict__ distances, float* __restrict__ gradients, float* __restrict__ weights,
     float* __restrict__ u_coarse_out, float* __restrict__ u_fine_out) {
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
     const WaveLds l = carve_lds(lds + wave * wave_lds_floats(S, f.num_instances), S);
     const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
     Shading sh = c.sh;
-    sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, f.num_instances, f.inv_t);
+    sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, f.num_instances, f.inv_t) + (kResidual ? 1.0f : 0.0f);
     const int stride = static_cast<int>(gridDim.x) * waves_per_block();
     for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
         const Ray r = load_ray(origins, directions, c.origin_stride, ray);
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
         }
         // ---- pass 1: coarse weights only (no labels, no outputs) ----------------------------------
         float w1[kRoundsS];
-        render_pass<kRoundsS, false>(instances, f.num_instances, sh, r, l.coarse, S, l.dcache, w1, nullptr, nullptr);
+        render_pass<kRoundsS, false, kResidual>(instances, mlp, f.num_instances, sh, r, l.coarse, S, l.dcache, w1, nullptr, nullptr);
         if (c.flags & 2u) {
             float total = 0.0f;
 #pragma unroll
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
         const int D = 2 * S;
         float* g_out = gradients ? gradients + static_cast<size_t>(ray) * (D - 1) * 3 : nullptr;
         float* w_out = weights ? weights + static_cast<size_t>(ray) * (D - 1) : nullptr;
-        const float label = render_pass<kRounds, true>(instances, f.num_instances, sh, r, l.merged, D, l.dcache, w2, g_out, w_out);
+        const float label = render_pass<kRounds, true, kResidual>(instances, mlp, f.num_instances, sh, r, l.merged, D, l.dcache, w2, g_out, w_out);
         if (lane < f.num_instances) labels[static_cast<size_t>(ray) * f.num_instances + lane] = label;
         if (distances != nullptr) {
             float* dst = distances + static_cast<size_t>(ray) * D;

@@ -56,7 +56,7 @@ class _RenderAtDistances(torch.autograd.Function):
     """renderers.py:212-270 at given sorted distances (ray-major [R,D])."""
 
     @staticmethod
-    def forward(ctx, instances, origins, directions, distances, temperature, scalars, origin_stride):
+    def forward(ctx, instances, mlp_weights, origins, directions, distances, temperature, scalars, origin_stride):
         lib = _lib.load()
         std, ratio, eps, near, far, num_samples = scalars
         R, D = distances.shape
@@ -65,13 +65,15 @@ class _RenderAtDistances(torch.autograd.Function):
         labels = torch.empty(R, N, dtype=torch.float32, device=distances.device)
         gradients = torch.empty(R, D - 1, 3, dtype=torch.float32, device=distances.device)
         weights = torch.empty(R, D - 1, dtype=torch.float32, device=distances.device)
-        field = _lib.make_field(instances, temperature)
+        mlp_weights = None if mlp_weights is None else mlp_weights.detach().contiguous()
+        field = _lib.make_field(instances, temperature, mlp_weights)
         config = _lib.make_config(R, num_samples, (near, far), std, ratio, eps, origin_stride, flags=_base_flags())
         with profiling.timed("vsrd_render_forward"):
             _lib.check(lib.vsrd_render_forward(field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(distances), D,
                                                _lib.ptr(labels), _lib.ptr(gradients), _lib.ptr(weights), _lib.stream()))
         ctx.save_for_backward(instances, origins, directions, distances)
         ctx.meta = (temperature, scalars, origin_stride)
+        ctx.residual = mlp_weights is not None
         ctx.set_materialize_grads(False)   # unused outputs arrive as None, not as zero tensors
         return labels, gradients, weights
 
@@ -79,8 +81,10 @@ class _RenderAtDistances(torch.autograd.Function):
     def backward(ctx, grad_labels, grad_gradients, grad_weights):
         instances, origins, directions, distances = ctx.saved_tensors
         temperature, scalars, origin_stride = ctx.meta
+        if ctx.residual:
+            raise NotImplementedError("backward through residual-MLP fields is not implemented yet (forward / inference only)")
         return (_backward(instances, origins, directions, distances, temperature, scalars, origin_stride,
-                          grad_labels, grad_gradients, grad_weights), None, None, None, None, None, None)
+                          grad_labels, grad_gradients, grad_weights), None, None, None, None, None, None, None)
 
 
 def _backward(instances, origins, directions, distances, temperature, scalars, origin_stride,
@@ -108,7 +112,7 @@ class _RenderHierarchical(torch.autograd.Function):
     """scripts/main.py:511-523 around renderers.py:177-270, both passes in one launch."""
 
     @staticmethod
-    def forward(ctx, instances, origins, directions, u_coarse, u_fine, temperature, scalars, origin_stride,
+    def forward(ctx, instances, mlp_weights, origins, directions, u_coarse, u_fine, temperature, scalars, origin_stride,
                 seed, stream_offset, flags, want_gradients, want_weights, want_uniforms):
         lib = _lib.load()
         std, ratio, eps, near, far, S = scalars
@@ -122,7 +126,9 @@ class _RenderHierarchical(torch.autograd.Function):
         weights = torch.empty(R, 2 * S - 1, dtype=torch.float32, device=dev) if want_weights else None
         uc_out = torch.empty(R, S, dtype=torch.float32, device=dev) if want_uniforms else None
         uf_out = torch.empty(R, S, dtype=torch.float32, device=dev) if want_uniforms else None
-        field = _lib.make_field(instances, temperature)
+        mlp_weights = None if mlp_weights is None else mlp_weights.detach().contiguous()
+        field = _lib.make_field(instances, temperature, mlp_weights)
+        ctx.residual = mlp_weights is not None
         config = _lib.make_config(R, S, (near, far), std, ratio, eps, origin_stride, seed, stream_offset, flags)
         with profiling.timed("vsrd_render_hierarchical_forward"):
             _lib.check(lib.vsrd_render_hierarchical_forward(
@@ -145,9 +151,11 @@ class _RenderHierarchical(torch.autograd.Function):
             grad_gradients = None
         if grad_weights is not None and grad_weights.numel() == 0:
             grad_weights = None
+        if ctx.residual:
+            raise NotImplementedError("backward through residual-MLP fields is not implemented yet (forward / inference only)")
         grad = _backward(instances, origins, directions, distances, temperature, scalars, origin_stride,
                          grad_labels, grad_gradients, grad_weights)
-        return (grad,) + (None,) * 13
+        return (grad,) + (None,) * 14
 
 
 def _scatter_labels(labels, block: FieldBlock):
@@ -162,12 +170,10 @@ def render_at_distances(distance_field, ray_positions, ray_directions, distances
                         cosine_ratio=1.0, epsilon=1.0e-6):
     """Ray-major core: distances [R,D] sorted -> (labels [R,N], gradients [R,D-1,3], weights [R,D-1])."""
     block = flatten(distance_field)
-    if block.mlp_weights is not None:
-        raise NotImplementedError("residual-MLP fields are not implemented in this round (SURVEY.md §8 row a9-a11)")
     origins, directions, stride, _ = _prepare_rays(ray_positions, ray_directions)
     distances = distances.to(torch.float32).contiguous()
     scalars = (float(sdf_std_deviation), float(cosine_ratio), float(epsilon), 0.0, 1.0, max(2, (distances.shape[1] + 1) // 2))
-    labels, gradients, weights = _RenderAtDistances.apply(block.instances, origins, directions, distances,
+    labels, gradients, weights = _RenderAtDistances.apply(block.instances, block.mlp_weights, origins, directions, distances,
                                                           block.temperature, scalars, stride)
     return _scatter_labels(labels, block), gradients, weights
 
@@ -178,8 +184,6 @@ def render_hierarchical(distance_field, ray_positions, ray_directions, distance_
     """Fused two-pass render.  Returns a dict: labels [R,N], distances [R,2S], optionally gradients
     [R,2S-1,3], weights [R,2S-1], u_coarse/u_fine [R,S] (the uniforms actually used)."""
     block = flatten(distance_field)
-    if block.mlp_weights is not None:
-        raise NotImplementedError("residual-MLP fields are not implemented in this round (SURVEY.md §8 row a9-a11)")
     origins, directions, stride, _ = _prepare_rays(ray_positions, ray_directions)
     if (u_coarse is None) != (u_fine is None):
         raise ValueError("pass both u_coarse and u_fine, or neither (in-kernel Philox)")
@@ -190,7 +194,7 @@ def render_hierarchical(distance_field, ray_positions, ray_directions, distance_
     scalars = (float(sdf_std_deviation), float(cosine_ratio), float(epsilon), float(distance_range[0]),
                float(distance_range[1]), int(num_samples))
     labels, gradients, weights, distances, uc, uf = _RenderHierarchical.apply(
-        block.instances, origins, directions, u_coarse, u_fine, block.temperature, scalars, stride,
+        block.instances, block.mlp_weights, origins, directions, u_coarse, u_fine, block.temperature, scalars, stride,
         int(seed), int(stream_offset), flags, bool(return_gradients), bool(return_weights), bool(return_uniforms))
     out = dict(labels=_scatter_labels(labels, block), distances=distances)
     if return_gradients:
@@ -222,8 +226,6 @@ def hierarchical_volumetric_rendering(
     """
     lib = _lib.load()
     block = flatten(distance_field)
-    if block.mlp_weights is not None:
-        raise NotImplementedError("residual-MLP fields are not implemented in this round (SURVEY.md §8 row a9-a11)")
     origins, directions, stride, lead = _prepare_rays(ray_positions, ray_directions)
     R = directions.shape[0]
     dev = directions.device
@@ -248,7 +250,7 @@ def hierarchical_volumetric_rendering(
                                                   _lib.ptr(distances), _lib.stream()))
     scalars = (float(sdf_std_deviation), float(cosine_ratio), float(epsilon), float(distance_range[0]),
                float(distance_range[1]), int(num_samples))
-    labels, gradients, weights = _RenderAtDistances.apply(block.instances, origins, directions, distances,
+    labels, gradients, weights = _RenderAtDistances.apply(block.instances, block.mlp_weights, origins, directions, distances,
                                                           block.temperature, scalars, stride)
     labels = _scatter_labels(labels, block)
     D = distances.shape[1]
@@ -265,8 +267,6 @@ def evaluate_field(distance_field, positions, with_gradients=False, with_labels=
     hard union / plain sdfs -> distances [...,1].  ``with_gradients`` adds the analytic normal [...,3]."""
     lib = _lib.load()
     block = flatten(distance_field)
-    if block.mlp_weights is not None:
-        raise NotImplementedError("residual-MLP fields are not implemented in this round")
     if with_labels is None:  # the soft union returns (distances, features); plain sdfs / hard unions distances only
         with_labels = (not block.hard) and (isinstance(distance_field, SoftUnion) or "distance_fields" in _closure_vars(distance_field))
     lead = positions.shape[:-1]
@@ -275,7 +275,8 @@ def evaluate_field(distance_field, positions, with_gradients=False, with_labels=
     distances = torch.empty(P, dtype=torch.float32, device=pts.device)
     gradients = torch.empty(P, 3, dtype=torch.float32, device=pts.device) if with_gradients else None
     labels = torch.empty(P, N, dtype=torch.float32, device=pts.device) if with_labels else None
-    field = _lib.make_field(block.instances.detach().contiguous(), block.temperature)
+    mlp = None if block.mlp_weights is None else block.mlp_weights.detach().contiguous()
+    field = _lib.make_field(block.instances.detach().contiguous(), block.temperature, mlp)
     _lib.check(lib.vsrd_field_eval(field, _lib.ptr(pts), P, _lib.ptr(distances), _lib.ptr(gradients), _lib.ptr(labels),
                                    1 if block.hard else 0, _lib.stream()))
     out = [distances.reshape(*lead, 1)]
