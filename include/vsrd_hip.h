@@ -77,8 +77,8 @@ typedef struct vsrd_render_config {
 int32_t vsrd_abi_version(void);
 const char* vsrd_error_string(int32_t code);
 
-/* Bytes of scratch vsrd_render_backward needs for a field of N instances. */
-size_t vsrd_workspace_bytes(int32_t num_instances);
+/* Bytes of scratch vsrd_render_backward needs for a field of N instances (residual != 0: with per-instance MLP). */
+size_t vsrd_workspace_bytes(int32_t num_instances, int32_t residual);
 
 /* vsrd.rendering.ray_casting (vsrd/rendering/utils.py:5-18), the per-pixel part:
  * directions[v,y,x,:] = normalize(inverse_projection[v] @ (x, y, 1)), integer pixel centres.
@@ -114,13 +114,14 @@ int32_t vsrd_render_forward(const vsrd_field* field, const vsrd_render_config* c
 /* Adjoint of vsrd_render_forward w.r.t. the packed instances (what autograd, including the
  * double-backward through the SDF normal, produces in the reference -- renderers.py:218-228).
  * grad_labels [R,N]; grad_gradients [R,D-1,3] or NULL; grad_weights [R,D-1] or NULL.
- * grad_instances [N,16] is OVERWRITTEN (pad column = 0).  workspace: vsrd_workspace_bytes(N). */
+ * grad_instances [N,16] is OVERWRITTEN (pad column = 0); grad_mlp_weights [N,1617] likewise (required iff the field
+ * carries mlp_weights, else NULL).  workspace: vsrd_workspace_bytes(N, residual). */
 int32_t vsrd_render_backward(const vsrd_field* field, const vsrd_render_config* config,
                              const float* origins, const float* directions,
                              const float* distances, int32_t num_distances,
                              const float* grad_labels, const float* grad_gradients, const float* grad_weights,
                              void* workspace, size_t workspace_bytes,
-                             float* grad_instances, void* stream);
+                             float* grad_instances, float* grad_mlp_weights, void* stream);
 
 /* The two-pass wrapper scripts/main.py:511-523 around renderers.py:177-270 in ONE launch:
  * pass 1 (stratified, no grad) -> importance sampling -> merge -> pass 2.

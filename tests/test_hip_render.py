@@ -241,6 +241,50 @@ def test_residual_field_forward_golden(dev, name):
     torch.testing.assert_close(grad.cpu(), og, rtol=5e-3, atol=5e-4)
 
 
+@pytest.mark.parametrize("name", RESIDUAL_CASES)
+def test_residual_field_backward_golden(dev, name):
+    """Config-3 backward: box parameters AND per-instance MLP weights, against the reference's autograd (G10) and against
+    float64 autograd through the oracle for random adjoints."""
+    from vsrd_amd import rendering, fields
+    g = load_golden(name)
+    S = int(g["num_samples"])
+    N = g["locations"].shape[0]
+    std, ratio = float(g["sdf_std_deviation"]), float(g["cosine_ratio"])
+    loc, dim, rot, mlp = (g[k].to(dev).requires_grad_(True) for k in ("locations", "dimensions", "orientations", "mlp_weights"))
+    union = fields.soft_union([
+        rendering.sdfs.translation(rendering.sdfs.rotation(fields.instance_field(
+            fields.residual_composition(rendering.sdfs.box(dim[i]), fields.ResidualField(mlp[i])), i, N), rot[i]), loc[i])
+        for i in range(N)], float(g["temperature"]))
+    out = rendering.render_hierarchical(union, g["origins"].to(dev), g["directions"].to(dev), (0.0, 100.0), S, std, ratio,
+                                        u_coarse=g["u_coarse"].to(dev), u_fine=g["u_fine"].to(dev), return_gradients=True)
+    miss = g["coarse_weights"].sum(0) == 0
+    bce = olosses.silhouette_loss(out["labels"], g["targets"].to(dev))
+    eik = olosses.eikonal_loss(out["gradients"][(~miss).to(dev)])
+    loss = bce + float(g["eikonal_weight"]) * eik
+    grads = torch.autograd.grad(loss, [loc, dim, rot, mlp])
+    for got, key in zip(grads, ("grad_locations", "grad_dimensions", "grad_orientations", "grad_mlp_weights")):
+        scale = max(float(g[key].abs().max()), 1e-6)
+        err = (got.cpu() - g[key]).abs().max().item() / scale
+        assert err < 2e-2, f"{key}: relative error {err:.3e}"
+    # given distances + random adjoints vs float64 autograd through the oracle (isolates the kernel from the sampler)
+    dist = g["fine_distances"].t().contiguous()
+    keep = ~miss
+    labels, gradients, weights = rendering.render_at_distances(union, g["origins"][keep].to(dev), g["directions"][keep].to(dev),
+                                                               dist[keep].to(dev), std, ratio)
+    gen = torch.Generator().manual_seed(0)
+    lam = torch.randn(labels.shape, generator=gen)
+    gam = torch.randn(gradients.shape, generator=gen) * 0.05
+    om = torch.randn(weights.shape, generator=gen) * 0.1
+    got = torch.autograd.grad([labels, gradients, weights], [loc, dim, rot, mlp], [lam.to(dev), gam.to(dev), om.to(dev)])
+    l64, d64, r64, m64 = (g[k].double().requires_grad_(True) for k in ("locations", "dimensions", "orientations", "mlp_weights"))
+    ou = ofields.InstanceUnion(l64, r64, d64, float(g["temperature"]), m64)
+    o = orendering.render_given_distances(ou, g["origins"][keep].double(), g["directions"][keep].double(), dist[keep].double(), std, ratio)
+    want = torch.autograd.grad([o.labels, o.gradients, o.weights], [l64, d64, r64, m64], [lam.double(), gam.double(), om.double()])
+    for a, b, key in zip(got, want, ("locations", "dimensions", "orientations", "mlp_weights")):
+        err = (a.cpu().double() - b).abs().max().item() / max(b.abs().max().item(), 1e-9)
+        assert err < 1e-2, f"{key}: relative error {err:.3e}"
+
+
 def test_philox_mode_matches_oracle_on_exported_uniforms(dev):
     from vsrd_amd import rendering
     g = load_golden("g4_render_n4_s32_mid")

@@ -54,7 +54,7 @@ class RenderConfig(ctypes.Structure):
 SIGNATURES = {
     "vsrd_abi_version": (ctypes.c_int32, []),
     "vsrd_error_string": (ctypes.c_char_p, [ctypes.c_int32]),
-    "vsrd_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32]),
+    "vsrd_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
     "vsrd_ray_directions": (ctypes.c_int32, [c_float_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_float_p, ctypes.c_void_p]),
     "vsrd_field_eval": (ctypes.c_int32, [ctypes.POINTER(Field), c_float_p, ctypes.c_int64, c_float_p, c_float_p, c_float_p,
                                          ctypes.c_int32, ctypes.c_void_p]),
@@ -64,7 +64,7 @@ SIGNATURES = {
                                              ctypes.c_int32, c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
     "vsrd_render_backward": (ctypes.c_int32, [ctypes.POINTER(Field), ctypes.POINTER(RenderConfig), c_float_p, c_float_p, c_float_p,
                                               ctypes.c_int32, c_float_p, c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_size_t,
-                                              c_float_p, ctypes.c_void_p]),
+                                              c_float_p, c_float_p, ctypes.c_void_p]),
     "vsrd_render_hierarchical_forward": (ctypes.c_int32, [ctypes.POINTER(Field), ctypes.POINTER(RenderConfig), c_float_p, c_float_p,
                                                           c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
                                                           c_float_p, c_float_p, ctypes.c_void_p]),

@@ -86,8 +86,12 @@ int rounds_for(int points) {
     return 0;
 }
 
-size_t partial_floats(int num_instances) {
-    return static_cast<size_t>(kMaxBlocks) * kMaxWavesPerBlock * num_instances * kGradStride;
+constexpr int kMaxBlocksResidual = 256;     // the residual kernels run one wave per SIMD: 256 CUs x 1 workgroup
+
+size_t partial_floats(int num_instances, bool residual) {
+    const size_t box = static_cast<size_t>(kMaxBlocks) * kMaxWavesPerBlock * num_instances * kGradStride;
+    const size_t mlp = residual ? static_cast<size_t>(kMaxBlocksResidual) * kMaxWavesPerBlock * num_instances * kMlpWeights : 0;
+    return box + mlp;
 }
 
 }  // namespace
@@ -107,9 +111,9 @@ const char* vsrd_error_string(int32_t code) {
     }
 }
 
-size_t vsrd_workspace_bytes(int32_t num_instances) {
+size_t vsrd_workspace_bytes(int32_t num_instances, int32_t residual) {
     if (num_instances < 1 || num_instances > VSRD_MAX_INSTANCES) return 0;
-    return partial_floats(num_instances) * sizeof(float);
+    return partial_floats(num_instances, residual != 0) * sizeof(float);
 }
 
 int32_t vsrd_ray_directions(const float* inverse_projection, int32_t num_views, int32_t height, int32_t width,
@@ -218,38 +222,55 @@ int32_t vsrd_render_backward(const vsrd_field* field, const vsrd_render_config* 
                              const float* distances, int32_t num_distances,
                              const float* grad_labels, const float* grad_gradients, const float* grad_weights,
                              void* workspace, size_t workspace_bytes,
-                             float* grad_instances, void* stream) {
+                             float* grad_instances, float* grad_mlp_weights, void* stream) {
     if (!valid_field(field) || !valid_config(config) || !grad_instances || !workspace || num_distances < 2 ||
         num_distances > 2 * VSRD_MAX_SAMPLES)
         return VSRD_E_INVALID_ARGUMENT;
     if (config->num_rays > 0 && (!origins || !directions || !distances || !grad_labels)) return VSRD_E_INVALID_ARGUMENT;
-    if (field->mlp_weights != nullptr) return VSRD_E_UNSUPPORTED;
+    const bool residual = field->mlp_weights != nullptr;
+    if (residual && !grad_mlp_weights) return VSRD_E_INVALID_ARGUMENT;
     const int N = field->num_instances;
-    if (workspace_bytes < vsrd_workspace_bytes(N)) return VSRD_E_WORKSPACE;
+    if (workspace_bytes < vsrd_workspace_bytes(N, residual)) return VSRD_E_WORKSPACE;
     const hipStream_t s = static_cast<hipStream_t>(stream);
     const int row = N * kGradStride;
+    const int mlp_row = N * kMlpWeights;
     if (config->num_rays == 0) {
+        if (residual && hipMemsetAsync(grad_mlp_weights, 0, mlp_row * sizeof(float), s) != hipSuccess) return VSRD_E_LAUNCH;
         return hipMemsetAsync(grad_instances, 0, row * sizeof(float), s) == hipSuccess ? VSRD_OK : VSRD_E_LAUNCH;
     }
     Geometry g;
-    if (!plan(config->num_rays, static_cast<size_t>(num_distances) + N + row, &g)) return VSRD_E_UNSUPPORTED;
+    if (!plan(config->num_rays, static_cast<size_t>(num_distances) + N + row + (residual ? kMlpWeights : 0), &g)) return VSRD_E_UNSUPPORTED;
+    if (residual && g.blocks > kMaxBlocksResidual) g.blocks = kMaxBlocksResidual;
     const FieldArgs f = field_args(field);
     RenderArgs c = render_args(config);
     c.sh.inv_t = f.inv_t;
     float* partials = static_cast<float*>(workspace);
-#define VSRD_LAUNCH(K)                                                                                                       \
-    hipLaunchKernelGGL(render_backward_kernel<K>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins, directions, \
-                       distances, num_distances, grad_labels, grad_gradients, grad_weights, partials)
-    switch (rounds_for(num_distances - 1)) {
-        case 1: VSRD_LAUNCH(1); break;
-        case 2: VSRD_LAUNCH(2); break;
-        case 4: VSRD_LAUNCH(4); break;
-        default: return VSRD_E_UNSUPPORTED;
+    float* mlp_partials = partials + static_cast<size_t>(kMaxBlocks) * kMaxWavesPerBlock * row;
+#define VSRD_LAUNCH(K, RES)                                                                                                    \
+    hipLaunchKernelGGL((render_backward_kernel<K, RES>), dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances,    \
+                       field->mlp_weights, c, origins, directions, distances, num_distances, grad_labels, grad_gradients,         \
+                       grad_weights, partials, mlp_partials)
+    const int rounds = rounds_for(num_distances - 1);
+    if (residual) {
+        switch (rounds) {
+            case 1: VSRD_LAUNCH(1, true); break;
+            case 2: VSRD_LAUNCH(2, true); break;
+            default: return VSRD_E_UNSUPPORTED;
+        }
+    } else {
+        switch (rounds) {
+            case 1: VSRD_LAUNCH(1, false); break;
+            case 2: VSRD_LAUNCH(2, false); break;
+            case 4: VSRD_LAUNCH(4, false); break;
+            default: return VSRD_E_UNSUPPORTED;
+        }
     }
 #undef VSRD_LAUNCH
     if (launch_status() != VSRD_OK) return VSRD_E_LAUNCH;
     const int num_waves = g.blocks * (g.threads / kWave);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(row), dim3(256), 0, s, partials, num_waves, row, grad_instances);
+    if (residual)
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(mlp_row), dim3(256), 0, s, mlp_partials, num_waves, mlp_row, grad_mlp_weights);
     return launch_status();
 }
 

@@ -166,25 +166,33 @@ struct SampleAdjoint {
     float A, B;           // g_bar . g,  g_bar . sum_i w_i grad d_i
 };
 
-template <int kRounds>
+template <int kRounds, bool kResidual>
 __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
-    FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
+    FieldArgs f, const float* __restrict__ instances, const float* __restrict__ mlp, RenderArgs c,
+    const float* __restrict__ origins, const float* __restrict__ directions,
     const float* __restrict__ distances, int num_distances,
     const float* __restrict__ grad_labels, const float* __restrict__ grad_gradients, const float* __restrict__ grad_weights,
-    float* __restrict__ partials) {
+    float* __restrict__ partials, float* __restrict__ mlp_partials) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = wave_in_block();
     const int lane = lane_id();
     const int N = f.num_instances;
     const int num_points = num_distances - 1;
-    const int per_wave = num_distances + N + N * kGradStride;
+    const int per_wave = num_distances + N + N * kGradStride + (kResidual ? kMlpWeights : 0);
     float* dist = lds + wave * per_wave;
     float* lam = dist + num_distances;
     float* G = lam + N;
+    float* wbar = G + N * kGradStride;                                   // [1617] MLP weight adjoints of the current instance
     for (int idx = lane; idx < N * kGradStride; idx += kWave) G[idx] = 0.0f;
+    const size_t wave_global0 = static_cast<size_t>(blockIdx.x) * waves_per_block() + wave;
+    float* my_mlp = kResidual ? mlp_partials + wave_global0 * (static_cast<size_t>(N) * kMlpWeights) : nullptr;
+    if (kResidual) {
+        for (int idx = lane; idx < N * kMlpWeights; idx += kWave) my_mlp[idx] = 0.0f;
+        for (int idx = lane; idx < kMlpWeights; idx += kWave) wbar[idx] = 0.0f;
+    }
     const float inv_t = f.inv_t;
     Shading sh = c.sh;
-    sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, N, inv_t);
+    sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, N, inv_t) + (kResidual ? 1.0f : 0.0f);
     const int stride = static_cast<int>(gridDim.x) * waves_per_block();
     for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
         wave_lds_sync();
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
                 const Instance in = load_instance(instances, i);
                 const float lb = centre_distance(in, sa[k].x, sa[k].y, sa[k].z) * (1.0f - kCullSlack) - bounding_radius(in);
                 if (!wave_any(lb <= thr[k])) continue;
-                const BoxEval e = eval_box(in, sa[k].x, sa[k].y, sa[k].z);
+                const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, sa[k].x, sa[k].y, sa[k].z);
                 union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lam[i], inv_t);
             }
             const UnionValue v = union_finish(sums, inv_t);
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
 #pragma unroll
             for (int k = 0; k < kRounds; ++k) {
                 if (!active[k]) continue;
-                const BoxEval e = eval_box(in, sa[k].x, sa[k].y, sa[k].z);
+                const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, sa[k].x, sa[k].y, sa[k].z);
                 const float ds = e.d - sa[k].m;
                 const float w = fast_exp(-ds * inv_t) * sa[k].inv_z;
                 const float cc = w * (1.0f - (ds - sa[k].us) * inv_t);
@@ -323,8 +331,12 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
                 const float qbx = d_bar * e.hx + ((e.qx > 0.0f) ? (vx - hx * hv) * inv_n : 0.0f);
                 const float qby = d_bar * e.hy + ((e.qy > 0.0f) ? (vy - hy * hv) * inv_n : 0.0f);
                 const float qbz = d_bar * e.hz + ((e.qz > 0.0f) ? (vz - hz * hv) * inv_n : 0.0f);
-                const float pbx = sx * qbx, pby = sy * qby, pbz = sz * qbz;
+                float pbx = sx * qbx, pby = sy * qby, pbz = sz * qbz;
                 ad0 -= qbx; ad1 -= qby; ad2 -= qbz;
+                if (kResidual) {        // residual(p): value adjoint d_bar, local-gradient adjoint gl_bar (main.py:451-458)
+                    const ResidualAdjoint ra = residual_backward(mlp + i * kMlpWeights, e.px, e.py, e.pz, d_bar, glbx, glby, glbz, wbar, lane);
+                    pbx += ra.px; pby += ra.py; pbz += ra.pz;
+                }
                 r00 += e.relx * pbx + gwbx * e.glx; r01 += e.relx * pby + gwbx * e.gly; r02 += e.relx * pbz + gwbx * e.glz;
                 r10 += e.rely * pbx + gwby * e.glx; r11 += e.rely * pby + gwby * e.gly; r12 += e.rely * pbz + gwby * e.glz;
                 r20 += e.relz * pbx + gwbz * e.glx; r21 += e.relz * pby + gwbz * e.gly; r22 += e.relz * pbz + gwbz * e.glz;
@@ -336,6 +348,10 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
             const float packed[16] = {at0, at1, at2, r00, r01, r02, r10, r11, r12, r20, r21, r22, ad0, ad1, ad2, 0.0f};
             const float mine = wave_reduce16_scatter(packed, lane);
             if (lane < kGradStride) G[i * kGradStride + lane] += mine;
+            if (kResidual) {            // flush this instance's MLP weight adjoints into the wave's global row (wave-private RMW)
+                float* dst = my_mlp + static_cast<size_t>(i) * kMlpWeights;
+                for (int idx = lane; idx < kMlpWeights; idx += kWave) { dst[idx] += wbar[idx]; wbar[idx] = 0.0f; }
+            }
         }
     }
     wave_lds_sync();

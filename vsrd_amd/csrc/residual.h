@@ -138,4 +138,218 @@ __device__ __forceinline__ Residual residual_forward(const float* __restrict__ w
     return r;
 }
 
+// ---- adjoint ------------------------------------------------------------------------------------------------
+// Blueprint: oracle/analytic_mlp.py::backward (float64, checked against autograd).  One lane = one sample.
+// Weight adjoints are reduced over the 64 lanes 16 values at a time with the reduce-scatter butterfly and added
+// into the wave's LDS row `wbar` [1617] (lane j < 16 owns column j of the current weight row: thread-private
+// addresses, no hazards).
+
+// What the adjoint of one [LayerNorm -> GELU -> Linear] block needs, recomputed from the block's input jet.
+struct BlockState {
+    float y[kMlpHidden], g1[kMlpHidden], g2[kMlpHidden];   // normalised value, GELU', pdf(y)(2 - y^2)
+    float dy[3][kMlpHidden];
+    float a[kMlpHidden], da[3][kMlpHidden];                // activations fed to the linear
+    float q[3];                                            // mean(y * dz_c)
+    float inv_s;
+};
+
+__device__ __forceinline__ void block_state(const Jet16& z, BlockState& b) {
+    float mean = 0.0f;
+#pragma unroll
+    for (int o = 0; o < kMlpHidden; ++o) mean += z.v[o];
+    mean *= (1.0f / kMlpHidden);
+    float var = 0.0f;
+#pragma unroll
+    for (int o = 0; o < kMlpHidden; ++o) { b.y[o] = z.v[o] - mean; var += b.y[o] * b.y[o]; }
+    b.inv_s = __builtin_amdgcn_rsqf(var * (1.0f / kMlpHidden) + kLayerNormEps);
+    float tmean[3] = {0.0f, 0.0f, 0.0f};
+    b.q[0] = b.q[1] = b.q[2] = 0.0f;
+#pragma unroll
+    for (int o = 0; o < kMlpHidden; ++o) {
+        b.y[o] *= b.inv_s;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { tmean[c] += z.t[c][o]; b.q[c] += b.y[o] * z.t[c][o]; }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { tmean[c] *= (1.0f / kMlpHidden); b.q[c] *= (1.0f / kMlpHidden); }
+#pragma unroll
+    for (int o = 0; o < kMlpHidden; ++o) {
+        const float y = b.y[o];
+        const float cdf = gauss_cdf(y), pdf = gauss_pdf(y);
+        b.g1[o] = cdf + y * pdf;
+        b.g2[o] = pdf * (2.0f - y * y);
+        b.a[o] = y * cdf;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            b.dy[c][o] = (z.t[c][o] - tmean[c] - y * b.q[c]) * b.inv_s;
+            b.da[c][o] = b.dy[c][o] * b.g1[o];
+        }
+    }
+}
+
+// P(v) = (v - mean(v) - y mean(v y)) / s  (LayerNorm's symmetric Jacobian), in place on 16 values.
+__device__ __forceinline__ void layer_norm_adjoint(float (&v)[kMlpHidden], const BlockState& b) {
+    float m = 0.0f, my = 0.0f;
+#pragma unroll
+    for (int o = 0; o < kMlpHidden; ++o) { m += v[o]; my += v[o] * b.y[o]; }
+    m *= (1.0f / kMlpHidden); my *= (1.0f / kMlpHidden);
+#pragma unroll
+    for (int o = 0; o < kMlpHidden; ++o) v[o] = (v[o] - m - b.y[o] * my) * b.inv_s;
+}
+
+// Adjoint of one block: (z_bar, dz_bar) of the linear's kOut outputs -> adjoint of the block's input jet (returned in zb),
+// weight adjoints of the linear accumulated into wbar (row-major [kOut][17]).
+template <int kOut>
+__device__ __forceinline__ void block_adjoint(const float* __restrict__ w, const Jet16& z_in, Jet16& zb, float* wbar, int lane) {
+    BlockState b;
+    block_state(z_in, b);
+    float a_bar[kMlpHidden], da_bar[3][kMlpHidden];
+#pragma unroll
+    for (int j = 0; j < kMlpHidden; ++j) { a_bar[j] = 0.0f; da_bar[0][j] = da_bar[1][j] = da_bar[2][j] = 0.0f; }
+    float bias[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) bias[o] = 0.0f;
+#pragma unroll
+    for (int o = 0; o < kOut; ++o) {
+        const float* row = w + o * (kMlpHidden + 1);
+        float prod[16];
+#pragma unroll
+        for (int j = 0; j < kMlpHidden; ++j) {
+            prod[j] = zb.v[o] * b.a[j] + zb.t[0][o] * b.da[0][j] + zb.t[1][o] * b.da[1][j] + zb.t[2][o] * b.da[2][j];
+            const float wj = row[j];
+            a_bar[j] += wj * zb.v[o];
+            da_bar[0][j] += wj * zb.t[0][o]; da_bar[1][j] += wj * zb.t[1][o]; da_bar[2][j] += wj * zb.t[2][o];
+        }
+        const float r = wave_reduce16_scatter(prod, lane);
+        if (lane < kMlpHidden) wbar[o * (kMlpHidden + 1) + lane] += r;
+        bias[o] = zb.v[o];
+    }
+    {
+        const float r = wave_reduce16_scatter(bias, lane);
+        if (lane < kOut) wbar[lane * (kMlpHidden + 1) + kMlpHidden] += r;
+    }
+    // GELU jet adjoint
+    float y_bar[kMlpHidden];
+    float dyb[3][kMlpHidden];
+    float s_bar = 0.0f;
+    float dot[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < kMlpHidden; ++j) {
+        float cross = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            cross += da_bar[c][j] * b.dy[c][j];
+            dyb[c][j] = da_bar[c][j] * b.g1[j];
+            s_bar -= dyb[c][j] * b.dy[c][j];
+            dot[c] += dyb[c][j] * b.y[j];
+        }
+        y_bar[j] = a_bar[j] * b.g1[j] + cross * b.g2[j];
+    }
+    s_bar *= b.inv_s;
+    // LayerNorm jet adjoint: explicit dependence of dy on (y, s), then through y = (z - mean)/s
+#pragma unroll
+    for (int j = 0; j < kMlpHidden; ++j) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            y_bar[j] -= (dyb[c][j] * b.q[c] + z_in.t[c][j] * dot[c] * (1.0f / kMlpHidden)) * b.inv_s;
+    }
+    layer_norm_adjoint(y_bar, b);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) layer_norm_adjoint(dyb[c], b);
+#pragma unroll
+    for (int j = 0; j < kMlpHidden; ++j) {
+        zb.v[j] = y_bar[j] + s_bar * b.y[j] * (1.0f / kMlpHidden);
+        zb.t[0][j] = dyb[0][j]; zb.t[1][j] = dyb[1][j]; zb.t[2][j] = dyb[2][j];
+    }
+}
+
+struct ResidualAdjoint { float px, py, pz; };
+
+// Adjoint of residual_forward at local position p: res_bar = dL/d residual, (gbx,gby,gbz) = dL/d(grad_p residual).
+// Accumulates dL/dw into wbar (LDS, [1617]); returns dL/dp.
+__device__ __forceinline__ ResidualAdjoint residual_backward(const float* __restrict__ w, float px, float py, float pz,
+                                                             float res_bar, float gbx, float gby, float gbz, float* wbar, int lane) {
+    const float fold = (px > 0.0f) ? 1.0f : ((px < 0.0f) ? -1.0f : 0.0f);
+    const float inv = 1.0f / kPositionScale;
+    const float f[3] = {fabsf(px) * inv, py * inv, pz * inv};
+    const float folds[3] = {fold, 1.0f, 1.0f};
+    // ---- forward with the four block inputs kept (z0 = first layer output, z1..z3 = hidden linear outputs) -----------
+    Jet16 z0, z1, z2, z3, a, out;
+    mlp_first_layer(w, f[0], f[1], f[2], z0);
+    const float* w1 = w + (kMlpFeatures + 1) * kMlpHidden;
+    const float* w2 = w1 + (kMlpHidden + 1) * kMlpHidden;
+    const float* w3 = w2 + (kMlpHidden + 1) * kMlpHidden;
+    const float* w4 = w3 + (kMlpHidden + 1) * kMlpHidden;
+    a = z0; mlp_norm_gelu(a); mlp_linear<kMlpHidden>(w1, a, z1);
+    a = z1; mlp_norm_gelu(a); mlp_linear<kMlpHidden>(w2, a, z2);
+    a = z2; mlp_norm_gelu(a); mlp_linear<kMlpHidden>(w3, a, z3);
+    a = z3; mlp_norm_gelu(a); mlp_linear<1>(w4, a, out);
+    const float res = fast_rcp(1.0f + fast_exp(-(out.v[0] - 1.0f)));
+    const float kappa = res * (1.0f - res);
+    const float gb[3] = {gbx, gby, gbz};
+    // ---- adjoint of the sigmoid head -----------------------------------------------------------------------------------
+    Jet16 zb;
+    float kappa_bar = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        zb.t[c][0] = gb[c] * kappa * folds[c] * inv;
+        kappa_bar += gb[c] * out.t[c][0] * folds[c] * inv;
+    }
+    zb.v[0] = (res_bar + kappa_bar * (1.0f - 2.0f * res)) * kappa;
+    // ---- blocks 4..1 ---------------------------------------------------------------------------------------------------
+    const int off1 = (kMlpFeatures + 1) * kMlpHidden, blk = (kMlpHidden + 1) * kMlpHidden;
+    block_adjoint<1>(w4, z3, zb, wbar + off1 + 3 * blk, lane);
+    block_adjoint<kMlpHidden>(w3, z2, zb, wbar + off1 + 2 * blk, lane);
+    block_adjoint<kMlpHidden>(w2, z1, zb, wbar + off1 + blk, lane);
+    block_adjoint<kMlpHidden>(w1, z0, zb, wbar + off1, lane);
+    // ---- first layer + encoder -----------------------------------------------------------------------------------------
+    float f_bar[3] = {0.0f, 0.0f, 0.0f};
+    float bias[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) bias[o] = zb.v[o];
+    {
+        const float r = wave_reduce16_scatter(bias, lane);
+        if (lane < kMlpHidden) wbar[lane * (kMlpFeatures + 1) + kMlpFeatures] += r;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float feat[16], dfeat[16], feat_bar[16], dfeat_bar[16];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float octave = static_cast<float>(1 << k);
+            const float x = f[c] * octave;
+            const float s = sinpif(x), co = cospif(x);
+            const float omega = octave * 3.14159265358979323846f;
+            feat[2 * k] = co; feat[2 * k + 1] = s;
+            dfeat[2 * k] = -omega * s; dfeat[2 * k + 1] = omega * co;
+            feat_bar[2 * k] = feat_bar[2 * k + 1] = 0.0f;
+            dfeat_bar[2 * k] = dfeat_bar[2 * k + 1] = 0.0f;
+        }
+#pragma unroll
+        for (int o = 0; o < kMlpHidden; ++o) {
+            const float* row = w + o * (kMlpFeatures + 1) + c * 16;
+            float prod[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                prod[j] = zb.v[o] * feat[j] + zb.t[c][o] * dfeat[j];
+                const float wj = row[j];
+                feat_bar[j] += wj * zb.v[o];
+                dfeat_bar[j] += wj * zb.t[c][o];
+            }
+            const float r = wave_reduce16_scatter(prod, lane);
+            if (lane < 16) wbar[o * (kMlpFeatures + 1) + c * 16 + lane] += r;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float omega = static_cast<float>(1 << k) * 3.14159265358979323846f;
+            const float co = feat[2 * k], s = feat[2 * k + 1];
+            f_bar[c] += feat_bar[2 * k] * (-omega * s) + feat_bar[2 * k + 1] * (omega * co)
+                      + dfeat_bar[2 * k] * (-omega * omega * co) + dfeat_bar[2 * k + 1] * (-omega * omega * s);
+        }
+    }
+    ResidualAdjoint r;
+    r.px = f_bar[0] * fold * inv; r.py = f_bar[1] * inv; r.pz = f_bar[2] * inv;
+    return r;
+}
+
 }  // namespace vsrd

@@ -31,11 +31,11 @@ def _base_flags():
     return 0 if CULLING else _lib.FLAG_NO_CULLING
 
 
-def _workspace(device, num_instances):
-    key = (device, num_instances)
+def _workspace(device, num_instances, residual=False):
+    key = (device, num_instances, bool(residual))
     buf = _workspaces.get(key)
     if buf is None:
-        nbytes = _lib.load().vsrd_workspace_bytes(num_instances)
+        nbytes = _lib.load().vsrd_workspace_bytes(num_instances, 1 if residual else 0)
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _workspaces[key] = buf
     return buf
@@ -71,23 +71,22 @@ class _RenderAtDistances(torch.autograd.Function):
         with profiling.timed("vsrd_render_forward"):
             _lib.check(lib.vsrd_render_forward(field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(distances), D,
                                                _lib.ptr(labels), _lib.ptr(gradients), _lib.ptr(weights), _lib.stream()))
-        ctx.save_for_backward(instances, origins, directions, distances)
-        ctx.meta = (temperature, scalars, origin_stride)
         ctx.residual = mlp_weights is not None
+        ctx.save_for_backward(instances, origins, directions, distances, *([mlp_weights] if ctx.residual else []))
+        ctx.meta = (temperature, scalars, origin_stride)
         ctx.set_materialize_grads(False)   # unused outputs arrive as None, not as zero tensors
         return labels, gradients, weights
 
     @staticmethod
     def backward(ctx, grad_labels, grad_gradients, grad_weights):
-        instances, origins, directions, distances = ctx.saved_tensors
+        instances, origins, directions, distances, *rest = ctx.saved_tensors
         temperature, scalars, origin_stride = ctx.meta
-        if ctx.residual:
-            raise NotImplementedError("backward through residual-MLP fields is not implemented yet (forward / inference only)")
-        return (_backward(instances, origins, directions, distances, temperature, scalars, origin_stride,
-                          grad_labels, grad_gradients, grad_weights), None, None, None, None, None, None, None)
+        grad_instances, grad_mlp = _backward(instances, rest[0] if rest else None, origins, directions, distances, temperature, scalars,
+                                             origin_stride, grad_labels, grad_gradients, grad_weights)
+        return (grad_instances, grad_mlp, None, None, None, None, None, None)
 
 
-def _backward(instances, origins, directions, distances, temperature, scalars, origin_stride,
+def _backward(instances, mlp_weights, origins, directions, distances, temperature, scalars, origin_stride,
               grad_labels, grad_gradients, grad_weights):
     lib = _lib.load()
     std, ratio, eps, near, far, num_samples = scalars
@@ -98,14 +97,16 @@ def _backward(instances, origins, directions, distances, temperature, scalars, o
     grad_gradients = None if grad_gradients is None else grad_gradients.to(torch.float32).contiguous()
     grad_weights = None if grad_weights is None else grad_weights.to(torch.float32).contiguous()
     grad_instances = torch.empty_like(instances)
-    workspace = _workspace(distances.device, N)
-    field = _lib.make_field(instances, temperature)
+    grad_mlp = None if mlp_weights is None else torch.empty_like(mlp_weights)
+    workspace = _workspace(distances.device, N, mlp_weights is not None)
+    field = _lib.make_field(instances, temperature, mlp_weights)
     config = _lib.make_config(R, num_samples, (near, far), std, ratio, eps, origin_stride, flags=_base_flags())
     with profiling.timed("vsrd_render_backward"):
         _lib.check(lib.vsrd_render_backward(field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(distances), D,
                                             _lib.ptr(grad_labels), _lib.ptr(grad_gradients), _lib.ptr(grad_weights),
-                                            workspace.data_ptr(), workspace.numel(), _lib.ptr(grad_instances), _lib.stream()))
-    return grad_instances
+                                            workspace.data_ptr(), workspace.numel(), _lib.ptr(grad_instances), _lib.ptr(grad_mlp),
+                                            _lib.stream()))
+    return grad_instances, grad_mlp
 
 
 class _RenderHierarchical(torch.autograd.Function):
@@ -129,6 +130,7 @@ class _RenderHierarchical(torch.autograd.Function):
         mlp_weights = None if mlp_weights is None else mlp_weights.detach().contiguous()
         field = _lib.make_field(instances, temperature, mlp_weights)
         ctx.residual = mlp_weights is not None
+        ctx.mlp = mlp_weights
         config = _lib.make_config(R, S, (near, far), std, ratio, eps, origin_stride, seed, stream_offset, flags)
         with profiling.timed("vsrd_render_hierarchical_forward"):
             _lib.check(lib.vsrd_render_hierarchical_forward(
@@ -151,11 +153,9 @@ class _RenderHierarchical(torch.autograd.Function):
             grad_gradients = None
         if grad_weights is not None and grad_weights.numel() == 0:
             grad_weights = None
-        if ctx.residual:
-            raise NotImplementedError("backward through residual-MLP fields is not implemented yet (forward / inference only)")
-        grad = _backward(instances, origins, directions, distances, temperature, scalars, origin_stride,
-                         grad_labels, grad_gradients, grad_weights)
-        return (grad,) + (None,) * 14
+        grad, grad_mlp = _backward(instances, ctx.mlp, origins, directions, distances, temperature, scalars, origin_stride,
+                                   grad_labels, grad_gradients, grad_weights)
+        return (grad, grad_mlp) + (None,) * 13
 
 
 def _scatter_labels(labels, block: FieldBlock):
