@@ -265,7 +265,8 @@ def test_residual_field_backward_golden(dev, name):
     for got, key in zip(grads, ("grad_locations", "grad_dimensions", "grad_orientations", "grad_mlp_weights")):
         scale = max(float(g[key].abs().max()), 1e-6)
         err = (got.cpu() - g[key]).abs().max().item() / scale
-        assert err < 2e-2, f"{key}: relative error {err:.3e}"
+        print(f"[residual golden] {key}: rel err {err:.3e}")
+        assert err < 2e-3, f"{key}: relative error {err:.3e}"
     # given distances + random adjoints vs float64 autograd through the oracle (isolates the kernel from the sampler)
     dist = g["fine_distances"].t().contiguous()
     keep = ~miss
@@ -282,7 +283,8 @@ def test_residual_field_backward_golden(dev, name):
     want = torch.autograd.grad([o.labels, o.gradients, o.weights], [l64, d64, r64, m64], [lam.double(), gam.double(), om.double()])
     for a, b, key in zip(got, want, ("locations", "dimensions", "orientations", "mlp_weights")):
         err = (a.cpu().double() - b).abs().max().item() / max(b.abs().max().item(), 1e-9)
-        assert err < 1e-2, f"{key}: relative error {err:.3e}"
+        print(f"[residual f64 oracle] {key}: rel err {err:.3e}")
+        assert err < 2e-3, f"{key}: relative error {err:.3e}"
 
 
 def test_philox_mode_matches_oracle_on_exported_uniforms(dev):

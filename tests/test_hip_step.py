@@ -143,3 +143,50 @@ def test_five_optimisation_steps_match_oracle(dev):
     # the loop also runs with its own in-kernel randomness and sampling
     losses_free = device_loop.step()
     assert torch.isfinite(losses_free["loss"])
+
+
+def test_residual_phase_step_matches_oracle(dev):
+    """Post-warm-up step (config 3 shape): hypernetwork -> per-instance MLP weights -> residual field + eikonal loss, gradients
+    into boxes, embeddings and hypernetwork, against the CPU oracle step with identical weights and randomness."""
+    from vsrd_amd import optimization, rendering, fields
+    V, H, W, N, S, R = 3, 128, 128, 4, 32, 256
+    K, E, (loc, dim, rot), gt_boxes, visible = c1_frame()
+    cam, dirs = rendering.ray_casting((H, W), K.to(dev), E.to(dev))
+    block = fields.FieldBlock(fields.pack_instances(loc.to(dev), rot.to(dev), dim.to(dev)), 0.1, None, None)
+    origins = cam[:, None, None, :].expand(V, H, W, 3).reshape(-1, 3).contiguous()
+    soft = rendering.render_hierarchical(block, origins, dirs.reshape(-1, 3), (0.0, 100.0), S, 0.1, 1.0, seed=5)["labels"].clamp(0, 1)
+    soft = (soft.reshape(V, H, W, N) * visible.to(dev)[:, None, None, :]).contiguous()
+    inputs = optimization.FrameInputs((H, W), K.to(dev), E.to(dev), soft, gt_boxes.to(dev), visible.to(dev))
+    config = optimization.OptimizationConfig(num_samples=S, num_rays=R, warmup_steps=0, num_steps=3000)
+    torch.manual_seed(0)
+    device_loop = optimization.FrameOptimizer(inputs, config, dev)
+    device_loop.step_index = 1500                                     # mid schedule: T = std = 0.55
+    oracle_loop = ostep.OracleFrame((H, W), K, E, soft.cpu(), gt_boxes, visible, S)
+    oracle_loop.step_index = 1500
+    g = torch.Generator().manual_seed(4)
+    start = [torch.randn(N, 3, generator=g) * 0.2, torch.randn(N, 3, generator=g) * 0.2,
+             torch.nn.functional.normalize(torch.tensor([1.0, 0.0]) + torch.randn(N, 2, generator=g) * 0.2, dim=-1)]
+    start[0][:, 2] -= 1.5
+    with torch.no_grad():
+        for p, q, v in zip((device_loop.detector.locations, device_loop.detector.dimensions, device_loop.detector.orientations), oracle_loop.raw, start):
+            p.copy_(v[None].to(dev))
+            q.copy_(v)
+    from vsrd_amd import models
+    hyper_cpu = models.HyperDistanceField(48, [16, 16, 16, 16], 256, [256, 256, 256, 256])
+    hyper_cpu.load_state_dict({k: v.cpu() for k, v in device_loop.hyper_distance_field.state_dict().items()})
+    emb_cpu = device_loop.detector.embeddings.detach().cpu()[0].clone().requires_grad_(True)
+    oracle_loop.enable_residual(hyper_cpu, emb_cpu)
+    # rays through the objects only: the eikonal term over 1e6 m extrapolated miss samples is fp32 noise in any implementation
+    weights = soft.reshape(-1, N).max(-1).values
+    idx = torch.multinomial((weights > 0.5).float(), R, replacement=False)
+    u1, u2 = torch.rand(R, S, generator=g), torch.rand(R, S, generator=g)
+    got = device_loop.step(idx, u1.to(dev), u2.to(dev))
+    want = oracle_loop.step(idx.cpu(), u1, u2, residual=True)
+    for key in ("iou_projection_loss", "l1_projection_loss", "silhouette_loss", "eikonal_loss", "loss"):
+        torch.testing.assert_close(got[key].cpu(), want[key], rtol=5e-3, atol=1e-5), key
+    for k, (gg, gw) in enumerate(zip(got["raw_gradients"], want["raw_gradients"])):
+        assert (gg.cpu()[0] - gw).abs().max() <= 1e-2 * float(gw.abs().max()), k
+    ge = device_loop.detector.embeddings.grad.cpu()[0]
+    assert (ge - emb_cpu.grad).abs().max() <= 2e-2 * float(emb_cpu.grad.abs().max())
+    for pd, pc in zip(device_loop.hyper_distance_field.parameters(), hyper_cpu.parameters()):
+        assert (pd.grad.cpu() - pc.grad).abs().max() <= 2e-2 * max(float(pc.grad.abs().max()), 1e-8)

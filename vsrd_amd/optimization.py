@@ -39,6 +39,8 @@ class OptimizationConfig:
     max_sdf_std_deviation: float = 1.0
     min_sdf_std_deviation: float = 0.1
     learning_rate: float = 1.0e-2
+    embedding_learning_rate: float = 1.0e-3       # config.json:193-196
+    hypernetwork_learning_rate: float = 1.0e-4    # config.json:197-200
     lr_gamma: float = 0.01 ** (1.0 / 3000.0)
     loss_weights: dict = dataclass_field(default_factory=lambda: dict(losses.LOSS_WEIGHTS))
     seed: int = 0
@@ -51,7 +53,11 @@ class FrameOptimizer:
         V, H, W, N = inputs.soft_masks.shape
         self.num_views, self.num_instances = V, N
         self.detector = models.BoxParameters3D(1, N).to(self.device)
+        # config.json:143-156: per-instance residual MLP 48->16->16->16->16->1 generated from 256-d embeddings
+        self.hyper_distance_field = models.HyperDistanceField(48, [16, 16, 16, 16], 256, [256, 256, 256, 256]).to(self.device)
         groups = [dict(params=[p], lr=config.learning_rate) for p in (self.detector.locations, self.detector.dimensions, self.detector.orientations)]
+        groups.append(dict(params=[self.detector.embeddings], lr=config.embedding_learning_rate))
+        groups.append(dict(params=list(self.hyper_distance_field.parameters()), lr=config.hypernetwork_learning_rate))
         self.optimizer = torch.optim.Adam(groups, lr=config.learning_rate)
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=config.lr_gamma)
         # rays of every view, once per frame (main.py:267-296)
@@ -68,16 +74,17 @@ class FrameOptimizer:
         """main.py:620-627: importance-sample rays by the strongest soft mask (torch.multinomial, no replacement)."""
         return torch.multinomial(self.sampling_weights, self.config.num_rays, replacement=False)
 
-    def field_block(self, outputs, temperature):
+    def field_block(self, outputs, temperature, mlp_weights=None):
         return fields.FieldBlock(fields.pack_instances(outputs["locations"][0], outputs["orientations"][0], outputs["dimensions"][0]),
-                                 float(temperature), None, None)
+                                 float(temperature), mlp_weights, None)
 
     def step(self, ray_indices: Optional[torch.Tensor] = None, u_coarse=None, u_fine=None):
-        """One optimisation step (box-only phase).  ray_indices / uniforms may be supplied for reproducible parity runs."""
+        """One optimisation step.  Steps < warmup_steps optimise the boxes only; later steps add the per-instance residual MLP
+        (hypernetwork on the embeddings, main.py:525-578) and the eikonal loss (main.py:679-687).
+        ray_indices / uniforms may be supplied for reproducible parity runs."""
         cfg, inp = self.config, self.inputs
         step = self.step_index
-        if step >= cfg.warmup_steps:
-            raise NotImplementedError("residual-MLP phase (step >= warmup_steps) is not implemented in this round")
+        residual = step >= cfg.warmup_steps
         self.optimizer.zero_grad(set_to_none=True)
         outputs = self.detector()
         # ---- multi-view projection, matching, projection losses (main.py:339-415) --------------------
@@ -87,16 +94,19 @@ class FrameOptimizer:
         # ---- instance loss (main.py:420-671) ---------------------------------------------------------
         ratio, temperature, std = losses.schedules(step, cfg.num_steps, cfg.max_sdf_union_temperature, cfg.min_sdf_union_temperature,
                                                    cfg.max_sdf_std_deviation, cfg.min_sdf_std_deviation)
-        block = self.field_block(outputs, temperature)
+        mlp_weights = self.hyper_distance_field(outputs["embeddings"])[0].contiguous() if residual else None     # [N,1617]
+        block = self.field_block(outputs, temperature, mlp_weights)
         if ray_indices is None:
             ray_indices = self.sample_rays()
         origins = self.camera_positions[ray_indices // self.pixels_per_view]
         directions = self.ray_directions[ray_indices]
         out = rendering.render_hierarchical(block, origins, directions, cfg.distance_range, cfg.num_samples, std, ratio,
                                             u_coarse=u_coarse, u_fine=u_fine, seed=cfg.seed, stream_offset=step,
-                                            skip_exact_misses=cfg.skip_exact_misses)
+                                            return_gradients=residual, skip_exact_misses=cfg.skip_exact_misses and not residual)
         silhouette = losses.silhouette_loss(out["labels"], self.flat_masks[ray_indices], pd_idx, gt_idx)
         terms = dict(iou_projection_loss=iou_loss, l1_projection_loss=l1_loss, silhouette_loss=silhouette)
+        if residual:
+            terms["eikonal_loss"] = losses.eikonal_loss(out["gradients"])
         total = sum(cfg.loss_weights[name] * value for name, value in terms.items())   # main.py:855
         total.backward()
         raw_gradients = [p.grad.detach().clone() for p in (self.detector.locations, self.detector.dimensions, self.detector.orientations)]
