@@ -138,6 +138,7 @@ def main():
     parser.add_argument("--cpu-threads", type=int, default=16)   # best of {8,16,32,64} on the 2x64-core EPYC 9575F GPU host
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-skip-misses", action="store_true")
+    parser.add_argument("--residual", action="store_true", help="BASELINE config 3: per-instance residual MLP + eikonal loss")
     args = parser.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -179,15 +180,25 @@ def main():
         perturbed.orientations.copy_(raw_ori + torch.randn(raw_ori.shape, generator=g) * 0.1)
         targets = rendering.render_hierarchical(build_union(perturbed, 0.1), origins, directions, (0.0, 100.0), S, 0.1, 1.0,
                                                 seed=99, skip_exact_misses=True)["labels"].clamp(0.0, 1.0).contiguous()
-    optimizer = torch.optim.Adam([detector.locations, detector.dimensions, detector.orientations], lr=1e-2)
-    skip = not args.no_skip_misses
+    params = [detector.locations, detector.dimensions, detector.orientations]
+    hyper = None
+    if args.residual:
+        torch.manual_seed(rank)
+        hyper = models.HyperDistanceField(48, [16, 16, 16, 16], 256, [256, 256, 256, 256]).to(dev)
+        params += [detector.embeddings, *hyper.parameters()]
+    optimizer = torch.optim.Adam(params, lr=1e-2)
+    skip = not args.no_skip_misses and not args.residual     # eikonal needs every ray's gradients
 
     def step(index):
         optimizer.zero_grad(set_to_none=True)
         union = build_union(detector, sched["temperature"])
-        labels = rendering.render_hierarchical(union, origins, directions, (0.0, 100.0), S, sched["std"], sched["cosine_ratio"],
-                                               seed=rank, stream_offset=index, skip_exact_misses=skip)["labels"]
-        loss = torch.nn.functional.binary_cross_entropy(labels.clamp(1.0e-6, 1.0 - 1.0e-6), targets, reduction="none").mean()
+        if hyper is not None:
+            union.mlp_weights = hyper(detector.embeddings)[0].contiguous()
+        out = rendering.render_hierarchical(union, origins, directions, (0.0, 100.0), S, sched["std"], sched["cosine_ratio"],
+                                            seed=rank, stream_offset=index, skip_exact_misses=skip, return_gradients=hyper is not None)
+        loss = torch.nn.functional.binary_cross_entropy(out["labels"].clamp(1.0e-6, 1.0 - 1.0e-6), targets, reduction="none").mean()
+        if hyper is not None:
+            loss = loss + 0.01 * ((out["gradients"].norm(dim=-1) - 1.0) ** 2).mean()
         loss.backward()
         optimizer.step()
         return loss
@@ -233,7 +244,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE config 2: dense frame, {V} views x {H}x{W} = {R} rays/step/GPU, {N} box instances, "
-                                   f"{S} samples/ray (pass 1: {S - 1}, pass 2: {2 * S - 1} points), box-only field",
+                                   f"{S} samples/ray (pass 1: {S - 1}, pass 2: {2 * S - 1} points), " + ("box + residual-MLP field, eikonal loss" if args.residual else "box-only field"),
                        "schedule": f"{args.schedule}: T=std={sched['std']:.3f}, cosine_ratio={sched['cosine_ratio']:.2f}",
                        "skip_exact_misses": skip, "rng": "in-kernel Philox4x32-10", "rays_per_gpu": R,
                        "loss": "silhouette BCE (torch elementwise) + Adam on raw box parameters",
