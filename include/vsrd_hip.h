@@ -93,6 +93,16 @@ int32_t vsrd_ray_directions(const float* inverse_projection, int32_t num_views, 
 int32_t vsrd_field_eval(const vsrd_field* field, const float* positions /* [P,3] */, int64_t num_points,
                         float* distances, float* gradients, float* labels, int32_t hard_union, void* stream);
 
+/* vsrd.rendering.sphere_tracing, non-differentiable part (renderers.py:21-59): march each ray by the union distance until
+ * |sdf| < convergence_criteria, it leaves the bounding sphere, or num_iterations is reached.
+ * origins [R,3] (origin_stride 3) or [3] (stride 0); foreground [R] uint8 or NULL (= all finite origins);
+ * bounding_radius <= 0: none; initialise != 0: start from the bounding-sphere entry point (renderers.py:36-43).
+ * Outputs: positions [R,3], converged [R] uint8 (the reference's convergence_masks). */
+int32_t vsrd_sphere_trace(const vsrd_field* field, const float* origins, int32_t origin_stride, const float* directions,
+                          const uint8_t* foreground, int64_t num_rays, int32_t num_iterations, float convergence_criteria,
+                          float bounding_radius, int32_t initialise, int32_t hard_union,
+                          float* positions, uint8_t* converged, void* stream);
+
 /* samplers.quadrature_sampler over linspace bins (renderers.py:191-194, samplers.py:5-8).
  * u_coarse [R,S] in [0,1) -> distances [R,S]. */
 int32_t vsrd_sample_stratified(const vsrd_render_config* config, const float* u_coarse, float* distances, void* stream);

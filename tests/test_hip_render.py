@@ -409,3 +409,33 @@ def test_argument_validation(dev):
     empty = rendering.render_at_distances(union, g["origins"][:0].to(dev), g["directions"][:0].to(dev),
                                           g["fine_distances"].t()[:0].contiguous().to(dev), 0.5)
     assert empty[0].shape == (0, 4)
+
+
+def test_sphere_tracing_and_surface_normal_g9(dev):
+    """N1: vsrd.rendering.sphere_tracing / surface_normal over the soft union, driven like main.py:1028-1041
+    (compose(field, itemgetter(0)), shared camera position), against the reference's own outputs."""
+    import operator
+    from vsrd_amd import rendering, fields, utils
+    g = load_golden("g9_sphere_tracing")
+    N = g["locations"].shape[0]
+    loc, dim, rot = (g[k].to(dev) for k in ("locations", "dimensions", "orientations"))
+    union = fields.soft_union([
+        rendering.sdfs.translation(rendering.sdfs.rotation(fields.instance_field(rendering.sdfs.box(dim[i]), i, N), rot[i]), loc[i])
+        for i in range(N)], float(g["temperature"]))
+    field = utils.compose(union, operator.itemgetter(0))
+    pos, conv = rendering.sphere_tracing(field, g["origins"].to(dev), g["directions"].to(dev), num_iterations=200,
+                                         convergence_criteria=0.01, bounding_radius=100.0)
+    assert conv.shape == (96, 1) and conv.dtype == torch.bool
+    assert torch.equal(conv.cpu(), g["convergence_masks"])
+    hit = g["convergence_masks"][:, 0]
+    assert 5 < int(hit.sum()) < 96
+    torch.testing.assert_close(pos.cpu()[hit], g["surface_positions"][hit], rtol=1e-5, atol=2e-3)
+    normals = rendering.surface_normal(field, pos)
+    torch.testing.assert_close(normals.cpu()[hit], g["surface_normals"][hit], rtol=1e-3, atol=2e-3)
+    fd = rendering.surface_normal(field, pos, finite_difference_epsilon=1e-3)
+    assert (torch.nn.functional.cosine_similarity(fd.cpu()[hit], g["surface_normals"][hit], dim=-1) > 0.97).all()      # finite differences of an fp32 distance: a sanity check only
+    # shared origin + image-shaped directions (main.py passes [3] and [H,W,3]); initialization=False as in main.py:1036
+    pos2, conv2 = rendering.sphere_tracing(field, g["origins"][0].to(dev), g["directions"].reshape(8, 12, 3).to(dev), 200, 0.01,
+                                           bounding_radius=100.0, initialization=False)
+    assert pos2.shape == (8, 12, 3) and conv2.shape == (8, 12, 1)
+    assert torch.equal(conv2.reshape(-1, 1).cpu(), g["convergence_masks"])

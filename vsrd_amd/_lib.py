@@ -58,6 +58,9 @@ SIGNATURES = {
     "vsrd_ray_directions": (ctypes.c_int32, [c_float_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_float_p, ctypes.c_void_p]),
     "vsrd_field_eval": (ctypes.c_int32, [ctypes.POINTER(Field), c_float_p, ctypes.c_int64, c_float_p, c_float_p, c_float_p,
                                          ctypes.c_int32, ctypes.c_void_p]),
+    "vsrd_sphere_trace": (ctypes.c_int32, [ctypes.POINTER(Field), c_float_p, ctypes.c_int32, c_float_p, ctypes.c_void_p, ctypes.c_int64,
+                                           ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_int32, ctypes.c_int32,
+                                           c_float_p, ctypes.c_void_p, ctypes.c_void_p]),
     "vsrd_sample_stratified": (ctypes.c_int32, [ctypes.POINTER(RenderConfig), c_float_p, c_float_p, ctypes.c_void_p]),
     "vsrd_sample_importance": (ctypes.c_int32, [ctypes.POINTER(RenderConfig), c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
     "vsrd_render_forward": (ctypes.c_int32, [ctypes.POINTER(Field), ctypes.POINTER(RenderConfig), c_float_p, c_float_p, c_float_p,

@@ -141,6 +141,26 @@ int32_t vsrd_field_eval(const vsrd_field* field, const float* positions, int64_t
     return launch_status();
 }
 
+int32_t vsrd_sphere_trace(const vsrd_field* field, const float* origins, int32_t origin_stride, const float* directions,
+                          const uint8_t* foreground, int64_t num_rays, int32_t num_iterations, float convergence_criteria,
+                          float bounding_radius, int32_t initialise, int32_t hard_union,
+                          float* positions, uint8_t* converged, void* stream) {
+    if (!valid_field(field) || num_rays < 0 || num_iterations < 0 || (origin_stride != 0 && origin_stride != 3)) return VSRD_E_INVALID_ARGUMENT;
+    if (num_rays == 0) return VSRD_OK;
+    if (!origins || !directions || !positions || !converged) return VSRD_E_INVALID_ARGUMENT;
+    const int blocks = static_cast<int>(std::min<int64_t>((num_rays + 255) / 256, 16384));
+    const hipStream_t s = static_cast<hipStream_t>(stream);
+    if (field->mlp_weights != nullptr)
+        hipLaunchKernelGGL(sphere_trace_kernel<true>, dim3(blocks), dim3(256), 0, s, field_args(field), field->instances, field->mlp_weights,
+                           origins, origin_stride, directions, foreground, static_cast<long long>(num_rays), num_iterations,
+                           convergence_criteria, bounding_radius, initialise, hard_union, positions, converged);
+    else
+        hipLaunchKernelGGL(sphere_trace_kernel<false>, dim3(blocks), dim3(256), 0, s, field_args(field), field->instances, field->mlp_weights,
+                           origins, origin_stride, directions, foreground, static_cast<long long>(num_rays), num_iterations,
+                           convergence_criteria, bounding_radius, initialise, hard_union, positions, converged);
+    return launch_status();
+}
+
 int32_t vsrd_sample_stratified(const vsrd_render_config* config, const float* u_coarse, float* distances, void* stream) {
     if (!valid_config(config)) return VSRD_E_INVALID_ARGUMENT;
     if (config->num_rays == 0) return VSRD_OK;

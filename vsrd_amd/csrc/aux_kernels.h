@@ -65,6 +65,67 @@ __global__ __launch_bounds__(256) void field_eval_kernel(FieldArgs f, const floa
     }
 }
 
+// Union distance only (no normal): what sphere tracing evaluates per step.
+template <bool kResidual>
+__device__ __forceinline__ float union_distance(const FieldArgs& f, const float* __restrict__ instances, const float* __restrict__ mlp,
+                                                float x, float y, float z, int hard_union) {
+    float m = 3.0e38f, Z = 0.0f, S1 = 0.0f;           // online soft-min (field.h), value part only
+    for (int i = 0; i < f.num_instances; ++i) {
+        const BoxEval e = eval_instance<kResidual>(load_instance(instances, i), kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z);
+        const float d = e.d;
+        if (hard_union) { m = fminf(m, d); continue; }
+        const bool lower = d < m;
+        const float gap = lower ? (m - d) : (d - m);
+        const float ex = fast_exp(-gap * f.inv_t);
+        const float scale = lower ? ex : 1.0f, w = lower ? 1.0f : ex;
+        S1 = scale * (S1 + (lower ? gap : 0.0f) * Z) + w * (lower ? 0.0f : gap);
+        Z = scale * Z + w;
+        m = lower ? d : m;
+    }
+    return hard_union ? m : (m + S1 * fast_rcp(Z));
+}
+
+// vsrd.rendering.sphere_tracing (renderers.py:21-59, the non-differentiable part), one thread per ray.  The reference
+// evaluates every ray until ALL have stopped (a host sync per iteration, :57); a stopped ray no longer moves, so stopping
+// each thread on its own condition gives identical positions and masks.
+//   origins: origin_stride 3 (per ray) or 0 (shared); foreground [R] (uint8, in/out semantics of `foreground_masks`)
+//   bounding_radius <= 0: no bounding sphere.  initialise != 0: start at the sphere entry point (renderers.py:36-43).
+template <bool kResidual>
+__global__ __launch_bounds__(256) void sphere_trace_kernel(FieldArgs f, const float* __restrict__ instances, const float* __restrict__ mlp,
+                                                           const float* __restrict__ origins, int origin_stride,
+                                                           const float* __restrict__ directions, const unsigned char* __restrict__ foreground,
+                                                           long long num_rays, int num_iterations, float criteria, float bounding_radius,
+                                                           int initialise, int hard_union,
+                                                           float* __restrict__ positions, unsigned char* __restrict__ converged) {
+    for (long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; idx < num_rays;
+         idx += static_cast<long long>(gridDim.x) * blockDim.x) {
+        const float* o = origins + idx * origin_stride;
+        float px = o[0], py = o[1], pz = o[2];
+        const float dx = directions[idx * 3 + 0], dy = directions[idx * 3 + 1], dz = directions[idx * 3 + 2];
+        bool fg = foreground ? (foreground[idx] != 0) : (isfinite(px) && isfinite(py) && isfinite(pz));
+        if (bounding_radius > 0.0f && initialise) {                    // sphere_intersection, renderers.py:9-18
+            const float a = dx * dx + dy * dy + dz * dz;
+            const float b = dx * px + dy * py + dz * pz;
+            const float cc = px * px + py * py + pz * pz - bounding_radius * bounding_radius;
+            const float disc = b * b - a * cc;
+            const bool hit = disc >= 0.0f;
+            const float t = (-b - sqrtf(disc)) / a;
+            if (hit) { px += dx * t; py += dy * t; pz += dz * t; }
+            fg = fg && hit;
+        }
+        bool conv = false;
+        for (int it = 0; it < num_iterations; ++it) {
+            const float sd = union_distance<kResidual>(f, instances, mlp, px, py, pz, hard_union);
+            if (fg && !conv) { px += dx * sd; py += dy * sd; pz += dz * sd; }
+            if (bounding_radius > 0.0f) fg = fg && (sqrtf(px * px + py * py + pz * pz) < bounding_radius);
+            conv = fabsf(sd) < criteria;
+            if (!fg || conv) break;
+        }
+        positions[idx * 3 + 0] = px; positions[idx * 3 + 1] = py; positions[idx * 3 + 2] = pz;
+        converged[idx] = conv ? 1 : 0;
+    }
+}
+
 // renderers.py:191-194 + samplers.py:5-8, one thread per (ray, bin).
 __global__ __launch_bounds__(256) void sample_stratified_kernel(RenderArgs c, const float* __restrict__ u_coarse, float* __restrict__ distances) {
     const size_t total = static_cast<size_t>(c.num_rays) * c.num_samples;

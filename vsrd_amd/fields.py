@@ -156,6 +156,9 @@ def _closure_vars(fn):
 
 
 def _as_soft_union(field):
+    from .utils import Composition
+    if isinstance(field, Composition):       # compose(soft_distance_field, itemgetter(0)), main.py:1030: same field, distances only
+        return _as_soft_union(field.functions[0])
     if isinstance(field, SoftUnion):
         return field.distance_fields, field.temperature, False
     if isinstance(field, HardUnion):

@@ -1,6 +1,7 @@
 """Mirror of the ``vsrd.rendering`` call surface used by scripts/main.py."""
 from . import sdfs
 from .sdfs import box, rotation, translation, hard_union, soft_union
-from .renderers import (hierarchical_volumetric_rendering, render_hierarchical, render_at_distances, evaluate_field)
+from .renderers import (hierarchical_volumetric_rendering, render_hierarchical, render_at_distances, evaluate_field,
+                        sphere_tracing, surface_normal)
 from .samplers import quadrature_sampler, importance_merge
 from .utils import ray_casting

@@ -285,3 +285,41 @@ def evaluate_field(distance_field, positions, with_gradients=False, with_labels=
     if with_gradients:
         out.append(gradients.reshape(*lead, 3))
     return out[0] if len(out) == 1 else tuple(out)
+
+
+def sphere_tracing(distance_field, ray_positions, ray_directions, num_iterations, convergence_criteria, foreground_masks=None,
+                   bounding_radius=None, initialization=True, differentiable=False):
+    """Drop-in for vsrd.rendering.sphere_tracing (renderers.py:21-73): returns (ray_positions [...,3], convergence_masks [...,1])."""
+    if differentiable:
+        raise NotImplementedError("sphere_tracing(differentiable=True) (renderers.py:61-71) is not implemented; scripts/main.py uses False")
+    lib = _lib.load()
+    block = flatten(distance_field)
+    origins, directions, stride, lead = _prepare_rays(ray_positions, ray_directions)
+    R = directions.shape[0]
+    positions = torch.empty(R, 3, dtype=torch.float32, device=directions.device)
+    converged = torch.empty(R, dtype=torch.uint8, device=directions.device)
+    fg = None
+    if foreground_masks is not None:
+        fg = foreground_masks.expand(*lead, 1).reshape(R).to(torch.uint8).contiguous()
+    mlp = None if block.mlp_weights is None else block.mlp_weights.detach().contiguous()
+    field = _lib.make_field(block.instances.detach().contiguous(), block.temperature, mlp)
+    _lib.check(lib.vsrd_sphere_trace(field, _lib.ptr(origins), stride, _lib.ptr(directions), None if fg is None else fg.data_ptr(), R,
+                                     int(num_iterations), float(convergence_criteria), float(bounding_radius or 0.0),
+                                     1 if initialization else 0, 1 if block.hard else 0, _lib.ptr(positions), converged.data_ptr(),
+                                     _lib.stream()))
+    return positions.reshape(*lead, 3), converged.to(torch.bool).reshape(*lead, 1)
+
+
+def surface_normal(distance_field, surface_positions, finite_difference_epsilon=None):
+    """Drop-in for vsrd.rendering.surface_normal (renderers.py:76-113): unit normals of the field at the given points
+    (analytic gradient, or central differences when finite_difference_epsilon is given).  Not differentiable w.r.t. the field."""
+    if finite_difference_epsilon:
+        eps = float(finite_difference_epsilon)
+        offsets = torch.eye(3, device=surface_positions.device, dtype=surface_positions.dtype) * eps
+        probes = torch.stack([surface_positions + offsets[k] for k in range(3)] + [surface_positions - offsets[k] for k in range(3)])
+        d = evaluate_field(distance_field, probes, with_labels=False)
+        normals = torch.cat([d[k] - d[k + 3] for k in range(3)], dim=-1)
+    else:
+        out = evaluate_field(distance_field, surface_positions, with_gradients=True, with_labels=False)
+        normals = out[-1] if isinstance(out, tuple) else out
+    return torch.nn.functional.normalize(normals, dim=-1)
