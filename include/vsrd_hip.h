@@ -103,6 +103,14 @@ int32_t vsrd_sphere_trace(const vsrd_field* field, const float* origins, int32_t
                           float bounding_radius, int32_t initialise, int32_t hard_union,
                           float* positions, uint8_t* converged, void* stream);
 
+/* SoftRasterizer.make_distance_map + soft masks (vsrd/transforms/geometric_transforms.py:265-317), the step that produces the
+ * path's targets: per instance, distance of every pixel to the closed polygon [count,2] (x,y), then
+ * soft = sigmoid((inside ? d : -d) / temperature).  polygons [B,Pmax,2] (rows beyond counts[b] ignored), counts [B] int32,
+ * inside [B,H,W] uint8 (required for soft_masks).  distance_maps / soft_masks [B,H,W], either may be NULL. */
+int32_t vsrd_polygon_soft_masks(const float* polygons, const int32_t* counts, int32_t num_polygons, int32_t max_vertices,
+                                int32_t height, int32_t width, const uint8_t* inside, float temperature,
+                                float* distance_maps, float* soft_masks, void* stream);
+
 /* samplers.quadrature_sampler over linspace bins (renderers.py:191-194, samplers.py:5-8).
  * u_coarse [R,S] in [0,1) -> distances [R,S]. */
 int32_t vsrd_sample_stratified(const vsrd_render_config* config, const float* u_coarse, float* distances, void* stream);

@@ -156,3 +156,21 @@ def distance_box_iou_loss(boxes1, boxes2, eps=1.0e-7):
     diag = (torch.max(x2, x2g) - torch.min(x1, x1g)) ** 2 + (torch.max(y2, y2g) - torch.min(y1, y1g)) ** 2 + eps
     centre = ((x1 + x2) / 2 - (x1g + x2g) / 2) ** 2 + ((y1 + y2) / 2 - (y1g + y2g) / 2) ** 2
     return 1 - iou + centre / diag
+
+
+def polygon_distance_map(polygon, image_size):
+    """SoftRasterizer.make_distance_map (vsrd/transforms/geometric_transforms.py:265-290): distance of every integer pixel
+    centre to the closed polygon [P,2] (x, y)."""
+    height, width = image_size
+    ys, xs = torch.meshgrid(torch.arange(height), torch.arange(width), indexing="ij")
+    pixels = torch.stack([xs.flatten(), ys.flatten()], dim=-1).to(torch.float32)         # [HW,2]
+    start = polygon.to(torch.float32)
+    side = torch.roll(start, shifts=-1, dims=0) - start                                   # [P,2]
+    rel = pixels[:, None, :] - start[None, :, :]                                          # [HW,P,2]
+    ratio = ((side[None] * rel).sum(-1, keepdim=True) / ((side * side).sum(-1, keepdim=True)[None] + 1.0e-6)).clamp(0.0, 1.0)
+    return (rel - side[None] * ratio).norm(dim=-1).min(dim=-1).values.reshape(height, width)
+
+
+def soft_mask(distance_map, inside, temperature=10.0):
+    """geometric_transforms.py:306-307."""
+    return torch.sigmoid(torch.where(inside, distance_map, -distance_map) / temperature)

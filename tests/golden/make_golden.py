@@ -445,6 +445,32 @@ def golden_sphere_tracing(ref):
          temperature=np.array(0.1, dtype=np.float32), surface_positions=pos, convergence_masks=conv, surface_normals=normals.detach())
 
 
+def golden_soft_rasterizer():
+    """N2: SoftRasterizer.make_distance_map + the soft-mask formula (geometric_transforms.py:265-317).
+    The module imports torchvision / cv2 / skimage at the top; empty placeholder modules let the import through and are
+    never called: only the pure-torch ``make_distance_map`` and the sigmoid formula of ``forward`` are exercised (the OpenCV
+    polygon extraction / filling steps need the real libraries and are not part of this fixture)."""
+    for name in ("torchvision", "cv2", "skimage"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    _stub_package("vsrd.transforms", os.path.join(REFERENCE_ROOT, "vsrd", "transforms"))
+    gt = importlib.import_module("vsrd.transforms.geometric_transforms")
+    rast = gt.SoftRasterizer(threshold=0.5, temperature=10.0)
+    g = torch.Generator().manual_seed(12)
+    H, W = 40, 56
+    polygons = [
+        torch.tensor([[10, 8], [30, 6], [44, 20], [36, 33], [14, 30]], dtype=torch.int32),
+        torch.tensor([[3, 3], [20, 4], [20, 18], [3, 17]], dtype=torch.int32),
+        torch.randint(0, 40, (9, 2), generator=g).to(torch.int32),
+    ]
+    maps = [rast.make_distance_map(p, (H, W)) for p in polygons]
+    inside = [(torch.rand(H, W, generator=g) > 0.5) for _ in polygons]      # arbitrary binary masks: the formula is per pixel
+    soft = [torch.sigmoid(torch.where(b, d, -d) / rast.temperature) for b, d in zip(inside, maps)]
+    arrays = {"hw": np.array([H, W]), "temperature": np.array(rast.temperature, dtype=np.float32)}
+    for k, (p, d, b, s) in enumerate(zip(polygons, maps, inside, soft)):
+        arrays.update({f"polygon_{k}": p, f"distance_{k}": d, f"inside_{k}": b, f"soft_{k}": s})
+    save("g11_soft_rasterizer", **arrays)
+
+
 def main():
     torch.set_num_threads(4)
     ref = import_reference()
@@ -454,6 +480,7 @@ def main():
     golden_mlp(ref)
     golden_projection(ref)
     golden_sphere_tracing(ref)
+    golden_soft_rasterizer()
     golden_rendering(ref)
     leftovers = [p for p, _, _ in os.walk(REFERENCE_ROOT) if p.endswith("__pycache__")]
     assert not leftovers, leftovers

@@ -190,3 +190,19 @@ def test_residual_phase_step_matches_oracle(dev):
     assert (ge - emb_cpu.grad).abs().max() <= 2e-2 * float(emb_cpu.grad.abs().max())
     for pd, pc in zip(device_loop.hyper_distance_field.parameters(), hyper_cpu.parameters()):
         assert (pd.grad.cpu() - pc.grad).abs().max() <= 2e-2 * max(float(pc.grad.abs().max()), 1e-8)
+
+
+def test_soft_rasterizer_g11(dev):
+    """N2: pixel-to-polygon distance maps and soft masks for all instances of a frame in one launch."""
+    from vsrd_amd import transforms
+    g = load_golden("g11_soft_rasterizer")
+    H, W = (int(v) for v in g["hw"])
+    polys = [g[f"polygon_{k}"].to(dev) for k in range(3)]
+    maps = transforms.make_distance_map(polys, (H, W))
+    for k in range(3):
+        torch.testing.assert_close(maps[k].cpu(), g[f"distance_{k}"], rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(transforms.make_distance_map(polys[1], (H, W)).cpu(), g["distance_1"], rtol=1e-5, atol=1e-4)
+    inside = torch.stack([g[f"inside_{k}"] for k in range(3)]).to(dev)
+    soft = transforms.soft_masks(polys, inside, float(g["temperature"]))
+    for k in range(3):
+        torch.testing.assert_close(soft[k].cpu(), g[f"soft_{k}"], rtol=1e-5, atol=1e-5)

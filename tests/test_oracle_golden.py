@@ -207,3 +207,12 @@ def test_diou_hand_cases():
     np.testing.assert_allclose(geometry.distance_box_iou(a, c).item(), -(4.5 ** 2 + 0.5 ** 2) / 40.0, rtol=1e-6)
     clipped = geometry.clip_boxes_to_image(torch.tensor([[[-5.0, 3.0], [2000.0, 500.0]]]), (376, 1408))
     assert clipped.tolist() == [[[0.0, 3.0], [1408.0, 376.0]]]
+
+
+def test_g11_soft_rasterizer():
+    g = load_golden("g11_soft_rasterizer")
+    H, W = (int(v) for v in g["hw"])
+    for k in range(3):
+        d = geometry.polygon_distance_map(g[f"polygon_{k}"], (H, W))
+        torch.testing.assert_close(d, g[f"distance_{k}"], rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(geometry.soft_mask(d, g[f"inside_{k}"], float(g["temperature"])), g[f"soft_{k}"], rtol=1e-5, atol=1e-5)

@@ -61,6 +61,8 @@ SIGNATURES = {
     "vsrd_sphere_trace": (ctypes.c_int32, [ctypes.POINTER(Field), c_float_p, ctypes.c_int32, c_float_p, ctypes.c_void_p, ctypes.c_int64,
                                            ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_int32, ctypes.c_int32,
                                            c_float_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "vsrd_polygon_soft_masks": (ctypes.c_int32, [c_float_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                 ctypes.c_void_p, ctypes.c_float, c_float_p, c_float_p, ctypes.c_void_p]),
     "vsrd_sample_stratified": (ctypes.c_int32, [ctypes.POINTER(RenderConfig), c_float_p, c_float_p, ctypes.c_void_p]),
     "vsrd_sample_importance": (ctypes.c_int32, [ctypes.POINTER(RenderConfig), c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
     "vsrd_render_forward": (ctypes.c_int32, [ctypes.POINTER(Field), ctypes.POINTER(RenderConfig), c_float_p, c_float_p, c_float_p,

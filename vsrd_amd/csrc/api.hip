@@ -161,6 +161,19 @@ int32_t vsrd_sphere_trace(const vsrd_field* field, const float* origins, int32_t
     return launch_status();
 }
 
+int32_t vsrd_polygon_soft_masks(const float* polygons, const int32_t* counts, int32_t num_polygons, int32_t max_vertices,
+                                int32_t height, int32_t width, const uint8_t* inside, float temperature,
+                                float* distance_maps, float* soft_masks, void* stream) {
+    if (num_polygons < 0 || max_vertices < 1 || height < 1 || width < 1 || temperature <= 0.0f) return VSRD_E_INVALID_ARGUMENT;
+    if (num_polygons == 0) return VSRD_OK;
+    if (!polygons || !counts || (!distance_maps && !soft_masks) || (soft_masks && !inside)) return VSRD_E_INVALID_ARGUMENT;
+    const int pixels = height * width;
+    const dim3 grid(static_cast<unsigned>(std::min((pixels + 255) / 256, 4096)), static_cast<unsigned>(num_polygons));
+    hipLaunchKernelGGL(polygon_soft_mask_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), polygons, counts, num_polygons,
+                       max_vertices, height, width, inside, temperature, distance_maps, soft_masks);
+    return launch_status();
+}
+
 int32_t vsrd_sample_stratified(const vsrd_render_config* config, const float* u_coarse, float* distances, void* stream) {
     if (!valid_config(config)) return VSRD_E_INVALID_ARGUMENT;
     if (config->num_rays == 0) return VSRD_OK;

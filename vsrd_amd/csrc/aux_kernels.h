@@ -126,6 +126,40 @@ __global__ __launch_bounds__(256) void sphere_trace_kernel(FieldArgs f, const fl
     }
 }
 
+// SoftRasterizer.make_distance_map + the soft-mask formula (vsrd/transforms/geometric_transforms.py:265-317): distance of every
+// pixel (integer centres) to the closed polygon of an instance mask, then sigmoid(+-distance / temperature).  One thread per
+// pixel; the loop over polygon sides is wave-uniform (vertices via scalar loads).  The reference broadcasts a [HW, P, 2] tensor
+// per instance on the CPU inside the dataset; here it is one launch for all instances of a frame.
+__global__ __launch_bounds__(256) void polygon_soft_mask_kernel(const float* __restrict__ polygons, const int* __restrict__ counts,
+                                                                int num_polygons, int max_vertices, int height, int width,
+                                                                const unsigned char* __restrict__ inside, float temperature,
+                                                                float* __restrict__ distance_maps, float* __restrict__ soft_masks) {
+    const int b = blockIdx.y;
+    const int count = counts[b];
+    const float* poly = polygons + static_cast<size_t>(b) * max_vertices * 2;
+    const int pixels = height * width;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < pixels; idx += gridDim.x * blockDim.x) {
+        const float px = static_cast<float>(idx % width), py = static_cast<float>(idx / width);
+        float best = 3.0e38f;
+        for (int k = 0; k < count; ++k) {
+            const int kn = (k + 1 == count) ? 0 : k + 1;                       // torch.roll(polygons, -1)
+            const float ax = poly[2 * k], ay = poly[2 * k + 1];
+            const float sx = poly[2 * kn] - ax, sy = poly[2 * kn + 1] - ay;
+            const float rx = px - ax, ry = py - ay;
+            float ratio = (sx * rx + sy * ry) / (sx * sx + sy * sy + 1.0e-6f);
+            ratio = fminf(fmaxf(ratio, 0.0f), 1.0f);
+            const float nx = rx - sx * ratio, ny = ry - sy * ratio;
+            best = fminf(best, sqrtf(nx * nx + ny * ny));
+        }
+        const size_t out = static_cast<size_t>(b) * pixels + idx;
+        if (distance_maps) distance_maps[out] = best;
+        if (soft_masks) {
+            const float sdf = inside[out] ? best : -best;
+            soft_masks[out] = 1.0f / (1.0f + expf(-sdf / temperature));
+        }
+    }
+}
+
 // renderers.py:191-194 + samplers.py:5-8, one thread per (ray, bin).
 __global__ __launch_bounds__(256) void sample_stratified_kernel(RenderArgs c, const float* __restrict__ u_coarse, float* __restrict__ distances) {
     const size_t total = static_cast<size_t>(c.num_rays) * c.num_samples;
