@@ -471,6 +471,34 @@ def golden_soft_rasterizer():
     save("g11_soft_rasterizer", **arrays)
 
 
+def golden_formats(ref):
+    """N4 (SURVEY §8f): KITTI label lines written by the reference's tools/kitti_360/convert_predictions.py::save_prediction,
+    and the key/shape layout of the detector state dict the checkpoint consumer (make_predictions.py:61-66) loads.
+    convert_predictions imports torchvision / pycocotools at the top: empty placeholders (never called) let it import."""
+    import tempfile
+    for name in ("torchvision", "pycocotools", "pycocotools.mask"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.path.insert(0, os.path.join(REFERENCE_ROOT, "tools", "kitti_360"))
+    convert = importlib.import_module("convert_predictions")
+    g = torch.Generator().manual_seed(21)
+    bp = ref.box_parameters.BoxParameters3D(1, 3)
+    with torch.no_grad():
+        bp.locations.copy_(torch.randn(1, 3, 3, generator=g) * 0.4)
+        bp.dimensions.copy_(torch.randn(1, 3, 3, generator=g))
+        bp.orientations.copy_(torch.randn(1, 3, 2, generator=g))
+    boxes_3d = bp()["boxes_3d"][0].detach()
+    boxes_2d = torch.rand(3, 2, 2, generator=g) * 300
+    scores = torch.rand(3, generator=g)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "labels", "0000.txt")
+        convert.save_prediction(path, ["car"] * 3, boxes_3d, boxes_2d, scores)
+        text = open(path).read()
+    state = bp.state_dict()
+    save("g12_formats", boxes_3d=boxes_3d, boxes_2d=boxes_2d, scores=scores,
+         kitti_text=np.frombuffer(text.encode(), dtype=np.uint8),
+         state_keys=np.frombuffer("\n".join(f"{k}:{tuple(v.shape)}" for k, v in state.items()).encode(), dtype=np.uint8))
+
+
 def main():
     torch.set_num_threads(4)
     ref = import_reference()
@@ -481,6 +509,7 @@ def main():
     golden_projection(ref)
     golden_sphere_tracing(ref)
     golden_soft_rasterizer()
+    golden_formats(ref)
     golden_rendering(ref)
     leftovers = [p for p, _, _ in os.walk(REFERENCE_ROOT) if p.endswith("__pycache__")]
     assert not leftovers, leftovers

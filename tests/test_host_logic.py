@@ -129,3 +129,36 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(base, name)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"{name} imports the oracle"
                 assert "/root/reference" not in text
+
+
+def test_formats_match_reference_writers():
+    """N4: KITTI label lines byte-for-byte against the reference's convert_predictions.save_prediction (golden g12), the
+    prediction JSON layout, the checkpoint's detector state-dict layout and the multi-view confidence voting."""
+    import json
+    import tempfile
+    import numpy as np
+    from conftest import load_golden
+    from vsrd_amd import formats, models
+    g = load_golden("g12_formats")
+    want = bytes(g["kitti_text"].numpy().astype(np.uint8)).decode()
+    got = "".join(formats.kitti_label_line("car", b3, b2, s) for b3, b2, s in zip(g["boxes_3d"], g["boxes_2d"], g["scores"]))
+    for a, b in zip(got.splitlines(), want.splitlines()):
+        fa, fb = a.split(" "), b.split(" ")
+        assert fa[0] == fb[0] and len(fa) == len(fb) == 16
+        np.testing.assert_allclose([float(x) for x in fa[1:]], [float(x) for x in fb[1:]], rtol=1e-5, atol=1e-5)
+    assert got.count("\n") == want.count("\n") == 3
+    keys = bytes(g["state_keys"].numpy().astype(np.uint8)).decode().split("\n")
+    mine = [f"{k}:{tuple(v.shape)}" for k, v in models.BoxParameters3D(1, 3).state_dict().items()]
+    assert mine == keys                                           # loadable by make_predictions.py:61-66
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "predictions", "frame.json")
+        formats.save_prediction(path, g["boxes_3d"], g["boxes_2d"], g["scores"])
+        record = json.load(open(path))
+        assert list(record) == ["boxes_3d", "boxes_2d", "confidences"] and list(record["boxes_3d"]) == ["car"]
+        assert np.asarray(record["boxes_3d"]["car"]).shape == (3, 8, 3) and np.asarray(record["boxes_2d"]["car"]).shape == (3, 2, 2)
+    # voting: prediction 0 overlaps target instance 1 in both views, prediction 1 overlaps instance 0 in one view
+    pd = [torch.tensor([[[0., 0.], [10., 10.]], [[20., 20.], [30., 30.]]])] * 2
+    gt = [torch.tensor([[[20., 20.], [30., 30.]], [[0., 0.], [10., 10.]]]), torch.tensor([[[0., 0.], [10., 5.]]])]
+    conf, pd_idx, gt_idx = formats.multi_view_confidences(pd, gt, [torch.tensor([0, 1]), torch.tensor([1])])
+    assert pd_idx.tolist() == [0, 1] and gt_idx.tolist() == [1, 0]
+    np.testing.assert_allclose(conf.numpy(), [0.75, 1.0], rtol=1e-6)
