@@ -499,6 +499,34 @@ def golden_formats(ref):
          state_keys=np.frombuffer("\n".join(f"{k}:{tuple(v.shape)}" for k, v in state.items()).encode(), dtype=np.uint8))
 
 
+def golden_loss_library():
+    """a22: the vsrd.losses library (never called by main.py) -- outputs of the reference functions on seeded inputs."""
+    _stub_package("vsrd.losses", os.path.join(REFERENCE_ROOT, "vsrd", "losses"))
+    mods = [importlib.import_module("vsrd.losses." + m) for m in
+            ("classification_losses", "photometric_losses", "smoothness_losses", "probabilistic_losses")]
+    lib = {}
+    for m in mods:
+        lib.update({k: v for k, v in vars(m).items() if callable(v)})
+    g = torch.Generator().manual_seed(31)
+    p, t = torch.rand(2, 3, 8, 9, generator=g), torch.rand(2, 3, 8, 9, generator=g)
+    img_a, img_b = torch.rand(2, 3, 12, 10, generator=g), torch.rand(2, 3, 12, 10, generator=g)
+    mean, target = torch.randn(5, 7, generator=g), torch.randn(5, 7, generator=g)
+    var, shape, scale = torch.rand(5, 7, generator=g) + 0.1, torch.rand(5, 7, generator=g) + 1.5, torch.rand(5, 7, generator=g) + 0.2
+    arrays = dict(p=p, t=t, img_a=img_a, img_b=img_b, mean=mean, target=target, var=var, shape=shape, scale=scale)
+    for name in ("cross_entropy", "binary_cross_entropy", "kl_divergence", "binary_kl_divergence", "js_divergence",
+                 "binary_js_divergence", "focal_loss", "quality_focal_loss", "tversky_loss", "focal_tversky_loss"):
+        arrays["out_" + name] = lib[name](p, t, reduction="none")
+    arrays["out_cross_entropy_dim1"] = lib["cross_entropy"](p, t, dim=1, reduction="mean")
+    arrays["out_ssim_loss"] = lib["ssim_loss"](img_a, img_b, reduction="none")
+    arrays["out_photometric_loss"] = lib["photometric_loss"](img_a, img_b, reduction="none")
+    arrays["out_smoothness_loss"] = lib["smoothness_loss"](img_a[:, :1], img_b, reduction="none")
+    arrays["out_motion_smoothness_loss"] = lib["motion_smoothness_loss"](img_a, reduction="none")
+    arrays["out_motion_sparsity_loss"] = lib["motion_sparsity_loss"](img_a - 0.5, reduction="sum")
+    arrays["out_gaussian_nll"] = lib["gaussian_nll"](mean, var, target, reduction="none")
+    arrays["out_student_nll"] = lib["student_nll"](mean, shape, scale, target, reduction="none")
+    save("g13_loss_library", **arrays)
+
+
 def main():
     torch.set_num_threads(4)
     ref = import_reference()
@@ -510,6 +538,7 @@ def main():
     golden_sphere_tracing(ref)
     golden_soft_rasterizer()
     golden_formats(ref)
+    golden_loss_library()
     golden_rendering(ref)
     leftovers = [p for p, _, _ in os.walk(REFERENCE_ROOT) if p.endswith("__pycache__")]
     assert not leftovers, leftovers

@@ -162,3 +162,25 @@ def test_formats_match_reference_writers():
     conf, pd_idx, gt_idx = formats.multi_view_confidences(pd, gt, [torch.tensor([0, 1]), torch.tensor([1])])
     assert pd_idx.tolist() == [0, 1] and gt_idx.tolist() == [1, 0]
     np.testing.assert_allclose(conf.numpy(), [0.75, 1.0], rtol=1e-6)
+
+
+def test_loss_library_matches_reference_g13():
+    """a22: the vsrd.losses call surface (pure PyTorch) against the reference's own outputs."""
+    from conftest import load_golden
+    from vsrd_amd import loss_library as L
+    g = load_golden("g13_loss_library")
+    p, t = g["p"], g["t"]
+    for name in ("cross_entropy", "binary_cross_entropy", "kl_divergence", "binary_kl_divergence", "js_divergence",
+                 "binary_js_divergence", "focal_loss", "quality_focal_loss", "tversky_loss", "focal_tversky_loss"):
+        torch.testing.assert_close(getattr(L, name)(p, t, reduction="none"), g["out_" + name], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(L.cross_entropy(p, t, dim=1), g["out_cross_entropy_dim1"], rtol=1e-5, atol=1e-6)
+    a, b = g["img_a"], g["img_b"]
+    torch.testing.assert_close(L.ssim_loss(a, b, reduction="none"), g["out_ssim_loss"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(L.photometric_loss(a, b, reduction="none"), g["out_photometric_loss"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(L.smoothness_loss(a[:, :1], b, reduction="none"), g["out_smoothness_loss"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(L.motion_smoothness_loss(a, reduction="none"), g["out_motion_smoothness_loss"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(L.motion_sparsity_loss(a - 0.5, reduction="sum"), g["out_motion_sparsity_loss"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(L.gaussian_nll(g["mean"], g["var"], g["target"], reduction="none"), g["out_gaussian_nll"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(L.student_nll(g["mean"], g["shape"], g["scale"], g["target"], reduction="none"), g["out_student_nll"], rtol=1e-4, atol=1e-5)
+    with pytest.raises(ValueError):
+        L.cross_entropy(p, t, reduction="median")

@@ -6,7 +6,7 @@ The sub-packages mirror the part of the reference's ``vsrd`` package that ``scri
 its hot path: ``rendering``, ``operations``, plus ``fields`` (the closures of ``main.py:433-523`` as
 importable objects) and ``models`` (the optimised parameters).
 """
-from . import _lib, fields, rendering, operations, models, utils
+from . import _lib, fields, rendering, operations, models, utils, loss_library
 
 __all__ = ["fields", "rendering", "operations", "models", "install_as_vsrd"]
 
@@ -21,3 +21,4 @@ def install_as_vsrd():
     sys.modules.setdefault("vsrd.operations", operations)
     sys.modules.setdefault("vsrd.models", models)
     sys.modules.setdefault("vsrd.utils", utils)
+    sys.modules.setdefault("vsrd.losses", loss_library)

@@ -1,0 +1,155 @@
+"""The ``vsrd.losses`` call surface: named in BASELINE.json's north star but never called by
+scripts/main.py (its losses are assembled inline, see vsrd_amd/losses.py).  Restated in plain PyTorch so that code written
+against ``vsrd.losses`` keeps working; device-agnostic, no kernels.
+
+Every function takes ``reduction="mean" | "sum" | "none"`` like the reference's ``@reduced`` decorator (losses/utils.py:4-15).
+Not provided: the sampling-based energy scores (probabilistic_losses.py:45-170) and the extrinsic-consistency / Sampson terms
+(geometric_losses.py) -- no shipped configuration reaches them.
+"""
+import functools
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _reduced(function):
+    @functools.wraps(function)
+    def wrapper(*args, reduction="mean", **kwargs):
+        values = function(*args, **kwargs)
+        if reduction == "none":
+            return values
+        if reduction == "mean":
+            return values.mean()
+        if reduction == "sum":
+            return values.sum()
+        raise ValueError(f"`reduction` argument should be 'none'|'mean'|'sum', but got {reduction}.")
+    return wrapper
+
+
+def _clip(p, epsilon):
+    return p.clamp(epsilon, 1.0 - epsilon)
+
+
+def _maybe_sum(values, dim, keepdim):
+    return values.sum(dim=dim, keepdim=keepdim) if dim else values
+
+
+# ---- classification (classification_losses.py:7-148) ----------------------------------------------------------
+@_reduced
+def cross_entropy(inputs, targets, dim=None, keepdim=False, epsilon=1e-6):
+    return _maybe_sum(-targets * torch.log(_clip(inputs, epsilon)), dim, keepdim)
+
+
+def _two_sided(term):
+    """f(p, t) + f(1 - p, 1 - t): how every ``binary_*`` loss of the reference is built."""
+    @_reduced
+    def loss(inputs, targets, epsilon=1e-6):
+        return term(inputs, targets, epsilon=epsilon, reduction="none") + term(1.0 - inputs, 1.0 - targets, epsilon=epsilon, reduction="none")
+    return loss
+
+
+@_reduced
+def kl_divergence(inputs, targets, dim=None, keepdim=False, epsilon=1e-6):
+    p, t = _clip(inputs, epsilon), _clip(targets, epsilon)
+    return _maybe_sum(-t * (torch.log(p) - torch.log(t)), dim, keepdim)
+
+
+@_reduced
+def js_divergence(inputs, targets, dim=None, keepdim=False, epsilon=1e-6):
+    mid = 0.5 * inputs + 0.5 * targets
+    kw = dict(dim=dim, keepdim=keepdim, epsilon=epsilon, reduction="none")
+    return 0.5 * kl_divergence(mid, inputs, **kw) + 0.5 * kl_divergence(mid, targets, **kw)
+
+
+binary_cross_entropy = _two_sided(cross_entropy)
+binary_kl_divergence = _two_sided(kl_divergence)
+binary_js_divergence = _two_sided(js_divergence)
+
+
+@_reduced
+def focal_loss(inputs, targets, alpha=0.25, gamma=2.0):
+    return (1.0 - (targets - alpha).abs()) * (targets - inputs).abs() ** gamma * binary_cross_entropy(inputs, targets, reduction="none")
+
+
+@_reduced
+def quality_focal_loss(inputs, targets, beta=2.0):
+    return (targets - inputs).abs() ** beta * binary_cross_entropy(inputs, targets, reduction="none")
+
+
+@_reduced
+def tversky_loss(inputs, targets, alpha=0.7, beta=0.3, epsilon=1.0):
+    tp = (inputs * targets).sum(dim=(-2, -1))
+    fn = ((1.0 - inputs) * targets).sum(dim=(-2, -1))
+    fp = (inputs * (1.0 - targets)).sum(dim=(-2, -1))
+    return 1.0 - (tp + epsilon) / (tp + alpha * fn + beta * fp + epsilon)
+
+
+@_reduced
+def focal_tversky_loss(inputs, targets, gamma=0.75, **kwargs):
+    return tversky_loss(inputs, targets, **kwargs, reduction="none") ** gamma
+
+
+# ---- photometric (photometric_losses.py:7-36) -------------------------------------------------------------------
+@_reduced
+def ssim_loss(inputs, targets, C1=0.01 ** 2, C2=0.03 ** 2, kernel_size=3, stride=1, padding=1, padding_mode="reflect"):
+    x, y = (F.pad(t, [padding] * 4, padding_mode) for t in (inputs, targets))
+    pool = lambda t: F.avg_pool2d(t, kernel_size, stride)
+    mx, my = pool(x), pool(y)
+    vxx, vyy, vxy = pool(x * x) - mx * mx, pool(y * y) - my * my, pool(x * y) - mx * my
+    ssim = ((2.0 * mx * my + C1) / (mx * mx + my * my + C1)) * ((2.0 * vxy + C2) / (vxx + vyy + C2))
+    return ((1.0 - ssim) / 2.0).clamp(0.0, 1.0)
+
+
+@_reduced
+def photometric_loss(inputs, targets, alpha=0.75):
+    return alpha * ssim_loss(inputs, targets, reduction="none") + (1.0 - alpha) * F.smooth_l1_loss(inputs, targets, reduction="none")
+
+
+# ---- smoothness (smoothness_losses.py:7-56) -----------------------------------------------------------------------
+def gradient_x(inputs, padding=(0, 1), padding_mode="replicate"):
+    padded = F.pad(inputs, (*padding, 0, 0), padding_mode)
+    return padded[..., :, 1:] - padded[..., :, :-1]
+
+
+def gradient_y(inputs, padding=(0, 1), padding_mode="replicate"):
+    padded = F.pad(inputs, (0, 0, *padding), padding_mode)
+    return padded[..., 1:, :] - padded[..., :-1, :]
+
+
+@_reduced
+def smoothness_loss(inputs, references, normalize=True, epsilon=1e-6):
+    if normalize:
+        inputs = inputs / (inputs.mean(dim=(-2, -1), keepdim=True) + epsilon)
+    edge_x = torch.exp(-gradient_x(references).abs().mean(dim=1, keepdim=True))
+    edge_y = torch.exp(-gradient_y(references).abs().mean(dim=1, keepdim=True))
+    return gradient_x(inputs).abs() * edge_x + gradient_y(inputs).abs() * edge_y
+
+
+@_reduced
+def motion_smoothness_loss(inputs, epsilon=1e-6):
+    return torch.sqrt(gradient_x(inputs) ** 2.0 + gradient_y(inputs) ** 2.0 + epsilon)
+
+
+@_reduced
+def motion_sparsity_loss(inputs, epsilon=1e-6):
+    with torch.no_grad():
+        scale = inputs.abs().mean(dim=(-2, -1), keepdim=True)
+    return torch.sqrt(inputs.abs() * scale + scale * scale + epsilon)
+
+
+# ---- probabilistic NLLs (probabilistic_losses.py:8-42) --------------------------------------------------------------
+@_reduced
+def gaussian_nll(means, variances, targets, epsilon=1e-6):
+    var = variances + epsilon
+    return 0.5 * torch.log(2.0 * math.pi * var) + (targets - means) ** 2 / (2.0 * var)
+
+
+@_reduced
+def student_nll(means, shapes, scales, targets, epsilon=1e-6):
+    """Gaussian marginalised over an inverse-gamma variance = generalised Student-t (dof 2*shape, scale^2 = scale/shape)."""
+    dof = 2.0 * shapes
+    sigma = torch.sqrt(scales / shapes + epsilon)
+    z = (targets - means) / sigma
+    log_norm = torch.lgamma(0.5 * dof) - torch.lgamma(0.5 * (dof + 1.0)) + 0.5 * torch.log(dof * math.pi) + torch.log(sigma)
+    return log_norm + 0.5 * (dof + 1.0) * torch.log1p(z * z / dof)
