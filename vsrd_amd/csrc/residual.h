@@ -29,8 +29,19 @@ struct Jet16 {
 __device__ __forceinline__ float gauss_pdf(float y) { return fast_exp(-0.5f * y * y) * 0.3989422804014327f; }
 __device__ __forceinline__ float gauss_cdf(float y) { return 0.5f * (1.0f + erff(y * 0.7071067811865476f)); }
 
+// Start of a weight row: makes the row pointer opaque to the optimiser at this point, so the scalar loads of the row are
+// issued here and not hoisted to the top of the function -- with ~100 rows of 16 SGPRs each in flight the compiler otherwise
+// spills SGPRs into VGPR lanes (59k v_readlane in the adjoint before this).
+// `after` is any value produced by the previous row: the data dependence is what keeps the rows (and their loads) in order.
+template <typename W>
+__device__ __forceinline__ W row_begin(W row, float after) {
+    asm volatile("" : "+s"(row) : "v"(after));
+    return row;
+}
+
 // First layer: encoder fused with Linear(48 -> 16).  Row o of the weight block is [W[o][0..47], bias].
-__device__ __forceinline__ void mlp_first_layer(const float* __restrict__ w, float f0, float f1, float f2, Jet16& z) {
+template <typename W>
+__device__ __forceinline__ void mlp_first_layer(W w, float f0, float f1, float f2, Jet16& z) {
     float feat[3][16], dfeat[3][16];
     const float f[3] = {f0, f1, f2};
 #pragma unroll
@@ -45,9 +56,10 @@ __device__ __forceinline__ void mlp_first_layer(const float* __restrict__ w, flo
             dfeat[c][2 * k] = -omega * s; dfeat[c][2 * k + 1] = omega * co;
         }
     }
+    float chain = f0;
 #pragma unroll
     for (int o = 0; o < kMlpHidden; ++o) {
-        const float* row = w + o * (kMlpFeatures + 1);
+        const W row = row_begin(w + o * (kMlpFeatures + 1), chain);
         float acc = row[kMlpFeatures];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -61,6 +73,8 @@ __device__ __forceinline__ void mlp_first_layer(const float* __restrict__ w, flo
             z.t[c][o] = tan;
         }
         z.v[o] = acc;
+        chain = acc;
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -96,11 +110,12 @@ __device__ __forceinline__ void mlp_norm_gelu(Jet16& z) {
 }
 
 // Linear(16 -> kOut) on a jet; weight rows are [W[o][0..15], bias].
-template <int kOut>
-__device__ __forceinline__ void mlp_linear(const float* __restrict__ w, const Jet16& a, Jet16& z) {
+template <int kOut, typename W>
+__device__ __forceinline__ void mlp_linear(W w, const Jet16& a, Jet16& z) {
+    float chain = a.v[0];
 #pragma unroll
     for (int o = 0; o < kOut; ++o) {
-        const float* row = w + o * (kMlpHidden + 1);
+        const W row = row_begin(w + o * (kMlpHidden + 1), chain);
         float acc = row[kMlpHidden], t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
 #pragma unroll
         for (int j = 0; j < kMlpHidden; ++j) {
@@ -109,18 +124,36 @@ __device__ __forceinline__ void mlp_linear(const float* __restrict__ w, const Je
             t0 += wj * a.t[0][j]; t1 += wj * a.t[1][j]; t2 += wj * a.t[2][j];
         }
         z.v[o] = acc; z.t[0][o] = t0; z.t[1][o] = t1; z.t[2][o] = t2;
+        chain = t2;
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 struct Residual { float value; float gx, gy, gz; };
 
+// A pointer that arrives in VGPRs (function argument of a non-inlined call) made provably wave-uniform again, so that the
+// weight loads behind it are selected as scalar loads.
+// constant address space (4): read-only for the whole launch (the MLP weights are never written by these kernels), which is what
+// lets uniform loads through it be selected as SMEM inside a non-inlined function.
+using GlobalFloats = const __attribute__((address_space(4))) float*;
+
+__device__ __forceinline__ GlobalFloats uniform_pointer(const float* p) {
+    const unsigned long long bits = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(bits));
+    const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(bits >> 32));
+    return reinterpret_cast<GlobalFloats>((static_cast<unsigned long long>(hi) << 32) | lo);   // SGPR pair
+}
+
 // residual(p) and d residual / d p for local position p, instance weights w (wave-uniform pointer).
-__device__ __forceinline__ Residual residual_forward(const float* __restrict__ w, float px, float py, float pz) {
+// NOT inlined: the fully unrolled MLP is ~9k instructions; one copy per kernel instead of one per call site keeps the
+// residual kernels from being megabytes of straight-line code (the 64 KB instruction cache is the scarce resource here).
+__device__ __attribute__((noinline)) Residual residual_forward(const float* w_in, float px, float py, float pz) {
+    const GlobalFloats w = uniform_pointer(w_in);
     const float fold = (px > 0.0f) ? 1.0f : ((px < 0.0f) ? -1.0f : 0.0f);
     const float inv = 1.0f / kPositionScale;
     Jet16 a, z;
     mlp_first_layer(w, fabsf(px) * inv, py * inv, pz * inv, z);
-    const float* wl = w + (kMlpFeatures + 1) * kMlpHidden;
+    GlobalFloats wl = w + (kMlpFeatures + 1) * kMlpHidden;
 #pragma unroll
     for (int layer = 0; layer < 3; ++layer) {
         mlp_norm_gelu(z);
@@ -199,8 +232,8 @@ __device__ __forceinline__ void layer_norm_adjoint(float (&v)[kMlpHidden], const
 
 // Adjoint of one block: (z_bar, dz_bar) of the linear's kOut outputs -> adjoint of the block's input jet (returned in zb),
 // weight adjoints of the linear accumulated into wbar (row-major [kOut][17]).
-template <int kOut>
-__device__ __forceinline__ void block_adjoint(const float* __restrict__ w, const Jet16& z_in, Jet16& zb, float* wbar, int lane) {
+template <int kOut, typename W>
+__device__ __forceinline__ void block_adjoint(W w, const Jet16& z_in, Jet16& zb, float* wbar, int lane) {
     BlockState b;
     block_state(z_in, b);
     float a_bar[kMlpHidden], da_bar[3][kMlpHidden];
@@ -209,17 +242,13 @@ __device__ __forceinline__ void block_adjoint(const float* __restrict__ w, const
     float bias[16];
 #pragma unroll
     for (int o = 0; o < 16; ++o) bias[o] = 0.0f;
+    // (1) weight adjoints: outer products reduced over the wave -- no weights needed
 #pragma unroll
     for (int o = 0; o < kOut; ++o) {
-        const float* row = w + o * (kMlpHidden + 1);
         float prod[16];
 #pragma unroll
-        for (int j = 0; j < kMlpHidden; ++j) {
+        for (int j = 0; j < kMlpHidden; ++j)
             prod[j] = zb.v[o] * b.a[j] + zb.t[0][o] * b.da[0][j] + zb.t[1][o] * b.da[1][j] + zb.t[2][o] * b.da[2][j];
-            const float wj = row[j];
-            a_bar[j] += wj * zb.v[o];
-            da_bar[0][j] += wj * zb.t[0][o]; da_bar[1][j] += wj * zb.t[1][o]; da_bar[2][j] += wj * zb.t[2][o];
-        }
         const float r = wave_reduce16_scatter(prod, lane);
         if (lane < kMlpHidden) wbar[o * (kMlpHidden + 1) + lane] += r;
         bias[o] = zb.v[o];
@@ -227,6 +256,20 @@ __device__ __forceinline__ void block_adjoint(const float* __restrict__ w, const
     {
         const float r = wave_reduce16_scatter(bias, lane);
         if (lane < kOut) wbar[lane * (kMlpHidden + 1) + kMlpHidden] += r;
+    }
+    // (2) activation adjoints: transposed mat-vec, one weight row (16 SGPRs) live at a time
+    float chain = b.inv_s;
+#pragma unroll
+    for (int o = 0; o < kOut; ++o) {
+        const W row = row_begin(w + o * (kMlpHidden + 1), chain);
+#pragma unroll
+        for (int j = 0; j < kMlpHidden; ++j) {
+            const float wj = row[j];
+            a_bar[j] += wj * zb.v[o];
+            da_bar[0][j] += wj * zb.t[0][o]; da_bar[1][j] += wj * zb.t[1][o]; da_bar[2][j] += wj * zb.t[2][o];
+        }
+        chain = da_bar[2][kMlpHidden - 1];
+        __builtin_amdgcn_sched_barrier(0);
     }
     // GELU jet adjoint
     float y_bar[kMlpHidden];
@@ -267,23 +310,28 @@ struct ResidualAdjoint { float px, py, pz; };
 
 // Adjoint of residual_forward at local position p: res_bar = dL/d residual, (gbx,gby,gbz) = dL/d(grad_p residual).
 // Accumulates dL/dw into wbar (LDS, [1617]); returns dL/dp.
-__device__ __forceinline__ ResidualAdjoint residual_backward(const float* __restrict__ w, float px, float py, float pz,
-                                                             float res_bar, float gbx, float gby, float gbz, float* wbar, int lane) {
+__device__ __attribute__((noinline)) ResidualAdjoint residual_backward(const float* w_in, float px, float py, float pz,
+                                                                       float res_bar, float gbx, float gby, float gbz, float* wbar, int lane) {
+    const GlobalFloats w = uniform_pointer(w_in);
     const float fold = (px > 0.0f) ? 1.0f : ((px < 0.0f) ? -1.0f : 0.0f);
     const float inv = 1.0f / kPositionScale;
     const float f[3] = {fabsf(px) * inv, py * inv, pz * inv};
     const float folds[3] = {fold, 1.0f, 1.0f};
-    // ---- forward with the four block inputs kept (z0 = first layer output, z1..z3 = hidden linear outputs) -----------
-    Jet16 z0, z1, z2, z3, a, out;
+    // ---- forward; only z0 (first-layer output) and z2 (second hidden linear's output) are kept: z1 and z3 are recomputed
+    //      from them when their block's adjoint runs (two extra hidden layers instead of 128 more live registers) ---------
+    Jet16 z0, z2, a, out;
     mlp_first_layer(w, f[0], f[1], f[2], z0);
-    const float* w1 = w + (kMlpFeatures + 1) * kMlpHidden;
-    const float* w2 = w1 + (kMlpHidden + 1) * kMlpHidden;
-    const float* w3 = w2 + (kMlpHidden + 1) * kMlpHidden;
-    const float* w4 = w3 + (kMlpHidden + 1) * kMlpHidden;
-    a = z0; mlp_norm_gelu(a); mlp_linear<kMlpHidden>(w1, a, z1);
-    a = z1; mlp_norm_gelu(a); mlp_linear<kMlpHidden>(w2, a, z2);
-    a = z2; mlp_norm_gelu(a); mlp_linear<kMlpHidden>(w3, a, z3);
-    a = z3; mlp_norm_gelu(a); mlp_linear<1>(w4, a, out);
+    const GlobalFloats w1 = w + (kMlpFeatures + 1) * kMlpHidden;
+    const GlobalFloats w2 = w1 + (kMlpHidden + 1) * kMlpHidden;
+    const GlobalFloats w3 = w2 + (kMlpHidden + 1) * kMlpHidden;
+    const GlobalFloats w4 = w3 + (kMlpHidden + 1) * kMlpHidden;
+    {
+        Jet16 z1, z3;
+        a = z0; mlp_norm_gelu(a); mlp_linear<kMlpHidden>(w1, a, z1);
+        mlp_norm_gelu(z1); mlp_linear<kMlpHidden>(w2, z1, z2);
+        a = z2; mlp_norm_gelu(a); mlp_linear<kMlpHidden>(w3, a, z3);
+        mlp_norm_gelu(z3); mlp_linear<1>(w4, z3, out);
+    }
     const float res = fast_rcp(1.0f + fast_exp(-(out.v[0] - 1.0f)));
     const float kappa = res * (1.0f - res);
     const float gb[3] = {gbx, gby, gbz};
@@ -298,9 +346,17 @@ __device__ __forceinline__ ResidualAdjoint residual_backward(const float* __rest
     zb.v[0] = (res_bar + kappa_bar * (1.0f - 2.0f * res)) * kappa;
     // ---- blocks 4..1 ---------------------------------------------------------------------------------------------------
     const int off1 = (kMlpFeatures + 1) * kMlpHidden, blk = (kMlpHidden + 1) * kMlpHidden;
-    block_adjoint<1>(w4, z3, zb, wbar + off1 + 3 * blk, lane);
+    {
+        Jet16 z3;
+        a = z2; mlp_norm_gelu(a); mlp_linear<kMlpHidden>(w3, a, z3);
+        block_adjoint<1>(w4, z3, zb, wbar + off1 + 3 * blk, lane);
+    }
     block_adjoint<kMlpHidden>(w3, z2, zb, wbar + off1 + 2 * blk, lane);
-    block_adjoint<kMlpHidden>(w2, z1, zb, wbar + off1 + blk, lane);
+    {
+        Jet16 z1;
+        a = z0; mlp_norm_gelu(a); mlp_linear<kMlpHidden>(w1, a, z1);
+        block_adjoint<kMlpHidden>(w2, z1, zb, wbar + off1 + blk, lane);
+    }
     block_adjoint<kMlpHidden>(w1, z0, zb, wbar + off1, lane);
     // ---- first layer + encoder -----------------------------------------------------------------------------------------
     float f_bar[3] = {0.0f, 0.0f, 0.0f};
@@ -327,17 +383,24 @@ __device__ __forceinline__ ResidualAdjoint residual_backward(const float* __rest
         }
 #pragma unroll
         for (int o = 0; o < kMlpHidden; ++o) {
-            const float* row = w + o * (kMlpFeatures + 1) + c * 16;
             float prod[16];
 #pragma unroll
+            for (int j = 0; j < 16; ++j) prod[j] = zb.v[o] * feat[j] + zb.t[c][o] * dfeat[j];
+            const float r = wave_reduce16_scatter(prod, lane);
+            if (lane < 16) wbar[o * (kMlpFeatures + 1) + c * 16 + lane] += r;
+        }
+        float chain = feat[0];
+#pragma unroll
+        for (int o = 0; o < kMlpHidden; ++o) {
+            const GlobalFloats row = row_begin(w + o * (kMlpFeatures + 1) + c * 16, chain);
+#pragma unroll
             for (int j = 0; j < 16; ++j) {
-                prod[j] = zb.v[o] * feat[j] + zb.t[c][o] * dfeat[j];
                 const float wj = row[j];
                 feat_bar[j] += wj * zb.v[o];
                 dfeat_bar[j] += wj * zb.t[c][o];
             }
-            const float r = wave_reduce16_scatter(prod, lane);
-            if (lane < 16) wbar[o * (kMlpFeatures + 1) + c * 16 + lane] += r;
+            chain = dfeat_bar[15];
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
