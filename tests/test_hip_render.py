@@ -301,6 +301,12 @@ def test_philox_mode_matches_oracle_on_exported_uniforms(dev):
     assert not torch.equal(a["u_coarse"], c["u_coarse"])
     u = torch.cat([a["u_coarse"].flatten(), a["u_fine"].flatten()]).cpu()
     assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.01 and abs(u.var() - 1 / 12) < 0.005
+    # the fine uniforms come out sorted (order statistics via exponential spacings): k-th of S has mean k/(S+1)
+    uf = a["u_fine"].cpu()
+    assert torch.all(uf[:, 1:] >= uf[:, :-1])
+    expected = torch.arange(1, S + 1, dtype=torch.float32) / (S + 1)
+    assert (uf.mean(0) - expected).abs().max() < 0.02
+    assert abs(float(uf[:, S // 2].var()) - (S // 2 + 1) * (S - S // 2) / ((S + 1) ** 2 * (S + 2))) < 2e-3
     ounion, _ = cpu_union(g)
     fine = orendering.hierarchical_render(ounion, g["origins"], g["directions"], (0.0, 100.0), S, std, ratio,
                                           a["u_coarse"].cpu(), a["u_fine"].cpu())

@@ -120,6 +120,12 @@ def test_five_optimisation_steps_match_oracle(dev):
             q.copy_(v)
     well_conditioned = [torch.ones(N, 3, dtype=torch.bool), torch.ones(N, 3, dtype=torch.bool), torch.ones(N, 2, dtype=torch.bool)]
     for step in range(5):
+        # both loops take every step from the same parameters: Adam turns ulp-level gradient differences into lr-sized parameter
+        # differences for near-zero gradients, and a discrete event (arg-max corner, image clamp) that flips between two such
+        # trajectories is not a kernel property.  What is compared is each step, not the accumulated drift.
+        with torch.no_grad():
+            for p_dev, p_cpu in zip((device_loop.detector.locations, device_loop.detector.dimensions, device_loop.detector.orientations), oracle_loop.raw):
+                p_cpu.copy_(p_dev[0].cpu())
         torch.manual_seed(100 + step)
         idx = device_loop.sample_rays()
         assert idx.shape == (R,) and idx.unique().numel() == R

@@ -30,8 +30,8 @@ def test_header_symbols_are_exported(lib):
     for name in declared:
         assert getattr(lib, name) is not None
     assert lib.vsrd_abi_version() == 1
-    assert lib.vsrd_workspace_bytes(16, 0) == 2048 * 4 * 16 * 16 * 4
-    assert lib.vsrd_workspace_bytes(16, 1) == 2048 * 4 * 16 * 16 * 4 + 256 * 4 * 16 * 1617 * 4
+    assert lib.vsrd_workspace_bytes(16, 0) == 16384 * 4 * 16 * 16 * 4
+    assert lib.vsrd_workspace_bytes(16, 1) == 16384 * 4 * 16 * 16 * 4 + 256 * 4 * 16 * 1617 * 4
     assert lib.vsrd_workspace_bytes(0, 0) == 0 and lib.vsrd_workspace_bytes(65, 0) == 0
     assert lib.vsrd_error_string(-1) == b"invalid argument"
 

@@ -1,5 +1,6 @@
 // C ABI of libvsrd_hip (include/vsrd_hip.h): argument validation, launch geometry, dispatch on the
 // number of 64-sample rounds.  No torch types, no global state, no allocation.
+#include <cstdlib>
 #include "../../include/vsrd_hip.h"
 #include "aux_kernels.h"
 #include "projection.h"
@@ -8,7 +9,16 @@ namespace {
 
 using namespace vsrd;
 
-constexpr int kMaxBlocks = 2048;             // 256 CUs x 8 workgroups: persistent-ish grid
+constexpr int kMaxBlocks = 16384;             // 256 CUs x 8 workgroups: many more workgroups than are resident: rays differ a lot in cost and the dispatcher is the load balancer (r01: 2048 -> 16384 workgroups = -12 % time); also sizes the partial buffer
+
+int grid_cap() {                              // experiment switch: VSRD_GRID_BLOCKS=<n> (<= kMaxBlocks)
+    static const int cap = [] {
+        const char* e = getenv("VSRD_GRID_BLOCKS");
+        const int v = e ? atoi(e) : 0;
+        return (v > 0 && v <= kMaxBlocks) ? v : kMaxBlocks;
+    }();
+    return cap;
+}
 constexpr size_t kLdsLimit = 160 * 1024;     // gfx950 LDS per CU
 constexpr size_t kLdsDefault = 64 * 1024;    // dynamic LDS without opting in
 
@@ -27,8 +37,32 @@ bool plan(int num_rays, size_t floats_per_wave, Geometry* g) {
     g->threads = waves * kWave;
     g->lds_bytes = per_wave * waves;
     const long long want = (static_cast<long long>(num_rays) + waves - 1) / waves;
-    g->blocks = static_cast<int>(want < 1 ? 1 : (want > kMaxBlocks ? kMaxBlocks : want));
+    const int cap = grid_cap();
+    g->blocks = static_cast<int>(want < 1 ? 1 : (want > cap ? cap : want));
     return true;
+}
+
+// Size a persistent launch to what is actually co-resident: with a static ray -> wave assignment a grid larger than the
+// residency runs in "phases", and a partially filled last phase idles most of the chip (2048 workgroups at 6 resident per CU
+// = 1.33 phases cost 2).  Performance only -- correctness never depends on residency (no inter-workgroup communication).
+template <typename Kernel>
+void fit_to_residency(Kernel kernel, Geometry* g) {
+    static int num_cus = 0;
+    if (num_cus == 0) {
+        int device = 0;
+        hipDeviceProp_t props;
+        if (hipGetDevice(&device) == hipSuccess && hipGetDeviceProperties(&props, device) == hipSuccess) num_cus = props.multiProcessorCount;
+        if (num_cus <= 0) num_cus = 256;
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel), g->threads, g->lds_bytes) != hipSuccess || per_cu < 1)
+        return;
+    const int resident = per_cu * num_cus;
+    // Measured on C2 (r01): capping the grid at `resident` (one phase) is 5 % SLOWER than 2048 workgroups -- rays differ a lot in
+    // cost (culling, early outs) and the extra workgroups act as dynamic load balancing -- so the grid is left alone unless the
+    // experiment switch asks for it.
+    static const char* cap = getenv("VSRD_CAP_TO_RESIDENCY");
+    if (cap && cap[0] == '1' && g->blocks > resident) g->blocks = resident;
 }
 
 template <typename Kernel>
@@ -226,6 +260,7 @@ int32_t vsrd_render_forward(const vsrd_field* field, const vsrd_render_config* c
 #define VSRD_LAUNCH(K, RES)                                                                                                  \
     do {                                                                                                                       \
         if (opt_in_lds(render_forward_kernel<K, RES>, g.lds_bytes) != VSRD_OK) return VSRD_E_LAUNCH;                         \
+        fit_to_residency(render_forward_kernel<K, RES>, &g);                                                                  \
         hipLaunchKernelGGL((render_forward_kernel<K, RES>), dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, \
                            field->mlp_weights, c, origins, directions, distances, num_distances, labels, gradients, weights);   \
     } while (0)
@@ -280,6 +315,8 @@ int32_t vsrd_render_backward(const vsrd_field* field, const vsrd_render_config* 
     float* partials = static_cast<float*>(workspace);
     float* mlp_partials = partials + static_cast<size_t>(kMaxBlocks) * kMaxWavesPerBlock * row;
 #define VSRD_LAUNCH(K, RES)                                                                                                    \
+    fit_to_residency(render_backward_kernel<K, RES>, &g);                                                                        \
+    if (residual && g.blocks > kMaxBlocksResidual) g.blocks = kMaxBlocksResidual;                                                \
     hipLaunchKernelGGL((render_backward_kernel<K, RES>), dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances,    \
                        field->mlp_weights, c, origins, directions, distances, num_distances, grad_labels, grad_gradients,         \
                        grad_weights, partials, mlp_partials)
@@ -327,6 +364,7 @@ int32_t vsrd_render_hierarchical_forward(const vsrd_field* field, const vsrd_ren
 #define VSRD_LAUNCH(K, RES)                                                                                                  \
     do {                                                                                                                       \
         if (opt_in_lds(render_hierarchical_kernel<K, RES>, g.lds_bytes) != VSRD_OK) return VSRD_E_LAUNCH;                    \
+        fit_to_residency(render_hierarchical_kernel<K, RES>, &g);                                                             \
         hipLaunchKernelGGL((render_hierarchical_kernel<K, RES>), dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f,            \
                            field->instances, field->mlp_weights, c, origins, directions, u_coarse, u_fine, labels, distances,   \
                            gradients, weights, u_coarse_out, u_fine_out);                                                     \

@@ -47,6 +47,10 @@ struct BoxEval {
 
 __device__ __forceinline__ float sign_of(float v) { return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); }
 
+// sign(p) * h for h >= 0 with torch's sign(0) = 0: one v_bfi (copysign) + compare + select instead of two compares,
+// two selects and a multiply.
+__device__ __forceinline__ float times_sign(float h, float p) { return (p == 0.0f) ? 0.0f : __builtin_copysignf(h, p); }
+
 __device__ __forceinline__ BoxEval eval_box(const Instance& in, float x, float y, float z) {
     BoxEval e;
     e.relx = x - in.tx; e.rely = y - in.ty; e.relz = z - in.tz;
@@ -67,7 +71,7 @@ __device__ __forceinline__ BoxEval eval_box(const Instance& in, float x, float y
     e.hx = ax * inv + ((arg == 0) ? inside : 0.0f);
     e.hy = ay * inv + ((arg == 1) ? inside : 0.0f);
     e.hz = az * inv + ((arg == 2) ? inside : 0.0f);
-    e.glx = sign_of(e.px) * e.hx; e.gly = sign_of(e.py) * e.hy; e.glz = sign_of(e.pz) * e.hz;
+    e.glx = times_sign(e.hx, e.px); e.gly = times_sign(e.hy, e.py); e.glz = times_sign(e.hz, e.pz);
     // gw_k = sum_j R_kj gl_j
     e.gwx = in.r00 * e.glx + in.r01 * e.gly + in.r02 * e.glz;
     e.gwy = in.r10 * e.glx + in.r11 * e.gly + in.r12 * e.glz;

@@ -93,30 +93,59 @@ __global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
         const Ray r = load_ray(origins, directions, c.origin_stride, ray);
         const size_t row = static_cast<size_t>(ray) * S;
         // ---- stratified distances (samplers.py:5-8) and the fine uniforms -------------------------
+        // In-kernel randomness: Philox4x32-10 per (ray, sample).  The S fine uniforms are needed SORTED (samplers.py:22);
+        // instead of drawing and sorting, they are generated in order as normalised partial sums of S+1 exponential spacings
+        // (the order statistics of S iid uniforms have exactly this distribution): one log + one wave scan instead of a sort.
+        const bool philox = (u_coarse == nullptr || u_fine == nullptr);
+        float spacing[kRoundsS];
+        float running = 0.0f, extra_spacing = 0.0f;
 #pragma unroll
         for (int k = 0; k < kRoundsS; ++k) {
             const int idx = k * kWave + lane;
-            if (idx < S) {
-                float uc, uf;
-                if (u_coarse == nullptr || u_fine == nullptr) {
-                    const Philox4 rnd = philox4x32_10(static_cast<uint32_t>(ray), static_cast<uint32_t>(idx),
-                                                      static_cast<uint32_t>(c.stream_offset), static_cast<uint32_t>(c.stream_offset >> 32),
-                                                      static_cast<uint32_t>(c.seed), static_cast<uint32_t>(c.seed >> 32));
-                    uc = uniform_from_bits(rnd.x);
-                    uf = uniform_from_bits(rnd.y);
-                }
-                if (u_coarse != nullptr) uc = u_coarse[row + idx];
-                if (u_fine != nullptr) uf = u_fine[row + idx];
+            spacing[k] = 0.0f;
+            if (k * kWave >= S) continue;
+            float uc = 0.0f, uf = 0.0f;
+            if (philox) {
+                const Philox4 rnd = philox4x32_10(static_cast<uint32_t>(ray), static_cast<uint32_t>(idx),
+                                                  static_cast<uint32_t>(c.stream_offset), static_cast<uint32_t>(c.stream_offset >> 32),
+                                                  static_cast<uint32_t>(c.seed), static_cast<uint32_t>(c.seed >> 32));
+                uc = uniform_from_bits(rnd.x);
+                uf = uniform_from_bits(rnd.y);
+                if (k == 0) extra_spacing = -fast_log(1.0f - read_lane(uniform_from_bits(rnd.z), 0));   // the (S+1)-th spacing
+            }
+            const bool valid = idx < S;
+            if (u_coarse != nullptr && valid) uc = u_coarse[row + idx];
+            if (u_fine != nullptr && valid) uf = u_fine[row + idx];
+            if (valid) {
                 const float lo = torch_linspace(c.near, c.far, S + 1, idx);
                 const float hi = torch_linspace(c.near, c.far, S + 1, idx + 1);
                 l.coarse[idx] = torch_lerp(lo, hi, uc);
-                (sorted_input ? l.usorted : l.uraw)[idx] = uf;
                 if (u_coarse_out != nullptr) u_coarse_out[row + idx] = uc;
+            }
+            if (u_fine == nullptr) {
+                const float e = valid ? -fast_log(1.0f - uf) : 0.0f;          // exponential spacing, > 0
+                const float inclusive = wave_inclusive_sum(e) + running;
+                spacing[k] = inclusive;
+                running = read_lane(inclusive, kWave - 1);
+            } else if (valid) {
+                (sorted_input ? l.usorted : l.uraw)[idx] = uf;
                 if (u_fine_out != nullptr) u_fine_out[row + idx] = uf;
             }
         }
+        if (u_fine == nullptr) {
+            const float inv_total = fast_rcp(running + extra_spacing);
+#pragma unroll
+            for (int k = 0; k < kRoundsS; ++k) {
+                const int idx = k * kWave + lane;
+                if (idx < S) {
+                    const float sorted_u = fminf(spacing[k] * inv_total, 0.99999994f);
+                    l.usorted[idx] = sorted_u;
+                    if (u_fine_out != nullptr) u_fine_out[row + idx] = sorted_u;
+                }
+            }
+        }
         wave_lds_sync();
-        if (!sorted_input) {
+        if (u_fine != nullptr && !sorted_input) {
             rank_sort<kRoundsS>(l.uraw, l.usorted, S);
             wave_lds_sync();
         }

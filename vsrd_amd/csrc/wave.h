@@ -152,10 +152,12 @@ __device__ __forceinline__ float wave_reverse(float v, int lane) { return __shfl
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
 #else
 __device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
 __device__ __forceinline__ float fast_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ float fast_exp(float x) { return expf(x); }
+__device__ __forceinline__ float fast_log(float x) { return logf(x); }
 #endif
 
 // ---- Philox4x32-10 (counter-based; the same generator family torch uses on device) --------------
