@@ -195,6 +195,181 @@ struct SampleAdjoint {
     float A, B;           // g_bar . g,  g_bar . sum_i w_i grad d_i
 };
 
+// Per-ray state of the adjoint, one or a few samples per lane.
+template <int kRounds>
+struct RayAdjoint {
+    SampleAdjoint sa[kRounds];
+    Opacity op[kRounds];
+    float gx[kRounds], gy[kRounds], gz[kRounds], trans[kRounds], delta[kRounds], thr[kRounds];
+};
+
+// Phase A, forward sweep: union sums (with Lambda = sum_n lambda_n e_n when `lam` is given), opacity, transmittance.
+// kCacheD additionally keeps every instance's distance of every round in `dcache` [kRounds][N][64] (fused loss kernel).
+template <int kRounds, bool kResidual, bool kCacheD>
+__device__ __forceinline__ void adjoint_forward_sweep(RayAdjoint<kRounds>& st, const float* __restrict__ instances, const float* __restrict__ mlp,
+                                                      int N, const Shading& sh, const Ray& r, const float* dist, int num_points,
+                                                      const float* lam, float* dcache, int lane) {
+    const float inv_t = sh.inv_t;
+    float carry = 1.0f;
+#pragma unroll
+    for (int k = 0; k < kRounds; ++k) {
+        const int s = k * kWave + lane;
+        const bool valid = s < num_points;
+        const int s0 = valid ? s : (num_points - 1);
+        const float d0 = dist[s0], d1 = dist[s0 + 1];
+        st.delta[k] = d1 - d0;
+        const float mid = (d0 + d1) / 2.0f;
+        st.sa[k].x = r.ox + r.rx * mid; st.sa[k].y = r.oy + r.ry * mid; st.sa[k].z = r.oz + r.rz * mid;
+        // culling (field.h): nearest centre first, then one ballot per instance
+        float nearest = 3.0e38f;
+        for (int i = 0; i < N; ++i) nearest = fminf(nearest, centre_distance(load_instance(instances, i), st.sa[k].x, st.sa[k].y, st.sa[k].z));
+        st.thr[k] = nearest * (1.0f + kCullSlack) + sh.cull;
+        UnionSums sums = union_init();
+        for (int i = 0; i < N; ++i) {
+            const Instance in = load_instance(instances, i);
+            const float lb = centre_distance(in, st.sa[k].x, st.sa[k].y, st.sa[k].z) * (1.0f - kCullSlack) - bounding_radius(in);
+            if (!wave_any(lb <= st.thr[k])) {
+                if (kCacheD) dcache[(k * N + i) * kWave + lane] = lb;      // > thr on every lane: marks the instance as culled
+                continue;
+            }
+            const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, st.sa[k].x, st.sa[k].y, st.sa[k].z);
+            if (kCacheD) dcache[(k * N + i) * kWave + lane] = e.d;
+            union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, inv_t);
+        }
+        const UnionValue v = union_finish(sums, inv_t);
+        st.op[k] = opacity_of(v, r, st.delta[k], sh);
+        const float alpha = valid ? st.op[k].alpha : 0.0f;
+        st.op[k].alpha = alpha;
+        const float inclusive = wave_inclusive_product(1.0f - alpha);
+        st.trans[k] = carry * wave_shift_up(inclusive, 1.0f, lane);
+        carry *= read_lane(inclusive, kWave - 1);
+        st.sa[k].m = v.m; st.sa[k].inv_z = v.inv_z; st.sa[k].us = v.us;
+        st.sa[k].wgt = st.trans[k] * alpha;
+        st.sa[k].lam_z = sums.L * v.inv_z;
+        st.gx[k] = v.gx; st.gy[k] = v.gy; st.gz[k] = v.gz;
+        // B needs sum_i w_i grad d_i: stash it in (gbx,gby,gbz) until the reverse sweep
+        st.sa[k].gbx = v.b0x; st.sa[k].gby = v.b0y; st.sa[k].gbz = v.b0z;
+    }
+}
+
+// Phase A, reverse sweep: labels -> weights -> opacity -> (u_bar, g_bar).  Returns (wave-uniformly) whether any adjoint is non-zero.
+template <int kRounds>
+__device__ __forceinline__ bool adjoint_reverse_sweep(RayAdjoint<kRounds>& st, const Shading& sh, const Ray& r, int num_points,
+                                                      const float* grad_weights_row, const float* grad_gradients_row, int lane) {
+    float suffix_carry = 0.0f;
+    bool any_flow = false;
+#pragma unroll
+    for (int k = kRounds - 1; k >= 0; --k) {
+        const int s = k * kWave + lane;
+        const bool valid = s < num_points;
+        float w_bar = st.sa[k].lam_z;
+        if (grad_weights_row != nullptr && valid) w_bar += grad_weights_row[s];
+        const float contrib = valid ? w_bar * st.sa[k].wgt : 0.0f;
+        const float rev_inclusive = wave_inclusive_sum(wave_reverse(contrib, lane));
+        const float suffix_inclusive = wave_reverse(rev_inclusive, lane);
+        const float Q = suffix_inclusive - contrib + suffix_carry;          // sum over later samples
+        suffix_carry += read_lane(rev_inclusive, kWave - 1);
+        const float alpha = st.op[k].alpha;
+        const float alpha_bar = w_bar * st.trans[k] - Q * fast_rcp(1.0f - alpha);
+        const float x_bar = (valid && st.op[k].xx > 0.0f) ? alpha_bar : 0.0f;
+        const float inv_pe = fast_rcp(st.op[k].phi_p + sh.eps);
+        const float phi_p_bar = x_bar * (st.op[k].phi_n + sh.eps) * inv_pe * inv_pe;
+        const float phi_n_bar = -x_bar * inv_pe;
+        const float sp_bar = phi_p_bar * st.op[k].phi_p * (1.0f - st.op[k].phi_p) * sh.inv_std;
+        const float sn_bar = phi_n_bar * st.op[k].phi_n * (1.0f - st.op[k].phi_n) * sh.inv_std;
+        const float u_bar = sp_bar + sn_bar;
+        const float cprime_bar = (sn_bar - sp_bar) * st.delta[k] / 2.0f;
+        const float slope = (1.0f - sh.ratio) * ((0.5f - 0.5f * st.op[k].cosine > 0.0f) ? 0.5f : 0.0f)
+                          + sh.ratio * ((-st.op[k].cosine > 0.0f) ? 1.0f : 0.0f);
+        const float cos_bar = cprime_bar * slope;
+        const float nbx = cos_bar * r.rx, nby = cos_bar * r.ry, nbz = cos_bar * r.rz;
+        const float n_dot = st.op[k].nx * nbx + st.op[k].ny * nby + st.op[k].nz * nbz;
+        float gbx = (nbx - st.op[k].nx * n_dot) * st.op[k].inv_gn;
+        float gby = (nby - st.op[k].ny * n_dot) * st.op[k].inv_gn;
+        float gbz = (nbz - st.op[k].nz * n_dot) * st.op[k].inv_gn;
+        if (grad_gradients_row != nullptr && valid) {
+            const float* gg = grad_gradients_row + s * 3;
+            gbx += gg[0]; gby += gg[1]; gbz += gg[2];
+        }
+        if (!valid) { gbx = 0.0f; gby = 0.0f; gbz = 0.0f; }
+        st.sa[k].B = gbx * st.sa[k].gbx + gby * st.sa[k].gby + gbz * st.sa[k].gbz;
+        st.sa[k].A = gbx * st.gx[k] + gby * st.gy[k] + gbz * st.gz[k];
+        st.sa[k].gbx = gbx; st.sa[k].gby = gby; st.sa[k].gbz = gbz;
+        st.sa[k].u_bar = valid ? u_bar : 0.0f;
+        if (!valid) { st.sa[k].wgt = 0.0f; st.sa[k].lam_z = 0.0f; }
+        any_flow = any_flow || (st.sa[k].u_bar != 0.0f) || (gbx != 0.0f) || (gby != 0.0f) || (gbz != 0.0f) || (st.sa[k].wgt != 0.0f);
+    }
+    return __ballot(any_flow) != 0ull;
+}
+
+// Phase B: per instance, adjoint of (d_i, grad d_i) w.r.t. (t, R, dim) (and the residual MLP weights), accumulated into the wave's
+// LDS rows G [N,16] / wbar [1617].
+template <int kRounds, bool kResidual>
+__device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, const float* __restrict__ instances, const float* __restrict__ mlp,
+                                                int N, float inv_t, int num_points, const float* lam, float* G, float* wbar, float* my_mlp, int lane) {
+    for (int i = 0; i < N; ++i) {
+        const Instance in = load_instance(instances, i);
+        const float lam_i = lam[i];
+        const float rho = bounding_radius(in);
+        bool active[kRounds];
+        bool any_active = false;
+#pragma unroll
+        for (int k = 0; k < kRounds; ++k) {
+            const float lb = centre_distance(in, st.sa[k].x, st.sa[k].y, st.sa[k].z) * (1.0f - kCullSlack) - rho;
+            active[k] = (k * kWave < num_points) && wave_any(lb <= st.thr[k]);
+            any_active = any_active || active[k];
+        }
+        if (!any_active) continue;                                            // negligible for this ray (field.h culling)
+        float at0 = 0, at1 = 0, at2 = 0, ad0 = 0, ad1 = 0, ad2 = 0;
+        float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
+#pragma unroll
+        for (int k = 0; k < kRounds; ++k) {
+            if (!active[k]) continue;
+            const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, st.sa[k].x, st.sa[k].y, st.sa[k].z);
+            const float ds = e.d - st.sa[k].m;
+            const float w = fast_exp(-ds * inv_t) * st.sa[k].inv_z;
+            const float cc = w * (1.0f - (ds - st.sa[k].us) * inv_t);
+            const float beta = st.sa[k].gbx * e.gwx + st.sa[k].gby * e.gwy + st.sa[k].gbz * e.gwz;
+            const float d_bar = st.sa[k].u_bar * cc
+                              + inv_t * (-beta * cc + w * st.sa[k].A - beta * w + cc * st.sa[k].B)
+                              - inv_t * w * st.sa[k].wgt * (lam_i - st.sa[k].lam_z);
+            const float gwbx = cc * st.sa[k].gbx, gwby = cc * st.sa[k].gby, gwbz = cc * st.sa[k].gbz;
+            // gl_bar_j = sum_k R_kj gw_bar_k
+            const float glbx = in.r00 * gwbx + in.r10 * gwby + in.r20 * gwbz;
+            const float glby = in.r01 * gwbx + in.r11 * gwby + in.r21 * gwbz;
+            const float glbz = in.r02 * gwbx + in.r12 * gwby + in.r22 * gwbz;
+            const float sx = sign_of(e.px), sy = sign_of(e.py), sz = sign_of(e.pz);
+            const float vx = sx * glbx, vy = sy * glby, vz = sz * glbz;
+            const float inv_n = fast_rcp(e.nrm);
+            const float hx = fmaxf(e.qx, 0.0f) * inv_n, hy = fmaxf(e.qy, 0.0f) * inv_n, hz = fmaxf(e.qz, 0.0f) * inv_n;
+            const float hv = hx * vx + hy * vy + hz * vz;
+            const float qbx = d_bar * e.hx + ((e.qx > 0.0f) ? (vx - hx * hv) * inv_n : 0.0f);
+            const float qby = d_bar * e.hy + ((e.qy > 0.0f) ? (vy - hy * hv) * inv_n : 0.0f);
+            const float qbz = d_bar * e.hz + ((e.qz > 0.0f) ? (vz - hz * hv) * inv_n : 0.0f);
+            float pbx = sx * qbx, pby = sy * qby, pbz = sz * qbz;
+            ad0 -= qbx; ad1 -= qby; ad2 -= qbz;
+            if (kResidual) {        // residual(p): value adjoint d_bar, local-gradient adjoint gl_bar (main.py:451-458)
+                const ResidualAdjoint ra = residual_backward(mlp + i * kMlpWeights, e.px, e.py, e.pz, d_bar, glbx, glby, glbz, wbar, lane);
+                pbx += ra.px; pby += ra.py; pbz += ra.pz;
+            }
+            r00 += e.relx * pbx + gwbx * e.glx; r01 += e.relx * pby + gwbx * e.gly; r02 += e.relx * pbz + gwbx * e.glz;
+            r10 += e.rely * pbx + gwby * e.glx; r11 += e.rely * pby + gwby * e.gly; r12 += e.rely * pbz + gwby * e.glz;
+            r20 += e.relz * pbx + gwbz * e.glx; r21 += e.relz * pby + gwbz * e.gly; r22 += e.relz * pbz + gwbz * e.glz;
+            at0 -= in.r00 * pbx + in.r01 * pby + in.r02 * pbz;
+            at1 -= in.r10 * pbx + in.r11 * pby + in.r12 * pbz;
+            at2 -= in.r20 * pbx + in.r21 * pby + in.r22 * pbz;
+        }
+        // one reduce-scatter butterfly: lane j (< 16) receives parameter j of instance i and keeps it in its LDS slot
+        const float packed[16] = {at0, at1, at2, r00, r01, r02, r10, r11, r12, r20, r21, r22, ad0, ad1, ad2, 0.0f};
+        const float mine = wave_reduce16_scatter(packed, lane);
+        if (lane < kGradStride) G[i * kGradStride + lane] += mine;
+        if (kResidual) {            // flush this instance's MLP weight adjoints into the wave's global row (wave-private RMW)
+            float* dst = my_mlp + static_cast<size_t>(i) * kMlpWeights;
+            for (int idx = lane; idx < kMlpWeights; idx += kWave) { dst[idx] += wbar[idx]; wbar[idx] = 0.0f; }
+        }
+    }
+}
+
 template <int kRounds, bool kResidual>
 __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
     FieldArgs f, const float* __restrict__ instances, const float* __restrict__ mlp, RenderArgs c,
@@ -219,9 +394,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
         for (int idx = lane; idx < N * kMlpWeights; idx += kWave) my_mlp[idx] = 0.0f;
         for (int idx = lane; idx < kMlpWeights; idx += kWave) wbar[idx] = 0.0f;
     }
-    const float inv_t = f.inv_t;
     Shading sh = c.sh;
-    sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, N, inv_t) + (kResidual ? 1.0f : 0.0f);
+    sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, N, f.inv_t) + (kResidual ? 1.0f : 0.0f);
     const int stride = static_cast<int>(gridDim.x) * waves_per_block();
     for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
         wave_lds_sync();
@@ -233,159 +407,15 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
         if (lane < N) lam[lane] = lam_lane;
         wave_lds_sync();
         if (dist[0] != dist[0]) continue;                            // NaN sentinel: ray skipped by the forward
-
-        // ---- phase A, forward sweep: union sums, opacity, transmittance -----------------------------
-        SampleAdjoint sa[kRounds];
-        Opacity op[kRounds];
-        float gx[kRounds], gy[kRounds], gz[kRounds], trans[kRounds], delta[kRounds], thr[kRounds];
-        float carry = 1.0f;
-#pragma unroll
-        for (int k = 0; k < kRounds; ++k) {
-            const int s = k * kWave + lane;
-            const bool valid = s < num_points;
-            const int s0 = valid ? s : (num_points - 1);
-            const float d0 = dist[s0], d1 = dist[s0 + 1];
-            delta[k] = d1 - d0;
-            const float mid = (d0 + d1) / 2.0f;
-            sa[k].x = r.ox + r.rx * mid; sa[k].y = r.oy + r.ry * mid; sa[k].z = r.oz + r.rz * mid;
-            // culling (field.h): nearest centre first, then one ballot per instance
-            float nearest = 3.0e38f;
-            for (int i = 0; i < N; ++i) nearest = fminf(nearest, centre_distance(load_instance(instances, i), sa[k].x, sa[k].y, sa[k].z));
-            thr[k] = nearest * (1.0f + kCullSlack) + sh.cull;
-            UnionSums sums = union_init();
-            for (int i = 0; i < N; ++i) {
-                const Instance in = load_instance(instances, i);
-                const float lb = centre_distance(in, sa[k].x, sa[k].y, sa[k].z) * (1.0f - kCullSlack) - bounding_radius(in);
-                if (!wave_any(lb <= thr[k])) continue;
-                const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, sa[k].x, sa[k].y, sa[k].z);
-                union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lam[i], inv_t);
-            }
-            const UnionValue v = union_finish(sums, inv_t);
-            op[k] = opacity_of(v, r, delta[k], sh);
-            const float alpha = valid ? op[k].alpha : 0.0f;
-            op[k].alpha = alpha;
-            const float inclusive = wave_inclusive_product(1.0f - alpha);
-            trans[k] = carry * wave_shift_up(inclusive, 1.0f, lane);
-            carry *= read_lane(inclusive, kWave - 1);
-            sa[k].m = v.m; sa[k].inv_z = v.inv_z; sa[k].us = v.us;
-            sa[k].wgt = trans[k] * alpha;
-            sa[k].lam_z = sums.L * v.inv_z;
-            gx[k] = v.gx; gy[k] = v.gy; gz[k] = v.gz;
-            // B needs sum_i w_i grad d_i: stash it in (gbx,gby,gbz) until the reverse sweep
-            sa[k].gbx = v.b0x; sa[k].gby = v.b0y; sa[k].gbz = v.b0z;
-        }
-        // ---- phase A, reverse sweep: labels -> weights -> opacity -> (u_bar, g_bar) -----------------
-        float suffix_carry = 0.0f;
-        bool any_flow = false;
-#pragma unroll
-        for (int k = kRounds - 1; k >= 0; --k) {
-            const int s = k * kWave + lane;
-            const bool valid = s < num_points;
-            float w_bar = sa[k].lam_z;
-            if (grad_weights != nullptr && valid) w_bar += grad_weights[static_cast<size_t>(ray) * num_points + s];
-            const float contrib = valid ? w_bar * sa[k].wgt : 0.0f;
-            const float rev_inclusive = wave_inclusive_sum(wave_reverse(contrib, lane));
-            const float suffix_inclusive = wave_reverse(rev_inclusive, lane);
-            const float Q = suffix_inclusive - contrib + suffix_carry;          // sum over later samples
-            suffix_carry += read_lane(rev_inclusive, kWave - 1);
-            const float alpha = op[k].alpha;
-            const float alpha_bar = w_bar * trans[k] - Q * fast_rcp(1.0f - alpha);
-            const float x_bar = (valid && op[k].xx > 0.0f) ? alpha_bar : 0.0f;
-            const float inv_pe = fast_rcp(op[k].phi_p + sh.eps);
-            const float phi_p_bar = x_bar * (op[k].phi_n + sh.eps) * inv_pe * inv_pe;
-            const float phi_n_bar = -x_bar * inv_pe;
-            const float sp_bar = phi_p_bar * op[k].phi_p * (1.0f - op[k].phi_p) * sh.inv_std;
-            const float sn_bar = phi_n_bar * op[k].phi_n * (1.0f - op[k].phi_n) * sh.inv_std;
-            const float u_bar = sp_bar + sn_bar;
-            const float cprime_bar = (sn_bar - sp_bar) * delta[k] / 2.0f;
-            const float slope = (1.0f - sh.ratio) * ((0.5f - 0.5f * op[k].cosine > 0.0f) ? 0.5f : 0.0f)
-                              + sh.ratio * ((-op[k].cosine > 0.0f) ? 1.0f : 0.0f);
-            const float cos_bar = cprime_bar * slope;
-            const float nbx = cos_bar * r.rx, nby = cos_bar * r.ry, nbz = cos_bar * r.rz;
-            const float n_dot = op[k].nx * nbx + op[k].ny * nby + op[k].nz * nbz;
-            float gbx = (nbx - op[k].nx * n_dot) * op[k].inv_gn;
-            float gby = (nby - op[k].ny * n_dot) * op[k].inv_gn;
-            float gbz = (nbz - op[k].nz * n_dot) * op[k].inv_gn;
-            if (grad_gradients != nullptr && valid) {
-                const float* gg = grad_gradients + (static_cast<size_t>(ray) * num_points + s) * 3;
-                gbx += gg[0]; gby += gg[1]; gbz += gg[2];
-            }
-            if (!valid) { gbx = 0.0f; gby = 0.0f; gbz = 0.0f; }
-            sa[k].B = gbx * sa[k].gbx + gby * sa[k].gby + gbz * sa[k].gbz;
-            sa[k].A = gbx * gx[k] + gby * gy[k] + gbz * gz[k];
-            sa[k].gbx = gbx; sa[k].gby = gby; sa[k].gbz = gbz;
-            sa[k].u_bar = valid ? u_bar : 0.0f;
-            if (!valid) { sa[k].wgt = 0.0f; sa[k].lam_z = 0.0f; }
-            any_flow = any_flow || (sa[k].u_bar != 0.0f) || (gbx != 0.0f) || (gby != 0.0f) || (gbz != 0.0f) || (sa[k].wgt != 0.0f);
-        }
-        if (__ballot(any_flow) == 0ull) continue;                                  // wave-uniform: exact zero adjoint
-
-        // ---- phase B: per instance, adjoint of (d_i, grad d_i) w.r.t. (t, R, dim) -------------------
-        for (int i = 0; i < N; ++i) {
-            const Instance in = load_instance(instances, i);
-            const float lam_i = lam[i];
-            const float rho = bounding_radius(in);
-            bool active[kRounds];
-            bool any_active = false;
-#pragma unroll
-            for (int k = 0; k < kRounds; ++k) {
-                const float lb = centre_distance(in, sa[k].x, sa[k].y, sa[k].z) * (1.0f - kCullSlack) - rho;
-                active[k] = (k * kWave < num_points) && wave_any(lb <= thr[k]);
-                any_active = any_active || active[k];
-            }
-            if (!any_active) continue;                                            // negligible for this ray (field.h culling)
-            float at0 = 0, at1 = 0, at2 = 0, ad0 = 0, ad1 = 0, ad2 = 0;
-            float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
-#pragma unroll
-            for (int k = 0; k < kRounds; ++k) {
-                if (!active[k]) continue;
-                const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, sa[k].x, sa[k].y, sa[k].z);
-                const float ds = e.d - sa[k].m;
-                const float w = fast_exp(-ds * inv_t) * sa[k].inv_z;
-                const float cc = w * (1.0f - (ds - sa[k].us) * inv_t);
-                const float beta = sa[k].gbx * e.gwx + sa[k].gby * e.gwy + sa[k].gbz * e.gwz;
-                const float d_bar = sa[k].u_bar * cc
-                                  + inv_t * (-beta * cc + w * sa[k].A - beta * w + cc * sa[k].B)
-                                  - inv_t * w * sa[k].wgt * (lam_i - sa[k].lam_z);
-                const float gwbx = cc * sa[k].gbx, gwby = cc * sa[k].gby, gwbz = cc * sa[k].gbz;
-                // gl_bar_j = sum_k R_kj gw_bar_k
-                const float glbx = in.r00 * gwbx + in.r10 * gwby + in.r20 * gwbz;
-                const float glby = in.r01 * gwbx + in.r11 * gwby + in.r21 * gwbz;
-                const float glbz = in.r02 * gwbx + in.r12 * gwby + in.r22 * gwbz;
-                const float sx = sign_of(e.px), sy = sign_of(e.py), sz = sign_of(e.pz);
-                const float vx = sx * glbx, vy = sy * glby, vz = sz * glbz;
-                const float inv_n = fast_rcp(e.nrm);
-                const float hx = fmaxf(e.qx, 0.0f) * inv_n, hy = fmaxf(e.qy, 0.0f) * inv_n, hz = fmaxf(e.qz, 0.0f) * inv_n;
-                const float hv = hx * vx + hy * vy + hz * vz;
-                const float qbx = d_bar * e.hx + ((e.qx > 0.0f) ? (vx - hx * hv) * inv_n : 0.0f);
-                const float qby = d_bar * e.hy + ((e.qy > 0.0f) ? (vy - hy * hv) * inv_n : 0.0f);
-                const float qbz = d_bar * e.hz + ((e.qz > 0.0f) ? (vz - hz * hv) * inv_n : 0.0f);
-                float pbx = sx * qbx, pby = sy * qby, pbz = sz * qbz;
-                ad0 -= qbx; ad1 -= qby; ad2 -= qbz;
-                if (kResidual) {        // residual(p): value adjoint d_bar, local-gradient adjoint gl_bar (main.py:451-458)
-                    const ResidualAdjoint ra = residual_backward(mlp + i * kMlpWeights, e.px, e.py, e.pz, d_bar, glbx, glby, glbz, wbar, lane);
-                    pbx += ra.px; pby += ra.py; pbz += ra.pz;
-                }
-                r00 += e.relx * pbx + gwbx * e.glx; r01 += e.relx * pby + gwbx * e.gly; r02 += e.relx * pbz + gwbx * e.glz;
-                r10 += e.rely * pbx + gwby * e.glx; r11 += e.rely * pby + gwby * e.gly; r12 += e.rely * pbz + gwby * e.glz;
-                r20 += e.relz * pbx + gwbz * e.glx; r21 += e.relz * pby + gwbz * e.gly; r22 += e.relz * pbz + gwbz * e.glz;
-                at0 -= in.r00 * pbx + in.r01 * pby + in.r02 * pbz;
-                at1 -= in.r10 * pbx + in.r11 * pby + in.r12 * pbz;
-                at2 -= in.r20 * pbx + in.r21 * pby + in.r22 * pbz;
-            }
-            // one reduce-scatter butterfly: lane j (< 16) receives parameter j of instance i and keeps it in its LDS slot
-            const float packed[16] = {at0, at1, at2, r00, r01, r02, r10, r11, r12, r20, r21, r22, ad0, ad1, ad2, 0.0f};
-            const float mine = wave_reduce16_scatter(packed, lane);
-            if (lane < kGradStride) G[i * kGradStride + lane] += mine;
-            if (kResidual) {            // flush this instance's MLP weight adjoints into the wave's global row (wave-private RMW)
-                float* dst = my_mlp + static_cast<size_t>(i) * kMlpWeights;
-                for (int idx = lane; idx < kMlpWeights; idx += kWave) { dst[idx] += wbar[idx]; wbar[idx] = 0.0f; }
-            }
-        }
+        RayAdjoint<kRounds> st;
+        adjoint_forward_sweep<kRounds, kResidual, false>(st, instances, mlp, N, sh, r, dist, num_points, lam, nullptr, lane);
+        const float* gw_row = grad_weights ? grad_weights + static_cast<size_t>(ray) * num_points : nullptr;
+        const float* gg_row = grad_gradients ? grad_gradients + static_cast<size_t>(ray) * num_points * 3 : nullptr;
+        if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, gw_row, gg_row, lane)) continue;      // exact zero adjoint
+        adjoint_phase_b<kRounds, kResidual>(st, instances, mlp, N, f.inv_t, num_points, lam, G, wbar, my_mlp, lane);
     }
     wave_lds_sync();
-    const size_t wave_global = static_cast<size_t>(blockIdx.x) * waves_per_block() + wave;
-    float* out = partials + wave_global * (N * kGradStride);
+    float* out = partials + wave_global0 * (N * kGradStride);
     for (int idx = lane; idx < N * kGradStride; idx += kWave) out[idx] = G[idx];
 }
 
