@@ -139,6 +139,8 @@ def main():
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-skip-misses", action="store_true")
     parser.add_argument("--residual", action="store_true", help="BASELINE config 3: per-instance residual MLP + eikonal loss")
+    parser.add_argument("--two-launch", action="store_true",
+                        help="render forward, torch BCE, render backward as separate launches instead of the fused step kernel")
     args = parser.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -188,10 +190,17 @@ def main():
         params += [detector.embeddings, *hyper.parameters()]
     optimizer = torch.optim.Adam(params, lr=1e-2)
     skip = not args.no_skip_misses and not args.residual     # eikonal needs every ray's gradients
+    fused = not args.two_launch and not args.residual        # one launch: render + silhouette BCE + adjoint
 
     def step(index):
         optimizer.zero_grad(set_to_none=True)
         union = build_union(detector, sched["temperature"])
+        if fused:
+            loss = rendering.silhouette_step(union, origins, directions, targets, (0.0, 100.0), S, sched["std"], sched["cosine_ratio"],
+                                             seed=rank, stream_offset=index, skip_exact_misses=skip)
+            loss.backward()
+            optimizer.step()
+            return loss
         if hyper is not None:
             union.mlp_weights = hyper(detector.embeddings)[0].contiguous()
         out = rendering.render_hierarchical(union, origins, directions, (0.0, 100.0), S, sched["std"], sched["cosine_ratio"],
@@ -226,12 +235,18 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * R * args.steps / elapsed
-        fwd_n, fwd_ms = kernels["vsrd_render_hierarchical_forward"]
-        bwd_n, bwd_ms = kernels["vsrd_render_backward"]
         # Algorithmic bytes per ray (B_api = 24 + 12 N for fwd+bwd with per-ray origins excluded):
         #   forward launch : direction 12 + labels out 4N ; backward launch: direction re-read 12 + grad_labels in 4N
-        dominant, dom_ms, dom_bytes, symbol = ("vsrd_render_backward", bwd_ms, 12 + 4 * N, "render_backward_kernel") if bwd_ms >= fwd_ms else \
-                                              ("vsrd_render_hierarchical_forward", fwd_ms, 12 + 4 * N, "render_hierarchical_kernel")
+        #   fused step launch: direction 12 + targets 4N (labels, label adjoints and saved distances never leave the chip)
+        if fused:
+            fwd_n, fwd_ms = kernels["vsrd_render_silhouette_step"]
+            bwd_n, bwd_ms = 0, 0.0
+            dominant, dom_ms, dom_bytes, symbol = "vsrd_render_silhouette_step", fwd_ms, 12 + 4 * N, "render_silhouette_kernel"
+        else:
+            fwd_n, fwd_ms = kernels["vsrd_render_hierarchical_forward"]
+            bwd_n, bwd_ms = kernels["vsrd_render_backward"]
+            dominant, dom_ms, dom_bytes, symbol = ("vsrd_render_backward", bwd_ms, 12 + 4 * N, "render_backward_kernel") if bwd_ms >= fwd_ms else \
+                                                  ("vsrd_render_hierarchical_forward", fwd_ms, 12 + 4 * N, "render_hierarchical_kernel")
         traffic, traffic_source = measured_traffic(symbol)
         achieved_gbs = R * dom_bytes / (dom_ms * 1e-3) / 1e9
         flop_per_ray = 3.5 * (3 * S - 2) * (63 * N + 45)           # SURVEY.md §8d box-only model, fwd+bwd
@@ -247,7 +262,8 @@ def main():
                                    f"{S} samples/ray (pass 1: {S - 1}, pass 2: {2 * S - 1} points), " + ("box + residual-MLP field, eikonal loss" if args.residual else "box-only field"),
                        "schedule": f"{args.schedule}: T=std={sched['std']:.3f}, cosine_ratio={sched['cosine_ratio']:.2f}",
                        "skip_exact_misses": skip, "rng": "in-kernel Philox4x32-10", "rays_per_gpu": R,
-                       "loss": "silhouette BCE (torch elementwise) + Adam on raw box parameters",
+                       "loss": ("silhouette BCE fused into the render kernel" if fused else "silhouette BCE (torch elementwise)") + " + Adam on raw box parameters",
+                       "launches_per_step": "1 fused (render + BCE + adjoint) + partial reductions" if fused else "forward, torch BCE, backward",
                        "final_loss": float(loss.detach()), "target_empty_fraction": miss},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

@@ -153,6 +153,18 @@ int32_t vsrd_render_hierarchical_forward(const vsrd_field* field, const vsrd_ren
                                          float* labels, float* distances, float* gradients, float* weights,
                                          float* u_coarse_out, float* u_fine_out, void* stream);
 
+/* One fused optimisation-step launch for box-only fields: the two-pass render of vsrd_render_hierarchical_forward, the
+ * silhouette loss of scripts/main.py:653-671  --  loss = loss_scale * sum_{r,n} w_n BCE(clamp(labels[r,n], 1e-6, 1-1e-6), targets[r,n])
+ * --  and its gradient w.r.t. the packed instances, without writing any per-sample data to HBM.
+ * targets [R,N] in prediction order; instance_weights [N] or NULL (all 1; 0 drops an unmatched instance);
+ * loss_scale = 1 / (R * number of kept instances) gives the reference's mean.  Outputs: loss [1], grad_instances [N,16]
+ * (d loss / d instances), labels [R,N] or NULL.  workspace: vsrd_workspace_bytes(N, 0). */
+int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_config* config,
+                                    const float* origins, const float* directions, const float* u_coarse, const float* u_fine,
+                                    const float* targets, const float* instance_weights, float loss_scale,
+                                    void* workspace, size_t workspace_bytes,
+                                    float* loss, float* grad_instances, float* labels, void* stream);
+
 /* Multi-view projection of N boxes (8 corners each, world frame) into V cameras and reduction to clipped 2-D boxes:
  * scripts/main.py:339-362 = einsum with E + divide by w, vsrd.operations.project_box_3d / clip_lines_to_front
  * (geometric_operations.py:343-389) per box, torchvision.ops.clip_boxes_to_image.  One launch for all V*N boxes.

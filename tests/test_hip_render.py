@@ -445,3 +445,44 @@ def test_sphere_tracing_and_surface_normal_g9(dev):
                                            bounding_radius=100.0, initialization=False)
     assert pos2.shape == (8, 12, 3) and conv2.shape == (8, 12, 1)
     assert torch.equal(conv2.reshape(-1, 1).cpu(), g["convergence_masks"])
+
+
+@pytest.mark.parametrize("name", ["g4_render_n4_s32_mid", "g4_render_n16_s64_mid", "g4_render_n4_s32_late", "g4_render_n3_s20_mid"])
+def test_fused_silhouette_step_matches_two_launch_path_and_golden(dev, name):
+    """vsrd_render_silhouette_step (render + BCE + adjoint in one launch) against the reference's loss / gradients (golden, cases
+    without an eikonal term) and against the two-launch path with torch's BCE, including a Hungarian-style column permutation."""
+    from vsrd_amd import rendering
+    g = load_golden(name)
+    S = int(g["num_samples"])
+    N = g["locations"].shape[0]
+    std, ratio = float(g["sdf_std_deviation"]), float(g["cosine_ratio"])
+    rays = (g["origins"].to(dev), g["directions"].to(dev))
+    uni = dict(u_coarse=g["u_coarse"].to(dev), u_fine=g["u_fine"].to(dev))
+    union, params = hip_union(g, dev, requires_grad=True)
+    loss, labels = rendering.silhouette_step(union, *rays, g["targets"].to(dev), (0.0, 100.0), S, std, ratio, return_labels=True, **uni)
+    assert (labels.cpu() - g["fine_labels"]).abs().max() < LABEL_TOL
+    torch.testing.assert_close(loss.detach().cpu(), g["bce"], rtol=1e-4, atol=1e-6)
+    grads = torch.autograd.grad(loss, params)
+    if float(g["eikonal_weight"]) == 0.0:
+        for got, key in zip(grads, ("grad_locations", "grad_dimensions", "grad_orientations")):
+            assert (got.cpu() - g[key]).abs().max().item() <= GRAD_TOL * max(float(g[key].abs().max()), 1e-6), key
+    # two-launch path, same uniforms, torch BCE
+    union2, params2 = hip_union(g, dev, requires_grad=True)
+    ref_labels = rendering.render_hierarchical(union2, *rays, (0.0, 100.0), S, std, ratio, **uni)["labels"]
+    ref_loss = olosses.silhouette_loss(ref_labels, g["targets"].to(dev))
+    torch.testing.assert_close(loss.detach(), ref_loss.detach(), rtol=1e-5, atol=1e-7)
+    for a, b in zip(grads, torch.autograd.grad(ref_loss, params2)):
+        assert (a - b).abs().max() <= 1e-4 * max(float(b.abs().max()), 1e-6)
+    # matched-instance form of main.py:653-671 (pd_indices / gt_indices), fewer ground-truth instances than predictions
+    if N >= 3:
+        pd_idx = torch.tensor([2, 0], device=dev)
+        gt_idx = torch.tensor([1, 0], device=dev)
+        tg = g["targets"][:, :2].to(dev).contiguous()
+        union3, params3 = hip_union(g, dev, requires_grad=True)
+        fused = rendering.silhouette_step(union3, *rays, tg, (0.0, 100.0), S, std, ratio, pd_indices=pd_idx, gt_indices=gt_idx, **uni)
+        union4, params4 = hip_union(g, dev, requires_grad=True)
+        lab = rendering.render_hierarchical(union4, *rays, (0.0, 100.0), S, std, ratio, **uni)["labels"]
+        want = olosses.silhouette_loss(lab, tg, pd_idx, gt_idx)
+        torch.testing.assert_close(fused.detach(), want.detach(), rtol=1e-5, atol=1e-7)
+        for a, b in zip(torch.autograd.grad(fused, params3), torch.autograd.grad(want, params4)):
+            assert (a - b).abs().max() <= 1e-4 * max(float(b.abs().max()), 1e-6)

@@ -418,6 +418,57 @@ int32_t vsrd_project_boxes_backward(const float* world_corners, const float* ext
     return launch_status();
 }
 
+int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_config* config,
+                                    const float* origins, const float* directions, const float* u_coarse, const float* u_fine,
+                                    const float* targets, const float* instance_weights, float loss_scale,
+                                    void* workspace, size_t workspace_bytes,
+                                    float* loss, float* grad_instances, float* labels, void* stream) {
+    if (!valid_field(field) || !valid_config(config) || !workspace || !loss || !grad_instances) return VSRD_E_INVALID_ARGUMENT;
+    if (field->mlp_weights != nullptr) return VSRD_E_UNSUPPORTED;            // box-only fast path
+    const int N = field->num_instances;
+    if (workspace_bytes < vsrd_workspace_bytes(N, 0)) return VSRD_E_WORKSPACE;
+    const hipStream_t s = static_cast<hipStream_t>(stream);
+    const int row = N * kGradStride;
+    if (config->num_rays == 0) {
+        if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) return VSRD_E_LAUNCH;
+        return hipMemsetAsync(grad_instances, 0, row * sizeof(float), s) == hipSuccess ? VSRD_OK : VSRD_E_LAUNCH;
+    }
+    if (!origins || !directions || !targets) return VSRD_E_INVALID_ARGUMENT;
+    const int S = config->num_samples;
+    const int rounds = rounds_for(2 * S - 1);
+    if (rounds < 1 || rounds > 4) return VSRD_E_UNSUPPORTED;
+    Geometry g;
+    const size_t per_wave = static_cast<size_t>(wave_lds_floats(S, N)) + N + row;
+    if (!plan(config->num_rays, per_wave, &g)) return VSRD_E_UNSUPPORTED;
+    // the partial buffer holds one gradient row per wave; the loss partials live in the tail of the same row budget
+    const int max_waves_for_loss = static_cast<int>(vsrd_workspace_bytes(N, 0) / sizeof(float) / (row + 1));
+    if (g.blocks * (g.threads / kWave) > max_waves_for_loss) g.blocks = max_waves_for_loss / (g.threads / kWave);
+    const FieldArgs f = field_args(field);
+    RenderArgs c = render_args(config);
+    c.sh.inv_t = f.inv_t;
+    const int num_waves = g.blocks * (g.threads / kWave);
+    float* partials = static_cast<float*>(workspace);
+    float* loss_partials = partials + static_cast<size_t>(num_waves) * row;
+#define VSRD_LAUNCH(K)                                                                                                          \
+    do {                                                                                                                          \
+        if (opt_in_lds(render_silhouette_kernel<K>, g.lds_bytes) != VSRD_OK) return VSRD_E_LAUNCH;                               \
+        hipLaunchKernelGGL(render_silhouette_kernel<K>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c,    \
+                           origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, labels, partials,        \
+                           loss_partials);                                                                                       \
+    } while (0)
+    switch (rounds) {
+        case 1: VSRD_LAUNCH(1); break;
+        case 2: VSRD_LAUNCH(2); break;
+        case 4: VSRD_LAUNCH(4); break;
+        default: return VSRD_E_UNSUPPORTED;
+    }
+#undef VSRD_LAUNCH
+    if (launch_status() != VSRD_OK) return VSRD_E_LAUNCH;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(row), dim3(256), 0, s, partials, num_waves, row, grad_instances);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, loss_partials, num_waves, 1, loss);
+    return launch_status();
+}
+
 // Not part of the public header: exercised by tests/test_hip_wave.py.
 int32_t vsrd_selftest_wave(const float* in64, float* out512, void* stream) {
     if (!in64 || !out512) return VSRD_E_INVALID_ARGUMENT;

@@ -204,12 +204,14 @@ struct RayAdjoint {
 };
 
 // Phase A, forward sweep: union sums (with Lambda = sum_n lambda_n e_n when `lam` is given), opacity, transmittance.
-// kCacheD additionally keeps every instance's distance of every round in `dcache` [kRounds][N][64] (fused loss kernel).
+// kCacheD (fused loss kernel): the instance distances of the current round are cached in `dcache` [N][64] and turned into the
+// ray's labels right away; the return value then holds label n in lane n.
 template <int kRounds, bool kResidual, bool kCacheD>
-__device__ __forceinline__ void adjoint_forward_sweep(RayAdjoint<kRounds>& st, const float* __restrict__ instances, const float* __restrict__ mlp,
-                                                      int N, const Shading& sh, const Ray& r, const float* dist, int num_points,
-                                                      const float* lam, float* dcache, int lane) {
+__device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, const float* __restrict__ instances, const float* __restrict__ mlp,
+                                                       int N, const Shading& sh, const Ray& r, const float* dist, int num_points,
+                                                       const float* lam, float* dcache, int lane) {
     const float inv_t = sh.inv_t;
+    float label = 0.0f;
     float carry = 1.0f;
 #pragma unroll
     for (int k = 0; k < kRounds; ++k) {
@@ -229,11 +231,11 @@ __device__ __forceinline__ void adjoint_forward_sweep(RayAdjoint<kRounds>& st, c
             const Instance in = load_instance(instances, i);
             const float lb = centre_distance(in, st.sa[k].x, st.sa[k].y, st.sa[k].z) * (1.0f - kCullSlack) - bounding_radius(in);
             if (!wave_any(lb <= st.thr[k])) {
-                if (kCacheD) dcache[(k * N + i) * kWave + lane] = lb;      // > thr on every lane: marks the instance as culled
+                if (kCacheD) dcache[i * kWave + lane] = lb;      // > thr on every lane: marks the instance as culled
                 continue;
             }
             const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, st.sa[k].x, st.sa[k].y, st.sa[k].z);
-            if (kCacheD) dcache[(k * N + i) * kWave + lane] = e.d;
+            if (kCacheD) dcache[i * kWave + lane] = e.d;
             union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, inv_t);
         }
         const UnionValue v = union_finish(sums, inv_t);
@@ -249,7 +251,17 @@ __device__ __forceinline__ void adjoint_forward_sweep(RayAdjoint<kRounds>& st, c
         st.gx[k] = v.gx; st.gy[k] = v.gy; st.gz[k] = v.gz;
         // B needs sum_i w_i grad d_i: stash it in (gbx,gby,gbz) until the reverse sweep
         st.sa[k].gbx = v.b0x; st.sa[k].gby = v.b0y; st.sa[k].gbz = v.b0z;
+        if (kCacheD && k * kWave < num_points) {
+            const float scale = st.sa[k].wgt * v.inv_z;
+            for (int i = 0; i < N; ++i) {
+                const float di = dcache[i * kWave + lane];
+                if (!wave_any(di <= st.thr[k])) continue;
+                const float total = wave_sum(fast_exp(-(di - v.m) * inv_t) * scale);
+                label = (lane == i) ? (label + total) : label;
+            }
+        }
     }
+    return label;
 }
 
 // Phase A, reverse sweep: labels -> weights -> opacity -> (u_bar, g_bar).  Returns (wave-uniformly) whether any adjoint is non-zero.
@@ -417,6 +429,145 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
     wave_lds_sync();
     float* out = partials + wave_global0 * (N * kGradStride);
     for (int idx = lane; idx < N * kGradStride; idx += kWave) out[idx] = G[idx];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused optimisation-step kernel: two-pass render + silhouette BCE + adjoint, one launch, nothing per-sample in HBM.
+//   scripts/main.py:511-523 (two-pass wrapper), :653-671 (mean BCE of clamp(labels, 1e-6, 1-1e-6) against the soft masks),
+//   and the backward of both.  The BCE is element-wise in (ray, instance), so each wave can turn its ray's labels into
+//   label adjoints on the spot and run the adjoint sweep on the pass-2 state it still holds in registers: no saved
+//   distances, no recomputation of pass 2, no second launch.
+// targets [R,N] are already in prediction order (the host applies the Hungarian permutation); instance_weights [N]
+// (0 = unmatched instance) and loss_scale = 1 / (R * matched) reproduce the mean over kept elements.
+// ---------------------------------------------------------------------------------------------------
+template <int kRounds>
+__global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_silhouette_kernel(
+    FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
+    const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
+    const float* __restrict__ targets, const float* __restrict__ instance_weights, float loss_scale,
+    float* __restrict__ labels_out, float* __restrict__ partials, float* __restrict__ loss_partials) {
+    constexpr int kRoundsS = (kRounds + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = wave_in_block();
+    const int lane = lane_id();
+    const int S = c.num_samples;
+    const int N = f.num_instances;
+    const int per_wave = wave_lds_floats(S, N) + N + N * kGradStride;
+    float* base = lds + wave * per_wave;
+    WaveLds l = carve_lds(base, S);                                        // l.dcache: [N][64], one round at a time
+    float* lam = base + wave_lds_floats(S, N);
+    float* G = lam + N;
+    for (int idx = lane; idx < N * kGradStride; idx += kWave) G[idx] = 0.0f;
+    const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
+    Shading sh = c.sh;
+    sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, N, f.inv_t);
+    const float weight_lane = (lane < N) ? (instance_weights ? instance_weights[lane] : 1.0f) : 0.0f;
+    float loss_acc = 0.0f;                                                  // lane n: this wave's BCE sum of instance n
+    const int D = 2 * S, num_points = D - 1;
+    const int stride = static_cast<int>(gridDim.x) * waves_per_block();
+    for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
+        wave_lds_sync();
+        const Ray r = load_ray(origins, directions, c.origin_stride, ray);
+        const size_t row = static_cast<size_t>(ray) * S;
+        const float target = (lane < N) ? targets[static_cast<size_t>(ray) * N + lane] : 0.0f;
+        // ---- uniforms + stratified distances (as render_hierarchical_kernel) --------------------------
+        const bool philox = (u_coarse == nullptr || u_fine == nullptr);
+        float spacing[kRoundsS];
+        float running = 0.0f, extra_spacing = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kRoundsS; ++k) {
+            const int idx = k * kWave + lane;
+            spacing[k] = 0.0f;
+            if (k * kWave >= S) continue;
+            float uc = 0.0f, uf = 0.0f;
+            if (philox) {
+                const Philox4 rnd = philox4x32_10(static_cast<uint32_t>(ray), static_cast<uint32_t>(idx),
+                                                  static_cast<uint32_t>(c.stream_offset), static_cast<uint32_t>(c.stream_offset >> 32),
+                                                  static_cast<uint32_t>(c.seed), static_cast<uint32_t>(c.seed >> 32));
+                uc = uniform_from_bits(rnd.x);
+                uf = uniform_from_bits(rnd.y);
+                if (k == 0) extra_spacing = -fast_log(1.0f - read_lane(uniform_from_bits(rnd.z), 0));
+            }
+            const bool valid = idx < S;
+            if (u_coarse != nullptr && valid) uc = u_coarse[row + idx];
+            if (u_fine != nullptr && valid) uf = u_fine[row + idx];
+            if (valid) {
+                const float lo = torch_linspace(c.near, c.far, S + 1, idx);
+                const float hi = torch_linspace(c.near, c.far, S + 1, idx + 1);
+                l.coarse[idx] = torch_lerp(lo, hi, uc);
+            }
+            if (u_fine == nullptr) {
+                const float e = valid ? -fast_log(1.0f - uf) : 0.0f;
+                const float inclusive = wave_inclusive_sum(e) + running;
+                spacing[k] = inclusive;
+                running = read_lane(inclusive, kWave - 1);
+            } else if (valid) {
+                (sorted_input ? l.usorted : l.uraw)[idx] = uf;
+            }
+        }
+        if (u_fine == nullptr) {
+            const float inv_total = fast_rcp(running + extra_spacing);
+#pragma unroll
+            for (int k = 0; k < kRoundsS; ++k) {
+                const int idx = k * kWave + lane;
+                if (idx < S) l.usorted[idx] = fminf(spacing[k] * inv_total, 0.99999994f);
+            }
+        }
+        wave_lds_sync();
+        if (u_fine != nullptr && !sorted_input) {
+            rank_sort<kRoundsS>(l.uraw, l.usorted, S);
+            wave_lds_sync();
+        }
+        // ---- pass 1 ------------------------------------------------------------------------------------
+        float w1[kRoundsS];
+        render_pass<kRoundsS, false, false>(instances, nullptr, N, sh, r, l.coarse, S, l.dcache, w1, nullptr, nullptr);
+        float coarse_total = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kRoundsS; ++k) coarse_total += wave_sum(w1[k]);
+        float label = 0.0f;
+        bool rendered = false;
+        RayAdjoint<kRounds> st;
+        if (!((c.flags & 2u) && coarse_total == 0.0f)) {                    // exact miss: labels are exactly 0, adjoint exactly 0
+            rendered = true;
+            importance_merge<kRoundsS>(l, S, w1);
+            // ---- pass 2 with the adjoint's state kept in registers ------------------------------------
+            label = adjoint_forward_sweep<kRounds, false, true>(st, instances, nullptr, N, sh, r, l.merged, num_points, nullptr, l.dcache, lane);
+        }
+        if (labels_out != nullptr && lane < N) labels_out[static_cast<size_t>(ray) * N + lane] = label;
+        // ---- silhouette BCE and its gradient (main.py:653-671; torch clamp / binary_cross_entropy backward) -----------------
+        const float p = fminf(fmaxf(label, 1.0e-6f), 1.0f - 1.0e-6f);
+        const float bce = -(target * logf(p) + (1.0f - target) * logf(1.0f - p));
+        loss_acc += (lane < N) ? weight_lane * bce : 0.0f;
+        const bool inside_clamp = (label >= 1.0e-6f) && (label <= 1.0f - 1.0e-6f);
+        const float lam_lane = (lane < N && inside_clamp) ? weight_lane * loss_scale * (p - target) / fmaxf(p * (1.0f - p), 1.0e-12f) : 0.0f;
+        if (!rendered || wave_max(fabsf(lam_lane)) == 0.0f) continue;
+        if (lane < N) lam[lane] = lam_lane;
+        wave_lds_sync();
+        // Lambda_s = sum_n lambda_n w_{s,n}: the box distances are re-evaluated (value only, ~45 instructions) instead of keeping
+        // every round's [N][64] distance cache in LDS, which would halve the occupancy of this kernel
+#pragma unroll
+        for (int k = 0; k < kRounds; ++k) {
+            if (k * kWave >= num_points) continue;
+            float acc = 0.0f;
+            for (int i = 0; i < N; ++i) {
+                if (lam[i] == 0.0f) continue;                               // wave-uniform
+                const Instance in = load_instance(instances, i);
+                const float lb = centre_distance(in, st.sa[k].x, st.sa[k].y, st.sa[k].z) * (1.0f - kCullSlack) - bounding_radius(in);
+                if (!wave_any(lb <= st.thr[k])) continue;
+                const BoxEval e = eval_box(in, st.sa[k].x, st.sa[k].y, st.sa[k].z);
+                acc += lam[i] * fast_exp(-(e.d - st.sa[k].m) * sh.inv_t);
+            }
+            st.sa[k].lam_z = acc * st.sa[k].inv_z;
+        }
+        if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, nullptr, nullptr, lane)) continue;
+        adjoint_phase_b<kRounds, false>(st, instances, nullptr, N, f.inv_t, num_points, lam, G, nullptr, nullptr, lane);
+    }
+    wave_lds_sync();
+    const size_t wave_global = static_cast<size_t>(blockIdx.x) * waves_per_block() + wave;
+    float* out = partials + wave_global * (N * kGradStride);
+    for (int idx = lane; idx < N * kGradStride; idx += kWave) out[idx] = G[idx];
+    const float loss_total = wave_sum(loss_acc);
+    if (lane == 0) loss_partials[wave_global] = loss_total * loss_scale;
 }
 
 // Deterministic second stage: grad[idx] = sum over waves of partials[wave][idx].

@@ -323,3 +323,70 @@ def surface_normal(distance_field, surface_positions, finite_difference_epsilon=
         out = evaluate_field(distance_field, surface_positions, with_gradients=True, with_labels=False)
         normals = out[-1] if isinstance(out, tuple) else out
     return torch.nn.functional.normalize(normals, dim=-1)
+
+
+class _SilhouetteStep(torch.autograd.Function):
+    """Fused render + silhouette BCE + adjoint (vsrd_render_silhouette_step).  The kernel produces the loss and its gradient
+    w.r.t. the packed instances in the forward; backward only scales that gradient."""
+
+    @staticmethod
+    def forward(ctx, instances, origins, directions, targets, weights, u_coarse, u_fine, temperature, scalars, origin_stride,
+                seed, stream_offset, flags, loss_scale, want_labels):
+        lib = _lib.load()
+        std, ratio, eps, near, far, S = scalars
+        R, N = directions.shape[0], instances.shape[0]
+        dev = directions.device
+        instances = instances.detach().contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        grad = torch.empty_like(instances)
+        labels = torch.empty(R, N, dtype=torch.float32, device=dev) if want_labels else None
+        workspace = _workspace(dev, N, False)
+        field = _lib.make_field(instances, temperature)
+        config = _lib.make_config(R, S, (near, far), std, ratio, eps, origin_stride, seed, stream_offset, flags)
+        with profiling.timed("vsrd_render_silhouette_step"):
+            _lib.check(lib.vsrd_render_silhouette_step(field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(u_coarse), _lib.ptr(u_fine),
+                                                       _lib.ptr(targets), _lib.ptr(weights), float(loss_scale), workspace.data_ptr(),
+                                                       workspace.numel(), _lib.ptr(loss), _lib.ptr(grad), _lib.ptr(labels), _lib.stream()))
+        ctx.save_for_backward(grad)
+        out_labels = labels if want_labels else loss.new_empty(0)
+        ctx.mark_non_differentiable(out_labels)
+        return loss[0], out_labels
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_labels):
+        grad, = ctx.saved_tensors
+        return (grad * grad_loss,) + (None,) * 14
+
+
+def silhouette_step(distance_field, ray_positions, ray_directions, targets, distance_range, num_samples, sdf_std_deviation,
+                    cosine_ratio=1.0, epsilon=1.0e-6, pd_indices=None, gt_indices=None, u_coarse=None, u_fine=None, seed=0,
+                    stream_offset=0, return_labels=False, skip_exact_misses=True):
+    """Fused fast path of scripts/main.py:629-671 for box-only fields: the two-pass render AND
+    ``mean(BCE(clamp(labels[..., pd_indices], 1e-6, 1 - 1e-6), targets[..., gt_indices]))`` in one launch.
+    Returns the loss (autograd-connected to the field parameters), and the labels [R,N] when asked."""
+    block = flatten(distance_field)
+    if block.mlp_weights is not None:
+        raise NotImplementedError("silhouette_step is the box-only fast path; use render_hierarchical + losses for residual fields")
+    origins, directions, stride, _ = _prepare_rays(ray_positions, ray_directions)
+    R, N = directions.shape[0], block.num_instances
+    targets = targets.reshape(R, -1).to(torch.float32)
+    if block.label_indices is not None:
+        raise NotImplementedError("permuted instance labels are not supported by the fused path")
+    if pd_indices is None:
+        ordered, weights, kept = targets.contiguous(), None, N
+    else:   # labels[..., pd] vs targets[..., gt]  ==  labels[:, n] vs ordered[:, n] for n in pd, weight 0 elsewhere
+        ordered = torch.zeros(R, N, dtype=torch.float32, device=targets.device)
+        ordered[:, pd_indices] = targets[:, gt_indices]
+        weights = torch.zeros(N, dtype=torch.float32, device=targets.device)
+        weights[pd_indices] = 1.0
+        kept = int(pd_indices.numel())
+    if (u_coarse is None) != (u_fine is None):
+        raise ValueError("pass both u_coarse and u_fine, or neither (in-kernel Philox)")
+    if u_coarse is not None:
+        u_coarse = u_coarse.reshape(-1, num_samples).to(torch.float32).contiguous()
+        u_fine = u_fine.reshape(-1, num_samples).to(torch.float32).contiguous()
+    flags = (_lib.FLAG_SKIP_EXACT_MISSES if skip_exact_misses else 0) | _base_flags()
+    scalars = (float(sdf_std_deviation), float(cosine_ratio), float(epsilon), float(distance_range[0]), float(distance_range[1]), int(num_samples))
+    loss, labels = _SilhouetteStep.apply(block.instances, origins, directions, ordered, weights, u_coarse, u_fine, block.temperature, scalars,
+                                         stride, int(seed), int(stream_offset), flags, 1.0 / (R * max(kept, 1)), bool(return_labels))
+    return (loss, labels) if return_labels else loss
