@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Steps/s of the whole per-frame loop (vsrd_amd.optimization.FrameOptimizer) in the reference's NATIVE mode:
+1 target + 16 source views of 376x1408, 1000 importance-sampled rays per step, 100 samples per ray
+(configs/kitti_360/vsrd/*/config.json:16,22-23,236-237), box-only warm-up phase.  The reference's only published
+number for this loop is "about 15 minutes per frame on a V100" for 3000 steps = 3.3 steps/s (README.md:128).
+
+  python tools/native_mode_bench.py [--steps 200] [--instances 8]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--steps", type=int, default=200)
+    parser.add_argument("--instances", type=int, default=8)
+    parser.add_argument("--views", type=int, default=17)
+    args = parser.parse_args()
+    import __graft_entry__
+    __graft_entry__.build()
+    import bench
+    from vsrd_amd import optimization, rendering, fields, models, operations
+    dev = torch.device("cuda:0")
+    V, H, W, N = args.views, 376, 1408, args.instances
+    K, E, raw_loc, raw_dim, raw_ori = bench.synthetic_frame(0, V, H, W, N)
+    det = models.BoxParameters3D(1, N).to(dev)
+    with torch.no_grad():
+        det.locations.copy_(raw_loc); det.dimensions.copy_(raw_dim); det.orientations.copy_(raw_ori)
+        out = det()
+        cam, dirs = rendering.ray_casting((H, W), K.to(dev), E.to(dev))
+        block = fields.FieldBlock(fields.pack_instances(out["locations"][0], out["orientations"][0], out["dimensions"][0]), 0.1, None, None)
+        origins = cam[:, None, None, :].expand(V, H, W, 3).reshape(-1, 3).contiguous()
+        soft = rendering.render_hierarchical(block, origins, dirs.reshape(-1, 3), (0.0, 100.0), 64, 0.1, 1.0, seed=1,
+                                             skip_exact_misses=True)["labels"].clamp(0, 1).reshape(V, H, W, N).contiguous()
+        gt_boxes, _ = operations.project_boxes_multi_view(out["boxes_3d"][0], E.to(dev), K.to(dev), (H, W))
+    inputs = optimization.FrameInputs((H, W), K.to(dev), E.to(dev), soft, gt_boxes, torch.ones(V, N, dtype=torch.bool, device=dev))
+    loop = optimization.FrameOptimizer(inputs, optimization.OptimizationConfig(), dev)
+    for _ in range(20):
+        loop.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = loop.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"native mode: {args.steps / dt:.1f} steps/s ({dt / args.steps * 1e3:.2f} ms/step, 1000 rays x 100 samples, V={V}, N={N}); "
+          f"3000-step frame = {3000 * dt / args.steps:.1f} s; reference: ~3.3 steps/s on a V100 (README.md:128); final loss {float(losses['loss']):.4f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -100,10 +100,15 @@ class FrameOptimizer:
             ray_indices = self.sample_rays()
         origins = self.camera_positions[ray_indices // self.pixels_per_view]
         directions = self.ray_directions[ray_indices]
-        out = rendering.render_hierarchical(block, origins, directions, cfg.distance_range, cfg.num_samples, std, ratio,
-                                            u_coarse=u_coarse, u_fine=u_fine, seed=cfg.seed, stream_offset=step,
-                                            return_gradients=residual, skip_exact_misses=cfg.skip_exact_misses and not residual)
-        silhouette = losses.silhouette_loss(out["labels"], self.flat_masks[ray_indices], pd_idx, gt_idx)
+        if residual:
+            out = rendering.render_hierarchical(block, origins, directions, cfg.distance_range, cfg.num_samples, std, ratio,
+                                                u_coarse=u_coarse, u_fine=u_fine, seed=cfg.seed, stream_offset=step, return_gradients=True)
+            silhouette = losses.silhouette_loss(out["labels"], self.flat_masks[ray_indices], pd_idx, gt_idx)
+        else:   # box-only phase: render + silhouette BCE + adjoint in one launch
+            silhouette = rendering.silhouette_step(block, origins, directions, self.flat_masks[ray_indices], cfg.distance_range,
+                                                   cfg.num_samples, std, ratio, pd_indices=pd_idx, gt_indices=gt_idx,
+                                                   u_coarse=u_coarse, u_fine=u_fine, seed=cfg.seed, stream_offset=step,
+                                                   skip_exact_misses=cfg.skip_exact_misses)
         terms = dict(iou_projection_loss=iou_loss, l1_projection_loss=l1_loss, silhouette_loss=silhouette)
         if residual:
             terms["eikonal_loss"] = losses.eikonal_loss(out["gradients"])
