@@ -307,7 +307,7 @@ int32_t vsrd_render_backward(const vsrd_field* field, const vsrd_render_config* 
         return hipMemsetAsync(grad_instances, 0, row * sizeof(float), s) == hipSuccess ? VSRD_OK : VSRD_E_LAUNCH;
     }
     Geometry g;
-    if (!plan(config->num_rays, static_cast<size_t>(num_distances) + N + row + (residual ? kMlpWeights : 0), &g)) return VSRD_E_UNSUPPORTED;
+    if (!plan(config->num_rays, static_cast<size_t>(backward_lds_floats(num_distances, N, residual)), &g)) return VSRD_E_UNSUPPORTED;
     if (residual && g.blocks > kMaxBlocksResidual) g.blocks = kMaxBlocksResidual;
     const FieldArgs f = field_args(field);
     RenderArgs c = render_args(config);

@@ -35,8 +35,11 @@ __global__ __launch_bounds__(256) void field_eval_kernel(FieldArgs f, const floa
                                                          const float* __restrict__ positions, long long num_points,
                                                          float* __restrict__ distances, float* __restrict__ gradients,
                                                          float* __restrict__ labels, int hard_union) {
-    for (long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; idx < num_points;
-         idx += static_cast<long long>(gridDim.x) * blockDim.x) {
+    // whole waves stay in the loop (the residual MLP is wave-cooperative): tail lanes evaluate the last point and store nothing
+    for (long long base = static_cast<long long>(blockIdx.x) * blockDim.x + (threadIdx.x & ~(kWave - 1)); base < num_points;
+         base += static_cast<long long>(gridDim.x) * blockDim.x) {
+        const bool valid = base + lane_id() < num_points;
+        const long long idx = valid ? base + lane_id() : num_points - 1;
         const float x = positions[idx * 3 + 0], y = positions[idx * 3 + 1], z = positions[idx * 3 + 2];
         if (hard_union) {
             float best = 3.0e38f, bx = 0.0f, by = 0.0f, bz = 0.0f;
@@ -44,8 +47,8 @@ __global__ __launch_bounds__(256) void field_eval_kernel(FieldArgs f, const floa
                 const BoxEval e = eval_instance<kResidual>(load_instance(instances, i), kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z);
                 if (e.d < best) { best = e.d; bx = e.gwx; by = e.gwy; bz = e.gwz; }   // argmin: first minimum
             }
-            if (distances) distances[idx] = best;
-            if (gradients) { gradients[idx * 3 + 0] = bx; gradients[idx * 3 + 1] = by; gradients[idx * 3 + 2] = bz; }
+            if (distances && valid) distances[idx] = best;
+            if (gradients && valid) { gradients[idx * 3 + 0] = bx; gradients[idx * 3 + 1] = by; gradients[idx * 3 + 2] = bz; }
             continue;
         }
         UnionSums sums = union_init();
@@ -54,12 +57,12 @@ __global__ __launch_bounds__(256) void field_eval_kernel(FieldArgs f, const floa
             union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, 0.0f, f.inv_t);
         }
         const UnionValue v = union_finish(sums, f.inv_t);
-        if (distances) distances[idx] = v.u;
-        if (gradients) { gradients[idx * 3 + 0] = v.gx; gradients[idx * 3 + 1] = v.gy; gradients[idx * 3 + 2] = v.gz; }
+        if (distances && valid) distances[idx] = v.u;
+        if (gradients && valid) { gradients[idx * 3 + 0] = v.gx; gradients[idx * 3 + 1] = v.gy; gradients[idx * 3 + 2] = v.gz; }
         if (labels) {
             for (int i = 0; i < f.num_instances; ++i) {
                 const BoxEval e = eval_instance<kResidual>(load_instance(instances, i), kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z);
-                labels[idx * f.num_instances + i] = fast_exp(-(e.d - v.m) * f.inv_t) * v.inv_z;
+                if (valid) labels[idx * f.num_instances + i] = fast_exp(-(e.d - v.m) * f.inv_t) * v.inv_z;
             }
         }
     }
@@ -97,8 +100,10 @@ __global__ __launch_bounds__(256) void sphere_trace_kernel(FieldArgs f, const fl
                                                            long long num_rays, int num_iterations, float criteria, float bounding_radius,
                                                            int initialise, int hard_union,
                                                            float* __restrict__ positions, unsigned char* __restrict__ converged) {
-    for (long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; idx < num_rays;
-         idx += static_cast<long long>(gridDim.x) * blockDim.x) {
+    for (long long base = static_cast<long long>(blockIdx.x) * blockDim.x + (threadIdx.x & ~(kWave - 1)); base < num_rays;
+         base += static_cast<long long>(gridDim.x) * blockDim.x) {                 // whole waves (see field_eval_kernel)
+        const bool valid = base + lane_id() < num_rays;
+        const long long idx = valid ? base + lane_id() : num_rays - 1;
         const float* o = origins + idx * origin_stride;
         float px = o[0], py = o[1], pz = o[2];
         const float dx = directions[idx * 3 + 0], dy = directions[idx * 3 + 1], dz = directions[idx * 3 + 2];
@@ -113,16 +118,21 @@ __global__ __launch_bounds__(256) void sphere_trace_kernel(FieldArgs f, const fl
             if (hit) { px += dx * t; py += dy * t; pz += dz * t; }
             fg = fg && hit;
         }
-        bool conv = false;
+        bool conv = false, done = !valid;
         for (int it = 0; it < num_iterations; ++it) {
-            const float sd = union_distance<kResidual>(f, instances, mlp, px, py, pz, hard_union);
-            if (fg && !conv) { px += dx * sd; py += dy * sd; pz += dz * sd; }
-            if (bounding_radius > 0.0f) fg = fg && (sqrtf(px * px + py * py + pz * pz) < bounding_radius);
-            conv = fabsf(sd) < criteria;
-            if (!fg || conv) break;
+            const float sd = union_distance<kResidual>(f, instances, mlp, px, py, pz, hard_union);     // all lanes, stopped or not
+            if (!done) {
+                if (fg && !conv) { px += dx * sd; py += dy * sd; pz += dz * sd; }
+                if (bounding_radius > 0.0f) fg = fg && (sqrtf(px * px + py * py + pz * pz) < bounding_radius);
+                conv = fabsf(sd) < criteria;
+                done = !fg || conv;
+            }
+            if (!wave_any(!done)) break;
         }
-        positions[idx * 3 + 0] = px; positions[idx * 3 + 1] = py; positions[idx * 3 + 2] = pz;
-        converged[idx] = conv ? 1 : 0;
+        if (valid) {
+            positions[idx * 3 + 0] = px; positions[idx * 3 + 1] = py; positions[idx * 3 + 2] = pz;
+            converged[idx] = conv ? 1 : 0;
+        }
     }
 }
 

@@ -85,7 +85,7 @@ template <bool kResidual>
 __device__ __forceinline__ BoxEval eval_instance(const Instance& in, const float* __restrict__ mlp, float x, float y, float z) {
     BoxEval e = eval_box(in, x, y, z);
     if (kResidual) {
-        const Residual r = residual_forward(mlp, e.px, e.py, e.pz);
+        const Residual r = residual_forward(mlp, e.px, e.py, e.pz);      // wave-cooperative: all 64 lanes active
         e.d += r.value;
         e.glx += r.gx; e.gly += r.gy; e.glz += r.gz;
         e.gwx = in.r00 * e.glx + in.r01 * e.gly + in.r02 * e.glz;

@@ -11,6 +11,11 @@ constexpr int kBlockThreads = kMaxWavesPerBlock * kWave;   // launch bound; the 
 __device__ __forceinline__ int waves_per_block() { return static_cast<int>(blockDim.x) >> 6; }
 constexpr int kGradStride = kInstanceStride;   // grad_instances rows are [t(3) R(9) dim(3) pad]
 
+// Floats of LDS one wave of render_backward_kernel owns (a multiple of 4: the partitions stay 16-byte aligned).
+__host__ __device__ constexpr int backward_lds_floats(int num_distances, int num_instances, bool residual) {
+    return ((residual ? kMlpLdsFloats : 0) + num_distances + num_instances + num_instances * kGradStride + 3) & ~3;
+}
+
 // The instance block [N,16] travels as its own `const float* __restrict__` kernel argument (not inside this
 // struct): only then does the compiler prove the uniform loads in the instance loops are not clobbered by the
 // kernel's stores and select SMEM (s_load_dwordx8/x4) instead of VMEM for them.
@@ -377,7 +382,9 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
         if (lane < kGradStride) G[i * kGradStride + lane] += mine;
         if (kResidual) {            // flush this instance's MLP weight adjoints into the wave's global row (wave-private RMW)
             float* dst = my_mlp + static_cast<size_t>(i) * kMlpWeights;
+            wave_lds_sync();
             for (int idx = lane; idx < kMlpWeights; idx += kWave) { dst[idx] += wbar[idx]; wbar[idx] = 0.0f; }
+            wave_lds_sync();
         }
     }
 }
@@ -394,11 +401,11 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
     const int lane = lane_id();
     const int N = f.num_instances;
     const int num_points = num_distances - 1;
-    const int per_wave = num_distances + N + N * kGradStride + (kResidual ? kMlpWeights : 0);
-    float* dist = lds + wave * per_wave;
+    const int per_wave = backward_lds_floats(num_distances, N, kResidual);
+    float* wbar = lds + wave * per_wave;                                 // residual only: [1617] MLP weight adjoints of the current
+    float* dist = wbar + (kResidual ? kMlpLdsFloats : 0);                // instance + the transposition scratch (residual.h), 16 B aligned
     float* lam = dist + num_distances;
     float* G = lam + N;
-    float* wbar = G + N * kGradStride;                                   // [1617] MLP weight adjoints of the current instance
     for (int idx = lane; idx < N * kGradStride; idx += kWave) G[idx] = 0.0f;
     const size_t wave_global0 = static_cast<size_t>(blockIdx.x) * waves_per_block() + wave;
     float* my_mlp = kResidual ? mlp_partials + wave_global0 * (static_cast<size_t>(N) * kMlpWeights) : nullptr;

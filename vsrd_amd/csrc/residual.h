@@ -1,15 +1,25 @@
-// Per-instance residual SDF: sigmoid(MLP_w(encode((|x|, y, z) / 100)) - 1) as a first-order jet (value + gradient
-// w.r.t. the local position), evaluated per lane with wave-uniform weights.
+// Per-instance residual SDF on the matrix cores: sigmoid(MLP_w(encode((|x|, y, z) / 100)) - 1) as a first-order jet
+// (value + gradient w.r.t. the local position) for the 64 samples of a wave.
 //
-// Reference semantics (CPU restatement: oracle/fields.py, float64 blueprint incl. the adjoint: oracle/analytic_mlp.py):
-//   residual_distance_field / residual_composition   scripts/main.py:433-458
+// Reference semantics (CPU restatement: oracle/fields.py; float64 blueprint of the adjoint: oracle/analytic_mlp.py):
+//   residual_distance_field / residual_composition          scripts/main.py:433-458
 //   SinusoidalEncoder (8 octaves, [coord][freq][cos,sin])   vsrd/models/encoders/sinusoidal_encoder.py:12-18
-//   HyperDistanceField.distance_field (49->16, 3 x 17->16, 17->1; LayerNorm without affine + exact GELU
-//   between layers; weights [out][in+1], bias last)          vsrd/models/fields/hyper_distance_field.py:57-73
-//   gradient = autograd.grad(sdf, positions)                 vsrd/rendering/renderers.py:218-228 (forward-mode here)
+//   HyperDistanceField.distance_field (49->16, 3 x 17->16, 17->1; LayerNorm without affine + exact GELU between the
+//   layers; weights [out][in+1], bias last)                 vsrd/models/fields/hyper_distance_field.py:57-73
+//   gradient = autograd.grad(sdf, positions)                vsrd/rendering/renderers.py:218-228 (forward mode here)
 //
-// All 1617 weights of instance i are wave-uniform: they are read with scalar loads and used as SGPR operands;
-// the activations (16 channels x (value + 3 tangents)) live in registers with compile-time indices.
+// Mapping.  The wave holds 64 sample points (lane = point).  The MLP runs on TILES of 16 points: for tile q the lane
+// (g = lane >> 4, m = lane & 15) works on point 16 q + m, and a 16-channel activation of that point is spread over the four
+// lanes {m, m+16, m+32, m+48} x 4 registers: register j of row g is channel 4 g + j.  That is exactly the C/D layout of
+// v_mfma_f32_16x16x4_f32 (col = lane & 15 = point, row = 4 (lane >> 4) + reg = channel), and -- because the k index of a B
+// operand is also lane >> 4 -- register s of a layer's output IS the B operand of k-step s of the next layer when the weight
+// (A) operand of that step is W[o = lane & 15][4 g + s].  Layers therefore chain with no data movement; the per-point
+// reductions of LayerNorm run over 4 registers and 2 row swaps (v_permlane16/32_swap).  The exact-f32 MFMA has the same
+// peak as the f32 VALU (MI355X_MICROARCH.md: 64 FLOP/clk/SIMD) but frees the VALU for the encoder / LayerNorm / GELU work,
+// needs one VGPR per weight operand instead of one SGPR per weight (the scalar version spilled SGPRs and waited on a scalar
+// load per weight row), and is bitwise a k-ordered fmaf chain.
+//
+// All functions here are WAVE-COOPERATIVE: they must be called with all 64 lanes active.
 #pragma once
 #include "wave.h"
 
@@ -18,401 +28,508 @@ namespace vsrd {
 constexpr int kMlpWeights = 1617;
 constexpr int kMlpHidden = 16;
 constexpr int kMlpFeatures = 48;
-constexpr float kPositionScale = 100.0f;      // max(distance_range), main.py:441
+constexpr int kMlpRow0 = kMlpFeatures + 1;                   // first-layer row: 48 weights + bias
+constexpr int kMlpRow = kMlpHidden + 1;                      // hidden row: 16 weights + bias
+constexpr int kMlpLayer1 = kMlpRow0 * kMlpHidden;            // 784: offset of the first hidden linear
+constexpr int kMlpBlock = kMlpRow * kMlpHidden;              // 272
+constexpr int kMlpHead = kMlpLayer1 + 3 * kMlpBlock;         // 1600: [w4[0..15], b4]
+constexpr float kPositionScale = 100.0f;                     // max(distance_range), main.py:441
 constexpr float kLayerNormEps = 1.0e-5f;
+constexpr float kPi = 3.14159265358979323846f;
 
-struct Jet16 {
-    float v[kMlpHidden];        // value
-    float t[3][kMlpHidden];     // tangents d/d(folded, scaled position)
-};
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-__device__ __forceinline__ float gauss_pdf(float y) { return fast_exp(-0.5f * y * y) * 0.3989422804014327f; }
-__device__ __forceinline__ float gauss_cdf(float y) { return 0.5f * (1.0f + erff(y * 0.7071067811865476f)); }
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
+__device__ __forceinline__ float hsum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+__device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]); }
 
-// Start of a weight row: makes the row pointer opaque to the optimiser at this point, so the scalar loads of the row are
-// issued here and not hoisted to the top of the function -- with ~100 rows of 16 SGPRs each in flight the compiler otherwise
-// spills SGPRs into VGPR lanes (59k v_readlane in the adjoint before this).
-// `after` is any value produced by the previous row: the data dependence is what keeps the rows (and their loads) in order.
-template <typename W>
-__device__ __forceinline__ W row_begin(W row, float after) {
-    asm volatile("" : "+s"(row) : "v"(after));
-    return row;
+// Sum over the four rows of 16 lanes: every lane (g, m) receives sum_g' v(g', m).  One MFMA with an all-ones A operand
+// (D[i][m] = sum_k 1 * B[k][m], k = row) instead of two row swaps: ~10 VALU issue slots become one matrix-pipe slot.
+#ifdef VSRD_ROWS_SUM_SWAP
+__device__ __forceinline__ float rows_sum(float v) { return add_xor32(add_xor16(v)); }
+#else
+__device__ __forceinline__ float rows_sum(float v) { return mfma4(1.0f, v, f32x4{0.0f, 0.0f, 0.0f, 0.0f})[0]; }
+#endif
+
+// Value of lane 16 q + (lane & 15): row q broadcast to all four rows.
+__device__ __forceinline__ float from_row(float v, int q, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((q << 4) | (lane & 15)) << 2, __builtin_bit_cast(int, v)));
 }
 
-// First layer: encoder fused with Linear(48 -> 16).  Row o of the weight block is [W[o][0..47], bias].
-template <typename W>
-__device__ __forceinline__ void mlp_first_layer(W w, float f0, float f1, float f2, Jet16& z) {
-    float feat[3][16], dfeat[3][16];
+// Standard normal pdf and cdf (exact GELU = y * cdf(y)).  erf through Abramowitz & Stegun 7.1.26,
+//   erf(x) = 1 - (a1 t + ... + a5 t^5) exp(-x^2), t = 1 / (1 + p x), x >= 0, |error| <= 1.5e-7 (one f32 ulp of a cdf near 1),
+// which shares its exponential exp(-y^2 / 2) with the pdf: ~17 instructions for (cdf, pdf) instead of ~60 through erff.
+struct Gauss { float cdf, pdf; };
+__device__ __forceinline__ Gauss gauss(float y) {
+#ifdef VSRD_LIBM_ERF
+    return {0.5f * (1.0f + erff(y * 0.7071067811865476f)), fast_exp(-0.5f * y * y) * 0.3989422804014327f};
+#else
+    const float e = fast_exp(-0.5f * y * y);
+    const float t = fast_rcp(1.0f + 0.3275911f * 0.7071067811865476f * fabsf(y));
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const float half_erfc = 0.5f * poly * e;                      // 0.5 erfc(|y| / sqrt 2)
+    return {(y < 0.0f) ? half_erfc : 1.0f - half_erfc, e * 0.3989422804014327f};
+#endif
+}
+__device__ __forceinline__ float gauss_pdf(float y) { return gauss(y).pdf; }
+__device__ __forceinline__ float gauss_cdf(float y) { return gauss(y).cdf; }
+
+// One 16-point tile of a 16-channel jet: value and the three tangents d/d(folded, scaled local position).
+struct TileJet { f32x4 v, t[3]; };
+
+// A operands and C initialisers of one instance for the forward pass, per lane (g, o = lane & 15).
+struct ForwardWeights {
+    float a0[12];     // W0[o][16 c + 4 g + s']  at index 4 c + s'   (k-step of the first layer: coordinate c, feature 4 g + s')
+    float a[3][4];    // W_l[o][4 g + s]
+    f32x4 b0, b[3];   // biases as accumulator initialisers: channel 4 g + j
+    f32x4 w4;         // head weights of channel 4 g + j
+    float b4;
+};
+
+// The weight pointer reaches the non-inlined functions in VGPRs: made wave-uniform again (SGPR base + per-lane offset
+// addressing) and typed as global memory so the loads are global_load, not flat_load.
+using GlobalWeights = const __attribute__((address_space(1))) float*;
+
+__device__ __forceinline__ GlobalWeights uniform_weights(const float* p) {
+    const unsigned long long bits = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(bits));
+    const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(bits >> 32));
+    return reinterpret_cast<GlobalWeights>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
+__device__ __forceinline__ void load_forward_weights(GlobalWeights w, int lane, ForwardWeights& fw) {
+    const int g = lane >> 4, o = lane & 15;
+    const GlobalWeights row0 = w + o * kMlpRow0 + 4 * g;
+#pragma unroll
+    for (int s = 0; s < 12; ++s) fw.a0[s] = row0[(s >> 2) * 16 + (s & 3)];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fw.b0[j] = w[(4 * g + j) * kMlpRow0 + kMlpFeatures];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        const GlobalWeights wl = w + kMlpLayer1 + l * kMlpBlock;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fw.a[l][s] = wl[o * kMlpRow + 4 * g + s];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fw.b[l][j] = wl[(4 * g + j) * kMlpRow + kMlpHidden];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fw.w4[j] = w[kMlpHead + 4 * g + j];
+    fw.b4 = w[kMlpHead + kMlpHidden];
+}
+
+// Encoder features of one tile: row g evaluates octaves 2 g and 2 g + 1 of every coordinate, i.e. features 4 g .. 4 g + 3
+// ([cos, sin] per octave) of each 16-feature coordinate block, and their derivatives w.r.t. the scaled coordinate.
+struct TileFeatures { f32x4 f[3], d[3]; };
+
+__device__ __forceinline__ void encode_tile(float f0, float f1, float f2, int g, TileFeatures& e) {
+    const float base = (g == 0) ? 1.0f : ((g == 1) ? 4.0f : ((g == 2) ? 16.0f : 64.0f));
     const float f[3] = {f0, f1, f2};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float octave = static_cast<float>(1 << k);
+        for (int kk = 0; kk < 2; ++kk) {
+            const float octave = kk ? 2.0f * base : base;
             const float x = f[c] * octave;                       // exact scaling; sin(pi x), cos(pi x)
             const float s = sinpif(x), co = cospif(x);
-            const float omega = octave * 3.14159265358979323846f;
-            feat[c][2 * k] = co; feat[c][2 * k + 1] = s;
-            dfeat[c][2 * k] = -omega * s; dfeat[c][2 * k + 1] = omega * co;
+            const float omega = octave * kPi;
+            e.f[c][2 * kk] = co; e.f[c][2 * kk + 1] = s;
+            e.d[c][2 * kk] = -omega * s; e.d[c][2 * kk + 1] = omega * co;
         }
-    }
-    float chain = f0;
-#pragma unroll
-    for (int o = 0; o < kMlpHidden; ++o) {
-        const W row = row_begin(w + o * (kMlpFeatures + 1), chain);
-        float acc = row[kMlpFeatures];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float tan = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float wj = row[c * 16 + j];
-                acc += wj * feat[c][j];
-                tan += wj * dfeat[c][j];
-            }
-            z.t[c][o] = tan;
-        }
-        z.v[o] = acc;
-        chain = acc;
-        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// LayerNorm (no affine) followed by exact GELU on a jet, in place.
-__device__ __forceinline__ void mlp_norm_gelu(Jet16& z) {
-    float mean = 0.0f;
+// Encoder fused with Linear(48 -> 16).  The tangent w.r.t. coordinate c only sees the 16 features of that coordinate.
+__device__ __forceinline__ void first_layer_tile(const ForwardWeights& fw, const TileFeatures& e, TileJet& z) {
+    z.v = fw.b0;
 #pragma unroll
-    for (int o = 0; o < kMlpHidden; ++o) mean += z.v[o];
-    mean *= (1.0f / kMlpHidden);
-    float var = 0.0f;
+    for (int c = 0; c < 3; ++c) {
+        z.t[c] = splat4(0.0f);
 #pragma unroll
-    for (int o = 0; o < kMlpHidden; ++o) { z.v[o] -= mean; var += z.v[o] * z.v[o]; }
-    const float inv_s = __builtin_amdgcn_rsqf(var * (1.0f / kMlpHidden) + kLayerNormEps);
-    float tmean[3] = {0.0f, 0.0f, 0.0f}, q[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int o = 0; o < kMlpHidden; ++o) {
-        z.v[o] *= inv_s;                                                     // y
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { tmean[c] += z.t[c][o]; q[c] += z.v[o] * z.t[c][o]; }
-    }
-#pragma unroll
-    for (int o = 0; o < kMlpHidden; ++o) {
-        const float y = z.v[o];
-        const float cdf = gauss_cdf(y);
-        const float g1 = cdf + y * gauss_pdf(y);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float dy = (z.t[c][o] - tmean[c] * (1.0f / kMlpHidden) - y * q[c] * (1.0f / kMlpHidden)) * inv_s;
-            z.t[c][o] = dy * g1;
+        for (int s = 0; s < 4; ++s) {
+            z.v = mfma4(fw.a0[4 * c + s], e.f[c][s], z.v);
+            z.t[c] = mfma4(fw.a0[4 * c + s], e.d[c][s], z.t[c]);
         }
-        z.v[o] = y * cdf;
     }
 }
 
-// Linear(16 -> kOut) on a jet; weight rows are [W[o][0..15], bias].
-template <int kOut, typename W>
-__device__ __forceinline__ void mlp_linear(W w, const Jet16& a, Jet16& z) {
-    float chain = a.v[0];
+// Linear(16 -> 16) on a tile jet.
+__device__ __forceinline__ void linear_tile(const float (&a)[4], f32x4 bias, const TileJet& in, TileJet& out) {
+    out.v = bias;
+    out.t[0] = out.t[1] = out.t[2] = splat4(0.0f);
 #pragma unroll
-    for (int o = 0; o < kOut; ++o) {
-        const W row = row_begin(w + o * (kMlpHidden + 1), chain);
-        float acc = row[kMlpHidden], t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+    for (int s = 0; s < 4; ++s) {
+        out.v = mfma4(a[s], in.v[s], out.v);
 #pragma unroll
-        for (int j = 0; j < kMlpHidden; ++j) {
-            const float wj = row[j];
-            acc += wj * a.v[j];
-            t0 += wj * a.t[0][j]; t1 += wj * a.t[1][j]; t2 += wj * a.t[2][j];
-        }
-        z.v[o] = acc; z.t[0][o] = t0; z.t[1][o] = t1; z.t[2][o] = t2;
-        chain = t2;
-        __builtin_amdgcn_sched_barrier(0);
+        for (int c = 0; c < 3; ++c) out.t[c] = mfma4(a[s], in.t[c][s], out.t[c]);
+    }
+}
+
+// LayerNorm (no affine) followed by exact GELU on a tile jet, in place.
+__device__ __forceinline__ void norm_gelu_tile(TileJet& z) {
+    const float mean = rows_sum(hsum4(z.v)) * (1.0f / kMlpHidden);
+    f32x4 y = z.v - splat4(mean);
+    const float var = rows_sum(dot4(y, y)) * (1.0f / kMlpHidden);
+    const float inv_s = __builtin_amdgcn_rsqf(var + kLayerNormEps);
+    y *= splat4(inv_s);
+    float tmean[3], q[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        tmean[c] = rows_sum(hsum4(z.t[c])) * (1.0f / kMlpHidden);
+        q[c] = rows_sum(dot4(y, z.t[c])) * (1.0f / kMlpHidden);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const Gauss n = gauss(y[j]);
+        const float g1 = n.cdf + y[j] * n.pdf;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) z.t[c][j] = (z.t[c][j] - tmean[c] - y[j] * q[c]) * inv_s * g1;
+        z.v[j] = y[j] * n.cdf;
     }
 }
 
 struct Residual { float value; float gx, gy, gz; };
 
-// A pointer that arrives in VGPRs (function argument of a non-inlined call) made provably wave-uniform again, so that the
-// weight loads behind it are selected as scalar loads.
-// constant address space (4): read-only for the whole launch (the MLP weights are never written by these kernels), which is what
-// lets uniform loads through it be selected as SMEM inside a non-inlined function.
-using GlobalFloats = const __attribute__((address_space(4))) float*;
-
-__device__ __forceinline__ GlobalFloats uniform_pointer(const float* p) {
-    const unsigned long long bits = reinterpret_cast<unsigned long long>(p);
-    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(bits));
-    const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(bits >> 32));
-    return reinterpret_cast<GlobalFloats>((static_cast<unsigned long long>(hi) << 32) | lo);   // SGPR pair
-}
-
-// residual(p) and d residual / d p for local position p, instance weights w (wave-uniform pointer).
-// NOT inlined: the fully unrolled MLP is ~9k instructions; one copy per kernel instead of one per call site keeps the
-// residual kernels from being megabytes of straight-line code (the 64 KB instruction cache is the scarce resource here).
+// residual(p) and d residual / d p for the local positions p of the wave's 64 points, instance weights w (wave-uniform).
+// NOT inlined: one copy per kernel keeps the residual kernels' code inside the instruction cache.
 __device__ __attribute__((noinline)) Residual residual_forward(const float* w_in, float px, float py, float pz) {
-    const GlobalFloats w = uniform_pointer(w_in);
+    const int lane = lane_id();
+    const int g = lane >> 4;
+    const GlobalWeights w = uniform_weights(w_in);
+    ForwardWeights fw;
+    load_forward_weights(w, lane, fw);
     const float fold = (px > 0.0f) ? 1.0f : ((px < 0.0f) ? -1.0f : 0.0f);
     const float inv = 1.0f / kPositionScale;
-    Jet16 a, z;
-    mlp_first_layer(w, fabsf(px) * inv, py * inv, pz * inv, z);
-    GlobalFloats wl = w + (kMlpFeatures + 1) * kMlpHidden;
+    const float f0 = fabsf(px) * inv, f1 = py * inv, f2 = pz * inv;
+    float out_v = 0.0f, out_t0 = 0.0f, out_t1 = 0.0f, out_t2 = 0.0f;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        TileFeatures e;
+        encode_tile(from_row(f0, q, lane), from_row(f1, q, lane), from_row(f2, q, lane), g, e);
+        TileJet z, n;
+        first_layer_tile(fw, e, z);
 #pragma unroll
-    for (int layer = 0; layer < 3; ++layer) {
-        mlp_norm_gelu(z);
-        a = z;
-        mlp_linear<kMlpHidden>(wl, a, z);
-        wl += (kMlpHidden + 1) * kMlpHidden;
+        for (int l = 0; l < 3; ++l) {
+            norm_gelu_tile(z);
+            linear_tile(fw.a[l], fw.b[l], z, n);
+            z = n;
+        }
+        norm_gelu_tile(z);
+        const float v = rows_sum(dot4(fw.w4, z.v)) + fw.b4;
+        const float t0 = rows_sum(dot4(fw.w4, z.t[0])), t1 = rows_sum(dot4(fw.w4, z.t[1])), t2 = rows_sum(dot4(fw.w4, z.t[2]));
+        const bool mine = (g == q);                              // row q of tile q holds point 16 q + m = this lane
+        out_v = mine ? v : out_v; out_t0 = mine ? t0 : out_t0; out_t1 = mine ? t1 : out_t1; out_t2 = mine ? t2 : out_t2;
     }
-    mlp_norm_gelu(z);
-    a = z;
-    mlp_linear<1>(wl, a, z);
     Residual r;
-    r.value = fast_rcp(1.0f + fast_exp(-(z.v[0] - 1.0f)));
+    r.value = fast_rcp(1.0f + fast_exp(-(out_v - 1.0f)));
     const float kappa = r.value * (1.0f - r.value) * inv;
-    r.gx = kappa * z.t[0][0] * fold; r.gy = kappa * z.t[1][0]; r.gz = kappa * z.t[2][0];
+    r.gx = kappa * out_t0 * fold; r.gy = kappa * out_t1; r.gz = kappa * out_t2;
     return r;
 }
 
-// ---- adjoint ------------------------------------------------------------------------------------------------
-// Blueprint: oracle/analytic_mlp.py::backward (float64, checked against autograd).  One lane = one sample.
-// Weight adjoints are reduced over the 64 lanes 16 values at a time with the reduce-scatter butterfly and added
-// into the wave's LDS row `wbar` [1617] (lane j < 16 owns column j of the current weight row: thread-private
-// addresses, no hazards).
 
-// What the adjoint of one [LayerNorm -> GELU -> Linear] block needs, recomputed from the block's input jet.
-struct BlockState {
-    float y[kMlpHidden], g1[kMlpHidden], g2[kMlpHidden];   // normalised value, GELU', pdf(y)(2 - y^2)
-    float dy[3][kMlpHidden];
-    float a[kMlpHidden], da[3][kMlpHidden];                // activations fed to the linear
-    float q[3];                                            // mean(y * dz_c)
+// ---- adjoint ------------------------------------------------------------------------------------------------------
+// Blueprint: oracle/analytic_mlp.py::backward (float64, checked against autograd).  Same tile layout as the forward.
+//   activation adjoints  a_bar = W^T z_bar        : MFMA with the transposed weight operands  W[4 g + s][i = lane & 15]
+//   weight adjoints      W_bar += z_bar a^T        : MFMA whose k index is the POINT: both operands are needed with the
+//                                                    channel along lane & 15 and the point along (lane >> 4, k-step), i.e.
+//                                                    transposed; the tiles go through a wave-private LDS scratch
+//                                                    (4 ds_write_b32 + 1 ds_read_b128 per tile, conflict-free with a row
+//                                                    pitch of 20 floats).  The accumulators come out as W_bar[4 g + j][lane & 15]
+//                                                    -- the row-major layout of the weight block itself.
+// Per call (64 points x 1 instance) the accumulators live in registers; they are added into the wave's LDS row
+// `wbar` [1617] at the end (each lane owns its addresses).
+
+constexpr int kTilePitch = 20;                               // floats per channel row of a staged tile (16 points + 4 pad)
+constexpr int kTileFloats = 16 * kTilePitch;
+constexpr int kMlpWbarFloats = 1632;                         // wbar [1617] padded to a multiple of 4 floats
+constexpr int kMlpScratchTiles = 8;
+constexpr int kMlpLdsFloats = kMlpWbarFloats + kMlpScratchTiles * kTileFloats;   // per-wave LDS of the residual adjoint
+
+// Compiler-only ordering between LDS accesses of different lanes of this wave (DS operations of a wave execute in order).
+__device__ __forceinline__ void wave_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Stage a tile (register j of lane (g, m) = X[4 g + j][m]) / fetch it transposed: lane (g, r) <- X[r][4 g + s], s = 0..3.
+__device__ __forceinline__ void stage_tile(float* tile, f32x4 x, int lane) {
+    float* dst = tile + (lane >> 4) * 4 * kTilePitch + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dst[j * kTilePitch] = x[j];
+}
+__device__ __forceinline__ f32x4 fetch_tile(const float* tile, int lane) {
+    return *reinterpret_cast<const f32x4*>(tile + (lane & 15) * kTilePitch + (lane >> 4) * 4);
+}
+
+struct BackwardWeights {    // transposed A operands, lane (g, i = lane & 15)
+    float at[3][4];         // W_l[4 g + s][i]
+    float at0[3][4];        // W0[4 g + s][16 c + i]
+};
+
+__device__ __forceinline__ void load_backward_weights(GlobalWeights w, int lane, BackwardWeights& bw) {
+    const int g = lane >> 4, i = lane & 15;
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bw.at[l][s] = w[kMlpLayer1 + l * kMlpBlock + (4 * g + s) * kMlpRow + i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bw.at0[c][s] = w[(4 * g + s) * kMlpRow0 + 16 * c + i];
+}
+
+// What the adjoint of one [LayerNorm -> GELU] needs, recomputed from the block's input jet.
+struct TileState {
+    f32x4 y, g1, g2, a;         // normalised value, GELU', pdf(y)(2 - y^2), activation
+    f32x4 dy[3], da[3];
+    float q[3];                 // mean(y * dz_c)
     float inv_s;
 };
 
-__device__ __forceinline__ void block_state(const Jet16& z, BlockState& b) {
-    float mean = 0.0f;
+__device__ __forceinline__ void tile_state(const TileJet& z, TileState& b) {
+    const float mean = rows_sum(hsum4(z.v)) * (1.0f / kMlpHidden);
+    b.y = z.v - splat4(mean);
+    const float var = rows_sum(dot4(b.y, b.y)) * (1.0f / kMlpHidden);
+    b.inv_s = __builtin_amdgcn_rsqf(var + kLayerNormEps);
+    b.y *= splat4(b.inv_s);
+    float tmean[3];
 #pragma unroll
-    for (int o = 0; o < kMlpHidden; ++o) mean += z.v[o];
-    mean *= (1.0f / kMlpHidden);
-    float var = 0.0f;
-#pragma unroll
-    for (int o = 0; o < kMlpHidden; ++o) { b.y[o] = z.v[o] - mean; var += b.y[o] * b.y[o]; }
-    b.inv_s = __builtin_amdgcn_rsqf(var * (1.0f / kMlpHidden) + kLayerNormEps);
-    float tmean[3] = {0.0f, 0.0f, 0.0f};
-    b.q[0] = b.q[1] = b.q[2] = 0.0f;
-#pragma unroll
-    for (int o = 0; o < kMlpHidden; ++o) {
-        b.y[o] *= b.inv_s;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { tmean[c] += z.t[c][o]; b.q[c] += b.y[o] * z.t[c][o]; }
+    for (int c = 0; c < 3; ++c) {
+        tmean[c] = rows_sum(hsum4(z.t[c])) * (1.0f / kMlpHidden);
+        b.q[c] = rows_sum(dot4(b.y, z.t[c])) * (1.0f / kMlpHidden);
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { tmean[c] *= (1.0f / kMlpHidden); b.q[c] *= (1.0f / kMlpHidden); }
-#pragma unroll
-    for (int o = 0; o < kMlpHidden; ++o) {
-        const float y = b.y[o];
-        const float cdf = gauss_cdf(y), pdf = gauss_pdf(y);
-        b.g1[o] = cdf + y * pdf;
-        b.g2[o] = pdf * (2.0f - y * y);
-        b.a[o] = y * cdf;
+    for (int j = 0; j < 4; ++j) {
+        const float y = b.y[j];
+        const Gauss n = gauss(y);
+        b.g1[j] = n.cdf + y * n.pdf;
+        b.g2[j] = n.pdf * (2.0f - y * y);
+        b.a[j] = y * n.cdf;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            b.dy[c][o] = (z.t[c][o] - tmean[c] - y * b.q[c]) * b.inv_s;
-            b.da[c][o] = b.dy[c][o] * b.g1[o];
+            b.dy[c][j] = (z.t[c][j] - tmean[c] - y * b.q[c]) * b.inv_s;
+            b.da[c][j] = b.dy[c][j] * b.g1[j];
         }
     }
 }
 
-// P(v) = (v - mean(v) - y mean(v y)) / s  (LayerNorm's symmetric Jacobian), in place on 16 values.
-__device__ __forceinline__ void layer_norm_adjoint(float (&v)[kMlpHidden], const BlockState& b) {
-    float m = 0.0f, my = 0.0f;
-#pragma unroll
-    for (int o = 0; o < kMlpHidden; ++o) { m += v[o]; my += v[o] * b.y[o]; }
-    m *= (1.0f / kMlpHidden); my *= (1.0f / kMlpHidden);
-#pragma unroll
-    for (int o = 0; o < kMlpHidden; ++o) v[o] = (v[o] - m - b.y[o] * my) * b.inv_s;
+// P(v) = (v - mean(v) - y mean(v y)) / s  (LayerNorm's symmetric Jacobian), in place on a tile.
+__device__ __forceinline__ void layer_norm_adjoint_tile(f32x4& v, const TileState& b) {
+    const float m = rows_sum(hsum4(v)) * (1.0f / kMlpHidden);
+    const float my = rows_sum(dot4(v, b.y)) * (1.0f / kMlpHidden);
+    v = (v - splat4(m) - b.y * splat4(my)) * splat4(b.inv_s);
 }
 
-// Adjoint of one block: (z_bar, dz_bar) of the linear's kOut outputs -> adjoint of the block's input jet (returned in zb),
-// weight adjoints of the linear accumulated into wbar (row-major [kOut][17]).
-template <int kOut, typename W>
-__device__ __forceinline__ void block_adjoint(W w, const Jet16& z_in, Jet16& zb, float* wbar, int lane) {
-    BlockState b;
-    block_state(z_in, b);
-    float a_bar[kMlpHidden], da_bar[3][kMlpHidden];
+// Adjoint of [LayerNorm -> GELU] on a jet: (a_bar, da_bar) of the activations -> adjoint of the block's input jet z_in.
+__device__ __forceinline__ void gelu_norm_adjoint_tile(const TileState& b, const TileJet& z_in, f32x4 a_bar, const f32x4 (&da_bar)[3], TileJet& zb) {
+    f32x4 y_bar, dyb[3];
+    float s_part = 0.0f, dot_part[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int j = 0; j < kMlpHidden; ++j) { a_bar[j] = 0.0f; da_bar[0][j] = da_bar[1][j] = da_bar[2][j] = 0.0f; }
-    float bias[16];
-#pragma unroll
-    for (int o = 0; o < 16; ++o) bias[o] = 0.0f;
-    // (1) weight adjoints: outer products reduced over the wave -- no weights needed
-#pragma unroll
-    for (int o = 0; o < kOut; ++o) {
-        float prod[16];
-#pragma unroll
-        for (int j = 0; j < kMlpHidden; ++j)
-            prod[j] = zb.v[o] * b.a[j] + zb.t[0][o] * b.da[0][j] + zb.t[1][o] * b.da[1][j] + zb.t[2][o] * b.da[2][j];
-        const float r = wave_reduce16_scatter(prod, lane);
-        if (lane < kMlpHidden) wbar[o * (kMlpHidden + 1) + lane] += r;
-        bias[o] = zb.v[o];
-    }
-    {
-        const float r = wave_reduce16_scatter(bias, lane);
-        if (lane < kOut) wbar[lane * (kMlpHidden + 1) + kMlpHidden] += r;
-    }
-    // (2) activation adjoints: transposed mat-vec, one weight row (16 SGPRs) live at a time
-    float chain = b.inv_s;
-#pragma unroll
-    for (int o = 0; o < kOut; ++o) {
-        const W row = row_begin(w + o * (kMlpHidden + 1), chain);
-#pragma unroll
-        for (int j = 0; j < kMlpHidden; ++j) {
-            const float wj = row[j];
-            a_bar[j] += wj * zb.v[o];
-            da_bar[0][j] += wj * zb.t[0][o]; da_bar[1][j] += wj * zb.t[1][o]; da_bar[2][j] += wj * zb.t[2][o];
-        }
-        chain = da_bar[2][kMlpHidden - 1];
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // GELU jet adjoint
-    float y_bar[kMlpHidden];
-    float dyb[3][kMlpHidden];
-    float s_bar = 0.0f;
-    float dot[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int j = 0; j < kMlpHidden; ++j) {
+    for (int j = 0; j < 4; ++j) {
         float cross = 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             cross += da_bar[c][j] * b.dy[c][j];
             dyb[c][j] = da_bar[c][j] * b.g1[j];
-            s_bar -= dyb[c][j] * b.dy[c][j];
-            dot[c] += dyb[c][j] * b.y[j];
+            s_part -= dyb[c][j] * b.dy[c][j];
+            dot_part[c] += dyb[c][j] * b.y[j];
         }
         y_bar[j] = a_bar[j] * b.g1[j] + cross * b.g2[j];
     }
-    s_bar *= b.inv_s;
-    // LayerNorm jet adjoint: explicit dependence of dy on (y, s), then through y = (z - mean)/s
+    const float s_bar = rows_sum(s_part) * b.inv_s;
+    float dot[3];
 #pragma unroll
-    for (int j = 0; j < kMlpHidden; ++j) {
+    for (int c = 0; c < 3; ++c) dot[c] = rows_sum(dot_part[c]) * (1.0f / kMlpHidden);
+    // explicit dependence of dy on (y, s), then through y = (z - mean) / s
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-            y_bar[j] -= (dyb[c][j] * b.q[c] + z_in.t[c][j] * dot[c] * (1.0f / kMlpHidden)) * b.inv_s;
-    }
-    layer_norm_adjoint(y_bar, b);
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) layer_norm_adjoint(dyb[c], b);
+        for (int c = 0; c < 3; ++c) y_bar[j] -= (dyb[c][j] * b.q[c] + z_in.t[c][j] * dot[c]) * b.inv_s;
+    layer_norm_adjoint_tile(y_bar, b);
 #pragma unroll
-    for (int j = 0; j < kMlpHidden; ++j) {
-        zb.v[j] = y_bar[j] + s_bar * b.y[j] * (1.0f / kMlpHidden);
-        zb.t[0][j] = dyb[0][j]; zb.t[1][j] = dyb[1][j]; zb.t[2][j] = dyb[2][j];
-    }
+    for (int c = 0; c < 3; ++c) layer_norm_adjoint_tile(dyb[c], b);
+    zb.v = y_bar + b.y * splat4(s_bar * (1.0f / kMlpHidden));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) zb.t[c] = dyb[c];
 }
+
+// Sum over the 16 lanes of each row (every lane of the row receives it).
+__device__ __forceinline__ float row_sum16(float v) {
+    v += dpp_move<kDppQuadXor1>(0.0f, v);
+    v += dpp_move<kDppQuadXor2>(0.0f, v);
+    v += dpp_move<kDppRowHalfMirror>(0.0f, v);
+    v += dpp_move<kDppRowMirror>(0.0f, v);
+    return v;
+}
+__device__ __forceinline__ float pick4(f32x4 v, int m) { return (m == 0) ? v[0] : ((m == 1) ? v[1] : ((m == 2) ? v[2] : v[3])); }
+__device__ __forceinline__ f32x4 row_sum16(f32x4 v) { return f32x4{row_sum16(v[0]), row_sum16(v[1]), row_sum16(v[2]), row_sum16(v[3])}; }
 
 struct ResidualAdjoint { float px, py, pz; };
 
-// Adjoint of residual_forward at local position p: res_bar = dL/d residual, (gbx,gby,gbz) = dL/d(grad_p residual).
-// Accumulates dL/dw into wbar (LDS, [1617]); returns dL/dp.
+// Adjoint of residual_forward at the wave's local positions p: res_bar = dL/d residual, (gbx, gby, gbz) = dL/d(grad_p residual).
+// Adds dL/dw into `mlp_lds` (the wave's LDS: wbar [1617], then the transposition scratch); returns dL/dp per lane.
 __device__ __attribute__((noinline)) ResidualAdjoint residual_backward(const float* w_in, float px, float py, float pz,
-                                                                       float res_bar, float gbx, float gby, float gbz, float* wbar, int lane) {
-    const GlobalFloats w = uniform_pointer(w_in);
+                                                                       float res_bar, float gbx, float gby, float gbz, float* mlp_lds, int lane) {
+    const int g = lane >> 4, m = lane & 15;
+    const GlobalWeights w = uniform_weights(w_in);
+    float* wbar = mlp_lds;
+    float* scratch = mlp_lds + kMlpWbarFloats;
+    ForwardWeights fw;
+    BackwardWeights bw;
+    load_forward_weights(w, lane, fw);
+    load_backward_weights(w, lane, bw);
     const float fold = (px > 0.0f) ? 1.0f : ((px < 0.0f) ? -1.0f : 0.0f);
     const float inv = 1.0f / kPositionScale;
-    const float f[3] = {fabsf(px) * inv, py * inv, pz * inv};
-    const float folds[3] = {fold, 1.0f, 1.0f};
-    // ---- forward; only z0 (first-layer output) and z2 (second hidden linear's output) are kept: z1 and z3 are recomputed
-    //      from them when their block's adjoint runs (two extra hidden layers instead of 128 more live registers) ---------
-    Jet16 z0, z2, a, out;
-    mlp_first_layer(w, f[0], f[1], f[2], z0);
-    const GlobalFloats w1 = w + (kMlpFeatures + 1) * kMlpHidden;
-    const GlobalFloats w2 = w1 + (kMlpHidden + 1) * kMlpHidden;
-    const GlobalFloats w3 = w2 + (kMlpHidden + 1) * kMlpHidden;
-    const GlobalFloats w4 = w3 + (kMlpHidden + 1) * kMlpHidden;
-    {
-        Jet16 z1, z3;
-        a = z0; mlp_norm_gelu(a); mlp_linear<kMlpHidden>(w1, a, z1);
-        mlp_norm_gelu(z1); mlp_linear<kMlpHidden>(w2, z1, z2);
-        a = z2; mlp_norm_gelu(a); mlp_linear<kMlpHidden>(w3, a, z3);
-        mlp_norm_gelu(z3); mlp_linear<1>(w4, z3, out);
-    }
-    const float res = fast_rcp(1.0f + fast_exp(-(out.v[0] - 1.0f)));
-    const float kappa = res * (1.0f - res);
-    const float gb[3] = {gbx, gby, gbz};
-    // ---- adjoint of the sigmoid head -----------------------------------------------------------------------------------
-    Jet16 zb;
-    float kappa_bar = 0.0f;
+    const float f0 = fabsf(px) * inv, f1 = py * inv, f2 = pz * inv;
+    const float base = (g == 0) ? 1.0f : ((g == 1) ? 4.0f : ((g == 2) ? 16.0f : 64.0f));
+    const float omega_sq[2] = {(base * kPi) * (base * kPi), (2.0f * base * kPi) * (2.0f * base * kPi)};
+    f32x4 acc_w[3], acc_w0[3], acc_b[3], acc_b0 = splat4(0.0f), acc_w4 = splat4(0.0f);
+    float acc_b4 = 0.0f;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        zb.t[c][0] = gb[c] * kappa * folds[c] * inv;
-        kappa_bar += gb[c] * out.t[c][0] * folds[c] * inv;
-    }
-    zb.v[0] = (res_bar + kappa_bar * (1.0f - 2.0f * res)) * kappa;
-    // ---- blocks 4..1 ---------------------------------------------------------------------------------------------------
-    const int off1 = (kMlpFeatures + 1) * kMlpHidden, blk = (kMlpHidden + 1) * kMlpHidden;
-    {
-        Jet16 z3;
-        a = z2; mlp_norm_gelu(a); mlp_linear<kMlpHidden>(w3, a, z3);
-        block_adjoint<1>(w4, z3, zb, wbar + off1 + 3 * blk, lane);
-    }
-    block_adjoint<kMlpHidden>(w3, z2, zb, wbar + off1 + 2 * blk, lane);
-    {
-        Jet16 z1;
-        a = z0; mlp_norm_gelu(a); mlp_linear<kMlpHidden>(w1, a, z1);
-        block_adjoint<kMlpHidden>(w2, z1, zb, wbar + off1 + blk, lane);
-    }
-    block_adjoint<kMlpHidden>(w1, z0, zb, wbar + off1, lane);
-    // ---- first layer + encoder -----------------------------------------------------------------------------------------
-    float f_bar[3] = {0.0f, 0.0f, 0.0f};
-    float bias[16];
+    for (int l = 0; l < 3; ++l) { acc_w[l] = splat4(0.0f); acc_w0[l] = splat4(0.0f); acc_b[l] = splat4(0.0f); }
+    ResidualAdjoint mine = {0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        const float tfold = from_row(fold, q, lane);
+        const float folds[3] = {tfold, 1.0f, 1.0f};
+        const float gb[3] = {from_row(gbx, q, lane), from_row(gby, q, lane), from_row(gbz, q, lane)};
+        const float t_res_bar = from_row(res_bar, q, lane);
+        TileFeatures e;
+        encode_tile(from_row(f0, q, lane), from_row(f1, q, lane), from_row(f2, q, lane), g, e);
+        // ---- forward, keeping the pre-norm jets z[0..3] ------------------------------------------------------------------
+        TileJet z[4];
+        first_layer_tile(fw, e, z[0]);
 #pragma unroll
-    for (int o = 0; o < 16; ++o) bias[o] = zb.v[o];
-    {
-        const float r = wave_reduce16_scatter(bias, lane);
-        if (lane < kMlpHidden) wbar[lane * (kMlpFeatures + 1) + kMlpFeatures] += r;
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float feat[16], dfeat[16], feat_bar[16], dfeat_bar[16];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float octave = static_cast<float>(1 << k);
-            const float x = f[c] * octave;
-            const float s = sinpif(x), co = cospif(x);
-            const float omega = octave * 3.14159265358979323846f;
-            feat[2 * k] = co; feat[2 * k + 1] = s;
-            dfeat[2 * k] = -omega * s; dfeat[2 * k + 1] = omega * co;
-            feat_bar[2 * k] = feat_bar[2 * k + 1] = 0.0f;
-            dfeat_bar[2 * k] = dfeat_bar[2 * k + 1] = 0.0f;
+        for (int l = 0; l < 3; ++l) {
+            TileJet a = z[l];
+            norm_gelu_tile(a);
+            linear_tile(fw.a[l], fw.b[l], a, z[l + 1]);
         }
+        TileState st;
+        tile_state(z[3], st);
+        const float out_v = rows_sum(dot4(fw.w4, st.a)) + fw.b4;
+        float out_t[3];
 #pragma unroll
-        for (int o = 0; o < kMlpHidden; ++o) {
-            float prod[16];
+        for (int c = 0; c < 3; ++c) out_t[c] = rows_sum(dot4(fw.w4, st.da[c]));
+        // ---- sigmoid head ---------------------------------------------------------------------------------------------------
+        const float res = fast_rcp(1.0f + fast_exp(-(out_v - 1.0f)));
+        const float kappa = res * (1.0f - res);
+        float zb_t[3], kappa_bar = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) prod[j] = zb.v[o] * feat[j] + zb.t[c][o] * dfeat[j];
-            const float r = wave_reduce16_scatter(prod, lane);
-            if (lane < 16) wbar[o * (kMlpFeatures + 1) + c * 16 + lane] += r;
+        for (int c = 0; c < 3; ++c) {
+            zb_t[c] = gb[c] * kappa * folds[c] * inv;
+            kappa_bar += gb[c] * out_t[c] * folds[c] * inv;
         }
-        float chain = feat[0];
+        const float zb_v = (t_res_bar + kappa_bar * (1.0f - 2.0f * res)) * kappa;
+        // ---- block 4: LayerNorm -> GELU -> Linear(16 -> 1) -----------------------------------------------------------------
+        TileJet zb;
+        {
+            acc_w4 += splat4(zb_v) * st.a;
+            f32x4 da_bar[3];
 #pragma unroll
-        for (int o = 0; o < kMlpHidden; ++o) {
-            const GlobalFloats row = row_begin(w + o * (kMlpFeatures + 1) + c * 16, chain);
+            for (int c = 0; c < 3; ++c) { acc_w4 += splat4(zb_t[c]) * st.da[c]; da_bar[c] = fw.w4 * splat4(zb_t[c]); }
+            acc_b4 += zb_v;
+            gelu_norm_adjoint_tile(st, z[3], fw.w4 * splat4(zb_v), da_bar, zb);
+        }
+        // ---- blocks 3..1: LayerNorm -> GELU -> Linear(16 -> 16); zb is the adjoint of z[l + 1] -----------------------------
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float wj = row[j];
-                feat_bar[j] += wj * zb.v[o];
-                dfeat_bar[j] += wj * zb.t[c][o];
+        for (int l = 2; l >= 0; --l) {
+            tile_state(z[l], st);
+            acc_b[l] += zb.v;
+            stage_tile(scratch + 0 * kTileFloats, zb.v, lane);
+            stage_tile(scratch + 1 * kTileFloats, st.a, lane);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                stage_tile(scratch + (2 + 2 * c) * kTileFloats, zb.t[c], lane);
+                stage_tile(scratch + (3 + 2 * c) * kTileFloats, st.da[c], lane);
             }
-            chain = dfeat_bar[15];
-            __builtin_amdgcn_sched_barrier(0);
-        }
+            wave_lds_order();
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float omega = static_cast<float>(1 << k) * 3.14159265358979323846f;
-            const float co = feat[2 * k], s = feat[2 * k + 1];
-            f_bar[c] += feat_bar[2 * k] * (-omega * s) + feat_bar[2 * k + 1] * (omega * co)
-                      + dfeat_bar[2 * k] * (-omega * omega * co) + dfeat_bar[2 * k + 1] * (-omega * omega * s);
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 xt = fetch_tile(scratch + (2 * k) * kTileFloats, lane), yt = fetch_tile(scratch + (2 * k + 1) * kTileFloats, lane);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc_w[l] = mfma4(xt[s], yt[s], acc_w[l]);
+            }
+            wave_lds_order();
+            f32x4 a_bar = splat4(0.0f), da_bar[3] = {splat4(0.0f), splat4(0.0f), splat4(0.0f)};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                a_bar = mfma4(bw.at[l][s], zb.v[s], a_bar);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) da_bar[c] = mfma4(bw.at[l][s], zb.t[c][s], da_bar[c]);
+            }
+            TileJet zin_bar;
+            gelu_norm_adjoint_tile(st, z[l], a_bar, da_bar, zin_bar);
+            zb = zin_bar;
         }
+        // ---- first layer + encoder; zb is the adjoint of z[0] -----------------------------------------------------------------
+        acc_b0 += zb.v;
+        stage_tile(scratch + 0 * kTileFloats, zb.v, lane);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            stage_tile(scratch + (1 + c) * kTileFloats, zb.t[c], lane);
+        }
+        stage_tile(scratch + 4 * kTileFloats, e.f[0], lane);
+        stage_tile(scratch + 5 * kTileFloats, e.d[0], lane);
+        stage_tile(scratch + 6 * kTileFloats, e.f[1], lane);
+        stage_tile(scratch + 7 * kTileFloats, e.d[1], lane);
+        wave_lds_order();
+        const f32x4 xv = fetch_tile(scratch + 0 * kTileFloats, lane);
+        f32x4 xt[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) xt[c] = fetch_tile(scratch + (1 + c) * kTileFloats, lane);
+        f32x4 ft[3], dt[3];
+        ft[0] = fetch_tile(scratch + 4 * kTileFloats, lane); dt[0] = fetch_tile(scratch + 5 * kTileFloats, lane);
+        ft[1] = fetch_tile(scratch + 6 * kTileFloats, lane); dt[1] = fetch_tile(scratch + 7 * kTileFloats, lane);
+        wave_lds_order();
+        stage_tile(scratch + 4 * kTileFloats, e.f[2], lane);
+        stage_tile(scratch + 5 * kTileFloats, e.d[2], lane);
+        wave_lds_order();
+        ft[2] = fetch_tile(scratch + 4 * kTileFloats, lane); dt[2] = fetch_tile(scratch + 5 * kTileFloats, lane);
+        wave_lds_order();
+        float f_bar[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            f32x4 feat_bar = splat4(0.0f), dfeat_bar = splat4(0.0f);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc_w0[c] = mfma4(xv[s], ft[c][s], acc_w0[c]);
+                acc_w0[c] = mfma4(xt[c][s], dt[c][s], acc_w0[c]);
+                feat_bar = mfma4(bw.at0[c][s], zb.v[s], feat_bar);
+                dfeat_bar = mfma4(bw.at0[c][s], zb.t[c][s], dfeat_bar);
+            }
+            // d feat / d f = dfeat;  d dfeat / d f = -omega^2 feat   (feature j of this row: octave j >> 1)
+            float part = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part += feat_bar[j] * e.d[c][j] - dfeat_bar[j] * omega_sq[j >> 1] * e.f[c][j];
+            f_bar[c] = rows_sum(part);
+        }
+        if (g == q) { mine.px = f_bar[0] * tfold * inv; mine.py = f_bar[1] * inv; mine.pz = f_bar[2] * inv; }
     }
-    ResidualAdjoint r;
-    r.px = f_bar[0] * fold * inv; r.py = f_bar[1] * inv; r.pz = f_bar[2] * inv;
-    return r;
+    // ---- flush the accumulators into the wave's LDS row (row-major weight blocks; every lane owns its addresses) -------------
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int l = 0; l < 3; ++l) wbar[kMlpLayer1 + l * kMlpBlock + (4 * g + j) * kMlpRow + m] += acc_w[l][j];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) wbar[(4 * g + j) * kMlpRow0 + 16 * c + m] += acc_w0[c][j];
+    }
+    // biases / head weights: sum over the 16 points of the row, lane m < 4 of row g stores channel 4 g + m
+    const float b0 = pick4(row_sum16(acc_b0), m), w4 = pick4(row_sum16(acc_w4), m);
+    float bl[3];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) bl[l] = pick4(row_sum16(acc_b[l]), m);
+    const float b4 = row_sum16(acc_b4);
+    if (m < 4) {
+        wbar[(4 * g + m) * kMlpRow0 + kMlpFeatures] += b0;
+        wbar[kMlpHead + 4 * g + m] += w4;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) wbar[kMlpLayer1 + l * kMlpBlock + (4 * g + m) * kMlpRow + kMlpHidden] += bl[l];
+    }
+    if (lane == 0) wbar[kMlpHead + kMlpHidden] += b4;
+    return mine;
 }
 
 }  // namespace vsrd
