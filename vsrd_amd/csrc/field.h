@@ -81,11 +81,13 @@ __device__ __forceinline__ BoxEval eval_box(const Instance& in, float x, float y
 
 // Box (+ optional residual MLP) evaluation of instance i: d_i = box(p) + residual(p), local gradient likewise
 // (scripts/main.py:451-458).  `mlp` is the wave-uniform weight row of the instance.
+// `tiles`: wave-uniform 4-bit mask of the 16-lane rows that need the residual (rows_with(ballot of un-culled lanes)); the lanes
+// of the other rows get residual 0 -- their soft-min weight is below exp(-tau) on the box distance alone (culling, below).
 template <bool kResidual>
-__device__ __forceinline__ BoxEval eval_instance(const Instance& in, const float* __restrict__ mlp, float x, float y, float z) {
+__device__ __forceinline__ BoxEval eval_instance(const Instance& in, const float* __restrict__ mlp, float x, float y, float z, unsigned tiles = 0xFu) {
     BoxEval e = eval_box(in, x, y, z);
     if (kResidual) {
-        const Residual r = residual_forward(mlp, e.px, e.py, e.pz);      // wave-cooperative: all 64 lanes active
+        const Residual r = residual_forward(mlp, e.px, e.py, e.pz, tiles);      // wave-cooperative: all 64 lanes active
         e.d += r.value;
         e.glx += r.gx; e.gly += r.gy; e.glz += r.gz;
         e.gwx = in.r00 * e.glx + in.r01 * e.gly + in.r02 * e.glz;
@@ -104,6 +106,12 @@ __device__ __forceinline__ BoxEval eval_instance(const Instance& in, const float
 // The decision is wave-uniform (one ballot), so a skipped instance costs ~14 instructions instead of ~120.
 constexpr float kCullTau = 18.0f;
 constexpr float kCullSlack = 2.0e-4f;
+
+// 4-bit mask of the 16-lane rows in which `ballot` has a lane set (scalar arithmetic on the ballot).
+__device__ __forceinline__ unsigned rows_with(unsigned long long ballot) {
+    return ((ballot & 0xFFFFull) ? 1u : 0u) | ((ballot & 0xFFFF0000ull) ? 2u : 0u) | ((ballot & 0xFFFF00000000ull) ? 4u : 0u) |
+           ((ballot & 0xFFFF000000000000ull) ? 8u : 0u);
+}
 
 __device__ __forceinline__ float centre_distance(const Instance& in, float x, float y, float z) {
     const float rx = x - in.tx, ry = y - in.ty, rz = z - in.tz;

@@ -92,9 +92,10 @@ __device__ __forceinline__ UnionValue eval_union(const float* __restrict__ insta
     const float threshold = cull_prepass(instances, num_instances, sh.cull, x, y, z, dcache, lane);
     UnionSums sums = union_init();
     for (int i = 0; i < num_instances; ++i) {
-        if (!wave_any(dcache[i * kWave + lane] <= threshold)) continue;        // wave-uniform skip
+        const unsigned long long near = __ballot(dcache[i * kWave + lane] <= threshold);
+        if (near == 0ull) continue;                                             // wave-uniform skip
         const Instance in = load_instance(instances, i);
-        const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z);
+        const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z, rows_with(near));
         if (kCacheDistances) dcache[i * kWave + lane] = e.d;
         union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, sh.inv_t);
     }

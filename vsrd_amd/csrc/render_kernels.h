@@ -235,11 +235,12 @@ __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, 
         for (int i = 0; i < N; ++i) {
             const Instance in = load_instance(instances, i);
             const float lb = centre_distance(in, st.sa[k].x, st.sa[k].y, st.sa[k].z) * (1.0f - kCullSlack) - bounding_radius(in);
-            if (!wave_any(lb <= st.thr[k])) {
+            const unsigned long long near = __ballot(lb <= st.thr[k]);
+            if (near == 0ull) {
                 if (kCacheD) dcache[i * kWave + lane] = lb;      // > thr on every lane: marks the instance as culled
                 continue;
             }
-            const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, st.sa[k].x, st.sa[k].y, st.sa[k].z);
+            const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, st.sa[k].x, st.sa[k].y, st.sa[k].z, rows_with(near));
             if (kCacheD) dcache[i * kWave + lane] = e.d;
             union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, inv_t);
         }
@@ -329,11 +330,13 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
         const float lam_i = lam[i];
         const float rho = bounding_radius(in);
         bool active[kRounds];
+        unsigned tiles[kRounds];
         bool any_active = false;
 #pragma unroll
         for (int k = 0; k < kRounds; ++k) {
             const float lb = centre_distance(in, st.sa[k].x, st.sa[k].y, st.sa[k].z) * (1.0f - kCullSlack) - rho;
-            active[k] = (k * kWave < num_points) && wave_any(lb <= st.thr[k]);
+            tiles[k] = rows_with(__ballot(lb <= st.thr[k]));
+            active[k] = (k * kWave < num_points) && tiles[k] != 0u;
             any_active = any_active || active[k];
         }
         if (!any_active) continue;                                            // negligible for this ray (field.h culling)
@@ -342,7 +345,7 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
 #pragma unroll
         for (int k = 0; k < kRounds; ++k) {
             if (!active[k]) continue;
-            const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, st.sa[k].x, st.sa[k].y, st.sa[k].z);
+            const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, st.sa[k].x, st.sa[k].y, st.sa[k].z, tiles[k]);
             const float ds = e.d - st.sa[k].m;
             const float w = fast_exp(-ds * inv_t) * st.sa[k].inv_z;
             const float cc = w * (1.0f - (ds - st.sa[k].us) * inv_t);
@@ -366,7 +369,7 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
             float pbx = sx * qbx, pby = sy * qby, pbz = sz * qbz;
             ad0 -= qbx; ad1 -= qby; ad2 -= qbz;
             if (kResidual) {        // residual(p): value adjoint d_bar, local-gradient adjoint gl_bar (main.py:451-458)
-                const ResidualAdjoint ra = residual_backward(mlp + i * kMlpWeights, e.px, e.py, e.pz, d_bar, glbx, glby, glbz, wbar, lane);
+                const ResidualAdjoint ra = residual_backward(mlp + i * kMlpWeights, e.px, e.py, e.pz, d_bar, glbx, glby, glbz, wbar, lane, tiles[k]);
                 pbx += ra.px; pby += ra.py; pbz += ra.pz;
             }
             r00 += e.relx * pbx + gwbx * e.glx; r01 += e.relx * pby + gwbx * e.gly; r02 += e.relx * pbz + gwbx * e.glz;

@@ -39,6 +39,9 @@ constexpr float kPi = 3.14159265358979323846f;
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+// The two entry points are NOT inlined: one copy per kernel keeps the residual kernels inside the instruction cache.
+#define VSRD_RESIDUAL_FN __device__ __attribute__((noinline))
+
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
 __device__ __forceinline__ float hsum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
@@ -192,9 +195,11 @@ struct Residual { float value; float gx, gy, gz; };
 
 // residual(p) and d residual / d p for the local positions p of the wave's 64 points, instance weights w (wave-uniform).
 // NOT inlined: one copy per kernel keeps the residual kernels' code inside the instruction cache.
-__device__ __attribute__((noinline)) Residual residual_forward(const float* w_in, float px, float py, float pz) {
+// `tiles_in`: wave-uniform mask of the 16-point tiles to evaluate; lanes of the other tiles return 0.
+VSRD_RESIDUAL_FN Residual residual_forward(const float* w_in, float px, float py, float pz, unsigned tiles_in) {
     const int lane = lane_id();
     const int g = lane >> 4;
+    const unsigned tiles = __builtin_amdgcn_readfirstlane(tiles_in);
     const GlobalWeights w = uniform_weights(w_in);
     ForwardWeights fw;
     load_forward_weights(w, lane, fw);
@@ -204,6 +209,7 @@ __device__ __attribute__((noinline)) Residual residual_forward(const float* w_in
     float out_v = 0.0f, out_t0 = 0.0f, out_t1 = 0.0f, out_t2 = 0.0f;
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
+        if (!((tiles >> q) & 1u)) continue;
         TileFeatures e;
         encode_tile(from_row(f0, q, lane), from_row(f1, q, lane), from_row(f2, q, lane), g, e);
         TileJet z, n;
@@ -221,7 +227,7 @@ __device__ __attribute__((noinline)) Residual residual_forward(const float* w_in
         out_v = mine ? v : out_v; out_t0 = mine ? t0 : out_t0; out_t1 = mine ? t1 : out_t1; out_t2 = mine ? t2 : out_t2;
     }
     Residual r;
-    r.value = fast_rcp(1.0f + fast_exp(-(out_v - 1.0f)));
+    r.value = ((tiles >> g) & 1u) ? fast_rcp(1.0f + fast_exp(-(out_v - 1.0f))) : 0.0f;
     const float kappa = r.value * (1.0f - r.value) * inv;
     r.gx = kappa * out_t0 * fold; r.gy = kappa * out_t1; r.gz = kappa * out_t2;
     return r;
@@ -254,13 +260,17 @@ __device__ __forceinline__ void wave_lds_order() {
 }
 
 // Stage a tile (register j of lane (g, m) = X[4 g + j][m]) / fetch it transposed: lane (g, r) <- X[r][4 g + s], s = 0..3.
-__device__ __forceinline__ void stage_tile(float* tile, f32x4 x, int lane) {
-    float* dst = tile + (lane >> 4) * 4 * kTilePitch + (lane & 15);
+// LDS reached through a non-inlined call arrives as a generic pointer; typed back to the local address space so the accesses
+// are ds_read / ds_write, not flat_*.
+using LdsFloats = __attribute__((address_space(3))) float*;
+
+__device__ __forceinline__ void stage_tile(LdsFloats tile, f32x4 x, int lane) {
+    LdsFloats dst = tile + (lane >> 4) * 4 * kTilePitch + (lane & 15);
 #pragma unroll
     for (int j = 0; j < 4; ++j) dst[j * kTilePitch] = x[j];
 }
-__device__ __forceinline__ f32x4 fetch_tile(const float* tile, int lane) {
-    return *reinterpret_cast<const f32x4*>(tile + (lane & 15) * kTilePitch + (lane >> 4) * 4);
+__device__ __forceinline__ f32x4 fetch_tile(LdsFloats tile, int lane) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(tile + (lane & 15) * kTilePitch + (lane >> 4) * 4);
 }
 
 struct BackwardWeights {    // transposed A operands, lane (g, i = lane & 15)
@@ -370,12 +380,13 @@ struct ResidualAdjoint { float px, py, pz; };
 
 // Adjoint of residual_forward at the wave's local positions p: res_bar = dL/d residual, (gbx, gby, gbz) = dL/d(grad_p residual).
 // Adds dL/dw into `mlp_lds` (the wave's LDS: wbar [1617], then the transposition scratch); returns dL/dp per lane.
-__device__ __attribute__((noinline)) ResidualAdjoint residual_backward(const float* w_in, float px, float py, float pz,
-                                                                       float res_bar, float gbx, float gby, float gbz, float* mlp_lds, int lane) {
+VSRD_RESIDUAL_FN ResidualAdjoint residual_backward(const float* w_in, float px, float py, float pz,
+                                                                       float res_bar, float gbx, float gby, float gbz, float* mlp_lds, int lane, unsigned tiles_in) {
     const int g = lane >> 4, m = lane & 15;
+    const unsigned tiles = __builtin_amdgcn_readfirstlane(tiles_in);
     const GlobalWeights w = uniform_weights(w_in);
-    float* wbar = mlp_lds;
-    float* scratch = mlp_lds + kMlpWbarFloats;
+    const LdsFloats wbar = (LdsFloats)mlp_lds;
+    const LdsFloats scratch = wbar + kMlpWbarFloats;
     ForwardWeights fw;
     BackwardWeights bw;
     load_forward_weights(w, lane, fw);
@@ -392,6 +403,7 @@ __device__ __attribute__((noinline)) ResidualAdjoint residual_backward(const flo
     ResidualAdjoint mine = {0.0f, 0.0f, 0.0f};
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
+        if (!((tiles >> q) & 1u)) continue;
         const float tfold = from_row(fold, q, lane);
         const float folds[3] = {tfold, 1.0f, 1.0f};
         const float gb[3] = {from_row(gbx, q, lane), from_row(gby, q, lane), from_row(gbz, q, lane)};
