@@ -120,12 +120,17 @@ int rounds_for(int points) {
     return 0;
 }
 
-constexpr int kMaxBlocksResidual = 256;     // the residual kernels run one wave per SIMD: 256 CUs x 1 workgroup
+constexpr int kMaxBlocksResidual = 512;     // residual adjoint: one wave per SIMD resident; more workgroups than CUs = load balancing (each wave owns N x 1617 partials)
+
+// Residual jets (value + local gradient) the adjoint's forward sweep leaves for its per-instance phase: [wave][round <= 2][N][64] float4.
+size_t residual_cache_floats(int num_instances, bool residual) {
+    return residual ? static_cast<size_t>(kMaxBlocksResidual) * kMaxWavesPerBlock * 2 * num_instances * kWave * 4 : 0;
+}
 
 size_t partial_floats(int num_instances, bool residual) {
     const size_t box = static_cast<size_t>(kMaxBlocks) * kMaxWavesPerBlock * num_instances * kGradStride;
     const size_t mlp = residual ? static_cast<size_t>(kMaxBlocksResidual) * kMaxWavesPerBlock * num_instances * kMlpWeights : 0;
-    return box + mlp;
+    return box + mlp + residual_cache_floats(num_instances, residual);
 }
 
 }  // namespace
@@ -314,12 +319,13 @@ int32_t vsrd_render_backward(const vsrd_field* field, const vsrd_render_config* 
     c.sh.inv_t = f.inv_t;
     float* partials = static_cast<float*>(workspace);
     float* mlp_partials = partials + static_cast<size_t>(kMaxBlocks) * kMaxWavesPerBlock * row;
+    float4* residual_cache = reinterpret_cast<float4*>(mlp_partials + (residual ? static_cast<size_t>(kMaxBlocksResidual) * kMaxWavesPerBlock * mlp_row : 0));
 #define VSRD_LAUNCH(K, RES)                                                                                                    \
     fit_to_residency(render_backward_kernel<K, RES>, &g);                                                                        \
     if (residual && g.blocks > kMaxBlocksResidual) g.blocks = kMaxBlocksResidual;                                                \
     hipLaunchKernelGGL((render_backward_kernel<K, RES>), dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances,    \
                        field->mlp_weights, c, origins, directions, distances, num_distances, grad_labels, grad_gradients,         \
-                       grad_weights, partials, mlp_partials)
+                       grad_weights, partials, mlp_partials, residual_cache)
     const int rounds = rounds_for(num_distances - 1);
     if (residual) {
         switch (rounds) {

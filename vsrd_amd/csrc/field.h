@@ -81,18 +81,27 @@ __device__ __forceinline__ BoxEval eval_box(const Instance& in, float x, float y
 
 // Box (+ optional residual MLP) evaluation of instance i: d_i = box(p) + residual(p), local gradient likewise
 // (scripts/main.py:451-458).  `mlp` is the wave-uniform weight row of the instance.
+// d_i = box(p) + residual(p), local gradient likewise (scripts/main.py:451-458).
+__device__ __forceinline__ void add_residual(BoxEval& e, const Instance& in, const Residual& r) {
+    e.d += r.value;
+    e.glx += r.gx; e.gly += r.gy; e.glz += r.gz;
+    e.gwx = in.r00 * e.glx + in.r01 * e.gly + in.r02 * e.glz;
+    e.gwy = in.r10 * e.glx + in.r11 * e.gly + in.r12 * e.glz;
+    e.gwz = in.r20 * e.glx + in.r21 * e.gly + in.r22 * e.glz;
+}
+
+// Box (+ optional residual MLP) evaluation of instance i.  `mlp` is the wave-uniform weight row of the instance.
 // `tiles`: wave-uniform 4-bit mask of the 16-lane rows that need the residual (rows_with(ballot of un-culled lanes)); the lanes
 // of the other rows get residual 0 -- their soft-min weight is below exp(-tau) on the box distance alone (culling, below).
+// `keep`: where to leave the residual jet for the adjoint (render_backward_kernel caches it instead of re-evaluating the MLP).
 template <bool kResidual>
-__device__ __forceinline__ BoxEval eval_instance(const Instance& in, const float* __restrict__ mlp, float x, float y, float z, unsigned tiles = 0xFu) {
+__device__ __forceinline__ BoxEval eval_instance(const Instance& in, const float* __restrict__ mlp, float x, float y, float z, unsigned tiles = 0xFu,
+                                                 Residual* keep = nullptr) {
     BoxEval e = eval_box(in, x, y, z);
     if (kResidual) {
         const Residual r = residual_forward(mlp, e.px, e.py, e.pz, tiles);      // wave-cooperative: all 64 lanes active
-        e.d += r.value;
-        e.glx += r.gx; e.gly += r.gy; e.glz += r.gz;
-        e.gwx = in.r00 * e.glx + in.r01 * e.gly + in.r02 * e.glz;
-        e.gwy = in.r10 * e.glx + in.r11 * e.gly + in.r12 * e.glz;
-        e.gwz = in.r20 * e.glx + in.r21 * e.gly + in.r22 * e.glz;
+        add_residual(e, in, r);
+        if (keep) *keep = r;
     }
     return e;
 }

@@ -214,7 +214,7 @@ struct RayAdjoint {
 template <int kRounds, bool kResidual, bool kCacheD>
 __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, const float* __restrict__ instances, const float* __restrict__ mlp,
                                                        int N, const Shading& sh, const Ray& r, const float* dist, int num_points,
-                                                       const float* lam, float* dcache, int lane) {
+                                                       const float* lam, float* dcache, int lane, float4* rcache = nullptr) {
     const float inv_t = sh.inv_t;
     float label = 0.0f;
     float carry = 1.0f;
@@ -240,7 +240,9 @@ __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, 
                 if (kCacheD) dcache[i * kWave + lane] = lb;      // > thr on every lane: marks the instance as culled
                 continue;
             }
-            const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, st.sa[k].x, st.sa[k].y, st.sa[k].z, rows_with(near));
+            Residual res;
+            const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, st.sa[k].x, st.sa[k].y, st.sa[k].z, rows_with(near), &res);
+            if (kResidual && rcache) rcache[(k * N + i) * kWave + lane] = make_float4(res.value, res.gx, res.gy, res.gz);
             if (kCacheD) dcache[i * kWave + lane] = e.d;
             union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, inv_t);
         }
@@ -324,7 +326,8 @@ __device__ __forceinline__ bool adjoint_reverse_sweep(RayAdjoint<kRounds>& st, c
 // LDS rows G [N,16] / wbar [1617].
 template <int kRounds, bool kResidual>
 __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, const float* __restrict__ instances, const float* __restrict__ mlp,
-                                                int N, float inv_t, int num_points, const float* lam, float* G, float* wbar, float* my_mlp, int lane) {
+                                                int N, float inv_t, int num_points, const float* lam, float* G, float* wbar, float* my_mlp, int lane,
+                                                const float4* rcache) {
     for (int i = 0; i < N; ++i) {
         const Instance in = load_instance(instances, i);
         const float lam_i = lam[i];
@@ -345,7 +348,11 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
 #pragma unroll
         for (int k = 0; k < kRounds; ++k) {
             if (!active[k]) continue;
-            const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, st.sa[k].x, st.sa[k].y, st.sa[k].z, tiles[k]);
+            BoxEval e = eval_box(in, st.sa[k].x, st.sa[k].y, st.sa[k].z);
+            if (kResidual) {        // the residual jet of this (round, instance) was left by the forward sweep
+                const float4 res = rcache[(k * N + i) * kWave + lane];
+                add_residual(e, in, Residual{res.x, res.y, res.z, res.w});
+            }
             const float ds = e.d - st.sa[k].m;
             const float w = fast_exp(-ds * inv_t) * st.sa[k].inv_z;
             const float cc = w * (1.0f - (ds - st.sa[k].us) * inv_t);
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
     const float* __restrict__ origins, const float* __restrict__ directions,
     const float* __restrict__ distances, int num_distances,
     const float* __restrict__ grad_labels, const float* __restrict__ grad_gradients, const float* __restrict__ grad_weights,
-    float* __restrict__ partials, float* __restrict__ mlp_partials) {
+    float* __restrict__ partials, float* __restrict__ mlp_partials, float4* __restrict__ residual_cache) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = wave_in_block();
     const int lane = lane_id();
@@ -412,6 +419,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
     for (int idx = lane; idx < N * kGradStride; idx += kWave) G[idx] = 0.0f;
     const size_t wave_global0 = static_cast<size_t>(blockIdx.x) * waves_per_block() + wave;
     float* my_mlp = kResidual ? mlp_partials + wave_global0 * (static_cast<size_t>(N) * kMlpWeights) : nullptr;
+    float4* rcache = kResidual ? residual_cache + wave_global0 * (static_cast<size_t>(kRounds) * N * kWave) : nullptr;   // [round][instance][lane]
     if (kResidual) {
         for (int idx = lane; idx < N * kMlpWeights; idx += kWave) my_mlp[idx] = 0.0f;
         for (int idx = lane; idx < kMlpWeights; idx += kWave) wbar[idx] = 0.0f;
@@ -430,11 +438,11 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
         wave_lds_sync();
         if (dist[0] != dist[0]) continue;                            // NaN sentinel: ray skipped by the forward
         RayAdjoint<kRounds> st;
-        adjoint_forward_sweep<kRounds, kResidual, false>(st, instances, mlp, N, sh, r, dist, num_points, lam, nullptr, lane);
+        adjoint_forward_sweep<kRounds, kResidual, false>(st, instances, mlp, N, sh, r, dist, num_points, lam, nullptr, lane, rcache);
         const float* gw_row = grad_weights ? grad_weights + static_cast<size_t>(ray) * num_points : nullptr;
         const float* gg_row = grad_gradients ? grad_gradients + static_cast<size_t>(ray) * num_points * 3 : nullptr;
         if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, gw_row, gg_row, lane)) continue;      // exact zero adjoint
-        adjoint_phase_b<kRounds, kResidual>(st, instances, mlp, N, f.inv_t, num_points, lam, G, wbar, my_mlp, lane);
+        adjoint_phase_b<kRounds, kResidual>(st, instances, mlp, N, f.inv_t, num_points, lam, G, wbar, my_mlp, lane, rcache);
     }
     wave_lds_sync();
     float* out = partials + wave_global0 * (N * kGradStride);
@@ -570,7 +578,7 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
             st.sa[k].lam_z = acc * st.sa[k].inv_z;
         }
         if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, nullptr, nullptr, lane)) continue;
-        adjoint_phase_b<kRounds, false>(st, instances, nullptr, N, f.inv_t, num_points, lam, G, nullptr, nullptr, lane);
+        adjoint_phase_b<kRounds, false>(st, instances, nullptr, N, f.inv_t, num_points, lam, G, nullptr, nullptr, lane, nullptr);
     }
     wave_lds_sync();
     const size_t wave_global = static_cast<size_t>(blockIdx.x) * waves_per_block() + wave;
