@@ -157,15 +157,19 @@ __device__ __forceinline__ void first_layer_tile(const ForwardWeights& fw, const
 }
 
 // Linear(16 -> 16) on a tile jet.
-__device__ __forceinline__ void linear_tile(const float (&a)[4], f32x4 bias, const TileJet& in, TileJet& out) {
+__device__ __forceinline__ void linear_tile(const float (&a)[4], f32x4 bias, f32x4 in_v, f32x4 in_t0, f32x4 in_t1, f32x4 in_t2, TileJet& out) {
     out.v = bias;
     out.t[0] = out.t[1] = out.t[2] = splat4(0.0f);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        out.v = mfma4(a[s], in.v[s], out.v);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) out.t[c] = mfma4(a[s], in.t[c][s], out.t[c]);
+        out.v = mfma4(a[s], in_v[s], out.v);
+        out.t[0] = mfma4(a[s], in_t0[s], out.t[0]);
+        out.t[1] = mfma4(a[s], in_t1[s], out.t[1]);
+        out.t[2] = mfma4(a[s], in_t2[s], out.t[2]);
     }
+}
+__device__ __forceinline__ void linear_tile(const float (&a)[4], f32x4 bias, const TileJet& in, TileJet& out) {
+    linear_tile(a, bias, in.v, in.t[0], in.t[1], in.t[2], out);
 }
 
 // LayerNorm (no affine) followed by exact GELU on a tile jet, in place.
@@ -293,9 +297,10 @@ __device__ __forceinline__ void load_backward_weights(GlobalWeights w, int lane,
 // What the adjoint of one [LayerNorm -> GELU] needs, recomputed from the block's input jet.
 struct TileState {
     f32x4 y, g1, g2, a;         // normalised value, GELU', pdf(y)(2 - y^2), activation
-    f32x4 dy[3], da[3];
+    f32x4 dy[3];                // tangents of y; the activation tangents are dy * g1
     float q[3];                 // mean(y * dz_c)
     float inv_s;
+    __device__ __forceinline__ f32x4 da(int c) const { return dy[c] * g1; }
 };
 
 __device__ __forceinline__ void tile_state(const TileJet& z, TileState& b) {
@@ -320,7 +325,6 @@ __device__ __forceinline__ void tile_state(const TileJet& z, TileState& b) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             b.dy[c][j] = (z.t[c][j] - tmean[c] - y * b.q[c]) * b.inv_s;
-            b.da[c][j] = b.dy[c][j] * b.g1[j];
         }
     }
 }
@@ -332,37 +336,35 @@ __device__ __forceinline__ void layer_norm_adjoint_tile(f32x4& v, const TileStat
     v = (v - splat4(m) - b.y * splat4(my)) * splat4(b.inv_s);
 }
 
-// Adjoint of [LayerNorm -> GELU] on a jet: (a_bar, da_bar) of the activations -> adjoint of the block's input jet z_in.
-__device__ __forceinline__ void gelu_norm_adjoint_tile(const TileState& b, const TileJet& z_in, f32x4 a_bar, const f32x4 (&da_bar)[3], TileJet& zb) {
+// Adjoint of [LayerNorm -> GELU] on a jet: (a_bar, da_bar) of the activations -> adjoint zb of the block's input jet.
+// With P the LayerNorm Jacobian above, P(dz_c) = dy_c, so the input tangents themselves are not needed:
+//   z_bar = P(y_bar - sum_c dyb_c q_c / s) - sum_c dy_c mean(dyb_c y) / s + y s_bar / 16,   dz_bar_c = P(dyb_c).
+__device__ __forceinline__ void gelu_norm_adjoint_tile(const TileState& b, f32x4 a_bar, const f32x4 (&da_bar)[3], TileJet& zb) {
     f32x4 y_bar, dyb[3];
     float s_part = 0.0f, dot_part[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        float cross = 0.0f;
+        float cross = 0.0f, through_q = 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             cross += da_bar[c][j] * b.dy[c][j];
             dyb[c][j] = da_bar[c][j] * b.g1[j];
             s_part -= dyb[c][j] * b.dy[c][j];
             dot_part[c] += dyb[c][j] * b.y[j];
+            through_q += dyb[c][j] * b.q[c];
         }
-        y_bar[j] = a_bar[j] * b.g1[j] + cross * b.g2[j];
+        y_bar[j] = a_bar[j] * b.g1[j] + cross * b.g2[j] - through_q * b.inv_s;
     }
     const float s_bar = rows_sum(s_part) * b.inv_s;
     float dot[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) dot[c] = rows_sum(dot_part[c]) * (1.0f / kMlpHidden);
-    // explicit dependence of dy on (y, s), then through y = (z - mean) / s
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) y_bar[j] -= (dyb[c][j] * b.q[c] + z_in.t[c][j] * dot[c]) * b.inv_s;
+    for (int c = 0; c < 3; ++c) dot[c] = rows_sum(dot_part[c]) * (b.inv_s * (1.0f / kMlpHidden));
     layer_norm_adjoint_tile(y_bar, b);
 #pragma unroll
     for (int c = 0; c < 3; ++c) layer_norm_adjoint_tile(dyb[c], b);
     zb.v = y_bar + b.y * splat4(s_bar * (1.0f / kMlpHidden));
 #pragma unroll
-    for (int c = 0; c < 3; ++c) zb.t[c] = dyb[c];
+    for (int c = 0; c < 3; ++c) { zb.v -= b.dy[c] * splat4(dot[c]); zb.t[c] = dyb[c]; }
 }
 
 // Sum over the 16 lanes of each row (every lane of the row receives it).
@@ -410,21 +412,22 @@ VSRD_RESIDUAL_FN ResidualAdjoint residual_backward(const float* w_in, float px, 
         const float t_res_bar = from_row(res_bar, q, lane);
         TileFeatures e;
         encode_tile(from_row(f0, q, lane), from_row(f1, q, lane), from_row(f2, q, lane), g, e);
-        // ---- forward, keeping the pre-norm jets z[0..3] ------------------------------------------------------------------
-        TileJet z[4];
-        first_layer_tile(fw, e, z[0]);
+        // ---- forward, keeping the [LayerNorm -> GELU] state of every layer ----------------------------------------------------
+        TileState st[4];
+        {
+            TileJet z;
+            first_layer_tile(fw, e, z);
 #pragma unroll
-        for (int l = 0; l < 3; ++l) {
-            TileJet a = z[l];
-            norm_gelu_tile(a);
-            linear_tile(fw.a[l], fw.b[l], a, z[l + 1]);
+            for (int l = 0; l < 3; ++l) {
+                tile_state(z, st[l]);
+                linear_tile(fw.a[l], fw.b[l], st[l].a, st[l].da(0), st[l].da(1), st[l].da(2), z);
+            }
+            tile_state(z, st[3]);
         }
-        TileState st;
-        tile_state(z[3], st);
-        const float out_v = rows_sum(dot4(fw.w4, st.a)) + fw.b4;
+        const float out_v = rows_sum(dot4(fw.w4, st[3].a)) + fw.b4;
         float out_t[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) out_t[c] = rows_sum(dot4(fw.w4, st.da[c]));
+        for (int c = 0; c < 3; ++c) out_t[c] = rows_sum(dot4(fw.w4, st[3].da(c)));
         // ---- sigmoid head ---------------------------------------------------------------------------------------------------
         const float res = fast_rcp(1.0f + fast_exp(-(out_v - 1.0f)));
         const float kappa = res * (1.0f - res);
@@ -438,24 +441,23 @@ VSRD_RESIDUAL_FN ResidualAdjoint residual_backward(const float* w_in, float px, 
         // ---- block 4: LayerNorm -> GELU -> Linear(16 -> 1) -----------------------------------------------------------------
         TileJet zb;
         {
-            acc_w4 += splat4(zb_v) * st.a;
+            acc_w4 += splat4(zb_v) * st[3].a;
             f32x4 da_bar[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { acc_w4 += splat4(zb_t[c]) * st.da[c]; da_bar[c] = fw.w4 * splat4(zb_t[c]); }
+            for (int c = 0; c < 3; ++c) { acc_w4 += splat4(zb_t[c]) * st[3].da(c); da_bar[c] = fw.w4 * splat4(zb_t[c]); }
             acc_b4 += zb_v;
-            gelu_norm_adjoint_tile(st, z[3], fw.w4 * splat4(zb_v), da_bar, zb);
+            gelu_norm_adjoint_tile(st[3], fw.w4 * splat4(zb_v), da_bar, zb);
         }
-        // ---- blocks 3..1: LayerNorm -> GELU -> Linear(16 -> 16); zb is the adjoint of z[l + 1] -----------------------------
+        // ---- blocks 3..1: LayerNorm -> GELU -> Linear(16 -> 16); zb is the adjoint of the linear's output ------------------
 #pragma unroll
         for (int l = 2; l >= 0; --l) {
-            tile_state(z[l], st);
             acc_b[l] += zb.v;
             stage_tile(scratch + 0 * kTileFloats, zb.v, lane);
-            stage_tile(scratch + 1 * kTileFloats, st.a, lane);
+            stage_tile(scratch + 1 * kTileFloats, st[l].a, lane);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 stage_tile(scratch + (2 + 2 * c) * kTileFloats, zb.t[c], lane);
-                stage_tile(scratch + (3 + 2 * c) * kTileFloats, st.da[c], lane);
+                stage_tile(scratch + (3 + 2 * c) * kTileFloats, st[l].da(c), lane);
             }
             wave_lds_order();
 #pragma unroll
@@ -473,7 +475,7 @@ VSRD_RESIDUAL_FN ResidualAdjoint residual_backward(const float* w_in, float px, 
                 for (int c = 0; c < 3; ++c) da_bar[c] = mfma4(bw.at[l][s], zb.t[c][s], da_bar[c]);
             }
             TileJet zin_bar;
-            gelu_norm_adjoint_tile(st, z[l], a_bar, da_bar, zin_bar);
+            gelu_norm_adjoint_tile(st[l], a_bar, da_bar, zin_bar);
             zb = zin_bar;
         }
         // ---- first layer + encoder; zb is the adjoint of z[0] -----------------------------------------------------------------
