@@ -345,6 +345,7 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
         if (!any_active) continue;                                            // negligible for this ray (field.h culling)
         float at0 = 0, at1 = 0, at2 = 0, ad0 = 0, ad1 = 0, ad2 = 0;
         float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
+        float seed[kRounds][10];
 #pragma unroll
         for (int k = 0; k < kRounds; ++k) {
             if (!active[k]) continue;
@@ -373,11 +374,12 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
             const float qbx = d_bar * e.hx + ((e.qx > 0.0f) ? (vx - hx * hv) * inv_n : 0.0f);
             const float qby = d_bar * e.hy + ((e.qy > 0.0f) ? (vy - hy * hv) * inv_n : 0.0f);
             const float qbz = d_bar * e.hz + ((e.qz > 0.0f) ? (vz - hz * hv) * inv_n : 0.0f);
-            float pbx = sx * qbx, pby = sy * qby, pbz = sz * qbz;
+            const float pbx = sx * qbx, pby = sy * qby, pbz = sz * qbz;
             ad0 -= qbx; ad1 -= qby; ad2 -= qbz;
-            if (kResidual) {        // residual(p): value adjoint d_bar, local-gradient adjoint gl_bar (main.py:451-458)
-                const ResidualAdjoint ra = residual_backward(mlp + i * kMlpWeights, e.px, e.py, e.pz, d_bar, glbx, glby, glbz, wbar, lane, tiles[k]);
-                pbx += ra.px; pby += ra.py; pbz += ra.pz;
+            if (kResidual) {        // seeds of the residual adjoint: value adjoint d_bar, local-gradient adjoint gl_bar (main.py:451-458)
+                seed[k][0] = e.px; seed[k][1] = e.py; seed[k][2] = e.pz; seed[k][3] = d_bar;
+                seed[k][4] = glbx; seed[k][5] = glby; seed[k][6] = glbz;
+                seed[k][7] = e.relx; seed[k][8] = e.rely; seed[k][9] = e.relz;
             }
             r00 += e.relx * pbx + gwbx * e.glx; r01 += e.relx * pby + gwbx * e.gly; r02 += e.relx * pbz + gwbx * e.glz;
             r10 += e.rely * pbx + gwby * e.glx; r11 += e.rely * pby + gwby * e.gly; r12 += e.rely * pbz + gwby * e.glz;
@@ -385,6 +387,32 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
             at0 -= in.r00 * pbx + in.r01 * pby + in.r02 * pbz;
             at1 -= in.r10 * pbx + in.r11 * pby + in.r12 * pbz;
             at2 -= in.r20 * pbx + in.r21 * pby + in.r22 * pbz;
+        }
+        if (kResidual) {
+            // ONE call site for the MLP adjoint: a rolled loop over the rounds picks the round's seeds with selects.  Its result only
+            // adds the local-position adjoint p_bar to the terms above (they are linear in p_bar).
+#pragma unroll 1
+            for (int k = 0; k < kRounds; ++k) {
+                float sd[10];
+                bool on = false;
+                unsigned rows = 0u;
+#pragma unroll
+                for (int kk = 0; kk < kRounds; ++kk) {
+                    if (kk == k) {
+                        on = active[kk]; rows = tiles[kk];
+#pragma unroll
+                        for (int v = 0; v < 10; ++v) sd[v] = seed[kk][v];
+                    }
+                }
+                if (!on) continue;
+                const ResidualAdjoint ra = residual_backward(mlp + i * kMlpWeights, sd[0], sd[1], sd[2], sd[3], sd[4], sd[5], sd[6], wbar, lane, rows);
+                r00 += sd[7] * ra.px; r01 += sd[7] * ra.py; r02 += sd[7] * ra.pz;
+                r10 += sd[8] * ra.px; r11 += sd[8] * ra.py; r12 += sd[8] * ra.pz;
+                r20 += sd[9] * ra.px; r21 += sd[9] * ra.py; r22 += sd[9] * ra.pz;
+                at0 -= in.r00 * ra.px + in.r01 * ra.py + in.r02 * ra.pz;
+                at1 -= in.r10 * ra.px + in.r11 * ra.py + in.r12 * ra.pz;
+                at2 -= in.r20 * ra.px + in.r21 * ra.py + in.r22 * ra.pz;
+            }
         }
         // one reduce-scatter butterfly: lane j (< 16) receives parameter j of instance i and keeps it in its LDS slot
         const float packed[16] = {at0, at1, at2, r00, r01, r02, r10, r11, r12, r20, r21, r22, ad0, ad1, ad2, 0.0f};
