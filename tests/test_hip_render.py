@@ -357,6 +357,44 @@ def test_culling_is_invisible(dev, name):
         assert (a - b).abs().max() <= 1e-4 * max(float(b.abs().max()), 1e-6)
 
 
+def test_residual_tile_culling_is_invisible(dev):
+    """Residual fields are culled per 16-point tile (the MLP is skipped for rows of lanes whose soft-min weight is below exp(-18) on
+    the box distance alone): labels, box-parameter and MLP-weight gradients must not change against evaluating everything.
+    A street-like scene (8 instances spread over 8-60 m, late schedule) makes most tiles of most rays culled."""
+    import bench
+    from vsrd_amd import fields, models, rendering
+    from vsrd_amd.rendering import renderers
+    V, H, W, N, S = 1, 24, 176, 8, 64
+    K, E, raw_loc, raw_dim, raw_ori = bench.synthetic_frame(0, V, H, W, N)
+    det = models.BoxParameters3D(1, N)
+    with torch.no_grad():
+        det.locations.copy_(raw_loc); det.dimensions.copy_(raw_dim); det.orientations.copy_(raw_ori)
+        boxes = det()
+    cam, dirs = rendering.ray_casting((H, W), K.to(dev), E.to(dev))
+    origins = cam[:, None, None, :].expand(V, H, W, 3).reshape(-1, 3).contiguous()
+    dirs = dirs.reshape(-1, 3)[H * W // 3:]                   # rows through the objects
+    origins = origins[H * W // 3:]
+    gen = torch.Generator().manual_seed(5)
+    results = {}
+    for culling in (True, False):
+        renderers.CULLING = culling
+        try:
+            inst = fields.pack_instances(boxes["locations"][0], boxes["orientations"][0], boxes["dimensions"][0]).to(dev).requires_grad_(True)
+            mlp = (torch.randn(N, 1617, generator=torch.Generator().manual_seed(6)) * 0.3).to(dev).requires_grad_(True)
+            block = fields.FieldBlock(inst, 0.15, mlp, None)
+            out = rendering.render_hierarchical(block, origins, dirs, (0.0, 100.0), S, 0.15, 0.9, seed=3, return_gradients=True)
+            lam = torch.randn(out["labels"].shape, generator=torch.Generator().manual_seed(2)).to(dev)
+            hit = out["labels"].detach().sum(-1) > 0.5
+            loss = (out["labels"] * lam).sum() + 0.01 * ((out["gradients"][hit].norm(dim=-1) - 1.0) ** 2).mean()
+            results[culling] = (out["labels"].detach(), torch.autograd.grad(loss, (inst, mlp)), int(hit.sum()))
+        finally:
+            renderers.CULLING = True
+    assert results[True][2] > 100
+    assert (results[True][0] - results[False][0]).abs().max() < 1e-6
+    for a, b in zip(results[True][1], results[False][1]):
+        assert (a - b).abs().max() <= 2e-4 * max(float(b.abs().max()), 1e-6)
+
+
 def test_single_origin_and_leading_dims(dev):
     """main.py:1011-1026 renders image rows with a [3] camera position and [W,3] directions."""
     from vsrd_amd import rendering
