@@ -80,6 +80,18 @@ const char* vsrd_error_string(int32_t code);
 /* Bytes of scratch vsrd_render_backward needs for a field of N instances (residual != 0: with per-instance MLP). */
 size_t vsrd_workspace_bytes(int32_t num_instances, int32_t residual);
 
+/* Hungarian matching of predicted to ground-truth 2-D boxes of the target view (scripts/main.py:374-386:
+ * scipy.optimize.linear_sum_assignment(-torchvision.ops.distance_box_iou(pd, gt).cpu())), on the device -- no host
+ * synchronisation, capturable in a hipGraph.  pd_boxes [P,4], gt_boxes [G,4] (x1,y1,x2,y2), 1 <= P,G <= 64.
+ * pd_indices / gt_indices [min(P,G)] (int64): the matched pairs ordered by pd index, exactly what scipy returns
+ * (same shortest-augmenting-path algorithm, float64 duals, same tie rule). */
+int32_t vsrd_match_boxes(const float* pd_boxes, const float* gt_boxes, int32_t num_pd, int32_t num_gt,
+                         int64_t* pd_indices, int64_t* gt_indices, void* stream);
+
+/* The assignment alone on a given cost matrix [P,G] (float32, row-major): scipy.optimize.linear_sum_assignment(cost). */
+int32_t vsrd_linear_sum_assignment(const float* cost, int32_t num_rows, int32_t num_cols,
+                                   int64_t* row_indices, int64_t* col_indices, void* stream);
+
 /* vsrd.rendering.ray_casting (vsrd/rendering/utils.py:5-18), the per-pixel part:
  * directions[v,y,x,:] = normalize(inverse_projection[v] @ (x, y, 1)), integer pixel centres.
  * inverse_projection [V,9] = inv(E)[:3,:3] @ inv(K) (row-major), computed by the caller. */

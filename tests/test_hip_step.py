@@ -151,11 +151,12 @@ def test_five_optimisation_steps_match_oracle(dev):
     assert torch.isfinite(losses_free["loss"])
 
 
-def test_residual_phase_step_matches_oracle(dev):
+@pytest.mark.parametrize("S", [32, 100])          # 100 = the reference's own samples per ray (config.json:236): 199 points, 4 rounds
+def test_residual_phase_step_matches_oracle(dev, S):
     """Post-warm-up step (config 3 shape): hypernetwork -> per-instance MLP weights -> residual field + eikonal loss, gradients
     into boxes, embeddings and hypernetwork, against the CPU oracle step with identical weights and randomness."""
     from vsrd_amd import optimization, rendering, fields
-    V, H, W, N, S, R = 3, 128, 128, 4, 32, 256
+    V, H, W, N, R = 3, 128, 128, 4, 256
     K, E, (loc, dim, rot), gt_boxes, visible = c1_frame()
     cam, dirs = rendering.ray_casting((H, W), K.to(dev), E.to(dev))
     block = fields.FieldBlock(fields.pack_instances(loc.to(dev), rot.to(dev), dim.to(dev)), 0.1, None, None)
@@ -196,6 +197,34 @@ def test_residual_phase_step_matches_oracle(dev):
     assert (ge - emb_cpu.grad).abs().max() <= 2e-2 * float(emb_cpu.grad.abs().max())
     for pd, pc in zip(device_loop.hyper_distance_field.parameters(), hyper_cpu.parameters()):
         assert (pd.grad.cpu() - pc.grad).abs().max() <= 2e-2 * max(float(pc.grad.abs().max()), 1e-8)
+
+
+def test_device_hungarian_matches_scipy(dev):
+    """a15: scipy.optimize.linear_sum_assignment (the reference's matcher, main.py:383) against the single-wave device solver:
+    random rectangular float costs, integer costs full of ties, constant matrices (scipy's reversed scan order makes those the
+    identity), and the DIoU cost of box sets incl. identical boxes."""
+    from scipy.optimize import linear_sum_assignment
+    from vsrd_amd import losses
+    gen = torch.Generator().manual_seed(0)
+    cases = []
+    for P, G in [(1, 1), (4, 4), (8, 8), (16, 16), (64, 64), (5, 9), (9, 5), (64, 17), (3, 64), (33, 32)]:
+        cases.append(torch.randn(P, G, generator=gen))
+        cases.append(torch.randint(0, 4, (P, G), generator=gen).float())            # many ties
+        cases.append(torch.zeros(P, G))                                             # all ties
+    for cost in cases:
+        rows, cols = losses.linear_sum_assignment(cost.to(dev))
+        want_rows, want_cols = linear_sum_assignment(cost.numpy())
+        assert rows.cpu().tolist() == want_rows.tolist() and cols.cpu().tolist() == want_cols.tolist(), cost.shape
+    for P, G in [(8, 8), (16, 12), (7, 16)]:
+        centres = torch.rand(max(P, G), 2, generator=gen) * 800
+        sizes = torch.rand(max(P, G), 2, generator=gen) * 100 + 10
+        boxes = torch.cat([centres - sizes / 2, centres + sizes / 2], -1)
+        pd = boxes[:P] + torch.randn(P, 4, generator=gen) * 5
+        gt = boxes[torch.randperm(max(P, G), generator=gen)][:G]
+        pd[-1] = pd[0]                                                              # identical predictions (degenerate start, main.py:309)
+        got = losses.match_instances(pd.to(dev).reshape(P, 2, 2), gt.to(dev).reshape(G, 2, 2))
+        want = linear_sum_assignment((-losses.distance_box_iou(pd, gt)).numpy())
+        assert got[0].cpu().tolist() == want[0].tolist() and got[1].cpu().tolist() == want[1].tolist()
 
 
 def test_soft_rasterizer_g11(dev):

@@ -79,6 +79,8 @@ SIGNATURES = {
     "vsrd_project_boxes_forward": (ctypes.c_int32, [c_float_p, c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                                     ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
                                                     c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "vsrd_match_boxes": (ctypes.c_int32, [c_float_p, c_float_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "vsrd_linear_sum_assignment": (ctypes.c_int32, [c_float_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "vsrd_project_boxes_backward": (ctypes.c_int32, [c_float_p, c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                                      ctypes.c_int32, ctypes.c_float, c_float_p, ctypes.c_void_p, c_float_p,
                                                      ctypes.c_void_p]),

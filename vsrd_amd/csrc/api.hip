@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include "../../include/vsrd_hip.h"
 #include "aux_kernels.h"
+#include "matching.h"
 #include "projection.h"
 
 namespace {
@@ -122,9 +123,9 @@ int rounds_for(int points) {
 
 constexpr int kMaxBlocksResidual = 512;     // residual adjoint: one wave per SIMD resident; more workgroups than CUs = load balancing (each wave owns N x 1617 partials)
 
-// Residual jets (value + local gradient) the adjoint's forward sweep leaves for its per-instance phase: [wave][round <= 2][N][64] float4.
+// Residual jets (value + local gradient) the adjoint's forward sweep leaves for its per-instance phase: [wave][round <= 4][N][64] float4.
 size_t residual_cache_floats(int num_instances, bool residual) {
-    return residual ? static_cast<size_t>(kMaxBlocksResidual) * kMaxWavesPerBlock * 2 * num_instances * kWave * 4 : 0;
+    return residual ? static_cast<size_t>(kMaxBlocksResidual) * kMaxWavesPerBlock * 4 * num_instances * kWave * 4 : 0;
 }
 
 size_t partial_floats(int num_instances, bool residual) {
@@ -331,6 +332,7 @@ int32_t vsrd_render_backward(const vsrd_field* field, const vsrd_render_config* 
         switch (rounds) {
             case 1: VSRD_LAUNCH(1, true); break;
             case 2: VSRD_LAUNCH(2, true); break;
+            case 4: VSRD_LAUNCH(4, true); break;
             default: return VSRD_E_UNSUPPORTED;
         }
     } else {
@@ -472,6 +474,21 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
     if (launch_status() != VSRD_OK) return VSRD_E_LAUNCH;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(row), dim3(256), 0, s, partials, num_waves, row, grad_instances);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, loss_partials, num_waves, 1, loss);
+    return launch_status();
+}
+
+int32_t vsrd_match_boxes(const float* pd_boxes, const float* gt_boxes, int32_t num_pd, int32_t num_gt,
+                         int64_t* pd_indices, int64_t* gt_indices, void* stream) {
+    if (!pd_boxes || !gt_boxes || !pd_indices || !gt_indices || num_pd < 1 || num_gt < 1 || num_pd > 64 || num_gt > 64) return VSRD_E_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(match_kernel, dim3(1), dim3(kWave), 0, static_cast<hipStream_t>(stream), nullptr, pd_boxes, gt_boxes, num_pd, num_gt,
+                       reinterpret_cast<long long*>(pd_indices), reinterpret_cast<long long*>(gt_indices));
+    return launch_status();
+}
+
+int32_t vsrd_linear_sum_assignment(const float* cost, int32_t num_rows, int32_t num_cols, int64_t* row_indices, int64_t* col_indices, void* stream) {
+    if (!cost || !row_indices || !col_indices || num_rows < 1 || num_cols < 1 || num_rows > 64 || num_cols > 64) return VSRD_E_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(match_kernel, dim3(1), dim3(kWave), 0, static_cast<hipStream_t>(stream), cost, nullptr, nullptr, num_rows, num_cols,
+                       reinterpret_cast<long long*>(row_indices), reinterpret_cast<long long*>(col_indices));
     return launch_status();
 }
 

@@ -53,12 +53,32 @@ def distance_box_iou_loss(boxes1, boxes2, eps=1e-7):
     return 1 - inter / (union + eps) + centres / diagonal
 
 
+def linear_sum_assignment(cost):
+    """scipy.optimize.linear_sum_assignment(cost) for a device matrix [P,G] (P, G <= 64) without leaving the device
+    (vsrd_linear_sum_assignment: the same shortest-augmenting-path algorithm and tie rule, float64 duals)."""
+    from . import _lib
+    lib = _lib.load()
+    cost = cost.detach().to(torch.float32).contiguous()
+    P, G = cost.shape
+    rows = torch.empty(min(P, G), dtype=torch.int64, device=cost.device)
+    cols = torch.empty_like(rows)
+    _lib.check(lib.vsrd_linear_sum_assignment(_lib.ptr(cost), P, G, rows.data_ptr(), cols.data_ptr(), _lib.stream()))
+    return rows, cols
+
+
 def match_instances(pd_boxes_2d, gt_boxes_2d):
-    """main.py:374-386: Hungarian assignment on -DIoU of the target view (host side, like the reference: one D2H sync)."""
-    from scipy.optimize import linear_sum_assignment
-    cost = -distance_box_iou(pd_boxes_2d, gt_boxes_2d)
-    pd_idx, gt_idx = linear_sum_assignment(cost.detach().cpu().numpy())
-    return torch.as_tensor(pd_idx, device=pd_boxes_2d.device), torch.as_tensor(gt_idx, device=pd_boxes_2d.device)
+    """main.py:374-386: Hungarian assignment on -DIoU of the target view.  The reference copies the cost matrix to the host for
+    scipy (one synchronisation per step); here both the cost and the assignment stay on the device (vsrd_match_boxes), so the
+    optimisation step has no host round trip and can be captured in a hipGraph."""
+    from . import _lib
+    lib = _lib.load()
+    pd = pd_boxes_2d.detach().reshape(-1, 4).to(torch.float32).contiguous()
+    gt = gt_boxes_2d.detach().reshape(-1, 4).to(torch.float32).contiguous()
+    P, G = pd.shape[0], gt.shape[0]
+    pd_idx = torch.empty(min(P, G), dtype=torch.int64, device=pd.device)
+    gt_idx = torch.empty_like(pd_idx)
+    _lib.check(lib.vsrd_match_boxes(_lib.ptr(pd), _lib.ptr(gt), P, G, pd_idx.data_ptr(), gt_idx.data_ptr(), _lib.stream()))
+    return pd_idx, gt_idx
 
 
 def projection_losses(pd_boxes_2d, gt_boxes_2d, visible_masks, pd_idx, gt_idx):

@@ -20,6 +20,17 @@ def yaw_matrix(cos, sin):
     return torch.stack(rows, -2)
 
 
+_corner_cache = {}
+
+
+def _unit_corners(like):
+    """The 8 unit corners on `like`'s device, uploaded once (a host-to-device copy per call would also break graph capture)."""
+    key = (like.device, like.dtype)
+    if key not in _corner_cache:
+        _corner_cache[key] = torch.tensor(_UNIT_CORNERS, dtype=like.dtype, device=like.device)
+    return _corner_cache[key]
+
+
 class BoxParameters3D(nn.Module):
     """Raw per-instance parameters -> boxes.  Same parameter names, ranges and initial values as the reference."""
 
@@ -46,7 +57,7 @@ class BoxParameters3D(nn.Module):
 
     @staticmethod
     def decode_box_3d(locations, dimensions, orientations):
-        corners = dimensions.new_tensor(_UNIT_CORNERS) * dimensions.unsqueeze(-2)
+        corners = _unit_corners(dimensions) * dimensions.unsqueeze(-2)
         return corners @ orientations.transpose(-2, -1) + locations.unsqueeze(-2)
 
     @staticmethod
