@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VSRD_ABI_VERSION 1
+#define VSRD_ABI_VERSION 2
 
 #define VSRD_OK 0
 #define VSRD_E_INVALID_ARGUMENT (-1) /* null pointer, non-positive size, unsupported N / S */
@@ -64,6 +64,11 @@ typedef struct vsrd_render_config {
     uint64_t seed;              /* Philox key when uniforms are generated in-kernel         */
     uint64_t stream_offset;     /* Philox counter offset (step index)                       */
     uint32_t flags;             /* VSRD_FLAG_*                                              */
+    /* Optional, DEVICE memory: per-step values that a captured hipGraph must not freeze in its kernel arguments.  When set, the
+     * render kernels read them at start and use them INSTEAD of the by-value fields above / field->temperature
+     * (the annealing schedules of scripts/main.py:420-431 and the Philox counter of the step). */
+    const float* device_schedule;          /* [3] = soft-min temperature, sdf_std_deviation, cosine_ratio; or NULL */
+    const uint64_t* device_stream_offset;  /* [1] replaces stream_offset; or NULL                                   */
 } vsrd_render_config;
 
 #define VSRD_FLAG_FINE_UNIFORMS_SORTED 1u /* u_fine is already sorted ascending per ray     */
@@ -91,6 +96,15 @@ int32_t vsrd_match_boxes(const float* pd_boxes, const float* gt_boxes, int32_t n
 /* The assignment alone on a given cost matrix [P,G] (float32, row-major): scipy.optimize.linear_sum_assignment(cost). */
 int32_t vsrd_linear_sum_assignment(const float* cost, int32_t num_rows, int32_t num_cols,
                                    int64_t* row_indices, int64_t* col_indices, void* stream);
+
+/* Importance sampling of rays (scripts/main.py:620-627: torch.multinomial(weights, num_rays, replacement=False)): num_samples
+ * (<= 2048) distinct indices with probability proportional to weights [count] (>= 0), by ATen's own algorithm (exponential race,
+ * keep the largest keys) with Philox4x32-10 keyed by (seed, stream_offset; index); deterministic in its arguments.
+ * device_stream_offset (device memory, may be NULL) replaces stream_offset (hipGraph replay).  Needs vsrd_sample_rays_workspace_bytes()
+ * of scratch.  indices [num_samples] int64, best key first; -1 fills the tail when fewer than num_samples weights are positive. */
+size_t vsrd_sample_rays_workspace_bytes(void);
+int32_t vsrd_sample_rays(const float* weights, int64_t count, int32_t num_samples, uint64_t seed, uint64_t stream_offset,
+                         const uint64_t* device_stream_offset, void* workspace, size_t workspace_bytes, int64_t* indices, void* stream);
 
 /* vsrd.rendering.ray_casting (vsrd/rendering/utils.py:5-18), the per-pixel part:
  * directions[v,y,x,:] = normalize(inverse_projection[v] @ (x, y, 1)), integer pixel centres.

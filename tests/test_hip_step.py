@@ -241,3 +241,98 @@ def test_soft_rasterizer_g11(dev):
     soft = transforms.soft_masks(polys, inside, float(g["temperature"]))
     for k in range(3):
         torch.testing.assert_close(soft[k].cpu(), g[f"soft_{k}"], rtol=1e-5, atol=1e-5)
+
+
+def test_ray_sampler_matches_multinomial_statistics(dev):
+    """a17: vsrd_sample_rays against torch.multinomial(weights, k, replacement=False): distinct indices, only positive weights,
+    deterministic in (seed, step), different across steps, and the same inclusion frequencies (exponential race = ATen's algorithm)."""
+    from vsrd_amd import rendering
+    gen = torch.Generator().manual_seed(0)
+    M, k, draws = 512, 64, 600
+    weights = torch.rand(M, generator=gen) ** 3
+    weights[torch.rand(M, generator=gen) < 0.3] = 0.0
+    w = weights.to(dev)
+    first = rendering.sample_rays(w, k, seed=7, stream_offset=0)
+    assert first.unique().numel() == k and bool((weights[first.cpu()] > 0).all())
+    assert torch.equal(first, rendering.sample_rays(w, k, seed=7, stream_offset=0))
+    assert not torch.equal(first, rendering.sample_rays(w, k, seed=7, stream_offset=1))
+    step = torch.zeros(1, dtype=torch.int64, device=dev)
+    assert torch.equal(first, rendering.sample_rays(w, k, seed=7, stream_offset=step))          # counter read on the device
+    ours, theirs = torch.zeros(M), torch.zeros(M)
+    torch.manual_seed(0)
+    for d in range(draws):
+        ours[rendering.sample_rays(w, k, seed=3, stream_offset=d).cpu()] += 1
+        theirs[torch.multinomial(w, k, replacement=False).cpu()] += 1
+    ours, theirs = ours / draws, theirs / draws
+    assert float((ours[weights == 0]).max()) == 0.0
+    sigma = (theirs * (1 - theirs) / draws).clamp_min(1e-4).sqrt()
+    assert float(((ours - theirs).abs() / sigma).max()) < 6.0                                     # two independent estimates: sqrt(2) sigma each
+    assert abs(float(ours.sum()) - k) < 1e-3
+    # a frame-sized problem: 2.6M weights, mostly empty, k = 1000 (the reference's num_rays)
+    big = (torch.rand(5 * 376 * 1408, generator=gen) - 0.6).clamp_min(0).to(dev)
+    idx = rendering.sample_rays(big, 1000, seed=1, stream_offset=5)
+    assert idx.unique().numel() == 1000 and bool((big[idx] > 0).all())
+    # fewer positive weights than samples: the tail is -1
+    few = torch.zeros(1000, device=dev); few[:10] = 1.0
+    idx = rendering.sample_rays(few, 32, seed=1)
+    assert sorted(idx[:10].cpu().tolist()) == list(range(10)) and bool((idx[10:] == -1).all())
+
+
+def test_graph_mode_replays_the_same_steps(dev):
+    """hipGraph mode (FrameOptimizer(graph=True)): the captured step reads its schedules, Philox counter, Adam step and learning
+    rates from device memory, so replaying it must walk the same trajectory as the eager loop given the same rays -- across the
+    warm-up -> residual phase switch (two captured graphs), and with the in-graph ray sampler."""
+    from vsrd_amd import optimization, rendering, fields
+    V, H, W, N, S, R = 3, 128, 128, 4, 32, 256
+    K, E, (loc, dim, rot), gt_boxes, visible = c1_frame()
+    cam, dirs = rendering.ray_casting((H, W), K.to(dev), E.to(dev))
+    block = fields.FieldBlock(fields.pack_instances(loc.to(dev), rot.to(dev), dim.to(dev)), 0.1, None, None)
+    origins = cam[:, None, None, :].expand(V, H, W, 3).reshape(-1, 3).contiguous()
+    soft = rendering.render_hierarchical(block, origins, dirs.reshape(-1, 3), (0.0, 100.0), S, 0.1, 1.0, seed=5)["labels"].clamp(0, 1)
+    soft = (soft.reshape(V, H, W, N) * visible.to(dev)[:, None, None, :]).contiguous()
+    inputs = optimization.FrameInputs((H, W), K.to(dev), E.to(dev), soft, gt_boxes.to(dev), visible.to(dev))
+    config = optimization.OptimizationConfig(num_samples=S, num_rays=R, warmup_steps=6, num_steps=3000)
+    g = torch.Generator().manual_seed(4)
+    start = [torch.randn(N, 3, generator=g) * 0.2, torch.randn(N, 3, generator=g) * 0.2,
+             torch.nn.functional.normalize(torch.tensor([1.0, 0.0]) + torch.randn(N, 2, generator=g) * 0.2, dim=-1)]
+    start[0][:, 2] -= 1.5
+    loops = []
+    for graph in (False, True):
+        torch.manual_seed(0)
+        loop = optimization.FrameOptimizer(inputs, config, dev, graph=graph)
+        with torch.no_grad():
+            for p, v in zip((loop.detector.locations, loop.detector.dimensions, loop.detector.orientations), start):
+                p.copy_(v[None].to(dev))
+        loops.append(loop)
+    loops[1].hyper_distance_field.load_state_dict(loops[0].hyper_distance_field.state_dict())
+    with torch.no_grad():
+        loops[1].detector.embeddings.copy_(loops[0].detector.embeddings)
+    weights = soft.reshape(-1, N).max(-1).values
+
+    def tensors(loop):      # parameters and Adam moments, in a fixed order
+        params = list(loop.detector.parameters()) + list(loop.hyper_distance_field.parameters())
+        moments = [loop.optimizer.state[p][k] for p in params if p in loop.optimizer.state for k in ("exp_avg", "exp_avg_sq")]
+        return params, moments
+
+    for step in range(12):                                  # 6 box-only steps (3 eager + capture + 2 replays), then 6 residual ones
+        idx = torch.multinomial((weights > 0.5).float(), R, replacement=False, generator=None)
+        with torch.no_grad():   # Adam turns 1e-7 gradient differences into 1e-2 steps when gradients vanish: compare step by step
+            (pe, me), (pg, mg) = tensors(loops[0]), tensors(loops[1])
+            for a, b in zip(pe + (me if len(me) == len(mg) else []), pg + (mg if len(me) == len(mg) else [])):
+                b.copy_(a)
+        eager, replayed = loops[0].step(idx), loops[1].step(idx)
+        for key in ("silhouette_loss", "iou_projection_loss", "l1_projection_loss", "loss"):
+            torch.testing.assert_close(replayed[key], eager[key], rtol=1e-4, atol=1e-6), (step, key)
+        for a, b in zip(eager["raw_gradients"], replayed["raw_gradients"]):
+            assert (a - b).abs().max() <= 1e-3 * max(float(a.abs().max()), 1e-6), step
+        for a, b in zip(loops[0].detector.parameters(), loops[1].detector.parameters()):
+            assert (a - b).detach().abs().max() <= 1e-4 * max(float(a.detach().abs().max()), 1e-3), step
+    assert len(loops[1]._graphs) == 2 and loops[1].step_index == 12 and int(loops[1].step_tensor) == 12
+    # sampling inside the graph: the loss keeps falling and every replay draws fresh rays
+    torch.manual_seed(0)
+    loop = optimization.FrameOptimizer(inputs, optimization.OptimizationConfig(num_samples=S, num_rays=R, warmup_steps=1000), dev, graph=True)
+    with torch.no_grad():
+        for p, v in zip((loop.detector.locations, loop.detector.dimensions, loop.detector.orientations), start):
+            p.copy_(v[None].to(dev))
+    history = [float(loop.step()["loss"]) for _ in range(40)]
+    assert sum(history[-5:]) < sum(history[:5]) and len(set(history)) == len(history)

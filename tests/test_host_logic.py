@@ -29,9 +29,10 @@ def test_header_symbols_are_exported(lib):
     assert declared == set(_lib.SIGNATURES), "ctypes binding and header disagree"
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.vsrd_abi_version() == 1
+    assert lib.vsrd_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define VSRD_ABI_VERSION (\d+)", header).group(1))
     assert lib.vsrd_workspace_bytes(16, 0) == 16384 * 4 * 16 * 16 * 4
-    assert lib.vsrd_workspace_bytes(16, 1) == 16384 * 4 * 16 * 16 * 4 + 256 * 4 * 16 * 1617 * 4
+    # box partials + per-wave MLP partials (512 workgroups x 4 waves) + the residual-jet cache [wave][4 rounds][N][64] float4
+    assert lib.vsrd_workspace_bytes(16, 1) == 16384 * 4 * 16 * 16 * 4 + 512 * 4 * 16 * 1617 * 4 + 512 * 4 * 4 * 16 * 64 * 16
     assert lib.vsrd_workspace_bytes(0, 0) == 0 and lib.vsrd_workspace_bytes(65, 0) == 0
     assert lib.vsrd_error_string(-1) == b"invalid argument"
 
@@ -40,8 +41,9 @@ def test_struct_layout_matches_header():
     from vsrd_amd import _lib
     assert ctypes.sizeof(_lib.Field) == 24                      # int32, float, 2 pointers
     assert _lib.Field.instances.offset == 8 and _lib.Field.mlp_weights.offset == 16
-    assert ctypes.sizeof(_lib.RenderConfig) == 56
+    assert ctypes.sizeof(_lib.RenderConfig) == 72
     assert _lib.RenderConfig.seed.offset == 32 and _lib.RenderConfig.stream_offset.offset == 40 and _lib.RenderConfig.flags.offset == 48
+    assert _lib.RenderConfig.device_schedule.offset == 56 and _lib.RenderConfig.device_stream_offset.offset == 64
 
 
 def test_cpu_tensors_are_rejected_not_emulated(lib):

@@ -22,6 +22,7 @@ def main():
     parser.add_argument("--steps", type=int, default=200)
     parser.add_argument("--instances", type=int, default=8)
     parser.add_argument("--views", type=int, default=17)
+    parser.add_argument("--graph", action="store_true", help="capture the step in a hipGraph and replay it")
     parser.add_argument("--residual", action="store_true", help="post-warm-up phase: residual MLP + eikonal loss (steps 1000-3000)")
     args = parser.parse_args()
     import __graft_entry__
@@ -42,9 +43,10 @@ def main():
                                              skip_exact_misses=True)["labels"].clamp(0, 1).reshape(V, H, W, N).contiguous()
         gt_boxes, _ = operations.project_boxes_multi_view(out["boxes_3d"][0], E.to(dev), K.to(dev), (H, W))
     inputs = optimization.FrameInputs((H, W), K.to(dev), E.to(dev), soft, gt_boxes, torch.ones(V, N, dtype=torch.bool, device=dev))
-    loop = optimization.FrameOptimizer(inputs, optimization.OptimizationConfig(), dev)
+    loop = optimization.FrameOptimizer(inputs, optimization.OptimizationConfig(), dev, graph=args.graph)
     if args.residual:
         loop.step_index = loop.config.warmup_steps
+        loop.step_tensor.fill_(loop.step_index)
     for _ in range(20):
         loop.step()
     torch.cuda.synchronize()
@@ -53,7 +55,7 @@ def main():
         losses = loop.step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"native mode ({'residual' if args.residual else 'box-only'} phase): {args.steps / dt:.1f} steps/s ({dt / args.steps * 1e3:.2f} ms/step, 1000 rays x 100 samples, V={V}, N={N}); "
+    print(f"native mode ({'residual' if args.residual else 'box-only'} phase{', hipGraph replay' if args.graph else ''}): {args.steps / dt:.1f} steps/s ({dt / args.steps * 1e3:.2f} ms/step, 1000 rays x 100 samples, V={V}, N={N}); "
           f"3000-step frame = {3000 * dt / args.steps:.1f} s; reference: ~3.3 steps/s on a V100 (README.md:128); final loss {float(losses['loss']):.4f}")
 
 

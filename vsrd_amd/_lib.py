@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(_HERE, "lib", "libvsrd_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_INSTANCES = 64
 MAX_SAMPLES = 256
 INSTANCE_STRIDE = 16
@@ -47,6 +47,8 @@ class RenderConfig(ctypes.Structure):
         ("seed", ctypes.c_uint64),
         ("stream_offset", ctypes.c_uint64),
         ("flags", ctypes.c_uint32),
+        ("device_schedule", ctypes.c_void_p),
+        ("device_stream_offset", ctypes.c_void_p),
     ]
 
 
@@ -79,6 +81,9 @@ SIGNATURES = {
     "vsrd_project_boxes_forward": (ctypes.c_int32, [c_float_p, c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                                     ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
                                                     c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "vsrd_sample_rays_workspace_bytes": (ctypes.c_size_t, []),
+    "vsrd_sample_rays": (ctypes.c_int32, [c_float_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
     "vsrd_match_boxes": (ctypes.c_int32, [c_float_p, c_float_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "vsrd_linear_sum_assignment": (ctypes.c_int32, [c_float_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "vsrd_project_boxes_backward": (ctypes.c_int32, [c_float_p, c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
@@ -151,7 +156,18 @@ def make_field(instances, temperature, mlp_weights=None):
 
 
 def make_config(num_rays, num_samples, distance_range, sdf_std_deviation, cosine_ratio, epsilon, origin_stride,
-                seed=0, stream_offset=0, flags=0):
+                seed=0, stream_offset=0, flags=0, schedule=None):
+    """`schedule`: optional device tensor float32 [3] = (temperature, sdf_std_deviation, cosine_ratio) read by the kernels at
+    start instead of the by-value scalars; `stream_offset` may likewise be a device int64 tensor (hipGraph replay)."""
+    schedule_ptr = offset_ptr = None
+    if schedule is not None:
+        if schedule.dtype != torch.float32 or schedule.numel() != 3 or not schedule.is_cuda or not schedule.is_contiguous():
+            raise ValueError("schedule must be a contiguous float32 device tensor of 3 elements")
+        schedule_ptr = schedule.data_ptr()
+    if isinstance(stream_offset, torch.Tensor):
+        if stream_offset.dtype != torch.int64 or stream_offset.numel() != 1 or not stream_offset.is_cuda:
+            raise ValueError("a tensor stream_offset must be a device int64 scalar")
+        offset_ptr, stream_offset = stream_offset.data_ptr(), 0
     return RenderConfig(int(num_rays), int(num_samples), float(distance_range[0]), float(distance_range[1]),
                         float(sdf_std_deviation), float(cosine_ratio), float(epsilon), int(origin_stride),
-                        int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_offset) & 0xFFFFFFFFFFFFFFFF, int(flags))
+                        int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_offset) & 0xFFFFFFFFFFFFFFFF, int(flags), schedule_ptr, offset_ptr)

@@ -4,6 +4,7 @@
 #include "../../include/vsrd_hip.h"
 #include "aux_kernels.h"
 #include "matching.h"
+#include "ray_sampling.h"
 #include "projection.h"
 
 namespace {
@@ -108,6 +109,8 @@ RenderArgs render_args(const vsrd_render_config* c) {
     a.seed = c->seed;
     a.stream_offset = c->stream_offset;
     a.flags = c->flags;
+    a.dynamic = c->device_schedule;
+    a.dynamic_offset = reinterpret_cast<const unsigned long long*>(c->device_stream_offset);
     return a;
 }
 
@@ -474,6 +477,25 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
     if (launch_status() != VSRD_OK) return VSRD_E_LAUNCH;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(row), dim3(256), 0, s, partials, num_waves, row, grad_instances);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, loss_partials, num_waves, 1, loss);
+    return launch_status();
+}
+
+size_t vsrd_sample_rays_workspace_bytes(void) { return sizeof(SampleScratch); }
+
+int32_t vsrd_sample_rays(const float* weights, int64_t count, int32_t num_samples, uint64_t seed, uint64_t stream_offset,
+                         const uint64_t* device_stream_offset, void* workspace, size_t workspace_bytes, int64_t* indices, void* stream) {
+    if (!weights || !workspace || !indices || count < 1 || num_samples < 1 || num_samples > kSampleMax) return VSRD_E_INVALID_ARGUMENT;
+    if (workspace_bytes < sizeof(SampleScratch)) return VSRD_E_WORKSPACE;
+    const hipStream_t s = static_cast<hipStream_t>(stream);
+    SampleScratch* scratch = static_cast<SampleScratch*>(workspace);
+    const unsigned long long* device_step = reinterpret_cast<const unsigned long long*>(device_stream_offset);
+    const long long want = (count + 255) / 256;
+    const int blocks = static_cast<int>(want > 4096 ? 4096 : want);
+    hipLaunchKernelGGL(sample_clear_kernel, dim3(1), dim3(256), 0, s, scratch);
+    hipLaunchKernelGGL(keys_histogram_kernel, dim3(blocks), dim3(256), 0, s, weights, static_cast<long long>(count), seed, stream_offset, device_step, scratch);
+    hipLaunchKernelGGL(threshold_kernel, dim3(1), dim3(kWave), 0, s, scratch, num_samples);
+    hipLaunchKernelGGL(collect_kernel, dim3(blocks), dim3(256), 0, s, weights, static_cast<long long>(count), seed, stream_offset, device_step, scratch);
+    hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, s, scratch, num_samples, reinterpret_cast<long long*>(indices));
     return launch_status();
 }
 

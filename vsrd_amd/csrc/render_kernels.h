@@ -32,7 +32,22 @@ struct RenderArgs {
     int origin_stride;
     unsigned long long seed, stream_offset;
     unsigned flags;
+    const float* dynamic;                         // vsrd_render_config::device_schedule
+    const unsigned long long* dynamic_offset;     // vsrd_render_config::device_stream_offset
 };
+
+// Per-step scalars that live on the device (hipGraph replay): applied to the kernel's private copies of its arguments.
+__device__ __forceinline__ void apply_device_schedule(FieldArgs& f, RenderArgs& c) {
+    if (c.dynamic != nullptr) {
+        const float temperature = c.dynamic[0], std = c.dynamic[1];
+        f.inv_t = 1.0f / temperature;
+        c.sh.inv_t = f.inv_t;
+        c.sh.std = std;
+        c.sh.inv_std = 1.0f / std;
+        c.sh.ratio = c.dynamic[2];
+    }
+    if (c.dynamic_offset != nullptr) c.stream_offset = *c.dynamic_offset;
+}
 
 __device__ __forceinline__ Ray load_ray(const float* __restrict__ origins, const float* __restrict__ directions,
                                         int origin_stride, int ray) {
@@ -52,6 +67,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_forward_kernel(
     FieldArgs f, const float* __restrict__ instances, const float* __restrict__ mlp, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
     const float* __restrict__ distances, int num_distances,
     float* __restrict__ labels, float* __restrict__ gradients, float* __restrict__ weights) {
+    apply_device_schedule(f, c);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = wave_in_block();
     const int lane = lane_id();
@@ -84,6 +100,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
     const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
     float* __restrict__ labels, float* __restrict__ distances, float* __restrict__ gradients, float* __restrict__ weights,
     float* __restrict__ u_coarse_out, float* __restrict__ u_fine_out) {
+    apply_device_schedule(f, c);
     constexpr int kRoundsS = (kRounds + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = wave_in_block();
@@ -434,6 +451,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
     const float* __restrict__ distances, int num_distances,
     const float* __restrict__ grad_labels, const float* __restrict__ grad_gradients, const float* __restrict__ grad_weights,
     float* __restrict__ partials, float* __restrict__ mlp_partials, float4* __restrict__ residual_cache) {
+    apply_device_schedule(f, c);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = wave_in_block();
     const int lane = lane_id();
@@ -492,6 +510,7 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
     const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
     const float* __restrict__ targets, const float* __restrict__ instance_weights, float loss_scale,
     float* __restrict__ labels_out, float* __restrict__ partials, float* __restrict__ loss_partials) {
+    apply_device_schedule(f, c);
     constexpr int kRoundsS = (kRounds + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = wave_in_block();

@@ -1,14 +1,21 @@
 """One target frame's optimisation loop: the hot path of scripts/main.py:323-865 assembled from the device pieces.
 
-    detector() -> multi-view projection (HIP) -> Hungarian matching (host, as the reference) -> projection losses
+    detector() -> multi-view projection (HIP) -> Hungarian matching (HIP, on the device) -> projection losses
     -> schedules -> field block -> ray sampling -> fused two-pass render (HIP) -> silhouette (+ eikonal) loss
     -> backward (HIP adjoint kernels + torch for the tiny decode) -> Adam -> ExponentialLR
+
+With ``graph=True`` the whole step is captured once per phase in a hipGraph (torch.cuda.CUDAGraph) and replayed: at 1000
+rays the step is ~360 small launches and host-bound, and nothing in it needs the host any more -- the matching runs on the
+device, and everything that changes from step to step (schedules, Philox counter, Adam step, learning rates) lives in
+device memory that the kernels read (vsrd_render_config::device_schedule / device_stream_offset).
 
 Frames are independent problems (README.md:128): multi-GPU runs shard *frames* over ranks (vsrd_amd/launcher.py) and
 never exchange gradients.
 """
 from dataclasses import dataclass, field as dataclass_field
 from typing import Optional, Sequence
+
+import math
 
 import torch
 
@@ -48,18 +55,26 @@ class OptimizationConfig:
 
 
 class FrameOptimizer:
-    def __init__(self, inputs: FrameInputs, config: OptimizationConfig, device):
+    def __init__(self, inputs: FrameInputs, config: OptimizationConfig, device, graph=False):
         self.inputs, self.config, self.device = inputs, config, torch.device(device)
+        self.graph = bool(graph)
         V, H, W, N = inputs.soft_masks.shape
         self.num_views, self.num_instances = V, N
         self.detector = models.BoxParameters3D(1, N).to(self.device)
         # config.json:143-156: per-instance residual MLP 48->16->16->16->16->1 generated from 256-d embeddings
         self.hyper_distance_field = models.HyperDistanceField(48, [16, 16, 16, 16], 256, [256, 256, 256, 256]).to(self.device)
-        groups = [dict(params=[p], lr=config.learning_rate) for p in (self.detector.locations, self.detector.dimensions, self.detector.orientations)]
-        groups.append(dict(params=[self.detector.embeddings], lr=config.embedding_learning_rate))
-        groups.append(dict(params=list(self.hyper_distance_field.parameters()), lr=config.hypernetwork_learning_rate))
-        self.optimizer = torch.optim.Adam(groups, lr=config.learning_rate)
-        self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=config.lr_gamma)
+        def rate(value):   # graph mode: learning rates are device tensors decayed in place inside the captured step
+            return torch.tensor(value, dtype=torch.float32, device=self.device) if self.graph else value
+        groups = [dict(params=[p], lr=rate(config.learning_rate)) for p in (self.detector.locations, self.detector.dimensions, self.detector.orientations)]
+        groups.append(dict(params=[self.detector.embeddings], lr=rate(config.embedding_learning_rate)))
+        groups.append(dict(params=list(self.hyper_distance_field.parameters()), lr=rate(config.hypernetwork_learning_rate)))
+        self.optimizer = torch.optim.Adam(groups, lr=rate(config.learning_rate), capturable=self.graph)
+        self.scheduler = None if self.graph else torch.optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=config.lr_gamma)
+        # per-step scalars on the device (graph mode): step index = Philox counter, (temperature, std, cosine_ratio)
+        self.step_tensor = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.schedule = torch.ones(3, dtype=torch.float32, device=self.device)
+        self._graphs = {}
+        self._eager_graph_steps = {}
         # rays of every view, once per frame (main.py:267-296)
         cam, dirs = rendering.ray_casting((H, W), inputs.intrinsic_matrices, inputs.extrinsic_matrices)
         self.camera_positions = cam                                         # [V,3]
@@ -71,7 +86,11 @@ class FrameOptimizer:
 
     # ------------------------------------------------------------------------------------------------
     def sample_rays(self):
-        """main.py:620-627: importance-sample rays by the strongest soft mask (torch.multinomial, no replacement)."""
+        """main.py:620-627: importance-sample rays by the strongest soft mask (torch.multinomial, no replacement).  Graph mode
+        uses the library's own sampler (same algorithm, Philox keyed by the device-side step counter): ATen's captured multinomial
+        faults on replay with this torch build, and it sorts all V*H*W keys every step."""
+        if self.graph:
+            return rendering.sample_rays(self.sampling_weights, self.config.num_rays, seed=self.config.seed + 1, stream_offset=self.step_tensor)
         return torch.multinomial(self.sampling_weights, self.config.num_rays, replacement=False)
 
     def field_block(self, outputs, temperature, mlp_weights=None):
@@ -82,6 +101,53 @@ class FrameOptimizer:
         """One optimisation step.  Steps < warmup_steps optimise the boxes only; later steps add the per-instance residual MLP
         (hypernetwork on the embeddings, main.py:525-578) and the eikonal loss (main.py:679-687).
         ray_indices / uniforms may be supplied for reproducible parity runs."""
+        if self.graph:
+            if u_coarse is not None or u_fine is not None:
+                raise ValueError("graph mode draws its uniforms in the kernels (Philox keyed by the device-side step counter)")
+            return self._graph_step(ray_indices)
+        return self._step(ray_indices, u_coarse, u_fine)
+
+    # ---- hipGraph mode ---------------------------------------------------------------------------------
+    def _device_schedule(self):
+        """scripts/main.py:420-431 evaluated on the device from the device-side step counter."""
+        cfg = self.config
+        x = self.step_tensor.to(torch.float32) / cfg.num_steps
+        anneal = (torch.cos(math.pi * x) + 1.0) / 2.0
+        self.schedule.copy_(torch.cat([anneal * (cfg.max_sdf_union_temperature - cfg.min_sdf_union_temperature) + cfg.min_sdf_union_temperature,
+                                       anneal * (cfg.max_sdf_std_deviation - cfg.min_sdf_std_deviation) + cfg.min_sdf_std_deviation, x]))
+
+    def _graph_step(self, ray_indices):
+        """Three eager steps per (phase, ray source) on a side stream warm the allocator and the lazy initialisations, then the step is
+        captured once and replayed.  The eager steps run the same device-side code, so they are ordinary optimisation steps."""
+        residual = self.step_index >= self.config.warmup_steps
+        key = (residual, ray_indices is not None)
+        if key in self._graphs:
+            graph, static_rays, outputs = self._graphs[key]
+            if static_rays is not None:
+                static_rays.copy_(ray_indices)
+            graph.replay()
+            self.step_index += 1
+            return outputs
+        done = self._eager_graph_steps.get(key, 0)
+        if done < 3:
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                outputs = self._step(ray_indices, None, None)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            self._eager_graph_steps[key] = done + 1
+            return outputs
+        static_rays = ray_indices.clone() if ray_indices is not None else None
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.graph(graph):
+            outputs = self._step(static_rays, None, None, count=False)
+        self._graphs[key] = (graph, static_rays, outputs)
+        graph.replay()                                   # capture does not execute: this replay IS the step
+        self.step_index += 1
+        return outputs
+
+    def _step(self, ray_indices, u_coarse, u_fine, count=True):
         cfg, inp = self.config, self.inputs
         step = self.step_index
         residual = step >= cfg.warmup_steps
@@ -94,6 +160,10 @@ class FrameOptimizer:
         # ---- instance loss (main.py:420-671) ---------------------------------------------------------
         ratio, temperature, std = losses.schedules(step, cfg.num_steps, cfg.max_sdf_union_temperature, cfg.min_sdf_union_temperature,
                                                    cfg.max_sdf_std_deviation, cfg.min_sdf_std_deviation)
+        schedule = offset = None
+        if self.graph:       # the kernels read (temperature, std, ratio) and the Philox counter from device memory instead
+            self._device_schedule()
+            schedule, offset = self.schedule, self.step_tensor
         mlp_weights = self.hyper_distance_field(outputs["embeddings"])[0].contiguous() if residual else None     # [N,1617]
         block = self.field_block(outputs, temperature, mlp_weights)
         if ray_indices is None:
@@ -102,13 +172,14 @@ class FrameOptimizer:
         directions = self.ray_directions[ray_indices]
         if residual:
             out = rendering.render_hierarchical(block, origins, directions, cfg.distance_range, cfg.num_samples, std, ratio,
-                                                u_coarse=u_coarse, u_fine=u_fine, seed=cfg.seed, stream_offset=step, return_gradients=True)
+                                                u_coarse=u_coarse, u_fine=u_fine, seed=cfg.seed, stream_offset=step if offset is None else offset,
+                                                return_gradients=True, schedule=schedule)
             silhouette = losses.silhouette_loss(out["labels"], self.flat_masks[ray_indices], pd_idx, gt_idx)
         else:   # box-only phase: render + silhouette BCE + adjoint in one launch
             silhouette = rendering.silhouette_step(block, origins, directions, self.flat_masks[ray_indices], cfg.distance_range,
                                                    cfg.num_samples, std, ratio, pd_indices=pd_idx, gt_indices=gt_idx,
-                                                   u_coarse=u_coarse, u_fine=u_fine, seed=cfg.seed, stream_offset=step,
-                                                   skip_exact_misses=cfg.skip_exact_misses)
+                                                   u_coarse=u_coarse, u_fine=u_fine, seed=cfg.seed, stream_offset=step if offset is None else offset,
+                                                   skip_exact_misses=cfg.skip_exact_misses, schedule=schedule)
         terms = dict(iou_projection_loss=iou_loss, l1_projection_loss=l1_loss, silhouette_loss=silhouette)
         if residual:
             terms["eikonal_loss"] = losses.eikonal_loss(out["gradients"])
@@ -116,8 +187,14 @@ class FrameOptimizer:
         total.backward()
         raw_gradients = [p.grad.detach().clone() for p in (self.detector.locations, self.detector.dimensions, self.detector.orientations)]
         self.optimizer.step()
-        self.scheduler.step()
-        self.step_index += 1
+        if self.graph:      # ExponentialLR and the step counter, in place on the device
+            for group in self.optimizer.param_groups:
+                group["lr"].mul_(cfg.lr_gamma)
+            self.step_tensor.add_(1)
+        else:
+            self.scheduler.step()
+        if count:
+            self.step_index += 1
         terms["loss"] = total
         result = {name: value.detach() for name, value in terms.items()}
         result["raw_gradients"] = raw_gradients

@@ -58,7 +58,7 @@ class _RenderAtDistances(torch.autograd.Function):
     @staticmethod
     def forward(ctx, instances, mlp_weights, origins, directions, distances, temperature, scalars, origin_stride):
         lib = _lib.load()
-        std, ratio, eps, near, far, num_samples = scalars
+        std, ratio, eps, near, far, num_samples, schedule = _unpack(scalars)
         R, D = distances.shape
         N = instances.shape[0]
         instances = instances.detach().contiguous()
@@ -67,7 +67,7 @@ class _RenderAtDistances(torch.autograd.Function):
         weights = torch.empty(R, D - 1, dtype=torch.float32, device=distances.device)
         mlp_weights = None if mlp_weights is None else mlp_weights.detach().contiguous()
         field = _lib.make_field(instances, temperature, mlp_weights)
-        config = _lib.make_config(R, num_samples, (near, far), std, ratio, eps, origin_stride, flags=_base_flags())
+        config = _lib.make_config(R, num_samples, (near, far), std, ratio, eps, origin_stride, flags=_base_flags(), schedule=schedule)
         with profiling.timed("vsrd_render_forward"):
             _lib.check(lib.vsrd_render_forward(field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(distances), D,
                                                _lib.ptr(labels), _lib.ptr(gradients), _lib.ptr(weights), _lib.stream()))
@@ -86,10 +86,19 @@ class _RenderAtDistances(torch.autograd.Function):
         return (grad_instances, grad_mlp, None, None, None, None, None, None)
 
 
+def _unpack(scalars):
+    """(std, ratio, eps, near, far, S[, schedule]) -> 7-tuple; `schedule` is the optional device tensor of _lib.make_config."""
+    return tuple(scalars) if len(scalars) == 7 else tuple(scalars) + (None,)
+
+
+def _offset(stream_offset):
+    return stream_offset if isinstance(stream_offset, torch.Tensor) else int(stream_offset)
+
+
 def _backward(instances, mlp_weights, origins, directions, distances, temperature, scalars, origin_stride,
               grad_labels, grad_gradients, grad_weights):
     lib = _lib.load()
-    std, ratio, eps, near, far, num_samples = scalars
+    std, ratio, eps, near, far, num_samples, schedule = _unpack(scalars)
     R, D = distances.shape
     N = instances.shape[0]
     grad_labels = torch.zeros(R, N, dtype=torch.float32, device=distances.device) if grad_labels is None \
@@ -100,7 +109,7 @@ def _backward(instances, mlp_weights, origins, directions, distances, temperatur
     grad_mlp = None if mlp_weights is None else torch.empty_like(mlp_weights)
     workspace = _workspace(distances.device, N, mlp_weights is not None)
     field = _lib.make_field(instances, temperature, mlp_weights)
-    config = _lib.make_config(R, num_samples, (near, far), std, ratio, eps, origin_stride, flags=_base_flags())
+    config = _lib.make_config(R, num_samples, (near, far), std, ratio, eps, origin_stride, flags=_base_flags(), schedule=schedule)
     with profiling.timed("vsrd_render_backward"):
         _lib.check(lib.vsrd_render_backward(field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(distances), D,
                                             _lib.ptr(grad_labels), _lib.ptr(grad_gradients), _lib.ptr(grad_weights),
@@ -116,7 +125,7 @@ class _RenderHierarchical(torch.autograd.Function):
     def forward(ctx, instances, mlp_weights, origins, directions, u_coarse, u_fine, temperature, scalars, origin_stride,
                 seed, stream_offset, flags, want_gradients, want_weights, want_uniforms):
         lib = _lib.load()
-        std, ratio, eps, near, far, S = scalars
+        std, ratio, eps, near, far, S, schedule = _unpack(scalars)
         R = directions.shape[0]
         N = instances.shape[0]
         dev = directions.device
@@ -131,7 +140,7 @@ class _RenderHierarchical(torch.autograd.Function):
         field = _lib.make_field(instances, temperature, mlp_weights)
         ctx.residual = mlp_weights is not None
         ctx.mlp = mlp_weights
-        config = _lib.make_config(R, S, (near, far), std, ratio, eps, origin_stride, seed, stream_offset, flags)
+        config = _lib.make_config(R, S, (near, far), std, ratio, eps, origin_stride, seed, stream_offset, flags, schedule=schedule)
         with profiling.timed("vsrd_render_hierarchical_forward"):
             _lib.check(lib.vsrd_render_hierarchical_forward(
                 field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(u_coarse), _lib.ptr(u_fine),
@@ -180,9 +189,11 @@ def render_at_distances(distance_field, ray_positions, ray_directions, distances
 
 def render_hierarchical(distance_field, ray_positions, ray_directions, distance_range, num_samples, sdf_std_deviation,
                         cosine_ratio=1.0, epsilon=1.0e-6, u_coarse=None, u_fine=None, seed=0, stream_offset=0,
-                        return_gradients=False, return_weights=False, return_uniforms=False, skip_exact_misses=False):
+                        return_gradients=False, return_weights=False, return_uniforms=False, skip_exact_misses=False, schedule=None):
     """Fused two-pass render.  Returns a dict: labels [R,N], distances [R,2S], optionally gradients
-    [R,2S-1,3], weights [R,2S-1], u_coarse/u_fine [R,S] (the uniforms actually used)."""
+    [R,2S-1,3], weights [R,2S-1], u_coarse/u_fine [R,S] (the uniforms actually used).
+    ``schedule`` (device float32 [3] = temperature, sdf_std_deviation, cosine_ratio) and a tensor ``stream_offset`` are read on the
+    device instead of the scalar arguments (hipGraph replay; see include/vsrd_hip.h)."""
     block = flatten(distance_field)
     origins, directions, stride, _ = _prepare_rays(ray_positions, ray_directions)
     if (u_coarse is None) != (u_fine is None):
@@ -192,10 +203,10 @@ def render_hierarchical(distance_field, ray_positions, ray_directions, distance_
         u_fine = u_fine.reshape(-1, num_samples).to(torch.float32).contiguous()
     flags = (_lib.FLAG_SKIP_EXACT_MISSES if skip_exact_misses else 0) | _base_flags()
     scalars = (float(sdf_std_deviation), float(cosine_ratio), float(epsilon), float(distance_range[0]),
-               float(distance_range[1]), int(num_samples))
+               float(distance_range[1]), int(num_samples), schedule)
     labels, gradients, weights, distances, uc, uf = _RenderHierarchical.apply(
         block.instances, block.mlp_weights, origins, directions, u_coarse, u_fine, block.temperature, scalars, stride,
-        int(seed), int(stream_offset), flags, bool(return_gradients), bool(return_weights), bool(return_uniforms))
+        int(seed), _offset(stream_offset), flags, bool(return_gradients), bool(return_weights), bool(return_uniforms))
     out = dict(labels=_scatter_labels(labels, block), distances=distances)
     if return_gradients:
         out["gradients"] = gradients
@@ -333,7 +344,7 @@ class _SilhouetteStep(torch.autograd.Function):
     def forward(ctx, instances, origins, directions, targets, weights, u_coarse, u_fine, temperature, scalars, origin_stride,
                 seed, stream_offset, flags, loss_scale, want_labels):
         lib = _lib.load()
-        std, ratio, eps, near, far, S = scalars
+        std, ratio, eps, near, far, S, schedule = _unpack(scalars)
         R, N = directions.shape[0], instances.shape[0]
         dev = directions.device
         instances = instances.detach().contiguous()
@@ -342,7 +353,7 @@ class _SilhouetteStep(torch.autograd.Function):
         labels = torch.empty(R, N, dtype=torch.float32, device=dev) if want_labels else None
         workspace = _workspace(dev, N, False)
         field = _lib.make_field(instances, temperature)
-        config = _lib.make_config(R, S, (near, far), std, ratio, eps, origin_stride, seed, stream_offset, flags)
+        config = _lib.make_config(R, S, (near, far), std, ratio, eps, origin_stride, seed, stream_offset, flags, schedule=schedule)
         with profiling.timed("vsrd_render_silhouette_step"):
             _lib.check(lib.vsrd_render_silhouette_step(field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(u_coarse), _lib.ptr(u_fine),
                                                        _lib.ptr(targets), _lib.ptr(weights), float(loss_scale), workspace.data_ptr(),
@@ -360,7 +371,7 @@ class _SilhouetteStep(torch.autograd.Function):
 
 def silhouette_step(distance_field, ray_positions, ray_directions, targets, distance_range, num_samples, sdf_std_deviation,
                     cosine_ratio=1.0, epsilon=1.0e-6, pd_indices=None, gt_indices=None, u_coarse=None, u_fine=None, seed=0,
-                    stream_offset=0, return_labels=False, skip_exact_misses=True):
+                    stream_offset=0, return_labels=False, skip_exact_misses=True, schedule=None):
     """Fused fast path of scripts/main.py:629-671 for box-only fields: the two-pass render AND
     ``mean(BCE(clamp(labels[..., pd_indices], 1e-6, 1 - 1e-6), targets[..., gt_indices]))`` in one launch.
     Returns the loss (autograd-connected to the field parameters), and the labels [R,N] when asked."""
@@ -378,7 +389,7 @@ def silhouette_step(distance_field, ray_positions, ray_directions, targets, dist
         ordered = torch.zeros(R, N, dtype=torch.float32, device=targets.device)
         ordered[:, pd_indices] = targets[:, gt_indices]
         weights = torch.zeros(N, dtype=torch.float32, device=targets.device)
-        weights[pd_indices] = 1.0
+        weights.index_fill_(0, pd_indices, 1.0)             # (an indexed scalar assignment would upload the scalar: not capturable)
         kept = int(pd_indices.numel())
     if (u_coarse is None) != (u_fine is None):
         raise ValueError("pass both u_coarse and u_fine, or neither (in-kernel Philox)")
@@ -386,7 +397,7 @@ def silhouette_step(distance_field, ray_positions, ray_directions, targets, dist
         u_coarse = u_coarse.reshape(-1, num_samples).to(torch.float32).contiguous()
         u_fine = u_fine.reshape(-1, num_samples).to(torch.float32).contiguous()
     flags = (_lib.FLAG_SKIP_EXACT_MISSES if skip_exact_misses else 0) | _base_flags()
-    scalars = (float(sdf_std_deviation), float(cosine_ratio), float(epsilon), float(distance_range[0]), float(distance_range[1]), int(num_samples))
+    scalars = (float(sdf_std_deviation), float(cosine_ratio), float(epsilon), float(distance_range[0]), float(distance_range[1]), int(num_samples), schedule)
     loss, labels = _SilhouetteStep.apply(block.instances, origins, directions, ordered, weights, u_coarse, u_fine, block.temperature, scalars,
-                                         stride, int(seed), int(stream_offset), flags, 1.0 / (R * max(kept, 1)), bool(return_labels))
+                                         stride, int(seed), _offset(stream_offset), flags, 1.0 / (R * max(kept, 1)), bool(return_labels))
     return (loss, labels) if return_labels else loss

@@ -41,3 +41,25 @@ def importance_merge(bins, weights, uniforms=None, sorted_uniforms=False):
                               flags=_lib.FLAG_FINE_UNIFORMS_SORTED if sorted_uniforms else 0)
     _lib.check(lib.vsrd_sample_importance(config, _lib.ptr(b), _lib.ptr(w), _lib.ptr(u), _lib.ptr(out), _lib.stream()))
     return out.reshape(*lead, 2 * S)
+
+
+_ray_workspaces = {}
+
+
+def sample_rays(weights, num_samples, seed=0, stream_offset=0):
+    """scripts/main.py:620-627: ``torch.multinomial(weights, num_samples, replacement=False)`` as a few streaming launches
+    (vsrd_sample_rays: ATen's exponential-race algorithm with Philox keyed by (seed, stream_offset; index), no full sort).
+    Deterministic in its arguments; ``stream_offset`` may be a device int64 tensor (read on the device: hipGraph replay).
+    Returns int64 indices [num_samples], best key first."""
+    lib = _lib.load()
+    weights = weights.detach().reshape(-1).to(torch.float32).contiguous()
+    buf = _ray_workspaces.get(weights.device)
+    if buf is None:
+        buf = _ray_workspaces[weights.device] = torch.empty(lib.vsrd_sample_rays_workspace_bytes(), dtype=torch.uint8, device=weights.device)
+    indices = torch.empty(int(num_samples), dtype=torch.int64, device=weights.device)
+    offset_ptr = None
+    if isinstance(stream_offset, torch.Tensor):
+        offset_ptr, stream_offset = stream_offset.data_ptr(), 0
+    _lib.check(lib.vsrd_sample_rays(_lib.ptr(weights), weights.numel(), int(num_samples), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                    int(stream_offset) & 0xFFFFFFFFFFFFFFFF, offset_ptr, buf.data_ptr(), buf.numel(), indices.data_ptr(), _lib.stream()))
+    return indices
