@@ -126,9 +126,14 @@ int rounds_for(int points) {
 
 constexpr int kMaxBlocksResidual = 512;     // residual adjoint: one wave per SIMD resident; more workgroups than CUs = load balancing (each wave owns N x 1617 partials)
 
-// Residual jets (value + local gradient) the adjoint's forward sweep leaves for its per-instance phase: [wave][round <= 4][N][64] float4.
-size_t residual_cache_floats(int num_instances, bool residual) {
+// Residual adjoint, per wave: the residual jets (value + local gradient) the forward sweep leaves for the per-instance phase
+// [round <= 4][N][64] float4, and the seeds that phase leaves for the MLP adjoint [round <= 4][N][10][64].
+size_t residual_jet_floats(int num_instances, bool residual) {
     return residual ? static_cast<size_t>(kMaxBlocksResidual) * kMaxWavesPerBlock * 4 * num_instances * kWave * 4 : 0;
+}
+size_t residual_cache_floats(int num_instances, bool residual) {
+    return residual_jet_floats(num_instances, residual) +
+           (residual ? static_cast<size_t>(kMaxBlocksResidual) * kMaxWavesPerBlock * 4 * num_instances * kSeedFloats * kWave : 0);
 }
 
 size_t partial_floats(int num_instances, bool residual) {
@@ -323,13 +328,15 @@ int32_t vsrd_render_backward(const vsrd_field* field, const vsrd_render_config* 
     c.sh.inv_t = f.inv_t;
     float* partials = static_cast<float*>(workspace);
     float* mlp_partials = partials + static_cast<size_t>(kMaxBlocks) * kMaxWavesPerBlock * row;
-    float4* residual_cache = reinterpret_cast<float4*>(mlp_partials + (residual ? static_cast<size_t>(kMaxBlocksResidual) * kMaxWavesPerBlock * mlp_row : 0));
+    float* jets = mlp_partials + (residual ? static_cast<size_t>(kMaxBlocksResidual) * kMaxWavesPerBlock * mlp_row : 0);
+    float4* residual_cache = reinterpret_cast<float4*>(jets);
+    float* seed_cache = jets + residual_jet_floats(N, residual);
 #define VSRD_LAUNCH(K, RES)                                                                                                    \
     fit_to_residency(render_backward_kernel<K, RES>, &g);                                                                        \
     if (residual && g.blocks > kMaxBlocksResidual) g.blocks = kMaxBlocksResidual;                                                \
     hipLaunchKernelGGL((render_backward_kernel<K, RES>), dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances,    \
                        field->mlp_weights, c, origins, directions, distances, num_distances, grad_labels, grad_gradients,         \
-                       grad_weights, partials, mlp_partials, residual_cache)
+                       grad_weights, partials, mlp_partials, residual_cache, seed_cache)
     const int rounds = rounds_for(num_distances - 1);
     if (residual) {
         switch (rounds) {

@@ -10,10 +10,11 @@ constexpr int kBlockThreads = kMaxWavesPerBlock * kWave;   // launch bound; the 
 
 __device__ __forceinline__ int waves_per_block() { return static_cast<int>(blockDim.x) >> 6; }
 constexpr int kGradStride = kInstanceStride;   // grad_instances rows are [t(3) R(9) dim(3) pad]
+constexpr int kSeedFloats = 10;                // per sample: local position (3), d_bar, gl_bar (3), x - t (3)
 
 // Floats of LDS one wave of render_backward_kernel owns (a multiple of 4: the partitions stay 16-byte aligned).
 __host__ __device__ constexpr int backward_lds_floats(int num_distances, int num_instances, bool residual) {
-    return ((residual ? kMlpLdsFloats : 0) + num_distances + num_instances + num_instances * kGradStride + 3) & ~3;
+    return ((residual ? kMlpLdsFloats + 4 * num_instances : 0) + num_distances + num_instances + num_instances * kGradStride + 3) & ~3;
 }
 
 // The instance block [N,16] travels as its own `const float* __restrict__` kernel argument (not inside this
@@ -343,8 +344,8 @@ __device__ __forceinline__ bool adjoint_reverse_sweep(RayAdjoint<kRounds>& st, c
 // LDS rows G [N,16] / wbar [1617].
 template <int kRounds, bool kResidual>
 __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, const float* __restrict__ instances, const float* __restrict__ mlp,
-                                                int N, float inv_t, int num_points, const float* lam, float* G, float* wbar, float* my_mlp, int lane,
-                                                const float4* rcache) {
+                                                int N, float inv_t, int num_points, const float* lam, float* G, int lane,
+                                                const float4* rcache, float* seeds, unsigned* masks) {
     for (int i = 0; i < N; ++i) {
         const Instance in = load_instance(instances, i);
         const float lam_i = lam[i];
@@ -359,10 +360,15 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
             active[k] = (k * kWave < num_points) && tiles[k] != 0u;
             any_active = any_active || active[k];
         }
+        if (kResidual && lane < kRounds) {                                    // which tiles of which rounds the MLP adjoint has to visit
+            unsigned mine = 0u;
+#pragma unroll
+            for (int k = 0; k < kRounds; ++k) mine = (lane == k && active[k]) ? tiles[k] : mine;
+            masks[lane * N + i] = mine;
+        }
         if (!any_active) continue;                                            // negligible for this ray (field.h culling)
         float at0 = 0, at1 = 0, at2 = 0, ad0 = 0, ad1 = 0, ad2 = 0;
         float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
-        float seed[kRounds][10];
 #pragma unroll
         for (int k = 0; k < kRounds; ++k) {
             if (!active[k]) continue;
@@ -393,10 +399,11 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
             const float qbz = d_bar * e.hz + ((e.qz > 0.0f) ? (vz - hz * hv) * inv_n : 0.0f);
             const float pbx = sx * qbx, pby = sy * qby, pbz = sz * qbz;
             ad0 -= qbx; ad1 -= qby; ad2 -= qbz;
-            if (kResidual) {        // seeds of the residual adjoint: value adjoint d_bar, local-gradient adjoint gl_bar (main.py:451-458)
-                seed[k][0] = e.px; seed[k][1] = e.py; seed[k][2] = e.pz; seed[k][3] = d_bar;
-                seed[k][4] = glbx; seed[k][5] = glby; seed[k][6] = glbz;
-                seed[k][7] = e.relx; seed[k][8] = e.rely; seed[k][9] = e.relz;
+            if (kResidual) {        // seeds of the residual adjoint (main.py:451-458): value adjoint d_bar, local-gradient adjoint gl_bar;
+                float* dst = seeds + static_cast<size_t>(k * N + i) * (kSeedFloats * kWave) + lane;       // left for adjoint_phase_mlp
+                dst[0 * kWave] = e.px; dst[1 * kWave] = e.py; dst[2 * kWave] = e.pz; dst[3 * kWave] = d_bar;
+                dst[4 * kWave] = glbx; dst[5 * kWave] = glby; dst[6 * kWave] = glbz;
+                dst[7 * kWave] = e.relx; dst[8 * kWave] = e.rely; dst[9 * kWave] = e.relz;
             }
             r00 += e.relx * pbx + gwbx * e.glx; r01 += e.relx * pby + gwbx * e.gly; r02 += e.relx * pbz + gwbx * e.glz;
             r10 += e.rely * pbx + gwby * e.glx; r11 += e.rely * pby + gwby * e.gly; r12 += e.rely * pbz + gwby * e.glz;
@@ -405,42 +412,52 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
             at1 -= in.r10 * pbx + in.r11 * pby + in.r12 * pbz;
             at2 -= in.r20 * pbx + in.r21 * pby + in.r22 * pbz;
         }
-        if (kResidual) {
-            // ONE call site for the MLP adjoint: a rolled loop over the rounds picks the round's seeds with selects.  Its result only
-            // adds the local-position adjoint p_bar to the terms above (they are linear in p_bar).
-#pragma unroll 1
-            for (int k = 0; k < kRounds; ++k) {
-                float sd[10];
-                bool on = false;
-                unsigned rows = 0u;
-#pragma unroll
-                for (int kk = 0; kk < kRounds; ++kk) {
-                    if (kk == k) {
-                        on = active[kk]; rows = tiles[kk];
-#pragma unroll
-                        for (int v = 0; v < 10; ++v) sd[v] = seed[kk][v];
-                    }
-                }
-                if (!on) continue;
-                const ResidualAdjoint ra = residual_backward(mlp + i * kMlpWeights, sd[0], sd[1], sd[2], sd[3], sd[4], sd[5], sd[6], wbar, lane, rows);
-                r00 += sd[7] * ra.px; r01 += sd[7] * ra.py; r02 += sd[7] * ra.pz;
-                r10 += sd[8] * ra.px; r11 += sd[8] * ra.py; r12 += sd[8] * ra.pz;
-                r20 += sd[9] * ra.px; r21 += sd[9] * ra.py; r22 += sd[9] * ra.pz;
-                at0 -= in.r00 * ra.px + in.r01 * ra.py + in.r02 * ra.pz;
-                at1 -= in.r10 * ra.px + in.r11 * ra.py + in.r12 * ra.pz;
-                at2 -= in.r20 * ra.px + in.r21 * ra.py + in.r22 * ra.pz;
-            }
-        }
         // one reduce-scatter butterfly: lane j (< 16) receives parameter j of instance i and keeps it in its LDS slot
         const float packed[16] = {at0, at1, at2, r00, r01, r02, r10, r11, r12, r20, r21, r22, ad0, ad1, ad2, 0.0f};
         const float mine = wave_reduce16_scatter(packed, lane);
         if (lane < kGradStride) G[i * kGradStride + lane] += mine;
-        if (kResidual) {            // flush this instance's MLP weight adjoints into the wave's global row (wave-private RMW)
-            float* dst = my_mlp + static_cast<size_t>(i) * kMlpWeights;
-            wave_lds_sync();
-            for (int idx = lane; idx < kMlpWeights; idx += kWave) { dst[idx] += wbar[idx]; wbar[idx] = 0.0f; }
-            wave_lds_sync();
+    }
+}
+
+// Phase B, residual part: the MLP adjoint of every (instance, round) the box phase left seeds for.  It runs AFTER the box phase,
+// when the per-ray adjoint state is dead: residual_backward (inlined here, its only call site) needs ~400 registers, and as a
+// function called from inside the box phase it saved and restored 217 of them per call -- 200 GB of scratch traffic per launch
+// on the C3-shaped bench (profiles/r01_c3).  The seeds (10 floats per sample) go through the workspace instead.
+// Its result p_bar = dL/d(local position) adds  rel (x) p_bar  to the rotation adjoint and  -R p_bar  to the translation adjoint.
+template <int kRounds>
+__device__ __forceinline__ void adjoint_phase_mlp(const float* __restrict__ instances, const float* __restrict__ mlp, int N, float* G, float* wbar,
+                                                  float* my_mlp, int lane, const float* seeds, const unsigned* masks) {
+    for (int i = 0; i < N; ++i) {
+        unsigned any = 0u;
+#pragma unroll
+        for (int k = 0; k < kRounds; ++k) any |= masks[k * N + i];
+        if (__builtin_amdgcn_readfirstlane(any) == 0u) continue;
+        const Instance in = load_instance(instances, i);
+        float at0 = 0, at1 = 0, at2 = 0;
+        float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
+#pragma unroll 1
+        for (int k = 0; k < kRounds; ++k) {
+            const unsigned rows = __builtin_amdgcn_readfirstlane(masks[k * N + i]);
+            if (rows == 0u) continue;
+            const float* src = seeds + static_cast<size_t>(k * N + i) * (kSeedFloats * kWave) + lane;
+            const float relx = src[7 * kWave], rely = src[8 * kWave], relz = src[9 * kWave];
+            const ResidualAdjoint ra = residual_backward(mlp + i * kMlpWeights, src[0 * kWave], src[1 * kWave], src[2 * kWave], src[3 * kWave],
+                                                         src[4 * kWave], src[5 * kWave], src[6 * kWave], wbar, lane, rows);
+            r00 += relx * ra.px; r01 += relx * ra.py; r02 += relx * ra.pz;
+            r10 += rely * ra.px; r11 += rely * ra.py; r12 += rely * ra.pz;
+            r20 += relz * ra.px; r21 += relz * ra.py; r22 += relz * ra.pz;
+            at0 -= in.r00 * ra.px + in.r01 * ra.py + in.r02 * ra.pz;
+            at1 -= in.r10 * ra.px + in.r11 * ra.py + in.r12 * ra.pz;
+            at2 -= in.r20 * ra.px + in.r21 * ra.py + in.r22 * ra.pz;
         }
+        const float packed[16] = {at0, at1, at2, r00, r01, r02, r10, r11, r12, r20, r21, r22, 0.0f, 0.0f, 0.0f, 0.0f};
+        const float mine = wave_reduce16_scatter(packed, lane);
+        if (lane < kGradStride) G[i * kGradStride + lane] += mine;
+        // flush this instance's MLP weight adjoints into the wave's global row (wave-private RMW)
+        float* dst = my_mlp + static_cast<size_t>(i) * kMlpWeights;
+        wave_lds_sync();
+        for (int idx = lane; idx < kMlpWeights; idx += kWave) { dst[idx] += wbar[idx]; wbar[idx] = 0.0f; }
+        wave_lds_sync();
     }
 }
 
@@ -450,7 +467,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
     const float* __restrict__ origins, const float* __restrict__ directions,
     const float* __restrict__ distances, int num_distances,
     const float* __restrict__ grad_labels, const float* __restrict__ grad_gradients, const float* __restrict__ grad_weights,
-    float* __restrict__ partials, float* __restrict__ mlp_partials, float4* __restrict__ residual_cache) {
+    float* __restrict__ partials, float* __restrict__ mlp_partials, float4* __restrict__ residual_cache, float* __restrict__ seed_cache) {
     apply_device_schedule(f, c);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = wave_in_block();
@@ -462,10 +479,13 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
     float* dist = wbar + (kResidual ? kMlpLdsFloats : 0);                // instance + the transposition scratch (residual.h), 16 B aligned
     float* lam = dist + num_distances;
     float* G = lam + N;
+    unsigned* masks = reinterpret_cast<unsigned*>(G + N * kGradStride);  // residual only: [kRounds][N] tile masks of the MLP adjoint
     for (int idx = lane; idx < N * kGradStride; idx += kWave) G[idx] = 0.0f;
     const size_t wave_global0 = static_cast<size_t>(blockIdx.x) * waves_per_block() + wave;
     float* my_mlp = kResidual ? mlp_partials + wave_global0 * (static_cast<size_t>(N) * kMlpWeights) : nullptr;
-    float4* rcache = kResidual ? residual_cache + wave_global0 * (static_cast<size_t>(kRounds) * N * kWave) : nullptr;   // [round][instance][lane]
+    // per-wave workspace of the residual adjoint: [round][instance][lane] residual jets (float4), then [round][instance][10][lane] seeds
+    float4* rcache = kResidual ? residual_cache + wave_global0 * (static_cast<size_t>(kRounds) * N * kWave) : nullptr;
+    float* seeds = kResidual ? seed_cache + wave_global0 * (static_cast<size_t>(kRounds) * N * kSeedFloats * kWave) : nullptr;
     if (kResidual) {
         for (int idx = lane; idx < N * kMlpWeights; idx += kWave) my_mlp[idx] = 0.0f;
         for (int idx = lane; idx < kMlpWeights; idx += kWave) wbar[idx] = 0.0f;
@@ -488,7 +508,11 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
         const float* gw_row = grad_weights ? grad_weights + static_cast<size_t>(ray) * num_points : nullptr;
         const float* gg_row = grad_gradients ? grad_gradients + static_cast<size_t>(ray) * num_points * 3 : nullptr;
         if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, gw_row, gg_row, lane)) continue;      // exact zero adjoint
-        adjoint_phase_b<kRounds, kResidual>(st, instances, mlp, N, f.inv_t, num_points, lam, G, wbar, my_mlp, lane, rcache);
+        adjoint_phase_b<kRounds, kResidual>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, seeds, masks);
+        if (kResidual) {
+            wave_lds_sync();                                                 // masks: written by lanes < kRounds, read by all
+            adjoint_phase_mlp<kRounds>(instances, mlp, N, G, wbar, my_mlp, lane, seeds, masks);
+        }
     }
     wave_lds_sync();
     float* out = partials + wave_global0 * (N * kGradStride);
@@ -625,7 +649,7 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
             st.sa[k].lam_z = acc * st.sa[k].inv_z;
         }
         if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, nullptr, nullptr, lane)) continue;
-        adjoint_phase_b<kRounds, false>(st, instances, nullptr, N, f.inv_t, num_points, lam, G, nullptr, nullptr, lane, nullptr);
+        adjoint_phase_b<kRounds, false>(st, instances, nullptr, N, f.inv_t, num_points, lam, G, lane, nullptr, nullptr, nullptr);
     }
     wave_lds_sync();
     const size_t wave_global = static_cast<size_t>(blockIdx.x) * waves_per_block() + wave;

@@ -382,8 +382,8 @@ struct ResidualAdjoint { float px, py, pz; };
 
 // Adjoint of residual_forward at the wave's local positions p: res_bar = dL/d residual, (gbx, gby, gbz) = dL/d(grad_p residual).
 // Adds dL/dw into `mlp_lds` (the wave's LDS: wbar [1617], then the transposition scratch); returns dL/dp per lane.
-// Not inlined (measured: inlined into the adjoint kernel it spills inside the tile loop, 111 vs 100 ms on the C3-shaped bench).
-VSRD_RESIDUAL_FN ResidualAdjoint residual_backward(const float* w_in, float px, float py, float pz,
+// Inlined into its only call site, adjoint_phase_mlp (render_kernels.h), which runs when nothing else of the ray is live.
+__device__ __forceinline__ ResidualAdjoint residual_backward(const float* w_in, float px, float py, float pz,
                                                                        float res_bar, float gbx, float gby, float gbz, float* mlp_lds, int lane, unsigned tiles_in) {
     const int g = lane >> 4, m = lane & 15;
     const unsigned tiles = __builtin_amdgcn_readfirstlane(tiles_in);
