@@ -127,13 +127,13 @@ int rounds_for(int points) {
 constexpr int kMaxBlocksResidual = 512;     // residual adjoint: one wave per SIMD resident; more workgroups than CUs = load balancing (each wave owns N x 1617 partials)
 
 // Residual adjoint, per wave: the residual jets (value + local gradient) the forward sweep leaves for the per-instance phase
-// [round <= 4][N][64] float4, and the seeds that phase leaves for the MLP adjoint [round <= 4][N][10][64].
+// [round <= 4][N][64] float4, and the seeds that phase leaves for the MLP adjoint [ray of batch][round <= 4][N][10][64].
 size_t residual_jet_floats(int num_instances, bool residual) {
     return residual ? static_cast<size_t>(kMaxBlocksResidual) * kMaxWavesPerBlock * 4 * num_instances * kWave * 4 : 0;
 }
 size_t residual_cache_floats(int num_instances, bool residual) {
     return residual_jet_floats(num_instances, residual) +
-           (residual ? static_cast<size_t>(kMaxBlocksResidual) * kMaxWavesPerBlock * 4 * num_instances * kSeedFloats * kWave : 0);
+           (residual ? static_cast<size_t>(kMaxBlocksResidual) * kMaxWavesPerBlock * kMlpBatch * 4 * num_instances * kSeedFloats * kWave : 0);
 }
 
 size_t partial_floats(int num_instances, bool residual) {

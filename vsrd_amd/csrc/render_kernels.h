@@ -11,10 +11,11 @@ constexpr int kBlockThreads = kMaxWavesPerBlock * kWave;   // launch bound; the 
 __device__ __forceinline__ int waves_per_block() { return static_cast<int>(blockDim.x) >> 6; }
 constexpr int kGradStride = kInstanceStride;   // grad_instances rows are [t(3) R(9) dim(3) pad]
 constexpr int kSeedFloats = 10;                // per sample: local position (3), d_bar, gl_bar (3), x - t (3)
+constexpr int kMlpBatch = 8;                   // rays whose MLP adjoints are run together, instance-major (adjoint_phase_mlp)
 
 // Floats of LDS one wave of render_backward_kernel owns (a multiple of 4: the partitions stay 16-byte aligned).
 __host__ __device__ constexpr int backward_lds_floats(int num_distances, int num_instances, bool residual) {
-    return ((residual ? kMlpLdsFloats + 4 * num_instances : 0) + num_distances + num_instances + num_instances * kGradStride + 3) & ~3;
+    return ((residual ? kMlpLdsFloats + kMlpBatch * 4 * num_instances : 0) + num_distances + num_instances + num_instances * kGradStride + 3) & ~3;
 }
 
 // The instance block [N,16] travels as its own `const float* __restrict__` kernel argument (not inside this
@@ -419,27 +420,29 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
     }
 }
 
-// Phase B, residual part: the MLP adjoint of every (instance, round) the box phase left seeds for.  It runs AFTER the box phase,
-// when the per-ray adjoint state is dead: residual_backward (inlined here, its only call site) needs ~400 registers, and as a
-// function called from inside the box phase it saved and restored 217 of them per call -- 200 GB of scratch traffic per launch
-// on the C3-shaped bench (profiles/r01_c3).  The seeds (10 floats per sample) go through the workspace instead.
+// Phase B, residual part: the MLP adjoint of every (ray of the batch, instance, round) the box phase left seeds for.
+// * It runs AFTER the box phases, when no per-ray adjoint state is live: residual_backward (inlined here, its only call site) needs
+//   ~400 registers, and as a function called from inside the box phase it saved and restored 217 of them per call -- 200 GB of
+//   scratch traffic per launch on the C3-shaped bench.  The seeds (10 floats per sample) go through the workspace instead.
+// * It is instance-major over a batch of kBatch rays: the 1617 weight adjoints of an instance are accumulated in LDS over the whole
+//   batch and flushed into the wave's global partial row once per (batch, instance) instead of once per (ray, instance) (that
+//   read-modify-write was 27 of the remaining 30 GB), the weight operands are loaded once, and one butterfly serves the batch.
 // Its result p_bar = dL/d(local position) adds  rel (x) p_bar  to the rotation adjoint and  -R p_bar  to the translation adjoint.
-template <int kRounds>
+template <int kRounds, int kBatch>
 __device__ __forceinline__ void adjoint_phase_mlp(const float* __restrict__ instances, const float* __restrict__ mlp, int N, float* G, float* wbar,
                                                   float* my_mlp, int lane, const float* seeds, const unsigned* masks) {
     for (int i = 0; i < N; ++i) {
         unsigned any = 0u;
-#pragma unroll
-        for (int k = 0; k < kRounds; ++k) any |= masks[k * N + i];
+        for (int slot = 0; slot < kBatch * kRounds; ++slot) any |= masks[slot * N + i];
         if (__builtin_amdgcn_readfirstlane(any) == 0u) continue;
         const Instance in = load_instance(instances, i);
         float at0 = 0, at1 = 0, at2 = 0;
         float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
 #pragma unroll 1
-        for (int k = 0; k < kRounds; ++k) {
-            const unsigned rows = __builtin_amdgcn_readfirstlane(masks[k * N + i]);
+        for (int slot = 0; slot < kBatch * kRounds; ++slot) {           // slot = ray-of-batch * kRounds + round
+            const unsigned rows = __builtin_amdgcn_readfirstlane(masks[slot * N + i]);
             if (rows == 0u) continue;
-            const float* src = seeds + static_cast<size_t>(k * N + i) * (kSeedFloats * kWave) + lane;
+            const float* src = seeds + static_cast<size_t>(slot * N + i) * (kSeedFloats * kWave) + lane;
             const float relx = src[7 * kWave], rely = src[8 * kWave], relz = src[9 * kWave];
             const ResidualAdjoint ra = residual_backward(mlp + i * kMlpWeights, src[0 * kWave], src[1 * kWave], src[2 * kWave], src[3 * kWave],
                                                          src[4 * kWave], src[5 * kWave], src[6 * kWave], wbar, lane, rows);
@@ -479,13 +482,13 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
     float* dist = wbar + (kResidual ? kMlpLdsFloats : 0);                // instance + the transposition scratch (residual.h), 16 B aligned
     float* lam = dist + num_distances;
     float* G = lam + N;
-    unsigned* masks = reinterpret_cast<unsigned*>(G + N * kGradStride);  // residual only: [kRounds][N] tile masks of the MLP adjoint
+    unsigned* masks = reinterpret_cast<unsigned*>(G + N * kGradStride);  // residual only: [kMlpBatch][kRounds][N] tile masks of the MLP adjoint
     for (int idx = lane; idx < N * kGradStride; idx += kWave) G[idx] = 0.0f;
     const size_t wave_global0 = static_cast<size_t>(blockIdx.x) * waves_per_block() + wave;
     float* my_mlp = kResidual ? mlp_partials + wave_global0 * (static_cast<size_t>(N) * kMlpWeights) : nullptr;
-    // per-wave workspace of the residual adjoint: [round][instance][lane] residual jets (float4), then [round][instance][10][lane] seeds
+    // per-wave workspace of the residual adjoint: [round][instance][lane] residual jets (float4); [ray of batch][round][instance][10][lane] seeds
     float4* rcache = kResidual ? residual_cache + wave_global0 * (static_cast<size_t>(kRounds) * N * kWave) : nullptr;
-    float* seeds = kResidual ? seed_cache + wave_global0 * (static_cast<size_t>(kRounds) * N * kSeedFloats * kWave) : nullptr;
+    float* seeds = kResidual ? seed_cache + wave_global0 * (static_cast<size_t>(kMlpBatch) * kRounds * N * kSeedFloats * kWave) : nullptr;
     if (kResidual) {
         for (int idx = lane; idx < N * kMlpWeights; idx += kWave) my_mlp[idx] = 0.0f;
         for (int idx = lane; idx < kMlpWeights; idx += kWave) wbar[idx] = 0.0f;
@@ -493,25 +496,36 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
     Shading sh = c.sh;
     sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, N, f.inv_t) + (kResidual ? 1.0f : 0.0f);
     const int stride = static_cast<int>(gridDim.x) * waves_per_block();
-    for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
-        wave_lds_sync();
-        const float lam_lane = (lane < N) ? grad_labels[static_cast<size_t>(ray) * N + lane] : 0.0f;
-        if (grad_gradients == nullptr && grad_weights == nullptr && wave_max(fabsf(lam_lane)) == 0.0f) continue;  // nothing flows back
-        const Ray r = load_ray(origins, directions, c.origin_stride, ray);
-        const float* src = distances + static_cast<size_t>(ray) * num_distances;
-        for (int idx = lane; idx < num_distances; idx += kWave) dist[idx] = src[idx];
-        if (lane < N) lam[lane] = lam_lane;
-        wave_lds_sync();
-        if (dist[0] != dist[0]) continue;                            // NaN sentinel: ray skipped by the forward
-        RayAdjoint<kRounds> st;
-        adjoint_forward_sweep<kRounds, kResidual, false>(st, instances, mlp, N, sh, r, dist, num_points, lam, nullptr, lane, rcache);
-        const float* gw_row = grad_weights ? grad_weights + static_cast<size_t>(ray) * num_points : nullptr;
-        const float* gg_row = grad_gradients ? grad_gradients + static_cast<size_t>(ray) * num_points * 3 : nullptr;
-        if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, gw_row, gg_row, lane)) continue;      // exact zero adjoint
-        adjoint_phase_b<kRounds, kResidual>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, seeds, masks);
+    constexpr int kBatch = kResidual ? kMlpBatch : 1;
+    for (int first = static_cast<int>(blockIdx.x) * waves_per_block() + wave; first < c.num_rays; first += stride * kBatch) {
+#pragma unroll 1
+        for (int b = 0; b < kBatch; ++b) {
+            const int ray = first + b * stride;
+            unsigned* ray_masks = masks + b * kRounds * N;
+            float* ray_seeds = kResidual ? seeds + static_cast<size_t>(b) * (kRounds * N * kSeedFloats * kWave) : nullptr;
+            wave_lds_sync();
+            if (kResidual) {
+                for (int idx = lane; idx < kRounds * N; idx += kWave) ray_masks[idx] = 0u;      // a ray that exits early leaves no work
+            }
+            if (ray >= c.num_rays) continue;
+            const float lam_lane = (lane < N) ? grad_labels[static_cast<size_t>(ray) * N + lane] : 0.0f;
+            if (grad_gradients == nullptr && grad_weights == nullptr && wave_max(fabsf(lam_lane)) == 0.0f) continue;  // nothing flows back
+            const Ray r = load_ray(origins, directions, c.origin_stride, ray);
+            const float* src = distances + static_cast<size_t>(ray) * num_distances;
+            for (int idx = lane; idx < num_distances; idx += kWave) dist[idx] = src[idx];
+            if (lane < N) lam[lane] = lam_lane;
+            wave_lds_sync();
+            if (dist[0] != dist[0]) continue;                            // NaN sentinel: ray skipped by the forward
+            RayAdjoint<kRounds> st;
+            adjoint_forward_sweep<kRounds, kResidual, false>(st, instances, mlp, N, sh, r, dist, num_points, lam, nullptr, lane, rcache);
+            const float* gw_row = grad_weights ? grad_weights + static_cast<size_t>(ray) * num_points : nullptr;
+            const float* gg_row = grad_gradients ? grad_gradients + static_cast<size_t>(ray) * num_points * 3 : nullptr;
+            if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, gw_row, gg_row, lane)) continue;      // exact zero adjoint
+            adjoint_phase_b<kRounds, kResidual>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, ray_seeds, ray_masks);
+        }
         if (kResidual) {
             wave_lds_sync();                                                 // masks: written by lanes < kRounds, read by all
-            adjoint_phase_mlp<kRounds>(instances, mlp, N, G, wbar, my_mlp, lane, seeds, masks);
+            adjoint_phase_mlp<kRounds, kBatch>(instances, mlp, N, G, wbar, my_mlp, lane, seeds, masks);
         }
     }
     wave_lds_sync();
