@@ -85,3 +85,42 @@ def test_config5_shapes_band(dev):
     finally:
         renderers.CULLING = True
     assert (ref["labels"] - out["labels"]).abs().max() < 2e-6
+
+
+def test_config3_shapes_many_instances(dev):
+    """Residual field at the size limits: N = 64 instances and S = 100 samples (the reference's own S: 199 points = 4 wave rounds of the
+    MLP adjoint).  Properties only: finite, bounded labels, sorted distances, the fused two-pass kernel agrees with rendering at its own
+    saved distances, gradients (boxes and MLP weights) are deterministic, and per-tile culling does not change them."""
+    import bench
+    from vsrd_amd import fields, rendering
+    from vsrd_amd.rendering import renderers
+    N, S, V, H, W = 64, 100, 1, 376, 1408
+    det, cam, dirs = scene(dev, N, V, H, W, seed=4)
+    rows = dirs[0, 200:204].reshape(-1, 3)[::4].contiguous()                      # 1408 rays
+    boxes = det()
+    mlp0 = (torch.randn(N, 1617, generator=torch.Generator().manual_seed(9)) * 0.3).to(dev)
+
+    def run():
+        inst = fields.pack_instances(boxes["locations"][0], boxes["orientations"][0], boxes["dimensions"][0]).detach().requires_grad_(True)
+        mlp = mlp0.clone().requires_grad_(True)
+        block = fields.FieldBlock(inst, 0.3, mlp, None)
+        out = rendering.render_hierarchical(block, cam[0], rows, (0.0, 100.0), S, 0.3, 0.7, seed=3, return_gradients=True)
+        hit = out["labels"].detach().sum(-1) > 0.5
+        loss = (out["labels"] ** 2).sum() + 0.01 * ((out["gradients"][hit].norm(dim=-1) - 1.0) ** 2).mean()
+        return block, out, torch.autograd.grad(loss, (inst, mlp))
+
+    block, out, grads = run()
+    check_properties(out, N, S)
+    assert all(torch.isfinite(g).all() for g in grads) and float(grads[1].abs().max()) > 0
+    labels, _, _ = rendering.render_at_distances(block, cam[0], rows, out["distances"], 0.3, 0.7)
+    assert (labels - out["labels"]).abs().max() < 1e-5
+    _, _, again = run()
+    assert all(torch.equal(a, b) for a, b in zip(grads, again))                   # deterministic two-stage reduction
+    renderers.CULLING = False
+    try:
+        _, ref, ref_grads = run()
+    finally:
+        renderers.CULLING = True
+    assert (ref["labels"] - out["labels"]).abs().max() < 2e-6
+    for a, b in zip(grads, ref_grads):
+        assert (a - b).abs().max() <= 2e-4 * max(float(b.abs().max()), 1e-6)
