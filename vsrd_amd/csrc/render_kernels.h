@@ -225,6 +225,10 @@ struct RayAdjoint {
     SampleAdjoint sa[kRounds];
     Opacity op[kRounds];
     float gx[kRounds], gy[kRounds], gz[kRounds], trans[kRounds], delta[kRounds], thr[kRounds];
+    // culling decisions of the forward sweep (wave-uniform, bit i = instance i): evaluated in the round at all / in 16-lane row q
+    // (residual fields).  The later phases read these instead of repeating the bound test per instance and round.
+    unsigned long long near_any[kRounds];
+    unsigned long long near_rows[kRounds][4];
 };
 
 // Phase A, forward sweep: union sums (with Lambda = sum_n lambda_n e_n when `lam` is given), opacity, transmittance.
@@ -251,6 +255,8 @@ __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, 
         for (int i = 0; i < N; ++i) nearest = fminf(nearest, centre_distance(load_instance(instances, i), st.sa[k].x, st.sa[k].y, st.sa[k].z));
         st.thr[k] = nearest * (1.0f + kCullSlack) + sh.cull;
         UnionSums sums = union_init();
+        st.near_any[k] = 0ull;
+        if (kResidual) st.near_rows[k][0] = st.near_rows[k][1] = st.near_rows[k][2] = st.near_rows[k][3] = 0ull;
         for (int i = 0; i < N; ++i) {
             const Instance in = load_instance(instances, i);
             const float lb = centre_distance(in, st.sa[k].x, st.sa[k].y, st.sa[k].z) * (1.0f - kCullSlack) - bounding_radius(in);
@@ -258,6 +264,11 @@ __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, 
             if (near == 0ull) {
                 if (kCacheD) dcache[i * kWave + lane] = lb;      // > thr on every lane: marks the instance as culled
                 continue;
+            }
+            st.near_any[k] |= 1ull << i;
+            if (kResidual) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) st.near_rows[k][q] |= ((near >> (16 * q)) & 0xFFFFull) ? (1ull << i) : 0ull;
             }
             Residual res;
             const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, st.sa[k].x, st.sa[k].y, st.sa[k].z, rows_with(near), &res);
@@ -348,16 +359,17 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
                                                 int N, float inv_t, int num_points, const float* lam, float* G, int lane,
                                                 const float4* rcache, float* seeds, unsigned* masks) {
     for (int i = 0; i < N; ++i) {
-        const Instance in = load_instance(instances, i);
-        const float lam_i = lam[i];
-        const float rho = bounding_radius(in);
         bool active[kRounds];
         unsigned tiles[kRounds];
         bool any_active = false;
 #pragma unroll
-        for (int k = 0; k < kRounds; ++k) {
-            const float lb = centre_distance(in, st.sa[k].x, st.sa[k].y, st.sa[k].z) * (1.0f - kCullSlack) - rho;
-            tiles[k] = rows_with(__ballot(lb <= st.thr[k]));
+        for (int k = 0; k < kRounds; ++k) {                                   // the forward sweep's culling decisions (scalar bit tests)
+            tiles[k] = static_cast<unsigned>((st.near_any[k] >> i) & 1ull);
+            if (kResidual) {
+                tiles[k] = 0u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tiles[k] |= static_cast<unsigned>((st.near_rows[k][q] >> i) & 1ull) << q;
+            }
             active[k] = (k * kWave < num_points) && tiles[k] != 0u;
             any_active = any_active || active[k];
         }
@@ -368,6 +380,8 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
             masks[lane * N + i] = mine;
         }
         if (!any_active) continue;                                            // negligible for this ray (field.h culling)
+        const Instance in = load_instance(instances, i);
+        const float lam_i = lam[i];
         float at0 = 0, at1 = 0, at2 = 0, ad0 = 0, ad1 = 0, ad2 = 0;
         float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
 #pragma unroll
@@ -654,9 +668,8 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
             float acc = 0.0f;
             for (int i = 0; i < N; ++i) {
                 if (lam[i] == 0.0f) continue;                               // wave-uniform
+                if (!((st.near_any[k] >> i) & 1ull)) continue;                // culled by the forward sweep
                 const Instance in = load_instance(instances, i);
-                const float lb = centre_distance(in, st.sa[k].x, st.sa[k].y, st.sa[k].z) * (1.0f - kCullSlack) - bounding_radius(in);
-                if (!wave_any(lb <= st.thr[k])) continue;
                 const BoxEval e = eval_box(in, st.sa[k].x, st.sa[k].y, st.sa[k].z);
                 acc += lam[i] * fast_exp(-(e.d - st.sa[k].m) * sh.inv_t);
             }
