@@ -252,14 +252,19 @@ __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, 
         st.sa[k].x = r.ox + r.rx * mid; st.sa[k].y = r.oy + r.ry * mid; st.sa[k].z = r.oz + r.rz * mid;
         // culling (field.h): nearest centre first, then one ballot per instance
         float nearest = 3.0e38f;
-        for (int i = 0; i < N; ++i) nearest = fminf(nearest, centre_distance(load_instance(instances, i), st.sa[k].x, st.sa[k].y, st.sa[k].z));
+        for (int i = 0; i < N; ++i) {
+            const float centre = centre_distance(load_instance(instances, i), st.sa[k].x, st.sa[k].y, st.sa[k].z);
+            if (kCacheD) dcache[i * kWave + lane] = centre;          // kept for the bound test below (own lane's slot: no hazard)
+            nearest = fminf(nearest, centre);
+        }
         st.thr[k] = nearest * (1.0f + kCullSlack) + sh.cull;
         UnionSums sums = union_init();
         st.near_any[k] = 0ull;
         if (kResidual) st.near_rows[k][0] = st.near_rows[k][1] = st.near_rows[k][2] = st.near_rows[k][3] = 0ull;
         for (int i = 0; i < N; ++i) {
             const Instance in = load_instance(instances, i);
-            const float lb = centre_distance(in, st.sa[k].x, st.sa[k].y, st.sa[k].z) * (1.0f - kCullSlack) - bounding_radius(in);
+            const float centre = kCacheD ? dcache[i * kWave + lane] : centre_distance(in, st.sa[k].x, st.sa[k].y, st.sa[k].z);
+            const float lb = centre * (1.0f - kCullSlack) - bounding_radius(in);
             const unsigned long long near = __ballot(lb <= st.thr[k]);
             if (near == 0ull) {
                 if (kCacheD) dcache[i * kWave + lane] = lb;      // > thr on every lane: marks the instance as culled
