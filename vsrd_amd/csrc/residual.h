@@ -101,6 +101,20 @@ __device__ __forceinline__ GlobalWeights uniform_weights(const float* p) {
     return reinterpret_cast<GlobalWeights>((static_cast<unsigned long long>(hi) << 32) | lo);
 }
 
+// Sum over the 16 lanes of each row (every lane of the row receives it).
+__device__ __forceinline__ float row_sum16(float v) {
+    v += dpp_move<kDppQuadXor1>(0.0f, v);
+    v += dpp_move<kDppQuadXor2>(0.0f, v);
+    v += dpp_move<kDppRowHalfMirror>(0.0f, v);
+    v += dpp_move<kDppRowMirror>(0.0f, v);
+    return v;
+}
+
+// LayerNorm's mean subtraction is folded into the weights: with C = I - 11^T/16, LN(W a + b) = LN(C W a + C b) and C W a + C b has zero
+// channel mean by construction -- so every linear that feeds a LayerNorm (all four) is loaded with its column means (over the output
+// channel = over the 16 lanes of a row) and its bias mean removed, and the norm needs no mean / tangent-mean reductions (4 of its 8).
+// The adjoint is unchanged: the LayerNorm Jacobian P already produces zero-mean adjoints, so W_bar = z_bar a^T and W^T z_bar hold for
+// the original W.
 __device__ __forceinline__ void load_forward_weights(GlobalWeights w, int lane, ForwardWeights& fw) {
     const int g = lane >> 4, o = lane & 15;
     const GlobalWeights row0 = w + o * kMlpRow0 + 4 * g;
@@ -119,6 +133,15 @@ __device__ __forceinline__ void load_forward_weights(GlobalWeights w, int lane, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) fw.w4[j] = w[kMlpHead + 4 * g + j];
     fw.b4 = w[kMlpHead + kMlpHidden];
+#pragma unroll
+    for (int s = 0; s < 12; ++s) fw.a0[s] -= row_sum16(fw.a0[s]) * (1.0f / kMlpHidden);
+    fw.b0 -= splat4(rows_sum(hsum4(fw.b0)) * (1.0f / kMlpHidden));
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fw.a[l][s] -= row_sum16(fw.a[l][s]) * (1.0f / kMlpHidden);
+        fw.b[l] -= splat4(rows_sum(hsum4(fw.b[l])) * (1.0f / kMlpHidden));
+    }
 }
 
 // Encoder features of one tile: row g evaluates octaves 2 g and 2 g + 1 of every coordinate, i.e. features 4 g .. 4 g + 3
@@ -173,24 +196,20 @@ __device__ __forceinline__ void linear_tile(const float (&a)[4], f32x4 bias, con
 }
 
 // LayerNorm (no affine) followed by exact GELU on a tile jet, in place.
+// The jet arrives with zero channel mean (value and tangents): see load_forward_weights.
 __device__ __forceinline__ void norm_gelu_tile(TileJet& z) {
-    const float mean = rows_sum(hsum4(z.v)) * (1.0f / kMlpHidden);
-    f32x4 y = z.v - splat4(mean);
-    const float var = rows_sum(dot4(y, y)) * (1.0f / kMlpHidden);
+    const float var = rows_sum(dot4(z.v, z.v)) * (1.0f / kMlpHidden);
     const float inv_s = __builtin_amdgcn_rsqf(var + kLayerNormEps);
-    y *= splat4(inv_s);
-    float tmean[3], q[3];
+    const f32x4 y = z.v * splat4(inv_s);
+    float q[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        tmean[c] = rows_sum(hsum4(z.t[c])) * (1.0f / kMlpHidden);
-        q[c] = rows_sum(dot4(y, z.t[c])) * (1.0f / kMlpHidden);
-    }
+    for (int c = 0; c < 3; ++c) q[c] = rows_sum(dot4(y, z.t[c])) * (1.0f / kMlpHidden);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const Gauss n = gauss(y[j]);
         const float g1 = n.cdf + y[j] * n.pdf;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) z.t[c][j] = (z.t[c][j] - tmean[c] - y[j] * q[c]) * inv_s * g1;
+        for (int c = 0; c < 3; ++c) z.t[c][j] = (z.t[c][j] - y[j] * q[c]) * inv_s * g1;
         z.v[j] = y[j] * n.cdf;
     }
 }
@@ -303,18 +322,12 @@ struct TileState {
     __device__ __forceinline__ f32x4 da(int c) const { return dy[c] * g1; }
 };
 
-__device__ __forceinline__ void tile_state(const TileJet& z, TileState& b) {
-    const float mean = rows_sum(hsum4(z.v)) * (1.0f / kMlpHidden);
-    b.y = z.v - splat4(mean);
-    const float var = rows_sum(dot4(b.y, b.y)) * (1.0f / kMlpHidden);
+__device__ __forceinline__ void tile_state(const TileJet& z, TileState& b) {      // z has zero channel mean (load_forward_weights)
+    const float var = rows_sum(dot4(z.v, z.v)) * (1.0f / kMlpHidden);
     b.inv_s = __builtin_amdgcn_rsqf(var + kLayerNormEps);
-    b.y *= splat4(b.inv_s);
-    float tmean[3];
+    b.y = z.v * splat4(b.inv_s);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        tmean[c] = rows_sum(hsum4(z.t[c])) * (1.0f / kMlpHidden);
-        b.q[c] = rows_sum(dot4(b.y, z.t[c])) * (1.0f / kMlpHidden);
-    }
+    for (int c = 0; c < 3; ++c) b.q[c] = rows_sum(dot4(b.y, z.t[c])) * (1.0f / kMlpHidden);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float y = b.y[j];
@@ -324,7 +337,7 @@ __device__ __forceinline__ void tile_state(const TileJet& z, TileState& b) {
         b.a[j] = y * n.cdf;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            b.dy[c][j] = (z.t[c][j] - tmean[c] - y * b.q[c]) * b.inv_s;
+            b.dy[c][j] = (z.t[c][j] - y * b.q[c]) * b.inv_s;
         }
     }
 }
@@ -367,14 +380,6 @@ __device__ __forceinline__ void gelu_norm_adjoint_tile(const TileState& b, f32x4
     for (int c = 0; c < 3; ++c) { zb.v -= b.dy[c] * splat4(dot[c]); zb.t[c] = dyb[c]; }
 }
 
-// Sum over the 16 lanes of each row (every lane of the row receives it).
-__device__ __forceinline__ float row_sum16(float v) {
-    v += dpp_move<kDppQuadXor1>(0.0f, v);
-    v += dpp_move<kDppQuadXor2>(0.0f, v);
-    v += dpp_move<kDppRowHalfMirror>(0.0f, v);
-    v += dpp_move<kDppRowMirror>(0.0f, v);
-    return v;
-}
 __device__ __forceinline__ float pick4(f32x4 v, int m) { return (m == 0) ? v[0] : ((m == 1) ? v[1] : ((m == 2) ? v[2] : v[3])); }
 __device__ __forceinline__ f32x4 row_sum16(f32x4 v) { return f32x4{row_sum16(v[0]), row_sum16(v[1]), row_sum16(v[2]), row_sum16(v[3])}; }
 
