@@ -453,6 +453,16 @@ def test_argument_validation(dev):
     empty = rendering.render_at_distances(union, g["origins"][:0].to(dev), g["directions"][:0].to(dev),
                                           g["fine_distances"].t()[:0].contiguous().to(dev), 0.5)
     assert empty[0].shape == (0, 4)
+    # the small entry points reject what they cannot do instead of truncating
+    from vsrd_amd import losses
+    with pytest.raises(_lib.VsrdHipError):
+        losses.linear_sum_assignment(torch.zeros(65, 3, device=dev))                  # more than 64 rows
+    with pytest.raises(_lib.VsrdHipError):
+        rendering.sample_rays(torch.ones(10000, device=dev), 4096)                    # more than 2048 samples
+    with pytest.raises(_lib.VsrdHipError):
+        rendering.sample_rays(torch.ones(16), 4)                                      # host tensor
+    with pytest.raises(ValueError):
+        _lib.make_config(1, 8, (0.0, 1.0), 0.5, 1.0, 1e-6, 3, schedule=torch.ones(2, device=dev))
 
 
 def test_sphere_tracing_and_surface_normal_g9(dev):
