@@ -100,26 +100,30 @@ __global__ __launch_bounds__(256) void collect_kernel(const float* __restrict__ 
     }
 }
 
-// (key desc, index asc) order on (key, index) pairs; empty slots (key < 0) sort last.
+// (key desc, index asc) order on (key, index) pairs.
 __device__ __forceinline__ bool race_before(float ka, long long ia, float kb, long long ib) { return (ka > kb) || (ka == kb && ia < ib); }
 
+// One workgroup sorts the n (~1.1 k) candidates by (key desc, index asc) with a bitonic network over the next power of two of n
+// (LDS) and emits the first k: the order is unique, so the output is deterministic.
 __global__ __launch_bounds__(1024) void select_kernel(SampleScratch* scratch, int k, long long* __restrict__ indices) {
     __shared__ float keys[kSampleCandidates];
     __shared__ long long ids[kSampleCandidates];
-    const unsigned n = min(scratch->num_candidates, static_cast<unsigned>(kSampleCandidates));
-    for (int i = threadIdx.x; i < kSampleCandidates; i += blockDim.x) {
-        keys[i] = (static_cast<unsigned>(i) < n) ? scratch->candidate_keys[i] : -1.0f;
-        ids[i] = (static_cast<unsigned>(i) < n) ? scratch->candidate_indices[i] : 0x7fffffffffffffffll;
+    const int n = static_cast<int>(min(scratch->num_candidates, static_cast<unsigned>(kSampleCandidates)));
+    int padded = 2;
+    while (padded < n) padded <<= 1;
+    for (int i = threadIdx.x; i < padded; i += blockDim.x) {
+        keys[i] = (i < n) ? scratch->candidate_keys[i] : -1.0f;                      // empty slots sort last
+        ids[i] = (i < n) ? scratch->candidate_indices[i] : 0x7fffffffffffffffll;
     }
     __syncthreads();
-    for (int size = 2; size <= kSampleCandidates; size <<= 1) {
+    for (int size = 2; size <= padded; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = threadIdx.x; t < kSampleCandidates / 2; t += blockDim.x) {
+            for (int t = threadIdx.x; t < padded / 2; t += blockDim.x) {
                 const int lo = 2 * t - (t & (stride - 1));
                 const int hi = lo + stride;
-                const bool ascending_block = (lo & size) == 0;       // "ascending" in the race order = best first
+                const bool best_first = (lo & size) == 0;
                 const bool in_order = race_before(keys[lo], ids[lo], keys[hi], ids[hi]);
-                if (in_order != ascending_block) {
+                if (in_order != best_first) {
                     const float tk = keys[lo]; keys[lo] = keys[hi]; keys[hi] = tk;
                     const long long ti = ids[lo]; ids[lo] = ids[hi]; ids[hi] = ti;
                 }
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(1024) void select_kernel(SampleScratch* scratch, in
             __syncthreads();
         }
     }
-    for (int i = threadIdx.x; i < k; i += blockDim.x) indices[i] = (keys[i] > 0.0f) ? ids[i] : -1ll;   // -1: fewer than k positive weights
+    for (int i = threadIdx.x; i < k; i += blockDim.x) indices[i] = (i < padded && keys[i] > 0.0f) ? ids[i] : -1ll;   // -1: fewer than k positive weights
 }
 
 }  // namespace vsrd

@@ -81,6 +81,9 @@ class FrameOptimizer:
         self.ray_directions = dirs.reshape(-1, 3).contiguous()              # [V*H*W,3]
         self.flat_masks = inputs.soft_masks.reshape(-1, N)
         self.sampling_weights = self.flat_masks.max(dim=-1).values          # main.py:620-624
+        # the weights are fixed for the frame: the library sampler only visits the pixels that can be drawn at all
+        self.positive_pixels = torch.nonzero(self.sampling_weights > 0).flatten()
+        self.positive_weights = self.sampling_weights[self.positive_pixels].contiguous()
         self.pixels_per_view = H * W
         self.step_index = 0
 
@@ -90,7 +93,8 @@ class FrameOptimizer:
         uses the library's own sampler (same algorithm, Philox keyed by the device-side step counter): ATen's captured multinomial
         faults on replay with this torch build, and it sorts all V*H*W keys every step."""
         if self.graph:
-            return rendering.sample_rays(self.sampling_weights, self.config.num_rays, seed=self.config.seed + 1, stream_offset=self.step_tensor)
+            picks = rendering.sample_rays(self.positive_weights, self.config.num_rays, seed=self.config.seed + 1, stream_offset=self.step_tensor)
+            return self.positive_pixels[picks]
         return torch.multinomial(self.sampling_weights, self.config.num_rays, replacement=False)
 
     def field_block(self, outputs, temperature, mlp_weights=None):
