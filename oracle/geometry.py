@@ -174,3 +174,73 @@ def polygon_distance_map(polygon, image_size):
 def soft_mask(distance_map, inside, temperature=10.0):
     """geometric_transforms.py:306-307."""
     return torch.sigmoid(torch.where(inside, distance_map, -distance_map) / temperature)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# vsrd.operations.box_3d_iou (vsrd/operations/kitti360_operations.py:8-116; caller scripts/main.py:888-905), numpy float64.
+# The quirks are part of the behaviour and are kept: the clip's intersection point divides by (determinant + 0.01) (:30), the
+# intersection area is capped by the smaller footprint (:104), and the clip assumes counter-clockwise input without checking it --
+# for the corner order main.py feeds it the footprints arrive clockwise, the clip keeps the subject polygon, and the "IoU" becomes
+# min(area) / (area1 + area2 - min(area)).
+# ---------------------------------------------------------------------------------------------------------------------------
+
+def clip_polygon(subject, clip):
+    """Sutherland-Hodgman (:8-55): `subject` clipped by every edge of `clip`; None once nothing is left."""
+    import numpy as np
+    output = [np.asarray(p, dtype=np.float64) for p in subject]
+    previous = np.asarray(clip[-1], dtype=np.float64)
+    for vertex in clip:
+        current = np.asarray(vertex, dtype=np.float64)
+        edge = current - previous
+
+        def inside(p):
+            return edge[0] * (p[1] - previous[1]) > edge[1] * (p[0] - previous[0])
+
+        def crossing(s, e):
+            dc, dp = previous - current, s - e
+            n1 = previous[0] * current[1] - previous[1] * current[0]
+            n2 = s[0] * e[1] - s[1] * e[0]
+            n3 = 1.0 / (dc[0] * dp[1] - dc[1] * dp[0] + 0.01)
+            return np.array([(n1 * dp[0] - n2 * dc[0]) * n3, (n1 * dp[1] - n2 * dc[1]) * n3])
+
+        source, output = output, []
+        s = source[-1]
+        for e in source:
+            if inside(e):
+                if not inside(s):
+                    output.append(crossing(s, e))
+                output.append(e)
+            elif inside(s):
+                output.append(crossing(s, e))
+            s = e
+        previous = current
+        if not output:
+            return None
+    return output
+
+
+def box_3d_iou(corners1, corners2):
+    """(:83-116) corners [8,3], up = +Z, corners 0-3 the upper face -> (3-D IoU, bird's-eye-view IoU)."""
+    import numpy as np
+    from scipy.spatial import ConvexHull
+    c1, c2 = np.asarray(corners1, dtype=np.float64), np.asarray(corners2, dtype=np.float64)
+
+    def footprint(c):
+        return [(c[i, 0], c[i, 1]) for i in (3, 2, 1, 0)]
+
+    def shoelace(poly):
+        x, y = np.array([p[0] for p in poly]), np.array([p[1] for p in poly])
+        return 0.5 * abs(np.dot(x, np.roll(y, 1)) - np.dot(y, np.roll(x, 1)))
+
+    def volume(c):
+        return np.linalg.norm(c[0] - c[1]) * np.linalg.norm(c[1] - c[2]) * np.linalg.norm(c[0] - c[4])
+
+    f1, f2 = footprint(c1), footprint(c2)
+    area1, area2 = shoelace(f1), shoelace(f2)
+    overlap = clip_polygon(f1, f2)
+    inter_area = ConvexHull(np.array(overlap)).volume if overlap is not None else 0.0
+    inter_area = min(min(area1, area2), inter_area)
+    iou_bev = inter_area / (area1 + area2 - inter_area)
+    height = max(0.0, min(c1[0, 2], c2[0, 2]) - max(c1[4, 2], c2[4, 2]))
+    inter_volume = inter_area * height
+    return inter_volume / (volume(c1) + volume(c2) - inter_volume), iou_bev

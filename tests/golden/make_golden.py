@@ -18,6 +18,7 @@ in an importable reference module is executed by the reference itself.
 
 Usage:  python tests/golden/make_golden.py   (writes tests/golden/*.npz)
 """
+import math
 import os
 import sys
 import types
@@ -527,9 +528,37 @@ def golden_loss_library():
     save("g13_loss_library", **arrays)
 
 
+def golden_box_3d_iou(ref):
+    """G9 of SURVEY.md §8c: vsrd.operations.box_3d_iou on box pairs prepared as scripts/main.py:888-905 does
+    (corners @ rotation_matrix_x(-pi/2).T, so that "up" is Z): identical, shifted, yawed, contained, touching and disjoint."""
+    g = torch.Generator().manual_seed(11)
+    bp = ref.box_parameters.BoxParameters3D(1, 8)
+    with torch.no_grad():
+        bp.locations.copy_(torch.randn(1, 8, 3, generator=g) * 0.3)
+        bp.dimensions.copy_(torch.randn(1, 8, 3, generator=g))
+        bp.orientations.copy_(torch.randn(1, 8, 2, generator=g))
+    first = bp()["boxes_3d"][0].detach()
+    second = first.clone()
+    centre = first.mean(1, keepdim=True)
+    second[1] = first[1] + torch.tensor([0.4, 0.0, 0.7])                                  # shifted
+    yaw = ref.box_parameters.rotation_matrix_y(torch.tensor(0.9659), torch.tensor(0.2588))    # 15 degrees about y
+    second[2] = (first[2] - centre[2]) @ yaw.T + centre[2]
+    second[3] = (first[3] - centre[3]) * 0.5 + centre[3]                                   # contained
+    second[4] = first[4] + torch.tensor([30.0, 0.0, 0.0])                                  # disjoint
+    second[5] = (first[5] - centre[5]) @ yaw.T @ yaw.T + centre[5] + torch.tensor([0.3, 0.2, -0.5])
+    second[6] = first[6] + torch.tensor([0.0, 0.6, 0.0])                                   # shifted along the up axis only
+    second[7] = (first[7] - centre[7]) * 1.7 + centre[7] + torch.tensor([-0.2, 0.0, 0.1])  # containing
+    rotation = ref.geo.rotation_matrix_x(torch.tensor(-math.pi / 2.0))
+    a, b = first @ rotation.T, second @ rotation.T
+    ious = [ref.k360.box_3d_iou(corners1=x, corners2=y) for x, y in zip(a, b)]
+    save("g14_box_3d_iou", corners1=a, corners2=b,
+         iou_3d=torch.tensor([float(i[0]) for i in ious], dtype=torch.float64), iou_bev=torch.tensor([float(i[1]) for i in ious], dtype=torch.float64))
+
+
 def main():
     torch.set_num_threads(4)
     ref = import_reference()
+    golden_box_3d_iou(ref)
     golden_ray_casting(ref)
     golden_sdf(ref)
     golden_samplers(ref)

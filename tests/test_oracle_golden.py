@@ -216,3 +216,22 @@ def test_g11_soft_rasterizer():
         d = geometry.polygon_distance_map(g[f"polygon_{k}"], (H, W))
         torch.testing.assert_close(d, g[f"distance_{k}"], rtol=1e-5, atol=1e-4)
         torch.testing.assert_close(geometry.soft_mask(d, g[f"inside_{k}"], float(g["temperature"])), g[f"soft_{k}"], rtol=1e-5, atol=1e-5)
+
+
+def test_g14_box_3d_iou():
+    """vsrd.operations.box_3d_iou (evaluation metric, scripts/main.py:888-905): the oracle restatement and the package's host-side
+    function against the reference's outputs, quirks included (clockwise footprints, + 0.01 in the clip)."""
+    from vsrd_amd import operations
+    g = load_golden("g14_box_3d_iou")
+    for a, b, want_3d, want_bev in zip(g["corners1"], g["corners2"], g["iou_3d"], g["iou_bev"]):
+        for function in (geometry.box_3d_iou, operations.box_3d_iou):
+            got_3d, got_bev = function(a, b)
+            assert abs(float(got_3d) - float(want_3d)) < 1e-5 and abs(float(got_bev) - float(want_bev)) < 1e-5, function.__module__
+    # a pair the reference's corner order does not break: counter-clockwise footprints, plain geometry
+    square = torch.tensor([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=torch.float32)[[3, 2, 1, 0]]
+    top, bottom = torch.cat([square, torch.ones(4, 1)], 1), torch.cat([square, torch.zeros(4, 1)], 1)
+    box = torch.cat([top, bottom])
+    shifted = box + torch.tensor([0.5, 0.0, 0.0])
+    for function in (geometry.box_3d_iou, operations.box_3d_iou):
+        iou_3d, iou_bev = function(box, shifted)
+        assert abs(float(iou_bev) - 1.0 / 3.0) < 2e-2 and abs(float(iou_3d) - 1.0 / 3.0) < 2e-2       # the + 0.01 moves the crossings a little
