@@ -104,6 +104,10 @@ def test_g7_projection():
     clipped, masks = geometry.clip_edges_to_front(g["boxes_3d"][:, idx, :])
     torch.testing.assert_close(clipped, g["clipped_lines"], rtol=1e-6, atol=1e-6)
     assert torch.equal(masks, g["clip_masks"])
+    from vsrd_amd import operations                                       # the package's own (host/torch) clip_lines_to_front
+    clipped, masks = operations.clip_lines_to_front(g["boxes_3d"][:, idx, :])
+    torch.testing.assert_close(clipped, g["clipped_lines"], rtol=1e-6, atol=1e-6)
+    assert torch.equal(masks, g["clip_masks"])
     # zero-parameter box projects to these pixels
     loc, dim, rot, corners = geometry.decode_box_parameters(torch.zeros(1, 3), torch.zeros(1, 3), torch.tensor([[1.0, 0.0]]))
     np.testing.assert_allclose(loc.numpy(), [[0.0, 0.675, 50.0]], atol=1e-6)

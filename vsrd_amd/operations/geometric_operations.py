@@ -83,3 +83,15 @@ def expand_to_4x4(matrices):
     out = torch.eye(4).to(matrices).repeat(*matrices.shape[:-2], 1, 1)
     out[..., :matrices.shape[-2], :matrices.shape[-1]] = matrices
     return out
+
+
+def clip_lines_to_front(lines, epsilon=1e-6):
+    """geometric_operations.py:343-365 (used by the reference's dataset and drawers, not by the optimisation loop, where the
+    projection kernel clips internally): lines [...,2,3] in the camera frame -> (lines with the deeper end first and the nearer end
+    pulled onto z = 0+ when it lies behind the camera, mask of lines whose deeper end is in front)."""
+    first, second = lines[..., 0, :], lines[..., 1, :]
+    swap = (second[..., 2] > first[..., 2]).unsqueeze(-1)
+    far, near = torch.where(swap, second, first), torch.where(swap, first, second)
+    fraction = (far[..., 2:] / (far[..., 2:] - near[..., 2:]).clamp_min(epsilon)).clamp_max(1.0)
+    near = far + fraction * (near - far)
+    return torch.stack([far, near], dim=-2), far[..., 2] > 0
