@@ -90,8 +90,8 @@ def clip_lines_to_front(lines, epsilon=1e-6):
     projection kernel clips internally): lines [...,2,3] in the camera frame -> (lines with the deeper end first and the nearer end
     pulled onto z = 0+ when it lies behind the camera, mask of lines whose deeper end is in front)."""
     first, second = lines[..., 0, :], lines[..., 1, :]
-    swap = (second[..., 2] > first[..., 2]).unsqueeze(-1)
-    far, near = torch.where(swap, second, first), torch.where(swap, first, second)
+    keep = (first[..., 2] > second[..., 2]).unsqueeze(-1)            # a tie puts the second point first, as the reference does
+    far, near = torch.where(keep, first, second), torch.where(keep, second, first)
     fraction = (far[..., 2:] / (far[..., 2:] - near[..., 2:]).clamp_min(epsilon)).clamp_max(1.0)
     near = far + fraction * (near - far)
     return torch.stack([far, near], dim=-2), far[..., 2] > 0
