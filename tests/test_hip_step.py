@@ -375,3 +375,52 @@ def test_optimisation_recovers_the_boxes(dev):
     assert float(box_error) < 2.0                          # every projected box sits on its ground truth in every view
     # three views one metre apart leave depth (against size, within the decode's size range) weakly constrained: metres, not tens of metres
     assert float(error.max()) < 5.0 and float(error.mean()) < 0.1 * float(start.mean())
+
+
+def test_two_frames_replayed_concurrently(dev):
+    """Frames are independent problems; two of them replayed at the same time (one host thread and stream each) fill each other's idle
+    SIMDs (+34 % / +66 % steps/s in the two phases).  Each FrameOptimizer owns its scratch (rendering.workspace_scope), so
+    the concurrent run must give bit-identical parameters to running the same two loops one after the other."""
+    import threading
+    from vsrd_amd import optimization, rendering, fields
+    V, H, W, N, S, R = 3, 128, 128, 4, 32, 256
+    K, E, (loc, dim, rot), gt_boxes, visible = c1_frame()
+    cam, dirs = rendering.ray_casting((H, W), K.to(dev), E.to(dev))
+    block = fields.FieldBlock(fields.pack_instances(loc.to(dev), rot.to(dev), dim.to(dev)), 0.1, None, None)
+    origins = cam[:, None, None, :].expand(V, H, W, 3).reshape(-1, 3).contiguous()
+    soft = rendering.render_hierarchical(block, origins, dirs.reshape(-1, 3), (0.0, 100.0), S, 0.1, 1.0, seed=5)["labels"].clamp(0, 1)
+    inputs = optimization.FrameInputs((H, W), K.to(dev), E.to(dev), soft.reshape(V, H, W, N).contiguous(), gt_boxes.to(dev), visible.to(dev))
+
+    def make(seed):       # warm-up + capture are serial (stream capture is process-global); 4 eager/capture steps, then replays only
+        torch.manual_seed(seed)
+        stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(stream):
+            loop = optimization.FrameOptimizer(inputs, optimization.OptimizationConfig(num_samples=S, num_rays=R, warmup_steps=2, seed=seed), dev, graph=True)
+            with torch.no_grad():
+                loop.detector.locations.add_(0.05 * seed)
+            for _ in range(8):            # 2 box-only steps, then the residual phase: 3 eager + capture + 2 replays
+                loop.step()
+        stream.synchronize()
+        return loop, stream
+
+    def run(loop, stream, steps=25):
+        with torch.cuda.stream(stream):
+            for _ in range(steps):
+                loop.step()
+        stream.synchronize()
+
+    serial = [make(seed) for seed in (1, 2)]
+    for loop, stream in serial:
+        run(loop, stream)
+    together = [make(seed) for seed in (1, 2)]
+    threads = [threading.Thread(target=run, args=pair) for pair in together]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    for (a, _), (b, _) in zip(serial, together):
+        for p, q in zip(list(a.detector.parameters()) + list(a.hyper_distance_field.parameters()),
+                        list(b.detector.parameters()) + list(b.hyper_distance_field.parameters())):
+            assert torch.equal(p, q)
+    assert not torch.equal(serial[0][0].detector.locations, serial[1][0].detector.locations)

@@ -23,6 +23,7 @@ def main():
     parser.add_argument("--instances", type=int, default=8)
     parser.add_argument("--views", type=int, default=17)
     parser.add_argument("--graph", action="store_true", help="capture the step in a hipGraph and replay it")
+    parser.add_argument("--concurrent", type=int, default=1, help="frames optimised at the same time (one host thread and stream each)")
     parser.add_argument("--residual", action="store_true", help="post-warm-up phase: residual MLP + eikonal loss (steps 1000-3000)")
     args = parser.parse_args()
     import __graft_entry__
@@ -43,20 +44,46 @@ def main():
                                              skip_exact_misses=True)["labels"].clamp(0, 1).reshape(V, H, W, N).contiguous()
         gt_boxes, _ = operations.project_boxes_multi_view(out["boxes_3d"][0], E.to(dev), K.to(dev), (H, W))
     inputs = optimization.FrameInputs((H, W), K.to(dev), E.to(dev), soft, gt_boxes, torch.ones(V, N, dtype=torch.bool, device=dev))
-    loop = optimization.FrameOptimizer(inputs, optimization.OptimizationConfig(), dev, graph=args.graph)
-    if args.residual:
-        loop.step_index = loop.config.warmup_steps
-        loop.step_tensor.fill_(loop.step_index)
-    for _ in range(20):
-        loop.step()
-    torch.cuda.synchronize()
+    import threading
+    # Frames are independent (README.md:128: no exchange): several can be optimised at once, each on its own stream with its own
+    # replayed graph, and fill each other's idle SIMDs.  Set-up and capture are serial (stream capture is process-global).
+    loops, streams = [], []
+    for slot in range(args.concurrent):
+        stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(stream):
+            loop = optimization.FrameOptimizer(inputs, optimization.OptimizationConfig(seed=slot), dev, graph=args.graph)
+            if args.residual:
+                loop.step_index = loop.config.warmup_steps
+                loop.step_tensor.fill_(loop.step_index)
+            for _ in range(20):
+                loop.step()
+        stream.synchronize()
+        loops.append(loop); streams.append(stream)
+    results = [None] * args.concurrent
+    start_line = threading.Barrier(args.concurrent + 1)
+
+    def worker(slot):
+        with torch.cuda.stream(streams[slot]):
+            start_line.wait()
+            for _ in range(args.steps):
+                losses = loops[slot].step()
+            streams[slot].synchronize()
+            results[slot] = float(losses["loss"])
+
+    threads = [threading.Thread(target=worker, args=(slot,)) for slot in range(args.concurrent)]
+    for t in threads:
+        t.start()
+    start_line.wait()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses = loop.step()
+    for t in threads:
+        t.join()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"native mode ({'residual' if args.residual else 'box-only'} phase{', hipGraph replay' if args.graph else ''}): {args.steps / dt:.1f} steps/s ({dt / args.steps * 1e3:.2f} ms/step, 1000 rays x 100 samples, V={V}, N={N}); "
-          f"3000-step frame = {3000 * dt / args.steps:.1f} s; reference: ~3.3 steps/s on a V100 (README.md:128); final loss {float(losses['loss']):.4f}")
+    total = args.steps * args.concurrent
+    print(f"native mode ({'residual' if args.residual else 'box-only'} phase{', hipGraph replay' if args.graph else ''}"
+          f"{', %d frames at once' % args.concurrent if args.concurrent > 1 else ''}): {total / dt:.1f} steps/s ({dt / total * 1e3:.2f} ms/step, "
+          f"1000 rays x 100 samples, V={V}, N={N}); 3000-step frame = {3000 * dt / total:.1f} s; reference: ~3.3 steps/s on a V100 "
+          f"(README.md:128); final loss {results[0]:.4f}")
 
 
 if __name__ == "__main__":

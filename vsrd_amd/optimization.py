@@ -74,6 +74,7 @@ class FrameOptimizer:
         self.step_tensor = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.schedule = torch.ones(3, dtype=torch.float32, device=self.device)
         self._graphs = {}
+        self._capture_stream = None
         self._eager_graph_steps = {}
         # rays of every view, once per frame (main.py:267-296)
         cam, dirs = rendering.ray_casting((H, W), inputs.intrinsic_matrices, inputs.extrinsic_matrices)
@@ -144,7 +145,11 @@ class FrameOptimizer:
         static_rays = ray_indices.clone() if ray_indices is not None else None
         graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(self.device)
-        with torch.cuda.graph(graph):
+        # an own capture stream per loop: torch keys the rocBLAS / hipBLASLt workspaces by stream, and its default capture stream is
+        # shared by every capture -- two loops replayed at the same time would then run their GEMMs in one workspace
+        if self._capture_stream is None:
+            self._capture_stream = torch.cuda.Stream(device=self.device)
+        with torch.cuda.graph(graph, stream=self._capture_stream):
             outputs = self._step(static_rays, None, None, count=False)
         self._graphs[key] = (graph, static_rays, outputs)
         graph.replay()                                   # capture does not execute: this replay IS the step
@@ -152,6 +157,10 @@ class FrameOptimizer:
         return outputs
 
     def _step(self, ray_indices, u_coarse, u_fine, count=True):
+        with rendering.workspace_scope(id(self)):      # this frame's own scratch: frames may be optimised concurrently on other streams
+            return self._step_in_scope(ray_indices, u_coarse, u_fine, count)
+
+    def _step_in_scope(self, ray_indices, u_coarse, u_fine, count):
         cfg, inp = self.config, self.inputs
         step = self.step_index
         residual = step >= cfg.warmup_steps

@@ -15,12 +15,37 @@ Two ways in:
 Gradients reach the field parameters through ``torch.autograd.Function``s whose backward is the
 hand-derived adjoint kernel (``vsrd_render_backward``); there is no PyTorch-op fallback.
 """
+import threading
+
 import torch
 
 from .. import _lib, profiling
 from ..fields import FieldBlock, SoftUnion, flatten, _closure_vars
 
+# Scratch of the adjoint launches (per-wave gradient partials, residual jets / seeds), one set per *workspace scope*: launches inside
+# one scope are assumed to be ordered on one stream; work that runs concurrently on another stream (a second frame being optimised,
+# optimization.py) must use its own scope.
 _workspaces = {}
+_scope = threading.local()
+
+
+class workspace_scope:
+    """``with workspace_scope(token): ...`` -- the launches inside use scratch buffers private to ``token``."""
+
+    def __init__(self, token):
+        self.token = token
+
+    def __enter__(self):
+        self.previous = getattr(_scope, "token", None)
+        _scope.token = self.token
+
+    def __exit__(self, *exc):
+        _scope.token = self.previous
+
+
+def current_scope():
+    return getattr(_scope, "token", None)
+
 
 # A/B switch for the conservative soft-min instance culling (DESIGN.md "Culling"): False sets VSRD_FLAG_NO_CULLING on
 # every launch so that each instance is evaluated at each sample, exactly like the reference's closure loop.
@@ -32,12 +57,11 @@ def _base_flags():
 
 
 def _workspace(device, num_instances, residual=False):
-    key = (device, num_instances, bool(residual))
+    key = (current_scope(), device, num_instances, bool(residual))
     buf = _workspaces.get(key)
     if buf is None:
         nbytes = _lib.load().vsrd_workspace_bytes(num_instances, 1 if residual else 0)
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _workspaces[key] = buf
+        buf = _workspaces[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
     return buf
 
 

@@ -43,7 +43,7 @@ def importance_merge(bins, weights, uniforms=None, sorted_uniforms=False):
     return out.reshape(*lead, 2 * S)
 
 
-_ray_workspaces = {}
+_ray_workspaces = {}                       # per workspace scope, like the adjoint workspaces (renderers.py)
 
 
 def sample_rays(weights, num_samples, seed=0, stream_offset=0):
@@ -53,9 +53,11 @@ def sample_rays(weights, num_samples, seed=0, stream_offset=0):
     Returns int64 indices [num_samples], best key first."""
     lib = _lib.load()
     weights = weights.detach().reshape(-1).to(torch.float32).contiguous()
-    buf = _ray_workspaces.get(weights.device)
+    from .renderers import current_scope
+    key = (current_scope(), weights.device)
+    buf = _ray_workspaces.get(key)
     if buf is None:
-        buf = _ray_workspaces[weights.device] = torch.empty(lib.vsrd_sample_rays_workspace_bytes(), dtype=torch.uint8, device=weights.device)
+        buf = _ray_workspaces[key] = torch.empty(lib.vsrd_sample_rays_workspace_bytes(), dtype=torch.uint8, device=weights.device)
     indices = torch.empty(int(num_samples), dtype=torch.int64, device=weights.device)
     offset_ptr = None
     if isinstance(stream_offset, torch.Tensor):
