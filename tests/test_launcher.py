@@ -52,3 +52,24 @@ def test_two_rank_frame_sharding_gloo():
     assert launcher.shard_frames(list("abcdefg"), 0, 1) and sorted(launcher.shard_frames(list("abcdefg"), 0, 1)) == list("abcdefg")
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_worker, args=(2, _free_port(), tmp), nprocs=2, join=True)
+
+
+def test_frames_in_flight_runs_every_frame_once():
+    """run_frames(frames_in_flight=2): worker threads (one stream each on a GPU; plain threads here), order kept, restart guard kept."""
+    import threading
+    from vsrd_amd import launcher
+    seen, lock = [], threading.Lock()
+
+    def optimise(frame):
+        with lock:
+            seen.append((frame, threading.current_thread().name))
+        return {"frame": frame}
+
+    with tempfile.TemporaryDirectory() as tmp:
+        path = lambda f: os.path.join(tmp, f"frame_{f}", "step_final.pt")
+        os.makedirs(os.path.dirname(path(2)), exist_ok=True)
+        torch.save({"step": -1}, path(2))
+        done = launcher.run_frames(list(range(7)), optimise, path, frames_in_flight=2)
+        assert done == [0, 1, 3, 4, 5, 6]
+        assert sorted(f for f, _ in seen) == done and all(os.path.exists(path(f)) for f in range(7))
+        assert torch.load(path(5))["frame"] == 5

@@ -65,16 +65,40 @@ def shard_frames(frames: Sequence, rank: int, world_size: int, seed: int = 0) ->
     return [frames[j] for position, j in enumerate(order) if position % world_size == rank]
 
 
-def run_frames(frames: Sequence, optimise: Callable, checkpoint_path: Callable[[object], str] = None):
-    """Optimise this rank's frames one after the other; a frame whose final checkpoint exists is skipped (main.py:134-136)."""
-    done = []
+def run_frames(frames: Sequence, optimise: Callable, checkpoint_path: Callable[[object], str] = None, frames_in_flight: int = 1):
+    """Optimise this rank's frames; a frame whose final checkpoint exists is skipped (main.py:134-136).
+
+    ``frames_in_flight`` > 1 runs that many frames at the same time on this rank's GPU, one host thread and one stream each: at the
+    reference's 1000 rays per step a single frame leaves SIMDs idle, and independent frames fill them (2 is the sweet spot,
+    DESIGN.md §6).  ``optimise`` is then called from worker threads, inside ``torch.cuda.stream(<own stream>)``; a
+    ``FrameOptimizer(graph=True)`` built there is safe (own scratch, own capture stream, captures serialised).
+    The returned list keeps the order of ``frames``."""
+    pending = []
     for frame in frames:
         path = checkpoint_path(frame) if checkpoint_path else None
-        if path and os.path.exists(path):
-            continue
+        if not (path and os.path.exists(path)):
+            pending.append((frame, path))
+
+    def one(item):
+        frame, path = item
         result = optimise(frame)
         if path:
             os.makedirs(os.path.dirname(path), exist_ok=True)
             torch.save(result, path)          # utils.Saver.save == torch.save(dict) (vsrd/utils.py:191-198)
-        done.append(frame)
-    return done
+        return frame
+
+    if frames_in_flight <= 1:
+        return [one(item) for item in pending]
+
+    from concurrent.futures import ThreadPoolExecutor
+
+    def on_own_stream(item):
+        if torch.cuda.is_available():
+            with torch.cuda.stream(torch.cuda.Stream()):
+                frame = one(item)
+                torch.cuda.current_stream().synchronize()
+                return frame
+        return one(item)
+
+    with ThreadPoolExecutor(max_workers=frames_in_flight) as pool:
+        return list(pool.map(on_own_stream, pending))

@@ -16,10 +16,14 @@ from dataclasses import dataclass, field as dataclass_field
 from typing import Optional, Sequence
 
 import math
+import threading
 
 import torch
 
 from . import fields, losses, models, operations, rendering
+
+
+_capture_lock = threading.Lock()
 
 
 @dataclass
@@ -149,7 +153,9 @@ class FrameOptimizer:
         # shared by every capture -- two loops replayed at the same time would then run their GEMMs in one workspace
         if self._capture_stream is None:
             self._capture_stream = torch.cuda.Stream(device=self.device)
-        with torch.cuda.graph(graph, stream=self._capture_stream):
+        # stream capture is a process-wide mode: one capture at a time, and thread-local error checking so that another frame's
+        # thread (launcher.run_frames(frames_in_flight=2)) may keep replaying its own graph meanwhile
+        with _capture_lock, torch.cuda.graph(graph, stream=self._capture_stream, capture_error_mode="thread_local"):
             outputs = self._step(static_rays, None, None, count=False)
         self._graphs[key] = (graph, static_rays, outputs)
         graph.replay()                                   # capture does not execute: this replay IS the step
