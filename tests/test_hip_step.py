@@ -215,6 +215,11 @@ def test_device_hungarian_matches_scipy(dev):
         rows, cols = losses.linear_sum_assignment(cost.to(dev))
         want_rows, want_cols = linear_sum_assignment(cost.numpy())
         assert rows.cpu().tolist() == want_rows.tolist() and cols.cpu().tolist() == want_cols.tolist(), cost.shape
+    # NaN entries (a diverged box): scipy raises; the device solver must still return a valid assignment (the indices feed gathers)
+    broken = torch.randn(6, 6, generator=gen)
+    broken[2, :] = float("nan")
+    rows, cols = losses.linear_sum_assignment(broken.to(dev))
+    assert sorted(rows.cpu().tolist()) == list(range(6)) and sorted(cols.cpu().tolist()) == list(range(6))
     for P, G in [(8, 8), (16, 12), (7, 16)]:
         centres = torch.rand(max(P, G), 2, generator=gen) * 800
         sizes = torch.rand(max(P, G), 2, generator=gen) * 100 + 10

@@ -129,7 +129,10 @@ __global__ __launch_bounds__(kWave) void match_kernel(const float* __restrict__ 
     const int nr = transposed ? G : P, nc = transposed ? P : G;
     for (int idx = lane; idx < P * G; idx += kWave) {
         const int p = idx / G, g = idx % G;
-        const float c = cost_in ? cost_in[idx] : negative_distance_iou(pd_boxes + 4 * p, gt_boxes + 4 * g);
+        float c = cost_in ? cost_in[idx] : negative_distance_iou(pd_boxes + 4 * p, gt_boxes + 4 * g);
+        // scipy raises on NaN / -inf entries; a kernel cannot, and an unsolved problem would leave the index buffers undefined (they
+        // are used for gathers right after): such entries become "never match" costs, the assignment stays a valid permutation
+        if (!(c == c) || c < -3.0e38f) c = 3.0e38f;
         cost[transposed ? (g * nc + p) : (p * nc + g)] = static_cast<double>(c);
     }
     __syncthreads();
