@@ -76,6 +76,12 @@ typedef struct vsrd_render_config {
                                              labels = 0 (exact); distances/gradients/weights of such
                                              rays are NOT produced (fused-loss mode only)        */
 
+#define VSRD_FLAG_MLP_WEIGHTS_CENTRED 8u   /* residual fields: the caller guarantees that, in each of the four linears that feed a
+                                             LayerNorm (rows [out][in+1] of mlp_weights), every column -- bias column included -- has
+                                             zero mean over the 16 output channels.  LayerNorm makes the field invariant to that
+                                             centring, and gradients w.r.t. centred weights equal those w.r.t. the originals; the
+                                             kernels then skip centring the weight operands on every evaluation.                     */
+
 #define VSRD_FLAG_NO_CULLING 4u           /* evaluate every instance at every sample (A/B switch for the
                                              conservative soft-min culling described in DESIGN.md)        */
 

@@ -21,6 +21,7 @@ MLP_WEIGHTS = 1617
 FLAG_FINE_UNIFORMS_SORTED = 1
 FLAG_SKIP_EXACT_MISSES = 2
 FLAG_NO_CULLING = 4
+FLAG_MLP_WEIGHTS_CENTRED = 8
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 

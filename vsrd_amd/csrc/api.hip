@@ -105,6 +105,7 @@ RenderArgs render_args(const vsrd_render_config* c) {
     a.sh.inv_std = 1.0f / c->sdf_std_deviation;
     a.sh.ratio = c->cosine_ratio;
     a.sh.eps = c->epsilon;
+    a.sh.mlp_bits = 0u;  // set in-kernel from the flags
     a.origin_stride = c->origin_stride;
     a.seed = c->seed;
     a.stream_offset = c->stream_offset;

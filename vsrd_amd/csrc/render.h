@@ -22,6 +22,7 @@ struct Shading {
     float inv_std;  // 1 / sdf_std_deviation
     float ratio;    // cosine_ratio
     float eps;      // epsilon (opacity denominator)
+    unsigned mlp_bits;   // kMlpCentredBit when VSRD_FLAG_MLP_WEIGHTS_CENTRED is set (OR-ed into the residual's tile mask), else 0
 };
 
 // torch.lerp(a, b, w): two-sided formula of ATen's lerp kernel.
@@ -95,7 +96,7 @@ __device__ __forceinline__ UnionValue eval_union(const float* __restrict__ insta
         const unsigned long long near = __ballot(dcache[i * kWave + lane] <= threshold);
         if (near == 0ull) continue;                                             // wave-uniform skip
         const Instance in = load_instance(instances, i);
-        const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z, rows_with(near));
+        const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z, rows_with(near) | sh.mlp_bits);
         if (kCacheDistances) dcache[i * kWave + lane] = e.d;
         union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, sh.inv_t);
     }

@@ -78,6 +78,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_forward_kernel(
     float* dcache = dist + num_distances;
     Shading sh = c.sh;
     sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, f.num_instances, f.inv_t) + (kResidual ? 1.0f : 0.0f);
+    sh.mlp_bits = (c.flags & 8u) ? kMlpCentredBit : 0u;
     const int stride = static_cast<int>(gridDim.x) * waves_per_block();
     for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
         const Ray r = load_ray(origins, directions, c.origin_stride, ray);
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
     const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
     Shading sh = c.sh;
     sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, f.num_instances, f.inv_t) + (kResidual ? 1.0f : 0.0f);
+    sh.mlp_bits = (c.flags & 8u) ? kMlpCentredBit : 0u;
     const int stride = static_cast<int>(gridDim.x) * waves_per_block();
     for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
         const Ray r = load_ray(origins, directions, c.origin_stride, ray);
@@ -276,7 +278,7 @@ __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, 
                 for (int q = 0; q < 4; ++q) st.near_rows[k][q] |= ((near >> (16 * q)) & 0xFFFFull) ? (1ull << i) : 0ull;
             }
             Residual res;
-            const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, st.sa[k].x, st.sa[k].y, st.sa[k].z, rows_with(near), &res);
+            const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, st.sa[k].x, st.sa[k].y, st.sa[k].z, rows_with(near) | sh.mlp_bits, &res);
             if (kResidual && rcache) rcache[(k * N + i) * kWave + lane] = make_float4(res.value, res.gx, res.gy, res.gz);
             if (kCacheD) dcache[i * kWave + lane] = e.d;
             union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, inv_t);
@@ -449,7 +451,7 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
 // Its result p_bar = dL/d(local position) adds  rel (x) p_bar  to the rotation adjoint and  -R p_bar  to the translation adjoint.
 template <int kRounds, int kBatch>
 __device__ __forceinline__ void adjoint_phase_mlp(const float* __restrict__ instances, const float* __restrict__ mlp, int N, float* G, float* wbar,
-                                                  float* my_mlp, int lane, const float* seeds, const unsigned* masks) {
+                                                  float* my_mlp, int lane, const float* seeds, const unsigned* masks, unsigned mlp_bits) {
     for (int i = 0; i < N; ++i) {
         unsigned any = 0u;
         for (int slot = 0; slot < kBatch * kRounds; ++slot) any |= masks[slot * N + i];
@@ -464,7 +466,7 @@ __device__ __forceinline__ void adjoint_phase_mlp(const float* __restrict__ inst
             const float* src = seeds + static_cast<size_t>(slot * N + i) * (kSeedFloats * kWave) + lane;
             const float relx = src[7 * kWave], rely = src[8 * kWave], relz = src[9 * kWave];
             const ResidualAdjoint ra = residual_backward(mlp + i * kMlpWeights, src[0 * kWave], src[1 * kWave], src[2 * kWave], src[3 * kWave],
-                                                         src[4 * kWave], src[5 * kWave], src[6 * kWave], wbar, lane, rows);
+                                                         src[4 * kWave], src[5 * kWave], src[6 * kWave], wbar, lane, rows | mlp_bits);
             r00 += relx * ra.px; r01 += relx * ra.py; r02 += relx * ra.pz;
             r10 += rely * ra.px; r11 += rely * ra.py; r12 += rely * ra.pz;
             r20 += relz * ra.px; r21 += relz * ra.py; r22 += relz * ra.pz;
@@ -514,6 +516,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
     }
     Shading sh = c.sh;
     sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, N, f.inv_t) + (kResidual ? 1.0f : 0.0f);
+    sh.mlp_bits = (c.flags & 8u) ? kMlpCentredBit : 0u;
     const int stride = static_cast<int>(gridDim.x) * waves_per_block();
     constexpr int kBatch = kResidual ? kMlpBatch : 1;
     for (int first = static_cast<int>(blockIdx.x) * waves_per_block() + wave; first < c.num_rays; first += stride * kBatch) {
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
         }
         if (kResidual) {
             wave_lds_sync();                                                 // masks: written by lanes < kRounds, read by all
-            adjoint_phase_mlp<kRounds, kBatch>(instances, mlp, N, G, wbar, my_mlp, lane, seeds, masks);
+            adjoint_phase_mlp<kRounds, kBatch>(instances, mlp, N, G, wbar, my_mlp, lane, seeds, masks, sh.mlp_bits);
         }
     }
     wave_lds_sync();
@@ -583,6 +586,7 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
     const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
     Shading sh = c.sh;
     sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, N, f.inv_t);
+    sh.mlp_bits = 0u;
     const float weight_lane = (lane < N) ? (instance_weights ? instance_weights[lane] : 1.0f) : 0.0f;
     float loss_acc = 0.0f;                                                  // lane n: this wave's BCE sum of instance n
     const int D = 2 * S, num_points = D - 1;

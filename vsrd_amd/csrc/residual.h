@@ -36,6 +36,7 @@ constexpr int kMlpHead = kMlpLayer1 + 3 * kMlpBlock;         // 1600: [w4[0..15]
 constexpr float kPositionScale = 100.0f;                     // max(distance_range), main.py:441
 constexpr float kLayerNormEps = 1.0e-5f;
 constexpr float kPi = 3.14159265358979323846f;
+constexpr unsigned kMlpCentredBit = 0x10u;                   // in the tile-mask argument: the weights arrive centred (VSRD_FLAG_MLP_WEIGHTS_CENTRED)
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
@@ -115,7 +116,7 @@ __device__ __forceinline__ float row_sum16(float v) {
 // channel = over the 16 lanes of a row) and its bias mean removed, and the norm needs no mean / tangent-mean reductions (4 of its 8).
 // The adjoint is unchanged: the LayerNorm Jacobian P already produces zero-mean adjoints, so W_bar = z_bar a^T and W^T z_bar hold for
 // the original W.
-__device__ __forceinline__ void load_forward_weights(GlobalWeights w, int lane, ForwardWeights& fw) {
+__device__ __forceinline__ void load_forward_weights(GlobalWeights w, int lane, ForwardWeights& fw, bool centred) {
     const int g = lane >> 4, o = lane & 15;
     const GlobalWeights row0 = w + o * kMlpRow0 + 4 * g;
 #pragma unroll
@@ -133,6 +134,7 @@ __device__ __forceinline__ void load_forward_weights(GlobalWeights w, int lane, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) fw.w4[j] = w[kMlpHead + 4 * g + j];
     fw.b4 = w[kMlpHead + kMlpHidden];
+    if (centred) return;                                           // wave-uniform: the caller did it once for the whole launch
 #pragma unroll
     for (int s = 0; s < 12; ++s) fw.a0[s] -= row_sum16(fw.a0[s]) * (1.0f / kMlpHidden);
     fw.b0 -= splat4(rows_sum(hsum4(fw.b0)) * (1.0f / kMlpHidden));
@@ -246,7 +248,7 @@ VSRD_RESIDUAL_FN Residual residual_forward(const float* w_in, float px, float py
     const unsigned tiles = __builtin_amdgcn_readfirstlane(tiles_in);
     const GlobalWeights w = uniform_weights(w_in);
     ForwardWeights fw;
-    load_forward_weights(w, lane, fw);
+    load_forward_weights(w, lane, fw, (tiles & kMlpCentredBit) != 0u);
     const float fold = (px > 0.0f) ? 1.0f : ((px < 0.0f) ? -1.0f : 0.0f);
     const float inv = 1.0f / kPositionScale;
     const float f0 = fabsf(px) * inv, f1 = py * inv, f2 = pz * inv;
@@ -418,7 +420,7 @@ __device__ __forceinline__ ResidualAdjoint residual_backward(const float* w_in, 
     const LdsFloats scratch = wbar + kMlpWbarFloats;
     ForwardWeights fw;
     BackwardWeights bw;
-    load_forward_weights(w, lane, fw);
+    load_forward_weights(w, lane, fw, (tiles & kMlpCentredBit) != 0u);
     load_backward_weights(w, lane, bw);
     const float fold = (px > 0.0f) ? 1.0f : ((px < 0.0f) ? -1.0f : 0.0f);
     const float inv = 1.0f / kPositionScale;

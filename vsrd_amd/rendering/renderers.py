@@ -56,6 +56,10 @@ def _base_flags():
     return 0 if CULLING else _lib.FLAG_NO_CULLING
 
 
+def _mlp_flag(centred_weights):
+    return _lib.FLAG_MLP_WEIGHTS_CENTRED if centred_weights is not None else 0
+
+
 def _workspace(device, num_instances, residual=False):
     key = (current_scope(), device, num_instances, bool(residual))
     buf = _workspaces.get(key)
@@ -89,9 +93,10 @@ class _RenderAtDistances(torch.autograd.Function):
         labels = torch.empty(R, N, dtype=torch.float32, device=distances.device)
         gradients = torch.empty(R, D - 1, 3, dtype=torch.float32, device=distances.device)
         weights = torch.empty(R, D - 1, dtype=torch.float32, device=distances.device)
-        mlp_weights = None if mlp_weights is None else mlp_weights.detach().contiguous()
+        mlp_weights = None if mlp_weights is None else _centre_mlp(mlp_weights)
         field = _lib.make_field(instances, temperature, mlp_weights)
-        config = _lib.make_config(R, num_samples, (near, far), std, ratio, eps, origin_stride, flags=_base_flags(), schedule=schedule)
+        config = _lib.make_config(R, num_samples, (near, far), std, ratio, eps, origin_stride, flags=_base_flags() | _mlp_flag(mlp_weights),
+                                  schedule=schedule)
         with profiling.timed("vsrd_render_forward"):
             _lib.check(lib.vsrd_render_forward(field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(distances), D,
                                                _lib.ptr(labels), _lib.ptr(gradients), _lib.ptr(weights), _lib.stream()))
@@ -108,6 +113,21 @@ class _RenderAtDistances(torch.autograd.Function):
         grad_instances, grad_mlp = _backward(instances, rest[0] if rest else None, origins, directions, distances, temperature, scalars,
                                              origin_stride, grad_labels, grad_gradients, grad_weights)
         return (grad_instances, grad_mlp, None, None, None, None, None, None)
+
+
+def _centre_mlp(mlp_weights):
+    """The four linears that feed a LayerNorm with their columns (bias column included) centred over the 16 output channels:
+    LayerNorm makes the field invariant to it and the gradients w.r.t. the centred weights ARE the gradients w.r.t. the originals
+    (the adjoint's z_bar has zero channel mean), so the kernels get VSRD_FLAG_MLP_WEIGHTS_CENTRED and skip centring the weight
+    operands on each of their ~10^5..10^7 evaluations (residual.h: load_forward_weights)."""
+    out = mlp_weights.detach().clone()
+    n = out.shape[0]
+    first = out[:, :784].view(n, 16, 49)
+    first -= first.mean(dim=1, keepdim=True)
+    for layer in range(3):
+        block = out[:, 784 + 272 * layer:784 + 272 * (layer + 1)].view(n, 16, 17)
+        block -= block.mean(dim=1, keepdim=True)
+    return out
 
 
 def _unpack(scalars):
@@ -133,7 +153,8 @@ def _backward(instances, mlp_weights, origins, directions, distances, temperatur
     grad_mlp = None if mlp_weights is None else torch.empty_like(mlp_weights)
     workspace = _workspace(distances.device, N, mlp_weights is not None)
     field = _lib.make_field(instances, temperature, mlp_weights)
-    config = _lib.make_config(R, num_samples, (near, far), std, ratio, eps, origin_stride, flags=_base_flags(), schedule=schedule)
+    config = _lib.make_config(R, num_samples, (near, far), std, ratio, eps, origin_stride, flags=_base_flags() | _mlp_flag(mlp_weights),
+                              schedule=schedule)
     with profiling.timed("vsrd_render_backward"):
         _lib.check(lib.vsrd_render_backward(field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(distances), D,
                                             _lib.ptr(grad_labels), _lib.ptr(grad_gradients), _lib.ptr(grad_weights),
@@ -160,11 +181,12 @@ class _RenderHierarchical(torch.autograd.Function):
         weights = torch.empty(R, 2 * S - 1, dtype=torch.float32, device=dev) if want_weights else None
         uc_out = torch.empty(R, S, dtype=torch.float32, device=dev) if want_uniforms else None
         uf_out = torch.empty(R, S, dtype=torch.float32, device=dev) if want_uniforms else None
-        mlp_weights = None if mlp_weights is None else mlp_weights.detach().contiguous()
+        mlp_weights = None if mlp_weights is None else _centre_mlp(mlp_weights)
         field = _lib.make_field(instances, temperature, mlp_weights)
         ctx.residual = mlp_weights is not None
-        ctx.mlp = mlp_weights
-        config = _lib.make_config(R, S, (near, far), std, ratio, eps, origin_stride, seed, stream_offset, flags, schedule=schedule)
+        ctx.mlp = mlp_weights                                   # the centred copy: what the backward launch is given as well
+        config = _lib.make_config(R, S, (near, far), std, ratio, eps, origin_stride, seed, stream_offset, flags | _mlp_flag(mlp_weights),
+                                  schedule=schedule)
         with profiling.timed("vsrd_render_hierarchical_forward"):
             _lib.check(lib.vsrd_render_hierarchical_forward(
                 field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(u_coarse), _lib.ptr(u_fine),
