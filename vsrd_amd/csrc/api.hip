@@ -125,21 +125,23 @@ int rounds_for(int points) {
     return 0;
 }
 
+// The residual adjoint needs >= 17 KB of LDS per wave (residual.h: kMlpLdsFloats): at most two waves fit the 64 KB of a workgroup.
+constexpr int kResidualWaves = 2;
 constexpr int kMaxBlocksResidual = 512;     // residual adjoint: one wave per SIMD resident; more workgroups than CUs = load balancing (each wave owns N x 1617 partials)
 
 // Residual adjoint, per wave: the residual jets (value + local gradient) the forward sweep leaves for the per-instance phase
 // [round <= 4][N][64] float4, and the seeds that phase leaves for the MLP adjoint [ray of batch][round <= 4][N][10][64].
 size_t residual_jet_floats(int num_instances, bool residual) {
-    return residual ? static_cast<size_t>(kMaxBlocksResidual) * kMaxWavesPerBlock * 4 * num_instances * kWave * 4 : 0;
+    return residual ? static_cast<size_t>(kMaxBlocksResidual) * kResidualWaves * 4 * num_instances * kWave * 4 : 0;
 }
 size_t residual_cache_floats(int num_instances, bool residual) {
     return residual_jet_floats(num_instances, residual) +
-           (residual ? static_cast<size_t>(kMaxBlocksResidual) * kMaxWavesPerBlock * kMlpBatch * 4 * num_instances * kSeedFloats * kWave : 0);
+           (residual ? static_cast<size_t>(kMaxBlocksResidual) * kResidualWaves * kMlpBatch * 4 * num_instances * kSeedFloats * kWave : 0);
 }
 
 size_t partial_floats(int num_instances, bool residual) {
     const size_t box = static_cast<size_t>(kMaxBlocks) * kMaxWavesPerBlock * num_instances * kGradStride;
-    const size_t mlp = residual ? static_cast<size_t>(kMaxBlocksResidual) * kMaxWavesPerBlock * num_instances * kMlpWeights : 0;
+    const size_t mlp = residual ? static_cast<size_t>(kMaxBlocksResidual) * kResidualWaves * num_instances * kMlpWeights : 0;
     return box + mlp + residual_cache_floats(num_instances, residual);
 }
 
@@ -323,13 +325,14 @@ int32_t vsrd_render_backward(const vsrd_field* field, const vsrd_render_config* 
     }
     Geometry g;
     if (!plan(config->num_rays, static_cast<size_t>(backward_lds_floats(num_distances, N, residual)), &g)) return VSRD_E_UNSUPPORTED;
+    if (residual && g.threads > kResidualWaves * kWave) return VSRD_E_UNSUPPORTED;      // cannot happen (LDS per wave), but the scratch is sized for it
     if (residual && g.blocks > kMaxBlocksResidual) g.blocks = kMaxBlocksResidual;
     const FieldArgs f = field_args(field);
     RenderArgs c = render_args(config);
     c.sh.inv_t = f.inv_t;
     float* partials = static_cast<float*>(workspace);
     float* mlp_partials = partials + static_cast<size_t>(kMaxBlocks) * kMaxWavesPerBlock * row;
-    float* jets = mlp_partials + (residual ? static_cast<size_t>(kMaxBlocksResidual) * kMaxWavesPerBlock * mlp_row : 0);
+    float* jets = mlp_partials + (residual ? static_cast<size_t>(kMaxBlocksResidual) * kResidualWaves * mlp_row : 0);
     float4* residual_cache = reinterpret_cast<float4*>(jets);
     float* seed_cache = jets + residual_jet_floats(N, residual);
 #define VSRD_LAUNCH(K, RES)                                                                                                    \
