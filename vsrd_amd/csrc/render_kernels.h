@@ -360,7 +360,7 @@ __device__ __forceinline__ bool adjoint_reverse_sweep(RayAdjoint<kRounds>& st, c
 }
 
 // Phase B: per instance, adjoint of (d_i, grad d_i) w.r.t. (t, R, dim) (and the residual MLP weights), accumulated into the wave's
-// LDS rows G [N,16] / wbar [1617].
+// LDS rows G [N,16]; for residual fields it leaves the seeds and tile masks of the MLP adjoint (adjoint_phase_mlp) instead of running it.
 template <int kRounds, bool kResidual>
 __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, const float* __restrict__ instances, const float* __restrict__ mlp,
                                                 int N, float inv_t, int num_points, const float* lam, float* G, int lane,
