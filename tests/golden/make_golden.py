@@ -555,9 +555,23 @@ def golden_box_3d_iou(ref):
          iou_3d=torch.tensor([float(i[0]) for i in ious], dtype=torch.float64), iou_bev=torch.tensor([float(i[1]) for i in ious], dtype=torch.float64))
 
 
+def golden_hypernetwork(ref):
+    """a12: HyperDistanceField.forward (weight-normed Linear + LayerNorm + GELU stack) with a small hyper width, its state dict
+    (the checkpoint layout scripts/main.py:1109-1121 saves) and the gradient of a scalar of its output w.r.t. the embeddings."""
+    torch.manual_seed(5)
+    module = ref.hyper.HyperDistanceField(48, [16, 16, 16, 16], 12, [10, 14])
+    embeddings = torch.randn(1, 3, 12).requires_grad_(True)
+    weights = module(embeddings)
+    probe = torch.randn(weights.shape, generator=torch.Generator().manual_seed(6))
+    grad_embeddings, = torch.autograd.grad((weights * probe).sum(), embeddings)
+    state = {"state__" + k.replace(".", "__"): v.detach() for k, v in module.state_dict().items()}
+    save("g15_hypernetwork", embeddings=embeddings.detach(), weights=weights.detach(), probe=probe, grad_embeddings=grad_embeddings, **state)
+
+
 def main():
     torch.set_num_threads(4)
     ref = import_reference()
+    golden_hypernetwork(ref)
     golden_box_3d_iou(ref)
     golden_ray_casting(ref)
     golden_sdf(ref)
