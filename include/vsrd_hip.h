@@ -125,6 +125,16 @@ int32_t vsrd_ray_directions(const float* inverse_projection, int32_t num_views, 
 int32_t vsrd_field_eval(const vsrd_field* field, const float* positions /* [P,3] */, int64_t num_points,
                         float* distances, float* gradients, float* labels, int32_t hard_union, void* stream);
 
+/* Adjoint of vsrd_field_eval w.r.t. the field parameters and the positions: the reference's closure call is differentiable
+ * (autograd), e.g. sphere_tracing(differentiable=True) (renderers.py:59-72).  grad_distances [P] and/or grad_labels [P,N] (soft
+ * union only) may be NULL; the analytic normal output of vsrd_field_eval is NOT differentiated (second order).
+ * Needs vsrd_workspace_bytes(N, residual) of scratch.  grad_positions [P,3] or NULL; grad_instances [N,16];
+ * grad_mlp_weights [N,1617] (required for residual fields). */
+int32_t vsrd_field_eval_backward(const vsrd_field* field, const float* positions, int64_t num_points,
+                                 const float* grad_distances, const float* grad_labels, int32_t hard_union,
+                                 void* workspace, size_t workspace_bytes, float* grad_positions,
+                                 float* grad_instances, float* grad_mlp_weights, void* stream);
+
 /* vsrd.rendering.sphere_tracing, non-differentiable part (renderers.py:21-59): march each ray by the union distance until
  * |sdf| < convergence_criteria, it leaves the bounding sphere, or num_iterations is reached.
  * origins [R,3] (origin_stride 3) or [3] (stride 0); foreground [R] uint8 or NULL (= all finite origins);

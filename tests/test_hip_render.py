@@ -534,3 +534,75 @@ def test_fused_silhouette_step_matches_two_launch_path_and_golden(dev, name):
         torch.testing.assert_close(fused.detach(), want.detach(), rtol=1e-5, atol=1e-7)
         for a, b in zip(torch.autograd.grad(fused, params3), torch.autograd.grad(want, params4)):
             assert (a - b).abs().max() <= 1e-4 * max(float(b.abs().max()), 1e-6)
+
+
+@pytest.mark.parametrize("residual", [False, True])
+def test_field_evaluation_is_differentiable(dev, residual):
+    """The closure call of scripts/main.py:433-509 carries autograd in the reference; here vsrd_field_eval_backward does: gradients of a
+    functional of (distances, labels) -- and of hard-union distances -- w.r.t. boxes, MLP weights and the positions, against the
+    oracle's autograd.  Then sphere_tracing(differentiable=True) (renderers.py:59-72), whose Newton step is the only place the
+    reference uses it."""
+    from vsrd_amd import fields, rendering
+    g = load_golden("g10_render_residual_n3_s16")
+    N = g["locations"].shape[0]
+    gen = torch.Generator().manual_seed(3)
+    centres = g["locations"][torch.randint(0, N, (300,), generator=gen)]
+    points = centres + torch.randn(300, 3, generator=gen) * 1.5
+    wa, wb = torch.randn(300, generator=gen), torch.randn(300, N, generator=gen)
+    T = 0.4
+
+    def parameters(device):
+        leaves = [g[k].clone().to(device).requires_grad_(True) for k in ("locations", "dimensions", "orientations")]
+        if residual:
+            leaves.append(g["mlp_weights"].clone().to(device).requires_grad_(True))
+        return leaves, points.clone().to(device).requires_grad_(True)
+
+    def hip_field(leaves, hard):
+        loc, dim, rot = leaves[:3]
+        def member(i):
+            box = rendering.sdfs.box(dim[i])
+            if residual:
+                box = fields.residual_composition(box, fields.ResidualField(leaves[3][i]))
+            return rendering.sdfs.translation(rendering.sdfs.rotation(fields.instance_field(box, i, N), rot[i]), loc[i])
+        members = [member(i) for i in range(N)]
+        return fields.hard_union(members) if hard else fields.soft_union(members, T)
+
+    for hard in (False, True):
+        leaves, pts = parameters(dev)
+        if hard:
+            loss = (rendering.evaluate_field(hip_field(leaves, True), pts)[..., 0] * wa.to(dev)).sum()
+        else:
+            u, w = rendering.evaluate_field(hip_field(leaves, False), pts)
+            loss = (u[..., 0] * wa.to(dev)).sum() + (w * wb.to(dev)).sum()
+        got = torch.autograd.grad(loss, leaves + [pts])
+        oleaves, opts = parameters(torch.device("cpu"))
+        ounion = ofields.InstanceUnion(oleaves[0], oleaves[2], oleaves[1], T, oleaves[3] if residual else None)
+        if hard:
+            oloss = (ounion.hard_distance(opts) * wa).sum()
+        else:
+            ou, ow, _ = ounion.evaluate(opts)
+            oloss = (ou * wa).sum() + (ow * wb).sum()
+        torch.testing.assert_close(loss.detach().cpu(), oloss.detach(), rtol=1e-4, atol=1e-4)
+        for a, b in zip(got, torch.autograd.grad(oloss, oleaves + [opts])):
+            assert (a.cpu() - b).abs().max() <= 2e-3 * max(float(b.abs().max()), 1e-6), (hard, a.shape)
+
+    # differentiable sphere tracing: x' = x + r (-sdf(x) / (grad sdf(x) . r)) at converged rays, grad taken as a constant
+    leaves, _ = parameters(dev)
+    origins = torch.zeros(64, 3)
+    directions = torch.nn.functional.normalize(g["locations"][torch.arange(64) % N] + torch.randn(64, 3, generator=gen) * 0.3, dim=-1)
+    field = hip_field(leaves, True)
+    traced, converged = rendering.sphere_tracing(field, origins.to(dev), directions.to(dev), 64, 1e-3, differentiable=True)
+    assert int(converged.sum()) > 16
+    plain, _ = rendering.sphere_tracing(field, origins.to(dev), directions.to(dev), 64, 1e-3)
+    probe = torch.randn(64, 3, generator=gen)
+    got = torch.autograd.grad((traced * probe.to(dev)).sum(), leaves)
+    oleaves, _ = parameters(torch.device("cpu"))
+    ounion = ofields.InstanceUnion(oleaves[0], oleaves[2], oleaves[1], T, oleaves[3] if residual else None)
+    x = plain.detach().cpu().requires_grad_(True)
+    sdf = ounion.hard_distance(x)
+    normal, = torch.autograd.grad(sdf.sum(), x, retain_graph=True)
+    step = -sdf / (normal * directions).sum(-1)
+    expected = torch.where(converged.cpu(), x.detach() + directions * step[..., None], x.detach())
+    torch.testing.assert_close(traced.detach().cpu(), expected.detach(), rtol=1e-4, atol=1e-4)
+    for a, b in zip(got, torch.autograd.grad((expected * probe).sum(), oleaves)):
+        assert (a.cpu() - b).abs().max() <= 5e-3 * max(float(b.abs().max()), 1e-6)

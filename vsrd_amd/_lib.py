@@ -82,6 +82,8 @@ SIGNATURES = {
     "vsrd_project_boxes_forward": (ctypes.c_int32, [c_float_p, c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                                     ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
                                                     c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "vsrd_field_eval_backward": (ctypes.c_int32, [ctypes.POINTER(Field), c_float_p, ctypes.c_int64, c_float_p, c_float_p, ctypes.c_int32,
+                                                  ctypes.c_void_p, ctypes.c_size_t, c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
     "vsrd_sample_rays_workspace_bytes": (ctypes.c_size_t, []),
     "vsrd_sample_rays": (ctypes.c_int32, [c_float_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),

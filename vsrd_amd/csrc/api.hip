@@ -192,6 +192,44 @@ int32_t vsrd_field_eval(const vsrd_field* field, const float* positions, int64_t
     return launch_status();
 }
 
+int32_t vsrd_field_eval_backward(const vsrd_field* field, const float* positions, int64_t num_points,
+                                 const float* grad_distances, const float* grad_labels, int32_t hard_union,
+                                 void* workspace, size_t workspace_bytes, float* grad_positions,
+                                 float* grad_instances, float* grad_mlp_weights, void* stream) {
+    if (!valid_field(field) || !grad_instances || num_points < 0 || (!positions && num_points > 0)) return VSRD_E_INVALID_ARGUMENT;
+    if (hard_union && grad_labels) return VSRD_E_INVALID_ARGUMENT;
+    const bool residual = field->mlp_weights != nullptr;
+    if (residual && !grad_mlp_weights) return VSRD_E_INVALID_ARGUMENT;
+    const int N = field->num_instances;
+    if (!workspace || workspace_bytes < vsrd_workspace_bytes(N, residual)) return VSRD_E_WORKSPACE;
+    const hipStream_t s = static_cast<hipStream_t>(stream);
+    const int row = N * kGradStride, mlp_row = N * kMlpWeights;
+    if (num_points == 0) {
+        if (residual && hipMemsetAsync(grad_mlp_weights, 0, mlp_row * sizeof(float), s) != hipSuccess) return VSRD_E_LAUNCH;
+        return hipMemsetAsync(grad_instances, 0, row * sizeof(float), s) == hipSuccess ? VSRD_OK : VSRD_E_LAUNCH;
+    }
+    Geometry g;
+    const size_t per_wave = (static_cast<size_t>(residual ? kMlpLdsFloats : 0) + row + 3) & ~static_cast<size_t>(3);
+    if (!plan(static_cast<int>(std::min<int64_t>((num_points + kWave - 1) / kWave, 1 << 30)), per_wave, &g)) return VSRD_E_UNSUPPORTED;
+    if (residual && g.threads > kResidualWaves * kWave) return VSRD_E_UNSUPPORTED;
+    g.blocks = std::min(g.blocks, residual ? kMaxBlocksResidual : 2048);
+    float* partials = static_cast<float*>(workspace);
+    float* mlp_partials = partials + static_cast<size_t>(kMaxBlocks) * kMaxWavesPerBlock * row;
+    const FieldArgs f = field_args(field);
+    if (residual)
+        hipLaunchKernelGGL(field_eval_backward_kernel<true>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, field->mlp_weights,
+                           positions, static_cast<long long>(num_points), grad_distances, grad_labels, hard_union, grad_positions, partials, mlp_partials);
+    else
+        hipLaunchKernelGGL(field_eval_backward_kernel<false>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, field->mlp_weights,
+                           positions, static_cast<long long>(num_points), grad_distances, grad_labels, hard_union, grad_positions, partials, mlp_partials);
+    if (launch_status() != VSRD_OK) return VSRD_E_LAUNCH;
+    const int num_waves = g.blocks * (g.threads / kWave);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(row), dim3(256), 0, s, partials, num_waves, row, grad_instances);
+    if (residual)
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(mlp_row), dim3(256), 0, s, mlp_partials, num_waves, mlp_row, grad_mlp_weights);
+    return launch_status();
+}
+
 int32_t vsrd_sphere_trace(const vsrd_field* field, const float* origins, int32_t origin_stride, const float* directions,
                           const uint8_t* foreground, int64_t num_rays, int32_t num_iterations, float convergence_criteria,
                           float bounding_radius, int32_t initialise, int32_t hard_union,

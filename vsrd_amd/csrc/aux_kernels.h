@@ -68,6 +68,94 @@ __global__ __launch_bounds__(256) void field_eval_kernel(FieldArgs f, const floa
     }
 }
 
+// Adjoint of field_eval_kernel: calling the distance_field closure is differentiable in the reference (autograd through
+// scripts/main.py:433-509), e.g. for sphere_tracing(differentiable=True) (renderers.py:59-72) whose Newton step depends on the field
+// parameters through sdf(x).  Given dL/d(distances) [P] and (soft union) dL/d(labels) [P,N]:
+//   soft:  d_bar_i = u_bar c_i - w_i (lambda_i - sum_j lambda_j w_j) / T,   c_i = w_i (1 - (d_i - u) / T)      (phase B of the renderer's
+//   hard:  d_bar_i = u_bar [i = argmin]                                                                          adjoint with g_bar = 0)
+// then the box adjoint of d_i (and the residual MLP's) and  x_bar = sum_i d_bar_i grad d_i.  One wave = 64 points, the instance
+// loop is wave-uniform; per-wave partial rows + reduce_partials_kernel as in the render adjoint (deterministic).
+template <bool kResidual>
+__global__ __launch_bounds__(kBlockThreads) void field_eval_backward_kernel(
+    FieldArgs f, const float* __restrict__ instances, const float* __restrict__ mlp, const float* __restrict__ positions, long long num_points,
+    const float* __restrict__ grad_distances, const float* __restrict__ grad_labels, int hard_union,
+    float* __restrict__ grad_positions, float* __restrict__ partials, float* __restrict__ mlp_partials) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = wave_in_block();
+    const int lane = lane_id();
+    const int N = f.num_instances;
+    const int per_wave = ((kResidual ? kMlpLdsFloats : 0) + N * kGradStride + 3) & ~3;
+    float* wbar = lds + wave * per_wave;                                  // residual only (residual.h)
+    float* G = wbar + (kResidual ? kMlpLdsFloats : 0);
+    for (int idx = lane; idx < N * kGradStride; idx += kWave) G[idx] = 0.0f;
+    const size_t wave_global = static_cast<size_t>(blockIdx.x) * waves_per_block() + wave;
+    float* my_mlp = kResidual ? mlp_partials + wave_global * (static_cast<size_t>(N) * kMlpWeights) : nullptr;
+    if (kResidual) {
+        for (int idx = lane; idx < N * kMlpWeights; idx += kWave) my_mlp[idx] = 0.0f;
+        for (int idx = lane; idx < kMlpWeights; idx += kWave) wbar[idx] = 0.0f;
+    }
+    wave_lds_sync();
+    const long long stride = static_cast<long long>(gridDim.x) * waves_per_block() * kWave;
+    for (long long base = static_cast<long long>(wave_global) * kWave; base < num_points; base += stride) {
+        const bool valid = base + lane < num_points;
+        const long long idx = valid ? base + lane : num_points - 1;
+        const float x = positions[idx * 3 + 0], y = positions[idx * 3 + 1], z = positions[idx * 3 + 2];
+        const float u_bar = (valid && grad_distances) ? grad_distances[idx] : 0.0f;
+        // ---- forward quantities of the union ------------------------------------------------------------------------------
+        UnionSums sums = union_init();
+        float best = 3.0e38f;
+        int best_index = 0;
+        for (int i = 0; i < N; ++i) {
+            const BoxEval e = eval_instance<kResidual>(load_instance(instances, i), kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z);
+            const float lambda = (valid && grad_labels && !hard_union) ? grad_labels[idx * N + i] : 0.0f;
+            union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lambda, f.inv_t);
+            if (e.d < best) { best = e.d; best_index = i; }                   // argmin: first minimum
+        }
+        const UnionValue v = union_finish(sums, f.inv_t);
+        const float lam_z = sums.L * v.inv_z;
+        // ---- per instance ------------------------------------------------------------------------------------------------------
+        float xb = 0.0f, yb = 0.0f, zb = 0.0f;
+        for (int i = 0; i < N; ++i) {
+            const Instance in = load_instance(instances, i);
+            const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z);
+            float d_bar;
+            if (hard_union) {
+                d_bar = (i == best_index) ? u_bar : 0.0f;
+            } else {
+                const float ds = e.d - v.m;
+                const float w = fast_exp(-ds * f.inv_t) * v.inv_z;
+                const float cc = w * (1.0f - (ds - v.us) * f.inv_t);
+                const float lambda = (valid && grad_labels) ? grad_labels[idx * N + i] : 0.0f;
+                d_bar = u_bar * cc - f.inv_t * w * (lambda - lam_z);
+            }
+            xb += d_bar * e.gwx; yb += d_bar * e.gwy; zb += d_bar * e.gwz;
+            // box adjoint of d_i with no gradient adjoint: q_bar = d_bar h, p_bar = sign(p) q_bar (+ the residual's)
+            const float qbx = d_bar * e.hx, qby = d_bar * e.hy, qbz = d_bar * e.hz;
+            float pbx = sign_of(e.px) * qbx, pby = sign_of(e.py) * qby, pbz = sign_of(e.pz) * qbz;
+            if (kResidual) {
+                const ResidualAdjoint ra = residual_backward(mlp + i * kMlpWeights, e.px, e.py, e.pz, d_bar, 0.0f, 0.0f, 0.0f, wbar, lane, 0xFu);
+                pbx += ra.px; pby += ra.py; pbz += ra.pz;
+            }
+            const float packed[16] = {-(in.r00 * pbx + in.r01 * pby + in.r02 * pbz), -(in.r10 * pbx + in.r11 * pby + in.r12 * pbz),
+                                      -(in.r20 * pbx + in.r21 * pby + in.r22 * pbz),
+                                      e.relx * pbx, e.relx * pby, e.relx * pbz, e.rely * pbx, e.rely * pby, e.rely * pbz,
+                                      e.relz * pbx, e.relz * pby, e.relz * pbz, -qbx, -qby, -qbz, 0.0f};
+            const float mine = wave_reduce16_scatter(packed, lane);
+            if (lane < kGradStride) G[i * kGradStride + lane] += mine;
+            if (kResidual) {
+                float* dst = my_mlp + static_cast<size_t>(i) * kMlpWeights;
+                wave_lds_sync();
+                for (int k = lane; k < kMlpWeights; k += kWave) { dst[k] += wbar[k]; wbar[k] = 0.0f; }
+                wave_lds_sync();
+            }
+        }
+        if (grad_positions && valid) { grad_positions[idx * 3 + 0] = xb; grad_positions[idx * 3 + 1] = yb; grad_positions[idx * 3 + 2] = zb; }
+    }
+    wave_lds_sync();
+    float* out = partials + wave_global * (N * kGradStride);
+    for (int idx = lane; idx < N * kGradStride; idx += kWave) out[idx] = G[idx];
+}
+
 // Union distance only (no normal): what sphere tracing evaluates per step.
 template <bool kResidual>
 __device__ __forceinline__ float union_distance(const FieldArgs& f, const float* __restrict__ instances, const float* __restrict__ mlp,

@@ -319,23 +319,64 @@ def hierarchical_volumetric_rendering(
     )
 
 
+class _EvaluateField(torch.autograd.Function):
+    """vsrd_field_eval / vsrd_field_eval_backward: the closure call of scripts/main.py:433-509, differentiable w.r.t. the field
+    parameters and the positions through the distances and the labels (the analytic normal output is not differentiated)."""
+
+    @staticmethod
+    def forward(ctx, instances, mlp_weights, positions, temperature, hard, want_gradients, want_labels):
+        lib = _lib.load()
+        P, N = positions.shape[0], instances.shape[0]
+        dev = positions.device
+        instances = instances.detach().contiguous()
+        mlp_weights = None if mlp_weights is None else mlp_weights.detach().contiguous()
+        distances = torch.empty(P, dtype=torch.float32, device=dev)
+        gradients = torch.empty(P, 3, dtype=torch.float32, device=dev) if want_gradients else None
+        labels = torch.empty(P, N, dtype=torch.float32, device=dev) if want_labels else None
+        field = _lib.make_field(instances, temperature, mlp_weights)
+        _lib.check(lib.vsrd_field_eval(field, _lib.ptr(positions), P, _lib.ptr(distances), _lib.ptr(gradients), _lib.ptr(labels),
+                                       1 if hard else 0, _lib.stream()))
+        ctx.save_for_backward(instances, positions, *([mlp_weights] if mlp_weights is not None else []))
+        ctx.meta = (temperature, hard)
+        ctx.set_materialize_grads(False)
+        outs = (distances, labels if want_labels else distances.new_empty(0), gradients if want_gradients else distances.new_empty(0))
+        ctx.mark_non_differentiable(outs[2])
+        return outs
+
+    @staticmethod
+    def backward(ctx, grad_distances, grad_labels, _grad_normals):
+        lib = _lib.load()
+        instances, positions, *rest = ctx.saved_tensors
+        mlp_weights = rest[0] if rest else None
+        temperature, hard = ctx.meta
+        if grad_labels is not None and grad_labels.numel() == 0:
+            grad_labels = None
+        P, N = positions.shape[0], instances.shape[0]
+        grad_distances = None if grad_distances is None else grad_distances.to(torch.float32).contiguous()
+        grad_labels = None if grad_labels is None else grad_labels.to(torch.float32).contiguous()
+        grad_positions = torch.empty_like(positions) if ctx.needs_input_grad[2] else None
+        grad_instances = torch.empty_like(instances)
+        grad_mlp = None if mlp_weights is None else torch.empty_like(mlp_weights)
+        workspace = _workspace(positions.device, N, mlp_weights is not None)
+        field = _lib.make_field(instances, temperature, mlp_weights)
+        _lib.check(lib.vsrd_field_eval_backward(field, _lib.ptr(positions), P, _lib.ptr(grad_distances), _lib.ptr(grad_labels), 1 if hard else 0,
+                                                workspace.data_ptr(), workspace.numel(), _lib.ptr(grad_positions), _lib.ptr(grad_instances),
+                                                _lib.ptr(grad_mlp), _lib.stream()))
+        return grad_instances, grad_mlp, grad_positions, None, None, None, None
+
+
 def evaluate_field(distance_field, positions, with_gradients=False, with_labels=None):
     """What calling the reference closure does (main.py:477-509): soft union -> (distances [...,1], labels [...,N]);
-    hard union / plain sdfs -> distances [...,1].  ``with_gradients`` adds the analytic normal [...,3]."""
-    lib = _lib.load()
+    hard union / plain sdfs -> distances [...,1].  ``with_gradients`` adds the analytic normal [...,3].
+    Distances and labels are autograd-connected to the field parameters and to ``positions`` (vsrd_field_eval_backward)."""
     block = flatten(distance_field)
     if with_labels is None:  # the soft union returns (distances, features); plain sdfs / hard unions distances only
         with_labels = (not block.hard) and (isinstance(distance_field, SoftUnion) or "distance_fields" in _closure_vars(distance_field))
     lead = positions.shape[:-1]
     pts = positions.reshape(-1, 3).to(torch.float32).contiguous()
-    P, N = pts.shape[0], block.num_instances
-    distances = torch.empty(P, dtype=torch.float32, device=pts.device)
-    gradients = torch.empty(P, 3, dtype=torch.float32, device=pts.device) if with_gradients else None
-    labels = torch.empty(P, N, dtype=torch.float32, device=pts.device) if with_labels else None
-    mlp = None if block.mlp_weights is None else block.mlp_weights.detach().contiguous()
-    field = _lib.make_field(block.instances.detach().contiguous(), block.temperature, mlp)
-    _lib.check(lib.vsrd_field_eval(field, _lib.ptr(pts), P, _lib.ptr(distances), _lib.ptr(gradients), _lib.ptr(labels),
-                                   1 if block.hard else 0, _lib.stream()))
+    N = block.num_instances
+    distances, labels, gradients = _EvaluateField.apply(block.instances, block.mlp_weights, pts, block.temperature, bool(block.hard),
+                                                        bool(with_gradients), bool(with_labels))
     out = [distances.reshape(*lead, 1)]
     if with_labels:
         out.append(_scatter_labels(labels, block).reshape(*lead, N))
@@ -347,8 +388,6 @@ def evaluate_field(distance_field, positions, with_gradients=False, with_labels=
 def sphere_tracing(distance_field, ray_positions, ray_directions, num_iterations, convergence_criteria, foreground_masks=None,
                    bounding_radius=None, initialization=True, differentiable=False):
     """Drop-in for vsrd.rendering.sphere_tracing (renderers.py:21-73): returns (ray_positions [...,3], convergence_masks [...,1])."""
-    if differentiable:
-        raise NotImplementedError("sphere_tracing(differentiable=True) (renderers.py:61-71) is not implemented; scripts/main.py uses False")
     lib = _lib.load()
     block = flatten(distance_field)
     origins, directions, stride, lead = _prepare_rays(ray_positions, ray_directions)
@@ -364,7 +403,16 @@ def sphere_tracing(distance_field, ray_positions, ray_directions, num_iterations
                                      int(num_iterations), float(convergence_criteria), float(bounding_radius or 0.0),
                                      1 if initialization else 0, 1 if block.hard else 0, _lib.ptr(positions), converged.data_ptr(),
                                      _lib.stream()))
-    return positions.reshape(*lead, 3), converged.to(torch.bool).reshape(*lead, 1)
+    positions, converged = positions.reshape(*lead, 3), converged.to(torch.bool).reshape(*lead, 1)
+    if differentiable:
+        # renderers.py:59-72: one Newton step along the ray at the traced point; the step length -sdf / (grad sdf . r) carries the
+        # dependence on the field parameters (the normal enters as a constant, exactly as the reference's autograd.grad without
+        # create_graph leaves it)
+        out = evaluate_field(distance_field, positions, with_gradients=True, with_labels=False)
+        sdf, normals = out[0], out[-1]
+        step = -sdf / (normals * ray_directions.to(normals.dtype)).sum(dim=-1, keepdim=True)
+        positions = torch.where(converged, positions + ray_directions * step, positions)
+    return positions, converged
 
 
 def surface_normal(distance_field, surface_positions, finite_difference_epsilon=None):
