@@ -541,7 +541,8 @@ int32_t vsrd_sample_rays(const float* weights, int64_t count, int32_t num_sample
     const long long want = (count + 255) / 256;
     const int blocks = static_cast<int>(want > 4096 ? 4096 : want);
     hipLaunchKernelGGL(sample_clear_kernel, dim3(1), dim3(256), 0, s, scratch);
-    hipLaunchKernelGGL(keys_histogram_kernel, dim3(blocks), dim3(256), 0, s, weights, static_cast<long long>(count), seed, stream_offset, device_step, scratch);
+    // every workgroup ends with one global atomic per occupied bin (~100): few, fat workgroups keep that tail short
+    hipLaunchKernelGGL(keys_histogram_kernel, dim3(blocks > 512 ? 512 : blocks), dim3(256), 0, s, weights, static_cast<long long>(count), seed, stream_offset, device_step, scratch);
     hipLaunchKernelGGL(threshold_kernel, dim3(1), dim3(kWave), 0, s, scratch, num_samples);
     hipLaunchKernelGGL(collect_kernel, dim3(blocks), dim3(256), 0, s, weights, static_cast<long long>(count), seed, stream_offset, device_step, scratch);
     hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, s, scratch, num_samples, reinterpret_cast<long long*>(indices));
