@@ -124,3 +124,47 @@ def test_config3_shapes_many_instances(dev):
     assert (ref["labels"] - out["labels"]).abs().max() < 2e-6
     for a, b in zip(grads, ref_grads):
         assert (a - b).abs().max() <= 2e-4 * max(float(b.abs().max()), 1e-6)
+
+
+def test_config1_full_frame_against_the_oracle(dev):
+    """BASELINE config 1 (1 target + 2 source views, 4 instances, 128 x 128, 32 samples/ray: the reference's CPU-runnable case) at
+    its FULL size, all 49 152 rays: the fused step (render + silhouette BCE + adjoint) against the CPU oracle with identical
+    uniforms -- silhouettes within 1e-4 max-abs (the north-star bar), the loss and the raw-parameter gradients."""
+    import bench
+    from oracle import fields as ofields, rendering as orendering, geometry as ogeometry, losses as olosses
+    from vsrd_amd import rendering
+    N, S, V, H, W = 4, 32, 3, 128, 128
+    det, cam, dirs = scene(dev, N, V, H, W, seed=1)
+    directions = dirs.reshape(-1, 3)
+    origins = cam[:, None, None, :].expand(V, H, W, 3).reshape(-1, 3).contiguous()
+    R = directions.shape[0]
+    gen = torch.Generator().manual_seed(0)
+    u_coarse, u_fine = torch.rand(R, S, generator=gen), torch.rand(R, S, generator=gen)
+    targets = torch.rand(R, N, generator=gen).round()
+    T, std, ratio = 0.55, 0.55, 0.5
+    loss, labels = rendering.silhouette_step(bench.build_union(det, T), origins, directions, targets.to(dev), (0.0, 100.0), S, std, ratio,
+                                             u_coarse=u_coarse.to(dev), u_fine=u_fine.to(dev), return_labels=True, skip_exact_misses=True)
+    raw = [det.locations, det.dimensions, det.orientations]
+    grads = torch.autograd.grad(loss, raw)
+    # oracle, in chunks of image rows (bounded memory), same decode from the raw parameters
+    oraw = [p.detach().cpu()[0].clone().requires_grad_(True) for p in raw]
+    loc, dim, rot, _ = ogeometry.decode_box_parameters(*oraw)
+    union = ofields.InstanceUnion(loc, rot, dim, T)
+    olabels, total = [], 0.0
+    ograds = [torch.zeros_like(p) for p in oraw]
+    chunk = 4096
+    for start in range(0, R, chunk):
+        sl = slice(start, start + chunk)
+        out = orendering.hierarchical_render(union, origins[sl].cpu(), directions[sl].cpu(), (0.0, 100.0), S, std, ratio, u_coarse[sl], u_fine[sl])
+        part = torch.nn.functional.binary_cross_entropy(out.labels.clamp(1e-6, 1 - 1e-6), targets[sl], reduction="none").sum() / (R * N)
+        for acc, g in zip(ograds, torch.autograd.grad(part, oraw, retain_graph=False)):
+            acc += g
+        total += float(part.detach())
+        olabels.append(out.labels.detach())
+        loc, dim, rot, _ = ogeometry.decode_box_parameters(*oraw)            # fresh graph for the next chunk
+        union = ofields.InstanceUnion(loc, rot, dim, T)
+    olabels = torch.cat(olabels)
+    assert (labels.cpu() - olabels).abs().max() < 1e-4
+    assert abs(float(loss) - total) < 1e-5 * max(total, 1.0)
+    for got, want in zip(grads, ograds):
+        assert (got.cpu()[0] - want).abs().max() <= 5e-3 * float(want.abs().max())
