@@ -97,6 +97,71 @@ __global__ __launch_bounds__(kBlockThreads) void render_forward_kernel(
 // ---------------------------------------------------------------------------------------------------
 // scripts/main.py:511-523 (two-pass wrapper) in one launch
 // ---------------------------------------------------------------------------------------------------
+// Stratified distances (samplers.py:5-8) and the sorted fine uniforms of one ray, into the wave's LDS (l.coarse, l.usorted).
+// In-kernel randomness: Philox4x32-10 per (ray, sample).  The S fine uniforms are needed SORTED (samplers.py:22); instead of drawing
+// and sorting, they are generated in order as normalised partial sums of S+1 exponential spacings (the order statistics of S iid
+// uniforms have exactly this distribution): one log + one wave scan instead of a sort.  Supplied uniforms (parity tests, the
+// API-faithful path) are rank-sorted in LDS unless the caller says they are sorted.
+template <int kRoundsS>
+__device__ __forceinline__ void stage_ray_samples(const WaveLds& l, const RenderArgs& c, int S, int ray, const float* __restrict__ u_coarse,
+                                                  const float* __restrict__ u_fine, float* __restrict__ u_coarse_out,
+                                                  float* __restrict__ u_fine_out, bool sorted_input, int lane) {
+    const size_t row = static_cast<size_t>(ray) * S;
+    const bool philox = (u_coarse == nullptr || u_fine == nullptr);
+    float spacing[kRoundsS];
+    float running = 0.0f, extra_spacing = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kRoundsS; ++k) {
+        const int idx = k * kWave + lane;
+        spacing[k] = 0.0f;
+        if (k * kWave >= S) continue;
+        float uc = 0.0f, uf = 0.0f;
+        if (philox) {
+            const Philox4 rnd = philox4x32_10(static_cast<uint32_t>(ray), static_cast<uint32_t>(idx),
+                                              static_cast<uint32_t>(c.stream_offset), static_cast<uint32_t>(c.stream_offset >> 32),
+                                              static_cast<uint32_t>(c.seed), static_cast<uint32_t>(c.seed >> 32));
+            uc = uniform_from_bits(rnd.x);
+            uf = uniform_from_bits(rnd.y);
+            if (k == 0) extra_spacing = -fast_log(1.0f - read_lane(uniform_from_bits(rnd.z), 0));   // the (S+1)-th spacing
+        }
+        const bool valid = idx < S;
+        if (u_coarse != nullptr && valid) uc = u_coarse[row + idx];
+        if (u_fine != nullptr && valid) uf = u_fine[row + idx];
+        if (valid) {
+            const float lo = torch_linspace(c.near, c.far, S + 1, idx);
+            const float hi = torch_linspace(c.near, c.far, S + 1, idx + 1);
+            l.coarse[idx] = torch_lerp(lo, hi, uc);
+            if (u_coarse_out != nullptr) u_coarse_out[row + idx] = uc;
+        }
+        if (u_fine == nullptr) {
+            const float e = valid ? -fast_log(1.0f - uf) : 0.0f;          // exponential spacing, > 0
+            const float inclusive = wave_inclusive_sum(e) + running;
+            spacing[k] = inclusive;
+            running = read_lane(inclusive, kWave - 1);
+        } else if (valid) {
+            (sorted_input ? l.usorted : l.uraw)[idx] = uf;
+            if (u_fine_out != nullptr) u_fine_out[row + idx] = uf;
+        }
+    }
+    if (u_fine == nullptr) {
+        const float inv_total = fast_rcp(running + extra_spacing);
+#pragma unroll
+        for (int k = 0; k < kRoundsS; ++k) {
+            const int idx = k * kWave + lane;
+            if (idx < S) {
+                const float sorted_u = fminf(spacing[k] * inv_total, 0.99999994f);
+                l.usorted[idx] = sorted_u;
+                if (u_fine_out != nullptr) u_fine_out[row + idx] = sorted_u;
+            }
+        }
+    }
+    wave_lds_sync();
+    if (u_fine != nullptr && !sorted_input) {
+        rank_sort<kRoundsS>(l.uraw, l.usorted, S);
+        wave_lds_sync();
+    }
+}
+
 template <int kRounds, bool kResidual>
 __global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
     FieldArgs f, const float* __restrict__ instances, const float* __restrict__ mlp, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
@@ -117,64 +182,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
     const int stride = static_cast<int>(gridDim.x) * waves_per_block();
     for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
         const Ray r = load_ray(origins, directions, c.origin_stride, ray);
-        const size_t row = static_cast<size_t>(ray) * S;
-        // ---- stratified distances (samplers.py:5-8) and the fine uniforms -------------------------
-        // In-kernel randomness: Philox4x32-10 per (ray, sample).  The S fine uniforms are needed SORTED (samplers.py:22);
-        // instead of drawing and sorting, they are generated in order as normalised partial sums of S+1 exponential spacings
-        // (the order statistics of S iid uniforms have exactly this distribution): one log + one wave scan instead of a sort.
-        const bool philox = (u_coarse == nullptr || u_fine == nullptr);
-        float spacing[kRoundsS];
-        float running = 0.0f, extra_spacing = 0.0f;
-#pragma unroll
-        for (int k = 0; k < kRoundsS; ++k) {
-            const int idx = k * kWave + lane;
-            spacing[k] = 0.0f;
-            if (k * kWave >= S) continue;
-            float uc = 0.0f, uf = 0.0f;
-            if (philox) {
-                const Philox4 rnd = philox4x32_10(static_cast<uint32_t>(ray), static_cast<uint32_t>(idx),
-                                                  static_cast<uint32_t>(c.stream_offset), static_cast<uint32_t>(c.stream_offset >> 32),
-                                                  static_cast<uint32_t>(c.seed), static_cast<uint32_t>(c.seed >> 32));
-                uc = uniform_from_bits(rnd.x);
-                uf = uniform_from_bits(rnd.y);
-                if (k == 0) extra_spacing = -fast_log(1.0f - read_lane(uniform_from_bits(rnd.z), 0));   // the (S+1)-th spacing
-            }
-            const bool valid = idx < S;
-            if (u_coarse != nullptr && valid) uc = u_coarse[row + idx];
-            if (u_fine != nullptr && valid) uf = u_fine[row + idx];
-            if (valid) {
-                const float lo = torch_linspace(c.near, c.far, S + 1, idx);
-                const float hi = torch_linspace(c.near, c.far, S + 1, idx + 1);
-                l.coarse[idx] = torch_lerp(lo, hi, uc);
-                if (u_coarse_out != nullptr) u_coarse_out[row + idx] = uc;
-            }
-            if (u_fine == nullptr) {
-                const float e = valid ? -fast_log(1.0f - uf) : 0.0f;          // exponential spacing, > 0
-                const float inclusive = wave_inclusive_sum(e) + running;
-                spacing[k] = inclusive;
-                running = read_lane(inclusive, kWave - 1);
-            } else if (valid) {
-                (sorted_input ? l.usorted : l.uraw)[idx] = uf;
-                if (u_fine_out != nullptr) u_fine_out[row + idx] = uf;
-            }
-        }
-        if (u_fine == nullptr) {
-            const float inv_total = fast_rcp(running + extra_spacing);
-#pragma unroll
-            for (int k = 0; k < kRoundsS; ++k) {
-                const int idx = k * kWave + lane;
-                if (idx < S) {
-                    const float sorted_u = fminf(spacing[k] * inv_total, 0.99999994f);
-                    l.usorted[idx] = sorted_u;
-                    if (u_fine_out != nullptr) u_fine_out[row + idx] = sorted_u;
-                }
-            }
-        }
-        wave_lds_sync();
-        if (u_fine != nullptr && !sorted_input) {
-            rank_sort<kRoundsS>(l.uraw, l.usorted, S);
-            wave_lds_sync();
-        }
+        stage_ray_samples<kRoundsS>(l, c, S, ray, u_coarse, u_fine, u_coarse_out, u_fine_out, sorted_input, lane);
         // ---- pass 1: coarse weights only (no labels, no outputs) ----------------------------------
         float w1[kRoundsS];
         render_pass<kRoundsS, false, kResidual>(instances, mlp, f.num_instances, sh, r, l.coarse, S, l.dcache, w1, nullptr, nullptr);
@@ -594,56 +602,8 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
     for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
         wave_lds_sync();
         const Ray r = load_ray(origins, directions, c.origin_stride, ray);
-        const size_t row = static_cast<size_t>(ray) * S;
         const float target = (lane < N) ? targets[static_cast<size_t>(ray) * N + lane] : 0.0f;
-        // ---- uniforms + stratified distances (as render_hierarchical_kernel) --------------------------
-        const bool philox = (u_coarse == nullptr || u_fine == nullptr);
-        float spacing[kRoundsS];
-        float running = 0.0f, extra_spacing = 0.0f;
-#pragma unroll
-        for (int k = 0; k < kRoundsS; ++k) {
-            const int idx = k * kWave + lane;
-            spacing[k] = 0.0f;
-            if (k * kWave >= S) continue;
-            float uc = 0.0f, uf = 0.0f;
-            if (philox) {
-                const Philox4 rnd = philox4x32_10(static_cast<uint32_t>(ray), static_cast<uint32_t>(idx),
-                                                  static_cast<uint32_t>(c.stream_offset), static_cast<uint32_t>(c.stream_offset >> 32),
-                                                  static_cast<uint32_t>(c.seed), static_cast<uint32_t>(c.seed >> 32));
-                uc = uniform_from_bits(rnd.x);
-                uf = uniform_from_bits(rnd.y);
-                if (k == 0) extra_spacing = -fast_log(1.0f - read_lane(uniform_from_bits(rnd.z), 0));
-            }
-            const bool valid = idx < S;
-            if (u_coarse != nullptr && valid) uc = u_coarse[row + idx];
-            if (u_fine != nullptr && valid) uf = u_fine[row + idx];
-            if (valid) {
-                const float lo = torch_linspace(c.near, c.far, S + 1, idx);
-                const float hi = torch_linspace(c.near, c.far, S + 1, idx + 1);
-                l.coarse[idx] = torch_lerp(lo, hi, uc);
-            }
-            if (u_fine == nullptr) {
-                const float e = valid ? -fast_log(1.0f - uf) : 0.0f;
-                const float inclusive = wave_inclusive_sum(e) + running;
-                spacing[k] = inclusive;
-                running = read_lane(inclusive, kWave - 1);
-            } else if (valid) {
-                (sorted_input ? l.usorted : l.uraw)[idx] = uf;
-            }
-        }
-        if (u_fine == nullptr) {
-            const float inv_total = fast_rcp(running + extra_spacing);
-#pragma unroll
-            for (int k = 0; k < kRoundsS; ++k) {
-                const int idx = k * kWave + lane;
-                if (idx < S) l.usorted[idx] = fminf(spacing[k] * inv_total, 0.99999994f);
-            }
-        }
-        wave_lds_sync();
-        if (u_fine != nullptr && !sorted_input) {
-            rank_sort<kRoundsS>(l.uraw, l.usorted, S);
-            wave_lds_sync();
-        }
+        stage_ray_samples<kRoundsS>(l, c, S, ray, u_coarse, u_fine, nullptr, nullptr, sorted_input, lane);
         // ---- pass 1 ------------------------------------------------------------------------------------
         float w1[kRoundsS];
         render_pass<kRoundsS, false, false>(instances, nullptr, N, sh, r, l.coarse, S, l.dcache, w1, nullptr, nullptr);
