@@ -190,19 +190,19 @@ def main():
         params += [detector.embeddings, *hyper.parameters()]
     optimizer = torch.optim.Adam(params, lr=1e-2)
     skip = not args.no_skip_misses and not args.residual     # eikonal needs every ray's gradients
-    fused = not args.two_launch and not args.residual        # one launch: render + silhouette BCE + adjoint
+    fused = not args.two_launch                               # one launch: render + silhouette BCE (+ eikonal) + adjoint
 
     def step(index):
         optimizer.zero_grad(set_to_none=True)
         union = build_union(detector, sched["temperature"])
+        if hyper is not None:
+            union.mlp_weights = hyper(detector.embeddings)[0].contiguous()
         if fused:
             loss = rendering.silhouette_step(union, origins, directions, targets, (0.0, 100.0), S, sched["std"], sched["cosine_ratio"],
-                                             seed=rank, stream_offset=index, skip_exact_misses=skip)
+                                             seed=rank, stream_offset=index, skip_exact_misses=skip, eikonal_ratio=0.01 if hyper is not None else 0.0)
             loss.backward()
             optimizer.step()
             return loss
-        if hyper is not None:
-            union.mlp_weights = hyper(detector.embeddings)[0].contiguous()
         out = rendering.render_hierarchical(union, origins, directions, (0.0, 100.0), S, sched["std"], sched["cosine_ratio"],
                                             seed=rank, stream_offset=index, skip_exact_misses=skip, return_gradients=hyper is not None)
         loss = torch.nn.functional.binary_cross_entropy(out["labels"].clamp(1.0e-6, 1.0 - 1.0e-6), targets, reduction="none").mean()
@@ -239,9 +239,10 @@ def main():
         #   forward launch : direction 12 + labels out 4N ; backward launch: direction re-read 12 + grad_labels in 4N
         #   fused step launch: direction 12 + targets 4N (labels, label adjoints and saved distances never leave the chip)
         if fused:
-            fwd_n, fwd_ms = kernels["vsrd_render_silhouette_step"]
+            entry = "vsrd_render_residual_step" if args.residual else "vsrd_render_silhouette_step"
+            fwd_n, fwd_ms = kernels[entry]
             bwd_n, bwd_ms = 0, 0.0
-            dominant, dom_ms, dom_bytes, symbol = "vsrd_render_silhouette_step", fwd_ms, 12 + 4 * N, "render_silhouette_kernel"
+            dominant, dom_ms, dom_bytes, symbol = entry, fwd_ms, 12 + 4 * N, "render_residual_step_kernel" if args.residual else "render_silhouette_kernel"
         else:
             fwd_n, fwd_ms = kernels["vsrd_render_hierarchical_forward"]
             bwd_n, bwd_ms = kernels["vsrd_render_backward"]
@@ -262,8 +263,9 @@ def main():
                                    f"{S} samples/ray (pass 1: {S - 1}, pass 2: {2 * S - 1} points), " + ("box + residual-MLP field, eikonal loss" if args.residual else "box-only field"),
                        "schedule": f"{args.schedule}: T=std={sched['std']:.3f}, cosine_ratio={sched['cosine_ratio']:.2f}",
                        "skip_exact_misses": skip, "rng": "in-kernel Philox4x32-10", "rays_per_gpu": R,
-                       "loss": ("silhouette BCE fused into the render kernel" if fused else "silhouette BCE (torch elementwise)") + " + Adam on raw box parameters",
-                       "launches_per_step": "1 fused (render + BCE + adjoint) + partial reductions" if fused else "forward, torch BCE, backward",
+                       "loss": ("silhouette BCE" + (" + 0.01 eikonal" if args.residual else "") + " fused into the render kernel" if fused
+                                else "silhouette BCE" + (" + 0.01 eikonal" if args.residual else "") + " (torch elementwise)") + " + Adam",
+                       "launches_per_step": "1 fused (render + loss + adjoint) + partial reductions" if fused else "forward, torch loss, backward",
                        "final_loss": float(loss.detach()), "target_empty_fraction": miss},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

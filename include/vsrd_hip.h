@@ -91,6 +91,19 @@ const char* vsrd_error_string(int32_t code);
 /* Bytes of scratch vsrd_render_backward needs for a field of N instances (residual != 0: with per-instance MLP). */
 size_t vsrd_workspace_bytes(int32_t num_instances, int32_t residual);
 
+/* The same fusion for RESIDUAL fields (BASELINE config 3; the reference's steps after warm-up): two-pass render + silhouette BCE
+ * (scripts/main.py:653-671) + eikonal term (main.py:679-687: mean over all R (2S-1) samples of (|grad sdf| - 1)^2) + adjoint, one
+ * launch.  The differentiated quantity is  losses[0] + eikonal_ratio * losses[1]  with
+ *   losses[0] = sum_{r,n} w_n BCE(...) * loss_scale      losses[1] = mean (|grad sdf| - 1)^2 ;
+ * grad_instances [N,16] and grad_mlp_weights [N,1617] are its gradients.  Needs vsrd_workspace_bytes(N, 1) of scratch.
+ * VSRD_FLAG_SKIP_EXACT_MISSES is ignored (the eikonal term needs every ray). */
+int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_config* config,
+                                  const float* origins, const float* directions, const float* u_coarse, const float* u_fine,
+                                  const float* targets /* [R,N] */, const float* instance_weights /* [N] or NULL */, float loss_scale,
+                                  float eikonal_ratio, void* workspace, size_t workspace_bytes,
+                                  float* losses /* [2] */, float* grad_instances, float* grad_mlp_weights, float* labels /* [R,N] or NULL */,
+                                  void* stream);
+
 /* Hungarian matching of predicted to ground-truth 2-D boxes of the target view (scripts/main.py:374-386:
  * scipy.optimize.linear_sum_assignment(-torchvision.ops.distance_box_iou(pd, gt).cpu())), on the device -- no host
  * synchronisation, capturable in a hipGraph.  pd_boxes [P,4], gt_boxes [G,4] (x1,y1,x2,y2), 1 <= P,G <= 64.

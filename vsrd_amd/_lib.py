@@ -79,6 +79,9 @@ SIGNATURES = {
     "vsrd_render_silhouette_step": (ctypes.c_int32, [ctypes.POINTER(Field), ctypes.POINTER(RenderConfig), c_float_p, c_float_p, c_float_p,
                                                      c_float_p, c_float_p, c_float_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,
                                                      c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
+    "vsrd_render_residual_step": (ctypes.c_int32, [ctypes.POINTER(Field), ctypes.POINTER(RenderConfig), c_float_p, c_float_p, c_float_p,
+                                                   c_float_p, c_float_p, c_float_p, ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
+                                                   ctypes.c_size_t, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
     "vsrd_project_boxes_forward": (ctypes.c_int32, [c_float_p, c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                                     ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
                                                     c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_void_p]),

@@ -529,6 +529,64 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
     return launch_status();
 }
 
+int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_config* config,
+                                  const float* origins, const float* directions, const float* u_coarse, const float* u_fine,
+                                  const float* targets, const float* instance_weights, float loss_scale, float eikonal_ratio,
+                                  void* workspace, size_t workspace_bytes,
+                                  float* losses, float* grad_instances, float* grad_mlp_weights, float* labels, void* stream) {
+    if (!valid_field(field) || !valid_config(config) || !workspace || !losses || !grad_instances || !grad_mlp_weights) return VSRD_E_INVALID_ARGUMENT;
+    if (field->mlp_weights == nullptr) return VSRD_E_INVALID_ARGUMENT;       // box-only fields: vsrd_render_silhouette_step
+    const int N = field->num_instances;
+    if (workspace_bytes < vsrd_workspace_bytes(N, 1)) return VSRD_E_WORKSPACE;
+    const hipStream_t s = static_cast<hipStream_t>(stream);
+    const int row = N * kGradStride, mlp_row = N * kMlpWeights;
+    if (config->num_rays == 0) {
+        if (hipMemsetAsync(losses, 0, 2 * sizeof(float), s) != hipSuccess) return VSRD_E_LAUNCH;
+        if (hipMemsetAsync(grad_mlp_weights, 0, mlp_row * sizeof(float), s) != hipSuccess) return VSRD_E_LAUNCH;
+        return hipMemsetAsync(grad_instances, 0, row * sizeof(float), s) == hipSuccess ? VSRD_OK : VSRD_E_LAUNCH;
+    }
+    if (!origins || !directions || !targets) return VSRD_E_INVALID_ARGUMENT;
+    const int S = config->num_samples;
+    const int num_points = 2 * S - 1;
+    const int rounds = rounds_for(num_points);
+    Geometry g;
+    if (!plan(config->num_rays, static_cast<size_t>(residual_step_lds_floats(S, N)), &g)) return VSRD_E_UNSUPPORTED;
+    if (g.threads > kResidualWaves * kWave) return VSRD_E_UNSUPPORTED;
+    if (g.blocks > kMaxBlocksResidual) g.blocks = kMaxBlocksResidual;
+    const FieldArgs f = field_args(field);
+    RenderArgs c = render_args(config);
+    c.sh.inv_t = f.inv_t;
+    const int num_waves = g.blocks * (g.threads / kWave);
+    float* partials = static_cast<float*>(workspace);
+    float* loss_partials = partials + static_cast<size_t>(num_waves) * row;             // inside the (much larger) box-partial region
+    float* mlp_partials = partials + static_cast<size_t>(kMaxBlocks) * kMaxWavesPerBlock * row;
+    float* jets = mlp_partials + static_cast<size_t>(kMaxBlocksResidual) * kResidualWaves * mlp_row;
+    float4* residual_cache = reinterpret_cast<float4*>(jets);
+    float* seed_cache = jets + residual_jet_floats(N, true);
+    // d/dg of  eikonal_ratio * mean over [R, 2S-1] of (|g| - 1)^2 ;  the reported eikonal term is the plain mean
+    const float eikonal_norm = 1.0f / (static_cast<float>(config->num_rays) * static_cast<float>(num_points));
+    const float eikonal_scale = eikonal_ratio * eikonal_norm;
+#define VSRD_LAUNCH(K)                                                                                                             \
+    do {                                                                                                                             \
+        if (opt_in_lds(render_residual_step_kernel<K>, g.lds_bytes) != VSRD_OK) return VSRD_E_LAUNCH;                                \
+        hipLaunchKernelGGL(render_residual_step_kernel<K>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances,       \
+                           field->mlp_weights, c, origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale,       \
+                           eikonal_scale, eikonal_norm, labels, partials, mlp_partials, residual_cache, seed_cache, loss_partials);  \
+    } while (0)
+    switch (rounds) {
+        case 1: VSRD_LAUNCH(1); break;
+        case 2: VSRD_LAUNCH(2); break;
+        case 4: VSRD_LAUNCH(4); break;
+        default: return VSRD_E_UNSUPPORTED;
+    }
+#undef VSRD_LAUNCH
+    if (launch_status() != VSRD_OK) return VSRD_E_LAUNCH;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(row), dim3(256), 0, s, partials, num_waves, row, grad_instances);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(mlp_row), dim3(256), 0, s, mlp_partials, num_waves, mlp_row, grad_mlp_weights);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), dim3(256), 0, s, loss_partials, num_waves, 2, losses);
+    return launch_status();
+}
+
 size_t vsrd_sample_rays_workspace_bytes(void) { return sizeof(SampleScratch); }
 
 int32_t vsrd_sample_rays(const float* weights, int64_t count, int32_t num_samples, uint64_t seed, uint64_t stream_offset,

@@ -320,7 +320,8 @@ __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, 
 // Phase A, reverse sweep: labels -> weights -> opacity -> (u_bar, g_bar).  Returns (wave-uniformly) whether any adjoint is non-zero.
 template <int kRounds>
 __device__ __forceinline__ bool adjoint_reverse_sweep(RayAdjoint<kRounds>& st, const Shading& sh, const Ray& r, int num_points,
-                                                      const float* grad_weights_row, const float* grad_gradients_row, int lane) {
+                                                      const float* grad_weights_row, const float* grad_gradients_row, int lane,
+                                                      float eikonal_scale = 0.0f) {
     float suffix_carry = 0.0f;
     bool any_flow = false;
 #pragma unroll
@@ -355,6 +356,11 @@ __device__ __forceinline__ bool adjoint_reverse_sweep(RayAdjoint<kRounds>& st, c
         if (grad_gradients_row != nullptr && valid) {
             const float* gg = grad_gradients_row + s * 3;
             gbx += gg[0]; gby += gg[1]; gbz += gg[2];
+        }
+        if (eikonal_scale != 0.0f) {        // fused eikonal term (main.py:679-687): d/dg of eikonal_scale * (|g| - 1)^2, torch's norm' (0) = 0
+            const float norm = fast_sqrt(st.gx[k] * st.gx[k] + st.gy[k] * st.gy[k] + st.gz[k] * st.gz[k]);
+            const float pull = (norm > 0.0f) ? eikonal_scale * 2.0f * (norm - 1.0f) * fast_rcp(norm) : 0.0f;
+            gbx += pull * st.gx[k]; gby += pull * st.gy[k]; gbz += pull * st.gz[k];
         }
         if (!valid) { gbx = 0.0f; gby = 0.0f; gbz = 0.0f; }
         st.sa[k].B = gbx * st.sa[k].gbx + gby * st.sa[k].gby + gbz * st.sa[k].gbz;
@@ -653,6 +659,109 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
     for (int idx = lane; idx < N * kGradStride; idx += kWave) out[idx] = G[idx];
     const float loss_total = wave_sum(loss_acc);
     if (lane == 0) loss_partials[wave_global] = loss_total * loss_scale;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused optimisation-step kernel for RESIDUAL fields (BASELINE config 3; scripts/main.py steps >= warm-up): two-pass render +
+// silhouette BCE + eikonal term (main.py:679-687, mean over every sample of every ray of (|grad sdf| - 1)^2) + the whole adjoint in
+// one launch.  As in render_silhouette_kernel the adjoint runs on the pass-2 state the wave still holds (no second evaluation of
+// pass 2, no saved distances / gradients in HBM); as in render_backward_kernel<K, true> the MLP adjoints of a batch of rays run
+// afterwards, instance-major (adjoint_phase_mlp).  Loss = loss_partials[.][0] + eikonal_ratio * loss_partials[.][1] summed over waves.
+// ---------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int residual_step_lds_floats(int num_samples, int num_instances) {
+    return (kMlpLdsFloats + kMlpBatch * 4 * num_instances + 7 * num_samples + num_instances * kWave + num_instances + num_instances * kGradStride + 3) & ~3;
+}
+
+template <int kRounds>
+__global__ __launch_bounds__(kBlockThreads) void render_residual_step_kernel(
+    FieldArgs f, const float* __restrict__ instances, const float* __restrict__ mlp, RenderArgs c,
+    const float* __restrict__ origins, const float* __restrict__ directions, const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
+    const float* __restrict__ targets, const float* __restrict__ instance_weights, float loss_scale, float eikonal_scale, float eikonal_norm,
+    float* __restrict__ labels_out, float* __restrict__ partials, float* __restrict__ mlp_partials,
+    float4* __restrict__ residual_cache, float* __restrict__ seed_cache, float* __restrict__ loss_partials) {
+    apply_device_schedule(f, c);
+    constexpr int kRoundsS = (kRounds + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = wave_in_block();
+    const int lane = lane_id();
+    const int S = c.num_samples;
+    const int N = f.num_instances;
+    float* wbar = lds + wave * residual_step_lds_floats(S, N);            // [1617] + transposition scratch (residual.h), 16 B aligned
+    unsigned* masks = reinterpret_cast<unsigned*>(wbar + kMlpLdsFloats);  // [kMlpBatch][kRounds][N]
+    float* base = wbar + kMlpLdsFloats + kMlpBatch * 4 * N;
+    WaveLds l = carve_lds(base, S);                                        // l.dcache: [N][64], one round at a time
+    float* lam = base + wave_lds_floats(S, N);
+    float* G = lam + N;
+    for (int idx = lane; idx < N * kGradStride; idx += kWave) G[idx] = 0.0f;
+    const size_t wave_global = static_cast<size_t>(blockIdx.x) * waves_per_block() + wave;
+    float* my_mlp = mlp_partials + wave_global * (static_cast<size_t>(N) * kMlpWeights);
+    float4* rcache = residual_cache + wave_global * (static_cast<size_t>(kRounds) * N * kWave);
+    float* seeds = seed_cache + wave_global * (static_cast<size_t>(kMlpBatch) * kRounds * N * kSeedFloats * kWave);
+    for (int idx = lane; idx < N * kMlpWeights; idx += kWave) my_mlp[idx] = 0.0f;
+    for (int idx = lane; idx < kMlpWeights; idx += kWave) wbar[idx] = 0.0f;
+    const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
+    Shading sh = c.sh;
+    sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, N, f.inv_t) + 1.0f;
+    sh.mlp_bits = (c.flags & 8u) ? kMlpCentredBit : 0u;
+    const float weight_lane = (lane < N) ? (instance_weights ? instance_weights[lane] : 1.0f) : 0.0f;
+    float loss_acc = 0.0f, eikonal_acc = 0.0f;
+    const int D = 2 * S, num_points = D - 1;
+    const int stride = static_cast<int>(gridDim.x) * waves_per_block();
+    for (int first = static_cast<int>(blockIdx.x) * waves_per_block() + wave; first < c.num_rays; first += stride * kMlpBatch) {
+#pragma unroll 1
+        for (int b = 0; b < kMlpBatch; ++b) {
+            const int ray = first + b * stride;
+            unsigned* ray_masks = masks + b * kRounds * N;
+            float* ray_seeds = seeds + static_cast<size_t>(b) * (kRounds * N * kSeedFloats * kWave);
+            wave_lds_sync();
+            for (int idx = lane; idx < kRounds * N; idx += kWave) ray_masks[idx] = 0u;
+            if (ray >= c.num_rays) continue;
+            const Ray r = load_ray(origins, directions, c.origin_stride, ray);
+            const float target = (lane < N) ? targets[static_cast<size_t>(ray) * N + lane] : 0.0f;
+            stage_ray_samples<kRoundsS>(l, c, S, ray, u_coarse, u_fine, nullptr, nullptr, sorted_input, lane);
+            float w1[kRoundsS];
+            render_pass<kRoundsS, false, true>(instances, mlp, N, sh, r, l.coarse, S, l.dcache, w1, nullptr, nullptr);
+            importance_merge<kRoundsS>(l, S, w1);
+            RayAdjoint<kRounds> st;
+            const float label = adjoint_forward_sweep<kRounds, true, true>(st, instances, mlp, N, sh, r, l.merged, num_points, nullptr, l.dcache, lane, rcache);
+            if (labels_out != nullptr && lane < N) labels_out[static_cast<size_t>(ray) * N + lane] = label;
+            // silhouette BCE and its gradient (as render_silhouette_kernel)
+            const float p = fminf(fmaxf(label, 1.0e-6f), 1.0f - 1.0e-6f);
+            const float bce = -(target * logf(p) + (1.0f - target) * logf(1.0f - p));
+            loss_acc += (lane < N) ? weight_lane * bce : 0.0f;
+            const bool inside_clamp = (label >= 1.0e-6f) && (label <= 1.0f - 1.0e-6f);
+            const float lam_lane = (lane < N && inside_clamp) ? weight_lane * loss_scale * (p - target) / fmaxf(p * (1.0f - p), 1.0e-12f) : 0.0f;
+            if (lane < N) lam[lane] = lam_lane;
+            wave_lds_sync();
+#pragma unroll
+            for (int k = 0; k < kRounds; ++k) {
+                if (k * kWave >= num_points) continue;
+                // eikonal value of this round's samples
+                const float norm = fast_sqrt(st.gx[k] * st.gx[k] + st.gy[k] * st.gy[k] + st.gz[k] * st.gz[k]);
+                eikonal_acc += (k * kWave + lane < num_points) ? (norm - 1.0f) * (norm - 1.0f) : 0.0f;
+                // Lambda_s = sum_n lambda_n w_{s,n}: box distance re-evaluated, residual value from the sweep's jet cache
+                float acc = 0.0f;
+                for (int i = 0; i < N; ++i) {
+                    if (lam[i] == 0.0f) continue;                               // wave-uniform
+                    if (!((st.near_any[k] >> i) & 1ull)) continue;                // culled by the forward sweep
+                    const Instance in = load_instance(instances, i);
+                    const BoxEval e = eval_box(in, st.sa[k].x, st.sa[k].y, st.sa[k].z);
+                    const float d = e.d + rcache[(k * N + i) * kWave + lane].x;
+                    acc += lam[i] * fast_exp(-(d - st.sa[k].m) * sh.inv_t);
+                }
+                st.sa[k].lam_z = acc * st.sa[k].inv_z;
+            }
+            if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, nullptr, nullptr, lane, eikonal_scale)) continue;
+            adjoint_phase_b<kRounds, true>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, ray_seeds, ray_masks);
+        }
+        wave_lds_sync();                                                     // masks: written by lanes < kRounds, read by all
+        adjoint_phase_mlp<kRounds, kMlpBatch>(instances, mlp, N, G, wbar, my_mlp, lane, seeds, masks, sh.mlp_bits);
+    }
+    wave_lds_sync();
+    float* out = partials + wave_global * (N * kGradStride);
+    for (int idx = lane; idx < N * kGradStride; idx += kWave) out[idx] = G[idx];
+    const float loss_total = wave_sum(loss_acc), eikonal_total = wave_sum(eikonal_acc);
+    if (lane == 0) { loss_partials[2 * wave_global] = loss_total * loss_scale; loss_partials[2 * wave_global + 1] = eikonal_total * eikonal_norm; }
 }
 
 // Deterministic second stage: grad[idx] = sum over waves of partials[wave][idx].

@@ -189,20 +189,25 @@ class FrameOptimizer:
             ray_indices = self.sample_rays()
         origins = self.camera_positions[ray_indices // self.pixels_per_view]
         directions = self.ray_directions[ray_indices]
-        if residual:
-            out = rendering.render_hierarchical(block, origins, directions, cfg.distance_range, cfg.num_samples, std, ratio,
-                                                u_coarse=u_coarse, u_fine=u_fine, seed=cfg.seed, stream_offset=step if offset is None else offset,
-                                                return_gradients=True, schedule=schedule)
-            silhouette = losses.silhouette_loss(out["labels"], self.flat_masks[ray_indices], pd_idx, gt_idx)
-        else:   # box-only phase: render + silhouette BCE + adjoint in one launch
-            silhouette = rendering.silhouette_step(block, origins, directions, self.flat_masks[ray_indices], cfg.distance_range,
-                                                   cfg.num_samples, std, ratio, pd_indices=pd_idx, gt_indices=gt_idx,
-                                                   u_coarse=u_coarse, u_fine=u_fine, seed=cfg.seed, stream_offset=step if offset is None else offset,
-                                                   skip_exact_misses=cfg.skip_exact_misses, schedule=schedule)
+        weights = cfg.loss_weights
+        if residual:    # render + silhouette BCE + eikonal term + adjoint (boxes and MLP weights) in one launch
+            eikonal_ratio = weights["eikonal_loss"] / weights["silhouette_loss"]
+            rendered, parts = rendering.silhouette_step(block, origins, directions, self.flat_masks[ray_indices], cfg.distance_range,
+                                                        cfg.num_samples, std, ratio, pd_indices=pd_idx, gt_indices=gt_idx,
+                                                        u_coarse=u_coarse, u_fine=u_fine, seed=cfg.seed, stream_offset=step if offset is None else offset,
+                                                        skip_exact_misses=False, schedule=schedule, eikonal_ratio=eikonal_ratio, return_terms=True)
+            silhouette, eikonal = parts[0], parts[1]
+        else:           # box-only phase: render + silhouette BCE + adjoint in one launch
+            rendered = rendering.silhouette_step(block, origins, directions, self.flat_masks[ray_indices], cfg.distance_range,
+                                                 cfg.num_samples, std, ratio, pd_indices=pd_idx, gt_indices=gt_idx,
+                                                 u_coarse=u_coarse, u_fine=u_fine, seed=cfg.seed, stream_offset=step if offset is None else offset,
+                                                 skip_exact_misses=cfg.skip_exact_misses, schedule=schedule)
+            silhouette = rendered.detach()
         terms = dict(iou_projection_loss=iou_loss, l1_projection_loss=l1_loss, silhouette_loss=silhouette)
         if residual:
-            terms["eikonal_loss"] = losses.eikonal_loss(out["gradients"])
-        total = sum(cfg.loss_weights[name] * value for name, value in terms.items())   # main.py:855
+            terms["eikonal_loss"] = eikonal
+        # main.py:855: sum of weighted terms; `rendered` already is silhouette (+ eikonal_ratio * eikonal)
+        total = weights["iou_projection_loss"] * iou_loss + weights["l1_projection_loss"] * l1_loss + weights["silhouette_loss"] * rendered
         total.backward()
         raw_gradients = [p.grad.detach().clone() for p in (self.detector.locations, self.detector.dimensions, self.detector.orientations)]
         self.optimizer.step()

@@ -463,15 +463,54 @@ class _SilhouetteStep(torch.autograd.Function):
         return (grad * grad_loss,) + (None,) * 14
 
 
+class _ResidualStep(torch.autograd.Function):
+    """vsrd_render_residual_step: render + silhouette BCE + eikonal term + adjoint of a residual field in one launch.  The kernel
+    produces losses = (silhouette, eikonal) and the gradient of  silhouette + eikonal_ratio * eikonal  w.r.t. instances / MLP weights."""
+
+    @staticmethod
+    def forward(ctx, instances, mlp_weights, origins, directions, targets, weights, u_coarse, u_fine, temperature, scalars, origin_stride,
+                seed, stream_offset, flags, loss_scale, eikonal_ratio, want_labels):
+        lib = _lib.load()
+        std, ratio, eps, near, far, S, schedule = _unpack(scalars)
+        R, N = directions.shape[0], instances.shape[0]
+        dev = directions.device
+        instances = instances.detach().contiguous()
+        centred = _centre_mlp(mlp_weights)
+        losses = torch.empty(2, dtype=torch.float32, device=dev)
+        grad, grad_mlp = torch.empty_like(instances), torch.empty_like(centred)
+        labels = torch.empty(R, N, dtype=torch.float32, device=dev) if want_labels else None
+        workspace = _workspace(dev, N, True)
+        field = _lib.make_field(instances, temperature, centred)
+        config = _lib.make_config(R, S, (near, far), std, ratio, eps, origin_stride, seed, stream_offset, flags | _mlp_flag(centred), schedule=schedule)
+        with profiling.timed("vsrd_render_residual_step"):
+            _lib.check(lib.vsrd_render_residual_step(field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(u_coarse), _lib.ptr(u_fine),
+                                                     _lib.ptr(targets), _lib.ptr(weights), float(loss_scale), float(eikonal_ratio),
+                                                     workspace.data_ptr(), workspace.numel(), _lib.ptr(losses), _lib.ptr(grad), _lib.ptr(grad_mlp),
+                                                     _lib.ptr(labels), _lib.stream()))
+        ctx.save_for_backward(grad, grad_mlp)
+        out_labels = labels if want_labels else losses.new_empty(0)
+        terms = losses.clone()
+        ctx.mark_non_differentiable(out_labels, terms)
+        return losses[0] + eikonal_ratio * losses[1], terms, out_labels
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_terms, _grad_labels):
+        grad, grad_mlp = ctx.saved_tensors
+        return (grad * grad_loss, grad_mlp * grad_loss) + (None,) * 15
+
+
 def silhouette_step(distance_field, ray_positions, ray_directions, targets, distance_range, num_samples, sdf_std_deviation,
                     cosine_ratio=1.0, epsilon=1.0e-6, pd_indices=None, gt_indices=None, u_coarse=None, u_fine=None, seed=0,
-                    stream_offset=0, return_labels=False, skip_exact_misses=True, schedule=None):
-    """Fused fast path of scripts/main.py:629-671 for box-only fields: the two-pass render AND
-    ``mean(BCE(clamp(labels[..., pd_indices], 1e-6, 1 - 1e-6), targets[..., gt_indices]))`` in one launch.
-    Returns the loss (autograd-connected to the field parameters), and the labels [R,N] when asked."""
+                    stream_offset=0, return_labels=False, skip_exact_misses=True, schedule=None, eikonal_ratio=0.0, return_terms=False):
+    """Fused fast path of scripts/main.py:629-687: the two-pass render AND
+    ``mean(BCE(clamp(labels[..., pd_indices], 1e-6, 1 - 1e-6), targets[..., gt_indices]))`` in one launch; for residual fields
+    (box + per-instance MLP) also ``eikonal_ratio * mean((|sampled_gradients| - 1)^2)`` (main.py:679-687), i.e. the returned loss is
+    ``silhouette + eikonal_ratio * eikonal``.  Returns the loss (autograd-connected to the field parameters), then -- when asked --
+    the detached terms ``[silhouette, eikonal]`` and the labels [R,N]."""
     block = flatten(distance_field)
-    if block.mlp_weights is not None:
-        raise NotImplementedError("silhouette_step is the box-only fast path; use render_hierarchical + losses for residual fields")
+    residual = block.mlp_weights is not None
+    if eikonal_ratio and not residual:
+        raise NotImplementedError("the eikonal term is fused for residual fields only (a box-only union is not optimised with it)")
     origins, directions, stride, _ = _prepare_rays(ray_positions, ray_directions)
     R, N = directions.shape[0], block.num_instances
     targets = targets.reshape(R, -1).to(torch.float32)
@@ -492,6 +531,13 @@ def silhouette_step(distance_field, ray_positions, ray_directions, targets, dist
         u_fine = u_fine.reshape(-1, num_samples).to(torch.float32).contiguous()
     flags = (_lib.FLAG_SKIP_EXACT_MISSES if skip_exact_misses else 0) | _base_flags()
     scalars = (float(sdf_std_deviation), float(cosine_ratio), float(epsilon), float(distance_range[0]), float(distance_range[1]), int(num_samples), schedule)
-    loss, labels = _SilhouetteStep.apply(block.instances, origins, directions, ordered, weights, u_coarse, u_fine, block.temperature, scalars,
-                                         stride, int(seed), _offset(stream_offset), flags, 1.0 / (R * max(kept, 1)), bool(return_labels))
-    return (loss, labels) if return_labels else loss
+    if residual:
+        loss, terms, labels = _ResidualStep.apply(block.instances, block.mlp_weights, origins, directions, ordered, weights, u_coarse, u_fine,
+                                                  block.temperature, scalars, stride, int(seed), _offset(stream_offset), flags & ~_lib.FLAG_SKIP_EXACT_MISSES,
+                                                  1.0 / (R * max(kept, 1)), float(eikonal_ratio), bool(return_labels))
+    else:
+        loss, labels = _SilhouetteStep.apply(block.instances, origins, directions, ordered, weights, u_coarse, u_fine, block.temperature, scalars,
+                                             stride, int(seed), _offset(stream_offset), flags, 1.0 / (R * max(kept, 1)), bool(return_labels))
+        terms = torch.stack([loss.detach(), torch.zeros_like(loss.detach())])
+    out = (loss,) + ((terms,) if return_terms else ()) + ((labels,) if return_labels else ())
+    return out if len(out) > 1 else loss
