@@ -579,7 +579,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
 // (0 = unmatched instance) and loss_scale = 1 / (R * matched) reproduce the mean over kept elements.
 // ---------------------------------------------------------------------------------------------------
 template <int kRounds>
-__global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 5 : 2) void render_silhouette_kernel(
+__global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_silhouette_kernel(
     FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
     const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
     const float* __restrict__ targets, const float* __restrict__ instance_weights, float loss_scale,
