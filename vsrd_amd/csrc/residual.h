@@ -76,8 +76,6 @@ __device__ __forceinline__ Gauss gauss(float y) {
     return {(y < 0.0f) ? half_erfc : 1.0f - half_erfc, e * 0.3989422804014327f};
 #endif
 }
-__device__ __forceinline__ float gauss_pdf(float y) { return gauss(y).pdf; }
-__device__ __forceinline__ float gauss_cdf(float y) { return gauss(y).cdf; }
 
 // One 16-point tile of a 16-channel jet: value and the three tangents d/d(folded, scaled local position).
 struct TileJet { f32x4 v, t[3]; };
