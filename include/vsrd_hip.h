@@ -172,9 +172,10 @@ int32_t vsrd_sample_stratified(const vsrd_render_config* config, const float* u_
 
 /* Pass-2 distances: cat(coarse, inverse_transform_sampler(coarse, weights)) sorted
  * (renderers.py:198-210, samplers.py:11-36).  coarse_distances [R,S], coarse_weights [R,S-1],
- * u_fine [R,S] (raw draws, or sorted with VSRD_FLAG_FINE_UNIFORMS_SORTED) -> merged [R,2S]. */
+ * u_fine [R,S] (raw draws, or sorted with VSRD_FLAG_FINE_UNIFORMS_SORTED) -> merged [R,2S] and/or the sampler's own
+ * output fine [R,S] (either may be NULL). */
 int32_t vsrd_sample_importance(const vsrd_render_config* config, const float* coarse_distances,
-                               const float* coarse_weights, const float* u_fine, float* merged, void* stream);
+                               const float* coarse_weights, const float* u_fine, float* merged, float* fine, void* stream);
 
 /* renderers.py:212-270 for given sorted distances [R,D]: evaluates the field and its normal at
  * the D-1 interval mid-points, converts to opacities, composites front to back.

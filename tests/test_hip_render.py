@@ -134,6 +134,17 @@ def test_importance_merge_golden(dev, name):
     merged2 = rendering.importance_merge(g["coarse_distances"].t().contiguous().to(dev), g["coarse_weights"].t().contiguous().to(dev),
                                          uniforms=torch.sort(g["u_fine"], -1).values.to(dev), sorted_uniforms=True).cpu()
     assert torch.equal(merged, merged2)
+    # a6 by its own name: inverse_transform_sampler returns the fine samples alone; merged = sort(cat(coarse, fine))
+    hit = ~miss
+    sorted_u = torch.sort(g["u_fine"], -1).values
+    fine = rendering.inverse_transform_sampler(g["coarse_distances"].t().contiguous().to(dev), g["coarse_weights"].t().contiguous().to(dev),
+                                               int(g["num_samples"]), uniforms=sorted_u.to(dev)).cpu()
+    assert torch.equal(torch.sort(torch.cat([g["coarse_distances"].t(), fine], -1), -1).values, merged)
+    want = orendering.importance_distances(g["coarse_distances"].t().contiguous(), g["coarse_weights"].t().contiguous(), sorted_u)
+    assert_sampled_distances_close(fine[hit], want[hit], int(g["num_samples"]))
+    det = rendering.inverse_transform_sampler(g["coarse_distances"].t().contiguous().to(dev), g["coarse_weights"].t().contiguous().to(dev),
+                                              int(g["num_samples"]), deterministic=True).cpu()
+    assert torch.all(det[:, 1:] >= det[:, :-1]) and torch.isfinite(det[hit]).all()
 
 
 @pytest.mark.parametrize("name", RENDER_CASES)

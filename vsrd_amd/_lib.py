@@ -67,7 +67,7 @@ SIGNATURES = {
     "vsrd_polygon_soft_masks": (ctypes.c_int32, [c_float_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                  ctypes.c_void_p, ctypes.c_float, c_float_p, c_float_p, ctypes.c_void_p]),
     "vsrd_sample_stratified": (ctypes.c_int32, [ctypes.POINTER(RenderConfig), c_float_p, c_float_p, ctypes.c_void_p]),
-    "vsrd_sample_importance": (ctypes.c_int32, [ctypes.POINTER(RenderConfig), c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
+    "vsrd_sample_importance": (ctypes.c_int32, [ctypes.POINTER(RenderConfig), c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
     "vsrd_render_forward": (ctypes.c_int32, [ctypes.POINTER(Field), ctypes.POINTER(RenderConfig), c_float_p, c_float_p, c_float_p,
                                              ctypes.c_int32, c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
     "vsrd_render_backward": (ctypes.c_int32, [ctypes.POINTER(Field), ctypes.POINTER(RenderConfig), c_float_p, c_float_p, c_float_p,

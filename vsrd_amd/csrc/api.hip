@@ -275,10 +275,10 @@ int32_t vsrd_sample_stratified(const vsrd_render_config* config, const float* u_
 }
 
 int32_t vsrd_sample_importance(const vsrd_render_config* config, const float* coarse_distances,
-                               const float* coarse_weights, const float* u_fine, float* merged, void* stream) {
+                               const float* coarse_weights, const float* u_fine, float* merged, float* fine, void* stream) {
     if (!valid_config(config)) return VSRD_E_INVALID_ARGUMENT;
     if (config->num_rays == 0) return VSRD_OK;
-    if (!coarse_distances || !coarse_weights || !u_fine || !merged) return VSRD_E_INVALID_ARGUMENT;
+    if (!coarse_distances || !coarse_weights || !u_fine || (!merged && !fine)) return VSRD_E_INVALID_ARGUMENT;
     Geometry g;
     if (!plan(config->num_rays, wave_lds_floats(config->num_samples, 0), &g)) return VSRD_E_UNSUPPORTED;
     const RenderArgs c = render_args(config);
@@ -286,7 +286,7 @@ int32_t vsrd_sample_importance(const vsrd_render_config* config, const float* co
     const int rounds = rounds_for(config->num_samples);
 #define VSRD_LAUNCH(K)                                                                                                  \
     hipLaunchKernelGGL(sample_importance_kernel<K>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, c, coarse_distances, \
-                       coarse_weights, u_fine, merged)
+                       coarse_weights, u_fine, merged, fine)
     switch (rounds) {
         case 1: VSRD_LAUNCH(1); break;
         case 2: VSRD_LAUNCH(2); break;

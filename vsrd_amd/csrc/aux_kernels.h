@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void sample_stratified_kernel(RenderArgs c, co
 template <int kRoundsS>
 __global__ __launch_bounds__(kBlockThreads) void sample_importance_kernel(
     RenderArgs c, const float* __restrict__ coarse_distances, const float* __restrict__ coarse_weights,
-    const float* __restrict__ u_fine, float* __restrict__ merged) {
+    const float* __restrict__ u_fine, float* __restrict__ merged, float* __restrict__ fine) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = wave_in_block();
     const int lane = lane_id();
@@ -301,8 +301,13 @@ __global__ __launch_bounds__(kBlockThreads) void sample_importance_kernel(
             wave_lds_sync();
         }
         importance_merge<kRoundsS>(l, S, w1);
-        float* dst = merged + static_cast<size_t>(ray) * 2 * S;
-        for (int idx = lane; idx < 2 * S; idx += kWave) dst[idx] = l.merged[idx];
+        if (merged != nullptr) {
+            float* dst = merged + static_cast<size_t>(ray) * 2 * S;
+            for (int idx = lane; idx < 2 * S; idx += kWave) dst[idx] = l.merged[idx];
+        }
+        if (fine != nullptr) {                                                   // inverse_transform_sampler's own return value
+            for (int idx = lane; idx < S; idx += kWave) fine[row + idx] = l.fine[idx];
+        }
         wave_lds_sync();
     }
 }

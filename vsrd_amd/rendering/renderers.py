@@ -304,7 +304,7 @@ def hierarchical_volumetric_rendering(
             config = _lib.make_config(R, num_samples, distance_range, sdf_std_deviation, cosine_ratio, epsilon, stride,
                                       flags=_lib.FLAG_FINE_UNIFORMS_SORTED)
             _lib.check(lib.vsrd_sample_importance(config, _lib.ptr(coarse), _lib.ptr(cweights), _lib.ptr(u_fine),
-                                                  _lib.ptr(distances), _lib.stream()))
+                                                  _lib.ptr(distances), None, _lib.stream()))
     scalars = (float(sdf_std_deviation), float(cosine_ratio), float(epsilon), float(distance_range[0]),
                float(distance_range[1]), int(num_samples))
     labels, gradients, weights = _RenderAtDistances.apply(block.instances, block.mlp_weights, origins, directions, distances,

@@ -39,8 +39,29 @@ def importance_merge(bins, weights, uniforms=None, sorted_uniforms=False):
     out = torch.empty(b.shape[0], 2 * S, dtype=torch.float32, device=bins.device)
     config = _lib.make_config(b.shape[0], S, (0.0, 1.0), 1.0, 1.0, 1.0e-6, 3,
                               flags=_lib.FLAG_FINE_UNIFORMS_SORTED if sorted_uniforms else 0)
-    _lib.check(lib.vsrd_sample_importance(config, _lib.ptr(b), _lib.ptr(w), _lib.ptr(u), _lib.ptr(out), _lib.stream()))
+    _lib.check(lib.vsrd_sample_importance(config, _lib.ptr(b), _lib.ptr(w), _lib.ptr(u), _lib.ptr(out), None, _lib.stream()))
     return out.reshape(*lead, 2 * S)
+
+
+def inverse_transform_sampler(bins, weights, num_samples, deterministic=False, uniforms=None):
+    """Drop-in for vsrd.rendering.samplers.inverse_transform_sampler (samplers.py:11-36): ``num_samples`` (= bins.shape[-1], the
+    only case the renderer uses, renderers.py:203) sorted samples of the piecewise-constant pdf ``weights`` [..., S-1] over the
+    points ``bins`` [..., S].  ``deterministic`` takes linspace(0, 1, S) as the uniforms; ``uniforms`` [..., S] (sorted) may be given."""
+    lib = _lib.load()
+    S = bins.shape[-1]
+    if num_samples != S:
+        raise NotImplementedError("inverse_transform_sampler: num_samples must equal the number of bins (the renderer's case)")
+    lead = bins.shape[:-1]
+    b = bins.reshape(-1, S).to(torch.float32).contiguous()
+    w = weights.reshape(-1, S - 1).to(torch.float32).contiguous()
+    if uniforms is None:
+        uniforms = torch.linspace(0.0, 1.0, S, device=bins.device).expand(*lead, S) if deterministic else \
+            torch.sort(torch.rand(*lead, S, device=bins.device), dim=-1).values
+    u = uniforms.reshape(-1, S).to(torch.float32).contiguous()
+    fine = torch.empty_like(b)
+    config = _lib.make_config(b.shape[0], S, (0.0, 1.0), 1.0, 1.0, 1.0e-6, 3, flags=_lib.FLAG_FINE_UNIFORMS_SORTED)
+    _lib.check(lib.vsrd_sample_importance(config, _lib.ptr(b), _lib.ptr(w), _lib.ptr(u), None, _lib.ptr(fine), _lib.stream()))
+    return fine.reshape(*lead, S)
 
 
 _ray_workspaces = {}                       # per workspace scope, like the adjoint workspaces (renderers.py)
