@@ -568,9 +568,28 @@ def golden_hypernetwork(ref):
     save("g15_hypernetwork", embeddings=embeddings.detach(), weights=weights.detach(), probe=probe, grad_embeddings=grad_embeddings, **state)
 
 
+def golden_rendering_helpers(ref):
+    """The small functions that complete the vsrd.rendering listing: sphere_intersection, phong_shading, sdfs.norm."""
+    g = torch.Generator().manual_seed(21)
+    positions = torch.randn(12, 3, generator=g) * 3.0
+    directions = nn.functional.normalize(torch.randn(12, 3, generator=g), dim=-1)
+    near, far, hit = ref.renderers.sphere_intersection(positions, directions, 4.0)
+    args = dict(ray_directions=torch.randn(12, 3, generator=g), surface_normals=torch.randn(12, 3, generator=g),
+                light_directions=torch.randn(12, 3, generator=g), light_ambient_colors=torch.rand(3, generator=g),
+                light_diffuse_colors=torch.rand(3, generator=g), light_specular_colors=torch.rand(3, generator=g),
+                material_ambient_colors=torch.rand(12, 3, generator=g), material_diffuse_colors=torch.rand(12, 3, generator=g),
+                material_specular_colors=torch.rand(12, 3, generator=g), material_emission_colors=torch.rand(12, 3, generator=g) * 0.2,
+                material_shininesses=torch.tensor(8.0))
+    colors = ref.renderers.phong_shading(**args)
+    vectors = torch.randn(5, 3, generator=g)
+    save("g16_rendering_helpers", positions=positions, directions=directions, near=near, far=far, hit=hit, colors=colors,
+         vectors=vectors, norms=ref.sdfs.norm(vectors, dim=-1, keepdim=True), **{"phong__" + k: v for k, v in args.items()})
+
+
 def main():
     torch.set_num_threads(4)
     ref = import_reference()
+    golden_rendering_helpers(ref)
     golden_hypernetwork(ref)
     golden_box_3d_iou(ref)
     golden_ray_casting(ref)

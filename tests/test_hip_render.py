@@ -661,3 +661,21 @@ def test_fused_residual_step_matches_two_launch_path(dev, name):
         torch.testing.assert_close(loss.detach(), (silhouette + eikonal_ratio * eikonal).detach(), rtol=1e-5, atol=1e-7)
         for a, b in zip(grads, torch.autograd.grad(silhouette + eikonal_ratio * eikonal, reference)):
             assert (a - b).abs().max() <= 2e-4 * max(float(b.abs().max()), 1e-6)
+
+
+def test_shadow_rendering(dev):
+    """vsrd.rendering.shadow_rendering (renderers.py:149-174): a point is in shadow when the ray from just above it towards the light
+    converges on geometry.  One box hovering over a plane of points, light straight down (+y is down in the camera frame)."""
+    from vsrd_amd import fields, rendering
+    loc = torch.tensor([[0.0, -3.0, 10.0]], device=dev)
+    dim = torch.tensor([[1.0, 0.5, 1.0]], device=dev)
+    rot = torch.eye(3, device=dev)[None]
+    field = fields.hard_union([rendering.sdfs.translation(rendering.sdfs.rotation(fields.instance_field(rendering.sdfs.box(dim[0]), 0, 1), rot[0]), loc[0])])
+    xs = torch.linspace(-4.0, 4.0, 33, device=dev)
+    points = torch.stack([xs, torch.zeros_like(xs), torch.full_like(xs, 10.0)], -1)
+    normals = torch.tensor([0.0, -1.0, 0.0], device=dev).expand_as(points)
+    light = torch.tensor([0.0, 1.0, 0.0], device=dev).expand_as(points)
+    shadow = rendering.shadow_rendering(field, points, normals, light, 64, 1e-3, torch.ones(33, 1, dtype=torch.bool, device=dev), bounding_radius=50.0)
+    inside = (xs.abs() < 0.95)
+    outside = (xs.abs() > 1.05)
+    assert bool(shadow[inside, 0].all()) and not bool(shadow[outside, 0].any())

@@ -256,3 +256,16 @@ def test_g15_hypernetwork_state_dict_and_forward():
     torch.testing.assert_close(weights, g["weights"], rtol=1e-5, atol=1e-6)
     grad, = torch.autograd.grad((weights * g["probe"]).sum(), embeddings)
     torch.testing.assert_close(grad, g["grad_embeddings"], rtol=1e-4, atol=1e-6)
+
+
+def test_g16_rendering_helpers():
+    """sphere_intersection, phong_shading (visualisation helpers of vsrd.rendering) and sdfs.norm against the reference's outputs."""
+    from vsrd_amd import rendering
+    g = load_golden("g16_rendering_helpers")
+    near, far, hit = rendering.sphere_intersection(g["positions"], g["directions"], 4.0)
+    assert torch.equal(hit, g["hit"]) and int(hit.sum()) not in (0, hit.numel())
+    torch.testing.assert_close(near[hit], g["near"][g["hit"]], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(far[hit], g["far"][g["hit"]], rtol=1e-6, atol=1e-6)
+    colors = rendering.phong_shading(**{k[len("phong__"):]: v for k, v in g.items() if k.startswith("phong__")})
+    torch.testing.assert_close(colors, g["colors"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(rendering.sdfs.norm(g["vectors"], dim=-1, keepdim=True), g["norms"], rtol=1e-7, atol=0)

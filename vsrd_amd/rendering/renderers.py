@@ -415,6 +415,43 @@ def sphere_tracing(distance_field, ray_positions, ray_directions, num_iterations
     return positions, converged
 
 
+def sphere_intersection(ray_positions, ray_directions, bounding_radius):
+    """vsrd.rendering.sphere_intersection (renderers.py:10-18): entry / exit distances of rays with the origin-centred sphere and
+    the hit mask (the entry point is also computed inside vsrd_sphere_trace when ``initialization`` is set)."""
+    a = (ray_directions * ray_directions).sum(dim=-1, keepdim=True)
+    b = (ray_directions * ray_positions).sum(dim=-1, keepdim=True)
+    c = (ray_positions * ray_positions).sum(dim=-1, keepdim=True) - bounding_radius ** 2.0
+    discriminant = b ** 2.0 - a * c
+    root = torch.sqrt(discriminant)
+    return (-b - root) / a, (-b + root) / a, discriminant >= 0.0
+
+
+def phong_shading(ray_directions, surface_normals, light_directions, light_ambient_colors, light_diffuse_colors, light_specular_colors,
+                  material_ambient_colors, material_diffuse_colors, material_specular_colors, material_emission_colors, material_shininesses):
+    """vsrd.rendering.phong_shading (renderers.py:116-146), used by the reference's visualisation only: element-wise torch."""
+    view = torch.nn.functional.normalize(ray_directions, dim=-1)
+    normal = torch.nn.functional.normalize(surface_normals, dim=-1)
+    light = torch.nn.functional.normalize(light_directions, dim=-1)
+    incidence = (light * normal).sum(dim=-1, keepdim=True)
+    reflected = light - 2.0 * normal * incidence
+    diffuse = torch.relu(-incidence)
+    specular = torch.relu(-(reflected * view).sum(dim=-1, keepdim=True)) ** material_shininesses
+    colors = (material_emission_colors + material_ambient_colors * light_ambient_colors
+              + material_diffuse_colors * light_diffuse_colors * diffuse + material_specular_colors * light_specular_colors * specular)
+    return colors.clamp(0.0, 1.0)
+
+
+def shadow_rendering(distance_field, surface_positions, surface_normals, light_directions, num_iterations, convergence_criteria,
+                     foreground_masks, bounding_radius=None, initialization=False, implicit_differentiation=False):
+    """vsrd.rendering.shadow_rendering (renderers.py:149-174): trace from just above the surface towards the light; a point whose
+    ray converges on geometry is in shadow."""
+    _, convergence_masks = sphere_tracing(distance_field, surface_positions + surface_normals * convergence_criteria, -light_directions,
+                                          num_iterations, convergence_criteria, foreground_masks=foreground_masks,
+                                          bounding_radius=bounding_radius, initialization=initialization,
+                                          differentiable=implicit_differentiation)
+    return foreground_masks & convergence_masks
+
+
 def surface_normal(distance_field, surface_positions, finite_difference_epsilon=None):
     """Drop-in for vsrd.rendering.surface_normal (renderers.py:76-113): unit normals of the field at the given points
     (analytic gradient, or central differences when finite_difference_epsilon is given).  Not differentiable w.r.t. the field."""

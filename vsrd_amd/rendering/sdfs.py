@@ -5,7 +5,14 @@ objects (vsrd_amd.fields) instead of closures, so the renderer can hand their pa
 HIP library.  They pass through whatever the wrapped callable is (scripts/main.py wraps them
 around its own ``instance_field`` closure, main.py:533-537).
 """
+import torch
+
 from ..fields import BoxSDF, Rotation, Translation, SoftUnion, HardUnion
+
+
+def norm(inputs, *args, epsilon=1e-6, **kwargs):
+    """sdfs.py:5-6: sqrt(sum(x^2) + eps), the smoothed norm the box SDF uses (the kernels inline it: field.h kNormEpsilon)."""
+    return torch.sqrt(torch.sum(inputs ** 2.0, *args, **kwargs) + epsilon)
 
 
 def box(dimension):
