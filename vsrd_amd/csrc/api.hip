@@ -307,7 +307,7 @@ int32_t vsrd_render_forward(const vsrd_field* field, const vsrd_render_config* c
     if (!origins || !directions || !distances || !labels) return VSRD_E_INVALID_ARGUMENT;
     const bool residual = field->mlp_weights != nullptr;
     Geometry g;
-    if (!plan(config->num_rays, static_cast<size_t>(num_distances) + field->num_instances * kWave, &g)) return VSRD_E_UNSUPPORTED;
+    if (!plan(config->num_rays, static_cast<size_t>(forward_lds_floats(num_distances, field->num_instances)), &g)) return VSRD_E_UNSUPPORTED;
     const FieldArgs f = field_args(field);
     RenderArgs c = render_args(config);
     c.sh.inv_t = f.inv_t;

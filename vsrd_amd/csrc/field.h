@@ -108,7 +108,7 @@ __device__ __forceinline__ BoxEval eval_instance(const Instance& in, const float
 
 // ---- conservative instance culling -------------------------------------------------------------------
 // For a sample x, instance i's soft-min weight relative to the best instance is at most
-//   exp(-(LB_i - UB) / T),  LB_i = |x - t_i| (1 - k) - |dim_i|  <=  d_i(x),   UB = min_j |x - t_j| (1 + k) + 1e-3  >=  min_j d_j(x)
+//   exp(-(LB_i - UB) / T),  LB_i = |x - t_i| (1 - k) - |dim_i|  <=  d_i(x),   UB = min_j |x - t_j| (1 + k) + 2e-3  >=  min_j d_j(x)
 // (a box lies inside its circumscribed sphere and contains its centre; k = 2e-4 absorbs rotation matrices that are
 // orthonormal only to ~1e-4).  When LB_i - UB > tau T on EVERY lane of the wave the instance is skipped for that round:
 // with tau = 18 its weight is below exp(-18) = 1.5e-8 < 2^-24, i.e. below half an ulp of the soft-min normaliser.
@@ -122,11 +122,71 @@ __device__ __forceinline__ unsigned rows_with(unsigned long long ballot) {
            ((ballot & 0xFFFF000000000000ull) ? 8u : 0u);
 }
 
-__device__ __forceinline__ float centre_distance(const Instance& in, float x, float y, float z) {
-    const float rx = x - in.tx, ry = y - in.ty, rz = z - in.tz;
-    return fast_sqrt(rx * rx + ry * ry + rz * rz);
+// The bound test itself works on SQUARED centre distances along the ray: x(t) = o + r t gives
+//   |x(t) - t_i|^2 = a_i + b_i t + (r.r) t^2,   a_i = |o - t_i|^2,  b_i = 2 (o - t_i).r
+// so a sample costs two FMAs per instance (a_i, b_i: per-ray values, wave-uniform LDS reads) instead of three subtractions,
+// three multiply-adds and a square root, and the test  LB_i - UB > tau T  is compared in squares:
+//   cull  <=>  d2_i - E > ((UB + tau T + |dim_i|) / (1 - k))^2,   UB = sqrt(min_j d2_j + E) (1 + k) + 2e-3
+// E bounds the rounding error of the quadratic form AND of the sample position itself (x is computed as o + r t in fp32):
+// both are below 6 * 2^-24 * (max(|o - t_i|, |o|) + |r| |t|)^2 = 3.6e-7 (...)^2; E = 2e-6 (...)^2.
+constexpr float kCullQuadSlack = 2.0e-6f;
+constexpr int kCullCoefs = 4;                      // a_i, b_i, |dim_i| / (1 - k), pad  (per instance, in the wave's LDS)
+
+__host__ __device__ constexpr int cull_coef_floats(int num_instances) { return kCullCoefs * num_instances; }
+
+struct RayCull {
+    const float* coef;   // LDS [N][kCullCoefs]
+    float c2;            // r.r
+    float rnorm;         // |r|
+    float reach;         // max(max_i |o - t_i|, |o|): scale of the error bound E
+};
+
+struct RoundCull {       // one round (64 samples) of one ray
+    float err;           // E of this lane's sample
+    float limit;         // (UB + margin) / (1 - k) of this lane's sample
+};
+
+// Per ray: lane i prepares instance i's coefficients (N <= 64 = VSRD_MAX_INSTANCES).
+__device__ __forceinline__ RayCull cull_ray_setup(const float* __restrict__ instances, int num_instances, float ox, float oy, float oz,
+                                                  float rx, float ry, float rz, float* coef, int lane) {
+    float a = 0.0f;
+    if (lane < num_instances) {
+        const float* p = instances + lane * kInstanceStride;
+        const float ex = ox - p[0], ey = oy - p[1], ez = oz - p[2];
+        a = ex * ex + ey * ey + ez * ez;
+        coef[kCullCoefs * lane + 0] = a;
+        coef[kCullCoefs * lane + 1] = 2.0f * (ex * rx + ey * ry + ez * rz);
+        coef[kCullCoefs * lane + 2] = fast_sqrt(p[12] * p[12] + p[13] * p[13] + p[14] * p[14]) * (1.0f / (1.0f - kCullSlack));
+    }
+    RayCull rc;
+    rc.coef = coef;
+    rc.c2 = rx * rx + ry * ry + rz * rz;
+    rc.rnorm = fast_sqrt(rc.c2);
+    rc.reach = fast_sqrt(fmaxf(wave_max(a), ox * ox + oy * oy + oz * oz));
+    wave_lds_sync();
+    return rc;
 }
-__device__ __forceinline__ float bounding_radius(const Instance& in) { return fast_sqrt(in.dx * in.dx + in.dy * in.dy + in.dz * in.dz); }
+
+// Squared centre distance of instance i at ray parameter t (ct = c2 * t).
+__device__ __forceinline__ float centre_distance2(const RayCull& rc, int i, float t, float ct) {
+    return fmaf(t, ct + rc.coef[kCullCoefs * i + 1], rc.coef[kCullCoefs * i + 0]);
+}
+
+// After the minimum of the squared centre distances over the instances is known.
+__device__ __forceinline__ RoundCull cull_round(const RayCull& rc, float t, float nearest2, float margin) {
+    RoundCull c;
+    const float s = rc.reach + rc.rnorm * fabsf(t);
+    c.err = kCullQuadSlack * s * s;
+    const float nearest = fast_sqrt(fmaxf(nearest2, 0.0f) + c.err);
+    c.limit = (nearest * (1.0f + kCullSlack) + margin) * (1.0f / (1.0f - kCullSlack));
+    return c;
+}
+
+// Lanes on which instance i may matter (NaN-safe: an undecidable comparison keeps the instance).
+__device__ __forceinline__ unsigned long long cull_near(const RayCull& rc, const RoundCull& c, int i, float d2) {
+    const float reach = c.limit + rc.coef[kCullCoefs * i + 2];
+    return __ballot(!(d2 > fmaf(reach, reach, c.err)));
+}
 
 // tau * T + slack, or +huge (culling off) when some rotation matrix is not orthonormal to 1e-4.
 __device__ __forceinline__ float cull_margin(const float* __restrict__ instances, int num_instances, float inv_t) {

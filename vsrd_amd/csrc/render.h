@@ -67,41 +67,38 @@ __device__ __forceinline__ Opacity opacity_of(const UnionValue& v, const Ray& ra
     return o;
 }
 
-// Culling pre-pass (field.h): writes the per-instance lower bounds into dcache[i][lane] and returns this lane's
-// threshold; instance i is negligible for the whole round iff  dcache[i][lane] > threshold  on every lane.
-__device__ __forceinline__ float cull_prepass(const float* __restrict__ instances, int num_instances, float margin,
-                                              float x, float y, float z, float* dcache, int lane) {
-    float nearest = 3.0e38f;
-    for (int i = 0; i < num_instances; ++i) {
-        const Instance in = load_instance(instances, i);
-        const float dist = centre_distance(in, x, y, z);
-        dcache[i * kWave + lane] = dist * (1.0f - kCullSlack) - bounding_radius(in);
-        nearest = fminf(nearest, dist);
-    }
-    return nearest * (1.0f + kCullSlack) + margin;
-}
-
 __device__ __forceinline__ bool wave_any(bool pred) { return __ballot(pred) != 0ull; }
 
-// Evaluate the union at one point: a uniform loop over the instances with scalar parameter loads.
+// Evaluate the union at the sample of ray parameter t (position x, y, z): culling pre-pass (field.h) over the squared centre
+// distances, then a uniform loop over the instances that survive it, with scalar parameter loads.
 // `lam` (LDS, or nullptr) are the per-instance label adjoints accumulated into sums.L by the backward.
-// On return dcache[i][lane] holds d_i for evaluated instances (a value > threshold on all lanes marks a culled one).
+// On return bit i of *near_out says whether instance i was evaluated this round (wave-uniform) and, with kCacheDistances,
+// dcache[i][lane] holds d_i for those instances.
 template <bool kCacheDistances, bool kResidual>
 __device__ __forceinline__ UnionValue eval_union(const float* __restrict__ instances, const float* __restrict__ mlp, int num_instances,
-                                                 const Shading& sh, float x, float y, float z, float* dcache, int lane, const float* lam,
-                                                 float* threshold_out, float* lam_z_out) {
-    const float threshold = cull_prepass(instances, num_instances, sh.cull, x, y, z, dcache, lane);
-    UnionSums sums = union_init();
+                                                 const Shading& sh, const RayCull& rc, float t, float x, float y, float z, float* dcache, int lane,
+                                                 const float* lam, unsigned long long* near_out, float* lam_z_out) {
+    const float ct = rc.c2 * t;
+    float nearest2 = 3.0e38f;
     for (int i = 0; i < num_instances; ++i) {
-        const unsigned long long near = __ballot(dcache[i * kWave + lane] <= threshold);
+        const float d2 = centre_distance2(rc, i, t, ct);
+        dcache[i * kWave + lane] = d2;                                           // own lane's slot: no hazard
+        nearest2 = fminf(nearest2, d2);
+    }
+    const RoundCull cull = cull_round(rc, t, nearest2, sh.cull);
+    UnionSums sums = union_init();
+    unsigned long long evaluated = 0ull;
+    for (int i = 0; i < num_instances; ++i) {
+        const unsigned long long near = cull_near(rc, cull, i, dcache[i * kWave + lane]);
         if (near == 0ull) continue;                                             // wave-uniform skip
+        evaluated |= 1ull << i;
         const Instance in = load_instance(instances, i);
         const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z, rows_with(near) | sh.mlp_bits);
         if (kCacheDistances) dcache[i * kWave + lane] = e.d;
         union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, sh.inv_t);
     }
     const UnionValue v = union_finish(sums, sh.inv_t);
-    if (threshold_out) *threshold_out = threshold;
+    if (near_out) *near_out = evaluated;
     if (lam_z_out) *lam_z_out = sums.L * v.inv_z;
     return v;
 }
@@ -112,7 +109,7 @@ __device__ __forceinline__ UnionValue eval_union(const float* __restrict__ insta
 //   grad_out / weight_out: this ray's [D-1,3] / [D-1] rows in HBM, or nullptr.
 template <int kRounds, bool kLabels, bool kResidual>
 __device__ __forceinline__ float render_pass(const float* __restrict__ instances, const float* __restrict__ mlp, int num_instances, const Shading& sh,
-                                             const Ray& ray, const float* dist, int num_distances, float* dcache,
+                                             const Ray& ray, const RayCull& rc, const float* dist, int num_distances, float* dcache,
                                              float (&weights)[kRounds], float* grad_out, float* weight_out) {
     const int lane = lane_id();
     const int num_points = num_distances - 1;
@@ -129,8 +126,8 @@ __device__ __forceinline__ float render_pass(const float* __restrict__ instances
         const float delta = d1 - d0;
         const float mid = (d0 + d1) / 2.0f;
         const float x = ray.ox + ray.rx * mid, y = ray.oy + ray.ry * mid, z = ray.oz + ray.rz * mid;
-        float threshold;
-        const UnionValue v = eval_union<kLabels, kResidual>(instances, mlp, num_instances, sh, x, y, z, dcache, lane, nullptr, &threshold, nullptr);
+        unsigned long long evaluated;
+        const UnionValue v = eval_union<kLabels, kResidual>(instances, mlp, num_instances, sh, rc, mid, x, y, z, dcache, lane, nullptr, &evaluated, nullptr);
         const Opacity op = opacity_of(v, ray, delta, sh);
         const float alpha = valid ? op.alpha : 0.0f;
         const float inclusive = wave_inclusive_product(1.0f - alpha);
@@ -145,9 +142,8 @@ __device__ __forceinline__ float render_pass(const float* __restrict__ instances
         if (kLabels) {
             const float scale = w * v.inv_z;
             for (int i = 0; i < num_instances; ++i) {
-                const float di = dcache[i * kWave + lane];
-                if (!wave_any(di <= threshold)) continue;                       // culled: weight < exp(-18)
-                const float e = fast_exp(-(di - v.m) * sh.inv_t) * scale;
+                if (!((evaluated >> i) & 1ull)) continue;                       // culled: weight < exp(-18)
+                const float e = fast_exp(-(dcache[i * kWave + lane] - v.m) * sh.inv_t) * scale;
                 const float total = wave_sum(e);
                 label_acc = (lane == i) ? (label_acc + total) : label_acc;
             }
@@ -182,16 +178,18 @@ struct WaveLds {
     float* fine;      // [S]   importance samples
     float* merged;    // [2S]  sorted union
     float* dcache;    // [N,64] per-instance distances of the current round
+    float* cull;      // [N,4]  per-ray culling coefficients (field.h: RayCull)
 };
 
-__host__ __device__ inline int wave_lds_floats(int num_samples, int num_instances) {
-    return 7 * num_samples + num_instances * kWave;
+__host__ __device__ constexpr int wave_lds_floats(int num_samples, int num_instances) {
+    return 7 * num_samples + num_instances * kWave + cull_coef_floats(num_instances);
 }
 
-__device__ __forceinline__ WaveLds carve_lds(float* base, int num_samples) {
+__device__ __forceinline__ WaveLds carve_lds(float* base, int num_samples, int num_instances = 0) {
     WaveLds l;
     l.coarse = base; l.cdf = base + num_samples; l.uraw = base + 2 * num_samples; l.usorted = base + 3 * num_samples;
     l.fine = base + 4 * num_samples; l.merged = base + 5 * num_samples; l.dcache = base + 7 * num_samples;
+    l.cull = l.dcache + num_instances * kWave;
     return l;
 }
 

@@ -15,7 +15,13 @@ constexpr int kMlpBatch = 8;                   // rays whose MLP adjoints are ru
 
 // Floats of LDS one wave of render_backward_kernel owns (a multiple of 4: the partitions stay 16-byte aligned).
 __host__ __device__ constexpr int backward_lds_floats(int num_distances, int num_instances, bool residual) {
-    return ((residual ? kMlpLdsFloats + kMlpBatch * 4 * num_instances : 0) + num_distances + num_instances + num_instances * kGradStride + 3) & ~3;
+    return ((residual ? kMlpLdsFloats + kMlpBatch * 4 * num_instances : 0) + num_distances + num_instances + num_instances * kGradStride +
+            cull_coef_floats(num_instances) + 3) & ~3;
+}
+
+// Floats of LDS one wave of render_forward_kernel owns: sorted distances, [N][64] distance cache, culling coefficients.
+__host__ __device__ constexpr int forward_lds_floats(int num_distances, int num_instances) {
+    return num_distances + num_instances * kWave + cull_coef_floats(num_instances);
 }
 
 // The instance block [N,16] travels as its own `const float* __restrict__` kernel argument (not inside this
@@ -73,9 +79,10 @@ __global__ __launch_bounds__(kBlockThreads) void render_forward_kernel(
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = wave_in_block();
     const int lane = lane_id();
-    const int per_wave = num_distances + f.num_instances * kWave;
+    const int per_wave = forward_lds_floats(num_distances, f.num_instances);
     float* dist = lds + wave * per_wave;
     float* dcache = dist + num_distances;
+    float* coef = dcache + f.num_instances * kWave;
     Shading sh = c.sh;
     sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, f.num_instances, f.inv_t) + (kResidual ? 1.0f : 0.0f);
     sh.mlp_bits = (c.flags & 8u) ? kMlpCentredBit : 0u;
@@ -84,11 +91,11 @@ __global__ __launch_bounds__(kBlockThreads) void render_forward_kernel(
         const Ray r = load_ray(origins, directions, c.origin_stride, ray);
         const float* src = distances + static_cast<size_t>(ray) * num_distances;
         for (int idx = lane; idx < num_distances; idx += kWave) dist[idx] = src[idx];
-        wave_lds_sync();
+        const RayCull rc = cull_ray_setup(instances, f.num_instances, r.ox, r.oy, r.oz, r.rx, r.ry, r.rz, coef, lane);   // (syncs the wave's LDS)
         float w[kRounds];
         float* g_out = gradients ? gradients + static_cast<size_t>(ray) * (num_distances - 1) * 3 : nullptr;
         float* w_out = weights ? weights + static_cast<size_t>(ray) * (num_distances - 1) : nullptr;
-        const float label = render_pass<kRounds, true, kResidual>(instances, mlp, f.num_instances, sh, r, dist, num_distances, dcache, w, g_out, w_out);
+        const float label = render_pass<kRounds, true, kResidual>(instances, mlp, f.num_instances, sh, r, rc, dist, num_distances, dcache, w, g_out, w_out);
         if (lane < f.num_instances) labels[static_cast<size_t>(ray) * f.num_instances + lane] = label;
         wave_lds_sync();
     }
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
     const int wave = wave_in_block();
     const int lane = lane_id();
     const int S = c.num_samples;
-    const WaveLds l = carve_lds(lds + wave * wave_lds_floats(S, f.num_instances), S);
+    const WaveLds l = carve_lds(lds + wave * wave_lds_floats(S, f.num_instances), S, f.num_instances);
     const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
     Shading sh = c.sh;
     sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, f.num_instances, f.inv_t) + (kResidual ? 1.0f : 0.0f);
@@ -182,10 +189,11 @@ __global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
     const int stride = static_cast<int>(gridDim.x) * waves_per_block();
     for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
         const Ray r = load_ray(origins, directions, c.origin_stride, ray);
+        const RayCull rc = cull_ray_setup(instances, f.num_instances, r.ox, r.oy, r.oz, r.rx, r.ry, r.rz, l.cull, lane);
         stage_ray_samples<kRoundsS>(l, c, S, ray, u_coarse, u_fine, u_coarse_out, u_fine_out, sorted_input, lane);
         // ---- pass 1: coarse weights only (no labels, no outputs) ----------------------------------
         float w1[kRoundsS];
-        render_pass<kRoundsS, false, kResidual>(instances, mlp, f.num_instances, sh, r, l.coarse, S, l.dcache, w1, nullptr, nullptr);
+        render_pass<kRoundsS, false, kResidual>(instances, mlp, f.num_instances, sh, r, rc, l.coarse, S, l.dcache, w1, nullptr, nullptr);
         if (c.flags & 2u) {
             float total = 0.0f;
 #pragma unroll
@@ -205,7 +213,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
         const int D = 2 * S;
         float* g_out = gradients ? gradients + static_cast<size_t>(ray) * (D - 1) * 3 : nullptr;
         float* w_out = weights ? weights + static_cast<size_t>(ray) * (D - 1) : nullptr;
-        const float label = render_pass<kRounds, true, kResidual>(instances, mlp, f.num_instances, sh, r, l.merged, D, l.dcache, w2, g_out, w_out);
+        const float label = render_pass<kRounds, true, kResidual>(instances, mlp, f.num_instances, sh, r, rc, l.merged, D, l.dcache, w2, g_out, w_out);
         if (lane < f.num_instances) labels[static_cast<size_t>(ray) * f.num_instances + lane] = label;
         if (distances != nullptr) {
             float* dst = distances + static_cast<size_t>(ray) * D;
@@ -234,7 +242,7 @@ template <int kRounds>
 struct RayAdjoint {
     SampleAdjoint sa[kRounds];
     Opacity op[kRounds];
-    float gx[kRounds], gy[kRounds], gz[kRounds], trans[kRounds], delta[kRounds], thr[kRounds];
+    float gx[kRounds], gy[kRounds], gz[kRounds], trans[kRounds], delta[kRounds];
     // culling decisions of the forward sweep (wave-uniform, bit i = instance i): evaluated in the round at all / in 16-lane row q
     // (residual fields).  The later phases read these instead of repeating the bound test per instance and round.
     unsigned long long near_any[kRounds];
@@ -246,7 +254,7 @@ struct RayAdjoint {
 // ray's labels right away; the return value then holds label n in lane n.
 template <int kRounds, bool kResidual, bool kCacheD>
 __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, const float* __restrict__ instances, const float* __restrict__ mlp,
-                                                       int N, const Shading& sh, const Ray& r, const float* dist, int num_points,
+                                                       int N, const Shading& sh, const Ray& r, const RayCull& rc, const float* dist, int num_points,
                                                        const float* lam, float* dcache, int lane, float4* rcache = nullptr) {
     const float inv_t = sh.inv_t;
     float label = 0.0f;
@@ -260,26 +268,22 @@ __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, 
         st.delta[k] = d1 - d0;
         const float mid = (d0 + d1) / 2.0f;
         st.sa[k].x = r.ox + r.rx * mid; st.sa[k].y = r.oy + r.ry * mid; st.sa[k].z = r.oz + r.rz * mid;
-        // culling (field.h): nearest centre first, then one ballot per instance
-        float nearest = 3.0e38f;
+        // culling (field.h): nearest squared centre distance first, then one ballot per instance
+        const float ct = rc.c2 * mid;
+        float nearest2 = 3.0e38f;
         for (int i = 0; i < N; ++i) {
-            const float centre = centre_distance(load_instance(instances, i), st.sa[k].x, st.sa[k].y, st.sa[k].z);
-            if (kCacheD) dcache[i * kWave + lane] = centre;          // kept for the bound test below (own lane's slot: no hazard)
-            nearest = fminf(nearest, centre);
+            const float d2 = centre_distance2(rc, i, mid, ct);
+            if (kCacheD) dcache[i * kWave + lane] = d2;              // kept for the bound test below (own lane's slot: no hazard)
+            nearest2 = fminf(nearest2, d2);
         }
-        st.thr[k] = nearest * (1.0f + kCullSlack) + sh.cull;
+        const RoundCull cull = cull_round(rc, mid, nearest2, sh.cull);
         UnionSums sums = union_init();
         st.near_any[k] = 0ull;
         if (kResidual) st.near_rows[k][0] = st.near_rows[k][1] = st.near_rows[k][2] = st.near_rows[k][3] = 0ull;
         for (int i = 0; i < N; ++i) {
+            const unsigned long long near = cull_near(rc, cull, i, kCacheD ? dcache[i * kWave + lane] : centre_distance2(rc, i, mid, ct));
+            if (near == 0ull) continue;
             const Instance in = load_instance(instances, i);
-            const float centre = kCacheD ? dcache[i * kWave + lane] : centre_distance(in, st.sa[k].x, st.sa[k].y, st.sa[k].z);
-            const float lb = centre * (1.0f - kCullSlack) - bounding_radius(in);
-            const unsigned long long near = __ballot(lb <= st.thr[k]);
-            if (near == 0ull) {
-                if (kCacheD) dcache[i * kWave + lane] = lb;      // > thr on every lane: marks the instance as culled
-                continue;
-            }
             st.near_any[k] |= 1ull << i;
             if (kResidual) {
 #pragma unroll
@@ -307,9 +311,8 @@ __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, 
         if (kCacheD && k * kWave < num_points) {
             const float scale = st.sa[k].wgt * v.inv_z;
             for (int i = 0; i < N; ++i) {
-                const float di = dcache[i * kWave + lane];
-                if (!wave_any(di <= st.thr[k])) continue;
-                const float total = wave_sum(fast_exp(-(di - v.m) * inv_t) * scale);
+                if (!((st.near_any[k] >> i) & 1ull)) continue;
+                const float total = wave_sum(fast_exp(-(dcache[i * kWave + lane] - v.m) * inv_t) * scale);
                 label = (lane == i) ? (label + total) : label;
             }
         }
@@ -517,7 +520,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
     float* dist = wbar + (kResidual ? kMlpLdsFloats : 0);                // instance + the transposition scratch (residual.h), 16 B aligned
     float* lam = dist + num_distances;
     float* G = lam + N;
-    unsigned* masks = reinterpret_cast<unsigned*>(G + N * kGradStride);  // residual only: [kMlpBatch][kRounds][N] tile masks of the MLP adjoint
+    float* coef = G + N * kGradStride;                                   // per-ray culling coefficients (field.h: RayCull)
+    unsigned* masks = reinterpret_cast<unsigned*>(coef + cull_coef_floats(N));   // residual only: [kMlpBatch][kRounds][N] tile masks of the MLP adjoint
     for (int idx = lane; idx < N * kGradStride; idx += kWave) G[idx] = 0.0f;
     const size_t wave_global0 = static_cast<size_t>(blockIdx.x) * waves_per_block() + wave;
     float* my_mlp = kResidual ? mlp_partials + wave_global0 * (static_cast<size_t>(N) * kMlpWeights) : nullptr;
@@ -550,10 +554,10 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
             const float* src = distances + static_cast<size_t>(ray) * num_distances;
             for (int idx = lane; idx < num_distances; idx += kWave) dist[idx] = src[idx];
             if (lane < N) lam[lane] = lam_lane;
-            wave_lds_sync();
+            const RayCull rc = cull_ray_setup(instances, N, r.ox, r.oy, r.oz, r.rx, r.ry, r.rz, coef, lane);       // (syncs the wave's LDS)
             if (dist[0] != dist[0]) continue;                            // NaN sentinel: ray skipped by the forward
             RayAdjoint<kRounds> st;
-            adjoint_forward_sweep<kRounds, kResidual, false>(st, instances, mlp, N, sh, r, dist, num_points, lam, nullptr, lane, rcache);
+            adjoint_forward_sweep<kRounds, kResidual, false>(st, instances, mlp, N, sh, r, rc, dist, num_points, lam, nullptr, lane, rcache);
             const float* gw_row = grad_weights ? grad_weights + static_cast<size_t>(ray) * num_points : nullptr;
             const float* gg_row = grad_gradients ? grad_gradients + static_cast<size_t>(ray) * num_points * 3 : nullptr;
             if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, gw_row, gg_row, lane)) continue;      // exact zero adjoint
@@ -593,7 +597,7 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
     const int N = f.num_instances;
     const int per_wave = wave_lds_floats(S, N) + N + N * kGradStride;
     float* base = lds + wave * per_wave;
-    WaveLds l = carve_lds(base, S);                                        // l.dcache: [N][64], one round at a time
+    WaveLds l = carve_lds(base, S, N);                                     // l.dcache: [N][64], one round at a time
     float* lam = base + wave_lds_floats(S, N);
     float* G = lam + N;
     for (int idx = lane; idx < N * kGradStride; idx += kWave) G[idx] = 0.0f;
@@ -609,10 +613,11 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
         wave_lds_sync();
         const Ray r = load_ray(origins, directions, c.origin_stride, ray);
         const float target = (lane < N) ? targets[static_cast<size_t>(ray) * N + lane] : 0.0f;
+        const RayCull rc = cull_ray_setup(instances, N, r.ox, r.oy, r.oz, r.rx, r.ry, r.rz, l.cull, lane);
         stage_ray_samples<kRoundsS>(l, c, S, ray, u_coarse, u_fine, nullptr, nullptr, sorted_input, lane);
         // ---- pass 1 ------------------------------------------------------------------------------------
         float w1[kRoundsS];
-        render_pass<kRoundsS, false, false>(instances, nullptr, N, sh, r, l.coarse, S, l.dcache, w1, nullptr, nullptr);
+        render_pass<kRoundsS, false, false>(instances, nullptr, N, sh, r, rc, l.coarse, S, l.dcache, w1, nullptr, nullptr);
         float coarse_total = 0.0f;
 #pragma unroll
         for (int k = 0; k < kRoundsS; ++k) coarse_total += wave_sum(w1[k]);
@@ -623,7 +628,7 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
             rendered = true;
             importance_merge<kRoundsS>(l, S, w1);
             // ---- pass 2 with the adjoint's state kept in registers ------------------------------------
-            label = adjoint_forward_sweep<kRounds, false, true>(st, instances, nullptr, N, sh, r, l.merged, num_points, nullptr, l.dcache, lane);
+            label = adjoint_forward_sweep<kRounds, false, true>(st, instances, nullptr, N, sh, r, rc, l.merged, num_points, nullptr, l.dcache, lane);
         }
         if (labels_out != nullptr && lane < N) labels_out[static_cast<size_t>(ray) * N + lane] = label;
         // ---- silhouette BCE and its gradient (main.py:653-671; torch clamp / binary_cross_entropy backward) -----------------
@@ -669,7 +674,7 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
 // afterwards, instance-major (adjoint_phase_mlp).  Loss = loss_partials[.][0] + eikonal_ratio * loss_partials[.][1] summed over waves.
 // ---------------------------------------------------------------------------------------------------
 __host__ __device__ constexpr int residual_step_lds_floats(int num_samples, int num_instances) {
-    return (kMlpLdsFloats + kMlpBatch * 4 * num_instances + 7 * num_samples + num_instances * kWave + num_instances + num_instances * kGradStride + 3) & ~3;
+    return (kMlpLdsFloats + kMlpBatch * 4 * num_instances + wave_lds_floats(num_samples, num_instances) + num_instances + num_instances * kGradStride + 3) & ~3;
 }
 
 template <int kRounds>
@@ -689,7 +694,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_residual_step_kernel(
     float* wbar = lds + wave * residual_step_lds_floats(S, N);            // [1617] + transposition scratch (residual.h), 16 B aligned
     unsigned* masks = reinterpret_cast<unsigned*>(wbar + kMlpLdsFloats);  // [kMlpBatch][kRounds][N]
     float* base = wbar + kMlpLdsFloats + kMlpBatch * 4 * N;
-    WaveLds l = carve_lds(base, S);                                        // l.dcache: [N][64], one round at a time
+    WaveLds l = carve_lds(base, S, N);                                     // l.dcache: [N][64], one round at a time
     float* lam = base + wave_lds_floats(S, N);
     float* G = lam + N;
     for (int idx = lane; idx < N * kGradStride; idx += kWave) G[idx] = 0.0f;
@@ -718,12 +723,13 @@ __global__ __launch_bounds__(kBlockThreads) void render_residual_step_kernel(
             if (ray >= c.num_rays) continue;
             const Ray r = load_ray(origins, directions, c.origin_stride, ray);
             const float target = (lane < N) ? targets[static_cast<size_t>(ray) * N + lane] : 0.0f;
+            const RayCull rc = cull_ray_setup(instances, N, r.ox, r.oy, r.oz, r.rx, r.ry, r.rz, l.cull, lane);
             stage_ray_samples<kRoundsS>(l, c, S, ray, u_coarse, u_fine, nullptr, nullptr, sorted_input, lane);
             float w1[kRoundsS];
-            render_pass<kRoundsS, false, true>(instances, mlp, N, sh, r, l.coarse, S, l.dcache, w1, nullptr, nullptr);
+            render_pass<kRoundsS, false, true>(instances, mlp, N, sh, r, rc, l.coarse, S, l.dcache, w1, nullptr, nullptr);
             importance_merge<kRoundsS>(l, S, w1);
             RayAdjoint<kRounds> st;
-            const float label = adjoint_forward_sweep<kRounds, true, true>(st, instances, mlp, N, sh, r, l.merged, num_points, nullptr, l.dcache, lane, rcache);
+            const float label = adjoint_forward_sweep<kRounds, true, true>(st, instances, mlp, N, sh, r, rc, l.merged, num_points, nullptr, l.dcache, lane, rcache);
             if (labels_out != nullptr && lane < N) labels_out[static_cast<size_t>(ray) * N + lane] = label;
             // silhouette BCE and its gradient (as render_silhouette_kernel)
             const float p = fminf(fmaxf(label, 1.0e-6f), 1.0f - 1.0e-6f);
