@@ -188,6 +188,53 @@ __device__ __forceinline__ unsigned long long cull_near(const RayCull& rc, const
     return __ballot(!(d2 > fmaf(reach, reach, c.err)));
 }
 
+// The culling pre-pass of one round: bit i of the result = instance i has to be evaluated (wave-uniform).
+// Two branch-free loops, so that the LDS reads of consecutive instances are in flight together: squared centre distances (kept in
+// d2cache[i][lane] when kCache, else recomputed) and their minimum; then one ballot per instance.
+template <bool kCache>
+__device__ __forceinline__ unsigned long long cull_round_mask(const RayCull& rc, int num_instances, float t, float margin, float* d2cache, int lane,
+                                                              RoundCull* round_out) {
+    const float ct = rc.c2 * t;
+    float nearest2 = 3.0e38f;
+    int i = 0;
+    for (; i + 4 <= num_instances; i += 4) {          // coefficient reads first, then the stores (they may alias for the compiler)
+        float d2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d2[j] = centre_distance2(rc, i + j, t, ct);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (kCache) d2cache[(i + j) * kWave + lane] = d2[j];
+            nearest2 = fminf(nearest2, d2[j]);
+        }
+    }
+    for (; i < num_instances; ++i) {
+        const float d2 = centre_distance2(rc, i, t, ct);
+        if (kCache) d2cache[i * kWave + lane] = d2;
+        nearest2 = fminf(nearest2, d2);
+    }
+    const RoundCull cull = cull_round(rc, t, nearest2, margin);
+    unsigned long long mask = 0ull;
+    for (i = 0; i + 4 <= num_instances; i += 4) {
+        float d2[4], radius[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            d2[j] = kCache ? d2cache[(i + j) * kWave + lane] : centre_distance2(rc, i + j, t, ct);
+            radius[j] = rc.coef[kCullCoefs * (i + j) + 2];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float reach = cull.limit + radius[j];
+            mask |= (__ballot(!(d2[j] > fmaf(reach, reach, cull.err))) != 0ull) ? (1ull << (i + j)) : 0ull;
+        }
+    }
+    for (; i < num_instances; ++i) {
+        const float d2 = kCache ? d2cache[i * kWave + lane] : centre_distance2(rc, i, t, ct);
+        mask |= (cull_near(rc, cull, i, d2) != 0ull) ? (1ull << i) : 0ull;
+    }
+    if (round_out) *round_out = cull;
+    return mask;
+}
+
 // tau * T + slack, or +huge (culling off) when some rotation matrix is not orthonormal to 1e-4.
 __device__ __forceinline__ float cull_margin(const float* __restrict__ instances, int num_instances, float inv_t) {
     float worst = 0.0f;

@@ -78,22 +78,14 @@ template <bool kCacheDistances, bool kResidual>
 __device__ __forceinline__ UnionValue eval_union(const float* __restrict__ instances, const float* __restrict__ mlp, int num_instances,
                                                  const Shading& sh, const RayCull& rc, float t, float x, float y, float z, float* dcache, int lane,
                                                  const float* lam, unsigned long long* near_out, float* lam_z_out) {
-    const float ct = rc.c2 * t;
-    float nearest2 = 3.0e38f;
-    for (int i = 0; i < num_instances; ++i) {
-        const float d2 = centre_distance2(rc, i, t, ct);
-        dcache[i * kWave + lane] = d2;                                           // own lane's slot: no hazard
-        nearest2 = fminf(nearest2, d2);
-    }
-    const RoundCull cull = cull_round(rc, t, nearest2, sh.cull);
+    RoundCull cull;
+    const unsigned long long evaluated = cull_round_mask<true>(rc, num_instances, t, sh.cull, dcache, lane, &cull);
     UnionSums sums = union_init();
-    unsigned long long evaluated = 0ull;
-    for (int i = 0; i < num_instances; ++i) {
-        const unsigned long long near = cull_near(rc, cull, i, dcache[i * kWave + lane]);
-        if (near == 0ull) continue;                                             // wave-uniform skip
-        evaluated |= 1ull << i;
+    for (unsigned long long todo = evaluated; todo != 0ull; todo &= todo - 1ull) {    // wave-uniform: the instances that survive
+        const int i = __builtin_ctzll(todo);
         const Instance in = load_instance(instances, i);
-        const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z, rows_with(near) | sh.mlp_bits);
+        const unsigned tiles = kResidual ? rows_with(cull_near(rc, cull, i, dcache[i * kWave + lane])) : 0xFu;
+        const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z, tiles | sh.mlp_bits);
         if (kCacheDistances) dcache[i * kWave + lane] = e.d;
         union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, sh.inv_t);
     }
@@ -141,8 +133,8 @@ __device__ __forceinline__ float render_pass(const float* __restrict__ instances
         if (weight_out != nullptr && valid) weight_out[s] = w;
         if (kLabels) {
             const float scale = w * v.inv_z;
-            for (int i = 0; i < num_instances; ++i) {
-                if (!((evaluated >> i) & 1ull)) continue;                       // culled: weight < exp(-18)
+            for (unsigned long long todo = evaluated; todo != 0ull; todo &= todo - 1ull) {     // (culled instances: weight < exp(-18))
+                const int i = __builtin_ctzll(todo);
                 const float e = fast_exp(-(dcache[i * kWave + lane] - v.m) * sh.inv_t) * scale;
                 const float total = wave_sum(e);
                 label_acc = (lane == i) ? (label_acc + total) : label_acc;

@@ -268,24 +268,17 @@ __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, 
         st.delta[k] = d1 - d0;
         const float mid = (d0 + d1) / 2.0f;
         st.sa[k].x = r.ox + r.rx * mid; st.sa[k].y = r.oy + r.ry * mid; st.sa[k].z = r.oz + r.rz * mid;
-        // culling (field.h): nearest squared centre distance first, then one ballot per instance
-        const float ct = rc.c2 * mid;
-        float nearest2 = 3.0e38f;
-        for (int i = 0; i < N; ++i) {
-            const float d2 = centre_distance2(rc, i, mid, ct);
-            if (kCacheD) dcache[i * kWave + lane] = d2;              // kept for the bound test below (own lane's slot: no hazard)
-            nearest2 = fminf(nearest2, d2);
-        }
-        const RoundCull cull = cull_round(rc, mid, nearest2, sh.cull);
+        // culling (field.h): which instances this round has to evaluate
+        RoundCull cull;
+        st.near_any[k] = cull_round_mask<kCacheD>(rc, N, mid, sh.cull, dcache, lane, &cull);
         UnionSums sums = union_init();
-        st.near_any[k] = 0ull;
         if (kResidual) st.near_rows[k][0] = st.near_rows[k][1] = st.near_rows[k][2] = st.near_rows[k][3] = 0ull;
-        for (int i = 0; i < N; ++i) {
-            const unsigned long long near = cull_near(rc, cull, i, kCacheD ? dcache[i * kWave + lane] : centre_distance2(rc, i, mid, ct));
-            if (near == 0ull) continue;
+        for (unsigned long long todo = st.near_any[k]; todo != 0ull; todo &= todo - 1ull) {
+            const int i = __builtin_ctzll(todo);
             const Instance in = load_instance(instances, i);
-            st.near_any[k] |= 1ull << i;
+            unsigned long long near = ~0ull;
             if (kResidual) {
+                near = cull_near(rc, cull, i, kCacheD ? dcache[i * kWave + lane] : centre_distance2(rc, i, mid, rc.c2 * mid));
 #pragma unroll
                 for (int q = 0; q < 4; ++q) st.near_rows[k][q] |= ((near >> (16 * q)) & 0xFFFFull) ? (1ull << i) : 0ull;
             }
@@ -310,8 +303,8 @@ __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, 
         st.sa[k].gbx = v.b0x; st.sa[k].gby = v.b0y; st.sa[k].gbz = v.b0z;
         if (kCacheD && k * kWave < num_points) {
             const float scale = st.sa[k].wgt * v.inv_z;
-            for (int i = 0; i < N; ++i) {
-                if (!((st.near_any[k] >> i) & 1ull)) continue;
+            for (unsigned long long todo = st.near_any[k]; todo != 0ull; todo &= todo - 1ull) {
+                const int i = __builtin_ctzll(todo);
                 const float total = wave_sum(fast_exp(-(dcache[i * kWave + lane] - v.m) * inv_t) * scale);
                 label = (lane == i) ? (label + total) : label;
             }
@@ -382,7 +375,11 @@ template <int kRounds, bool kResidual>
 __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, const float* __restrict__ instances, const float* __restrict__ mlp,
                                                 int N, float inv_t, int num_points, const float* lam, float* G, int lane,
                                                 const float4* rcache, float* seeds, unsigned* masks) {
-    for (int i = 0; i < N; ++i) {
+    unsigned long long todo = 0ull;                                           // instances evaluated in some round of this ray
+#pragma unroll
+    for (int k = 0; k < kRounds; ++k) todo |= (k * kWave < num_points) ? st.near_any[k] : 0ull;
+    for (; todo != 0ull; todo &= todo - 1ull) {
+        const int i = __builtin_ctzll(todo);
         bool active[kRounds];
         unsigned tiles[kRounds];
         bool any_active = false;
@@ -646,9 +643,9 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
         for (int k = 0; k < kRounds; ++k) {
             if (k * kWave >= num_points) continue;
             float acc = 0.0f;
-            for (int i = 0; i < N; ++i) {
+            for (unsigned long long todo = st.near_any[k]; todo != 0ull; todo &= todo - 1ull) {   // the instances the forward sweep evaluated
+                const int i = __builtin_ctzll(todo);
                 if (lam[i] == 0.0f) continue;                               // wave-uniform
-                if (!((st.near_any[k] >> i) & 1ull)) continue;                // culled by the forward sweep
                 const Instance in = load_instance(instances, i);
                 const BoxEval e = eval_box(in, st.sa[k].x, st.sa[k].y, st.sa[k].z);
                 acc += lam[i] * fast_exp(-(e.d - st.sa[k].m) * sh.inv_t);
@@ -747,9 +744,9 @@ __global__ __launch_bounds__(kBlockThreads) void render_residual_step_kernel(
                 eikonal_acc += (k * kWave + lane < num_points) ? (norm - 1.0f) * (norm - 1.0f) : 0.0f;
                 // Lambda_s = sum_n lambda_n w_{s,n}: box distance re-evaluated, residual value from the sweep's jet cache
                 float acc = 0.0f;
-                for (int i = 0; i < N; ++i) {
+                for (unsigned long long todo = st.near_any[k]; todo != 0ull; todo &= todo - 1ull) {   // evaluated by the forward sweep
+                    const int i = __builtin_ctzll(todo);
                     if (lam[i] == 0.0f) continue;                               // wave-uniform
-                    if (!((st.near_any[k] >> i) & 1ull)) continue;                // culled by the forward sweep
                     const Instance in = load_instance(instances, i);
                     const BoxEval e = eval_box(in, st.sa[k].x, st.sa[k].y, st.sa[k].z);
                     const float d = e.d + rcache[(k * N + i) * kWave + lane].x;
