@@ -85,6 +85,10 @@ typedef struct vsrd_render_config {
 #define VSRD_FLAG_NO_CULLING 4u           /* evaluate every instance at every sample (A/B switch for the
                                              conservative soft-min culling described in DESIGN.md)        */
 
+#define VSRD_FLAG_RUNNING_MINIMUM 16u      /* shift the soft-min by the running minimum of the instance distances instead of the
+                                             lower bound known before the instance loop (A/B switch; the kernels fall back to it by
+                                             themselves wherever the bound is unavailable or too loose)                              */
+
 int32_t vsrd_abi_version(void);
 const char* vsrd_error_string(int32_t code);
 

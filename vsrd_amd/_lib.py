@@ -22,6 +22,7 @@ FLAG_FINE_UNIFORMS_SORTED = 1
 FLAG_SKIP_EXACT_MISSES = 2
 FLAG_NO_CULLING = 4
 FLAG_MLP_WEIGHTS_CENTRED = 8
+FLAG_RUNNING_MINIMUM = 16
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 

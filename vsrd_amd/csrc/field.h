@@ -144,6 +144,7 @@ struct RayCull {
 struct RoundCull {       // one round (64 samples) of one ray
     float err;           // E of this lane's sample
     float limit;         // (UB + margin) / (1 - k) of this lane's sample
+    float nearest_lo;    // lower bound of the nearest centre distance of this lane's sample: sqrt(max(min_j d2_j - E, 0)) (1 - k)
 };
 
 // Per ray: lane i prepares instance i's coefficients (N <= 64 = VSRD_MAX_INSTANCES).
@@ -179,6 +180,7 @@ __device__ __forceinline__ RoundCull cull_round(const RayCull& rc, float t, floa
     c.err = kCullQuadSlack * s * s;
     const float nearest = fast_sqrt(fmaxf(nearest2, 0.0f) + c.err);
     c.limit = (nearest * (1.0f + kCullSlack) + margin) * (1.0f / (1.0f - kCullSlack));
+    c.nearest_lo = fast_sqrt(fmaxf(nearest2 - c.err, 0.0f)) * (1.0f - kCullSlack);
     return c;
 }
 
@@ -235,21 +237,34 @@ __device__ __forceinline__ unsigned long long cull_round_mask(const RayCull& rc,
     return mask;
 }
 
-// tau * T + slack, or +huge (culling off) when some rotation matrix is not orthonormal to 1e-4.
-__device__ __forceinline__ float cull_margin(const float* __restrict__ instances, int num_instances, float inv_t) {
-    float worst = 0.0f;
+// Per-launch bounds of the field (wave-uniform; every wave computes them once):
+//   margin  tau * T + slack of the culling test, or +huge (culling off) when some rotation matrix is not orthonormal to 1e-4;
+//   reach   max_i |dim_i| + slack: every d_i(x) >= (nearest centre distance) (1 - k) - reach, which gives the soft-min a shift it
+//           knows BEFORE the instance loop (union_accumulate); < 0 when that bound is unavailable (non-orthonormal rotations) or
+//           reach / T is so large that exp(-(d - floor)/T) could underflow for the best instance.
+struct FieldBounds { float margin, reach; };
+
+__device__ __forceinline__ FieldBounds field_bounds(const float* __restrict__ instances, int num_instances, float inv_t, bool residual, unsigned flags) {
+    float worst = 0.0f, rmax = 0.0f;
     for (int i = 0; i < num_instances; ++i) {
         const Instance in = load_instance(instances, i);
         const float g00 = in.r00 * in.r00 + in.r10 * in.r10 + in.r20 * in.r20, g11 = in.r01 * in.r01 + in.r11 * in.r11 + in.r21 * in.r21;
         const float g22 = in.r02 * in.r02 + in.r12 * in.r12 + in.r22 * in.r22, g01 = in.r00 * in.r01 + in.r10 * in.r11 + in.r20 * in.r21;
         const float g02 = in.r00 * in.r02 + in.r10 * in.r12 + in.r20 * in.r22, g12 = in.r01 * in.r02 + in.r11 * in.r12 + in.r21 * in.r22;
         worst = fmaxf(worst, fmaxf(fmaxf(fabsf(g00 - 1.0f), fabsf(g11 - 1.0f)), fmaxf(fabsf(g22 - 1.0f), fmaxf(fabsf(g01), fmaxf(fabsf(g02), fabsf(g12))))));
+        rmax = fmaxf(rmax, fast_sqrt(in.dx * in.dx + in.dy * in.dy + in.dz * in.dz));
     }
-    return (worst < 1.0e-4f) ? (kCullTau / inv_t + 2.0e-3f) : 3.0e38f;   // (+1 for residual fields: added by the kernels)
+    const bool orthonormal = worst < 1.0e-4f;                      // (a NaN parameter fails the test: no culling, running minimum)
+    FieldBounds b;
+    // residual fields: d_i = box + residual, residual in (0, 1): the upper bound of the best distance grows by 1
+    b.margin = (orthonormal && !(flags & 4u)) ? (kCullTau / inv_t + 2.0e-3f + (residual ? 1.0f : 0.0f)) : 3.0e38f;
+    const float reach = rmax + 2.0e-3f;
+    b.reach = (orthonormal && !(flags & 16u) && (reach + 1.0f) * inv_t <= 50.0f) ? reach : -1.0f;
+    return b;
 }
 
-// Online soft-min over the instances, with the running minimum as the shift so that neither the
-// exponentials nor the (d_i - u)/T factor of the union gradient lose digits at small temperature.
+// Online soft-min over the instances with a shift m (a lower bound of the d_i close to the smallest, or the running minimum) so
+// that neither the exponentials nor the (d_i - u)/T factor of the union gradient lose digits at small temperature.
 //   e_i = exp(-(d_i - m)/T), Z = sum e_i, S1 = sum e_i (d_i - m),
 //   G0 = sum e_i gw_i, G1 = sum e_i (d_i - m) gw_i, L = sum e_i lambda_i (backward only)
 struct UnionSums {
@@ -258,16 +273,32 @@ struct UnionSums {
     float L;
 };
 
-__device__ __forceinline__ UnionSums union_init() {
+// `floor` >= 0 ... any finite value: a lower bound of every d_i known before the loop (fixed shift, see union_accumulate);
+// running = true: the shift is the running minimum.
+__device__ __forceinline__ UnionSums union_init(bool running = true, float floor = 0.0f) {
     UnionSums s;
-    s.m = 3.0e38f;  // finite: the first instance rescales the (all-zero) sums by exp(-3e38/T) = 0, no inf*0
+    s.m = running ? 3.0e38f : floor;  // 3e38 is finite: the first instance rescales the (all-zero) sums by exp(-3e38/T) = 0, no inf*0
     s.Z = 0.0f; s.S1 = 0.0f;
     s.g0x = s.g0y = s.g0z = 0.0f; s.g1x = s.g1y = s.g1z = 0.0f; s.L = 0.0f;
     return s;
 }
 
-__device__ __forceinline__ void union_accumulate(UnionSums& s, float d, float gwx, float gwy, float gwz, float lambda, float inv_t) {
-    // One exponential per instance: either the old sums are rescaled (new minimum) or the new term is.
+// running (wave-uniform) = false: s.m is a lower bound of all d_i that lies within ~50 T of the smallest (field_bounds / RoundCull):
+// no exponential overflows, the best one is >= e^-50, and every sum is a plain multiply-add: 12 instructions.  The caller checks Z
+// afterwards and repeats the round with running = true if it underflowed (never seen; far-extrapolated samples are the candidates).
+// running = true: one exponential per instance as well, but either the old sums are rescaled (new minimum) or the new term is:
+// ~36 instructions, valid for any inputs.
+__device__ __forceinline__ void union_accumulate(UnionSums& s, float d, float gwx, float gwy, float gwz, float lambda, float inv_t, bool running = true) {
+    if (!running) {
+        const float dd = d - s.m;
+        const float e = fast_exp(-dd * inv_t);
+        const float edd = e * dd;
+        s.Z += e; s.S1 += edd;
+        s.g0x += e * gwx; s.g0y += e * gwy; s.g0z += e * gwz;
+        s.g1x += edd * gwx; s.g1y += edd * gwy; s.g1z += edd * gwz;
+        s.L += e * lambda;
+        return;
+    }
     const bool lower = d < s.m;
     const float gap = lower ? (s.m - d) : (d - s.m);           // >= 0
     const float ex = fast_exp(-gap * inv_t);
@@ -286,6 +317,9 @@ __device__ __forceinline__ void union_accumulate(UnionSums& s, float d, float gw
     s.Z = scale * s.Z + e;
     s.m = lower ? d : s.m;
 }
+
+// Smallest normaliser the fixed-shift sums are trusted with: terms down to e^-18 of it are still normal numbers.
+constexpr float kUnionTinyZ = 1.0e-28f;
 
 struct UnionValue {
     float u;            // union distance  sum_i w_i d_i

@@ -18,6 +18,7 @@ struct Ray { float ox, oy, oz, rx, ry, rz; };
 struct Shading {
     float inv_t;    // 1 / soft-union temperature
     float cull;     // culling margin (field.h), wave-uniform; +huge disables culling
+    float reach;    // soft-min floor: every d_i >= nearest centre distance - reach (field.h: field_bounds); < 0: running minimum
     float std;      // sdf_std_deviation
     float inv_std;  // 1 / sdf_std_deviation
     float ratio;    // cosine_ratio
@@ -80,14 +81,21 @@ __device__ __forceinline__ UnionValue eval_union(const float* __restrict__ insta
                                                  const float* lam, unsigned long long* near_out, float* lam_z_out) {
     RoundCull cull;
     const unsigned long long evaluated = cull_round_mask<true>(rc, num_instances, t, sh.cull, dcache, lane, &cull);
-    UnionSums sums = union_init();
-    for (unsigned long long todo = evaluated; todo != 0ull; todo &= todo - 1ull) {    // wave-uniform: the instances that survive
-        const int i = __builtin_ctzll(todo);
-        const Instance in = load_instance(instances, i);
-        const unsigned tiles = kResidual ? rows_with(cull_near(rc, cull, i, dcache[i * kWave + lane])) : 0xFu;
-        const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z, tiles | sh.mlp_bits);
-        if (kCacheDistances) dcache[i * kWave + lane] = e.d;
-        union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, sh.inv_t);
+    bool running = sh.reach < 0.0f;                                             // wave-uniform
+    UnionSums sums;
+    while (true) {
+        sums = union_init(running, cull.nearest_lo - sh.reach);
+        for (unsigned long long todo = evaluated; todo != 0ull; todo &= todo - 1ull) {    // wave-uniform: the instances that survive
+            const int i = __builtin_ctzll(todo);
+            const Instance in = load_instance(instances, i);
+            // (a repeated round has lost the squared centre distances to the cache: every 16-lane row evaluates the residual)
+            const unsigned tiles = (kResidual && running == (sh.reach < 0.0f)) ? rows_with(cull_near(rc, cull, i, dcache[i * kWave + lane])) : 0xFu;
+            const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z, tiles | sh.mlp_bits);
+            if (kCacheDistances) dcache[i * kWave + lane] = e.d;
+            union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, sh.inv_t, running);
+        }
+        if (running || !wave_any(!(sums.Z >= kUnionTinyZ))) break;
+        running = true;                                                         // the fixed shift underflowed somewhere: repeat with the running minimum
     }
     const UnionValue v = union_finish(sums, sh.inv_t);
     if (near_out) *near_out = evaluated;

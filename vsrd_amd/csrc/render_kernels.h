@@ -84,7 +84,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_forward_kernel(
     float* dcache = dist + num_distances;
     float* coef = dcache + f.num_instances * kWave;
     Shading sh = c.sh;
-    sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, f.num_instances, f.inv_t) + (kResidual ? 1.0f : 0.0f);
+    const FieldBounds bounds = field_bounds(instances, f.num_instances, f.inv_t, kResidual, c.flags);
+    sh.cull = bounds.margin; sh.reach = bounds.reach;
     sh.mlp_bits = (c.flags & 8u) ? kMlpCentredBit : 0u;
     const int stride = static_cast<int>(gridDim.x) * waves_per_block();
     for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
@@ -184,7 +185,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
     const WaveLds l = carve_lds(lds + wave * wave_lds_floats(S, f.num_instances), S, f.num_instances);
     const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
     Shading sh = c.sh;
-    sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, f.num_instances, f.inv_t) + (kResidual ? 1.0f : 0.0f);
+    const FieldBounds bounds = field_bounds(instances, f.num_instances, f.inv_t, kResidual, c.flags);
+    sh.cull = bounds.margin; sh.reach = bounds.reach;
     sh.mlp_bits = (c.flags & 8u) ? kMlpCentredBit : 0u;
     const int stride = static_cast<int>(gridDim.x) * waves_per_block();
     for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
@@ -271,22 +273,30 @@ __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, 
         // culling (field.h): which instances this round has to evaluate
         RoundCull cull;
         st.near_any[k] = cull_round_mask<kCacheD>(rc, N, mid, sh.cull, dcache, lane, &cull);
-        UnionSums sums = union_init();
         if (kResidual) st.near_rows[k][0] = st.near_rows[k][1] = st.near_rows[k][2] = st.near_rows[k][3] = 0ull;
-        for (unsigned long long todo = st.near_any[k]; todo != 0ull; todo &= todo - 1ull) {
-            const int i = __builtin_ctzll(todo);
-            const Instance in = load_instance(instances, i);
-            unsigned long long near = ~0ull;
-            if (kResidual) {
-                near = cull_near(rc, cull, i, kCacheD ? dcache[i * kWave + lane] : centre_distance2(rc, i, mid, rc.c2 * mid));
+        bool running = sh.reach < 0.0f;                                      // wave-uniform
+        UnionSums sums;
+        while (true) {
+            sums = union_init(running, cull.nearest_lo - sh.reach);
+            for (unsigned long long todo = st.near_any[k]; todo != 0ull; todo &= todo - 1ull) {
+                const int i = __builtin_ctzll(todo);
+                const Instance in = load_instance(instances, i);
+                unsigned long long near = ~0ull;
+                if (kResidual && running == (sh.reach < 0.0f)) {                // (a repeated round evaluates every 16-lane row)
+                    near = cull_near(rc, cull, i, kCacheD ? dcache[i * kWave + lane] : centre_distance2(rc, i, mid, rc.c2 * mid));
+                }
+                if (kResidual) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) st.near_rows[k][q] |= ((near >> (16 * q)) & 0xFFFFull) ? (1ull << i) : 0ull;
+                    for (int q = 0; q < 4; ++q) st.near_rows[k][q] |= ((near >> (16 * q)) & 0xFFFFull) ? (1ull << i) : 0ull;
+                }
+                Residual res;
+                const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, st.sa[k].x, st.sa[k].y, st.sa[k].z, rows_with(near) | sh.mlp_bits, &res);
+                if (kResidual && rcache) rcache[(k * N + i) * kWave + lane] = make_float4(res.value, res.gx, res.gy, res.gz);
+                if (kCacheD) dcache[i * kWave + lane] = e.d;
+                union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, inv_t, running);
             }
-            Residual res;
-            const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, st.sa[k].x, st.sa[k].y, st.sa[k].z, rows_with(near) | sh.mlp_bits, &res);
-            if (kResidual && rcache) rcache[(k * N + i) * kWave + lane] = make_float4(res.value, res.gx, res.gy, res.gz);
-            if (kCacheD) dcache[i * kWave + lane] = e.d;
-            union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, inv_t);
+            if (running || !wave_any(!(sums.Z >= kUnionTinyZ))) break;
+            running = true;                                                      // the fixed shift underflowed somewhere: repeat with the running minimum
         }
         const UnionValue v = union_finish(sums, inv_t);
         st.op[k] = opacity_of(v, r, st.delta[k], sh);
@@ -530,7 +540,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
         for (int idx = lane; idx < kMlpWeights; idx += kWave) wbar[idx] = 0.0f;
     }
     Shading sh = c.sh;
-    sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, N, f.inv_t) + (kResidual ? 1.0f : 0.0f);
+    const FieldBounds bounds = field_bounds(instances, N, f.inv_t, kResidual, c.flags);
+    sh.cull = bounds.margin; sh.reach = bounds.reach;
     sh.mlp_bits = (c.flags & 8u) ? kMlpCentredBit : 0u;
     const int stride = static_cast<int>(gridDim.x) * waves_per_block();
     constexpr int kBatch = kResidual ? kMlpBatch : 1;
@@ -600,7 +611,8 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
     for (int idx = lane; idx < N * kGradStride; idx += kWave) G[idx] = 0.0f;
     const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
     Shading sh = c.sh;
-    sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, N, f.inv_t);
+    const FieldBounds bounds = field_bounds(instances, N, f.inv_t, false, c.flags);
+    sh.cull = bounds.margin; sh.reach = bounds.reach;
     sh.mlp_bits = 0u;
     const float weight_lane = (lane < N) ? (instance_weights ? instance_weights[lane] : 1.0f) : 0.0f;
     float loss_acc = 0.0f;                                                  // lane n: this wave's BCE sum of instance n
@@ -703,7 +715,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_residual_step_kernel(
     for (int idx = lane; idx < kMlpWeights; idx += kWave) wbar[idx] = 0.0f;
     const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
     Shading sh = c.sh;
-    sh.cull = (c.flags & 4u) ? 3.0e38f : cull_margin(instances, N, f.inv_t) + 1.0f;
+    const FieldBounds bounds = field_bounds(instances, N, f.inv_t, true, c.flags);
+    sh.cull = bounds.margin; sh.reach = bounds.reach;
     sh.mlp_bits = (c.flags & 8u) ? kMlpCentredBit : 0u;
     const float weight_lane = (lane < N) ? (instance_weights ? instance_weights[lane] : 1.0f) : 0.0f;
     float loss_acc = 0.0f, eikonal_acc = 0.0f;

@@ -50,10 +50,12 @@ def current_scope():
 # A/B switch for the conservative soft-min instance culling (DESIGN.md "Culling"): False sets VSRD_FLAG_NO_CULLING on
 # every launch so that each instance is evaluated at each sample, exactly like the reference's closure loop.
 CULLING = True
+# A/B switch for the soft-min shift (field.h: union_accumulate): True sets VSRD_FLAG_RUNNING_MINIMUM on every launch.
+RUNNING_MINIMUM = False
 
 
 def _base_flags():
-    return 0 if CULLING else _lib.FLAG_NO_CULLING
+    return (0 if CULLING else _lib.FLAG_NO_CULLING) | (_lib.FLAG_RUNNING_MINIMUM if RUNNING_MINIMUM else 0)
 
 
 def _mlp_flag(centred_weights):
