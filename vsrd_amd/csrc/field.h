@@ -288,8 +288,11 @@ __device__ __forceinline__ UnionSums union_init(bool running = true, float floor
 // afterwards and repeats the round with running = true if it underflowed (never seen; far-extrapolated samples are the candidates).
 // running = true: one exponential per instance as well, but either the old sums are rescaled (new minimum) or the new term is:
 // ~36 instructions, valid for any inputs.
-__device__ __forceinline__ void union_accumulate(UnionSums& s, float d, float gwx, float gwy, float gwz, float lambda, float inv_t, bool running = true) {
-    if (!running) {
+// (kRunning is a template parameter, and the callers instantiate their whole instance loop once per value: a run-time branch
+//  inside the loop costs eight register copies per instance where the two paths meet.)
+template <bool kRunning = true>
+__device__ __forceinline__ void union_accumulate(UnionSums& s, float d, float gwx, float gwy, float gwz, float lambda, float inv_t) {
+    if (!kRunning) {
         const float dd = d - s.m;
         const float e = fast_exp(-dd * inv_t);
         const float edd = e * dd;

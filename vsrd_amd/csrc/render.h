@@ -75,27 +75,38 @@ __device__ __forceinline__ bool wave_any(bool pred) { return __ballot(pred) != 0
 // `lam` (LDS, or nullptr) are the per-instance label adjoints accumulated into sums.L by the backward.
 // On return bit i of *near_out says whether instance i was evaluated this round (wave-uniform) and, with kCacheDistances,
 // dcache[i][lane] holds d_i for those instances.
+// The instance loop of eval_union: the instances of `evaluated`, accumulated with a fixed soft-min shift `floor` or (kRunning) the
+// running minimum.  kTiles: residual fields take the 16-lane rows that need the MLP from the squared centre distances in dcache.
+template <bool kCacheDistances, bool kResidual, bool kRunning, bool kTiles>
+__device__ __forceinline__ UnionSums union_loop(const float* __restrict__ instances, const float* __restrict__ mlp, unsigned long long evaluated,
+                                                const Shading& sh, const RayCull& rc, const RoundCull& cull, float floor, float x, float y, float z,
+                                                float* dcache, int lane, const float* lam) {
+    UnionSums sums = union_init(kRunning, floor);
+    for (unsigned long long todo = evaluated; todo != 0ull; todo &= todo - 1ull) {    // wave-uniform: the instances that survive
+        const int i = __builtin_ctzll(todo);
+        const Instance in = load_instance(instances, i);
+        const unsigned tiles = (kResidual && kTiles) ? rows_with(cull_near(rc, cull, i, dcache[i * kWave + lane])) : 0xFu;
+        const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z, tiles | sh.mlp_bits);
+        if (kCacheDistances) dcache[i * kWave + lane] = e.d;
+        union_accumulate<kRunning>(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, sh.inv_t);
+    }
+    return sums;
+}
+
 template <bool kCacheDistances, bool kResidual>
 __device__ __forceinline__ UnionValue eval_union(const float* __restrict__ instances, const float* __restrict__ mlp, int num_instances,
                                                  const Shading& sh, const RayCull& rc, float t, float x, float y, float z, float* dcache, int lane,
                                                  const float* lam, unsigned long long* near_out, float* lam_z_out) {
     RoundCull cull;
     const unsigned long long evaluated = cull_round_mask<true>(rc, num_instances, t, sh.cull, dcache, lane, &cull);
-    bool running = sh.reach < 0.0f;                                             // wave-uniform
     UnionSums sums;
-    while (true) {
-        sums = union_init(running, cull.nearest_lo - sh.reach);
-        for (unsigned long long todo = evaluated; todo != 0ull; todo &= todo - 1ull) {    // wave-uniform: the instances that survive
-            const int i = __builtin_ctzll(todo);
-            const Instance in = load_instance(instances, i);
-            // (a repeated round has lost the squared centre distances to the cache: every 16-lane row evaluates the residual)
-            const unsigned tiles = (kResidual && running == (sh.reach < 0.0f)) ? rows_with(cull_near(rc, cull, i, dcache[i * kWave + lane])) : 0xFu;
-            const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z, tiles | sh.mlp_bits);
-            if (kCacheDistances) dcache[i * kWave + lane] = e.d;
-            union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, sh.inv_t, running);
-        }
-        if (running || !wave_any(!(sums.Z >= kUnionTinyZ))) break;
-        running = true;                                                         // the fixed shift underflowed somewhere: repeat with the running minimum
+    bool running = sh.reach < 0.0f;                                             // wave-uniform
+    if (!running) {
+        sums = union_loop<kCacheDistances, kResidual, false, true>(instances, mlp, evaluated, sh, rc, cull, cull.nearest_lo - sh.reach, x, y, z, dcache, lane, lam);
+        running = wave_any(!(sums.Z >= kUnionTinyZ));                           // the fixed shift underflowed somewhere: repeat the round
+        if (running) sums = union_loop<kCacheDistances, kResidual, true, false>(instances, mlp, evaluated, sh, rc, cull, 0.0f, x, y, z, dcache, lane, lam);
+    } else {
+        sums = union_loop<kCacheDistances, kResidual, true, true>(instances, mlp, evaluated, sh, rc, cull, 0.0f, x, y, z, dcache, lane, lam);
     }
     const UnionValue v = union_finish(sums, sh.inv_t);
     if (near_out) *near_out = evaluated;

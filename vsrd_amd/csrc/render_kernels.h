@@ -251,6 +251,31 @@ struct RayAdjoint {
     unsigned long long near_rows[kRounds][4];
 };
 
+// The instance loop of the forward sweep for round k (render.h: union_loop, plus what the adjoint keeps: 16-lane row masks and the
+// residual jets).  kTiles = false (a repeated round, the cache no longer holds squared centre distances): every row evaluates the MLP.
+template <int kRounds, bool kResidual, bool kCacheD, bool kRunning, bool kTiles>
+__device__ __forceinline__ UnionSums sweep_union_loop(RayAdjoint<kRounds>& st, int k, const float* __restrict__ instances, const float* __restrict__ mlp, int N,
+                                                      const Shading& sh, const RayCull& rc, const RoundCull& cull, float floor, float mid, const float* lam,
+                                                      float* dcache, int lane, float4* rcache) {
+    UnionSums sums = union_init(kRunning, floor);
+    for (unsigned long long todo = st.near_any[k]; todo != 0ull; todo &= todo - 1ull) {
+        const int i = __builtin_ctzll(todo);
+        const Instance in = load_instance(instances, i);
+        unsigned long long near = ~0ull;
+        if (kResidual) {
+            if (kTiles) near = cull_near(rc, cull, i, kCacheD ? dcache[i * kWave + lane] : centre_distance2(rc, i, mid, rc.c2 * mid));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st.near_rows[k][q] |= ((near >> (16 * q)) & 0xFFFFull) ? (1ull << i) : 0ull;
+        }
+        Residual res;
+        const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, st.sa[k].x, st.sa[k].y, st.sa[k].z, rows_with(near) | sh.mlp_bits, &res);
+        if (kResidual && rcache) rcache[(k * N + i) * kWave + lane] = make_float4(res.value, res.gx, res.gy, res.gz);
+        if (kCacheD) dcache[i * kWave + lane] = e.d;
+        union_accumulate<kRunning>(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, sh.inv_t);
+    }
+    return sums;
+}
+
 // Phase A, forward sweep: union sums (with Lambda = sum_n lambda_n e_n when `lam` is given), opacity, transmittance.
 // kCacheD (fused loss kernel): the instance distances of the current round are cached in `dcache` [N][64] and turned into the
 // ray's labels right away; the return value then holds label n in lane n.
@@ -274,29 +299,14 @@ __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, 
         RoundCull cull;
         st.near_any[k] = cull_round_mask<kCacheD>(rc, N, mid, sh.cull, dcache, lane, &cull);
         if (kResidual) st.near_rows[k][0] = st.near_rows[k][1] = st.near_rows[k][2] = st.near_rows[k][3] = 0ull;
-        bool running = sh.reach < 0.0f;                                      // wave-uniform
         UnionSums sums;
-        while (true) {
-            sums = union_init(running, cull.nearest_lo - sh.reach);
-            for (unsigned long long todo = st.near_any[k]; todo != 0ull; todo &= todo - 1ull) {
-                const int i = __builtin_ctzll(todo);
-                const Instance in = load_instance(instances, i);
-                unsigned long long near = ~0ull;
-                if (kResidual && running == (sh.reach < 0.0f)) {                // (a repeated round evaluates every 16-lane row)
-                    near = cull_near(rc, cull, i, kCacheD ? dcache[i * kWave + lane] : centre_distance2(rc, i, mid, rc.c2 * mid));
-                }
-                if (kResidual) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) st.near_rows[k][q] |= ((near >> (16 * q)) & 0xFFFFull) ? (1ull << i) : 0ull;
-                }
-                Residual res;
-                const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, st.sa[k].x, st.sa[k].y, st.sa[k].z, rows_with(near) | sh.mlp_bits, &res);
-                if (kResidual && rcache) rcache[(k * N + i) * kWave + lane] = make_float4(res.value, res.gx, res.gy, res.gz);
-                if (kCacheD) dcache[i * kWave + lane] = e.d;
-                union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, inv_t, running);
-            }
-            if (running || !wave_any(!(sums.Z >= kUnionTinyZ))) break;
-            running = true;                                                      // the fixed shift underflowed somewhere: repeat with the running minimum
+        bool running = sh.reach < 0.0f;                                      // wave-uniform
+        if (!running) {
+            sums = sweep_union_loop<kRounds, kResidual, kCacheD, false, true>(st, k, instances, mlp, N, sh, rc, cull, cull.nearest_lo - sh.reach, mid, lam, dcache, lane, rcache);
+            running = wave_any(!(sums.Z >= kUnionTinyZ));                    // the fixed shift underflowed somewhere: repeat the round
+            if (running) sums = sweep_union_loop<kRounds, kResidual, kCacheD, true, false>(st, k, instances, mlp, N, sh, rc, cull, 0.0f, mid, lam, dcache, lane, rcache);
+        } else {
+            sums = sweep_union_loop<kRounds, kResidual, kCacheD, true, true>(st, k, instances, mlp, N, sh, rc, cull, 0.0f, mid, lam, dcache, lane, rcache);
         }
         const UnionValue v = union_finish(sums, inv_t);
         st.op[k] = opacity_of(v, r, st.delta[k], sh);
