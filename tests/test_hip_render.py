@@ -343,15 +343,18 @@ def test_skip_exact_misses_is_exact(dev):
 
 @pytest.mark.parametrize("name", ["g4_render_n16_s64_mid", "g4_render_n4_s32_late", "g4_render_n4_s32_step0"])
 def test_culling_is_invisible(dev, name):
-    """Conservative soft-min culling (weights < exp(-18) skipped wave-uniformly) against evaluating every instance."""
+    """The two things the kernels do differently from the reference's closure loop must not show: conservative soft-min culling
+    (instances whose weight is below exp(-18) on every lane are skipped wave-uniformly: sphere-bound test, then exact test on the
+    box distance) and the soft-min shift known before the instance loop.  Baseline: every instance evaluated at every sample,
+    running-minimum shift (VSRD_FLAG_NO_CULLING | VSRD_FLAG_RUNNING_MINIMUM)."""
     from vsrd_amd import rendering
     from vsrd_amd.rendering import renderers
     g = load_golden(name)
     S = int(g["num_samples"])
     std, ratio = float(g["sdf_std_deviation"]), float(g["cosine_ratio"])
     results = {}
-    for culling in (True, False):
-        renderers.CULLING = culling
+    for mode, (culling, running) in {"default": (True, False), "running": (True, True), "baseline": (False, True)}.items():
+        renderers.CULLING, renderers.RUNNING_MINIMUM = culling, running
         try:
             union, params = hip_union(g, dev, requires_grad=True)
             out = rendering.render_hierarchical(union, g["origins"].to(dev), g["directions"].to(dev), (0.0, 100.0), S, std, ratio,
@@ -360,12 +363,14 @@ def test_culling_is_invisible(dev, name):
             gam = (torch.randn(out["gradients"].shape, generator=torch.Generator().manual_seed(3)) * 0.01).to(dev)
             hit = (g["coarse_weights"].sum(0) > 0).to(dev)
             loss = (out["labels"] * lam).sum() + (out["gradients"][hit] * gam[hit]).sum()
-            results[culling] = (out["labels"].detach(), torch.autograd.grad(loss, params))
+            results[mode] = (out["labels"].detach(), torch.autograd.grad(loss, params))
         finally:
-            renderers.CULLING = True
-    assert (results[True][0] - results[False][0]).abs().max() < 1e-6
-    for a, b in zip(results[True][1], results[False][1]):
-        assert (a - b).abs().max() <= 1e-4 * max(float(b.abs().max()), 1e-6)
+            renderers.CULLING, renderers.RUNNING_MINIMUM = True, False
+    for mode in ("default", "running"):
+        assert (results[mode][0] - results["baseline"][0]).abs().max() < 1e-6, mode
+        for a, b in zip(results[mode][1], results["baseline"][1]):
+            assert (a - b).abs().max() <= 1e-4 * max(float(b.abs().max()), 1e-6), mode
+    assert not torch.equal(results["default"][1][0], results["running"][1][0])      # (the two shifts really are different code paths)
 
 
 def test_residual_tile_culling_is_invisible(dev):

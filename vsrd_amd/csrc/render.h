@@ -75,18 +75,23 @@ __device__ __forceinline__ bool wave_any(bool pred) { return __ballot(pred) != 0
 // `lam` (LDS, or nullptr) are the per-instance label adjoints accumulated into sums.L by the backward.
 // On return bit i of *near_out says whether instance i was evaluated this round (wave-uniform) and, with kCacheDistances,
 // dcache[i][lane] holds d_i for those instances.
-// The instance loop of eval_union: the instances of `evaluated`, accumulated with a fixed soft-min shift `floor` or (kRunning) the
-// running minimum.  kTiles: residual fields take the 16-lane rows that need the MLP from the squared centre distances in dcache.
-template <bool kCacheDistances, bool kResidual, bool kRunning, bool kTiles>
-__device__ __forceinline__ UnionSums union_loop(const float* __restrict__ instances, const float* __restrict__ mlp, unsigned long long evaluated,
-                                                const Shading& sh, const RayCull& rc, const RoundCull& cull, float floor, float x, float y, float z,
+// The instance loop of eval_union: the instances of `evaluated` (bound test, field.h) that also pass the exact test -- the others
+// are cleared from the mask --, accumulated with a fixed soft-min shift `floor` or (kRunning) the running minimum.
+template <bool kCacheDistances, bool kResidual, bool kRunning>
+__device__ __forceinline__ UnionSums union_loop(const float* __restrict__ instances, const float* __restrict__ mlp, unsigned long long& evaluated,
+                                                const Shading& sh, const RoundCull& cull, float floor, float x, float y, float z,
                                                 float* dcache, int lane, const float* lam) {
     UnionSums sums = union_init(kRunning, floor);
+    float best = cull.nearest_hi;                                               // upper bound of the smallest box distance, per lane
     for (unsigned long long todo = evaluated; todo != 0ull; todo &= todo - 1ull) {    // wave-uniform: the instances that survive
         const int i = __builtin_ctzll(todo);
         const Instance in = load_instance(instances, i);
-        const unsigned tiles = (kResidual && kTiles) ? rows_with(cull_near(rc, cull, i, dcache[i * kWave + lane])) : 0xFu;
-        const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z, tiles | sh.mlp_bits);
+        BoxEval e = box_value(in, x, y, z);
+        const unsigned long long near = __ballot(!(e.d - best > sh.cull));      // (NaN-safe: an undecidable comparison keeps the instance)
+        if (near == 0ull) { evaluated &= ~(1ull << i); continue; }
+        best = fminf(best, e.d);
+        box_gradient(e, in);
+        if (kResidual) add_residual(e, in, residual_forward(mlp + i * kMlpWeights, e.px, e.py, e.pz, rows_with(near) | sh.mlp_bits));
         if (kCacheDistances) dcache[i * kWave + lane] = e.d;
         union_accumulate<kRunning>(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, sh.inv_t);
     }
@@ -98,16 +103,14 @@ __device__ __forceinline__ UnionValue eval_union(const float* __restrict__ insta
                                                  const Shading& sh, const RayCull& rc, float t, float x, float y, float z, float* dcache, int lane,
                                                  const float* lam, unsigned long long* near_out, float* lam_z_out) {
     RoundCull cull;
-    const unsigned long long evaluated = cull_round_mask<true>(rc, num_instances, t, sh.cull, dcache, lane, &cull);
+    unsigned long long evaluated = cull_round_mask<true>(rc, num_instances, t, sh.cull, dcache, lane, &cull);
     UnionSums sums;
     bool running = sh.reach < 0.0f;                                             // wave-uniform
     if (!running) {
-        sums = union_loop<kCacheDistances, kResidual, false, true>(instances, mlp, evaluated, sh, rc, cull, cull.nearest_lo - sh.reach, x, y, z, dcache, lane, lam);
+        sums = union_loop<kCacheDistances, kResidual, false>(instances, mlp, evaluated, sh, cull, cull.nearest_lo - sh.reach, x, y, z, dcache, lane, lam);
         running = wave_any(!(sums.Z >= kUnionTinyZ));                           // the fixed shift underflowed somewhere: repeat the round
-        if (running) sums = union_loop<kCacheDistances, kResidual, true, false>(instances, mlp, evaluated, sh, rc, cull, 0.0f, x, y, z, dcache, lane, lam);
-    } else {
-        sums = union_loop<kCacheDistances, kResidual, true, true>(instances, mlp, evaluated, sh, rc, cull, 0.0f, x, y, z, dcache, lane, lam);
     }
+    if (running) sums = union_loop<kCacheDistances, kResidual, true>(instances, mlp, evaluated, sh, cull, 0.0f, x, y, z, dcache, lane, lam);
     const UnionValue v = union_finish(sums, sh.inv_t);
     if (near_out) *near_out = evaluated;
     if (lam_z_out) *lam_z_out = sums.L * v.inv_z;

@@ -251,25 +251,29 @@ struct RayAdjoint {
     unsigned long long near_rows[kRounds][4];
 };
 
-// The instance loop of the forward sweep for round k (render.h: union_loop, plus what the adjoint keeps: 16-lane row masks and the
-// residual jets).  kTiles = false (a repeated round, the cache no longer holds squared centre distances): every row evaluates the MLP.
-template <int kRounds, bool kResidual, bool kCacheD, bool kRunning, bool kTiles>
+// The instance loop of the forward sweep for round k (render.h: union_loop, plus what the adjoint keeps: the 16-lane row masks and
+// the residual jets).  Instances that fail the exact test are cleared from st.near_any[k]: the later phases never see them.
+template <int kRounds, bool kResidual, bool kCacheD, bool kRunning>
 __device__ __forceinline__ UnionSums sweep_union_loop(RayAdjoint<kRounds>& st, int k, const float* __restrict__ instances, const float* __restrict__ mlp, int N,
-                                                      const Shading& sh, const RayCull& rc, const RoundCull& cull, float floor, float mid, const float* lam,
+                                                      const Shading& sh, const RoundCull& cull, float floor, const float* lam,
                                                       float* dcache, int lane, float4* rcache) {
     UnionSums sums = union_init(kRunning, floor);
+    float best = cull.nearest_hi;
     for (unsigned long long todo = st.near_any[k]; todo != 0ull; todo &= todo - 1ull) {
         const int i = __builtin_ctzll(todo);
         const Instance in = load_instance(instances, i);
-        unsigned long long near = ~0ull;
+        BoxEval e = box_value(in, st.sa[k].x, st.sa[k].y, st.sa[k].z);
+        const unsigned long long near = __ballot(!(e.d - best > sh.cull));
+        if (near == 0ull) { st.near_any[k] &= ~(1ull << i); continue; }
+        best = fminf(best, e.d);
+        box_gradient(e, in);
         if (kResidual) {
-            if (kTiles) near = cull_near(rc, cull, i, kCacheD ? dcache[i * kWave + lane] : centre_distance2(rc, i, mid, rc.c2 * mid));
 #pragma unroll
             for (int q = 0; q < 4; ++q) st.near_rows[k][q] |= ((near >> (16 * q)) & 0xFFFFull) ? (1ull << i) : 0ull;
+            const Residual res = residual_forward(mlp + i * kMlpWeights, e.px, e.py, e.pz, rows_with(near) | sh.mlp_bits);
+            add_residual(e, in, res);
+            if (rcache) rcache[(k * N + i) * kWave + lane] = make_float4(res.value, res.gx, res.gy, res.gz);
         }
-        Residual res;
-        const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, st.sa[k].x, st.sa[k].y, st.sa[k].z, rows_with(near) | sh.mlp_bits, &res);
-        if (kResidual && rcache) rcache[(k * N + i) * kWave + lane] = make_float4(res.value, res.gx, res.gy, res.gz);
         if (kCacheD) dcache[i * kWave + lane] = e.d;
         union_accumulate<kRunning>(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, sh.inv_t);
     }
@@ -302,12 +306,10 @@ __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, 
         UnionSums sums;
         bool running = sh.reach < 0.0f;                                      // wave-uniform
         if (!running) {
-            sums = sweep_union_loop<kRounds, kResidual, kCacheD, false, true>(st, k, instances, mlp, N, sh, rc, cull, cull.nearest_lo - sh.reach, mid, lam, dcache, lane, rcache);
+            sums = sweep_union_loop<kRounds, kResidual, kCacheD, false>(st, k, instances, mlp, N, sh, cull, cull.nearest_lo - sh.reach, lam, dcache, lane, rcache);
             running = wave_any(!(sums.Z >= kUnionTinyZ));                    // the fixed shift underflowed somewhere: repeat the round
-            if (running) sums = sweep_union_loop<kRounds, kResidual, kCacheD, true, false>(st, k, instances, mlp, N, sh, rc, cull, 0.0f, mid, lam, dcache, lane, rcache);
-        } else {
-            sums = sweep_union_loop<kRounds, kResidual, kCacheD, true, true>(st, k, instances, mlp, N, sh, rc, cull, 0.0f, mid, lam, dcache, lane, rcache);
         }
+        if (running) sums = sweep_union_loop<kRounds, kResidual, kCacheD, true>(st, k, instances, mlp, N, sh, cull, 0.0f, lam, dcache, lane, rcache);
         const UnionValue v = union_finish(sums, inv_t);
         st.op[k] = opacity_of(v, r, st.delta[k], sh);
         const float alpha = valid ? st.op[k].alpha : 0.0f;

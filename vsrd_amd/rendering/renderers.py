@@ -15,6 +15,7 @@ Two ways in:
 Gradients reach the field parameters through ``torch.autograd.Function``s whose backward is the
 hand-derived adjoint kernel (``vsrd_render_backward``); there is no PyTorch-op fallback.
 """
+import os
 import threading
 
 import torch
@@ -51,7 +52,7 @@ def current_scope():
 # every launch so that each instance is evaluated at each sample, exactly like the reference's closure loop.
 CULLING = True
 # A/B switch for the soft-min shift (field.h: union_accumulate): True sets VSRD_FLAG_RUNNING_MINIMUM on every launch.
-RUNNING_MINIMUM = False
+RUNNING_MINIMUM = os.environ.get("VSRD_RUNNING_MINIMUM", "0") == "1"
 
 
 def _base_flags():
