@@ -89,6 +89,10 @@ typedef struct vsrd_render_config {
                                              lower bound known before the instance loop (A/B switch; the kernels fall back to it by
                                              themselves wherever the bound is unavailable or too loose)                              */
 
+#define VSRD_FLAG_GENERAL_ROTATIONS 32u     /* do not use the shortened rotation products the kernels select by themselves when every
+                                             instance's rotation is exactly one about the y axis (r01 = r10 = r12 = r21 = 0, r11 = 1,
+                                             what rotation_matrix_y produces); the results agree to rounding (A/B switch)              */
+
 int32_t vsrd_abi_version(void);
 const char* vsrd_error_string(int32_t code);
 

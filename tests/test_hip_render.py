@@ -345,16 +345,17 @@ def test_skip_exact_misses_is_exact(dev):
 def test_culling_is_invisible(dev, name):
     """The two things the kernels do differently from the reference's closure loop must not show: conservative soft-min culling
     (instances whose weight is below exp(-18) on every lane are skipped wave-uniformly: sphere-bound test, then exact test on the
-    box distance) and the soft-min shift known before the instance loop.  Baseline: every instance evaluated at every sample,
-    running-minimum shift (VSRD_FLAG_NO_CULLING | VSRD_FLAG_RUNNING_MINIMUM)."""
+    box distance), the soft-min shift known before the instance loop, and the shortened products for rotations about y.  Baseline: every instance evaluated at every sample,
+    running-minimum shift, general rotations (VSRD_FLAG_NO_CULLING | VSRD_FLAG_RUNNING_MINIMUM | VSRD_FLAG_GENERAL_ROTATIONS)."""
     from vsrd_amd import rendering
     from vsrd_amd.rendering import renderers
     g = load_golden(name)
     S = int(g["num_samples"])
     std, ratio = float(g["sdf_std_deviation"]), float(g["cosine_ratio"])
     results = {}
-    for mode, (culling, running) in {"default": (True, False), "running": (True, True), "baseline": (False, True)}.items():
-        renderers.CULLING, renderers.RUNNING_MINIMUM = culling, running
+    modes = {"default": (True, False, False), "running": (True, True, False), "general": (True, False, True), "baseline": (False, True, True)}
+    for mode, (culling, running, general) in modes.items():
+        renderers.CULLING, renderers.RUNNING_MINIMUM, renderers.GENERAL_ROTATIONS = culling, running, general
         try:
             union, params = hip_union(g, dev, requires_grad=True)
             out = rendering.render_hierarchical(union, g["origins"].to(dev), g["directions"].to(dev), (0.0, 100.0), S, std, ratio,
@@ -365,8 +366,9 @@ def test_culling_is_invisible(dev, name):
             loss = (out["labels"] * lam).sum() + (out["gradients"][hit] * gam[hit]).sum()
             results[mode] = (out["labels"].detach(), torch.autograd.grad(loss, params))
         finally:
-            renderers.CULLING, renderers.RUNNING_MINIMUM = True, False
-    for mode in ("default", "running"):
+            renderers.CULLING, renderers.RUNNING_MINIMUM, renderers.GENERAL_ROTATIONS = True, False, False
+    # (the y-rotation fast path only leaves out products with exact zeros and ones; the fixed shift changes the rounding of the sums)
+    for mode in ("default", "running", "general"):
         assert (results[mode][0] - results["baseline"][0]).abs().max() < 1e-6, mode
         for a, b in zip(results[mode][1], results["baseline"][1]):
             assert (a - b).abs().max() <= 1e-4 * max(float(b.abs().max()), 1e-6), mode

@@ -23,6 +23,7 @@ FLAG_SKIP_EXACT_MISSES = 2
 FLAG_NO_CULLING = 4
 FLAG_MLP_WEIGHTS_CENTRED = 8
 FLAG_RUNNING_MINIMUM = 16
+FLAG_GENERAL_ROTATIONS = 32
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 

@@ -102,6 +102,7 @@ RenderArgs render_args(const vsrd_render_config* c) {
     a.sh.inv_t = 0.0f;  // filled from the field
     a.sh.cull = 0.0f;   // computed in-kernel (field.h: field_bounds)
     a.sh.reach = -1.0f; // likewise
+    a.sh.yaw = false;   // likewise
     a.sh.std = c->sdf_std_deviation;
     a.sh.inv_std = 1.0f / c->sdf_std_deviation;
     a.sh.ratio = c->cosine_ratio;

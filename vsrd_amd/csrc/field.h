@@ -53,13 +53,25 @@ __device__ __forceinline__ float sign_of(float v) { return (v > 0.0f) ? 1.0f : (
 __device__ __forceinline__ float times_sign(float h, float p) { return (p == 0.0f) ? 0.0f : __builtin_copysignf(h, p); }
 
 // First half of the box evaluation: local position and signed distance (what the exact culling test of the render loops needs).
+// kYaw: the rotation is one about the y axis with r01 = r10 = r12 = r21 = 0 and r11 = 1 EXACTLY (what rotation_matrix_y,
+// box_parameters.py:5-13, produces; field_bounds checks it for the whole field): the products with those entries are left out,
+// which changes the results by rounding at most (x * 0 = 0, x * 1 = x) and saves 5 of the 9 multiply-adds of each rotation.
+template <bool kYaw = false>
 __device__ __forceinline__ BoxEval box_value(const Instance& in, float x, float y, float z) {
     BoxEval e;
     e.relx = x - in.tx; e.rely = y - in.ty; e.relz = z - in.tz;
     // row vector times R (sdfs.py:34): p_j = sum_k rel_k R_kj
-    e.px = e.relx * in.r00 + e.rely * in.r10 + e.relz * in.r20;
-    e.py = e.relx * in.r01 + e.rely * in.r11 + e.relz * in.r21;
-    e.pz = e.relx * in.r02 + e.rely * in.r12 + e.relz * in.r22;
+    // (explicit fma chains: every instantiation rounds the local position the same way -- the box SDF has kinks (arg max, relu),
+    //  and a last-bit difference in p moves samples across them, which shows up as 1e-4 differences in summed gradients)
+    if (kYaw) {
+        e.px = fmaf(e.relz, in.r20, e.relx * in.r00);
+        e.py = e.rely;
+        e.pz = fmaf(e.relz, in.r22, e.relx * in.r02);
+    } else {
+        e.px = fmaf(e.relz, in.r20, fmaf(e.rely, in.r10, e.relx * in.r00));
+        e.py = fmaf(e.relz, in.r21, fmaf(e.rely, in.r11, e.relx * in.r01));
+        e.pz = fmaf(e.relz, in.r22, fmaf(e.rely, in.r12, e.relx * in.r02));
+    }
     e.qx = fabsf(e.px) - in.dx; e.qy = fabsf(e.py) - in.dy; e.qz = fabsf(e.pz) - in.dz;
     const float ax = fmaxf(e.qx, 0.0f), ay = fmaxf(e.qy, 0.0f), az = fmaxf(e.qz, 0.0f);
     e.nrm = fast_sqrt(ax * ax + ay * ay + az * az + kNormEpsilon);
@@ -71,7 +83,22 @@ __device__ __forceinline__ BoxEval box_value(const Instance& in, float x, float 
     return e;
 }
 
+// gw_k = sum_j R_kj gl_j
+template <bool kYaw>
+__device__ __forceinline__ void rotate_to_world(BoxEval& e, const Instance& in) {
+    if (kYaw) {
+        e.gwx = fmaf(in.r02, e.glz, in.r00 * e.glx);
+        e.gwy = e.gly;
+        e.gwz = fmaf(in.r22, e.glz, in.r20 * e.glx);
+    } else {
+        e.gwx = fmaf(in.r02, e.glz, fmaf(in.r01, e.gly, in.r00 * e.glx));
+        e.gwy = fmaf(in.r12, e.glz, fmaf(in.r11, e.gly, in.r10 * e.glx));
+        e.gwz = fmaf(in.r22, e.glz, fmaf(in.r21, e.gly, in.r20 * e.glx));
+    }
+}
+
 // Second half: analytic gradient in the local and the world frame.
+template <bool kYaw = false>
 __device__ __forceinline__ void box_gradient(BoxEval& e, const Instance& in) {
     const float ax = fmaxf(e.qx, 0.0f), ay = fmaxf(e.qy, 0.0f), az = fmaxf(e.qz, 0.0f);
     const float inv = fast_rcp(e.nrm);
@@ -80,27 +107,24 @@ __device__ __forceinline__ void box_gradient(BoxEval& e, const Instance& in) {
     e.hy = ay * inv + ((e.arg == 1) ? inside : 0.0f);
     e.hz = az * inv + ((e.arg == 2) ? inside : 0.0f);
     e.glx = times_sign(e.hx, e.px); e.gly = times_sign(e.hy, e.py); e.glz = times_sign(e.hz, e.pz);
-    // gw_k = sum_j R_kj gl_j
-    e.gwx = in.r00 * e.glx + in.r01 * e.gly + in.r02 * e.glz;
-    e.gwy = in.r10 * e.glx + in.r11 * e.gly + in.r12 * e.glz;
-    e.gwz = in.r20 * e.glx + in.r21 * e.gly + in.r22 * e.glz;
+    rotate_to_world<kYaw>(e, in);
 }
 
+template <bool kYaw = false>
 __device__ __forceinline__ BoxEval eval_box(const Instance& in, float x, float y, float z) {
-    BoxEval e = box_value(in, x, y, z);
-    box_gradient(e, in);
+    BoxEval e = box_value<kYaw>(in, x, y, z);
+    box_gradient<kYaw>(e, in);
     return e;
 }
 
 // Box (+ optional residual MLP) evaluation of instance i: d_i = box(p) + residual(p), local gradient likewise
 // (scripts/main.py:451-458).  `mlp` is the wave-uniform weight row of the instance.
 // d_i = box(p) + residual(p), local gradient likewise (scripts/main.py:451-458).
+template <bool kYaw = false>
 __device__ __forceinline__ void add_residual(BoxEval& e, const Instance& in, const Residual& r) {
     e.d += r.value;
     e.glx += r.gx; e.gly += r.gy; e.glz += r.gz;
-    e.gwx = in.r00 * e.glx + in.r01 * e.gly + in.r02 * e.glz;
-    e.gwy = in.r10 * e.glx + in.r11 * e.gly + in.r12 * e.glz;
-    e.gwz = in.r20 * e.glx + in.r21 * e.gly + in.r22 * e.glz;
+    rotate_to_world<kYaw>(e, in);
 }
 
 // Box (+ optional residual MLP) evaluation of instance i.  `mlp` is the wave-uniform weight row of the instance.
@@ -262,12 +286,14 @@ __device__ __forceinline__ unsigned long long cull_round_mask(const RayCull& rc,
 //   reach   max_i |dim_i| + slack: every d_i(x) >= (nearest centre distance) (1 - k) - reach, which gives the soft-min a shift it
 //           knows BEFORE the instance loop (union_accumulate); < 0 when that bound is unavailable (non-orthonormal rotations) or
 //           reach / T is so large that exp(-(d - floor)/T) could underflow for the best instance.
-struct FieldBounds { float margin, reach; };
+struct FieldBounds { float margin, reach; bool yaw; };   // yaw: every rotation is exactly of the form box_value<true> assumes
 
 __device__ __forceinline__ FieldBounds field_bounds(const float* __restrict__ instances, int num_instances, float inv_t, bool residual, unsigned flags) {
     float worst = 0.0f, rmax = 0.0f;
+    bool yaw = true;
     for (int i = 0; i < num_instances; ++i) {
         const Instance in = load_instance(instances, i);
+        yaw = yaw && in.r01 == 0.0f && in.r10 == 0.0f && in.r12 == 0.0f && in.r21 == 0.0f && in.r11 == 1.0f;
         const float g00 = in.r00 * in.r00 + in.r10 * in.r10 + in.r20 * in.r20, g11 = in.r01 * in.r01 + in.r11 * in.r11 + in.r21 * in.r21;
         const float g22 = in.r02 * in.r02 + in.r12 * in.r12 + in.r22 * in.r22, g01 = in.r00 * in.r01 + in.r10 * in.r11 + in.r20 * in.r21;
         const float g02 = in.r00 * in.r02 + in.r10 * in.r12 + in.r20 * in.r22, g12 = in.r01 * in.r02 + in.r11 * in.r12 + in.r21 * in.r22;
@@ -280,6 +306,7 @@ __device__ __forceinline__ FieldBounds field_bounds(const float* __restrict__ in
     b.margin = (orthonormal && !(flags & 4u)) ? (kCullTau / inv_t + 2.0e-3f + (residual ? 1.0f : 0.0f)) : 3.0e38f;
     const float reach = rmax + 2.0e-3f;
     b.reach = (orthonormal && !(flags & 16u) && (reach + 1.0f) * inv_t <= 50.0f) ? reach : -1.0f;
+    b.yaw = yaw && !(flags & 32u);
     return b;
 }
 

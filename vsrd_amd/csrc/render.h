@@ -19,6 +19,7 @@ struct Shading {
     float inv_t;    // 1 / soft-union temperature
     float cull;     // culling margin (field.h), wave-uniform; +huge disables culling
     float reach;    // soft-min floor: every d_i >= nearest centre distance - reach (field.h: field_bounds); < 0: running minimum
+    bool yaw;       // every rotation is exactly a rotation about y (field.h: box_value<true>)
     float std;      // sdf_std_deviation
     float inv_std;  // 1 / sdf_std_deviation
     float ratio;    // cosine_ratio
@@ -77,7 +78,7 @@ __device__ __forceinline__ bool wave_any(bool pred) { return __ballot(pred) != 0
 // dcache[i][lane] holds d_i for those instances.
 // The instance loop of eval_union: the instances of `evaluated` (bound test, field.h) that also pass the exact test -- the others
 // are cleared from the mask --, accumulated with a fixed soft-min shift `floor` or (kRunning) the running minimum.
-template <bool kCacheDistances, bool kResidual, bool kRunning>
+template <bool kCacheDistances, bool kResidual, bool kRunning, bool kYaw>
 __device__ __forceinline__ UnionSums union_loop(const float* __restrict__ instances, const float* __restrict__ mlp, unsigned long long& evaluated,
                                                 const Shading& sh, const RoundCull& cull, float floor, float x, float y, float z,
                                                 float* dcache, int lane, const float* lam) {
@@ -86,12 +87,12 @@ __device__ __forceinline__ UnionSums union_loop(const float* __restrict__ instan
     for (unsigned long long todo = evaluated; todo != 0ull; todo &= todo - 1ull) {    // wave-uniform: the instances that survive
         const int i = __builtin_ctzll(todo);
         const Instance in = load_instance(instances, i);
-        BoxEval e = box_value(in, x, y, z);
+        BoxEval e = box_value<kYaw>(in, x, y, z);
         const unsigned long long near = __ballot(!(e.d - best > sh.cull));      // (NaN-safe: an undecidable comparison keeps the instance)
         if (near == 0ull) { evaluated &= ~(1ull << i); continue; }
         best = fminf(best, e.d);
-        box_gradient(e, in);
-        if (kResidual) add_residual(e, in, residual_forward(mlp + i * kMlpWeights, e.px, e.py, e.pz, rows_with(near) | sh.mlp_bits));
+        box_gradient<kYaw>(e, in);
+        if (kResidual) add_residual<kYaw>(e, in, residual_forward(mlp + i * kMlpWeights, e.px, e.py, e.pz, rows_with(near) | sh.mlp_bits));
         if (kCacheDistances) dcache[i * kWave + lane] = e.d;
         union_accumulate<kRunning>(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, sh.inv_t);
     }
@@ -107,10 +108,12 @@ __device__ __forceinline__ UnionValue eval_union(const float* __restrict__ insta
     UnionSums sums;
     bool running = sh.reach < 0.0f;                                             // wave-uniform
     if (!running) {
-        sums = union_loop<kCacheDistances, kResidual, false>(instances, mlp, evaluated, sh, cull, cull.nearest_lo - sh.reach, x, y, z, dcache, lane, lam);
+        const float floor = cull.nearest_lo - sh.reach;
+        sums = sh.yaw ? union_loop<kCacheDistances, kResidual, false, true>(instances, mlp, evaluated, sh, cull, floor, x, y, z, dcache, lane, lam)
+                      : union_loop<kCacheDistances, kResidual, false, false>(instances, mlp, evaluated, sh, cull, floor, x, y, z, dcache, lane, lam);
         running = wave_any(!(sums.Z >= kUnionTinyZ));                           // the fixed shift underflowed somewhere: repeat the round
     }
-    if (running) sums = union_loop<kCacheDistances, kResidual, true>(instances, mlp, evaluated, sh, cull, 0.0f, x, y, z, dcache, lane, lam);
+    if (running) sums = union_loop<kCacheDistances, kResidual, true, false>(instances, mlp, evaluated, sh, cull, 0.0f, x, y, z, dcache, lane, lam);
     const UnionValue v = union_finish(sums, sh.inv_t);
     if (near_out) *near_out = evaluated;
     if (lam_z_out) *lam_z_out = sums.L * v.inv_z;

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_forward_kernel(
     float* coef = dcache + f.num_instances * kWave;
     Shading sh = c.sh;
     const FieldBounds bounds = field_bounds(instances, f.num_instances, f.inv_t, kResidual, c.flags);
-    sh.cull = bounds.margin; sh.reach = bounds.reach;
+    sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
     sh.mlp_bits = (c.flags & 8u) ? kMlpCentredBit : 0u;
     const int stride = static_cast<int>(gridDim.x) * waves_per_block();
     for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
     const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
     Shading sh = c.sh;
     const FieldBounds bounds = field_bounds(instances, f.num_instances, f.inv_t, kResidual, c.flags);
-    sh.cull = bounds.margin; sh.reach = bounds.reach;
+    sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
     sh.mlp_bits = (c.flags & 8u) ? kMlpCentredBit : 0u;
     const int stride = static_cast<int>(gridDim.x) * waves_per_block();
     for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
@@ -253,7 +253,7 @@ struct RayAdjoint {
 
 // The instance loop of the forward sweep for round k (render.h: union_loop, plus what the adjoint keeps: the 16-lane row masks and
 // the residual jets).  Instances that fail the exact test are cleared from st.near_any[k]: the later phases never see them.
-template <int kRounds, bool kResidual, bool kCacheD, bool kRunning>
+template <int kRounds, bool kResidual, bool kCacheD, bool kRunning, bool kYaw>
 __device__ __forceinline__ UnionSums sweep_union_loop(RayAdjoint<kRounds>& st, int k, const float* __restrict__ instances, const float* __restrict__ mlp, int N,
                                                       const Shading& sh, const RoundCull& cull, float floor, const float* lam,
                                                       float* dcache, int lane, float4* rcache) {
@@ -262,16 +262,16 @@ __device__ __forceinline__ UnionSums sweep_union_loop(RayAdjoint<kRounds>& st, i
     for (unsigned long long todo = st.near_any[k]; todo != 0ull; todo &= todo - 1ull) {
         const int i = __builtin_ctzll(todo);
         const Instance in = load_instance(instances, i);
-        BoxEval e = box_value(in, st.sa[k].x, st.sa[k].y, st.sa[k].z);
+        BoxEval e = box_value<kYaw>(in, st.sa[k].x, st.sa[k].y, st.sa[k].z);
         const unsigned long long near = __ballot(!(e.d - best > sh.cull));
         if (near == 0ull) { st.near_any[k] &= ~(1ull << i); continue; }
         best = fminf(best, e.d);
-        box_gradient(e, in);
+        box_gradient<kYaw>(e, in);
         if (kResidual) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) st.near_rows[k][q] |= ((near >> (16 * q)) & 0xFFFFull) ? (1ull << i) : 0ull;
             const Residual res = residual_forward(mlp + i * kMlpWeights, e.px, e.py, e.pz, rows_with(near) | sh.mlp_bits);
-            add_residual(e, in, res);
+            add_residual<kYaw>(e, in, res);
             if (rcache) rcache[(k * N + i) * kWave + lane] = make_float4(res.value, res.gx, res.gy, res.gz);
         }
         if (kCacheD) dcache[i * kWave + lane] = e.d;
@@ -306,10 +306,12 @@ __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, 
         UnionSums sums;
         bool running = sh.reach < 0.0f;                                      // wave-uniform
         if (!running) {
-            sums = sweep_union_loop<kRounds, kResidual, kCacheD, false>(st, k, instances, mlp, N, sh, cull, cull.nearest_lo - sh.reach, lam, dcache, lane, rcache);
+            const float floor = cull.nearest_lo - sh.reach;
+            sums = sh.yaw ? sweep_union_loop<kRounds, kResidual, kCacheD, false, true>(st, k, instances, mlp, N, sh, cull, floor, lam, dcache, lane, rcache)
+                          : sweep_union_loop<kRounds, kResidual, kCacheD, false, false>(st, k, instances, mlp, N, sh, cull, floor, lam, dcache, lane, rcache);
             running = wave_any(!(sums.Z >= kUnionTinyZ));                    // the fixed shift underflowed somewhere: repeat the round
         }
-        if (running) sums = sweep_union_loop<kRounds, kResidual, kCacheD, true>(st, k, instances, mlp, N, sh, cull, 0.0f, lam, dcache, lane, rcache);
+        if (running) sums = sweep_union_loop<kRounds, kResidual, kCacheD, true, false>(st, k, instances, mlp, N, sh, cull, 0.0f, lam, dcache, lane, rcache);
         const UnionValue v = union_finish(sums, inv_t);
         st.op[k] = opacity_of(v, r, st.delta[k], sh);
         const float alpha = valid ? st.op[k].alpha : 0.0f;
@@ -391,9 +393,31 @@ __device__ __forceinline__ bool adjoint_reverse_sweep(RayAdjoint<kRounds>& st, c
     return __ballot(any_flow) != 0ull;
 }
 
+// Label-adjoint mix of the fused step kernels: Lambda_s = sum_n lambda_n w_{s,n} for the samples of every round, from box distances
+// that are re-evaluated (value only, ~30 instructions) instead of keeping every round's [N][64] distance cache in LDS, which would
+// halve the occupancy of render_silhouette_kernel; residual fields add the residual value the sweep left in its jet cache.
+template <int kRounds, bool kResidual, bool kYaw>
+__device__ __forceinline__ void adjoint_label_mix(RayAdjoint<kRounds>& st, const float* __restrict__ instances, int N, float inv_t, int num_points,
+                                                  const float* lam, int lane, const float4* rcache) {
+#pragma unroll
+    for (int k = 0; k < kRounds; ++k) {
+        if (k * kWave >= num_points) continue;
+        float acc = 0.0f;
+        for (unsigned long long todo = st.near_any[k]; todo != 0ull; todo &= todo - 1ull) {   // the instances the forward sweep evaluated
+            const int i = __builtin_ctzll(todo);
+            if (lam[i] == 0.0f) continue;                               // wave-uniform
+            const Instance in = load_instance(instances, i);
+            float d = box_value<kYaw>(in, st.sa[k].x, st.sa[k].y, st.sa[k].z).d;
+            if (kResidual) d += rcache[(k * N + i) * kWave + lane].x;
+            acc += lam[i] * fast_exp(-(d - st.sa[k].m) * inv_t);
+        }
+        st.sa[k].lam_z = acc * st.sa[k].inv_z;
+    }
+}
+
 // Phase B: per instance, adjoint of (d_i, grad d_i) w.r.t. (t, R, dim) (and the residual MLP weights), accumulated into the wave's
 // LDS rows G [N,16]; for residual fields it leaves the seeds and tile masks of the MLP adjoint (adjoint_phase_mlp) instead of running it.
-template <int kRounds, bool kResidual>
+template <int kRounds, bool kResidual, bool kYaw>
 __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, const float* __restrict__ instances, const float* __restrict__ mlp,
                                                 int N, float inv_t, int num_points, const float* lam, float* G, int lane,
                                                 const float4* rcache, float* seeds, unsigned* masks) {
@@ -430,10 +454,10 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
 #pragma unroll
         for (int k = 0; k < kRounds; ++k) {
             if (!active[k]) continue;
-            BoxEval e = eval_box(in, st.sa[k].x, st.sa[k].y, st.sa[k].z);
+            BoxEval e = eval_box<kYaw>(in, st.sa[k].x, st.sa[k].y, st.sa[k].z);
             if (kResidual) {        // the residual jet of this (round, instance) was left by the forward sweep
                 const float4 res = rcache[(k * N + i) * kWave + lane];
-                add_residual(e, in, Residual{res.x, res.y, res.z, res.w});
+                add_residual<kYaw>(e, in, Residual{res.x, res.y, res.z, res.w});
             }
             const float ds = e.d - st.sa[k].m;
             const float w = fast_exp(-ds * inv_t) * st.sa[k].inv_z;
@@ -444,9 +468,9 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
                               - inv_t * w * st.sa[k].wgt * (lam_i - st.sa[k].lam_z);
             const float gwbx = cc * st.sa[k].gbx, gwby = cc * st.sa[k].gby, gwbz = cc * st.sa[k].gbz;
             // gl_bar_j = sum_k R_kj gw_bar_k
-            const float glbx = in.r00 * gwbx + in.r10 * gwby + in.r20 * gwbz;
-            const float glby = in.r01 * gwbx + in.r11 * gwby + in.r21 * gwbz;
-            const float glbz = in.r02 * gwbx + in.r12 * gwby + in.r22 * gwbz;
+            const float glbx = kYaw ? fmaf(in.r20, gwbz, in.r00 * gwbx) : fmaf(in.r20, gwbz, fmaf(in.r10, gwby, in.r00 * gwbx));
+            const float glby = kYaw ? gwby : fmaf(in.r21, gwbz, fmaf(in.r11, gwby, in.r01 * gwbx));
+            const float glbz = kYaw ? fmaf(in.r22, gwbz, in.r02 * gwbx) : fmaf(in.r22, gwbz, fmaf(in.r12, gwby, in.r02 * gwbx));
             const float sx = sign_of(e.px), sy = sign_of(e.py), sz = sign_of(e.pz);
             const float vx = sx * glbx, vy = sy * glby, vz = sz * glbz;
             const float inv_n = fast_rcp(e.nrm);
@@ -466,9 +490,13 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
             r00 += e.relx * pbx + gwbx * e.glx; r01 += e.relx * pby + gwbx * e.gly; r02 += e.relx * pbz + gwbx * e.glz;
             r10 += e.rely * pbx + gwby * e.glx; r11 += e.rely * pby + gwby * e.gly; r12 += e.rely * pbz + gwby * e.glz;
             r20 += e.relz * pbx + gwbz * e.glx; r21 += e.relz * pby + gwbz * e.gly; r22 += e.relz * pbz + gwbz * e.glz;
-            at0 -= in.r00 * pbx + in.r01 * pby + in.r02 * pbz;
-            at1 -= in.r10 * pbx + in.r11 * pby + in.r12 * pbz;
-            at2 -= in.r20 * pbx + in.r21 * pby + in.r22 * pbz;
+            if (kYaw) {
+                at0 -= in.r00 * pbx + in.r02 * pbz; at1 -= pby; at2 -= in.r20 * pbx + in.r22 * pbz;
+            } else {
+                at0 -= in.r00 * pbx + in.r01 * pby + in.r02 * pbz;
+                at1 -= in.r10 * pbx + in.r11 * pby + in.r12 * pbz;
+                at2 -= in.r20 * pbx + in.r21 * pby + in.r22 * pbz;
+            }
         }
         // one reduce-scatter butterfly: lane j (< 16) receives parameter j of instance i and keeps it in its LDS slot
         const float packed[16] = {at0, at1, at2, r00, r01, r02, r10, r11, r12, r20, r21, r22, ad0, ad1, ad2, 0.0f};
@@ -553,7 +581,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
     }
     Shading sh = c.sh;
     const FieldBounds bounds = field_bounds(instances, N, f.inv_t, kResidual, c.flags);
-    sh.cull = bounds.margin; sh.reach = bounds.reach;
+    sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
     sh.mlp_bits = (c.flags & 8u) ? kMlpCentredBit : 0u;
     const int stride = static_cast<int>(gridDim.x) * waves_per_block();
     constexpr int kBatch = kResidual ? kMlpBatch : 1;
@@ -581,7 +609,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
             const float* gw_row = grad_weights ? grad_weights + static_cast<size_t>(ray) * num_points : nullptr;
             const float* gg_row = grad_gradients ? grad_gradients + static_cast<size_t>(ray) * num_points * 3 : nullptr;
             if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, gw_row, gg_row, lane)) continue;      // exact zero adjoint
-            adjoint_phase_b<kRounds, kResidual>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, ray_seeds, ray_masks);
+            if (sh.yaw) adjoint_phase_b<kRounds, kResidual, true>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, ray_seeds, ray_masks);
+            else adjoint_phase_b<kRounds, kResidual, false>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, ray_seeds, ray_masks);
         }
         if (kResidual) {
             wave_lds_sync();                                                 // masks: written by lanes < kRounds, read by all
@@ -624,7 +653,7 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
     const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
     Shading sh = c.sh;
     const FieldBounds bounds = field_bounds(instances, N, f.inv_t, false, c.flags);
-    sh.cull = bounds.margin; sh.reach = bounds.reach;
+    sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
     sh.mlp_bits = 0u;
     const float weight_lane = (lane < N) ? (instance_weights ? instance_weights[lane] : 1.0f) : 0.0f;
     float loss_acc = 0.0f;                                                  // lane n: this wave's BCE sum of instance n
@@ -661,23 +690,11 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
         if (!rendered || wave_max(fabsf(lam_lane)) == 0.0f) continue;
         if (lane < N) lam[lane] = lam_lane;
         wave_lds_sync();
-        // Lambda_s = sum_n lambda_n w_{s,n}: the box distances are re-evaluated (value only, ~45 instructions) instead of keeping
-        // every round's [N][64] distance cache in LDS, which would halve the occupancy of this kernel
-#pragma unroll
-        for (int k = 0; k < kRounds; ++k) {
-            if (k * kWave >= num_points) continue;
-            float acc = 0.0f;
-            for (unsigned long long todo = st.near_any[k]; todo != 0ull; todo &= todo - 1ull) {   // the instances the forward sweep evaluated
-                const int i = __builtin_ctzll(todo);
-                if (lam[i] == 0.0f) continue;                               // wave-uniform
-                const Instance in = load_instance(instances, i);
-                const BoxEval e = eval_box(in, st.sa[k].x, st.sa[k].y, st.sa[k].z);
-                acc += lam[i] * fast_exp(-(e.d - st.sa[k].m) * sh.inv_t);
-            }
-            st.sa[k].lam_z = acc * st.sa[k].inv_z;
-        }
+        if (sh.yaw) adjoint_label_mix<kRounds, false, true>(st, instances, N, sh.inv_t, num_points, lam, lane, nullptr);
+        else adjoint_label_mix<kRounds, false, false>(st, instances, N, sh.inv_t, num_points, lam, lane, nullptr);
         if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, nullptr, nullptr, lane)) continue;
-        adjoint_phase_b<kRounds, false>(st, instances, nullptr, N, f.inv_t, num_points, lam, G, lane, nullptr, nullptr, nullptr);
+        if (sh.yaw) adjoint_phase_b<kRounds, false, true>(st, instances, nullptr, N, f.inv_t, num_points, lam, G, lane, nullptr, nullptr, nullptr);
+        else adjoint_phase_b<kRounds, false, false>(st, instances, nullptr, N, f.inv_t, num_points, lam, G, lane, nullptr, nullptr, nullptr);
     }
     wave_lds_sync();
     const size_t wave_global = static_cast<size_t>(blockIdx.x) * waves_per_block() + wave;
@@ -728,7 +745,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_residual_step_kernel(
     const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
     Shading sh = c.sh;
     const FieldBounds bounds = field_bounds(instances, N, f.inv_t, true, c.flags);
-    sh.cull = bounds.margin; sh.reach = bounds.reach;
+    sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
     sh.mlp_bits = (c.flags & 8u) ? kMlpCentredBit : 0u;
     const float weight_lane = (lane < N) ? (instance_weights ? instance_weights[lane] : 1.0f) : 0.0f;
     float loss_acc = 0.0f, eikonal_acc = 0.0f;
@@ -767,20 +784,12 @@ __global__ __launch_bounds__(kBlockThreads) void render_residual_step_kernel(
                 // eikonal value of this round's samples
                 const float norm = fast_sqrt(st.gx[k] * st.gx[k] + st.gy[k] * st.gy[k] + st.gz[k] * st.gz[k]);
                 eikonal_acc += (k * kWave + lane < num_points) ? (norm - 1.0f) * (norm - 1.0f) : 0.0f;
-                // Lambda_s = sum_n lambda_n w_{s,n}: box distance re-evaluated, residual value from the sweep's jet cache
-                float acc = 0.0f;
-                for (unsigned long long todo = st.near_any[k]; todo != 0ull; todo &= todo - 1ull) {   // evaluated by the forward sweep
-                    const int i = __builtin_ctzll(todo);
-                    if (lam[i] == 0.0f) continue;                               // wave-uniform
-                    const Instance in = load_instance(instances, i);
-                    const BoxEval e = eval_box(in, st.sa[k].x, st.sa[k].y, st.sa[k].z);
-                    const float d = e.d + rcache[(k * N + i) * kWave + lane].x;
-                    acc += lam[i] * fast_exp(-(d - st.sa[k].m) * sh.inv_t);
-                }
-                st.sa[k].lam_z = acc * st.sa[k].inv_z;
             }
+            if (sh.yaw) adjoint_label_mix<kRounds, true, true>(st, instances, N, sh.inv_t, num_points, lam, lane, rcache);
+            else adjoint_label_mix<kRounds, true, false>(st, instances, N, sh.inv_t, num_points, lam, lane, rcache);
             if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, nullptr, nullptr, lane, eikonal_scale)) continue;
-            adjoint_phase_b<kRounds, true>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, ray_seeds, ray_masks);
+            if (sh.yaw) adjoint_phase_b<kRounds, true, true>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, ray_seeds, ray_masks);
+            else adjoint_phase_b<kRounds, true, false>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, ray_seeds, ray_masks);
         }
         wave_lds_sync();                                                     // masks: written by lanes < kRounds, read by all
         adjoint_phase_mlp<kRounds, kMlpBatch>(instances, mlp, N, G, wbar, my_mlp, lane, seeds, masks, sh.mlp_bits);

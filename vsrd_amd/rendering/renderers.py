@@ -53,10 +53,13 @@ def current_scope():
 CULLING = True
 # A/B switch for the soft-min shift (field.h: union_accumulate): True sets VSRD_FLAG_RUNNING_MINIMUM on every launch.
 RUNNING_MINIMUM = os.environ.get("VSRD_RUNNING_MINIMUM", "0") == "1"
+# A/B switch for the y-rotation fast path (field.h: box_value<true>): True sets VSRD_FLAG_GENERAL_ROTATIONS on every launch.
+GENERAL_ROTATIONS = os.environ.get("VSRD_GENERAL_ROTATIONS", "0") == "1"
 
 
 def _base_flags():
-    return (0 if CULLING else _lib.FLAG_NO_CULLING) | (_lib.FLAG_RUNNING_MINIMUM if RUNNING_MINIMUM else 0)
+    return ((0 if CULLING else _lib.FLAG_NO_CULLING) | (_lib.FLAG_RUNNING_MINIMUM if RUNNING_MINIMUM else 0)
+            | (_lib.FLAG_GENERAL_ROTATIONS if GENERAL_ROTATIONS else 0))
 
 
 def _mlp_flag(centred_weights):
