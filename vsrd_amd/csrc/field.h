@@ -40,7 +40,7 @@ struct BoxEval {
     float qx, qy, qz;         // |p| - half extents
     float hx, hy, hz;         // d d / d q
     float nrm;                // sqrt(sum relu(q)^2 + 1e-6)
-    float qmax; int arg;      // max_j q_j and its (first) index
+    float qmax;               // max_j q_j
     float d;                  // signed distance
     float glx, gly, glz;      // local gradient  sign(p) * h
     float gwx, gwy, gwz;      // world gradient  R @ gl
@@ -75,10 +75,7 @@ __device__ __forceinline__ BoxEval box_value(const Instance& in, float x, float 
     e.qx = fabsf(e.px) - in.dx; e.qy = fabsf(e.py) - in.dy; e.qz = fabsf(e.pz) - in.dz;
     const float ax = fmaxf(e.qx, 0.0f), ay = fmaxf(e.qy, 0.0f), az = fmaxf(e.qz, 0.0f);
     e.nrm = fast_sqrt(ax * ax + ay * ay + az * az + kNormEpsilon);
-    // torch.max returns the first maximal index; its backward routes to that index.
-    e.qmax = e.qx; e.arg = 0;
-    if (e.qy > e.qmax) { e.qmax = e.qy; e.arg = 1; }
-    if (e.qz > e.qmax) { e.qmax = e.qz; e.arg = 2; }
+    e.qmax = fmaxf(fmaxf(e.qx, e.qy), e.qz);                            // one v_max3_f32
     e.d = e.nrm - fmaxf(-e.qmax, 0.0f);
     return e;
 }
@@ -98,15 +95,24 @@ __device__ __forceinline__ void rotate_to_world(BoxEval& e, const Instance& in) 
 }
 
 // Second half: analytic gradient in the local and the world frame.
+//   d d / d q_j = relu(q_j) / nrm + [inside] [j = arg max q]      (torch.max: the FIRST maximal index; its backward routes there)
+//   gl_j        = sign(p_j) * that                                (torch.sign(0) = 0)
+// Inside the box (q_max < 0) every relu(q_j) is 0, and p_j = 0 makes relu(q_j) = 0 (half extents are positive): per axis the
+// magnitude is one select between relu(q_j)/nrm and 1, the select mask carries "p_j != 0" (lane-mask logic on the scalar unit), and
+// the sign is a bit-field insert; the arg max is a v_max3 and two compares.  (Six vector instructions fewer than the obvious
+// form, and no faster: the fused step kernel is bound by its multiply-add stream, tools/micro/op_rates.hip.)
 template <bool kYaw = false>
 __device__ __forceinline__ void box_gradient(BoxEval& e, const Instance& in) {
-    const float ax = fmaxf(e.qx, 0.0f), ay = fmaxf(e.qy, 0.0f), az = fmaxf(e.qz, 0.0f);
     const float inv = fast_rcp(e.nrm);
-    const float inside = (e.qmax < 0.0f) ? 1.0f : 0.0f;
-    e.hx = ax * inv + ((e.arg == 0) ? inside : 0.0f);
-    e.hy = ay * inv + ((e.arg == 1) ? inside : 0.0f);
-    e.hz = az * inv + ((e.arg == 2) ? inside : 0.0f);
-    e.glx = times_sign(e.hx, e.px); e.gly = times_sign(e.hy, e.py); e.glz = times_sign(e.hz, e.pz);
+    const bool inside = e.qmax < 0.0f;
+    const bool first_x = e.qx == e.qmax;
+    const bool first_y = !first_x && (e.qy == e.qmax);
+    const bool one_x = inside && first_x, one_y = inside && first_y, one_z = inside && !first_x && !first_y;
+    const float tx = fmaxf(e.qx, 0.0f) * inv, ty = fmaxf(e.qy, 0.0f) * inv, tz = fmaxf(e.qz, 0.0f) * inv;
+    e.hx = one_x ? 1.0f : tx; e.hy = one_y ? 1.0f : ty; e.hz = one_z ? 1.0f : tz;      // (only the adjoint uses h itself)
+    e.glx = __builtin_copysignf((one_x && e.px != 0.0f) ? 1.0f : tx, e.px);
+    e.gly = __builtin_copysignf((one_y && e.py != 0.0f) ? 1.0f : ty, e.py);
+    e.glz = __builtin_copysignf((one_z && e.pz != 0.0f) ? 1.0f : tz, e.pz);
     rotate_to_world<kYaw>(e, in);
 }
 
