@@ -17,6 +17,8 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o bench -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline $* > "$OUT/pmc_write_stdout.log" 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SMEM SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES \
   --kernel-trace --output-format csv -d "$OUT/pmc_lds" -o bench -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline $* > "$OUT/pmc_lds_stdout.log" 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS \
+  --kernel-trace --output-format csv -d "$OUT/pmc_mix" -o bench -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline $* > "$OUT/pmc_mix_stdout.log" 2>&1
 cd "$ROOT"
 for f in "$OUT"/*_stdout.log; do echo "== $f"; tail -n 4 "$f" | cut -c1-600; done
 find "$OUT" -type f | head -60

@@ -55,7 +55,7 @@ def main():
         out.write("# rocprofv3 --pmc passes (one counter group per pass); values are per dispatch, summed over the chip.\n"
                   "# FETCH_SIZE / WRITE_SIZE are in KiB (rocprofv3 derived metrics); MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half\n"
                   "# the bytes of a wide coalesced read stream (uncalibrated for narrow accesses) -- treat as a lower bound.\n")
-        for sub in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write"):
+        for sub in ("pmc_sq", "pmc_lds", "pmc_mix", "pmc_fetch", "pmc_write"):
             path = os.path.join(src, sub, "bench_counter_collection.csv")
             if os.path.exists(path):
                 out.write(f"\n## {sub}\n")
