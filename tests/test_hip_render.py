@@ -686,3 +686,61 @@ def test_shadow_rendering(dev):
     inside = (xs.abs() < 0.95)
     outside = (xs.abs() > 1.05)
     assert bool(shadow[inside, 0].all()) and not bool(shadow[outside, 0].any())
+
+
+def _random_scene(seed, N, R, S, general_rotations=True, scale=1.0):
+    """Boxes in front of a camera at the origin with arbitrary (not about-y) rotations, rays aimed near them."""
+    g = torch.Generator().manual_seed(seed)
+    loc = torch.stack([torch.empty(N).uniform_(-6, 6, generator=g), torch.empty(N).uniform_(-1.0, 1.5, generator=g),
+                       torch.empty(N).uniform_(8, 30, generator=g)], -1)
+    dim = torch.stack([torch.empty(N).uniform_(0.75, 1.0, generator=g), torch.empty(N).uniform_(0.75, 1.0, generator=g),
+                       torch.empty(N).uniform_(1.5, 2.5, generator=g)], -1)
+    if general_rotations:
+        q, r = torch.linalg.qr(torch.randn(N, 3, 3, generator=g, dtype=torch.float64))
+        q = q * torch.sign(torch.diagonal(r, dim1=-2, dim2=-1)).unsqueeze(-2)
+        q[:, :, 0] *= torch.sign(torch.linalg.det(q)).unsqueeze(-1)                # proper rotations
+        rot = q.float()
+    else:
+        yaw = torch.empty(N).uniform_(-3.1, 3.1, generator=g)
+        rot = torch.stack([torch.stack([torch.cos(yaw), torch.zeros(N), torch.sin(yaw)], -1), torch.tensor([0.0, 1.0, 0.0]).expand(N, 3),
+                           torch.stack([-torch.sin(yaw), torch.zeros(N), torch.cos(yaw)], -1)], -2)
+    rot = rot * scale
+    target = loc[torch.randint(0, N, (R,), generator=g)] + torch.randn(R, 3, generator=g) * 0.7
+    directions = torch.nn.functional.normalize(target, dim=-1)
+    return dict(loc=loc, dim=dim, rot=rot, origins=torch.zeros(R, 3), directions=directions, u_coarse=torch.rand(R, S, generator=g),
+                u_fine=torch.rand(R, S, generator=g), targets=torch.rand(R, N, generator=g))
+
+
+@pytest.mark.parametrize("case", ["general_rotations", "scaled_rotations_no_bounds", "tiny_temperature_running_minimum"])
+def test_paths_the_kernel_selects_by_itself_match_the_oracle(dev, case):
+    """The kernels pick their instance-loop variants from the field: shortened products for rotations about y, culling and the
+    soft-min floor only for orthonormal rotations, the floor only while max|dim| / T <= 50.  The goldens (the reference's
+    rotation_matrix_y boxes at its schedule's temperatures) exercise one combination; these scenes exercise the others, against
+    the CPU oracle on the same uniforms: arbitrary rotations; rotations scaled by 1.01 (not orthonormal to 1e-4: no culling, running
+    minimum); T = 0.02 (running minimum with culling)."""
+    from vsrd_amd import fields, rendering
+    N, S, R = 5, 32, 256
+    sc = _random_scene(11, N, R, S, general_rotations=(case != "tiny_temperature_running_minimum"),
+                       scale=1.01 if case == "scaled_rotations_no_bounds" else 1.0)
+    T, std, ratio = (0.02, 0.3, 0.7) if case == "tiny_temperature_running_minimum" else (0.4, 0.4, 0.4)
+
+    def run(device, hip):
+        l, d, r = (sc[k].clone().to(device).requires_grad_(True) for k in ("loc", "dim", "rot"))
+        if hip:
+            union = fields.soft_union([
+                rendering.sdfs.translation(rendering.sdfs.rotation(fields.instance_field(rendering.sdfs.box(d[i]), i, N), r[i]), l[i])
+                for i in range(N)], T)
+            labels = rendering.render_hierarchical(union, sc["origins"].to(device), sc["directions"].to(device), (0.0, 100.0), S, std, ratio,
+                                                   u_coarse=sc["u_coarse"].to(device), u_fine=sc["u_fine"].to(device))["labels"]
+        else:
+            union = ofields.InstanceUnion(l, r, d, T)
+            labels = orendering.hierarchical_render(union, sc["origins"], sc["directions"], (0.0, 100.0), S, std, ratio,
+                                                    sc["u_coarse"], sc["u_fine"]).labels
+        loss = olosses.silhouette_loss(labels, sc["targets"].to(device))
+        return labels.detach().cpu(), [x.cpu() for x in torch.autograd.grad(loss, [l, d, r])]
+
+    hip_labels, hip_grads = run(dev, True)
+    ref_labels, ref_grads = run(torch.device("cpu"), False)
+    assert (hip_labels - ref_labels).abs().max() < 1e-4
+    for a, b in zip(hip_grads, ref_grads):
+        assert (a - b).abs().max() <= 5e-3 * max(float(b.abs().max()), 1e-6)

@@ -376,6 +376,8 @@ __device__ __forceinline__ void union_accumulate(UnionSums& s, float d, float gw
 
 // Smallest normaliser the fixed-shift sums are trusted with: terms down to e^-18 of it are still normal numbers.
 constexpr float kUnionTinyZ = 1.0e-28f;
+// Largest (upper bound of the smallest distance - floor) / T a round may have to use the floor: the best term is >= e^-60 then.
+constexpr float kUnionFloorSpan = 60.0f;
 
 struct UnionValue {
     float u;            // union distance  sum_i w_i d_i

@@ -106,9 +106,11 @@ __device__ __forceinline__ UnionValue eval_union(const float* __restrict__ insta
     RoundCull cull;
     unsigned long long evaluated = cull_round_mask<true>(rc, num_instances, t, sh.cull, dcache, lane, &cull);
     UnionSums sums;
-    bool running = sh.reach < 0.0f;                                             // wave-uniform
+    // wave-uniform: no floor for this field, or a floor too far below the minimum on some lane (samples extrapolated to 1e6 m,
+    // where the bounds are hundreds of metres wide): such rounds go straight to the running minimum
+    const float floor = cull.nearest_lo - sh.reach;
+    bool running = sh.reach < 0.0f || wave_any(!((cull.nearest_hi + 1.0f - floor) * sh.inv_t <= kUnionFloorSpan));
     if (!running) {
-        const float floor = cull.nearest_lo - sh.reach;
         sums = sh.yaw ? union_loop<kCacheDistances, kResidual, false, true>(instances, mlp, evaluated, sh, cull, floor, x, y, z, dcache, lane, lam)
                       : union_loop<kCacheDistances, kResidual, false, false>(instances, mlp, evaluated, sh, cull, floor, x, y, z, dcache, lane, lam);
         running = wave_any(!(sums.Z >= kUnionTinyZ));                           // the fixed shift underflowed somewhere: repeat the round

@@ -304,9 +304,9 @@ __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, 
         st.near_any[k] = cull_round_mask<kCacheD>(rc, N, mid, sh.cull, dcache, lane, &cull);
         if (kResidual) st.near_rows[k][0] = st.near_rows[k][1] = st.near_rows[k][2] = st.near_rows[k][3] = 0ull;
         UnionSums sums;
-        bool running = sh.reach < 0.0f;                                      // wave-uniform
+        const float floor = cull.nearest_lo - sh.reach;
+        bool running = sh.reach < 0.0f || wave_any(!((cull.nearest_hi + 1.0f - floor) * sh.inv_t <= kUnionFloorSpan));   // wave-uniform (render.h: eval_union)
         if (!running) {
-            const float floor = cull.nearest_lo - sh.reach;
             sums = sh.yaw ? sweep_union_loop<kRounds, kResidual, kCacheD, false, true>(st, k, instances, mlp, N, sh, cull, floor, lam, dcache, lane, rcache)
                           : sweep_union_loop<kRounds, kResidual, kCacheD, false, false>(st, k, instances, mlp, N, sh, cull, floor, lam, dcache, lane, rcache);
             running = wave_any(!(sums.Z >= kUnionTinyZ));                    // the fixed shift underflowed somewhere: repeat the round
