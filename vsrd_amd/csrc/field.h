@@ -48,9 +48,6 @@ struct BoxEval {
 
 __device__ __forceinline__ float sign_of(float v) { return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); }
 
-// sign(p) * h for h >= 0 with torch's sign(0) = 0: one v_bfi (copysign) + compare + select instead of two compares,
-// two selects and a multiply.
-__device__ __forceinline__ float times_sign(float h, float p) { return (p == 0.0f) ? 0.0f : __builtin_copysignf(h, p); }
 
 // First half of the box evaluation: local position and signed distance (what the exact culling test of the render loops needs).
 // kYaw: the rotation is one about the y axis with r01 = r10 = r12 = r21 = 0 and r11 = 1 EXACTLY (what rotation_matrix_y,
