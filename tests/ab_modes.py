@@ -1,5 +1,5 @@
 """A/B of the kernels' run-time switches (culling, soft-min shift, y-rotation fast path) on the golden scenes: labels and gradients
-of every combination against the all-off baseline and against the float64 oracle.  GPU only:  python tools/ab_modes.py"""
+of every combination against the all-off baseline and against the float64 oracle.  GPU only:  python tests/ab_modes.py"""
 import sys, itertools, torch
 sys.path.insert(0, ".")
 sys.path.insert(0, "tests")
