@@ -462,15 +462,18 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
             const float ds = e.d - st.sa[k].m;
             const float w = fast_exp(-ds * inv_t) * st.sa[k].inv_z;
             const float cc = w * (1.0f - (ds - st.sa[k].us) * inv_t);
-            const float beta = st.sa[k].gbx * e.gwx + st.sa[k].gby * e.gwy + st.sa[k].gbz * e.gwz;
+            // g_bar in the instance's frame, R^T g_bar: both beta = g_bar . grad d_i = (R^T g_bar) . gl  and  gl_bar = R^T (cc g_bar) need it,
+            // and the world-frame gradient R gl of this instance is then not needed at all (one rotation per pair instead of two)
+            const float gx_ = st.sa[k].gbx, gy_ = st.sa[k].gby, gz_ = st.sa[k].gbz;
+            const float rgx = kYaw ? fmaf(in.r20, gz_, in.r00 * gx_) : fmaf(in.r20, gz_, fmaf(in.r10, gy_, in.r00 * gx_));
+            const float rgy = kYaw ? gy_ : fmaf(in.r21, gz_, fmaf(in.r11, gy_, in.r01 * gx_));
+            const float rgz = kYaw ? fmaf(in.r22, gz_, in.r02 * gx_) : fmaf(in.r22, gz_, fmaf(in.r12, gy_, in.r02 * gx_));
+            const float beta = rgx * e.glx + rgy * e.gly + rgz * e.glz;
             const float d_bar = st.sa[k].u_bar * cc
                               + inv_t * (-beta * cc + w * st.sa[k].A - beta * w + cc * st.sa[k].B)
                               - inv_t * w * st.sa[k].wgt * (lam_i - st.sa[k].lam_z);
-            const float gwbx = cc * st.sa[k].gbx, gwby = cc * st.sa[k].gby, gwbz = cc * st.sa[k].gbz;
-            // gl_bar_j = sum_k R_kj gw_bar_k
-            const float glbx = kYaw ? fmaf(in.r20, gwbz, in.r00 * gwbx) : fmaf(in.r20, gwbz, fmaf(in.r10, gwby, in.r00 * gwbx));
-            const float glby = kYaw ? gwby : fmaf(in.r21, gwbz, fmaf(in.r11, gwby, in.r01 * gwbx));
-            const float glbz = kYaw ? fmaf(in.r22, gwbz, in.r02 * gwbx) : fmaf(in.r22, gwbz, fmaf(in.r12, gwby, in.r02 * gwbx));
+            const float gwbx = cc * gx_, gwby = cc * gy_, gwbz = cc * gz_;
+            const float glbx = cc * rgx, glby = cc * rgy, glbz = cc * rgz;       // gl_bar_j = sum_k R_kj gw_bar_k
             const float sx = sign_of(e.px), sy = sign_of(e.py), sz = sign_of(e.pz);
             const float vx = sx * glbx, vy = sy * glby, vz = sz * glbz;
             const float inv_n = fast_rcp(e.nrm);
