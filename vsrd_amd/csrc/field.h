@@ -340,8 +340,10 @@ __device__ __forceinline__ UnionSums union_init(bool running = true, float floor
 // ~36 instructions, valid for any inputs.
 // (kRunning is a template parameter, and the callers instantiate their whole instance loop once per value: a run-time branch
 //  inside the loop costs eight register copies per instance where the two paths meet.)
+// Returns the instance's soft-min term exp(-(d - s.m)/T) when the shift is fixed (kRunning = false; with the running minimum the
+// term is relative to a shift that may still move, and the return value is d itself).
 template <bool kRunning = true>
-__device__ __forceinline__ void union_accumulate(UnionSums& s, float d, float gwx, float gwy, float gwz, float lambda, float inv_t) {
+__device__ __forceinline__ float union_accumulate(UnionSums& s, float d, float gwx, float gwy, float gwz, float lambda, float inv_t) {
     if (!kRunning) {
         const float dd = d - s.m;
         const float e = fast_exp(-dd * inv_t);
@@ -350,7 +352,7 @@ __device__ __forceinline__ void union_accumulate(UnionSums& s, float d, float gw
         s.g0x += e * gwx; s.g0y += e * gwy; s.g0z += e * gwz;
         s.g1x += edd * gwx; s.g1y += edd * gwy; s.g1z += edd * gwz;
         s.L += e * lambda;
-        return;
+        return e;
     }
     const bool lower = d < s.m;
     const float gap = lower ? (s.m - d) : (d - s.m);           // >= 0
@@ -369,6 +371,7 @@ __device__ __forceinline__ void union_accumulate(UnionSums& s, float d, float gw
     s.L = scale * s.L + e * lambda;
     s.Z = scale * s.Z + e;
     s.m = lower ? d : s.m;
+    return d;
 }
 
 // Smallest normaliser the fixed-shift sums are trusted with: terms down to e^-18 of it are still normal numbers.

@@ -274,8 +274,9 @@ __device__ __forceinline__ UnionSums sweep_union_loop(RayAdjoint<kRounds>& st, i
             add_residual<kYaw>(e, in, res);
             if (rcache) rcache[(k * N + i) * kWave + lane] = make_float4(res.value, res.gx, res.gy, res.gz);
         }
-        if (kCacheD) dcache[i * kWave + lane] = e.d;
-        union_accumulate<kRunning>(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, sh.inv_t);
+        // the distance cache feeds the label sums of the round: with a fixed shift it can hold the soft-min term itself
+        const float term = union_accumulate<kRunning>(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, sh.inv_t);
+        if (kCacheD) dcache[i * kWave + lane] = term;
     }
     return sums;
 }
@@ -327,10 +328,18 @@ __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, 
         st.sa[k].gbx = v.b0x; st.sa[k].gby = v.b0y; st.sa[k].gbz = v.b0z;
         if (kCacheD && k * kWave < num_points) {
             const float scale = st.sa[k].wgt * v.inv_z;
-            for (unsigned long long todo = st.near_any[k]; todo != 0ull; todo &= todo - 1ull) {
-                const int i = __builtin_ctzll(todo);
-                const float total = wave_sum(fast_exp(-(dcache[i * kWave + lane] - v.m) * inv_t) * scale);
-                label = (lane == i) ? (label + total) : label;
+            if (running) {                                                   // the cache holds distances
+                for (unsigned long long todo = st.near_any[k]; todo != 0ull; todo &= todo - 1ull) {
+                    const int i = __builtin_ctzll(todo);
+                    const float total = wave_sum(fast_exp(-(dcache[i * kWave + lane] - v.m) * inv_t) * scale);
+                    label = (lane == i) ? (label + total) : label;
+                }
+            } else {                                                         // the cache holds exp(-(d_i - m)/T) (sweep_union_loop)
+                for (unsigned long long todo = st.near_any[k]; todo != 0ull; todo &= todo - 1ull) {
+                    const int i = __builtin_ctzll(todo);
+                    const float total = wave_sum(dcache[i * kWave + lane] * scale);
+                    label = (lane == i) ? (label + total) : label;
+                }
             }
         }
     }
