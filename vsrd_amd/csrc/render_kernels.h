@@ -249,6 +249,7 @@ struct RayAdjoint {
     // (residual fields).  The later phases read these instead of repeating the bound test per instance and round.
     unsigned long long near_any[kRounds];
     unsigned long long near_rows[kRounds][4];
+    bool last_running;       // the last round's soft-min used the running minimum: its cache rows hold distances, not soft-min terms
 };
 
 // The instance loop of the forward sweep for round k (render.h: union_loop, plus what the adjoint keeps: the 16-lane row masks and
@@ -328,6 +329,7 @@ __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, 
         st.sa[k].gbx = v.b0x; st.sa[k].gby = v.b0y; st.sa[k].gbz = v.b0z;
         if (kCacheD && k * kWave < num_points) {
             const float scale = st.sa[k].wgt * v.inv_z;
+            if (k == kRounds - 1) st.last_running = running;
             if (running) {                                                   // the cache holds distances
                 for (unsigned long long todo = st.near_any[k]; todo != 0ull; todo &= todo - 1ull) {
                     const int i = __builtin_ctzll(todo);
@@ -402,23 +404,38 @@ __device__ __forceinline__ bool adjoint_reverse_sweep(RayAdjoint<kRounds>& st, c
     return __ballot(any_flow) != 0ull;
 }
 
-// Label-adjoint mix of the fused step kernels: Lambda_s = sum_n lambda_n w_{s,n} for the samples of every round, from box distances
-// that are re-evaluated (value only, ~30 instructions) instead of keeping every round's [N][64] distance cache in LDS, which would
-// halve the occupancy of render_silhouette_kernel; residual fields add the residual value the sweep left in its jet cache.
+// Label-adjoint mix of the fused step kernels: Lambda_s = sum_n lambda_n w_{s,n} for the samples of every round.  The last round's
+// soft-min terms are still in the wave's distance cache; for the earlier rounds the box distances are re-evaluated (value only,
+// ~30 instructions) instead of keeping every round's [N][64] cache in LDS, which would cost render_silhouette_kernel a workgroup
+// per CU; residual fields add the residual value the sweep left in its jet cache.
 template <int kRounds, bool kResidual, bool kYaw>
 __device__ __forceinline__ void adjoint_label_mix(RayAdjoint<kRounds>& st, const float* __restrict__ instances, int N, float inv_t, int num_points,
-                                                  const float* lam, int lane, const float4* rcache) {
+                                                  const float* lam, int lane, const float4* rcache, const float* dcache) {
 #pragma unroll
     for (int k = 0; k < kRounds; ++k) {
         if (k * kWave >= num_points) continue;
         float acc = 0.0f;
-        for (unsigned long long todo = st.near_any[k]; todo != 0ull; todo &= todo - 1ull) {   // the instances the forward sweep evaluated
-            const int i = __builtin_ctzll(todo);
-            if (lam[i] == 0.0f) continue;                               // wave-uniform
-            const Instance in = load_instance(instances, i);
-            float d = box_value<kYaw>(in, st.sa[k].x, st.sa[k].y, st.sa[k].z).d;
-            if (kResidual) d += rcache[(k * N + i) * kWave + lane].x;
-            acc += lam[i] * fast_exp(-(d - st.sa[k].m) * inv_t);
+        if (k == kRounds - 1) {
+            if (st.last_running) {
+                for (unsigned long long todo = st.near_any[k]; todo != 0ull; todo &= todo - 1ull) {
+                    const int i = __builtin_ctzll(todo);
+                    if (lam[i] != 0.0f) acc += lam[i] * fast_exp(-(dcache[i * kWave + lane] - st.sa[k].m) * inv_t);
+                }
+            } else {
+                for (unsigned long long todo = st.near_any[k]; todo != 0ull; todo &= todo - 1ull) {
+                    const int i = __builtin_ctzll(todo);
+                    acc += lam[i] * dcache[i * kWave + lane];
+                }
+            }
+        } else {
+            for (unsigned long long todo = st.near_any[k]; todo != 0ull; todo &= todo - 1ull) {   // the instances the forward sweep evaluated
+                const int i = __builtin_ctzll(todo);
+                if (lam[i] == 0.0f) continue;                               // wave-uniform
+                const Instance in = load_instance(instances, i);
+                float d = box_value<kYaw>(in, st.sa[k].x, st.sa[k].y, st.sa[k].z).d;
+                if (kResidual) d += rcache[(k * N + i) * kWave + lane].x;
+                acc += lam[i] * fast_exp(-(d - st.sa[k].m) * inv_t);
+            }
         }
         st.sa[k].lam_z = acc * st.sa[k].inv_z;
     }
@@ -702,8 +719,8 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
         if (!rendered || wave_max(fabsf(lam_lane)) == 0.0f) continue;
         if (lane < N) lam[lane] = lam_lane;
         wave_lds_sync();
-        if (sh.yaw) adjoint_label_mix<kRounds, false, true>(st, instances, N, sh.inv_t, num_points, lam, lane, nullptr);
-        else adjoint_label_mix<kRounds, false, false>(st, instances, N, sh.inv_t, num_points, lam, lane, nullptr);
+        if (sh.yaw) adjoint_label_mix<kRounds, false, true>(st, instances, N, sh.inv_t, num_points, lam, lane, nullptr, l.dcache);
+        else adjoint_label_mix<kRounds, false, false>(st, instances, N, sh.inv_t, num_points, lam, lane, nullptr, l.dcache);
         if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, nullptr, nullptr, lane)) continue;
         if (sh.yaw) adjoint_phase_b<kRounds, false, true>(st, instances, nullptr, N, f.inv_t, num_points, lam, G, lane, nullptr, nullptr, nullptr);
         else adjoint_phase_b<kRounds, false, false>(st, instances, nullptr, N, f.inv_t, num_points, lam, G, lane, nullptr, nullptr, nullptr);
@@ -797,8 +814,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_residual_step_kernel(
                 const float norm = fast_sqrt(st.gx[k] * st.gx[k] + st.gy[k] * st.gy[k] + st.gz[k] * st.gz[k]);
                 eikonal_acc += (k * kWave + lane < num_points) ? (norm - 1.0f) * (norm - 1.0f) : 0.0f;
             }
-            if (sh.yaw) adjoint_label_mix<kRounds, true, true>(st, instances, N, sh.inv_t, num_points, lam, lane, rcache);
-            else adjoint_label_mix<kRounds, true, false>(st, instances, N, sh.inv_t, num_points, lam, lane, rcache);
+            if (sh.yaw) adjoint_label_mix<kRounds, true, true>(st, instances, N, sh.inv_t, num_points, lam, lane, rcache, l.dcache);
+            else adjoint_label_mix<kRounds, true, false>(st, instances, N, sh.inv_t, num_points, lam, lane, rcache, l.dcache);
             if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, nullptr, nullptr, lane, eikonal_scale)) continue;
             if (sh.yaw) adjoint_phase_b<kRounds, true, true>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, ray_seeds, ray_masks);
             else adjoint_phase_b<kRounds, true, false>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, ray_seeds, ray_masks);
