@@ -120,8 +120,6 @@ __device__ __forceinline__ BoxEval eval_box(const Instance& in, float x, float y
     return e;
 }
 
-// Box (+ optional residual MLP) evaluation of instance i: d_i = box(p) + residual(p), local gradient likewise
-// (scripts/main.py:451-458).  `mlp` is the wave-uniform weight row of the instance.
 // d_i = box(p) + residual(p), local gradient likewise (scripts/main.py:451-458).
 template <bool kYaw = false>
 __device__ __forceinline__ void add_residual(BoxEval& e, const Instance& in, const Residual& r) {
@@ -152,7 +150,7 @@ __device__ __forceinline__ BoxEval eval_instance(const Instance& in, const float
 // (a box lies inside its circumscribed sphere and contains its centre; k = 2e-4 absorbs rotation matrices that are
 // orthonormal only to ~1e-4).  When LB_i - UB > tau T on EVERY lane of the wave the instance is skipped for that round:
 // with tau = 18 its weight is below exp(-18) = 1.5e-8 < 2^-24, i.e. below half an ulp of the soft-min normaliser.
-// The decision is wave-uniform (one ballot), so a skipped instance costs ~14 instructions instead of ~120.
+// The decision is wave-uniform (one ballot), so a skipped instance costs six instructions instead of ~75.
 // Second, exact stage (render loops): an instance that passes the bound test gets its box distance evaluated (value only, ~30
 // instructions); if  d_i - min(UB, smallest box distance among the instances evaluated before it) > tau T  on every lane -- the same
 // criterion with an exact left-hand side -- the instance is dropped for the round before its gradient, its residual MLP, its
