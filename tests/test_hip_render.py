@@ -744,3 +744,54 @@ def test_paths_the_kernel_selects_by_itself_match_the_oracle(dev, case):
     assert (hip_labels - ref_labels).abs().max() < 1e-4
     for a, b in zip(hip_grads, ref_grads):
         assert (a - b).abs().max() <= 5e-3 * max(float(b.abs().max()), 1e-6)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_culling_bounds_hold_far_from_the_benchmark_scene(dev, seed):
+    """The culling bounds are compared in squares with an error term for the quadratic form along the ray; these scenes stress
+    what that term has to cover: camera far from the world origin, directions that are not unit vectors, boxes from 0.2 to 30 m,
+    one to 64 instances, temperatures from 0.05 to 2.  Default kernels against every-instance / running-minimum / general-rotation
+    kernels (a wrong bound would drop an instance that matters)."""
+    from vsrd_amd import fields, rendering
+    from vsrd_amd.rendering import renderers
+    g = torch.Generator().manual_seed(100 + seed)
+    N = [1, 2, 5, 16, 33, 64, 7, 12][seed]
+    S, R = [8, 33, 64, 64, 32, 16, 100, 64][seed], 96
+    T = [0.05, 0.1, 0.3, 0.55, 1.0, 2.0, 0.2, 0.8][seed]
+    offset = torch.tensor([[0.0, 0.0, 0.0], [5.0e3, -2.0e3, 1.0e3], [0.0, 0.0, 0.0], [300.0, 10.0, -40.0],
+                           [0.0, 0.0, 0.0], [-1.0e3, 0.0, 0.0], [40.0, 2.0, 7.0], [0.0, 0.0, 0.0]][seed])
+    scale = [1.0, 1.0, 3.0, 0.5, 1.0, 2.0, 1.0, 0.1][seed]                 # |direction|
+    loc = torch.stack([torch.empty(N).uniform_(-20, 20, generator=g), torch.empty(N).uniform_(-2, 3, generator=g),
+                       torch.empty(N).uniform_(4, 90, generator=g)], -1) / scale + offset
+    dim = torch.exp(torch.empty(N, 3).uniform_(-1.6, 3.4 if seed % 3 == 0 else 1.0, generator=g)) / scale
+    yaw = torch.empty(N).uniform_(-3.1, 3.1, generator=g)
+    rot = torch.stack([torch.stack([torch.cos(yaw), torch.zeros(N), torch.sin(yaw)], -1), torch.tensor([0.0, 1.0, 0.0]).expand(N, 3),
+                       torch.stack([-torch.sin(yaw), torch.zeros(N), torch.cos(yaw)], -1)], -2)
+    aim = loc[torch.randint(0, N, (R,), generator=g)] - offset + torch.randn(R, 3, generator=g) * 2.0 / scale
+    directions = torch.nn.functional.normalize(aim, dim=-1) * scale
+    origins = offset.expand(R, 3).contiguous()
+    u_coarse, u_fine = torch.rand(R, S, generator=g), torch.rand(R, S, generator=g)
+    lam = torch.randn(R, N, generator=g)
+    results = {}
+    modes = {"default": (True, False, False), "culling": (True, True, True), "baseline": (False, True, True)}
+    for mode, (culling, running, general) in modes.items():
+        renderers.CULLING, renderers.RUNNING_MINIMUM, renderers.GENERAL_ROTATIONS = culling, running, general
+        try:
+            l, d, r = (t.clone().to(dev).requires_grad_(True) for t in (loc, dim, rot))
+            union = fields.soft_union([
+                rendering.sdfs.translation(rendering.sdfs.rotation(fields.instance_field(rendering.sdfs.box(d[i]), i, N), r[i]), l[i])
+                for i in range(N)], T)
+            out = rendering.render_hierarchical(union, origins.to(dev), directions.to(dev), (0.0, 100.0 / scale), S, max(T, 0.1), 0.5,
+                                                u_coarse=u_coarse.to(dev), u_fine=u_fine.to(dev))
+            results[mode] = (out["labels"].detach(), torch.autograd.grad((out["labels"] * lam.to(dev)).sum(), (l, d, r)))
+        finally:
+            renderers.CULLING, renderers.RUNNING_MINIMUM, renderers.GENERAL_ROTATIONS = True, False, False
+    assert torch.isfinite(results["default"][0]).all()
+    # culling alone leaves the arithmetic of the surviving terms untouched: tight.  The soft-min floor and the shortened rotations
+    # change roundings, which the importance sampler (a division by cdf differences) amplifies on ill-conditioned rays: the
+    # parity tolerance of the path.
+    for mode, label_tolerance, gradient_tolerance in (("culling", 2e-6, 2e-4), ("default", 1e-4, 5e-3)):
+        assert (results[mode][0] - results["baseline"][0]).abs().max() < label_tolerance, mode
+        for a, b in zip(results[mode][1], results["baseline"][1]):
+            assert torch.isfinite(a).all()
+            assert (a - b).abs().max() <= gradient_tolerance * max(float(b.abs().max()), 1e-6), mode
