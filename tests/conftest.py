@@ -33,5 +33,10 @@ RENDER_CASES = [
     "g4_render_n3_s20_mid",
     "g4_render_n16_s64_mid",
     "g4_render_n1_s32_late",
+    "g17_render_n64_s128_mid",              # BASELINE config 5 shape: 4 wave rounds in pass 2, 64 instances
 ]
-RESIDUAL_CASES = ["g10_render_residual_n3_s16"]
+RESIDUAL_CASES = [
+    "g10_render_residual_n3_s16",
+    "g17_render_residual_n16_s64_mid",      # BASELINE config 3 shape: 2 wave rounds, 16 instances
+    "g17_render_residual_n4_s100_late",     # the reference's own num_fine_samples: 4 wave rounds (199 points)
+]

@@ -240,7 +240,7 @@ def build_rays(height, width, rows, cols, extrinsic=None):
 
 
 def render_case(ref, name, num_instances, num_samples, temperature, std, cosine_ratio, seed,
-                with_residual=False, eikonal_weight=0.0, z_range=(8.0, 40.0), ray_grid=(12, 20)):
+                with_residual=False, eikonal_weight=0.0, z_range=(8.0, 40.0), ray_grid=(12, 20), row_range=None, split_gradients=False):
     g = torch.Generator().manual_seed(seed)
     loc, dims, rot = scene_instances(num_instances, g, z_range=z_range)
     loc = loc.clone().requires_grad_(True)
@@ -248,7 +248,7 @@ def render_case(ref, name, num_instances, num_samples, temperature, std, cosine_
     rot = rot.clone().requires_grad_(True)
 
     H, W = 128, 128
-    rows = torch.linspace(0, H - 1, ray_grid[0]).long()
+    rows = torch.linspace(*(row_range or (0, H - 1)), ray_grid[0]).long()
     cols = torch.linspace(0, W - 1, ray_grid[1]).long()
     origins, directions = build_rays(H, W, rows, cols)
     num_rays = origins.shape[0]
@@ -305,7 +305,7 @@ def render_case(ref, name, num_instances, num_samples, temperature, std, cosine_
         torch.norm(f_grads[:, conditioned], dim=-1), f_grads.new_ones(f_grads[:, conditioned].shape[:-1]))
     loss = bce + eikonal_weight * eikonal_conditioned
     params = [loc, dims, rot] + ([mlp_weights] if with_residual else [])
-    grads = torch.autograd.grad(loss, params)
+    grads = torch.autograd.grad(loss, params, retain_graph=split_gradients)
 
     arrays = dict(
         locations=loc, dimensions=dims, orientations=rot,
@@ -321,6 +321,15 @@ def render_case(ref, name, num_instances, num_samples, temperature, std, cosine_
     )
     if with_residual:
         arrays.update(mlp_weights=mlp_weights, grad_mlp_weights=grads[3])
+    if split_gradients:
+        # the two terms separately: a fused step over the well-conditioned rays alone weighs them differently (means over fewer rays)
+        keys = ["locations", "dimensions", "orientations"] + (["mlp_weights"] if with_residual else [])
+        for tag, term in (("bce", bce), ("eikonal", eikonal_conditioned)):
+            if term.grad_fn is None:
+                continue
+            for key, value in zip(keys, torch.autograd.grad(term, params, retain_graph=True, allow_unused=True)):
+                arrays[f"grad_{tag}_{key}"] = torch.zeros_like(params[keys.index(key)]) if value is None else value
+        arrays["conditioned"] = conditioned
     hit = int((f_labels.sum(-1) > 1e-3).sum())
     miss = int((c_weights.sum(0)[..., 0] == 0).sum())
     print(f"  {name}: rays={num_rays} hit={hit} exact-miss={miss} loss={float(loss):.6f}")
@@ -341,6 +350,18 @@ def golden_rendering(ref):
     # G10: residual MLP enabled (C3-like, tiny)
     render_case(ref, "g10_render_residual_n3_s16", 3, 16, 0.4, 0.3, 0.6, seed=106, with_residual=True,
                 eikonal_weight=0.01, ray_grid=(5, 8), z_range=(6.0, 20.0))
+
+
+def golden_rendering_bench_shapes(ref):
+    """G17: the shapes bench.py times (VERDICT r01 "parity gaps"): BASELINE config 3 (N=16, S=64, residual MLP) runs
+    render_residual_step_kernel<2>, config 5 (N=64, S=128, box-only) runs render_silhouette_kernel<4>, and a residual field with
+    S in (64, 128] runs the <4> instantiations of the residual kernels.  A few dozen rays through the objects suffice."""
+    render_case(ref, "g17_render_residual_n16_s64_mid", 16, 64, 0.55, 0.55, 0.5, seed=107, with_residual=True, eikonal_weight=0.01,
+                ray_grid=(5, 8), row_range=(70, 112), z_range=(8.0, 60.0), split_gradients=True)
+    render_case(ref, "g17_render_n64_s128_mid", 64, 128, 0.55, 0.55, 0.5, seed=108, ray_grid=(5, 8), row_range=(70, 112),
+                z_range=(8.0, 60.0), split_gradients=True)
+    render_case(ref, "g17_render_residual_n4_s100_late", 4, 100, 0.2, 0.2, 0.8, seed=109, with_residual=True, eikonal_weight=0.01,
+                ray_grid=(5, 8), row_range=(70, 112), z_range=(6.0, 25.0), split_gradients=True)
 
 
 # ---------------------------------------------------------------------------
@@ -589,6 +610,10 @@ def golden_rendering_helpers(ref):
 def main():
     torch.set_num_threads(4)
     ref = import_reference()
+    if "--bench-shapes" in sys.argv:       # only the G17 files (the others are unchanged since round 1)
+        golden_rendering_bench_shapes(ref)
+        return
+    golden_rendering_bench_shapes(ref)
     golden_rendering_helpers(ref)
     golden_hypernetwork(ref)
     golden_box_3d_iou(ref)

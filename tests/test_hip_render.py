@@ -96,9 +96,12 @@ def test_field_eval_g3(dev, temperature, tag):
     torch.testing.assert_close(grad.cpu(), g[f"union_{tag}_gradients"], rtol=1e-4, atol=5e-5)
     # a single translated/rotated box called directly, and the hard union
     from vsrd_amd import fields
-    single = union.distance_fields[2]
-    d = rendering.evaluate_field(single, g["points"].to(dev))
+    single = union.distance_fields[2]      # a labelled member returns (distances, one-hot feature) like main.py's instance_field
+    d, feature = rendering.evaluate_field(single, g["points"].to(dev))
     torch.testing.assert_close(d.cpu(), g["instance_distances"][2], rtol=1e-6, atol=3e-6)
+    assert feature.shape == (g["points"].shape[0], 4) and feature.dtype == torch.int64 and bool((feature == torch.tensor([0, 0, 1, 0], device=dev)).all())
+    bare = rendering.evaluate_field(single.sdf.sdf.distance_field, g["points"].to(dev))      # sdfs.box alone: distances only
+    assert isinstance(bare, torch.Tensor) and bare.shape == (g["points"].shape[0], 1)
     hard = rendering.evaluate_field(fields.hard_union(union.distance_fields), g["points"].to(dev))
     torch.testing.assert_close(hard.cpu(), g["instance_distances"].min(0).values, rtol=1e-6, atol=3e-6)
 
@@ -513,7 +516,8 @@ def test_sphere_tracing_and_surface_normal_g9(dev):
     assert torch.equal(conv2.reshape(-1, 1).cpu(), g["convergence_masks"])
 
 
-@pytest.mark.parametrize("name", ["g4_render_n4_s32_mid", "g4_render_n16_s64_mid", "g4_render_n4_s32_late", "g4_render_n3_s20_mid"])
+@pytest.mark.parametrize("name", ["g4_render_n4_s32_mid", "g4_render_n16_s64_mid", "g4_render_n4_s32_late", "g4_render_n3_s20_mid",
+                                  "g17_render_n64_s128_mid"])     # the last one: BASELINE config 5's shape, render_silhouette_kernel<4>
 def test_fused_silhouette_step_matches_two_launch_path_and_golden(dev, name):
     """vsrd_render_silhouette_step (render + BCE + adjoint in one launch) against the reference's loss / gradients (golden, cases
     without an eikonal term) and against the two-launch path with torch's BCE, including a Hungarian-style column permutation."""
@@ -668,6 +672,42 @@ def test_fused_residual_step_matches_two_launch_path(dev, name):
         torch.testing.assert_close(loss.detach(), (silhouette + eikonal_ratio * eikonal).detach(), rtol=1e-5, atol=1e-7)
         for a, b in zip(grads, torch.autograd.grad(silhouette + eikonal_ratio * eikonal, reference)):
             assert (a - b).abs().max() <= 2e-4 * max(float(b.abs().max()), 1e-6)
+
+
+@pytest.mark.parametrize("name", [n for n in RESIDUAL_CASES if n.startswith("g17")])
+def test_fused_residual_step_golden(dev, name):
+    """vsrd_render_residual_step at the shapes the benchmark times (BASELINE config 3: N = 16, S = 64 ->
+    render_residual_step_kernel<2>; S = 100 -> <4>) against the REFERENCE's outputs: silhouettes, loss terms, and the gradients
+    w.r.t. box parameters and per-instance MLP weights.  The launch takes the well-conditioned rays (no 1e6 m extrapolation); on
+    those the step's loss is  mean BCE over R_c rays + ratio * eikonal, and the golden's two gradient terms (taken separately by
+    the generator) combine to  (R / R_c) grad_bce + ratio * grad_eikonal  -- the dropped rays have clamped (zero) labels, whose
+    BCE gradient is exactly zero."""
+    from vsrd_amd import fields, rendering
+    g = load_golden(name)
+    S, N = int(g["num_samples"]), g["locations"].shape[0]
+    std, ratio = float(g["sdf_std_deviation"]), float(g["cosine_ratio"])
+    keep = g["conditioned"].reshape(-1)
+    R, Rc = keep.numel(), int(keep.sum())
+    assert Rc >= 12 and float(g["fine_labels"][~keep].abs().max() if Rc < R else 0.0) < 1.0e-6
+    eikonal_ratio = float(g["eikonal_weight"])
+    loc, dim, rot, mlp = (g[k].clone().to(dev).requires_grad_(True) for k in ("locations", "dimensions", "orientations", "mlp_weights"))
+    union = fields.soft_union([
+        rendering.sdfs.translation(rendering.sdfs.rotation(fields.instance_field(
+            fields.residual_composition(rendering.sdfs.box(dim[i]), fields.ResidualField(mlp[i])), i, N), rot[i]), loc[i])
+        for i in range(N)], float(g["temperature"]))
+    loss, terms, labels = rendering.silhouette_step(union, g["origins"][keep].to(dev), g["directions"][keep].to(dev), g["targets"][keep].to(dev),
+                                                    (0.0, 100.0), S, std, ratio, u_coarse=g["u_coarse"][keep].to(dev), u_fine=g["u_fine"][keep].to(dev),
+                                                    eikonal_ratio=eikonal_ratio, return_terms=True, return_labels=True)
+    assert (labels.cpu() - g["fine_labels"][keep]).abs().max() < LABEL_TOL
+    want_bce = torch.nn.functional.binary_cross_entropy(g["fine_labels"][keep].clamp(1.0e-6, 1.0 - 1.0e-6), g["targets"][keep], reduction="none").mean()
+    torch.testing.assert_close(terms[0].cpu(), want_bce, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(terms[1].cpu(), g["eikonal_conditioned"], rtol=1e-2, atol=5e-6)
+    grads = torch.autograd.grad(loss, [loc, dim, rot, mlp])
+    for got, key in zip(grads, ("locations", "dimensions", "orientations", "mlp_weights")):
+        want = (R / Rc) * g["grad_bce_" + key] + eikonal_ratio * g["grad_eikonal_" + key]
+        err = (got.cpu() - want).abs().max().item() / max(float(want.abs().max()), 1e-6)
+        print(f"[fused residual step vs reference] {name} {key}: rel err {err:.3e}")
+        assert err < GRAD_TOL, f"{key}: relative error {err:.3e}"
 
 
 def test_shadow_rendering(dev):

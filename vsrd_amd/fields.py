@@ -176,7 +176,8 @@ def _as_soft_union(field):
 
 
 def _unwrap_instance(field):
-    """One union member -> (location, rotation, dimension, mlp_weights, instance_label)."""
+    """One union member -> (location, rotation, dimension, mlp_weights, instance_label, num_labels); ``num_labels`` is the width of
+    the member's one-hot feature (main.py:470: ``num_instances`` of the enclosing train()), None when the member has no label."""
     location = rotation = None
     node = field
     while True:
@@ -192,13 +193,13 @@ def _unwrap_instance(field):
             rotation, node = node.rotation_matrix, node.sdf
         else:
             break
-    label = None
+    label = num_labels = None
     if isinstance(node, InstanceField):
-        label, node = node.instance_label, node.distance_field
+        label, num_labels, node = node.instance_label, node.num_instances, node.distance_field
     else:
         free = _closure_vars(node)
         if "instance_label" in free and "distance_field" in free:     # main.py:460 instance_field.wrapper
-            label, node = free["instance_label"], free["distance_field"]
+            label, num_labels, node = free["instance_label"], free.get("num_instances"), free["distance_field"]
     mlp = None
     if isinstance(node, ResidualComposition):
         residual, node = node.residual_distance_field, node.distance_field
@@ -214,7 +215,17 @@ def _unwrap_instance(field):
         location = torch.zeros_like(dimension)
     if rotation is None:
         rotation = torch.eye(3, dtype=dimension.dtype, device=dimension.device)
-    return location, rotation, dimension, mlp, label
+    return location, rotation, dimension, mlp, label, num_labels
+
+
+def member_label(field):
+    """(instance_label, num_labels) of a single union member called on its own, as the reference's soft_union does with every
+    member (main.py:480-483): the member returns ``(distances, one_hot(instance_label, num_instances))``.  (None, None) for
+    anything that is not a labelled single instance."""
+    if not isinstance(field, (Translation, Rotation, InstanceField)):
+        return None, None
+    *_, label, num_labels = _unwrap_instance(field)
+    return (label, num_labels) if (label is not None and num_labels) else (None, None)
 
 
 def _residual_weights(residual):

@@ -104,5 +104,23 @@ class HyperDistanceField(nn.Module):
         blocks.append(nn.Sequential(nn.utils.weight_norm(nn.Linear(widths[-1], sum(self.num_neurons_list)))))
         self.hypernetwork = nn.Sequential(*blocks)
 
+    def distance_field(self, weights, positions):
+        """hyper_distance_field.py:57-73: the per-instance MLP on encoded positions, ``weights [...,1617]`` against
+        ``positions [...,48]`` -> ``[...,1]``.  Layer l > 0 is preceded by LayerNorm (no affine) and exact GELU; every linear is
+        ``W [out, in + 1]`` applied to ``[x; 1]``.
+
+        scripts/main.py:541 binds this method with ``functools.partial(..., weights)`` inside its field closures; the renderer
+        never calls it -- ``fields.flatten`` recovers ``weights`` from the partial and the HIP kernels (csrc/residual.h) evaluate
+        the MLP together with its input Jacobian.  The method itself is plain torch on whatever device its tensors live on,
+        like the rest of this module."""
+        features = positions
+        blocks = torch.split(weights, self.num_neurons_list, dim=-1)
+        for layer, (block, fan_in, fan_out) in enumerate(zip(blocks, self.in_channels_list, self.out_channels_list)):
+            if layer:
+                features = F.gelu(F.layer_norm(features, [fan_in]))
+            block = block.unflatten(-1, (fan_out, fan_in + 1))
+            features = (block[..., :fan_in] @ features.unsqueeze(-1)).squeeze(-1) + block[..., fan_in]
+        return features
+
     def forward(self, embeddings):
         return self.hypernetwork(embeddings)

@@ -21,7 +21,7 @@ import threading
 import torch
 
 from .. import _lib, profiling
-from ..fields import FieldBlock, SoftUnion, flatten, _closure_vars
+from ..fields import FieldBlock, SoftUnion, flatten, member_label, _closure_vars
 
 # Scratch of the adjoint launches (per-wave gradient partials, residual jets / seeds), one set per *workspace scope*: launches inside
 # one scope are assumed to be ordered on one stream; work that runs concurrently on another stream (a second frame being optimised,
@@ -376,14 +376,21 @@ def evaluate_field(distance_field, positions, with_gradients=False, with_labels=
     hard union / plain sdfs -> distances [...,1].  ``with_gradients`` adds the analytic normal [...,3].
     Distances and labels are autograd-connected to the field parameters and to ``positions`` (vsrd_field_eval_backward)."""
     block = flatten(distance_field)
+    one_hot = None
     if with_labels is None:  # the soft union returns (distances, features); plain sdfs / hard unions distances only
         with_labels = (not block.hard) and (isinstance(distance_field, SoftUnion) or "distance_fields" in _closure_vars(distance_field))
+        # a single labelled member (what main.py's soft_union calls N times, main.py:480-483) returns its one-hot feature as well
+        label, num_labels = member_label(distance_field)
+        if label is not None and not with_gradients:
+            one_hot = torch.nn.functional.one_hot(torch.as_tensor(label, dtype=torch.long, device=positions.device), int(num_labels))
     lead = positions.shape[:-1]
     pts = positions.reshape(-1, 3).to(torch.float32).contiguous()
     N = block.num_instances
     distances, labels, gradients = _EvaluateField.apply(block.instances, block.mlp_weights, pts, block.temperature, bool(block.hard),
                                                         bool(with_gradients), bool(with_labels))
     out = [distances.reshape(*lead, 1)]
+    if one_hot is not None:
+        out.append(one_hot.expand(*lead, -1))
     if with_labels:
         out.append(_scatter_labels(labels, block).reshape(*lead, N))
     if with_gradients:
