@@ -291,14 +291,22 @@ def test_residual_field_backward_golden(dev, name):
     gam = torch.randn(gradients.shape, generator=gen) * 0.05
     om = torch.randn(weights.shape, generator=gen) * 0.1
     got = torch.autograd.grad([labels, gradients, weights], [loc, dim, rot, mlp], [lam.to(dev), gam.to(dev), om.to(dev)])
-    l64, d64, r64, m64 = (g[k].double().requires_grad_(True) for k in ("locations", "dimensions", "orientations", "mlp_weights"))
-    ou = ofields.InstanceUnion(l64, r64, d64, float(g["temperature"]), m64)
-    o = orendering.render_given_distances(ou, g["origins"][keep].double(), g["directions"][keep].double(), dist[keep].double(), std, ratio)
-    want = torch.autograd.grad([o.labels, o.gradients, o.weights], [l64, d64, r64, m64], [lam.double(), gam.double(), om.double()])
-    for a, b, key in zip(got, want, ("locations", "dimensions", "orientations", "mlp_weights")):
-        err = (a.cpu().double() - b).abs().max().item() / max(b.abs().max().item(), 1e-9)
-        print(f"[residual f64 oracle] {key}: rel err {err:.3e}")
-        assert err < 2e-3, f"{key}: relative error {err:.3e}"
+    def oracle_vjp(dtype):
+        leaves = [g[k].to(dtype).requires_grad_(True) for k in ("locations", "dimensions", "orientations", "mlp_weights")]
+        ou = ofields.InstanceUnion(leaves[0], leaves[2], leaves[1], float(g["temperature"]), leaves[3])
+        o = orendering.render_given_distances(ou, g["origins"][keep].to(dtype), g["directions"][keep].to(dtype), dist[keep].to(dtype), std, ratio)
+        return torch.autograd.grad([o.labels, o.gradients, o.weights], leaves, [lam.to(dtype), gam.to(dtype), om.to(dtype)])
+
+    # Random adjoints of the SDF gradients weigh every sample, including those that sit on a kink of a box SDF (arg max, relu): at a
+    # sharp schedule the fp32 evaluation of the reference's own formulas then differs from the exact one by several per cent.  The
+    # kernel has to be as close to the float64 answer as fp32 allows: 2e-3, or twice the fp32 oracle's own distance from it.
+    want, want32 = oracle_vjp(torch.float64), oracle_vjp(torch.float32)
+    for a, b, c, key in zip(got, want, want32, ("locations", "dimensions", "orientations", "mlp_weights")):
+        scale = max(b.abs().max().item(), 1e-9)
+        err = (a.cpu().double() - b).abs().max().item() / scale
+        floor = (c.double() - b).abs().max().item() / scale
+        print(f"[residual f64 oracle] {key}: rel err {err:.3e} (fp32 oracle: {floor:.3e})")
+        assert err < max(2e-3, 2.0 * floor), f"{key}: relative error {err:.3e} (fp32 oracle {floor:.3e})"
 
 
 def test_philox_mode_matches_oracle_on_exported_uniforms(dev):

@@ -130,9 +130,10 @@ __global__ __launch_bounds__(kWave) void match_kernel(const float* __restrict__ 
     for (int idx = lane; idx < P * G; idx += kWave) {
         const int p = idx / G, g = idx % G;
         float c = cost_in ? cost_in[idx] : negative_distance_iou(pd_boxes + 4 * p, gt_boxes + 4 * g);
-        // scipy raises on NaN / -inf entries; a kernel cannot, and an unsolved problem would leave the index buffers undefined (they
-        // are used for gathers right after): such entries become "never match" costs, the assignment stays a valid permutation
-        if (!(c == c) || c < -3.0e38f) c = 3.0e38f;
+        // scipy raises on NaN / -inf entries and on an infeasible (+inf) matrix; a kernel cannot, and an unsolved problem would leave
+        // the index buffers undefined (they are used for gathers right after): NaN and +-inf entries become finite "never match"
+        // costs, so the assignment always is a valid permutation (and equals scipy's wherever scipy has one that avoids them)
+        if (!(c == c) || c < -3.0e38f || c > 3.0e38f) c = 3.0e38f;
         cost[transposed ? (g * nc + p) : (p * nc + g)] = static_cast<double>(c);
     }
     __syncthreads();

@@ -24,7 +24,8 @@ struct SampleScratch {                            // device workspace of one sam
     unsigned histogram[kSampleBins];
     unsigned threshold_bin;
     unsigned num_candidates;
-    unsigned pad[2];
+    unsigned overflow;                            // sticky: some call found more candidates than the list holds (the surplus was dropped)
+    unsigned pad;
     float candidate_keys[kSampleCandidates];
     long long candidate_indices[kSampleCandidates];
 };
@@ -40,7 +41,7 @@ __device__ __forceinline__ float race_key(float weight, long long index, unsigne
 
 __global__ __launch_bounds__(256) void sample_clear_kernel(SampleScratch* scratch) {
     for (int i = threadIdx.x; i < kSampleBins; i += blockDim.x) scratch->histogram[i] = 0u;
-    if (threadIdx.x == 0) { scratch->threshold_bin = 0u; scratch->num_candidates = 0u; }
+    if (threadIdx.x == 0) { scratch->threshold_bin = 0u; scratch->num_candidates = 0u; }     // (overflow is sticky: the host clears it)
 }
 
 __global__ __launch_bounds__(256) void keys_histogram_kernel(const float* __restrict__ weights, long long count, unsigned long long seed,
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(256) void collect_kernel(const float* __restrict__ 
         if (key > 0.0f && (__float_as_uint(key) >> 20) >= threshold) {
             const unsigned slot = atomicAdd(&scratch->num_candidates, 1u);
             if (slot < kSampleCandidates) { scratch->candidate_keys[slot] = key; scratch->candidate_indices[slot] = i; }
+            else scratch->overflow = 1u;          // a crowded threshold bin: which candidates were kept depends on the atomic order
         }
     }
 }

@@ -17,13 +17,26 @@ import torch
 def checkpoint_payload(frame_optimizer, step, metrics=None):
     models = {"detector": frame_optimizer.detector.state_dict(),
               "hyper_distance_field": frame_optimizer.hyper_distance_field.state_dict()}
-    return dict(step=step, models=models, optimizer=frame_optimizer.optimizer.state_dict(),
-                scheduler=frame_optimizer.scheduler.state_dict(), metrics=metrics or {})
+    # eager and hipGraph mode write the same layout (FrameOptimizer.optimizer_state_dict / scheduler_state_dict)
+    return dict(step=step, models=models, optimizer=frame_optimizer.optimizer_state_dict(),
+                scheduler=frame_optimizer.scheduler_state_dict(), metrics=metrics or {})
+
+
+def atomic_torch_save(payload, path):
+    """torch.save to ``path`` through a temporary file and os.replace: a process killed mid-write leaves no truncated file that
+    the "skip if the final checkpoint exists" restart guard (main.py:134-136) would take for a finished frame."""
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    temporary = f"{path}.tmp.{os.getpid()}"
+    try:
+        torch.save(payload, temporary)
+        os.replace(temporary, path)
+    finally:
+        if os.path.exists(temporary):
+            os.remove(temporary)
 
 
 def save_checkpoint(path, frame_optimizer, step, metrics=None):
-    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-    torch.save(checkpoint_payload(frame_optimizer, step, metrics), path)
+    atomic_torch_save(checkpoint_payload(frame_optimizer, step, metrics), path)
 
 
 def prediction_record(boxes_3d, boxes_2d, confidences, class_name="car"):

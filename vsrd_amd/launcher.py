@@ -83,8 +83,8 @@ def run_frames(frames: Sequence, optimise: Callable, checkpoint_path: Callable[[
         frame, path = item
         result = optimise(frame)
         if path:
-            os.makedirs(os.path.dirname(path), exist_ok=True)
-            torch.save(result, path)          # utils.Saver.save == torch.save(dict) (vsrd/utils.py:191-198)
+            from .formats import atomic_torch_save
+            atomic_torch_save(result, path)   # utils.Saver.save == torch.save(dict) (vsrd/utils.py:191-198), written atomically
         return frame
 
     if frames_in_flight <= 1:

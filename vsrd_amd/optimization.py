@@ -77,6 +77,11 @@ class FrameOptimizer:
         # per-step scalars on the device (graph mode): step index = Philox counter, (temperature, std, cosine_ratio)
         self.step_tensor = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.schedule = torch.ones(3, dtype=torch.float32, device=self.device)
+        # this frame's own scratch (frames may be optimised concurrently on other streams); freed with the optimizer.  Graph mode
+        # sizes it for the residual phase up front: a captured graph holds the buffer's address
+        self.workspace = rendering.Workspace()
+        if self.graph:
+            self.workspace.reserve(self.device, N, residual=True)
         self._graphs = {}
         self._capture_stream = None
         self._eager_graph_steps = {}
@@ -89,6 +94,11 @@ class FrameOptimizer:
         # the weights are fixed for the frame: the library sampler only visits the pixels that can be drawn at all
         self.positive_pixels = torch.nonzero(self.sampling_weights > 0).flatten()
         self.positive_weights = self.sampling_weights[self.positive_pixels].contiguous()
+        # torch.multinomial(replacement=False) raises when fewer categories than samples have weight; the device sampler would pad
+        # its output with -1 instead (ray_sampling.h), silently: the weights are fixed for the frame, so check once here
+        if int(self.positive_pixels.numel()) < config.num_rays:
+            raise ValueError(f"only {int(self.positive_pixels.numel())} pixels have a positive soft mask, fewer than num_rays = {config.num_rays} "
+                             "(torch.multinomial without replacement raises in the reference as well)")
         self.pixels_per_view = H * W
         self.step_index = 0
 
@@ -163,7 +173,7 @@ class FrameOptimizer:
         return outputs
 
     def _step(self, ray_indices, u_coarse, u_fine, count=True):
-        with rendering.workspace_scope(id(self)):      # this frame's own scratch: frames may be optimised concurrently on other streams
+        with rendering.workspace_scope(self.workspace):
             return self._step_in_scope(ray_indices, u_coarse, u_fine, count)
 
     def _step_in_scope(self, ray_indices, u_coarse, u_fine, count):
@@ -227,3 +237,42 @@ class FrameOptimizer:
     def boxes(self):
         with torch.no_grad():
             return self.detector()
+
+    def close(self):
+        """Drop the captured graphs and the scratch buffers (also happens when the optimizer is garbage-collected)."""
+        self._graphs.clear()
+        self.workspace.release()
+
+    # ---- checkpoint views (scripts/main.py:1109-1121 saves optimizer.state_dict() and scheduler.state_dict()) ----------------
+    def optimizer_state_dict(self):
+        """``optimizer.state_dict()`` in the layout the reference's ``torch.optim.Adam`` loads: float learning rates (graph mode
+        keeps them as device tensors decayed in place), ``initial_lr`` per group as ExponentialLR records it, step counters as
+        host float tensors (capturable Adam keeps them on the device)."""
+        cfg = self.config
+        state = self.optimizer.state_dict()
+        initial = [cfg.learning_rate] * 3 + [cfg.embedding_learning_rate, cfg.hypernetwork_learning_rate]
+        groups = []
+        for group, base in zip(state["param_groups"], initial):
+            group = dict(group)
+            group["lr"] = float(group["lr"])
+            group.setdefault("initial_lr", base)
+            group["capturable"] = False
+            groups.append(group)
+        per_param = {}
+        for index, entry in state["state"].items():
+            entry = dict(entry)
+            if isinstance(entry.get("step"), torch.Tensor):
+                entry["step"] = entry["step"].detach().to("cpu", torch.float32)
+            per_param[index] = entry
+        return dict(state=per_param, param_groups=groups)
+
+    def scheduler_state_dict(self):
+        """``ExponentialLR.state_dict()`` after ``step_index`` steps.  Graph mode has no scheduler object (the rates are decayed on
+        the device inside the captured step): the same dictionary is assembled from the step counter and the device-side rates."""
+        if self.scheduler is not None:
+            return self.scheduler.state_dict()
+        cfg = self.config
+        return {"gamma": cfg.lr_gamma,
+                "base_lrs": [cfg.learning_rate] * 3 + [cfg.embedding_learning_rate, cfg.hypernetwork_learning_rate],
+                "last_epoch": self.step_index, "_step_count": self.step_index + 1, "_is_initial": False,
+                "_get_lr_called_within_step": False, "_last_lr": [float(group["lr"]) for group in self.optimizer.param_groups]}

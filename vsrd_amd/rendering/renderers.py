@@ -23,29 +23,80 @@ import torch
 from .. import _lib, profiling
 from ..fields import FieldBlock, SoftUnion, flatten, member_label, _closure_vars
 
-# Scratch of the adjoint launches (per-wave gradient partials, residual jets / seeds), one set per *workspace scope*: launches inside
-# one scope are assumed to be ordered on one stream; work that runs concurrently on another stream (a second frame being optimised,
-# optimization.py) must use its own scope.
-_workspaces = {}
+class Workspace:
+    """Device scratch of one stream of work: the adjoint launches' per-wave gradient partials / residual jets and seeds
+    (``vsrd_workspace_bytes``) and the ray sampler's counters.  One grow-only buffer per device serves box-only and residual
+    launches alike (the residual layout starts with the box-only one, include/vsrd_hip.h), so a frame that switches phase does not
+    hold two.  Launches that share a Workspace must be ordered on one stream; work that runs concurrently on another stream (a
+    second frame being optimised, optimization.py) uses its own.  The buffers die with the object: a ``FrameOptimizer`` owns one,
+    so a rank working through its shard of frames returns the memory frame by frame (round 1 kept them in a module-global dict
+    keyed by ``id(optimizer)``: ~1.7 GB leaked per frame at N = 16)."""
+
+    def __init__(self):
+        self._adjoint = {}      # device -> uint8 tensor
+        self._sampler = {}      # device -> uint8 tensor
+        self._retired = []      # outgrown buffers that captured graphs may still reference (only kept when asked to)
+        self.keep_outgrown = False
+
+    def adjoint(self, device, num_instances, residual=False):
+        need = _lib.load().vsrd_workspace_bytes(int(num_instances), 1 if residual else 0)
+        buf = self._adjoint.get(device)
+        if buf is None or buf.numel() < need:
+            if buf is not None and self.keep_outgrown:
+                self._retired.append(buf)
+            buf = self._adjoint[device] = torch.empty(need, dtype=torch.uint8, device=device)
+        return buf
+
+    def reserve(self, device, num_instances, residual=True):
+        """Allocate now what the largest later launch will need (a hipGraph captures the buffer's address)."""
+        return self.adjoint(device, num_instances, residual)
+
+    def sampler(self, device):
+        buf = self._sampler.get(device)
+        if buf is None:
+            buf = self._sampler[device] = torch.zeros(_lib.load().vsrd_sample_rays_workspace_bytes(), dtype=torch.uint8, device=device)
+        return buf
+
+    def sampler_overflowed(self, device):
+        """True when some vsrd_sample_rays call on this workspace found more candidate keys than its list holds (4096; the
+        surplus is dropped in atomic order, so the draw is then neither complete nor deterministic).  Reads the sticky flag back
+        (a host synchronisation): call it outside captured regions, e.g. once per frame."""
+        buf = self._sampler.get(device)
+        if buf is None:
+            return False
+        offset = 4 * (4096 + 2)                   # SampleScratch: histogram[4096], threshold_bin, num_candidates, overflow
+        return bool(buf[offset:offset + 4].view(torch.int32).item())
+
+    def nbytes(self):
+        return sum(b.numel() for b in list(self._adjoint.values()) + list(self._sampler.values()) + self._retired)
+
+    def release(self):
+        self._adjoint.clear(); self._sampler.clear(); self._retired.clear()
+
+
+_default_workspace = Workspace()       # launches outside any scope (tests, the API-faithful entry points, bench.py)
 _scope = threading.local()
 
 
 class workspace_scope:
-    """``with workspace_scope(token): ...`` -- the launches inside use scratch buffers private to ``token``."""
+    """``with workspace_scope(workspace): ...`` -- the launches inside use that ``Workspace``'s scratch buffers."""
 
-    def __init__(self, token):
-        self.token = token
+    def __init__(self, workspace):
+        if not isinstance(workspace, Workspace):
+            raise TypeError("workspace_scope expects a rendering.Workspace (the owner of the scratch buffers)")
+        self.workspace = workspace
 
     def __enter__(self):
-        self.previous = getattr(_scope, "token", None)
-        _scope.token = self.token
+        self.previous = getattr(_scope, "workspace", None)
+        _scope.workspace = self.workspace
+        return self.workspace
 
     def __exit__(self, *exc):
-        _scope.token = self.previous
+        _scope.workspace = self.previous
 
 
-def current_scope():
-    return getattr(_scope, "token", None)
+def current_workspace():
+    return getattr(_scope, "workspace", None) or _default_workspace
 
 
 # A/B switch for the conservative soft-min instance culling (DESIGN.md "Culling"): False sets VSRD_FLAG_NO_CULLING on
@@ -67,12 +118,7 @@ def _mlp_flag(centred_weights):
 
 
 def _workspace(device, num_instances, residual=False):
-    key = (current_scope(), device, num_instances, bool(residual))
-    buf = _workspaces.get(key)
-    if buf is None:
-        nbytes = _lib.load().vsrd_workspace_bytes(num_instances, 1 if residual else 0)
-        buf = _workspaces[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    return buf
+    return current_workspace().adjoint(device, num_instances, residual)
 
 
 def _prepare_rays(ray_positions, ray_directions):

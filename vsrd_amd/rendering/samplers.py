@@ -64,9 +64,6 @@ def inverse_transform_sampler(bins, weights, num_samples, deterministic=False, u
     return fine.reshape(*lead, S)
 
 
-_ray_workspaces = {}                       # per workspace scope, like the adjoint workspaces (renderers.py)
-
-
 def sample_rays(weights, num_samples, seed=0, stream_offset=0):
     """scripts/main.py:620-627: ``torch.multinomial(weights, num_samples, replacement=False)`` as a few streaming launches
     (vsrd_sample_rays: ATen's exponential-race algorithm with Philox keyed by (seed, stream_offset; index), no full sort).
@@ -74,11 +71,8 @@ def sample_rays(weights, num_samples, seed=0, stream_offset=0):
     Returns int64 indices [num_samples], best key first."""
     lib = _lib.load()
     weights = weights.detach().reshape(-1).to(torch.float32).contiguous()
-    from .renderers import current_scope
-    key = (current_scope(), weights.device)
-    buf = _ray_workspaces.get(key)
-    if buf is None:
-        buf = _ray_workspaces[key] = torch.empty(lib.vsrd_sample_rays_workspace_bytes(), dtype=torch.uint8, device=weights.device)
+    from .renderers import current_workspace
+    buf = current_workspace().sampler(weights.device)       # owned by the caller's Workspace (renderers.py), freed with it
     indices = torch.empty(int(num_samples), dtype=torch.int64, device=weights.device)
     offset_ptr = None
     if isinstance(stream_offset, torch.Tensor):
