@@ -429,3 +429,66 @@ def test_two_frames_replayed_concurrently(dev):
                         list(b.detector.parameters()) + list(b.hyper_distance_field.parameters())):
             assert torch.equal(p, q)
     assert not torch.equal(serial[0][0].detector.locations, serial[1][0].detector.locations)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_checkpoint_round_trip_and_workspace_lifetime(dev, graph, tmp_path):
+    """scripts/main.py:1109-1121 writes {step, models, optimizer, scheduler, metrics}; the file of either mode must load into the
+    reference's own objects (plain torch.optim.Adam with float rates + ExponentialLR, make_predictions.py:61-66 for the detector),
+    with identical rates and moments in both modes.  And the frame's scratch memory belongs to the FrameOptimizer: it is released
+    with it instead of piling up per frame."""
+    import gc
+    from vsrd_amd import formats, models, optimization, rendering, fields
+    V, H, W, N, S, R = 3, 128, 128, 4, 32, 256
+    K, E, (loc, dim, rot), gt_boxes, visible = c1_frame()
+    cam, dirs = rendering.ray_casting((H, W), K.to(dev), E.to(dev))
+    block = fields.FieldBlock(fields.pack_instances(loc.to(dev), rot.to(dev), dim.to(dev)), 0.1, None, None)
+    origins = cam[:, None, None, :].expand(V, H, W, 3).reshape(-1, 3).contiguous()
+    soft = rendering.render_hierarchical(block, origins, dirs.reshape(-1, 3), (0.0, 100.0), S, 0.1, 1.0, seed=5)["labels"].clamp(0, 1)
+    inputs = optimization.FrameInputs((H, W), K.to(dev), E.to(dev), soft.reshape(V, H, W, N).contiguous(), gt_boxes.to(dev), visible.to(dev))
+    config = optimization.OptimizationConfig(num_samples=S, num_rays=R, warmup_steps=3, num_steps=3000)
+    torch.manual_seed(0)
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated(dev)
+    loop = optimization.FrameOptimizer(inputs, config, dev, graph=graph)
+    steps = 7
+    for _ in range(steps):
+        loop.step()
+    assert loop.workspace.nbytes() > 0 and not loop.workspace.sampler_overflowed(dev)
+    path = str(tmp_path / "ckpts" / f"step_{steps - 1}.pt")
+    formats.save_checkpoint(path, loop, steps - 1, metrics={"iou_3d": 0.5})
+    payload = torch.load(path, map_location="cpu", weights_only=False)
+    assert sorted(payload) == ["metrics", "models", "optimizer", "scheduler", "step"] and payload["step"] == steps - 1
+    # the consumer: tools/kitti_360/make_predictions.py loads models.detector into a fresh BoxParameters3D
+    detector = models.BoxParameters3D(1, N)
+    detector.load_state_dict(payload["models"]["detector"])
+    torch.testing.assert_close(detector.locations, loop.detector.locations.detach().cpu())
+    hyper = models.HyperDistanceField(48, [16, 16, 16, 16], 256, [256, 256, 256, 256])
+    hyper.load_state_dict(payload["models"]["hyper_distance_field"])
+    # the reference's optimiser / scheduler objects take the state (float rates, host step counters)
+    groups = [dict(params=[p], lr=1e-2) for p in (detector.locations, detector.dimensions, detector.orientations)]
+    groups += [dict(params=[detector.embeddings], lr=1e-3), dict(params=list(hyper.parameters()), lr=1e-4)]
+    optimizer = torch.optim.Adam(groups, lr=1e-2)
+    scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=config.lr_gamma)
+    optimizer.load_state_dict(payload["optimizer"])
+    scheduler.load_state_dict(payload["scheduler"])
+    expected = [base * config.lr_gamma ** steps for base in (1e-2, 1e-2, 1e-2, 1e-3, 1e-4)]
+    for group, want in zip(optimizer.param_groups, expected):
+        assert isinstance(group["lr"], float) and group["lr"] == pytest.approx(want, rel=1e-5) and group["initial_lr"] in (1e-2, 1e-3, 1e-4)
+    assert scheduler.last_epoch == steps and scheduler.get_last_lr() == pytest.approx(expected, rel=1e-5)
+    state = optimizer.state[detector.locations]
+    assert float(state["step"]) == steps and state["step"].device.type == "cpu"
+    torch.testing.assert_close(state["exp_avg"], loop.optimizer.state[loop.detector.locations]["exp_avg"].cpu())
+    optimizer.step()                                                        # usable: grads are None, nothing moves, nothing raises
+    # the scratch dies with the optimizer
+    held = loop.workspace.nbytes()
+    assert held >= 16384 * 4 * N * 16 * 4
+    loop.close()
+    del loop
+    gc.collect()
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated(dev) - before < held // 2
+    with pytest.raises(TypeError):
+        rendering.workspace_scope(1234)
+    with pytest.raises(ValueError):                                         # fewer positive pixels than rays: torch.multinomial's error, up front
+        optimization.FrameOptimizer(inputs, optimization.OptimizationConfig(num_samples=S, num_rays=V * H * W), dev, graph=graph)
