@@ -1,35 +1,67 @@
 #!/usr/bin/env python3
-"""Headline benchmark: rendered rays/s (forward + backward) on BASELINE.json config 2
-(KITTI-360 376x1408, 16 instances, 64 samples/ray, 8 source views), synthetic data.
+"""Headline benchmark: rendered rays/s (forward + backward), synthetic KITTI-360-shaped frames.
 
-One step = one pass of the hot path over one dense frame: fused two-pass render of all V*H*W rays
-(``vsrd_render_hierarchical_forward``), silhouette BCE against synthetic soft masks, backward
-(``vsrd_render_backward``) through the box decode to the raw box parameters, Adam update.
-Inputs are resident in HBM before the timed region.
+One step = one pass of the hot path over one dense frame: the fused two-pass render of all V*H*W rays + silhouette BCE
+(+ eikonal term for residual fields) + adjoint in one launch (``vsrd_render_silhouette_step`` / ``vsrd_render_residual_step``),
+backward through the box decode (and the hypernetwork) to the raw parameters, Adam update.  Inputs are resident in HBM
+before the timed region.  Defaults = BASELINE.json config 2 (9 views x 376x1408, 16 instances, 64 samples/ray).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--schedule start|mid|end]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--residual] [--schedule start|mid|end] [--no-culling] ...
 
-N > 1: launched by ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...``; every rank
-renders its own frame (target frames are independent optimisation problems -- no data-path collective),
-barrier + synchronize on both sides of the timed region, max over ranks.  Rank 0 prints ONE JSON line.
+Multi-GPU: target frames are independent optimisation problems (README.md:128) -- every rank renders its own frame, there is no
+data-path collective ("scaling": "weak"); RCCL carries the barriers and the max-reduce of the timing.  Either the driver starts
+the ranks (``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N``: RANK / WORLD_SIZE come from the env), or
+``python bench.py --gpus N`` alone spawns its N ranks as child processes itself -- before anything in the parent touches a GPU.
+``n_gpus`` in the JSON line is the number of ranks that passed the barrier, not the flag.  Rank 0 prints ONE JSON line.
+
+``--launcher-selftest`` runs the same launch / rendezvous / barrier / max-over-ranks / report path with a sleep instead of the
+render step, on gloo without a GPU (tests/test_launcher.py); its line says so and is not a measurement.
 """
 import argparse
 import json
 import math
 import os
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP32_VALU_PEAK_TF = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
+FP32_PEAK_TF = 157.3        # MI355X_MICROARCH.md: peak FP32 vector = dense FP32 MFMA peak (64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz)
+PEAK_CLOCK_HZ = 2.4e9
+NUM_SIMDS = 1024
+MFMA_16X16X4_FLOP = 2048    # one v_mfma_f32_16x16x4_f32 wave instruction: 16 x 16 x 4 multiply-adds
 
 SCHEDULES = {"start": 0.0, "mid": 0.5, "end": 1.0}   # fraction of the 3000 optimisation steps
+BASELINE_METRIC = "rendered rays/sec (fwd+bwd) per GPU, KITTI-360 376×1408, 16 instances"   # BASELINE.json:metric
+
+
+def parse_args(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--gpus", type=int, default=1)
+    parser.add_argument("--steps", type=int, default=10)
+    parser.add_argument("--warmup", type=int, default=2)
+    parser.add_argument("--views", type=int, default=9)         # 1 target + 8 source views
+    parser.add_argument("--height", type=int, default=376)
+    parser.add_argument("--width", type=int, default=1408)
+    parser.add_argument("--instances", type=int, default=16)
+    parser.add_argument("--samples", type=int, default=64)
+    parser.add_argument("--schedule", choices=sorted(SCHEDULES), default="mid")
+    parser.add_argument("--residual", action="store_true", help="BASELINE config 3: per-instance residual MLP + eikonal loss")
+    parser.add_argument("--two-launch", action="store_true",
+                        help="render forward, torch loss, render backward as separate launches instead of the fused step kernel")
+    parser.add_argument("--no-culling", action="store_true", help="VSRD_FLAG_NO_CULLING: every instance at every sample (worst case)")
+    parser.add_argument("--no-skip-misses", action="store_true")
+    parser.add_argument("--cpu-rays", type=int, default=0, help="rays of the CPU-baseline sample (default 16384; 1408 with --residual)")
+    parser.add_argument("--cpu-chunk", type=int, default=0, help="rays per oracle call (default: one image row; 352 with --residual)")
+    parser.add_argument("--cpu-threads", type=int, default=16)   # best of {8,16,32,64} on the 2x64-core EPYC 9575F GPU host (r01)
+    parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--launcher-selftest", action="store_true", help="no rendering: exercise the N-rank launch/report path (gloo, CPU)")
+    parser.add_argument("--master-port", type=int, default=0)
+    return parser.parse_args(argv)
 
 
 def schedule_values(fraction):
@@ -38,14 +70,75 @@ def schedule_values(fraction):
     return dict(temperature=value, std=value, cosine_ratio=fraction)
 
 
+def workload_key(args):
+    """Identifies the per-launch work: a committed rocprof summary is only quoted for the workload it was measured on."""
+    return (f"V{args.views}_H{args.height}_W{args.width}_N{args.instances}_S{args.samples}_{args.schedule}_"
+            f"{'residual' if args.residual else 'box'}_{'twolaunch' if args.two_launch else 'fused'}"
+            f"{'_nocull' if args.no_culling else ''}{'_noskip' if args.no_skip_misses else ''}")
+
+
+def describe_workload(args):
+    """(metric string, workload description) from the ACTUAL arguments; the BASELINE names only where the sizes are BASELINE's."""
+    V, H, W, N, S = args.views, args.height, args.width, args.instances, args.samples
+    c2 = (V, H, W, N, S) == (9, 376, 1408, 16, 64)
+    c5 = (V, H, W, N, S) == (17, 752, 2816, 64, 128)
+    c1 = (V, H, W, N, S) == (3, 128, 128, 4, 32)
+    if c2:
+        name = "BASELINE config 3" if args.residual else "BASELINE config 2"
+    elif c5 and not args.residual:
+        name = "BASELINE config 5 (stress) on one GPU"
+    elif c1 and not args.residual:
+        name = "BASELINE config 1 sizes"
+    else:
+        name = "custom sizes (not a BASELINE config)"
+    metric = BASELINE_METRIC if c2 else f"rendered rays/sec (fwd+bwd) per GPU, {H}×{W}, {N} instances"
+    field = "box + per-instance residual-MLP field, eikonal loss" if args.residual else "box-only field"
+    text = (f"{name}: dense frame, {V} views x {H}x{W} = {V * H * W} rays/step/GPU, {N} instances, {S} samples/ray "
+            f"(pass 1: {S - 1}, pass 2: {2 * S - 1} points), {field}")
+    return metric, text
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# launch: spawn the ranks ourselves when nobody else did
+# ---------------------------------------------------------------------------------------------------------------------
+
+def spawn_ranks(args):
+    """``python bench.py --gpus N`` without a launcher: start N copies of this script, one per GPU, with the torchrun environment.
+    The parent initialises no GPU (counting devices does not, on this image) and returns the worst child exit code."""
+    import socket
+    import torch
+    if not args.launcher_selftest:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this node has {have} visible GPU(s); one rank per GPU, no oversubscription")
+    port = args.master_port
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    children = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
+    codes = [child.wait() for child in children]
+    return max(abs(code) for code in codes)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# synthetic frame (SURVEY.md §8d)
+# ---------------------------------------------------------------------------------------------------------------------
+
 def kitti_intrinsics(height, width):
+    import torch
     sx, sy = width / 1408.0, height / 376.0
     return torch.tensor([[552.554261 * sx, 0.0, 682.049453 * sx], [0.0, 552.554261 * sy, 238.769549 * sy], [0.0, 0.0, 1.0]])
 
 
 def synthetic_frame(seed, num_views, height, width, num_instances):
-    """KITTI-360 intrinsics, target E = I, sources shifted along z with a small yaw; raw box
-    parameters ~ N(0, 0.5^2) with depth forced into 8-60 m."""
+    """KITTI-360 intrinsics, target E = I, sources shifted along z with a small yaw; raw box parameters ~ N(0, 0.5^2) with depth
+    forced into 8-60 m."""
+    import torch
     g = torch.Generator().manual_seed(seed)
     K = kitti_intrinsics(height, width).expand(num_views, 3, 3).contiguous()
     E = torch.eye(4).repeat(num_views, 1, 1)
@@ -64,223 +157,353 @@ def synthetic_frame(seed, num_views, height, width, num_instances):
 
 
 def build_union(detector, temperature):
-    """The soft-min union of the current boxes as the flat parameter block (what fields.flatten() produces
-    from the sdfs.translation(sdfs.rotation(instance_field(sdfs.box(...)))) tree, built here in one cat)."""
+    """The soft-min union of the current boxes as the flat parameter block (what fields.flatten() produces from the
+    sdfs.translation(sdfs.rotation(instance_field(sdfs.box(...)))) tree, built here in one cat)."""
     from vsrd_amd import fields
     out = detector()
     return fields.FieldBlock(fields.pack_instances(out["locations"][0], out["orientations"][0], out["dimensions"][0]),
                              float(temperature), None, None)
 
 
-def cpu_baseline(args, sched, frame, cores):
-    """The oracle (CPU PyTorch restatement, kind 'port') on a bounded sample of the same workload:
-    ``rows`` image rows of W rays each, issued row by row (the reference's dense idiom, main.py:1011-1023)."""
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (SURVEY.md §8d / BASELINE.md §2): the oracle on this host's cores, bounded sample, fwd and bwd separately
+# ---------------------------------------------------------------------------------------------------------------------
+
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(args, sched, frame, targets_of, hyper_state, cores):
+    """``kind: "port"``: oracle/ (the CPU restatement pinned by the goldens) on a fixed subset of the SAME frame: rows of W rays
+    through the objects of the target view, issued row by row (the reference's dense idiom, main.py:1011-1023), against the
+    frame's own targets.  1 warm-up + 3 timed repeats, the fastest repeat is reported; forward (two passes + loss) and backward
+    timed separately with time.perf_counter."""
+    import torch
     from oracle import fields as ofields, rendering as orendering, geometry as ogeometry, losses as olosses
     torch.set_num_threads(cores)
     K, E, raw_loc, raw_dim, raw_ori = frame
     H, W, N, S = args.height, args.width, args.instances, args.samples
+    num_rays = args.cpu_rays or (1408 if args.residual else 16384)
     cam, dirs = ogeometry.ray_casting((H, W), K[:1], E[:1])
+    first = int(H * 0.55) * W                                        # rows through the objects
+    first = max(0, min(first, H * W - num_rays))
+    # residual fields: a quarter row per call -- the oracle carries forward-mode tangents through the MLP, and at a full row its
+    # autograd state (tens of GB) is paged in afresh on every call (measured: 17 rays/s at 1408 rays per call, 75 at 352)
+    chunk = args.cpu_chunk or (352 if args.residual else W)
+    chunks = [(start, min(start + chunk, first + num_rays)) for start in range(first, first + num_rays, chunk)]
+    flat_dirs = dirs[0].reshape(-1, 3)
+    targets = targets_of(first, first + num_rays)                   # [num_rays, N] of view 0, from the device
     g = torch.Generator().manual_seed(1)
-    rows = torch.linspace(H * 0.45, H * 0.8, args.cpu_rows).long()
+    uniforms = [(torch.rand(b - a, S, generator=g), torch.rand(b - a, S, generator=g)) for a, b in chunks]
     raws = [t[0].clone().requires_grad_(True) for t in (raw_loc, raw_dim, raw_ori)]
+    mlp = None
+    if args.residual:
+        from vsrd_amd import models
+        hyper = models.HyperDistanceField(48, [16, 16, 16, 16], 256, [256, 256, 256, 256])
+        hyper.load_state_dict(hyper_state["hyper"])
+        embeddings = hyper_state["embeddings"].clone().requires_grad_(True)
 
     def one_pass():
-        total = 0.0
-        for r in rows:
+        forward = backward = 0.0
+        for (a, b), (uc, uf) in zip(chunks, uniforms):
+            t0 = time.perf_counter()
             loc, dim, rot, _ = ogeometry.decode_box_parameters(*raws)
-            union = ofields.InstanceUnion(loc, rot, dim, sched["temperature"])
-            d = dirs[0, r]
-            out = orendering.hierarchical_render(union, cam[0], d, (0.0, 100.0), S, sched["std"], sched["cosine_ratio"],
-                                                 torch.rand(W, S, generator=g), torch.rand(W, S, generator=g))
-            loss = olosses.silhouette_loss(out.labels, torch.rand(W, N, generator=g))
+            weights = hyper(embeddings)[0] if args.residual else None
+            union = ofields.InstanceUnion(loc, rot, dim, sched["temperature"], weights)
+            out = orendering.hierarchical_render(union, cam[0], flat_dirs[a:b], (0.0, 100.0), S, sched["std"], sched["cosine_ratio"], uc, uf)
+            loss = olosses.silhouette_loss(out.labels, targets[a - first:b - first])
+            if args.residual:
+                loss = loss + 0.01 * olosses.eikonal_loss(out.gradients)
+            t1 = time.perf_counter()
             loss.backward()
-            total += float(loss.detach())
-        return total
+            t2 = time.perf_counter()
+            forward += t1 - t0
+            backward += t2 - t1
+        return forward, backward
 
-    one_pass()  # warm-up
-    best = float("inf")
-    for _ in range(2):
-        t0 = time.perf_counter()
-        one_pass()
-        best = min(best, time.perf_counter() - t0)
-    rays = args.cpu_rows * W
-    return dict(value=rays / best, unit="rays/s", cores=cores, kind="port",
-                sample=f"{args.cpu_rows} image rows x {W} rays (fwd+bwd, N={N}, S={S}), oracle/ on host CPU, best of 2")
+    one_pass()                                                       # warm-up
+    repeats = [one_pass() for _ in range(3)]
+    forward, backward = min(repeats, key=lambda fb: fb[0] + fb[1])
+    return dict(value=num_rays / (forward + backward), unit="rays/s", cores=cores, kind="port", cpu=cpu_model_name(),
+                forward_s=forward, backward_s=backward, repeats=3,
+                sample=f"{num_rays} rays of the target view in {len(chunks)} calls of <= {chunk} rays (fwd+bwd, N={N}, S={S}"
+                       f"{', residual MLP + eikonal' if args.residual else ''}), the frame's own targets, oracle/ on {cores} threads, "
+                       "fastest of 3 repeats after 1 warm-up")
 
 
-def measured_traffic(kernel_symbol):
-    """HBM bytes per launch of `kernel_symbol` from the newest committed rocprofv3 PMC summary (profiles/rNN/traffic.json,
-    written by tools/summarize_profile.py from separate FETCH_SIZE / WRITE_SIZE passes of this same command), or None."""
+# ---------------------------------------------------------------------------------------------------------------------
+# committed rocprofv3 summaries (profiles/rNN*/counters.json, written by tools/summarize_profile.py)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def committed_counters(kernel_symbol, key):
+    """Per-launch PMC counters of `kernel_symbol` from the newest committed profile of exactly this workload, or (None, None)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "counters.json")), reverse=True):
         try:
-            kernels = json.load(open(path))["kernels"]
-        except (OSError, ValueError, KeyError):
+            data = json.load(open(path))
+        except (OSError, ValueError):
             continue
-        for name, entry in kernels.items():
-            if kernel_symbol in name and "FETCH_SIZE_bytes" in entry and "WRITE_SIZE_bytes" in entry:
-                return entry["FETCH_SIZE_bytes"] + entry["WRITE_SIZE_bytes"], os.path.relpath(path, ROOT)
+        if data.get("workload_key") != key:
+            continue
+        for name, entry in data.get("kernels", {}).items():
+            if kernel_symbol in name:
+                return entry, os.path.relpath(path, ROOT)
     return None, None
 
 
-def main():
-    parser = argparse.ArgumentParser()
-    parser.add_argument("--gpus", type=int, default=1)
-    parser.add_argument("--steps", type=int, default=10)
-    parser.add_argument("--warmup", type=int, default=2)
-    parser.add_argument("--views", type=int, default=9)         # 1 target + 8 source views
-    parser.add_argument("--height", type=int, default=376)
-    parser.add_argument("--width", type=int, default=1408)
-    parser.add_argument("--instances", type=int, default=16)
-    parser.add_argument("--samples", type=int, default=64)
-    parser.add_argument("--schedule", choices=sorted(SCHEDULES), default="mid")
-    parser.add_argument("--cpu-rows", type=int, default=24)
-    parser.add_argument("--cpu-threads", type=int, default=16)   # best of {8,16,32,64} on the 2x64-core EPYC 9575F GPU host
-    parser.add_argument("--no-cpu-baseline", action="store_true")
-    parser.add_argument("--no-skip-misses", action="store_true")
-    parser.add_argument("--residual", action="store_true", help="BASELINE config 3: per-instance residual MLP + eikonal loss")
-    parser.add_argument("--two-launch", action="store_true",
-                        help="render forward, torch BCE, render backward as separate launches instead of the fused step kernel")
-    args = parser.parse_args()
+def executed_view(counters, launch_ms):
+    """Hardware view of one launch from its PMC counters (wave-instruction counts) and the live launch duration."""
+    if not counters or "SQ_INSTS_VALU" not in counters:
+        return None
+    seconds = launch_ms * 1e-3
+    fma, mul, add = (counters.get(k, 0.0) for k in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32"))
+    trans = counters.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+    mfma = counters.get("SQ_INSTS_MFMA", counters.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0))
+    valu_flop = (2.0 * fma + mul + add + trans) * 64.0
+    mfma_flop = mfma * MFMA_16X16X4_FLOP
+    # a wave64 fp32 VALU instruction occupies its SIMD's issue port for 2 cycles at peak (32 lanes/clk); MFMA 16x16x4 f32: 8 passes x 4 clk
+    valu_slots = counters["SQ_INSTS_VALU"] - mfma
+    return {"valu_tflops": valu_flop / seconds / 1e12, "mfma_tflops": mfma_flop / seconds / 1e12,
+            "tflops": (valu_flop + mfma_flop) / seconds / 1e12, "frac": (valu_flop + mfma_flop) / seconds / 1e12 / FP32_PEAK_TF,
+            "valu_issue_utilisation": 2.0 * valu_slots / (NUM_SIMDS * PEAK_CLOCK_HZ * seconds),
+            "mfma_utilisation": mfma_flop / seconds / 1e12 / FP32_PEAK_TF,
+            "fma_share_of_fp32_ops": fma / max(fma + mul + add, 1.0),
+            "valu_wave_instructions": counters["SQ_INSTS_VALU"], "mfma_wave_instructions": mfma,
+            "lds_bank_conflict_share": (counters["SQ_LDS_BANK_CONFLICT"] / counters["SQ_LDS_IDX_ACTIVE"]
+                                        if counters.get("SQ_LDS_IDX_ACTIVE") else None)}
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------------------------------
+
+def run_rank(args):
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    selftest = args.launcher_selftest
+    use_gpu = torch.cuda.is_available() and not selftest
+    if not use_gpu and not selftest:
+        raise SystemExit("bench.py measures the HIP path and needs a HIP device: there is no CPU fallback (the CPU oracle is only the "
+                         "`cpu_baseline` leg).  `--launcher-selftest` exercises the multi-rank launch path without rendering.")
+    dev = torch.device("cuda", local_rank) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(dev)
+    dist = None
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)     # RCCL; used for barrier / max-reduce only
-
-    import __graft_entry__
-    if rank == 0:
-        __graft_entry__.build()
-    if distributed:
-        dist.barrier()
-    from vsrd_amd import models, rendering, profiling
-
-    sched = schedule_values(SCHEDULES[args.schedule])
-    V, H, W, N, S = args.views, args.height, args.width, args.instances, args.samples
-    frame = synthetic_frame(seed=rank, num_views=V, height=H, width=W, num_instances=N)   # one frame per rank
-    K, E, raw_loc, raw_dim, raw_ori = frame
-
-    # ---- resident inputs (untimed) -----------------------------------------------------------------
-    cam, dirs = rendering.ray_casting((H, W), K.to(dev), E.to(dev))                 # [V,3], [V,H,W,3]
-    directions = dirs.reshape(-1, 3).contiguous()
-    origins = cam[:, None, None, :].expand(V, H, W, 3).reshape(-1, 3).contiguous()   # per-pixel, as main.py:289-296
-    R = directions.shape[0]
-    detector = models.BoxParameters3D(1, N).to(dev)
-    with torch.no_grad():
-        detector.locations.copy_(raw_loc); detector.dimensions.copy_(raw_dim); detector.orientations.copy_(raw_ori)
-        # targets: soft silhouettes of a perturbed copy of the boxes at the final (sharp) schedule
-        perturbed = models.BoxParameters3D(1, N).to(dev)
-        g = torch.Generator().manual_seed(1000 + rank)
-        perturbed.locations.copy_(raw_loc + torch.randn(raw_loc.shape, generator=g) * 0.05)
-        perturbed.dimensions.copy_(raw_dim + torch.randn(raw_dim.shape, generator=g) * 0.2)
-        perturbed.orientations.copy_(raw_ori + torch.randn(raw_ori.shape, generator=g) * 0.1)
-        targets = rendering.render_hierarchical(build_union(perturbed, 0.1), origins, directions, (0.0, 100.0), S, 0.1, 1.0,
-                                                seed=99, skip_exact_misses=True)["labels"].clamp(0.0, 1.0).contiguous()
-    params = [detector.locations, detector.dimensions, detector.orientations]
-    hyper = None
-    if args.residual:
-        torch.manual_seed(rank)
-        hyper = models.HyperDistanceField(48, [16, 16, 16, 16], 256, [256, 256, 256, 256]).to(dev)
-        params += [detector.embeddings, *hyper.parameters()]
-    optimizer = torch.optim.Adam(params, lr=1e-2)
-    skip = not args.no_skip_misses and not args.residual     # eikonal needs every ray's gradients
-    fused = not args.two_launch                               # one launch: render + silhouette BCE (+ eikonal) + adjoint
-
-    def step(index):
-        optimizer.zero_grad(set_to_none=True)
-        union = build_union(detector, sched["temperature"])
-        if hyper is not None:
-            union.mlp_weights = hyper(detector.embeddings)[0].contiguous()
-        if fused:
-            loss = rendering.silhouette_step(union, origins, directions, targets, (0.0, 100.0), S, sched["std"], sched["cosine_ratio"],
-                                             seed=rank, stream_offset=index, skip_exact_misses=skip, eikonal_ratio=0.01 if hyper is not None else 0.0)
-            loss.backward()
-            optimizer.step()
-            return loss
-        out = rendering.render_hierarchical(union, origins, directions, (0.0, 100.0), S, sched["std"], sched["cosine_ratio"],
-                                            seed=rank, stream_offset=index, skip_exact_misses=skip, return_gradients=hyper is not None)
-        loss = torch.nn.functional.binary_cross_entropy(out["labels"].clamp(1.0e-6, 1.0 - 1.0e-6), targets, reduction="none").mean()
-        if hyper is not None:
-            loss = loss + 0.01 * ((out["gradients"].norm(dim=-1) - 1.0) ** 2).mean()
-        loss.backward()
-        optimizer.step()
-        return loss
+        if use_gpu:
+            dist.init_process_group(backend="nccl", device_id=dev)     # RCCL; barrier / max-reduce / gather of the timings only
+        else:
+            dist.init_process_group(backend="gloo")
 
     def fence():
         if distributed:
             dist.barrier()
-        torch.cuda.synchronize()
+        if use_gpu:
+            torch.cuda.synchronize()
 
+    sched = schedule_values(SCHEDULES[args.schedule])
+    V, H, W, N, S = args.views, args.height, args.width, args.instances, args.samples
+    R = V * H * W
+    loss = None
+    kernels = {}
+    if selftest:
+        def step(index):
+            time.sleep(0.002 * (1 + rank))          # ranks differ: the reported time must be the slowest rank's
+    else:
+        import __graft_entry__
+        if rank == 0:
+            __graft_entry__.build()
+        if distributed:
+            dist.barrier()
+        from vsrd_amd import models, rendering, profiling
+        from vsrd_amd.rendering import renderers
+        renderers.CULLING = not args.no_culling
+        frame = synthetic_frame(seed=rank, num_views=V, height=H, width=W, num_instances=N)   # one frame per rank
+        K, E, raw_loc, raw_dim, raw_ori = frame
+        # ---- resident inputs (untimed) -------------------------------------------------------------------------------
+        cam, dirs = rendering.ray_casting((H, W), K.to(dev), E.to(dev))                 # [V,3], [V,H,W,3]
+        directions = dirs.reshape(-1, 3).contiguous()
+        origins = cam[:, None, None, :].expand(V, H, W, 3).reshape(-1, 3).contiguous()   # per-pixel, as main.py:289-296
+        detector = models.BoxParameters3D(1, N).to(dev)
+        with torch.no_grad():
+            detector.locations.copy_(raw_loc); detector.dimensions.copy_(raw_dim); detector.orientations.copy_(raw_ori)
+            # targets: soft silhouettes of a perturbed copy of the boxes at the final (sharp) schedule
+            perturbed = models.BoxParameters3D(1, N).to(dev)
+            g = torch.Generator().manual_seed(1000 + rank)
+            perturbed.locations.copy_(raw_loc + torch.randn(raw_loc.shape, generator=g) * 0.05)
+            perturbed.dimensions.copy_(raw_dim + torch.randn(raw_dim.shape, generator=g) * 0.2)
+            perturbed.orientations.copy_(raw_ori + torch.randn(raw_ori.shape, generator=g) * 0.1)
+            targets = rendering.render_hierarchical(build_union(perturbed, 0.1), origins, directions, (0.0, 100.0), S, 0.1, 1.0,
+                                                    seed=99, skip_exact_misses=True)["labels"].clamp(0.0, 1.0).contiguous()
+        params = [detector.locations, detector.dimensions, detector.orientations]
+        hyper = None
+        hyper_state = None
+        if args.residual:
+            torch.manual_seed(rank)
+            hyper = models.HyperDistanceField(48, [16, 16, 16, 16], 256, [256, 256, 256, 256]).to(dev)
+            params += [detector.embeddings, *hyper.parameters()]
+            hyper_state = dict(hyper={k: v.detach().cpu().clone() for k, v in hyper.state_dict().items()},
+                               embeddings=detector.embeddings.detach().cpu().clone())
+        optimizer = torch.optim.Adam(params, lr=1e-2)
+        skip = not args.no_skip_misses and not args.residual     # eikonal needs every ray's gradients
+        fused = not args.two_launch                               # one launch: render + silhouette BCE (+ eikonal) + adjoint
+
+        def step(index):
+            optimizer.zero_grad(set_to_none=True)
+            union = build_union(detector, sched["temperature"])
+            if hyper is not None:
+                union.mlp_weights = hyper(detector.embeddings)[0].contiguous()
+            if fused:
+                value = rendering.silhouette_step(union, origins, directions, targets, (0.0, 100.0), S, sched["std"], sched["cosine_ratio"],
+                                                  seed=rank, stream_offset=index, skip_exact_misses=skip, eikonal_ratio=0.01 if hyper is not None else 0.0)
+            else:
+                out = rendering.render_hierarchical(union, origins, directions, (0.0, 100.0), S, sched["std"], sched["cosine_ratio"],
+                                                    seed=rank, stream_offset=index, skip_exact_misses=skip, return_gradients=hyper is not None)
+                value = torch.nn.functional.binary_cross_entropy(out["labels"].clamp(1.0e-6, 1.0 - 1.0e-6), targets, reduction="none").mean()
+                if hyper is not None:
+                    value = value + 0.01 * ((out["gradients"].norm(dim=-1) - 1.0) ** 2).mean()
+            value.backward()
+            optimizer.step()
+            return value
+
+    # ---- W warm-up steps, then exactly K timed steps between barrier + synchronize on both sides -------------------------
     for i in range(args.warmup):
         step(i)
     fence()
-    with profiling.kernel_timer() as timer:
+    if selftest:
         t0 = time.perf_counter()
         for i in range(args.steps):
-            loss = step(args.warmup + i)
+            step(args.warmup + i)
+        own = time.perf_counter() - t0                # this rank's own work, before it waits for the others
         fence()
         elapsed = time.perf_counter() - t0
+    else:
+        with profiling.kernel_timer() as timer:
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                loss = step(args.warmup + i)
+            torch.cuda.synchronize()
+            own = time.perf_counter() - t0            # this rank's own work, before it waits for the others
+            fence()
+            elapsed = time.perf_counter() - t0
+        kernels = timer.summary()
+    per_rank_ms = [own / args.steps * 1e3]
+    ranks_through = 1
     if distributed:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kernels = timer.summary()
+        mine = torch.tensor([elapsed, own], device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank_ms = [float(t[1].item()) / args.steps * 1e3 for t in gathered]
+        elapsed = max(float(t[0].item()) for t in gathered)           # MAX over ranks of the barrier-to-barrier time
+        count = torch.ones(1, device=dev, dtype=torch.float64)
+        dist.all_reduce(count)                                        # ranks that got here = ranks that passed every barrier
+        ranks_through = int(round(float(count.item())))
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * R * args.steps / elapsed
-        # Algorithmic bytes per ray (SURVEY.md §8d, B_api = 24 + 12 N for fwd+bwd with per-ray origins excluded):
-        #   forward launch : direction 12 + labels out 4N ; backward launch: direction re-read 12 + grad_labels in 4N
-        #   fused step launch: direction 12 + targets 4N (labels, label adjoints and saved distances never leave the chip)
-        if fused:
-            entry = "vsrd_render_residual_step" if args.residual else "vsrd_render_silhouette_step"
-            fwd_n, fwd_ms = kernels[entry]
-            bwd_n, bwd_ms = 0, 0.0
-            dominant, dom_ms, dom_bytes, symbol = entry, fwd_ms, 12 + 4 * N, "render_residual_step_kernel" if args.residual else "render_silhouette_kernel"
-        else:
-            fwd_n, fwd_ms = kernels["vsrd_render_hierarchical_forward"]
-            bwd_n, bwd_ms = kernels["vsrd_render_backward"]
-            dominant, dom_ms, dom_bytes, symbol = ("vsrd_render_backward", bwd_ms, 12 + 4 * N, "render_backward_kernel") if bwd_ms >= fwd_ms else \
-                                                  ("vsrd_render_hierarchical_forward", fwd_ms, 12 + 4 * N, "render_hierarchical_kernel")
-        traffic, traffic_source = measured_traffic(symbol)
-        achieved_gbs = R * dom_bytes / (dom_ms * 1e-3) / 1e9
-        flop_per_ray = 3.5 * (3 * S - 2) * (63 * N + 45)           # SURVEY.md §8d box-only model, fwd+bwd
-        valu_tf = R * flop_per_ray / ((fwd_ms + bwd_ms) * 1e-3) / 1e12
-        with torch.no_grad():
-            miss = float((targets.sum(-1) == 0).float().mean())
+        metric, workload = describe_workload(args)
         result = {
-            "metric": "rendered rays/sec (fwd+bwd), KITTI-360 376x1408, 16 instances",
-            "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE config 2: dense frame, {V} views x {H}x{W} = {R} rays/step/GPU, {N} box instances, "
-                                   f"{S} samples/ray (pass 1: {S - 1}, pass 2: {2 * S - 1} points), " + ("box + residual-MLP field, eikonal loss" if args.residual else "box-only field"),
-                       "schedule": f"{args.schedule}: T=std={sched['std']:.3f}, cosine_ratio={sched['cosine_ratio']:.2f}",
-                       "skip_exact_misses": skip, "rng": "in-kernel Philox4x32-10", "rays_per_gpu": R,
-                       "loss": ("silhouette BCE" + (" + 0.01 eikonal" if args.residual else "") + " fused into the render kernel" if fused
-                                else "silhouette BCE" + (" + 0.01 eikonal" if args.residual else "") + " (torch elementwise)") + " + Adam",
-                       "launches_per_step": "1 fused (render + loss + adjoint) + partial reductions" if fused else "forward, torch loss, backward",
-                       "final_loss": float(loss.detach()), "target_empty_fraction": miss},
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "algorithmic_bytes_per_ray": dom_bytes, "launch_ms": dom_ms,
-                         "note": "the fused path is fp32-VALU/transcendental bound, not HBM bound (SURVEY.md §8d); see roofline_valu"},
-            "roofline_valu": {"bound": "fp32-valu", "achieved": valu_tf, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
-                              "frac": valu_tf / FP32_VALU_PEAK_TF, "model_flop_per_ray": flop_per_ray,
-                              "forward_ms": fwd_ms, "backward_ms": bwd_ms, "launches": [fwd_n, bwd_n]},
+            "metric": metric, "value": ranks_through * R * args.steps / elapsed, "unit": "rays/s", "n_gpus": ranks_through,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "per_rank_ms_per_step": per_rank_ms,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args, sched, frame, min(args.cpu_threads, os.cpu_count() or 1))
-        print(json.dumps(result))
+        if selftest:
+            result.update(metric="launcher selftest: no rendering, NOT a measurement", value=0.0, unit="none",
+                          config={"workload": "sleep(2 ms x (1 + rank)) per step on gloo/CPU: exercises spawn, rendezvous, barriers, "
+                                              "max over ranks and the report only", "requested_gpus": args.gpus})
+        else:
+            result["config"] = {
+                "workload": workload, "workload_key": workload_key(args),
+                "schedule": f"{args.schedule}: T=std={sched['std']:.3f}, cosine_ratio={sched['cosine_ratio']:.2f}",
+                "culling": not args.no_culling, "skip_exact_misses": skip, "rng": "in-kernel Philox4x32-10", "rays_per_gpu": R,
+                "requested_gpus": args.gpus, "parallelism": f"frames sharded over {ranks_through} rank(s), no data-path collective",
+                "loss": ("silhouette BCE" + (" + 0.01 eikonal" if args.residual else "") + (" fused into the render kernel" if fused else " (torch elementwise)")) + " + Adam",
+                "launches_per_step": "1 fused (render + loss + adjoint) + partial reductions" if fused else "forward, torch loss, backward",
+                "final_loss": float(loss.detach()), "target_empty_fraction": float((targets.sum(-1) == 0).float().mean()),
+            }
+            result.update(rooflines(args, kernels, R, fused))
+            if world == 1 and not args.no_cpu_baseline:
+                result["cpu_baseline"] = cpu_baseline(args, sched, frame, lambda a, b: targets[a:b].cpu(), hyper_state,
+                                                      min(args.cpu_threads, os.cpu_count() or 1))
+        print(json.dumps(result), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def rooflines(args, kernels, R, fused):
+    """`roofline` (the mandated object, for the dominant kernel) and `roofline_valu` (the bound that actually applies to the fused
+    box kernel), both from launch durations measured live with HIP events on the launch stream (vsrd_amd/profiling.py).
+
+    Algorithmic bytes per ray: fused step = direction 12 + targets 4N (labels, label adjoints and the
+    sorted distances never leave the chip); two-launch path = 12 + 4N per launch.
+    Algorithmic flops per ray: box-only F = 3.5 (3S-2)(63N+45); residual fields add (3S-2) N 2*1617*9 -- both count
+    every instance at every sample, i.e. work the kernels cull, so the hardware view (`executed`, from the committed PMC counters
+    of this exact workload and the live duration) is reported next to them."""
+    N, S = args.instances, args.samples
+    if fused:
+        entry = "vsrd_render_residual_step" if args.residual else "vsrd_render_silhouette_step"
+        fwd_n, fwd_ms = kernels[entry]
+        bwd_n, bwd_ms = 0, 0.0
+        dominant, dom_ms = entry, fwd_ms
+        symbol = "render_residual_step_kernel" if args.residual else "render_silhouette_kernel"
+    else:
+        fwd_n, fwd_ms = kernels["vsrd_render_hierarchical_forward"]
+        bwd_n, bwd_ms = kernels["vsrd_render_backward"]
+        dominant, dom_ms, symbol = ("vsrd_render_backward", bwd_ms, "render_backward_kernel") if bwd_ms >= fwd_ms else \
+                                   ("vsrd_render_hierarchical_forward", fwd_ms, "render_hierarchical_kernel")
+    dom_bytes = 12 + 4 * N
+    counters, source = committed_counters(symbol, workload_key(args))
+    traffic = None
+    if counters and "FETCH_SIZE_bytes" in counters and "WRITE_SIZE_bytes" in counters:
+        traffic = counters["FETCH_SIZE_bytes"] + counters["WRITE_SIZE_bytes"]
+    executed = executed_view(counters, dom_ms)
+    box_flop = 3.5 * (3 * S - 2) * (63 * N + 45)
+    mlp_flop = (3 * S - 2) * N * 2 * 1617 * 9 if args.residual else 0.0
+    total_ms = fwd_ms + bwd_ms
+    achieved_gbs = R * dom_bytes / (dom_ms * 1e-3) / 1e9
+    hbm = {"bound": "hbm", "kernel": dominant, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+           "traffic": traffic, "traffic_source": source, "algorithmic_bytes_per_ray": dom_bytes, "launch_ms": dom_ms,
+           "note": "the fused path is compute bound (arithmetic intensity ~1e4 flop/B), not HBM bound (SURVEY.md §8d); see roofline_valu / roofline_mfma"}
+    out = {}
+    model_tf = R * box_flop / (total_ms * 1e-3) / 1e12
+    valu = {"bound": "fp32-valu", "achieved": model_tf, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": model_tf / FP32_PEAK_TF,
+            "model_flop_per_ray": box_flop, "model_note": "SURVEY §8d box-only flop model: counts every instance at every sample (work-equivalent, not utilisation)",
+            "forward_ms": fwd_ms, "backward_ms": bwd_ms, "launches": [fwd_n, bwd_n], "executed": executed, "executed_source": source}
+    if args.residual:
+        # the residual kernels are bound by the matrix pipe + the jet algebra on the VALU (same 157 TF peak, no overlap on a SIMD):
+        # the mandated object carries the EXECUTED flops when the counters of this workload are committed, else the model figure
+        achieved = executed["tflops"] if executed else R * (box_flop + mlp_flop) / (total_ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
+                           "frac": achieved / FP32_PEAK_TF, "traffic": traffic, "traffic_source": source, "launch_ms": dom_ms,
+                           "basis": ("executed MFMA + VALU flops from the committed PMC counters of this workload / live launch duration" if executed
+                                     else "SURVEY §8d flop model (no committed counters for this workload): work-equivalent, includes culled work"),
+                           "mfma_tflops": executed["mfma_tflops"] if executed else None, "mfma_frac": executed["mfma_utilisation"] if executed else None,
+                           "model_flop_per_ray": box_flop + mlp_flop, "algorithmic_bytes_per_ray": dom_bytes, "traffic_bytes_per_ray": traffic / R if traffic else None}
+        out["roofline_hbm"] = hbm
+        valu["model_note"] += "; for residual fields see `roofline` (MFMA + VALU)"
+    else:
+        out["roofline"] = hbm
+    out["roofline_valu"] = valu
+    return out
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -83,6 +83,26 @@ def _layer_norm_gelu(x, dx):
     return out, dout
 
 
+def _instance_linear(block, fan_in, x, dx):
+    """[x; 1] -> W [x; 1] for per-instance blocks W [..., out, in + 1] (hyper_distance_field.py:66-70).  When the blocks carry one
+    leading instance axis and are broadcast over all the points of x ([N, 1, .., 1, out, in + 1] against [N, .., in]) the product
+    is a batched GEMM over that axis; the element-wise form below would materialise an [N, points, out, in] tensor (9 GB per layer
+    at BASELINE config 3 sizes on one image row -- 14x slower than the reference itself)."""
+    matrix, bias = block[..., :fan_in], block[..., fan_in]
+    batched = block.dim() >= 3 and all(d == 1 for d in block.shape[1:-2]) and x.dim() == block.dim() - 1 and x.shape[0] == block.shape[0]
+    if block.dim() == 2:                                       # one weight vector for every point: a plain GEMM
+        return x @ matrix.t() + bias, (None if dx is None else dx @ matrix.t())
+    if batched:
+        n, out = block.shape[0], block.shape[-2]
+        w_t = matrix.reshape(n, out, fan_in).transpose(1, 2)
+        y = torch.bmm(x.reshape(n, -1, fan_in), w_t).reshape(*x.shape[:-1], out) + bias.reshape(n, *([1] * (x.dim() - 2)), out)
+        dy = None if dx is None else torch.bmm(dx.reshape(n, -1, fan_in), w_t).reshape(*dx.shape[:-1], out)
+        return y, dy
+    y = (matrix * x.unsqueeze(-2)).sum(-1) + bias
+    dy = None if dx is None else (matrix.unsqueeze(-3) * dx.unsqueeze(-2)).sum(-1)
+    return y, dy
+
+
 def instance_mlp(weights, feats, dfeats=None):
     """hyper_distance_field.py:57-73 for one weight vector per leading index.
 
@@ -97,10 +117,7 @@ def instance_mlp(weights, feats, dfeats=None):
         offset += count
         if layer:
             x, dx = _layer_norm_gelu(x, dx)
-        matrix, bias = block[..., :fan_in], block[..., fan_in]
-        x = (matrix * x.unsqueeze(-2)).sum(-1) + bias
-        if dx is not None:
-            dx = (matrix.unsqueeze(-3) * dx.unsqueeze(-2)).sum(-1)
+        x, dx = _instance_linear(block, fan_in, x, dx)
     if dx is None:
         return x.squeeze(-1)
     return x.squeeze(-1), dx.squeeze(-1)
@@ -140,7 +157,13 @@ class InstanceUnion:
         local = (rel.unsqueeze(-2) @ R).squeeze(-2)                   # row vector times R
         d, g_local = box_distance_and_gradient(local, self.dimensions.reshape(*lead, 3))
         if self.mlp_weights is not None:
-            res, g_res = residual_distance_and_gradient(local, self.mlp_weights.reshape(*lead, -1))
+            if local[0].numel() > (1 << 16):
+                # instance by instance, as the reference's closure loop does (main.py:480-483): the forward-mode tangents make the
+                # temporaries 4x the reference's, and [N, points, 3, 16]-sized ones fall out of every cache and into mmap/munmap churn
+                parts = [residual_distance_and_gradient(local[i], self.mlp_weights[i]) for i in range(self.num_instances)]
+                res, g_res = torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts])
+            else:
+                res, g_res = residual_distance_and_gradient(local, self.mlp_weights.reshape(*lead, -1))
             d, g_local = d + res, g_local + g_res
         g_world = (g_local.unsqueeze(-2) @ R.transpose(-1, -2)).squeeze(-2)
         return d, g_world

@@ -549,6 +549,42 @@ def golden_loss_library():
     save("g13_loss_library", **arrays)
 
 
+def golden_loss_library_rest():
+    """a22, second half (G18): geometric_losses.py and the rest of probabilistic_losses.py (logit-space NLLs, Monte-Carlo energy
+    scores).  The energy scores draw from torch's global generator: seeded right before each call, so a consumer that seeds the same
+    way and draws in the same order (one rsample([num_samples]) call) replays the reference's samples."""
+    _stub_package("vsrd.losses", os.path.join(REFERENCE_ROOT, "vsrd", "losses"))
+    geo = importlib.import_module("vsrd.losses.geometric_losses")
+    prob = importlib.import_module("vsrd.losses.probabilistic_losses")
+    g = torch.Generator().manual_seed(41)
+
+    def pose(n):
+        q, _ = torch.linalg.qr(torch.randn(n, 3, 3, generator=g))
+        m = torch.eye(4).repeat(n, 1, 1)
+        m[:, :3, :3] = q
+        m[:, :3, 3] = torch.randn(n, 3, generator=g)
+        return m
+    source, target = pose(6), pose(6)
+    target[0] = torch.linalg.inv(source[0])                      # a consistent pair: both losses vanish
+    k1, k2 = torch.rand(6, 11, 2, generator=g) * 100.0, torch.rand(6, 11, 2, generator=g) * 100.0
+    fundamental = torch.randn(6, 3, 3, generator=g) * 0.01
+    mean, target_v = torch.randn(5, 7, generator=g), torch.randn(5, 7, generator=g)
+    var, shape, scale = torch.rand(5, 7, generator=g) + 0.1, torch.rand(5, 7, generator=g) + 1.5, torch.rand(5, 7, generator=g) + 0.2
+    unit = torch.rand(5, 7, generator=g) * 0.9 + 0.05
+    arrays = dict(source=source, target=target, keypoints_1=k1, keypoints_2=k2, fundamental=fundamental, mean=mean, target_values=target_v,
+                  var=var, shape=shape, scale=scale, unit_targets=unit, num_samples=np.array(64), seed=np.array(1234))
+    arrays["out_rotation_consistency_loss"] = geo.rotation_consistency_loss(source, target, reduction="none")
+    arrays["out_translation_consistency_loss"] = geo.translation_consistency_loss(source, target, reduction="none")
+    arrays["out_sampson_epipolar_distance"] = geo.sampson_epipolar_distance(k1, k2, fundamental[:, None], reduction="none")
+    arrays["out_logit_gaussian_nll"] = prob.logit_gaussian_nll(mean, var, unit, reduction="none")
+    arrays["out_logit_student_nll"] = prob.logit_student_nll(mean, shape, scale, unit, reduction="none")
+    for name, args in (("gaussian_energy_score", (mean, var, target_v)), ("student_energy_score", (mean, shape, scale, target_v)),
+                       ("logit_gaussian_energy_score", (mean, var, unit)), ("logit_student_energy_score", (mean, shape, scale, unit))):
+        torch.manual_seed(1234)
+        arrays["out_" + name] = getattr(prob, name)(*args, num_samples=64, reduction="none")
+    save("g18_loss_library_rest", **arrays)
+
+
 def golden_box_3d_iou(ref):
     """G9 of SURVEY.md §8c: vsrd.operations.box_3d_iou on box pairs prepared as scripts/main.py:888-905 does
     (corners @ rotation_matrix_x(-pi/2).T, so that "up" is Z): identical, shifted, yawed, contained, touching and disjoint."""
@@ -613,7 +649,11 @@ def main():
     if "--bench-shapes" in sys.argv:       # only the G17 files (the others are unchanged since round 1)
         golden_rendering_bench_shapes(ref)
         return
+    if "--loss-library-rest" in sys.argv:  # only G18
+        golden_loss_library_rest()
+        return
     golden_rendering_bench_shapes(ref)
+    golden_loss_library_rest()
     golden_rendering_helpers(ref)
     golden_hypernetwork(ref)
     golden_box_3d_iou(ref)

@@ -168,3 +168,55 @@ def test_config1_full_frame_against_the_oracle(dev):
     assert abs(float(loss) - total) < 1e-5 * max(total, 1.0)
     for got, want in zip(grads, ograds):
         assert (got.cpu()[0] - want).abs().max() <= 5e-3 * float(want.abs().max())
+
+
+def _fused_step_properties(dev, N, S, V, H, W, residual, seed):
+    """One optimisation step of the FUSED kernels (the ones bench.py times) on a full-size frame, twice: finite loss and gradients,
+    bit-identical repeats (deterministic two-stage reduction, Philox keyed by ray), labels that are probabilities, and agreement of
+    the fused loss with the loss recomputed from the returned labels (a checksum over every ray of the frame)."""
+    import bench
+    from vsrd_amd import models, rendering
+    det, cam, dirs = scene(dev, N, V, H, W, seed=seed)
+    directions = dirs.reshape(-1, 3)
+    origins = cam[:, None, None, :].expand(V, H, W, 3).reshape(-1, 3).contiguous()
+    R = directions.shape[0]
+    with torch.no_grad():
+        targets = rendering.render_hierarchical(bench.build_union(det, 0.1), origins, directions, (0.0, 100.0), S, 0.1, 1.0, seed=99,
+                                                skip_exact_misses=True)["labels"].clamp(0.0, 1.0).contiguous()
+        det.locations.add_(0.02)                                     # so that the loss has a gradient
+    hyper = None
+    if residual:
+        torch.manual_seed(0)
+        hyper = models.HyperDistanceField(48, [16, 16, 16, 16], 256, [256, 256, 256, 256]).to(dev)
+    results = []
+    for _ in range(2):
+        union = bench.build_union(det, 0.55)
+        if hyper is not None:
+            union.mlp_weights = hyper(det.embeddings)[0].contiguous()
+        loss, terms, labels = rendering.silhouette_step(union, origins, directions, targets, (0.0, 100.0), S, 0.55, 0.5, seed=5, stream_offset=11,
+                                                        skip_exact_misses=not residual, eikonal_ratio=0.01 if residual else 0.0,
+                                                        return_terms=True, return_labels=True)
+        params = [det.locations, det.dimensions, det.orientations] + ([det.embeddings] if residual else [])
+        results.append((loss.detach().clone(), terms.clone(), labels, torch.autograd.grad(loss, params)))
+    (loss, terms, labels, grads), (loss2, _, labels2, grads2) = results
+    assert labels.shape == (R, N) and torch.isfinite(loss) and torch.equal(loss, loss2) and torch.equal(labels, labels2)
+    for a, b in zip(grads, grads2):
+        assert torch.isfinite(a).all() and torch.equal(a, b) and float(a.abs().max()) > 0
+    assert labels.min() >= -1e-6 and labels.sum(-1).max() <= 1 + 1e-4
+    recomputed = torch.nn.functional.binary_cross_entropy(labels.clamp(1.0e-6, 1.0 - 1.0e-6), targets, reduction="none").mean()
+    torch.testing.assert_close(terms[0], recomputed, rtol=2e-4, atol=1e-7)
+    if residual:
+        assert 0.0 <= float(terms[1]) < 1.0e3 and abs(float(loss) - float(terms[0] + 0.01 * terms[1])) <= 1e-5 * max(1.0, abs(float(loss)))
+    return float(loss)
+
+
+def test_config5_full_size_fused_step(dev):
+    """BASELINE config 5 at its full size on one GPU: 17 views x 752 x 2816 = 36.0 M rays, 64 instances, 128 samples per ray
+    (render_silhouette_kernel<4>; its arithmetic is pinned by golden g17_render_n64_s128_mid in test_hip_render.py)."""
+    _fused_step_properties(dev, N=64, S=128, V=17, H=752, W=2816, residual=False, seed=2)
+
+
+def test_config3_full_size_fused_step(dev):
+    """BASELINE config 3 at its full size: 9 views x 376 x 1408 = 4.76 M rays, 16 instances, 64 samples per ray, residual MLP from
+    the hypernetwork + eikonal term (render_residual_step_kernel<2>; arithmetic pinned by golden g17_render_residual_n16_s64_mid)."""
+    _fused_step_properties(dev, N=16, S=64, V=9, H=376, W=1408, residual=True, seed=3)

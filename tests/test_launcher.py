@@ -6,6 +6,8 @@ import tempfile
 import torch
 import torch.multiprocessing as mp
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def _free_port():
     with socket.socket() as s:
@@ -73,3 +75,34 @@ def test_frames_in_flight_runs_every_frame_once():
         assert done == [0, 1, 3, 4, 5, 6]
         assert sorted(f for f, _ in seen) == done and all(os.path.exists(path(f)) for f in range(7))
         assert torch.load(path(5))["frame"] == 5
+
+
+def test_bench_spawns_its_own_ranks_and_reports_what_ran():
+    """`python bench.py --gpus 2` without torchrun spawns the two ranks itself; the line reports the ranks that actually passed the
+    barriers (not the flag), the slowest rank's barrier-to-barrier time, and every rank's own time.  On this CPU-only container the
+    render step is replaced by a sleep (--launcher-selftest, gloo) and the line says that it is not a measurement; without that
+    flag and without a GPU the bench refuses to run instead of measuring something else."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--launcher-selftest", "--steps", "4", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                            # rank 0 prints ONE JSON line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert "NOT a measurement" in line["metric"] and line["value"] == 0.0
+    own = line["per_rank_ms_per_step"]
+    assert len(own) == 2 and own[1] > own[0] > 1.5                    # rank r sleeps 2 (1 + r) ms per step
+    assert line["ms_per_step"] >= max(own) - 0.2                      # the reported time is the slowest rank's
+    # under a launcher (the driver's torchrun form) the same script is a rank: WORLD_SIZE in the env, no second spawn
+    single = subprocess.run([sys.executable, bench, "--gpus", "1", "--launcher-selftest", "--steps", "2", "--warmup", "0"],
+                            capture_output=True, text=True, timeout=300, env=dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1"))
+    assert single.returncode == 0 and json.loads([l for l in single.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
+    if not torch.cuda.is_available():
+        refused = subprocess.run([sys.executable, bench, "--steps", "1"], capture_output=True, text=True, timeout=300, env=env)
+        assert refused.returncode != 0 and "no CPU fallback" in refused.stderr
+        assert not [l for l in refused.stdout.splitlines() if l.startswith("{")]

@@ -25,6 +25,7 @@ def main():
     parser.add_argument("--graph", action="store_true", help="capture the step in a hipGraph and replay it")
     parser.add_argument("--concurrent", type=int, default=1, help="frames optimised at the same time (one host thread and stream each)")
     parser.add_argument("--residual", action="store_true", help="post-warm-up phase: residual MLP + eikonal loss (steps 1000-3000)")
+    parser.add_argument("--json", action="store_true", help="also print one JSON line (tools/regimes.py)")
     args = parser.parse_args()
     import __graft_entry__
     __graft_entry__.build()
@@ -84,6 +85,11 @@ def main():
           f"{', %d frames at once' % args.concurrent if args.concurrent > 1 else ''}): {total / dt:.1f} steps/s ({dt / total * 1e3:.2f} ms/step, "
           f"1000 rays x 100 samples, V={V}, N={N}); 3000-step frame = {3000 * dt / total:.1f} s; reference: ~3.3 steps/s on a V100 "
           f"(README.md:128); final loss {results[0]:.4f}")
+    if args.json:
+        import json
+        print(json.dumps(dict(mode="native", phase="residual" if args.residual else "box-only", graph=bool(args.graph), frames_at_once=args.concurrent,
+                              steps_per_s=total / dt, ms_per_step=dt / total * 1e3, seconds_per_3000_step_frame=3000 * dt / total,
+                              rays_per_step=1000, samples_per_ray=100, views=V, instances=N, final_loss=results[0])))
 
 
 if __name__ == "__main__":

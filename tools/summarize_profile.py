@@ -61,6 +61,45 @@ def main():
                 out.write(f"\n## {sub}\n")
                 counters(path, out)
     traffic(src, dst)
+    counters_json(src, dst)
+
+
+def counters_json(src, dst):
+    """profiles/<tag>/counters.json: the per-launch counters bench.py quotes (`roofline.traffic`, `roofline_valu.executed`), keyed by
+    the workload they were measured on (config.workload_key of the bench line of the same command): last dispatch of each kernel."""
+    import json
+    key = line = None
+    log = os.path.join(src, "trace_stdout.log")
+    if os.path.exists(log):
+        for text in open(log):
+            if text.startswith("{\"metric\""):
+                line = json.loads(text)
+                key = line.get("config", {}).get("workload_key")
+    kernels = defaultdict(dict)
+    for sub in ("pmc_sq", "pmc_lds", "pmc_mix", "pmc_fetch", "pmc_write"):
+        path = os.path.join(src, sub, "bench_counter_collection.csv")
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                if "vsrd::" not in r["Kernel_Name"]:
+                    continue
+                name, counter, value = short(r["Kernel_Name"]), r["Counter_Name"], float(r["Counter_Value"])
+                if counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                    counter, value = counter + "_bytes", value * 1024.0
+                kernels[name][counter] = value                   # rows are in dispatch order: the last one (a timed step) stays
+                kernels[name]["vgpr"], kernels[name]["agpr"] = int(r["VGPR_Count"]), int(r["Accum_VGPR_Count"])
+    stats = os.path.join(src, "trace", "bench_kernel_stats.csv")
+    if os.path.exists(stats):
+        with open(stats) as f:
+            for r in csv.DictReader(f):
+                name = short(r["Name"])
+                if name in kernels:
+                    kernels[name]["rocprof_avg_ms"] = float(r["AverageNs"]) / 1e6
+    with open(os.path.join(dst, "counters.json"), "w") as f:
+        json.dump({"workload_key": key, "note": "rocprofv3 --pmc, one counter group per pass (tools/profile_bench.sh), last dispatch of each "
+                   "kernel; *_bytes = KiB x 1024, uncorrected (see traffic.json); counts are wave instructions summed over the chip",
+                   "bench_line": line, "kernels": kernels}, f, indent=1)
 
 
 def traffic(src, dst):

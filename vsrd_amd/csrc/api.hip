@@ -624,6 +624,18 @@ int32_t vsrd_linear_sum_assignment(const float* cost, int32_t num_rows, int32_t 
     return launch_status();
 }
 
+#ifdef VSRD_PHASE_TIMERS
+// Experiments only (tools/phase_timers.py): read (and optionally clear) the per-phase tick totals of the fused step kernels.
+int32_t vsrd_debug_phase_cycles(unsigned long long* out16, int32_t reset) {
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return VSRD_E_LAUNCH;
+    if (reset) {
+        unsigned long long zeros[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), zeros, sizeof(zeros)) != hipSuccess) return VSRD_E_LAUNCH;
+    }
+    return VSRD_OK;
+}
+#endif
+
 // Not part of the public header: exercised by tests/test_hip_wave.py.
 int32_t vsrd_selftest_wave(const float* in64, float* out512, void* stream) {
     if (!in64 || !out512) return VSRD_E_INVALID_ARGUMENT;

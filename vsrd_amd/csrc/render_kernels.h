@@ -44,6 +44,25 @@ struct RenderArgs {
     const unsigned long long* dynamic_offset;     // vsrd_render_config::device_stream_offset
 };
 
+// Phase clocks (experiments only: -DVSRD_PHASE_TIMERS, tools/phase_timers.py): every wave adds the s_memtime ticks it spends in each
+// phase of the fused step kernels to a global table that vsrd_debug_phase_cycles reads back.  Compiled out by default.
+#ifdef VSRD_PHASE_TIMERS
+__device__ unsigned long long g_phase_cycles[16];
+struct PhaseClock {
+    unsigned long long last, acc[8];
+    __device__ __forceinline__ PhaseClock() { for (int i = 0; i < 8; ++i) acc[i] = 0ull; last = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void mark(int phase) { const unsigned long long now = __builtin_readcyclecounter(); acc[phase] += now - last; last = now; }
+    __device__ __forceinline__ void flush(int lane) { if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_cycles[i], acc[i]); }
+};
+#define VSRD_PHASE_CLOCK() PhaseClock phase_clock
+#define VSRD_PHASE(i) phase_clock.mark(i)
+#define VSRD_PHASE_FLUSH(lane) phase_clock.flush(lane)
+#else
+#define VSRD_PHASE_CLOCK()
+#define VSRD_PHASE(i)
+#define VSRD_PHASE_FLUSH(lane)
+#endif
+
 // Per-step scalars that live on the device (hipGraph replay): applied to the kernel's private copies of its arguments.
 __device__ __forceinline__ void apply_device_schedule(FieldArgs& f, RenderArgs& c) {
     if (c.dynamic != nullptr) {
@@ -688,15 +707,19 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
     float loss_acc = 0.0f;                                                  // lane n: this wave's BCE sum of instance n
     const int D = 2 * S, num_points = D - 1;
     const int stride = static_cast<int>(gridDim.x) * waves_per_block();
+    VSRD_PHASE_CLOCK();
     for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
         wave_lds_sync();
+        VSRD_PHASE(7);
         const Ray r = load_ray(origins, directions, c.origin_stride, ray);
         const float target = (lane < N) ? targets[static_cast<size_t>(ray) * N + lane] : 0.0f;
         const RayCull rc = cull_ray_setup(instances, N, r.ox, r.oy, r.oz, r.rx, r.ry, r.rz, l.cull, lane);
         stage_ray_samples<kRoundsS>(l, c, S, ray, u_coarse, u_fine, nullptr, nullptr, sorted_input, lane);
+        VSRD_PHASE(0);
         // ---- pass 1 ------------------------------------------------------------------------------------
         float w1[kRoundsS];
         render_pass<kRoundsS, false, false>(instances, nullptr, N, sh, r, rc, l.coarse, S, l.dcache, w1, nullptr, nullptr);
+        VSRD_PHASE(1);
         float coarse_total = 0.0f;
 #pragma unroll
         for (int k = 0; k < kRoundsS; ++k) coarse_total += wave_sum(w1[k]);
@@ -706,8 +729,10 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
         if (!((c.flags & 2u) && coarse_total == 0.0f)) {                    // exact miss: labels are exactly 0, adjoint exactly 0
             rendered = true;
             importance_merge<kRoundsS>(l, S, w1);
+            VSRD_PHASE(2);
             // ---- pass 2 with the adjoint's state kept in registers ------------------------------------
             label = adjoint_forward_sweep<kRounds, false, true>(st, instances, nullptr, N, sh, r, rc, l.merged, num_points, nullptr, l.dcache, lane);
+            VSRD_PHASE(3);
         }
         if (labels_out != nullptr && lane < N) labels_out[static_cast<size_t>(ray) * N + lane] = label;
         // ---- silhouette BCE and its gradient (main.py:653-671; torch clamp / binary_cross_entropy backward) -----------------
@@ -722,10 +747,13 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
         if (sh.yaw) adjoint_label_mix<kRounds, false, true>(st, instances, N, sh.inv_t, num_points, lam, lane, nullptr, l.dcache);
         else adjoint_label_mix<kRounds, false, false>(st, instances, N, sh.inv_t, num_points, lam, lane, nullptr, l.dcache);
         if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, nullptr, nullptr, lane)) continue;
+        VSRD_PHASE(4);
         if (sh.yaw) adjoint_phase_b<kRounds, false, true>(st, instances, nullptr, N, f.inv_t, num_points, lam, G, lane, nullptr, nullptr, nullptr);
         else adjoint_phase_b<kRounds, false, false>(st, instances, nullptr, N, f.inv_t, num_points, lam, G, lane, nullptr, nullptr, nullptr);
+        VSRD_PHASE(5);
     }
     wave_lds_sync();
+    VSRD_PHASE_FLUSH(lane);
     const size_t wave_global = static_cast<size_t>(blockIdx.x) * waves_per_block() + wave;
     float* out = partials + wave_global * (N * kGradStride);
     for (int idx = lane; idx < N * kGradStride; idx += kWave) out[idx] = G[idx];
@@ -780,6 +808,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_residual_step_kernel(
     float loss_acc = 0.0f, eikonal_acc = 0.0f;
     const int D = 2 * S, num_points = D - 1;
     const int stride = static_cast<int>(gridDim.x) * waves_per_block();
+    VSRD_PHASE_CLOCK();
     for (int first = static_cast<int>(blockIdx.x) * waves_per_block() + wave; first < c.num_rays; first += stride * kMlpBatch) {
 #pragma unroll 1
         for (int b = 0; b < kMlpBatch; ++b) {
@@ -793,11 +822,15 @@ __global__ __launch_bounds__(kBlockThreads) void render_residual_step_kernel(
             const float target = (lane < N) ? targets[static_cast<size_t>(ray) * N + lane] : 0.0f;
             const RayCull rc = cull_ray_setup(instances, N, r.ox, r.oy, r.oz, r.rx, r.ry, r.rz, l.cull, lane);
             stage_ray_samples<kRoundsS>(l, c, S, ray, u_coarse, u_fine, nullptr, nullptr, sorted_input, lane);
+            VSRD_PHASE(0);
             float w1[kRoundsS];
             render_pass<kRoundsS, false, true>(instances, mlp, N, sh, r, rc, l.coarse, S, l.dcache, w1, nullptr, nullptr);
+            VSRD_PHASE(1);
             importance_merge<kRoundsS>(l, S, w1);
+            VSRD_PHASE(2);
             RayAdjoint<kRounds> st;
             const float label = adjoint_forward_sweep<kRounds, true, true>(st, instances, mlp, N, sh, r, rc, l.merged, num_points, nullptr, l.dcache, lane, rcache);
+            VSRD_PHASE(3);
             if (labels_out != nullptr && lane < N) labels_out[static_cast<size_t>(ray) * N + lane] = label;
             // silhouette BCE and its gradient (as render_silhouette_kernel)
             const float p = fminf(fmaxf(label, 1.0e-6f), 1.0f - 1.0e-6f);
@@ -817,13 +850,18 @@ __global__ __launch_bounds__(kBlockThreads) void render_residual_step_kernel(
             if (sh.yaw) adjoint_label_mix<kRounds, true, true>(st, instances, N, sh.inv_t, num_points, lam, lane, rcache, l.dcache);
             else adjoint_label_mix<kRounds, true, false>(st, instances, N, sh.inv_t, num_points, lam, lane, rcache, l.dcache);
             if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, nullptr, nullptr, lane, eikonal_scale)) continue;
+            VSRD_PHASE(4);
             if (sh.yaw) adjoint_phase_b<kRounds, true, true>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, ray_seeds, ray_masks);
             else adjoint_phase_b<kRounds, true, false>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, ray_seeds, ray_masks);
+            VSRD_PHASE(5);
         }
         wave_lds_sync();                                                     // masks: written by lanes < kRounds, read by all
+        VSRD_PHASE(7);
         adjoint_phase_mlp<kRounds, kMlpBatch>(instances, mlp, N, G, wbar, my_mlp, lane, seeds, masks, sh.mlp_bits);
+        VSRD_PHASE(6);
     }
     wave_lds_sync();
+    VSRD_PHASE_FLUSH(lane);
     float* out = partials + wave_global * (N * kGradStride);
     for (int idx = lane; idx < N * kGradStride; idx += kWave) out[idx] = G[idx];
     const float loss_total = wave_sum(loss_acc), eikonal_total = wave_sum(eikonal_acc);
