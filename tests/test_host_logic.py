@@ -186,3 +186,36 @@ def test_loss_library_matches_reference_g13():
     torch.testing.assert_close(L.student_nll(g["mean"], g["shape"], g["scale"], g["target"], reduction="none"), g["out_student_nll"], rtol=1e-4, atol=1e-5)
     with pytest.raises(ValueError):
         L.cross_entropy(p, t, reduction="median")
+
+
+def test_loss_library_rest_matches_reference_g18():
+    """a22, second half: geometric_losses.py and the logit-space NLLs / Monte-Carlo energy scores of probabilistic_losses.py against
+    the reference's outputs.  The energy scores sample from torch's global generator: seeding as the fixture generator did replays
+    the reference's draws (one rsample([num_samples]) call per score)."""
+    from conftest import load_golden
+    from vsrd_amd import loss_library as L
+    g = load_golden("g18_loss_library_rest")
+    torch.testing.assert_close(L.rotation_consistency_loss(g["source"], g["target"], reduction="none"), g["out_rotation_consistency_loss"], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(L.translation_consistency_loss(g["source"], g["target"], reduction="none"), g["out_translation_consistency_loss"], rtol=1e-5, atol=1e-7)
+    assert float(g["out_rotation_consistency_loss"][0]) < 1e-6 and float(g["out_translation_consistency_loss"][0]) < 1e-6      # target = source^-1
+    torch.testing.assert_close(L.sampson_epipolar_distance(g["keypoints_1"], g["keypoints_2"], g["fundamental"][:, None], reduction="none"),
+                               g["out_sampson_epipolar_distance"], rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(L.logit_gaussian_nll(g["mean"], g["var"], g["unit_targets"], reduction="none"), g["out_logit_gaussian_nll"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(L.logit_student_nll(g["mean"], g["shape"], g["scale"], g["unit_targets"], reduction="none"), g["out_logit_student_nll"], rtol=1e-4, atol=1e-5)
+    n, seed = int(g["num_samples"]), int(g["seed"])
+    for name, args in (("gaussian_energy_score", (g["mean"], g["var"], g["target_values"])),
+                       ("student_energy_score", (g["mean"], g["shape"], g["scale"], g["target_values"])),
+                       ("logit_gaussian_energy_score", (g["mean"], g["var"], g["unit_targets"])),
+                       ("logit_student_energy_score", (g["mean"], g["shape"], g["scale"], g["unit_targets"]))):
+        torch.manual_seed(seed)
+        torch.testing.assert_close(getattr(L, name)(*args, num_samples=n, reduction="none"), g["out_" + name], rtol=1e-5, atol=1e-6)
+    # reductions and the mean default, as the reference's @reduced decorator
+    torch.manual_seed(seed)
+    mean = L.gaussian_energy_score(g["mean"], g["var"], g["target_values"], num_samples=n)
+    torch.testing.assert_close(mean, g["out_gaussian_energy_score"].mean(), rtol=1e-5, atol=1e-6)
+    # every public name of the reference's vsrd/losses/*.py is there
+    for name in ("cross_entropy binary_cross_entropy kl_divergence binary_kl_divergence js_divergence binary_js_divergence focal_loss quality_focal_loss "
+                 "tversky_loss focal_tversky_loss rotation_consistency_loss translation_consistency_loss sampson_epipolar_distance ssim_loss photometric_loss "
+                 "gaussian_nll student_nll gaussian_energy_score student_energy_score logit_gaussian_nll logit_student_nll logit_gaussian_energy_score "
+                 "logit_student_energy_score smoothness_loss motion_smoothness_loss motion_sparsity_loss").split():
+        assert callable(getattr(L, name)), name
