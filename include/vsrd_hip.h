@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VSRD_ABI_VERSION 2
+#define VSRD_ABI_VERSION 3
 
 #define VSRD_OK 0
 #define VSRD_E_INVALID_ARGUMENT (-1) /* null pointer, non-positive size, unsupported N / S */
@@ -69,6 +69,18 @@ typedef struct vsrd_render_config {
      * (the annealing schedules of scripts/main.py:420-431 and the Philox counter of the step). */
     const float* device_schedule;          /* [3] = soft-min temperature, sdf_std_deviation, cosine_ratio; or NULL */
     const uint64_t* device_stream_offset;  /* [1] replaces stream_offset; or NULL                                   */
+    /* Optional gather (the two fused step entry points only; the others reject it): the step's rays are rows of FRAME-RESIDENT
+     * tensors picked by index, so that no per-step copies of directions / origins / targets are made (scripts/main.py:629-671 indexes
+     * multi_ray_directions, multi_camera_positions and multi_soft_masks with multi_ray_indices).  With ray_indices set, ray r reads
+     * directions[ray_indices[r]], origins[ray_indices[r] / rays_per_origin] (one camera position per view, origin_stride 3) and
+     * the targets row ray_indices[r]; labels (if requested) stay [R,N] in step order. */
+    const int64_t* ray_indices;            /* [R] or NULL                                                           */
+    int32_t rays_per_origin;               /* pixels per view (H * W); 0: origins are per ray, gathered like the directions */
+    /* Optional column map of the targets: a targets row has target_stride columns (ground-truth instance order) and predicted
+     * instance n is compared with column target_columns[n] (the Hungarian assignment, main.py:653-671); NULL: targets are [.,N]
+     * in prediction order. */
+    const int32_t* target_columns;         /* [N] or NULL                                                           */
+    int32_t target_stride;                 /* columns of a targets row when target_columns is set                   */
 } vsrd_render_config;
 
 #define VSRD_FLAG_FINE_UNIFORMS_SORTED 1u /* u_fine is already sorted ascending per ray     */
@@ -246,6 +258,61 @@ int32_t vsrd_project_boxes_forward(const float* world_corners, const float* extr
 int32_t vsrd_project_boxes_backward(const float* world_corners, const float* extrinsics, const float* intrinsics,
                                     const int32_t* edges, int32_t num_edges, int32_t num_views, int32_t num_boxes, float epsilon,
                                     const float* grad_boxes_2d, const int32_t* selection, float* grad_world_per_view, void* stream);
+
+/* ---- the rest of one optimisation step of scripts/main.py around the render launch, for <= 64 boxes and <= 32 views ------------
+ * In the reference these are a few hundred small ATen launches per step (box decode, V x N project_box_3d calls, DIoU matching
+ * through scipy on the host, projection losses, schedules, autograd through all of it, Adam, ExponentialLR); here two
+ * single-workgroup launches, so that the reference's native mode (1000 rays per step) is bound by its render launch. */
+typedef struct vsrd_frame_config {
+    int32_t num_boxes;              /* N (predictions = ground-truth slots, main.py:204-265 pads the sources to the target's N) */
+    int32_t num_views;              /* V, view 0 = target view                                                               */
+    float height, width;            /* image size for clip_boxes_to_image                                                     */
+    float epsilon;                  /* project_box_3d / clip_lines_to_front guard, 1e-6                                       */
+    float location_lo[3], location_hi[3];     /* BoxParameters3D.location_range (box_parameters.py:23-26)                     */
+    float dimension_lo[3], dimension_hi[3];   /* BoxParameters3D.dimension_range (box_parameters.py:27-30)                    */
+    int32_t num_steps;              /* optimisation steps of the schedules (config.json:167)                                  */
+    float max_temperature, min_temperature, max_std, min_std;   /* config.json:230-233                                        */
+    float weight_iou, weight_l1, weight_silhouette;             /* config.json:120-127                                        */
+    float beta1, beta2, adam_epsilon; /* torch.optim.Adam defaults 0.9, 0.999, 1e-8                                           */
+    float lr_gamma;                 /* ExponentialLR gamma (config.json:209-215)                                              */
+} vsrd_frame_config;
+
+size_t vsrd_frame_scratch_bytes(int32_t num_views, int32_t num_boxes);
+
+/* Before the render launch.  scripts/main.py:332 (BoxParameters3D.forward, box_parameters.py:124-146), :339-367 (projection),
+ * :374-386 (matching: -DIoU + linear_sum_assignment, as vsrd_match_boxes), :391-415 (distance_box_iou_loss + smooth_l1_loss over
+ * matched, visible instances), :420-431 (schedules from the device step counter).
+ * raw_locations / raw_dimensions [N,3], raw_orientations [N,2]; extrinsics [V,16], intrinsics [V,9]; gt_boxes [V,N,4];
+ * visible [V,N] uint8 (by ground-truth instance); step [1] int64 (device).
+ * Outputs: instances [N,16] (the renderer's field block); pd_indices / gt_indices [N] int64; target_columns [N] int32 and
+ * instance_weights [N] (for vsrd_render_config.target_columns / the step entry points); schedule [3] (for
+ * vsrd_render_config.device_schedule); projection_losses [2] = (iou, l1); grad_raw [N,8] = d (weight_iou * iou + weight_l1 * l1) /
+ * d (raw location 3 | raw dimension 3 | raw orientation 2). */
+int32_t vsrd_frame_prologue(const vsrd_frame_config* config, const float* raw_locations, const float* raw_dimensions,
+                            const float* raw_orientations, const float* extrinsics, const float* intrinsics, const float* gt_boxes,
+                            const uint8_t* visible, const int64_t* step, void* scratch, size_t scratch_bytes,
+                            float* instances, int64_t* pd_indices, int64_t* gt_indices, int32_t* target_columns, float* instance_weights,
+                            float* schedule, float* projection_losses, float* grad_raw, void* stream);
+
+/* torch.optim.Adam(capturable=True) state of one parameter tensor: all device memory, updated in place. */
+typedef struct vsrd_adam_tensors {
+    float* parameter;
+    float* exp_avg;
+    float* exp_avg_sq;
+    float* step;                    /* [1] float32                                                                            */
+    float* learning_rate;           /* [1] float32, multiplied by lr_gamma after the update (ExponentialLR)                   */
+} vsrd_adam_tensors;
+
+/* After the render launch.  scripts/main.py:855-865: total loss, backward through the decode (box_parameters.py:60-90), Adam step
+ * on locations / dimensions / orientations, scheduler step, step counter.  grad_instances [N,16] = d (silhouette + eikonal_ratio *
+ * eikonal) / d instances from the render step; grad_raw_projection [N,8] and projection_losses [2] from the prologue;
+ * render_losses [2] = (silhouette, eikonal).  other_learning_rates: two more [1] float32 rates decayed by lr_gamma (embeddings,
+ * hypernetwork groups), either may be NULL.  Outputs: record [5] = (iou, l1, silhouette, eikonal, total); raw_gradients [N,8] or NULL. */
+int32_t vsrd_frame_epilogue(const vsrd_frame_config* config, const float* grad_instances, const float* grad_raw_projection,
+                            const float* projection_losses, const float* render_losses, float eikonal_ratio,
+                            const vsrd_adam_tensors* locations, const vsrd_adam_tensors* dimensions, const vsrd_adam_tensors* orientations,
+                            float* other_learning_rate_0, float* other_learning_rate_1, int64_t* step,
+                            float* record, float* raw_gradients, void* stream);
 
 #ifdef __cplusplus
 }

@@ -283,10 +283,65 @@ def test_ray_sampler_matches_multinomial_statistics(dev):
     assert sorted(idx[:10].cpu().tolist()) == list(range(10)) and bool((idx[10:] == -1).all())
 
 
-def test_graph_mode_replays_the_same_steps(dev):
+def _c1_inputs(dev, V=3, H=128, W=128, N=4, S=32, all_visible=False, seed=0):
+    from vsrd_amd import optimization, rendering, fields
+    K, E, (loc, dim, rot), gt_boxes, visible = c1_frame(seed=seed, V=V, H=H, W=W, N=N)
+    if all_visible:
+        visible = torch.ones_like(visible)
+        gt_boxes, _ = ogeometry.project_boxes_multi_view(ogeometry.box_corners(loc, dim, rot), E, K, (H, W))
+    cam, dirs = rendering.ray_casting((H, W), K.to(dev), E.to(dev))
+    block = fields.FieldBlock(fields.pack_instances(loc.to(dev), rot.to(dev), dim.to(dev)), 0.1, None, None)
+    origins = cam[:, None, None, :].expand(V, H, W, 3).reshape(-1, 3).contiguous()
+    soft = rendering.render_hierarchical(block, origins, dirs.reshape(-1, 3), (0.0, 100.0), S, 0.1, 1.0, seed=5)["labels"].clamp(0, 1)
+    soft = (soft.reshape(V, H, W, N) * visible.to(dev)[:, None, None, :]).contiguous()
+    return optimization.FrameInputs((H, W), K.to(dev), E.to(dev), soft, gt_boxes.to(dev), visible.to(dev))
+
+
+@pytest.mark.parametrize("seed,V,N", [(0, 3, 4), (1, 5, 7), (2, 2, 1)])
+def test_frame_prologue_matches_the_torch_path(dev, seed, V, N):
+    """csrc/frame_step.h prologue (decode, projection, matching, projection losses AND their hand-derived gradient w.r.t. the raw box
+    parameters, schedules) against the same quantities from the torch ops of the eager step and autograd through them."""
+    from vsrd_amd import _lib, fields, losses, operations, optimization
+    inputs = _c1_inputs(dev, V=V, N=N, seed=seed)
+    config = optimization.OptimizationConfig(num_samples=32, num_rays=64, warmup_steps=100)
+    torch.manual_seed(seed)
+    loop = optimization.FrameOptimizer(inputs, config, dev, graph=True)
+    assert loop.fused_glue
+    g = torch.Generator().manual_seed(10 + seed)
+    with torch.no_grad():
+        loop.detector.locations.copy_((torch.randn(1, N, 3, generator=g) * 0.3 + torch.tensor([0.0, 0.0, -1.6])).to(dev))
+        loop.detector.dimensions.copy_((torch.randn(1, N, 3, generator=g) * 0.5).to(dev))
+        loop.detector.orientations.copy_(torch.nn.functional.normalize(torch.randn(1, N, 2, generator=g), dim=-1).to(dev) * 1.3)
+        loop.step_tensor.fill_(700)
+    lib, b, det = _lib.load(), loop._glue, loop.detector
+    _lib.check(lib.vsrd_frame_prologue(loop._frame, _lib.ptr(det.locations.data), _lib.ptr(det.dimensions.data), _lib.ptr(det.orientations.data),
+                                       _lib.ptr(b["extrinsics"]), _lib.ptr(b["intrinsics"]), _lib.ptr(b["gt_boxes"]), b["visible"].data_ptr(),
+                                       loop.step_tensor.data_ptr(), b["scratch"].data_ptr(), b["scratch"].numel(), _lib.ptr(b["instances"]),
+                                       b["pd_indices"].data_ptr(), b["gt_indices"].data_ptr(), b["target_columns"].data_ptr(), _lib.ptr(b["instance_weights"]),
+                                       _lib.ptr(loop.schedule), _lib.ptr(b["projection_losses"]), _lib.ptr(b["grad_raw"]), _lib.stream()))
+    out = det()
+    want_instances = fields.pack_instances(out["locations"][0], out["orientations"][0], out["dimensions"][0])
+    torch.testing.assert_close(b["instances"], want_instances.detach(), rtol=1e-6, atol=1e-6)
+    pd_boxes, _ = operations.project_boxes_multi_view(out["boxes_3d"][0], inputs.extrinsic_matrices, inputs.intrinsic_matrices, inputs.image_size)
+    pd_idx, gt_idx = losses.match_instances(pd_boxes[0], inputs.boxes_2d[0])
+    assert torch.equal(b["pd_indices"], pd_idx) and torch.equal(b["gt_indices"], gt_idx) and torch.equal(b["target_columns"].long(), gt_idx)
+    iou, l1 = losses.projection_losses(pd_boxes, inputs.boxes_2d, inputs.visible_masks, pd_idx, gt_idx)
+    torch.testing.assert_close(b["projection_losses"], torch.stack([iou, l1]).detach(), rtol=1e-5, atol=1e-6)
+    w = config.loss_weights
+    grads = torch.autograd.grad(w["iou_projection_loss"] * iou + w["l1_projection_loss"] * l1, [det.locations, det.dimensions, det.orientations])
+    want = torch.cat([g_[0] for g_ in grads], dim=-1)
+    assert float(want.abs().max()) > 0
+    assert (b["grad_raw"] - want).abs().max() <= 2e-4 * float(want.abs().max()), (b["grad_raw"], want)
+    ratio, temperature, std = losses.schedules(700, config.num_steps)
+    torch.testing.assert_close(loop.schedule.cpu(), torch.tensor([temperature, std, ratio]), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("fused_glue", [True, False])
+def test_graph_mode_replays_the_same_steps(dev, fused_glue):
     """hipGraph mode (FrameOptimizer(graph=True)): the captured step reads its schedules, Philox counter, Adam step and learning
     rates from device memory, so replaying it must walk the same trajectory as the eager loop given the same rays -- across the
-    warm-up -> residual phase switch (two captured graphs), and with the in-graph ray sampler."""
+    warm-up -> residual phase switch (two captured graphs), and with the in-graph ray sampler.  fused_glue: the box-side glue as the
+    two frame_step.h kernels (the default of graph mode) or as torch element-wise launches."""
     from vsrd_amd import optimization, rendering, fields
     V, H, W, N, S, R = 3, 128, 128, 4, 32, 256
     K, E, (loc, dim, rot), gt_boxes, visible = c1_frame()
@@ -304,7 +359,7 @@ def test_graph_mode_replays_the_same_steps(dev):
     loops = []
     for graph in (False, True):
         torch.manual_seed(0)
-        loop = optimization.FrameOptimizer(inputs, config, dev, graph=graph)
+        loop = optimization.FrameOptimizer(inputs, config, dev, graph=graph, fused_glue=fused_glue and graph)
         with torch.no_grad():
             for p, v in zip((loop.detector.locations, loop.detector.dimensions, loop.detector.orientations), start):
                 p.copy_(v[None].to(dev))

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VSRD_HIP_LIBRARY: an experiment build of the same ABI (tools/phase_timers.py, A/B macros); the product path is the in-tree default
 LIBRARY_PATH = os.environ.get("VSRD_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libvsrd_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_INSTANCES = 64
 MAX_SAMPLES = 256
 INSTANCE_STRIDE = 16
@@ -53,6 +53,46 @@ class RenderConfig(ctypes.Structure):
         ("flags", ctypes.c_uint32),
         ("device_schedule", ctypes.c_void_p),
         ("device_stream_offset", ctypes.c_void_p),
+        ("ray_indices", ctypes.c_void_p),
+        ("rays_per_origin", ctypes.c_int32),
+        ("target_columns", ctypes.c_void_p),
+        ("target_stride", ctypes.c_int32),
+    ]
+
+
+class FrameConfig(ctypes.Structure):
+    _fields_ = [
+        ("num_boxes", ctypes.c_int32),
+        ("num_views", ctypes.c_int32),
+        ("height", ctypes.c_float),
+        ("width", ctypes.c_float),
+        ("epsilon", ctypes.c_float),
+        ("location_lo", ctypes.c_float * 3),
+        ("location_hi", ctypes.c_float * 3),
+        ("dimension_lo", ctypes.c_float * 3),
+        ("dimension_hi", ctypes.c_float * 3),
+        ("num_steps", ctypes.c_int32),
+        ("max_temperature", ctypes.c_float),
+        ("min_temperature", ctypes.c_float),
+        ("max_std", ctypes.c_float),
+        ("min_std", ctypes.c_float),
+        ("weight_iou", ctypes.c_float),
+        ("weight_l1", ctypes.c_float),
+        ("weight_silhouette", ctypes.c_float),
+        ("beta1", ctypes.c_float),
+        ("beta2", ctypes.c_float),
+        ("adam_epsilon", ctypes.c_float),
+        ("lr_gamma", ctypes.c_float),
+    ]
+
+
+class AdamTensors(ctypes.Structure):
+    _fields_ = [
+        ("parameter", ctypes.c_void_p),
+        ("exp_avg", ctypes.c_void_p),
+        ("exp_avg_sq", ctypes.c_void_p),
+        ("step", ctypes.c_void_p),
+        ("learning_rate", ctypes.c_void_p),
     ]
 
 
@@ -95,6 +135,13 @@ SIGNATURES = {
                                           ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
     "vsrd_match_boxes": (ctypes.c_int32, [c_float_p, c_float_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "vsrd_linear_sum_assignment": (ctypes.c_int32, [c_float_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "vsrd_frame_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
+    "vsrd_frame_prologue": (ctypes.c_int32, [ctypes.POINTER(FrameConfig), c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, c_float_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
+    "vsrd_frame_epilogue": (ctypes.c_int32, [ctypes.POINTER(FrameConfig), c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_float,
+                                             ctypes.POINTER(AdamTensors), ctypes.POINTER(AdamTensors), ctypes.POINTER(AdamTensors),
+                                             c_float_p, c_float_p, ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_void_p]),
     "vsrd_project_boxes_backward": (ctypes.c_int32, [c_float_p, c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                                      ctypes.c_int32, ctypes.c_float, c_float_p, ctypes.c_void_p, c_float_p,
                                                      ctypes.c_void_p]),
@@ -165,7 +212,7 @@ def make_field(instances, temperature, mlp_weights=None):
 
 
 def make_config(num_rays, num_samples, distance_range, sdf_std_deviation, cosine_ratio, epsilon, origin_stride,
-                seed=0, stream_offset=0, flags=0, schedule=None):
+                seed=0, stream_offset=0, flags=0, schedule=None, gather=None):
     """`schedule`: optional device tensor float32 [3] = (temperature, sdf_std_deviation, cosine_ratio) read by the kernels at
     start instead of the by-value scalars; `stream_offset` may likewise be a device int64 tensor (hipGraph replay)."""
     schedule_ptr = offset_ptr = None
@@ -177,6 +224,16 @@ def make_config(num_rays, num_samples, distance_range, sdf_std_deviation, cosine
         if stream_offset.dtype != torch.int64 or stream_offset.numel() != 1 or not stream_offset.is_cuda:
             raise ValueError("a tensor stream_offset must be a device int64 scalar")
         offset_ptr, stream_offset = stream_offset.data_ptr(), 0
+    ray_indices = target_columns = None
+    rays_per_origin = target_stride = 0
+    if gather is not None:        # (ray_indices int64 [R], rays_per_origin, target_columns int32 [N] or None, target_stride): vsrd_render_config gather
+        indices, rays_per_origin, columns, target_stride = gather
+        if indices.dtype != torch.int64 or not indices.is_cuda or not indices.is_contiguous() or indices.numel() != int(num_rays):
+            raise ValueError("ray_indices must be a contiguous int64 device tensor with one entry per ray")
+        ray_indices = indices.data_ptr()
+        if columns is not None:
+            target_columns = iptr(columns).value
     return RenderConfig(int(num_rays), int(num_samples), float(distance_range[0]), float(distance_range[1]),
                         float(sdf_std_deviation), float(cosine_ratio), float(epsilon), int(origin_stride),
-                        int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_offset) & 0xFFFFFFFFFFFFFFFF, int(flags), schedule_ptr, offset_ptr)
+                        int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_offset) & 0xFFFFFFFFFFFFFFFF, int(flags), schedule_ptr, offset_ptr,
+                        ray_indices, int(rays_per_origin), target_columns, int(target_stride))

@@ -6,6 +6,7 @@
 #include "matching.h"
 #include "ray_sampling.h"
 #include "projection.h"
+#include "frame_step.h"
 
 namespace {
 
@@ -81,9 +82,15 @@ bool valid_field(const vsrd_field* f) {
            f->temperature > 0.0f;
 }
 
-bool valid_config(const vsrd_render_config* c) {
-    return c != nullptr && c->num_rays >= 0 && c->num_samples >= 2 && c->num_samples <= VSRD_MAX_SAMPLES &&
-           c->sdf_std_deviation > 0.0f && (c->origin_stride == 0 || c->origin_stride == 3);
+bool valid_config(const vsrd_render_config* c, bool gather_allowed = false) {
+    if (c == nullptr || c->num_rays < 0 || c->num_samples < 2 || c->num_samples > VSRD_MAX_SAMPLES || !(c->sdf_std_deviation > 0.0f) ||
+        (c->origin_stride != 0 && c->origin_stride != 3))
+        return false;
+    const bool gather = c->ray_indices != nullptr || c->target_columns != nullptr;
+    if (gather && !gather_allowed) return false;                 // only the fused step kernels read through an index
+    if (c->ray_indices != nullptr && c->rays_per_origin < 0) return false;
+    if (c->target_columns != nullptr && c->target_stride < 1) return false;
+    return true;
 }
 
 FieldArgs field_args(const vsrd_field* f) {
@@ -114,6 +121,10 @@ RenderArgs render_args(const vsrd_render_config* c) {
     a.flags = c->flags;
     a.dynamic = c->device_schedule;
     a.dynamic_offset = reinterpret_cast<const unsigned long long*>(c->device_stream_offset);
+    a.ray_indices = reinterpret_cast<const long long*>(c->ray_indices);
+    a.rays_per_origin = c->rays_per_origin;
+    a.target_columns = c->target_columns;
+    a.target_stride = c->target_stride;
     return a;
 }
 
@@ -485,7 +496,7 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
                                     const float* targets, const float* instance_weights, float loss_scale,
                                     void* workspace, size_t workspace_bytes,
                                     float* loss, float* grad_instances, float* labels, void* stream) {
-    if (!valid_field(field) || !valid_config(config) || !workspace || !loss || !grad_instances) return VSRD_E_INVALID_ARGUMENT;
+    if (!valid_field(field) || !valid_config(config, true) || !workspace || !loss || !grad_instances) return VSRD_E_INVALID_ARGUMENT;
     if (field->mlp_weights != nullptr) return VSRD_E_UNSUPPORTED;            // box-only fast path
     const int N = field->num_instances;
     if (workspace_bytes < vsrd_workspace_bytes(N, 0)) return VSRD_E_WORKSPACE;
@@ -536,7 +547,7 @@ int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_con
                                   const float* targets, const float* instance_weights, float loss_scale, float eikonal_ratio,
                                   void* workspace, size_t workspace_bytes,
                                   float* losses, float* grad_instances, float* grad_mlp_weights, float* labels, void* stream) {
-    if (!valid_field(field) || !valid_config(config) || !workspace || !losses || !grad_instances || !grad_mlp_weights) return VSRD_E_INVALID_ARGUMENT;
+    if (!valid_field(field) || !valid_config(config, true) || !workspace || !losses || !grad_instances || !grad_mlp_weights) return VSRD_E_INVALID_ARGUMENT;
     if (field->mlp_weights == nullptr) return VSRD_E_INVALID_ARGUMENT;       // box-only fields: vsrd_render_silhouette_step
     const int N = field->num_instances;
     if (workspace_bytes < vsrd_workspace_bytes(N, 1)) return VSRD_E_WORKSPACE;
@@ -586,6 +597,76 @@ int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_con
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(row), dim3(256), 0, s, partials, num_waves, row, grad_instances);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(mlp_row), dim3(256), 0, s, mlp_partials, num_waves, mlp_row, grad_mlp_weights);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), dim3(256), 0, s, loss_partials, num_waves, 2, losses);
+    return launch_status();
+}
+
+size_t vsrd_frame_scratch_bytes(int32_t num_views, int32_t num_boxes) {
+    if (num_views < 1 || num_views > kFrameMaxViews || num_boxes < 1 || num_boxes > kFrameMaxBoxes) return 0;
+    return frame_scratch_floats(num_views, num_boxes) * sizeof(float);
+}
+
+namespace {
+bool frame_args(const vsrd_frame_config* c, FrameStepArgs* a) {
+    if (!c || c->num_boxes < 1 || c->num_boxes > kFrameMaxBoxes || c->num_views < 1 || c->num_views > kFrameMaxViews || c->num_steps < 1) return false;
+    a->num_boxes = c->num_boxes; a->num_views = c->num_views;
+    a->height = c->height; a->width = c->width; a->epsilon = c->epsilon;
+    for (int j = 0; j < 3; ++j) {
+        a->location_lo[j] = c->location_lo[j]; a->location_hi[j] = c->location_hi[j];
+        a->dimension_lo[j] = c->dimension_lo[j]; a->dimension_hi[j] = c->dimension_hi[j];
+    }
+    a->num_steps = c->num_steps;
+    a->max_temperature = c->max_temperature; a->min_temperature = c->min_temperature; a->max_std = c->max_std; a->min_std = c->min_std;
+    a->weight_iou = c->weight_iou; a->weight_l1 = c->weight_l1; a->weight_silhouette = c->weight_silhouette;
+    a->beta1 = c->beta1; a->beta2 = c->beta2; a->adam_epsilon = c->adam_epsilon; a->lr_gamma = c->lr_gamma;
+    return true;
+}
+}  // namespace
+
+int32_t vsrd_frame_prologue(const vsrd_frame_config* config, const float* raw_locations, const float* raw_dimensions,
+                            const float* raw_orientations, const float* extrinsics, const float* intrinsics, const float* gt_boxes,
+                            const uint8_t* visible, const int64_t* step, void* scratch, size_t scratch_bytes,
+                            float* instances, int64_t* pd_indices, int64_t* gt_indices, int32_t* target_columns, float* instance_weights,
+                            float* schedule, float* projection_losses, float* grad_raw, void* stream) {
+    FrameStepArgs a;
+    if (!frame_args(config, &a)) return VSRD_E_INVALID_ARGUMENT;
+    if (!raw_locations || !raw_dimensions || !raw_orientations || !extrinsics || !intrinsics || !gt_boxes || !visible || !step || !instances ||
+        !pd_indices || !gt_indices || !target_columns || !instance_weights || !schedule || !projection_losses || !grad_raw)
+        return VSRD_E_INVALID_ARGUMENT;
+    if (!scratch || scratch_bytes < vsrd_frame_scratch_bytes(a.num_views, a.num_boxes)) return VSRD_E_WORKSPACE;
+    FrameBuffers b;
+    b.raw_locations = raw_locations; b.raw_dimensions = raw_dimensions; b.raw_orientations = raw_orientations;
+    b.extrinsics = extrinsics; b.intrinsics = intrinsics; b.gt_boxes = gt_boxes; b.visible = visible;
+    b.step = reinterpret_cast<const long long*>(step);
+    b.scratch = static_cast<float*>(scratch);
+    b.instances = instances;
+    b.pd_indices = reinterpret_cast<long long*>(pd_indices); b.gt_indices = reinterpret_cast<long long*>(gt_indices);
+    b.target_map = target_columns; b.instance_weights = instance_weights; b.schedule = schedule; b.losses = projection_losses; b.grad_raw = grad_raw;
+    hipLaunchKernelGGL(frame_prologue_kernel, dim3(1), dim3(kFrameThreads), 0, static_cast<hipStream_t>(stream), a, b);
+    return launch_status();
+}
+
+int32_t vsrd_frame_epilogue(const vsrd_frame_config* config, const float* grad_instances, const float* grad_raw_projection,
+                            const float* projection_losses, const float* render_losses, float eikonal_ratio,
+                            const vsrd_adam_tensors* locations, const vsrd_adam_tensors* dimensions, const vsrd_adam_tensors* orientations,
+                            float* other_learning_rate_0, float* other_learning_rate_1, int64_t* step,
+                            float* record, float* raw_gradients, void* stream) {
+    FrameStepArgs a;
+    if (!frame_args(config, &a)) return VSRD_E_INVALID_ARGUMENT;
+    if (!grad_instances || !grad_raw_projection || !projection_losses || !render_losses || !locations || !dimensions || !orientations || !step || !record)
+        return VSRD_E_INVALID_ARGUMENT;
+    const vsrd_adam_tensors* groups[3] = {locations, dimensions, orientations};
+    AdamTensors tensors[3];
+    for (int k = 0; k < 3; ++k) {
+        if (!groups[k]->parameter || !groups[k]->exp_avg || !groups[k]->exp_avg_sq || !groups[k]->step || !groups[k]->learning_rate) return VSRD_E_INVALID_ARGUMENT;
+        tensors[k] = AdamTensors{groups[k]->parameter, groups[k]->exp_avg, groups[k]->exp_avg_sq, groups[k]->step, groups[k]->learning_rate};
+    }
+    EpilogueBuffers e;
+    e.grad_instances = grad_instances; e.grad_raw_projection = grad_raw_projection; e.projection_losses = projection_losses;
+    e.render_losses = render_losses; e.eikonal_ratio = eikonal_ratio;
+    e.locations = tensors[0]; e.dimensions = tensors[1]; e.orientations = tensors[2];
+    e.other_learning_rates[0] = other_learning_rate_0; e.other_learning_rates[1] = other_learning_rate_1;
+    e.step = reinterpret_cast<long long*>(step); e.record = record; e.raw_gradients = raw_gradients;
+    hipLaunchKernelGGL(frame_epilogue_kernel, dim3(1), dim3(kFrameMaxBoxes), 0, static_cast<hipStream_t>(stream), a, e);
     return launch_status();
 }
 

@@ -42,7 +42,34 @@ struct RenderArgs {
     unsigned flags;
     const float* dynamic;                         // vsrd_render_config::device_schedule
     const unsigned long long* dynamic_offset;     // vsrd_render_config::device_stream_offset
+    const long long* ray_indices;                 // vsrd_render_config::ray_indices (fused step kernels only)
+    int rays_per_origin;
+    const int* target_columns;
+    int target_stride;
 };
+
+// Row of the frame-resident tensors that step ray `ray` reads (vsrd_render_config::ray_indices), as a wave-uniform value.
+__device__ __forceinline__ long long source_row(const RenderArgs& c, int ray) {
+    return c.ray_indices ? c.ray_indices[ray] : static_cast<long long>(ray);
+}
+
+__device__ __forceinline__ Ray load_ray_gathered(const RenderArgs& c, const float* __restrict__ origins, const float* __restrict__ directions, long long row) {
+    const long long origin_row = (c.ray_indices && c.rays_per_origin > 0) ? row / c.rays_per_origin : row;
+    const float* o = origins + origin_row * c.origin_stride;
+    const float* d = directions + row * 3;
+    Ray r;
+    r.ox = uniform(o[0]); r.oy = uniform(o[1]); r.oz = uniform(o[2]);
+    r.rx = uniform(d[0]); r.ry = uniform(d[1]); r.rz = uniform(d[2]);
+    return r;
+}
+
+// Target of predicted instance `lane` for the ray read from row `row` (vsrd_render_config::target_columns).
+__device__ __forceinline__ float load_target(const RenderArgs& c, const float* __restrict__ targets, long long row, int lane, int N) {
+    if (lane >= N) return 0.0f;
+    if (c.target_columns == nullptr) return targets[row * N + lane];
+    const int column = c.target_columns[lane];
+    return (column >= 0) ? targets[row * c.target_stride + column] : 0.0f;
+}
 
 // Phase clocks (experiments only: -DVSRD_PHASE_TIMERS, tools/phase_timers.py): every wave adds the s_memtime ticks it spends in each
 // phase of the fused step kernels to a global table that vsrd_debug_phase_cycles reads back.  Compiled out by default.
@@ -711,8 +738,9 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
     for (int ray = static_cast<int>(blockIdx.x) * waves_per_block() + wave; ray < c.num_rays; ray += stride) {
         wave_lds_sync();
         VSRD_PHASE(7);
-        const Ray r = load_ray(origins, directions, c.origin_stride, ray);
-        const float target = (lane < N) ? targets[static_cast<size_t>(ray) * N + lane] : 0.0f;
+        const long long row = source_row(c, ray);
+        const Ray r = load_ray_gathered(c, origins, directions, row);
+        const float target = load_target(c, targets, row, lane, N);
         const RayCull rc = cull_ray_setup(instances, N, r.ox, r.oy, r.oz, r.rx, r.ry, r.rz, l.cull, lane);
         stage_ray_samples<kRoundsS>(l, c, S, ray, u_coarse, u_fine, nullptr, nullptr, sorted_input, lane);
         VSRD_PHASE(0);
@@ -818,8 +846,9 @@ __global__ __launch_bounds__(kBlockThreads) void render_residual_step_kernel(
             wave_lds_sync();
             for (int idx = lane; idx < kRounds * N; idx += kWave) ray_masks[idx] = 0u;
             if (ray >= c.num_rays) continue;
-            const Ray r = load_ray(origins, directions, c.origin_stride, ray);
-            const float target = (lane < N) ? targets[static_cast<size_t>(ray) * N + lane] : 0.0f;
+            const long long row = source_row(c, ray);
+            const Ray r = load_ray_gathered(c, origins, directions, row);
+            const float target = load_target(c, targets, row, lane, N);
             const RayCull rc = cull_ray_setup(instances, N, r.ox, r.oy, r.oz, r.rx, r.ry, r.rz, l.cull, lane);
             stage_ray_samples<kRoundsS>(l, c, S, ray, u_coarse, u_fine, nullptr, nullptr, sorted_input, lane);
             VSRD_PHASE(0);

@@ -20,7 +20,7 @@ import threading
 
 import torch
 
-from . import fields, losses, models, operations, rendering
+from . import _lib, fields, losses, models, operations, rendering
 
 
 _capture_lock = threading.Lock()
@@ -59,9 +59,18 @@ class OptimizationConfig:
 
 
 class FrameOptimizer:
-    def __init__(self, inputs: FrameInputs, config: OptimizationConfig, device, graph=False):
+    """``graph=True``: the step is captured in a hipGraph and replayed.  ``fused_glue`` (default: on in graph mode): everything around
+    the render launch that concerns the boxes -- decode, projection, matching, projection losses and their gradients, schedules,
+    the chain rule through the decode, Adam and the learning-rate decay -- runs as two single-workgroup HIP kernels
+    (csrc/frame_step.h) instead of ~330 torch element-wise launches, and the render kernel gathers its rays from the
+    frame-resident tensors by index; torch keeps the hypernetwork (rocBLAS GEMMs) and its Adam in the residual phase."""
+
+    def __init__(self, inputs: FrameInputs, config: OptimizationConfig, device, graph=False, fused_glue=None):
         self.inputs, self.config, self.device = inputs, config, torch.device(device)
         self.graph = bool(graph)
+        self.fused_glue = self.graph if fused_glue is None else bool(fused_glue)
+        if self.fused_glue and not self.graph:
+            raise ValueError("fused_glue keeps the learning rates and Adam's counters on the device: it needs graph=True")
         V, H, W, N = inputs.soft_masks.shape
         self.num_views, self.num_instances = V, N
         self.detector = models.BoxParameters3D(1, N).to(self.device)
@@ -101,6 +110,117 @@ class FrameOptimizer:
                              "(torch.multinomial without replacement raises in the reference as well)")
         self.pixels_per_view = H * W
         self.step_index = 0
+        if self.fused_glue:
+            self._init_fused_glue()
+
+    # ---- fused glue (csrc/frame_step.h) ---------------------------------------------------------------------------------
+    def _init_fused_glue(self):
+        cfg, inp, dev = self.config, self.inputs, self.device
+        V, N = self.num_views, self.num_instances
+        lib = _lib.load()
+        det = self.detector
+        w = cfg.loss_weights
+        frame = _lib.FrameConfig()
+        frame.num_boxes, frame.num_views = N, V
+        frame.height, frame.width, frame.epsilon = float(inp.image_size[0]), float(inp.image_size[1]), 1.0e-6
+        for j in range(3):
+            frame.location_lo[j], frame.location_hi[j] = float(det.location_range[0, j]), float(det.location_range[1, j])
+            frame.dimension_lo[j], frame.dimension_hi[j] = float(det.dimension_range[0, j]), float(det.dimension_range[1, j])
+        frame.num_steps = cfg.num_steps
+        frame.max_temperature, frame.min_temperature = cfg.max_sdf_union_temperature, cfg.min_sdf_union_temperature
+        frame.max_std, frame.min_std = cfg.max_sdf_std_deviation, cfg.min_sdf_std_deviation
+        frame.weight_iou, frame.weight_l1, frame.weight_silhouette = w["iou_projection_loss"], w["l1_projection_loss"], w["silhouette_loss"]
+        frame.beta1, frame.beta2, frame.adam_epsilon, frame.lr_gamma = 0.9, 0.999, 1.0e-8, cfg.lr_gamma
+        self._frame = frame
+        f32 = dict(dtype=torch.float32, device=dev)
+        b = self._glue = {}
+        b["extrinsics"] = inp.extrinsic_matrices.to(**f32).reshape(V, 16).contiguous()
+        b["intrinsics"] = inp.intrinsic_matrices.to(**f32).reshape(V, 9).contiguous()
+        b["gt_boxes"] = inp.boxes_2d.to(**f32).reshape(V, N, 4).contiguous()
+        b["visible"] = inp.visible_masks.to(device=dev, dtype=torch.uint8).contiguous()
+        b["scratch"] = torch.empty(lib.vsrd_frame_scratch_bytes(V, N), dtype=torch.uint8, device=dev)
+        b["instances"] = torch.zeros(N, 16, **f32)
+        b["pd_indices"], b["gt_indices"] = torch.zeros(N, dtype=torch.int64, device=dev), torch.zeros(N, dtype=torch.int64, device=dev)
+        b["target_columns"] = torch.zeros(N, dtype=torch.int32, device=dev)
+        b["instance_weights"] = torch.ones(N, **f32)
+        b["projection_losses"], b["render_losses"] = torch.zeros(2, **f32), torch.zeros(2, **f32)
+        b["grad_raw"], b["raw_gradients"] = torch.zeros(N, 8, **f32), torch.zeros(N, 8, **f32)
+        b["grad_instances"], b["grad_mlp"] = torch.zeros(N, 16, **f32), torch.zeros(N, _lib.MLP_WEIGHTS, **f32)
+        b["record"] = torch.zeros(5, **f32)
+        b["masks"] = self.flat_masks.to(**f32).contiguous()
+        # Adam's state for the three box tensors exactly as torch.optim.Adam(capturable=True) lays it out, created up front (torch
+        # creates it lazily at a parameter's first step): the epilogue kernel updates these tensors in place, so checkpoints and
+        # optimizer.state_dict() see them like any other state
+        adam = []
+        for group, p in zip(self.optimizer.param_groups[:3], (det.locations, det.dimensions, det.orientations)):
+            state = self.optimizer.state[p]
+            if not state:
+                state["step"] = torch.zeros((), **f32)
+                state["exp_avg"], state["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
+            adam.append(_lib.AdamTensors(p.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(), state["step"].data_ptr(),
+                                         group["lr"].data_ptr()))
+        self._adam = adam
+
+    def _fused_step(self, ray_indices, count=True):
+        """One step with the box-side glue in frame_step.h.  Same arithmetic as `_step_in_scope` (the eager torch path is its
+        parity reference: tests/test_hip_step.py)."""
+        cfg, b, lib, frame = self.config, self._glue, _lib.load(), self._frame
+        det = self.detector
+        N = self.num_instances
+        residual = self.step_index >= cfg.warmup_steps
+        stream = _lib.stream()
+        _lib.check(lib.vsrd_frame_prologue(frame, _lib.ptr(det.locations.data), _lib.ptr(det.dimensions.data), _lib.ptr(det.orientations.data),
+                                           _lib.ptr(b["extrinsics"]), _lib.ptr(b["intrinsics"]), _lib.ptr(b["gt_boxes"]), b["visible"].data_ptr(),
+                                           self.step_tensor.data_ptr(), b["scratch"].data_ptr(), b["scratch"].numel(), _lib.ptr(b["instances"]),
+                                           b["pd_indices"].data_ptr(), b["gt_indices"].data_ptr(), b["target_columns"].data_ptr(),
+                                           _lib.ptr(b["instance_weights"]), _lib.ptr(self.schedule), _lib.ptr(b["projection_losses"]), _lib.ptr(b["grad_raw"]), stream))
+        if ray_indices is None:
+            ray_indices = self.sample_rays()
+        ray_indices = ray_indices.contiguous()
+        R = int(ray_indices.numel())
+        weights = cfg.loss_weights
+        eikonal_ratio = weights["eikonal_loss"] / weights["silhouette_loss"] if residual else 0.0
+        from .rendering import renderers
+        flags = renderers._base_flags()
+        mlp_weights = centred = None
+        if residual:
+            self.optimizer.zero_grad(set_to_none=True)
+            mlp_weights = self.hyper_distance_field(det.embeddings)[0].contiguous()          # [N,1617] (torch: rocBLAS GEMMs)
+            centred = renderers._centre_mlp(mlp_weights)
+            flags |= _lib.FLAG_MLP_WEIGHTS_CENTRED
+        elif cfg.skip_exact_misses:
+            flags |= _lib.FLAG_SKIP_EXACT_MISSES
+        workspace = self.workspace.adjoint(self.device, N, residual)
+        field = _lib.make_field(b["instances"], 1.0, centred)          # (the temperature comes from the device schedule)
+        config = _lib.make_config(R, cfg.num_samples, cfg.distance_range, 1.0, 1.0, 1.0e-6, 3, seed=cfg.seed, stream_offset=self.step_tensor, flags=flags,
+                                  schedule=self.schedule, gather=(ray_indices, self.pixels_per_view, b["target_columns"], N))
+        loss_scale = 1.0 / (R * N)
+        if residual:
+            _lib.check(lib.vsrd_render_residual_step(field, config, _lib.ptr(self.camera_positions), _lib.ptr(self.ray_directions), None, None,
+                                                     _lib.ptr(b["masks"]), _lib.ptr(b["instance_weights"]), loss_scale, float(eikonal_ratio),
+                                                     workspace.data_ptr(), workspace.numel(), _lib.ptr(b["render_losses"]), _lib.ptr(b["grad_instances"]),
+                                                     _lib.ptr(b["grad_mlp"]), None, stream))
+        else:
+            _lib.check(lib.vsrd_render_silhouette_step(field, config, _lib.ptr(self.camera_positions), _lib.ptr(self.ray_directions), None, None,
+                                                       _lib.ptr(b["masks"]), _lib.ptr(b["instance_weights"]), loss_scale,
+                                                       workspace.data_ptr(), workspace.numel(), _lib.ptr(b["render_losses"]), _lib.ptr(b["grad_instances"]),
+                                                       None, stream))
+        groups = self.optimizer.param_groups
+        _lib.check(lib.vsrd_frame_epilogue(frame, _lib.ptr(b["grad_instances"]), _lib.ptr(b["grad_raw"]), _lib.ptr(b["projection_losses"]),
+                                           _lib.ptr(b["render_losses"]), float(eikonal_ratio), self._adam[0], self._adam[1], self._adam[2],
+                                           _lib.ptr(groups[3]["lr"]), _lib.ptr(groups[4]["lr"]), self.step_tensor.data_ptr(),
+                                           _lib.ptr(b["record"]), _lib.ptr(b["raw_gradients"]), stream))
+        if residual:      # the hypernetwork and the embeddings stay with autograd + torch.optim.Adam (the box tensors have no .grad: skipped)
+            mlp_weights.backward(b["grad_mlp"] * weights["silhouette_loss"])
+            self.optimizer.step()
+        if count:
+            self.step_index += 1
+        record, raw = b["record"], b["raw_gradients"]
+        result = dict(iou_projection_loss=record[0], l1_projection_loss=record[1], silhouette_loss=record[2], loss=record[4],
+                      raw_gradients=[raw[:, 0:3].unsqueeze(0), raw[:, 3:6].unsqueeze(0), raw[:, 6:8].unsqueeze(0)])
+        if residual:
+            result["eikonal_loss"] = record[3]
+        return result
 
     # ------------------------------------------------------------------------------------------------
     def sample_rays(self):
@@ -174,6 +294,8 @@ class FrameOptimizer:
 
     def _step(self, ray_indices, u_coarse, u_fine, count=True):
         with rendering.workspace_scope(self.workspace):
+            if self.fused_glue:
+                return self._fused_step(ray_indices, count)
             return self._step_in_scope(ray_indices, u_coarse, u_fine, count)
 
     def _step_in_scope(self, ray_indices, u_coarse, u_fine, count):
