@@ -36,7 +36,8 @@ def c1_frame(seed=0, V=3, H=128, W=128, N=4):
     loc, dim, rot, corners = ogeometry.decode_box_parameters(raw_loc, raw_dim, raw_ori)
     gt_boxes, _ = ogeometry.project_boxes_multi_view(corners, E, K, (H, W))
     visible = torch.ones(V, N, dtype=torch.bool)
-    visible[2, 3] = False
+    if V > 2 and N > 3:
+        visible[2, 3] = False
     gt_boxes = gt_boxes * visible[..., None, None]
     return K, E, (loc, dim, rot), gt_boxes, visible
 
@@ -535,14 +536,19 @@ def test_checkpoint_round_trip_and_workspace_lifetime(dev, graph, tmp_path):
     assert float(state["step"]) == steps and state["step"].device.type == "cpu"
     torch.testing.assert_close(state["exp_avg"], loop.optimizer.state[loop.detector.locations]["exp_avg"].cpu())
     optimizer.step()                                                        # usable: grads are None, nothing moves, nothing raises
-    # the scratch dies with the optimizer
+    # the scratch dies with the optimizer (a captured graph's private pool is torch's to release: measured around close() alone)
     held = loop.workspace.nbytes()
     assert held >= 16384 * 4 * N * 16 * 4
+    torch.cuda.synchronize()
+    during = torch.cuda.memory_allocated(dev)
+    workspace = loop.workspace
     loop.close()
     del loop
     gc.collect()
     torch.cuda.synchronize()
-    assert torch.cuda.memory_allocated(dev) - before < held // 2
+    assert workspace.nbytes() == 0 and during - torch.cuda.memory_allocated(dev) >= held // 2
+    if not graph:
+        assert torch.cuda.memory_allocated(dev) - before < held // 2
     with pytest.raises(TypeError):
         rendering.workspace_scope(1234)
     with pytest.raises(ValueError):                                         # fewer positive pixels than rays: torch.multinomial's error, up front
