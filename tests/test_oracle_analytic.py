@@ -58,3 +58,10 @@ def test_residual_mlp_jet_adjoint_matches_autograd():
         a_p, a_w = analytic_mlp.backward(p, w, res_bar, gres_bar)
         np.testing.assert_allclose(a_p, gp.numpy(), rtol=1e-8, atol=1e-12)
         np.testing.assert_allclose(a_w, gw.numpy(), rtol=1e-8, atol=1e-12 * max(1.0, float(gw.abs().max())))
+        # the single-tangent form of the adjoint (what residual.h runs) and the value + reverse-column form of the forward
+        d_p, d_w = analytic_mlp.backward_directional(p, w, res_bar, gres_bar)
+        np.testing.assert_allclose(d_p, gp.numpy(), rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(d_w, gw.numpy(), rtol=1e-8, atol=1e-12 * max(1.0, float(gw.abs().max())))
+        r_res, r_gres = analytic_mlp.forward_reverse(p, w)
+        np.testing.assert_allclose(r_res, res.item(), rtol=1e-12)
+        np.testing.assert_allclose(r_gres, gres[0].detach().numpy(), rtol=1e-9, atol=1e-14)

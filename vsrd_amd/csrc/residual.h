@@ -334,21 +334,29 @@ __device__ __forceinline__ void load_backward_weights(GlobalWeights w, int lane,
         for (int s = 0; s < 4; ++s) bw.at0[c][s] = w[(4 * g + s) * kMlpRow0 + 16 * c + i];
 }
 
+// ---- single-tangent jets (the adjoint) -------------------------------------------------------------------------------------------
+// The loss sees the three tangents of the MLP output only through the linear form  sum_c gl_bar_c * kappa * fold_c / 100 * dout_c, and a
+// Jacobian-vector product is linear in its direction: with  delta = gl_bar * fold / 100  (per point) that form is kappa times the
+// tangent of `out` ALONG delta.  So the adjoint pushes the ONE tangent  sum_c delta_c dfeat_c  through the network (seed kappa)
+// instead of the three unit tangents (seeds kappa delta_c): the hidden layers carry 2 columns instead of 4 -- half their MFMAs, half
+// the LayerNorm / GELU jet algebra, half the staged tiles -- for the same derivatives (oracle/analytic_mlp.py: backward_directional,
+// checked against autograd).  delta is a constant of the adjoint (gl_bar is a seed), so nothing flows back into it.
+struct TileJet1 { f32x4 v, t; };
+
 // What the adjoint of one [LayerNorm -> GELU] needs, recomputed from the block's input jet.
 struct TileState {
     f32x4 y, g1, g2, a;         // normalised value, GELU', pdf(y)(2 - y^2), activation
-    f32x4 dy[3];                // tangents of y; the activation tangents are dy * g1
-    float q[3];                 // mean(y * dz_c)
+    f32x4 dy;                   // tangent of y; the activation tangent is dy * g1
+    float q;                    // mean(y * dz)
     float inv_s;
-    __device__ __forceinline__ f32x4 da(int c) const { return dy[c] * g1; }
+    __device__ __forceinline__ f32x4 da() const { return dy * g1; }
 };
 
-__device__ __forceinline__ void tile_state(const TileJet& z, TileState& b) {      // z has zero channel mean (load_forward_weights)
+__device__ __forceinline__ void tile_state(const TileJet1& z, TileState& b) {      // z has zero channel mean (load_forward_weights)
     const float var = rows_sum(dot4(z.v, z.v)) * (1.0f / kMlpHidden);
     b.inv_s = __builtin_amdgcn_rsqf(var + kLayerNormEps);
     b.y = z.v * splat4(b.inv_s);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) b.q[c] = rows_sum(dot4(b.y, z.t[c])) * (1.0f / kMlpHidden);
+    b.q = rows_sum(dot4(b.y, z.t)) * (1.0f / kMlpHidden);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float y = b.y[j];
@@ -356,10 +364,18 @@ __device__ __forceinline__ void tile_state(const TileJet& z, TileState& b) {    
         b.g1[j] = n.cdf + y * n.pdf;
         b.g2[j] = n.pdf * (2.0f - y * y);
         b.a[j] = y * n.cdf;
+        b.dy[j] = (z.t[j] - y * b.q) * b.inv_s;
+    }
+}
+
+// Linear(16 -> 16) on a single-tangent jet.
+__device__ __forceinline__ void linear_tile(const float (&a)[4], f32x4 bias, f32x4 in_v, f32x4 in_t, TileJet1& out) {
+    out.v = bias;
+    out.t = splat4(0.0f);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            b.dy[c][j] = (z.t[c][j] - y * b.q[c]) * b.inv_s;
-        }
+    for (int s = 0; s < 4; ++s) {
+        out.v = mfma4(a[s], in_v[s], out.v);
+        out.t = mfma4(a[s], in_t[s], out.t);
     }
 }
 
@@ -370,35 +386,25 @@ __device__ __forceinline__ void layer_norm_adjoint_tile(f32x4& v, const TileStat
     v = (v - splat4(m) - b.y * splat4(my)) * splat4(b.inv_s);
 }
 
-// Adjoint of [LayerNorm -> GELU] on a jet: (a_bar, da_bar) of the activations -> adjoint zb of the block's input jet.
-// With P the LayerNorm Jacobian above, P(dz_c) = dy_c, so the input tangents themselves are not needed:
-//   z_bar = P(y_bar - sum_c dyb_c q_c / s) - sum_c dy_c mean(dyb_c y) / s + y s_bar / 16,   dz_bar_c = P(dyb_c).
-__device__ __forceinline__ void gelu_norm_adjoint_tile(const TileState& b, f32x4 a_bar, const f32x4 (&da_bar)[3], TileJet& zb) {
-    f32x4 y_bar, dyb[3];
-    float s_part = 0.0f, dot_part[3] = {0.0f, 0.0f, 0.0f};
+// Adjoint of [LayerNorm -> GELU] on a single-tangent jet: (a_bar, da_bar) of the activations -> adjoint zb of the block's input jet.
+// With P the LayerNorm Jacobian above, P(dz) = dy, so the input tangent itself is not needed:
+//   z_bar = P(y_bar - dyb q / s) - dy mean(dyb y) / s + y s_bar / 16,   dz_bar = P(dyb).
+__device__ __forceinline__ void gelu_norm_adjoint_tile(const TileState& b, f32x4 a_bar, f32x4 da_bar, TileJet1& zb) {
+    f32x4 y_bar, dyb;
+    float s_part = 0.0f, dot_part = 0.0f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        float cross = 0.0f, through_q = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            cross += da_bar[c][j] * b.dy[c][j];
-            dyb[c][j] = da_bar[c][j] * b.g1[j];
-            s_part -= dyb[c][j] * b.dy[c][j];
-            dot_part[c] += dyb[c][j] * b.y[j];
-            through_q += dyb[c][j] * b.q[c];
-        }
-        y_bar[j] = a_bar[j] * b.g1[j] + cross * b.g2[j] - through_q * b.inv_s;
+        dyb[j] = da_bar[j] * b.g1[j];
+        s_part -= dyb[j] * b.dy[j];
+        dot_part += dyb[j] * b.y[j];
+        y_bar[j] = a_bar[j] * b.g1[j] + da_bar[j] * b.dy[j] * b.g2[j] - dyb[j] * b.q * b.inv_s;
     }
     const float s_bar = rows_sum(s_part) * b.inv_s;
-    float dot[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) dot[c] = rows_sum(dot_part[c]) * (b.inv_s * (1.0f / kMlpHidden));
+    const float dot = rows_sum(dot_part) * (b.inv_s * (1.0f / kMlpHidden));
     layer_norm_adjoint_tile(y_bar, b);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) layer_norm_adjoint_tile(dyb[c], b);
-    zb.v = y_bar + b.y * splat4(s_bar * (1.0f / kMlpHidden));
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { zb.v -= b.dy[c] * splat4(dot[c]); zb.t[c] = dyb[c]; }
+    layer_norm_adjoint_tile(dyb, b);
+    zb.v = y_bar + b.y * splat4(s_bar * (1.0f / kMlpHidden)) - b.dy * splat4(dot);
+    zb.t = dyb;
 }
 
 __device__ __forceinline__ float pick4(f32x4 v, int m) { return (m == 0) ? v[0] : ((m == 1) ? v[1] : ((m == 2) ? v[2] : v[3])); }
@@ -423,6 +429,8 @@ __device__ __forceinline__ ResidualAdjoint residual_backward(const float* w_in, 
     const float fold = (px > 0.0f) ? 1.0f : ((px < 0.0f) ? -1.0f : 0.0f);
     const float inv = 1.0f / kPositionScale;
     const float f0 = fabsf(px) * inv, f1 = py * inv, f2 = pz * inv;
+    // the direction of the single tangent, per point: delta = gl_bar * fold / 100 (header comment of this section)
+    const float d0 = gbx * fold * inv, d1 = gby * inv, d2 = gbz * inv;
     const float base = (g == 0) ? 1.0f : ((g == 1) ? 4.0f : ((g == 2) ? 16.0f : 64.0f));
     const float omega_sq[2] = {(base * kPi) * (base * kPi), (2.0f * base * kPi) * (2.0f * base * kPi)};
     f32x4 acc_w[3], acc_w0[3], acc_b[3], acc_b0 = splat4(0.0f), acc_w4 = splat4(0.0f);
@@ -434,117 +442,105 @@ __device__ __forceinline__ ResidualAdjoint residual_backward(const float* w_in, 
     for (int q = 0; q < 4; ++q) {
         if (!((tiles >> q) & 1u)) continue;
         const float tfold = from_row(fold, q, lane);
-        const float folds[3] = {tfold, 1.0f, 1.0f};
-        const float gb[3] = {from_row(gbx, q, lane), from_row(gby, q, lane), from_row(gbz, q, lane)};
+        const float delta[3] = {from_row(d0, q, lane), from_row(d1, q, lane), from_row(d2, q, lane)};
         const float t_res_bar = from_row(res_bar, q, lane);
         TileFeatures e;
         encode_tile(from_row(f0, q, lane), from_row(f1, q, lane), from_row(f2, q, lane), g, e);
+        f32x4 tangent[3];                                        // d features / d epsilon along delta, per coordinate block
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tangent[c] = e.d[c] * splat4(delta[c]);
         // ---- forward, keeping the [LayerNorm -> GELU] state of every layer ----------------------------------------------------
         TileState st[4];
         {
-            TileJet z;
-            first_layer_tile(fw, e, z);
+            TileJet1 z;
+            z.v = fw.b0;
+            z.t = splat4(0.0f);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    z.v = mfma4(fw.a0[4 * c + s], e.f[c][s], z.v);
+                    z.t = mfma4(fw.a0[4 * c + s], tangent[c][s], z.t);
+                }
+            }
 #pragma unroll
             for (int l = 0; l < 3; ++l) {
                 tile_state(z, st[l]);
-                linear_tile(fw.a[l], fw.b[l], st[l].a, st[l].da(0), st[l].da(1), st[l].da(2), z);
+                linear_tile(fw.a[l], fw.b[l], st[l].a, st[l].da(), z);
             }
             tile_state(z, st[3]);
         }
         const float out_v = rows_sum(dot4(fw.w4, st[3].a)) + fw.b4;
-        float out_t[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) out_t[c] = rows_sum(dot4(fw.w4, st[3].da(c)));
-        // ---- sigmoid head ---------------------------------------------------------------------------------------------------
+        const float out_t = rows_sum(dot4(fw.w4, st[3].da()));   // tangent of the MLP output along delta  (= kappa_bar of the 3-tangent form)
+        // ---- sigmoid head:  L = res_bar * res + kappa * out_t,  res = sigmoid(out - 1),  kappa = res (1 - res) ------------------------------
         const float res = fast_rcp(1.0f + fast_exp(-(out_v - 1.0f)));
         const float kappa = res * (1.0f - res);
-        float zb_t[3], kappa_bar = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            zb_t[c] = gb[c] * kappa * folds[c] * inv;
-            kappa_bar += gb[c] * out_t[c] * folds[c] * inv;
-        }
-        const float zb_v = (t_res_bar + kappa_bar * (1.0f - 2.0f * res)) * kappa;
+        const float zb_t = kappa;
+        const float zb_v = (t_res_bar + out_t * (1.0f - 2.0f * res)) * kappa;
         // ---- block 4: LayerNorm -> GELU -> Linear(16 -> 1) -----------------------------------------------------------------
-        TileJet zb;
-        {
-            acc_w4 += splat4(zb_v) * st[3].a;
-            f32x4 da_bar[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { acc_w4 += splat4(zb_t[c]) * st[3].da(c); da_bar[c] = fw.w4 * splat4(zb_t[c]); }
-            acc_b4 += zb_v;
-            gelu_norm_adjoint_tile(st[3], fw.w4 * splat4(zb_v), da_bar, zb);
-        }
+        TileJet1 zb;
+        acc_w4 += splat4(zb_v) * st[3].a + splat4(zb_t) * st[3].da();
+        acc_b4 += zb_v;
+        gelu_norm_adjoint_tile(st[3], fw.w4 * splat4(zb_v), fw.w4 * splat4(zb_t), zb);
         // ---- blocks 3..1: LayerNorm -> GELU -> Linear(16 -> 16); zb is the adjoint of the linear's output ------------------
 #pragma unroll
         for (int l = 2; l >= 0; --l) {
             acc_b[l] += zb.v;
             stage_tile(scratch + 0 * kTileFloats, zb.v, lane);
             stage_tile(scratch + 1 * kTileFloats, st[l].a, lane);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                stage_tile(scratch + (2 + 2 * c) * kTileFloats, zb.t[c], lane);
-                stage_tile(scratch + (3 + 2 * c) * kTileFloats, st[l].da(c), lane);
-            }
+            stage_tile(scratch + 2 * kTileFloats, zb.t, lane);
+            stage_tile(scratch + 3 * kTileFloats, st[l].da(), lane);
             wave_lds_order();
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 2; ++k) {
                 const f32x4 xt = fetch_tile(scratch + (2 * k) * kTileFloats, lane), yt = fetch_tile(scratch + (2 * k + 1) * kTileFloats, lane);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) acc_w[l] = mfma4(xt[s], yt[s], acc_w[l]);
             }
             wave_lds_order();
-            f32x4 a_bar = splat4(0.0f), da_bar[3] = {splat4(0.0f), splat4(0.0f), splat4(0.0f)};
+            f32x4 a_bar = splat4(0.0f), da_bar = splat4(0.0f);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 a_bar = mfma4(bw.at[l][s], zb.v[s], a_bar);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) da_bar[c] = mfma4(bw.at[l][s], zb.t[c][s], da_bar[c]);
+                da_bar = mfma4(bw.at[l][s], zb.t[s], da_bar);
             }
-            TileJet zin_bar;
+            TileJet1 zin_bar;
             gelu_norm_adjoint_tile(st[l], a_bar, da_bar, zin_bar);
             zb = zin_bar;
         }
         // ---- first layer + encoder; zb is the adjoint of z[0] -----------------------------------------------------------------
         acc_b0 += zb.v;
         stage_tile(scratch + 0 * kTileFloats, zb.v, lane);
+        stage_tile(scratch + 1 * kTileFloats, zb.t, lane);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            stage_tile(scratch + (1 + c) * kTileFloats, zb.t[c], lane);
+            stage_tile(scratch + (2 + 2 * c) * kTileFloats, e.f[c], lane);
+            stage_tile(scratch + (3 + 2 * c) * kTileFloats, tangent[c], lane);
         }
-        stage_tile(scratch + 4 * kTileFloats, e.f[0], lane);
-        stage_tile(scratch + 5 * kTileFloats, e.d[0], lane);
-        stage_tile(scratch + 6 * kTileFloats, e.f[1], lane);
-        stage_tile(scratch + 7 * kTileFloats, e.d[1], lane);
         wave_lds_order();
-        const f32x4 xv = fetch_tile(scratch + 0 * kTileFloats, lane);
-        f32x4 xt[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) xt[c] = fetch_tile(scratch + (1 + c) * kTileFloats, lane);
+        const f32x4 xv = fetch_tile(scratch + 0 * kTileFloats, lane), xt = fetch_tile(scratch + 1 * kTileFloats, lane);
         f32x4 ft[3], dt[3];
-        ft[0] = fetch_tile(scratch + 4 * kTileFloats, lane); dt[0] = fetch_tile(scratch + 5 * kTileFloats, lane);
-        ft[1] = fetch_tile(scratch + 6 * kTileFloats, lane); dt[1] = fetch_tile(scratch + 7 * kTileFloats, lane);
-        wave_lds_order();
-        stage_tile(scratch + 4 * kTileFloats, e.f[2], lane);
-        stage_tile(scratch + 5 * kTileFloats, e.d[2], lane);
-        wave_lds_order();
-        ft[2] = fetch_tile(scratch + 4 * kTileFloats, lane); dt[2] = fetch_tile(scratch + 5 * kTileFloats, lane);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ft[c] = fetch_tile(scratch + (2 + 2 * c) * kTileFloats, lane);
+            dt[c] = fetch_tile(scratch + (3 + 2 * c) * kTileFloats, lane);
+        }
         wave_lds_order();
         float f_bar[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            f32x4 feat_bar = splat4(0.0f), dfeat_bar = splat4(0.0f);
+            f32x4 feat_bar = splat4(0.0f), tangent_bar = splat4(0.0f);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 acc_w0[c] = mfma4(xv[s], ft[c][s], acc_w0[c]);
-                acc_w0[c] = mfma4(xt[c][s], dt[c][s], acc_w0[c]);
+                acc_w0[c] = mfma4(xt[s], dt[c][s], acc_w0[c]);
                 feat_bar = mfma4(bw.at0[c][s], zb.v[s], feat_bar);
-                dfeat_bar = mfma4(bw.at0[c][s], zb.t[c][s], dfeat_bar);
+                tangent_bar = mfma4(bw.at0[c][s], zb.t[s], tangent_bar);
             }
-            // d feat / d f = dfeat;  d dfeat / d f = -omega^2 feat   (feature j of this row: octave j >> 1)
+            // d feat / d f = dfeat;  d (delta dfeat) / d f = -delta omega^2 feat   (feature j of this row: octave j >> 1)
             float part = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) part += feat_bar[j] * e.d[c][j] - dfeat_bar[j] * omega_sq[j >> 1] * e.f[c][j];
+            for (int j = 0; j < 4; ++j) part += feat_bar[j] * e.d[c][j] - tangent_bar[j] * (delta[c] * omega_sq[j >> 1]) * e.f[c][j];
             f_bar[c] = rows_sum(part);
         }
         if (g == q) { mine.px = f_bar[0] * tfold * inv; mine.py = f_bar[1] * inv; mine.pz = f_bar[2] * inv; }
