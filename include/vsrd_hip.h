@@ -101,6 +101,11 @@ typedef struct vsrd_render_config {
                                              lower bound known before the instance loop (A/B switch; the kernels fall back to it by
                                              themselves wherever the bound is unavailable or too loose)                              */
 
+#define VSRD_FLAG_RESIDUAL_SINGLE_KERNEL 64u /* vsrd_render_residual_step: run the whole step in ONE kernel (render + loss + adjoint of a
+                                             batch of rays per wave, 427 registers, one wave per SIMD) instead of the default two
+                                             kernels per chunk of rays (front part + MLP adjoint distributed by instance, two waves per
+                                             SIMD each); the results agree to rounding (A/B switch)                         */
+
 #define VSRD_FLAG_GENERAL_ROTATIONS 32u     /* do not use the shortened rotation products the kernels select by themselves when every
                                              instance's rotation is exactly one about the y axis (r01 = r10 = r12 = r21 = 0, r11 = 1,
                                              what rotation_matrix_y produces); the results agree to rounding (A/B switch)              */
@@ -115,8 +120,10 @@ size_t vsrd_workspace_bytes(int32_t num_instances, int32_t residual);
  * (scripts/main.py:653-671) + eikonal term (main.py:679-687: mean over all R (2S-1) samples of (|grad sdf| - 1)^2) + adjoint, one
  * launch.  The differentiated quantity is  losses[0] + eikonal_ratio * losses[1]  with
  *   losses[0] = sum_{r,n} w_n BCE(...) * loss_scale      losses[1] = mean (|grad sdf| - 1)^2 ;
- * grad_instances [N,16] and grad_mlp_weights [N,1617] are its gradients.  Needs vsrd_workspace_bytes(N, 1) of scratch.
+ * grad_instances [N,16] and grad_mlp_weights [N,1617] are its gradients.  Needs vsrd_residual_step_workspace_bytes(N, S, R) of
+ * scratch (seeds of the MLP adjoint for a chunk of rays: the launch is cut into chunks of at most 3 GiB of them).
  * VSRD_FLAG_SKIP_EXACT_MISSES is ignored (the eikonal term needs every ray). */
+size_t vsrd_residual_step_workspace_bytes(int32_t num_instances, int32_t num_samples, int32_t num_rays);
 int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_config* config,
                                   const float* origins, const float* directions, const float* u_coarse, const float* u_fine,
                                   const float* targets /* [R,N] */, const float* instance_weights /* [N] or NULL */, float loss_scale,

@@ -25,6 +25,7 @@ FLAG_NO_CULLING = 4
 FLAG_MLP_WEIGHTS_CENTRED = 8
 FLAG_RUNNING_MINIMUM = 16
 FLAG_GENERAL_ROTATIONS = 32
+FLAG_RESIDUAL_SINGLE_KERNEL = 64
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 
@@ -122,6 +123,7 @@ SIGNATURES = {
     "vsrd_render_silhouette_step": (ctypes.c_int32, [ctypes.POINTER(Field), ctypes.POINTER(RenderConfig), c_float_p, c_float_p, c_float_p,
                                                      c_float_p, c_float_p, c_float_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,
                                                      c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
+    "vsrd_residual_step_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "vsrd_render_residual_step": (ctypes.c_int32, [ctypes.POINTER(Field), ctypes.POINTER(RenderConfig), c_float_p, c_float_p, c_float_p,
                                                    c_float_p, c_float_p, c_float_p, ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
                                                    ctypes.c_size_t, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),

@@ -542,7 +542,7 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
     return launch_status();
 }
 
-int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_config* config,
+static int32_t residual_step_single_kernel(const vsrd_field* field, const vsrd_render_config* config,
                                   const float* origins, const float* directions, const float* u_coarse, const float* u_fine,
                                   const float* targets, const float* instance_weights, float loss_scale, float eikonal_ratio,
                                   void* workspace, size_t workspace_bytes,
@@ -597,6 +597,135 @@ int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_con
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(row), dim3(256), 0, s, partials, num_waves, row, grad_instances);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(mlp_row), dim3(256), 0, s, mlp_partials, num_waves, mlp_row, grad_mlp_weights);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), dim3(256), 0, s, loss_partials, num_waves, 2, losses);
+    return launch_status();
+}
+
+
+// ---- the split form (render_kernels.h: residual_step_front_kernel + residual_mlp_adjoint_kernel), the default ---------------------
+namespace {
+
+constexpr size_t kSeedBudgetBytes = size_t(6) << 30;     // seeds of one chunk of rays: N x chunk x rounds x 2560 B (a launch is cut into chunks that fit)
+constexpr int kFrontBlocks = 512;                        // x 4 waves = two waves on each of the 1024 SIMDs
+constexpr int kMlpAdjointBlocks = 4096;                  // single-wave workgroups, dynamic item fetch (two per SIMD are resident)
+
+struct ResidualStepPlan {
+    int rounds, chunk, front_blocks, front_waves, slots_per_item, items_per_instance;
+    long long slots_per_instance;
+    size_t front_lds;
+    // workspace layout, in floats from the base
+    size_t box_partials, loss_partials, jets, box_extra, counter, segment_sums, seeds, item_rows, masks, item_flags, total_bytes;
+};
+
+bool plan_residual_step(int N, int S, int num_rays, ResidualStepPlan* p) {
+    p->rounds = rounds_for(2 * S - 1);
+    if (p->rounds < 1 || p->rounds > 4) return false;
+    p->front_lds = static_cast<size_t>(residual_front_lds_floats(S, N)) * sizeof(float) * kMaxWavesPerBlock;
+    if (p->front_lds > kLdsDefault) return false;        // (N = 64, S = 128: 81 KB -- the single-kernel form has the same limit at two waves)
+    const size_t per_ray = static_cast<size_t>(N) * p->rounds * kSeedFloats * kWave * sizeof(float);
+    long long chunk = static_cast<long long>(kSeedBudgetBytes / per_ray);
+    if (chunk < 256) chunk = 256;
+    if (chunk > num_rays) chunk = num_rays < 1 ? 1 : num_rays;
+    p->chunk = static_cast<int>(chunk);
+    const long long want = (chunk + kMaxWavesPerBlock - 1) / kMaxWavesPerBlock;
+    p->front_blocks = static_cast<int>(want > kFrontBlocks ? kFrontBlocks : want);
+    p->front_waves = p->front_blocks * kMaxWavesPerBlock;
+    p->slots_per_instance = chunk * p->rounds;
+    // items: enough of them to balance ~2000 waves, few enough that an item amortises its partial row (6.6 KB written and read once)
+    long long per_item = (p->slots_per_instance * N) / 16384;
+    per_item = per_item < 4 ? 4 : (per_item > 32 ? 32 : per_item);
+    p->slots_per_item = static_cast<int>(per_item);
+    p->items_per_instance = static_cast<int>((p->slots_per_instance + per_item - 1) / per_item);
+    size_t at = 0;
+    auto take = [&](size_t floats) { const size_t here = at; at += (floats + 3) & ~size_t(3); return here; };
+    p->box_partials = take(static_cast<size_t>(p->front_waves) * N * kGradStride);
+    p->loss_partials = take(static_cast<size_t>(p->front_waves) * 2);
+    p->jets = take(static_cast<size_t>(p->front_waves) * p->rounds * N * kWave * 4);
+    p->box_extra = take(static_cast<size_t>(N) * kGradStride);
+    p->counter = take(4);
+    p->segment_sums = take(static_cast<size_t>(N) * kItemSegments * kItemRowFloats);
+    p->seeds = take(static_cast<size_t>(N) * p->slots_per_instance * kSeedFloats * kWave);
+    p->item_rows = take(static_cast<size_t>(N) * p->items_per_instance * kItemRowFloats);
+    p->masks = take((static_cast<size_t>(N) * p->slots_per_instance + 3) / 4);
+    p->item_flags = take((static_cast<size_t>(N) * p->items_per_instance + 3) / 4);
+    p->total_bytes = at * sizeof(float);
+    return true;
+}
+
+}  // namespace
+
+size_t vsrd_residual_step_workspace_bytes(int32_t num_instances, int32_t num_samples, int32_t num_rays) {
+    if (num_instances < 1 || num_instances > VSRD_MAX_INSTANCES || num_samples < 2 || num_samples > VSRD_MAX_SAMPLES || num_rays < 0) return 0;
+    ResidualStepPlan p;
+    size_t need = vsrd_workspace_bytes(num_instances, 1);                 // (VSRD_FLAG_RESIDUAL_SINGLE_KERNEL and shapes the split form does not take)
+    if (plan_residual_step(num_instances, num_samples, num_rays, &p) && p.total_bytes > need) need = p.total_bytes;
+    return need;
+}
+
+int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_config* config,
+                                  const float* origins, const float* directions, const float* u_coarse, const float* u_fine,
+                                  const float* targets, const float* instance_weights, float loss_scale, float eikonal_ratio,
+                                  void* workspace, size_t workspace_bytes,
+                                  float* losses, float* grad_instances, float* grad_mlp_weights, float* labels, void* stream) {
+    if (!valid_field(field) || !valid_config(config, true) || !workspace || !losses || !grad_instances || !grad_mlp_weights) return VSRD_E_INVALID_ARGUMENT;
+    if (field->mlp_weights == nullptr) return VSRD_E_INVALID_ARGUMENT;       // box-only fields: vsrd_render_silhouette_step
+    const int N = field->num_instances, S = config->num_samples;
+    ResidualStepPlan p;
+    if ((config->flags & VSRD_FLAG_RESIDUAL_SINGLE_KERNEL) || config->num_rays == 0 || !plan_residual_step(N, S, config->num_rays, &p))
+        return residual_step_single_kernel(field, config, origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, eikonal_ratio,
+                                           workspace, workspace_bytes, losses, grad_instances, grad_mlp_weights, labels, stream);
+    if (workspace_bytes < p.total_bytes) return VSRD_E_WORKSPACE;
+    if (!origins || !directions || !targets) return VSRD_E_INVALID_ARGUMENT;
+    const hipStream_t s = static_cast<hipStream_t>(stream);
+    const int row = N * kGradStride, mlp_row = N * kMlpWeights;
+    const int num_points = 2 * S - 1;
+    const FieldArgs f = field_args(field);
+    RenderArgs c = render_args(config);
+    c.sh.inv_t = f.inv_t;
+    float* base = static_cast<float*>(workspace);
+    float* box_partials = base + p.box_partials;
+    float* loss_partials = base + p.loss_partials;
+    float4* jets = reinterpret_cast<float4*>(base + p.jets);
+    float* box_extra = base + p.box_extra;
+    unsigned* counter = reinterpret_cast<unsigned*>(base + p.counter);
+    float* segment_sums = base + p.segment_sums;
+    float* seeds = base + p.seeds;
+    float* item_rows = base + p.item_rows;
+    unsigned char* masks = reinterpret_cast<unsigned char*>(base + p.masks);
+    unsigned char* item_flags = reinterpret_cast<unsigned char*>(base + p.item_flags);
+    const float eikonal_norm = 1.0f / (static_cast<float>(config->num_rays) * static_cast<float>(num_points));
+    const float eikonal_scale = eikonal_ratio * eikonal_norm;
+    const unsigned mlp_bits = (config->flags & VSRD_FLAG_MLP_WEIGHTS_CENTRED) ? kMlpCentredBit : 0u;
+    const size_t adjoint_lds = (static_cast<size_t>(kMlpWbarFloats) + static_cast<size_t>(kMlpStashTiles) * kTileFloats) * sizeof(float);
+    int chunk_index = 0;
+    for (int first = 0; first < config->num_rays; first += p.chunk, ++chunk_index) {
+        const int rays = std::min(p.chunk, config->num_rays - first);
+        const long long used_slots = static_cast<long long>(rays) * p.rounds;
+        if (hipMemsetAsync(masks, 0, static_cast<size_t>(N) * p.slots_per_instance, s) != hipSuccess) return VSRD_E_LAUNCH;
+        if (hipMemsetAsync(counter, 0, sizeof(unsigned), s) != hipSuccess) return VSRD_E_LAUNCH;
+#define VSRD_LAUNCH(K)                                                                                                                   \
+        hipLaunchKernelGGL(residual_step_front_kernel<K>, dim3(p.front_blocks), dim3(kBlockThreads), p.front_lds, s, f, field->instances,    \
+                           field->mlp_weights, c, origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, eikonal_scale, \
+                           eikonal_norm, labels, box_partials, jets, loss_partials, seeds, masks, p.slots_per_instance, first, rays,           \
+                           chunk_index > 0 ? 1 : 0)
+        switch (p.rounds) {
+            case 1: VSRD_LAUNCH(1); break;
+            case 2: VSRD_LAUNCH(2); break;
+            case 4: VSRD_LAUNCH(4); break;
+            default: return VSRD_E_UNSUPPORTED;
+        }
+#undef VSRD_LAUNCH
+        hipLaunchKernelGGL(residual_mlp_adjoint_kernel, dim3(kMlpAdjointBlocks), dim3(kWave), adjoint_lds, s, field->instances,
+                           field->mlp_weights, N, mlp_bits, seeds, masks, p.slots_per_instance, used_slots, p.items_per_instance, p.slots_per_item,
+                           counter, item_rows, item_flags);
+        hipLaunchKernelGGL(reduce_item_rows_kernel, dim3(N, (kItemRowFloats + 255) / 256, kItemSegments), dim3(256), 0, s, item_rows, item_flags,
+                           p.items_per_instance, segment_sums);
+        hipLaunchKernelGGL(reduce_item_segments_kernel, dim3(N, (kItemRowFloats + 255) / 256), dim3(256), 0, s, segment_sums, grad_mlp_weights, box_extra,
+                           chunk_index > 0 ? 1 : 0);
+        if (launch_status() != VSRD_OK) return VSRD_E_LAUNCH;
+    }
+    (void)mlp_row;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(row), dim3(256), 0, s, box_partials, p.front_waves, row, grad_instances, box_extra);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), dim3(256), 0, s, loss_partials, p.front_waves, 2, losses, nullptr);
     return launch_status();
 }
 

@@ -487,12 +487,28 @@ __device__ __forceinline__ void adjoint_label_mix(RayAdjoint<kRounds>& st, const
     }
 }
 
+// Where the per-instance phase leaves the seeds (kSeedFloats x 64 floats per (round, instance)) and the 4-bit tile masks of the MLP
+// adjoint.  Two layouts: wave-private batches (render_backward_kernel / render_residual_step_kernel: [round][instance], 32-bit masks
+// in LDS) and the launch-wide dense table of the split residual step ([instance][ray of chunk][round], byte masks in global memory).
+struct SeedSink {
+    float* seeds;                    // base of this ray's seeds
+    long long instance_stride;       // floats between instances
+    long long round_stride;          // floats between rounds
+    unsigned* masks32;               // [round * mask_round_stride + instance * mask_instance_stride] (LDS), or nullptr
+    unsigned char* masks8;           // the same in bytes (global), or nullptr
+    long long mask_instance_stride, mask_round_stride;
+};
+
+__device__ __forceinline__ SeedSink batch_seed_sink(float* ray_seeds, unsigned* ray_masks, int N) {
+    return SeedSink{ray_seeds, static_cast<long long>(kSeedFloats) * kWave, static_cast<long long>(N) * kSeedFloats * kWave, ray_masks, nullptr, 1, N};
+}
+
 // Phase B: per instance, adjoint of (d_i, grad d_i) w.r.t. (t, R, dim) (and the residual MLP weights), accumulated into the wave's
 // LDS rows G [N,16]; for residual fields it leaves the seeds and tile masks of the MLP adjoint (adjoint_phase_mlp) instead of running it.
 template <int kRounds, bool kResidual, bool kYaw>
 __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, const float* __restrict__ instances, const float* __restrict__ mlp,
                                                 int N, float inv_t, int num_points, const float* lam, float* G, int lane,
-                                                const float4* rcache, float* seeds, unsigned* masks) {
+                                                const float4* rcache, const SeedSink& sink) {
     unsigned long long todo = 0ull;                                           // instances evaluated in some round of this ray
 #pragma unroll
     for (int k = 0; k < kRounds; ++k) todo |= (k * kWave < num_points) ? st.near_any[k] : 0ull;
@@ -516,7 +532,9 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
             unsigned mine = 0u;
 #pragma unroll
             for (int k = 0; k < kRounds; ++k) mine = (lane == k && active[k]) ? tiles[k] : mine;
-            masks[lane * N + i] = mine;
+            const long long at = lane * sink.mask_round_stride + i * sink.mask_instance_stride;
+            if (sink.masks32) sink.masks32[at] = mine;
+            else sink.masks8[at] = static_cast<unsigned char>(mine);
         }
         if (!any_active) continue;                                            // negligible for this ray (field.h culling)
         const Instance in = load_instance(instances, i);
@@ -557,7 +575,7 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
             const float pbx = sx * qbx, pby = sy * qby, pbz = sz * qbz;
             ad0 -= qbx; ad1 -= qby; ad2 -= qbz;
             if (kResidual) {        // seeds of the residual adjoint (main.py:451-458): value adjoint d_bar, local-gradient adjoint gl_bar;
-                float* dst = seeds + static_cast<size_t>(k * N + i) * (kSeedFloats * kWave) + lane;       // left for adjoint_phase_mlp
+                float* dst = sink.seeds + k * sink.round_stride + i * sink.instance_stride + lane;        // left for the MLP adjoint
                 dst[0 * kWave] = e.px; dst[1 * kWave] = e.py; dst[2 * kWave] = e.pz; dst[3 * kWave] = d_bar;
                 dst[4 * kWave] = glbx; dst[5 * kWave] = glby; dst[6 * kWave] = glbz;
                 dst[7 * kWave] = e.relx; dst[8 * kWave] = e.rely; dst[9 * kWave] = e.relz;
@@ -684,8 +702,9 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
             const float* gw_row = grad_weights ? grad_weights + static_cast<size_t>(ray) * num_points : nullptr;
             const float* gg_row = grad_gradients ? grad_gradients + static_cast<size_t>(ray) * num_points * 3 : nullptr;
             if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, gw_row, gg_row, lane)) continue;      // exact zero adjoint
-            if (sh.yaw) adjoint_phase_b<kRounds, kResidual, true>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, ray_seeds, ray_masks);
-            else adjoint_phase_b<kRounds, kResidual, false>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, ray_seeds, ray_masks);
+            const SeedSink sink = batch_seed_sink(ray_seeds, ray_masks, N);
+            if (sh.yaw) adjoint_phase_b<kRounds, kResidual, true>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink);
+            else adjoint_phase_b<kRounds, kResidual, false>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink);
         }
         if (kResidual) {
             wave_lds_sync();                                                 // masks: written by lanes < kRounds, read by all
@@ -776,8 +795,9 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
         else adjoint_label_mix<kRounds, false, false>(st, instances, N, sh.inv_t, num_points, lam, lane, nullptr, l.dcache);
         if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, nullptr, nullptr, lane)) continue;
         VSRD_PHASE(4);
-        if (sh.yaw) adjoint_phase_b<kRounds, false, true>(st, instances, nullptr, N, f.inv_t, num_points, lam, G, lane, nullptr, nullptr, nullptr);
-        else adjoint_phase_b<kRounds, false, false>(st, instances, nullptr, N, f.inv_t, num_points, lam, G, lane, nullptr, nullptr, nullptr);
+        const SeedSink no_sink = {};
+        if (sh.yaw) adjoint_phase_b<kRounds, false, true>(st, instances, nullptr, N, f.inv_t, num_points, lam, G, lane, nullptr, no_sink);
+        else adjoint_phase_b<kRounds, false, false>(st, instances, nullptr, N, f.inv_t, num_points, lam, G, lane, nullptr, no_sink);
         VSRD_PHASE(5);
     }
     wave_lds_sync();
@@ -800,8 +820,11 @@ __host__ __device__ constexpr int residual_step_lds_floats(int num_samples, int 
     return (kMlpLdsFloats + kMlpBatch * 4 * num_instances + wave_lds_floats(num_samples, num_instances) + num_instances + num_instances * kGradStride + 3) & ~3;
 }
 
+#ifndef VSRD_RESIDUAL_WAVES_PER_EU
+#define VSRD_RESIDUAL_WAVES_PER_EU 1
+#endif
 template <int kRounds>
-__global__ __launch_bounds__(kBlockThreads) void render_residual_step_kernel(
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(VSRD_RESIDUAL_WAVES_PER_EU, VSRD_RESIDUAL_WAVES_PER_EU))) void render_residual_step_kernel(
     FieldArgs f, const float* __restrict__ instances, const float* __restrict__ mlp, RenderArgs c,
     const float* __restrict__ origins, const float* __restrict__ directions, const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
     const float* __restrict__ targets, const float* __restrict__ instance_weights, float loss_scale, float eikonal_scale, float eikonal_norm,
@@ -880,8 +903,9 @@ __global__ __launch_bounds__(kBlockThreads) void render_residual_step_kernel(
             else adjoint_label_mix<kRounds, true, false>(st, instances, N, sh.inv_t, num_points, lam, lane, rcache, l.dcache);
             if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, nullptr, nullptr, lane, eikonal_scale)) continue;
             VSRD_PHASE(4);
-            if (sh.yaw) adjoint_phase_b<kRounds, true, true>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, ray_seeds, ray_masks);
-            else adjoint_phase_b<kRounds, true, false>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, ray_seeds, ray_masks);
+            const SeedSink sink = batch_seed_sink(ray_seeds, ray_masks, N);
+            if (sh.yaw) adjoint_phase_b<kRounds, true, true>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink);
+            else adjoint_phase_b<kRounds, true, false>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink);
             VSRD_PHASE(5);
         }
         wave_lds_sync();                                                     // masks: written by lanes < kRounds, read by all
@@ -897,8 +921,215 @@ __global__ __launch_bounds__(kBlockThreads) void render_residual_step_kernel(
     if (lane == 0) { loss_partials[2 * wave_global] = loss_total * loss_scale; loss_partials[2 * wave_global + 1] = eikonal_total * eikonal_norm; }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same step as TWO kernels per chunk of rays (the default for residual fields; VSRD_FLAG_RESIDUAL_SINGLE_KERNEL selects the
+// kernel above).  Why: on gfx950 one wave per SIMD issues a VALU instruction only every ~5 cycles, two waves every ~2.7 (tools/micro/
+// mfma_overlap.hip; fp32 MFMAs share the datapath and overlap with nothing), and the fused kernel needs 427 registers -- one wave per
+// SIMD -- because the MLP adjoint's state (four layers of [LayerNorm -> GELU] state, the weight operands in both orientations, 45
+// weight-adjoint accumulators) and the renderer's per-ray state must fit one allocation.  Split at the point where only the seeds
+// are live, each half fits 256 registers (two waves per SIMD), and the MLP adjoint can be distributed by INSTANCE over the whole
+// launch: weight operands and weight-adjoint accumulators stay in registers over ~32 point sets instead of one batch of 8 rays.
+//   residual_step_front_kernel     pass 1, sampling, pass 2, silhouette BCE, eikonal term, reverse sweep, per-instance box adjoint;
+//                                  leaves seeds [N][slot][10][64] and 4-bit tile masks [N][slot] (slot = ray of chunk * rounds + round)
+//   residual_mlp_adjoint_kernel    work items (instance, <= 64 consecutive slots), fetched dynamically by single-wave workgroups;
+//                                  ONE partial row [1617 weight adjoints | 16 box adjoints] per item, so the result does not depend
+//                                  on which wave ran which item (reduce_item_rows_kernel sums the rows in a fixed order)
+// ---------------------------------------------------------------------------------------------------
+constexpr int kItemRowFloats = kMlpWbarFloats + kGradStride;         // 1632 + 16
+
+__host__ __device__ constexpr int residual_front_lds_floats(int num_samples, int num_instances) {
+    return (wave_lds_floats(num_samples, num_instances) + num_instances + num_instances * kGradStride + 3) & ~3;
+}
+
+template <int kRounds>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void residual_step_front_kernel(
+    FieldArgs f, const float* __restrict__ instances, const float* __restrict__ mlp, RenderArgs c,
+    const float* __restrict__ origins, const float* __restrict__ directions, const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
+    const float* __restrict__ targets, const float* __restrict__ instance_weights, float loss_scale, float eikonal_scale, float eikonal_norm,
+    float* __restrict__ labels_out, float* __restrict__ partials, float4* __restrict__ residual_cache, float* __restrict__ loss_partials,
+    float* __restrict__ seed_table, unsigned char* __restrict__ mask_table, long long slots_per_instance, int chunk_base, int chunk_rays, int accumulate) {
+    apply_device_schedule(f, c);
+    constexpr int kRoundsS = (kRounds + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = wave_in_block();
+    const int lane = lane_id();
+    const int S = c.num_samples;
+    const int N = f.num_instances;
+    float* base = lds + wave * residual_front_lds_floats(S, N);
+    WaveLds l = carve_lds(base, S, N);                                     // l.dcache: [N][64], one round at a time
+    float* lam = base + wave_lds_floats(S, N);
+    float* G = lam + N;
+    const size_t wave_global = static_cast<size_t>(blockIdx.x) * waves_per_block() + wave;
+    float* out = partials + wave_global * (N * kGradStride);
+    for (int idx = lane; idx < N * kGradStride; idx += kWave) G[idx] = accumulate ? out[idx] : 0.0f;      // chunks of one call add up
+    float4* rcache = residual_cache + wave_global * (static_cast<size_t>(kRounds) * N * kWave);
+    const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
+    Shading sh = c.sh;
+    const FieldBounds bounds = field_bounds(instances, N, f.inv_t, true, c.flags);
+    sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
+    sh.mlp_bits = (c.flags & 8u) ? kMlpCentredBit : 0u;
+    const float weight_lane = (lane < N) ? (instance_weights ? instance_weights[lane] : 1.0f) : 0.0f;
+    float loss_acc = 0.0f, eikonal_acc = 0.0f;
+    const int D = 2 * S, num_points = D - 1;
+    const int stride = static_cast<int>(gridDim.x) * waves_per_block();
+    for (int local = static_cast<int>(wave_global); local < chunk_rays; local += stride) {
+        const int ray = chunk_base + local;
+        wave_lds_sync();
+        const long long row = source_row(c, ray);
+        const Ray r = load_ray_gathered(c, origins, directions, row);
+        const float target = load_target(c, targets, row, lane, N);
+        const RayCull rc = cull_ray_setup(instances, N, r.ox, r.oy, r.oz, r.rx, r.ry, r.rz, l.cull, lane);
+        stage_ray_samples<kRoundsS>(l, c, S, ray, u_coarse, u_fine, nullptr, nullptr, sorted_input, lane);
+        float w1[kRoundsS];
+        render_pass<kRoundsS, false, true>(instances, mlp, N, sh, r, rc, l.coarse, S, l.dcache, w1, nullptr, nullptr);
+        importance_merge<kRoundsS>(l, S, w1);
+        RayAdjoint<kRounds> st;
+        const float label = adjoint_forward_sweep<kRounds, true, true>(st, instances, mlp, N, sh, r, rc, l.merged, num_points, nullptr, l.dcache, lane, rcache);
+        if (labels_out != nullptr && lane < N) labels_out[static_cast<size_t>(ray) * N + lane] = label;
+        // silhouette BCE and its gradient (as render_silhouette_kernel)
+        const float p = fminf(fmaxf(label, 1.0e-6f), 1.0f - 1.0e-6f);
+        const float bce = -(target * logf(p) + (1.0f - target) * logf(1.0f - p));
+        loss_acc += (lane < N) ? weight_lane * bce : 0.0f;
+        const bool inside_clamp = (label >= 1.0e-6f) && (label <= 1.0f - 1.0e-6f);
+        const float lam_lane = (lane < N && inside_clamp) ? weight_lane * loss_scale * (p - target) / fmaxf(p * (1.0f - p), 1.0e-12f) : 0.0f;
+        if (lane < N) lam[lane] = lam_lane;
+        wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < kRounds; ++k) {
+            if (k * kWave >= num_points) continue;
+            const float norm = fast_sqrt(st.gx[k] * st.gx[k] + st.gy[k] * st.gy[k] + st.gz[k] * st.gz[k]);
+            eikonal_acc += (k * kWave + lane < num_points) ? (norm - 1.0f) * (norm - 1.0f) : 0.0f;
+        }
+        if (sh.yaw) adjoint_label_mix<kRounds, true, true>(st, instances, N, sh.inv_t, num_points, lam, lane, rcache, l.dcache);
+        else adjoint_label_mix<kRounds, true, false>(st, instances, N, sh.inv_t, num_points, lam, lane, rcache, l.dcache);
+        if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, nullptr, nullptr, lane, eikonal_scale)) continue;      // (masks stay 0)
+        const long long slot0 = static_cast<long long>(local) * kRounds;
+        const SeedSink sink = {seed_table + slot0 * (kSeedFloats * kWave), slots_per_instance * (kSeedFloats * kWave), static_cast<long long>(kSeedFloats) * kWave,
+                               nullptr, mask_table + slot0, slots_per_instance, 1};
+        if (sh.yaw) adjoint_phase_b<kRounds, true, true>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink);
+        else adjoint_phase_b<kRounds, true, false>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink);
+    }
+    wave_lds_sync();
+    for (int idx = lane; idx < N * kGradStride; idx += kWave) out[idx] = G[idx];
+    const float loss_total = wave_sum(loss_acc), eikonal_total = wave_sum(eikonal_acc);
+    if (lane == 0) {
+        float* mine = loss_partials + 2 * wave_global;
+        mine[0] = (accumulate ? mine[0] : 0.0f) + loss_total * loss_scale;
+        mine[1] = (accumulate ? mine[1] : 0.0f) + eikonal_total * eikonal_norm;
+    }
+}
+
+// One wave = one workgroup (its own staged weights and transposition scratch: 19.3 KB of LDS, eight workgroups per CU), so waves
+// never wait for each other: the active fraction of an item varies from 0 to 1.  Work item = (instance, kSlotsPerItem consecutive
+// slots), fetched with one global atomic; ONE partial row per item and a flag whether it holds anything.
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void residual_mlp_adjoint_kernel(
+    const float* __restrict__ instances, const float* __restrict__ mlp, int N, unsigned mlp_bits, const float* __restrict__ seed_table,
+    const unsigned char* __restrict__ mask_table, long long slots_per_instance, long long used_slots, int items_per_instance, int slots_per_item,
+    unsigned* __restrict__ next_item, float* __restrict__ item_rows, unsigned char* __restrict__ item_flags) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = lane_id();
+    const LdsFloats staged = (LdsFloats)lds;                                   // [1632] this item's instance weights, centred
+    const LdsFloats scratch = staged + kMlpWbarFloats;                         // kMlpStashTiles tiles
+    const LdsWeights wt = {staged, lane >> 4, lane & 15};
+    const int num_items = N * items_per_instance;
+    int staged_instance = -1;
+    while (true) {
+        int item = 0;
+        if (lane == 0) item = static_cast<int>(atomicAdd(next_item, 1u));
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= num_items) break;
+        const int i = item / items_per_instance;
+        const long long first = static_cast<long long>(item - i * items_per_instance) * slots_per_item;
+        const unsigned char* item_masks = mask_table + static_cast<long long>(i) * slots_per_instance + first;
+        // anything to do?  (lane k looks at slot k of the item; slots_per_item <= 64)
+        const bool mine_active = lane < slots_per_item && first + lane < used_slots && item_masks[lane] != 0;
+        const unsigned long long active = __ballot(mine_active);
+        if (active == 0ull) {
+            if (lane == 0) item_flags[item] = 0;
+            continue;
+        }
+        if (i != staged_instance) {
+            wave_lds_sync();
+            stage_centred_weights_wave(staged, mlp + static_cast<size_t>(i) * kMlpWeights, mlp_bits != 0u, lane);
+            staged_instance = i;
+            wave_lds_sync();
+        }
+        const Instance in = load_instance(instances, i);
+        MlpAdjoint s;
+        s.clear();
+        float at0 = 0, at1 = 0, at2 = 0;
+        float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
+#pragma unroll 1
+        for (unsigned long long todo = active; todo != 0ull; todo &= todo - 1ull) {
+            const int k = __builtin_ctzll(todo);
+            const unsigned rows = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(item_masks[k]));
+            const float* src = seed_table + (static_cast<long long>(i) * slots_per_instance + first + k) * (kSeedFloats * kWave) + lane;
+            const float relx = src[7 * kWave], rely = src[8 * kWave], relz = src[9 * kWave];
+            const ResidualAdjoint ra = mlp_adjoint_points<true>(s, wt, src[0 * kWave], src[1 * kWave], src[2 * kWave], src[3 * kWave],
+                                                                src[4 * kWave], src[5 * kWave], src[6 * kWave], scratch, lane, rows);
+            r00 += relx * ra.px; r01 += relx * ra.py; r02 += relx * ra.pz;
+            r10 += rely * ra.px; r11 += rely * ra.py; r12 += rely * ra.pz;
+            r20 += relz * ra.px; r21 += relz * ra.py; r22 += relz * ra.pz;
+            at0 -= in.r00 * ra.px + in.r01 * ra.py + in.r02 * ra.pz;
+            at1 -= in.r10 * ra.px + in.r11 * ra.py + in.r12 * ra.pz;
+            at2 -= in.r20 * ra.px + in.r21 * ra.py + in.r22 * ra.pz;
+        }
+        float* row = item_rows + static_cast<size_t>(item) * kItemRowFloats;
+        mlp_adjoint_flush<true>(s, row, lane);
+        const float packed[16] = {at0, at1, at2, r00, r01, r02, r10, r11, r12, r20, r21, r22, 0.0f, 0.0f, 0.0f, 0.0f};
+        const float mine = wave_reduce16_scatter(packed, lane);
+        if (lane < kGradStride) row[kMlpWbarFloats + lane] = mine;
+        if (lane == 0) item_flags[item] = 1;
+    }
+}
+
+// grad_mlp [N,1617] (+)= sum over the item rows of instance i (fixed order); box_extra [N,16] likewise (the MLP's dL/dp chained into t, R).
+// Two deterministic stages: kItemSegments contiguous row ranges per instance are summed in parallel (grid N x 7 x segments), then the
+// segment sums in a fixed order.
+constexpr int kItemSegments = 32;
+
+__global__ __launch_bounds__(256) void reduce_item_rows_kernel(const float* __restrict__ item_rows, const unsigned char* __restrict__ item_flags,
+                                                               int rows_per_instance, float* __restrict__ segment_sums) {
+    const int i = blockIdx.x, segment = blockIdx.z;
+    const int idx = blockIdx.y * blockDim.x + threadIdx.x;
+    if (idx >= kItemRowFloats) return;
+    const int per_segment = (rows_per_instance + kItemSegments - 1) / kItemSegments;
+    const int begin = segment * per_segment, end = min(begin + per_segment, rows_per_instance);
+    const float* rows = item_rows + static_cast<size_t>(i) * rows_per_instance * kItemRowFloats + idx;
+    const unsigned char* flags = item_flags + static_cast<size_t>(i) * rows_per_instance;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int r = begin;
+    for (; r + 4 <= end; r += 4) {                                      // (four fixed partial sums: the order never depends on the flags' pattern)
+        if (flags[r]) a0 += rows[static_cast<size_t>(r) * kItemRowFloats];
+        if (flags[r + 1]) a1 += rows[static_cast<size_t>(r + 1) * kItemRowFloats];
+        if (flags[r + 2]) a2 += rows[static_cast<size_t>(r + 2) * kItemRowFloats];
+        if (flags[r + 3]) a3 += rows[static_cast<size_t>(r + 3) * kItemRowFloats];
+    }
+    for (; r < end; ++r)
+        if (flags[r]) a0 += rows[static_cast<size_t>(r) * kItemRowFloats];
+    segment_sums[(static_cast<size_t>(i) * kItemSegments + segment) * kItemRowFloats + idx] = (a0 + a1) + (a2 + a3);
+}
+
+// grad_mlp [N,1617] (+)= the segment sums of instance i; box_extra [N,16] likewise (the MLP's dL/dp chained into t and R).
+__global__ __launch_bounds__(256) void reduce_item_segments_kernel(const float* __restrict__ segment_sums, float* __restrict__ grad_mlp,
+                                                                   float* __restrict__ box_extra, int accumulate) {
+    const int i = blockIdx.x;
+    const int idx = blockIdx.y * blockDim.x + threadIdx.x;
+    if (idx >= kItemRowFloats) return;
+    float total = 0.0f;
+    for (int segment = 0; segment < kItemSegments; ++segment) total += segment_sums[(static_cast<size_t>(i) * kItemSegments + segment) * kItemRowFloats + idx];
+    if (idx < kMlpWeights) {
+        float* dst = grad_mlp + static_cast<size_t>(i) * kMlpWeights + idx;
+        *dst = (accumulate ? *dst : 0.0f) + total;
+    } else if (idx >= kMlpWbarFloats) {
+        float* dst = box_extra + i * kGradStride + (idx - kMlpWbarFloats);
+        *dst = (accumulate ? *dst : 0.0f) + total;
+    }
+}
+
 // Deterministic second stage: grad[idx] = sum over waves of partials[wave][idx].
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int num_waves, int row, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int num_waves, int row, float* __restrict__ out,
+                                                              const float* __restrict__ extra = nullptr) {
     __shared__ float scratch[256 / kWave];
     const int idx = blockIdx.x;
     float acc = 0.0f;
@@ -909,7 +1140,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     if (threadIdx.x == 0) {
         float total = 0.0f;
         for (int k = 0; k < 256 / kWave; ++k) total += scratch[k];
-        out[idx] = total;
+        out[idx] = total + (extra ? extra[idx] : 0.0f);
     }
 }
 

@@ -294,6 +294,7 @@ constexpr int kTilePitch = 20;                               // floats per chann
 constexpr int kTileFloats = 16 * kTilePitch;
 constexpr int kMlpWbarFloats = 1632;                         // wbar [1617] padded to a multiple of 4 floats
 constexpr int kMlpScratchTiles = 8;
+constexpr int kMlpStashTiles = 10;                           // mlp_adjoint_points<true>: + six tiles of encoder features and tangents
 constexpr int kMlpLdsFloats = kMlpWbarFloats + kMlpScratchTiles * kTileFloats;   // per-wave LDS of the residual adjoint
 
 // Compiler-only ordering between LDS accesses of different lanes of this wave (DS operations of a wave execute in order).
@@ -412,31 +413,115 @@ __device__ __forceinline__ f32x4 row_sum16(f32x4 v) { return f32x4{row_sum16(v[0
 
 struct ResidualAdjoint { float px, py, pz; };
 
-// Adjoint of residual_forward at the wave's local positions p: res_bar = dL/d residual, (gbx, gby, gbz) = dL/d(grad_p residual).
-// Adds dL/dw into `mlp_lds` (the wave's LDS: wbar [1617], then the transposition scratch); returns dL/dp per lane.
-// Inlined into its only call site, adjoint_phase_mlp (render_kernels.h), which runs when nothing else of the ray is live.
-__device__ __forceinline__ ResidualAdjoint residual_backward(const float* w_in, float px, float py, float pz,
-                                                                       float res_bar, float gbx, float gby, float gbz, float* mlp_lds, int lane, unsigned tiles_in) {
-    const int g = lane >> 4, m = lane & 15;
-    const unsigned tiles = __builtin_amdgcn_readfirstlane(tiles_in);
-    const GlobalWeights w = uniform_weights(w_in);
-    const LdsFloats wbar = (LdsFloats)mlp_lds;
-    const LdsFloats scratch = wbar + kMlpWbarFloats;
+// ---- the adjoint proper, in pieces, so that a caller can keep the weight-adjoint accumulators in registers over MANY point sets of
+// one instance (residual_mlp_adjoint_kernel, render_kernels.h) or over one (residual_backward) -----------------------------------------
+struct MlpAdjoint {
+    f32x4 acc_w[3], acc_w0[3], acc_b[3], acc_b0, acc_w4;    // W_bar[4 g + j][lane & 15] of the three hidden blocks / the three coordinate blocks
+    float acc_b4;                                            // of the first layer; bias / head adjoints per point (summed over points at the end)
+    __device__ __forceinline__ void clear() {
+        acc_b0 = splat4(0.0f); acc_w4 = splat4(0.0f); acc_b4 = 0.0f;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) { acc_w[l] = splat4(0.0f); acc_w0[l] = splat4(0.0f); acc_b[l] = splat4(0.0f); }
+    }
+};
+
+// Where the MFMA weight operands come from.  RegisterWeights: 69 registers per lane, loaded once per point set (the wave-private
+// callers).  LdsWeights: the instance's 1617 weights staged once per work item in the workgroup's LDS (centred: stage_centred_weights)
+// and read operand by operand where they are used -- what lets residual_mlp_adjoint_kernel fit 256 registers (two waves per SIMD).
+struct RegisterWeights {
     ForwardWeights fw;
     BackwardWeights bw;
-    load_forward_weights(w, lane, fw, (tiles & kMlpCentredBit) != 0u);
-    load_backward_weights(w, lane, bw);
+    __device__ __forceinline__ float a0(int c, int k) const { return fw.a0[4 * c + k]; }      // W0[o][16 c + 4 g + k]
+    __device__ __forceinline__ f32x4 b0() const { return fw.b0; }
+    __device__ __forceinline__ float a(int l, int k) const { return fw.a[l][k]; }             // W_l[o][4 g + k]
+    __device__ __forceinline__ f32x4 b(int l) const { return fw.b[l]; }
+    __device__ __forceinline__ f32x4 w4() const { return fw.w4; }
+    __device__ __forceinline__ float b4() const { return fw.b4; }
+    __device__ __forceinline__ float at(int l, int k) const { return bw.at[l][k]; }           // W_l[4 g + k][i]
+    __device__ __forceinline__ float at0(int c, int k) const { return bw.at0[c][k]; }         // W0[4 g + k][16 c + i]
+};
+
+struct LdsWeights {
+    LdsFloats w;      // [1617] row-major, the four LayerNorm-fed linears centred
+    int g, o;         // lane >> 4, lane & 15
+    __device__ __forceinline__ float a0(int c, int k) const { return w[o * kMlpRow0 + 16 * c + 4 * g + k]; }
+    __device__ __forceinline__ f32x4 b0() const { return f32x4{w[(4 * g + 0) * kMlpRow0 + kMlpFeatures], w[(4 * g + 1) * kMlpRow0 + kMlpFeatures],
+                                                              w[(4 * g + 2) * kMlpRow0 + kMlpFeatures], w[(4 * g + 3) * kMlpRow0 + kMlpFeatures]}; }
+    __device__ __forceinline__ float a(int l, int k) const { return w[kMlpLayer1 + l * kMlpBlock + o * kMlpRow + 4 * g + k]; }
+    __device__ __forceinline__ f32x4 b(int l) const {
+        const LdsFloats wl = w + kMlpLayer1 + l * kMlpBlock + kMlpHidden;
+        return f32x4{wl[(4 * g + 0) * kMlpRow], wl[(4 * g + 1) * kMlpRow], wl[(4 * g + 2) * kMlpRow], wl[(4 * g + 3) * kMlpRow]};
+    }
+    __device__ __forceinline__ f32x4 w4() const { return f32x4{w[kMlpHead + 4 * g], w[kMlpHead + 4 * g + 1], w[kMlpHead + 4 * g + 2], w[kMlpHead + 4 * g + 3]}; }
+    __device__ __forceinline__ float b4() const { return w[kMlpHead + kMlpHidden]; }
+    __device__ __forceinline__ float at(int l, int k) const { return w[kMlpLayer1 + l * kMlpBlock + (4 * g + k) * kMlpRow + o]; }
+    __device__ __forceinline__ float at0(int c, int k) const { return w[(4 * g + k) * kMlpRow0 + 16 * c + o]; }
+};
+
+// Stage one instance's weights into LDS with the centring of load_forward_weights applied (column means over the 16 output channels
+// of the first linear and the three hidden ones removed, bias column included; skipped when the caller centred them for the launch).
+// The transposed operands read the same copy: the adjoints they multiply have zero channel mean, so W^T z_bar = (C W)^T z_bar.
+// Cooperative over `threads` threads of a workgroup; the caller synchronises before and after.
+__device__ __forceinline__ void stage_centred_weights(LdsFloats dst, const float* __restrict__ w, bool centred, int thread, int threads) {
+    for (int idx = thread; idx < kMlpWeights; idx += threads) dst[idx] = w[idx];
+    if (centred) return;
+    __syncthreads();
+    for (int column = thread; column < kMlpRow0 + 3 * kMlpRow; column += threads) {       // 49 + 3 x 17 columns, 16 rows each
+        const bool first = column < kMlpRow0;
+        const int l = first ? 0 : (column - kMlpRow0) / kMlpRow, col = first ? column : (column - kMlpRow0) % kMlpRow;
+        const int base = first ? col : kMlpLayer1 + l * kMlpBlock + col, pitch = first ? kMlpRow0 : kMlpRow;
+        float mean = 0.0f;
+        for (int r = 0; r < kMlpHidden; ++r) mean += dst[base + r * pitch];
+        mean *= 1.0f / kMlpHidden;
+        for (int r = 0; r < kMlpHidden; ++r) dst[base + r * pitch] -= mean;
+    }
+}
+
+// The same by the 64 lanes of one wave (single-wave workgroups).
+__device__ __forceinline__ void stage_centred_weights_wave(LdsFloats dst, const float* __restrict__ w, bool centred, int lane) {
+    for (int idx = lane; idx < kMlpWeights; idx += kWave) dst[idx] = w[idx];
+    if (centred) return;
+    wave_lds_order();
+    for (int column = lane; column < kMlpRow0 + 3 * kMlpRow; column += kWave) {
+        const bool first = column < kMlpRow0;
+        const int l = first ? 0 : (column - kMlpRow0) / kMlpRow, col = first ? column : (column - kMlpRow0) % kMlpRow;
+        const int base = first ? col : kMlpLayer1 + l * kMlpBlock + col, pitch = first ? kMlpRow0 : kMlpRow;
+        float mean = 0.0f;
+        for (int r = 0; r < kMlpHidden; ++r) mean += dst[base + r * pitch];
+        mean *= 1.0f / kMlpHidden;
+        for (int r = 0; r < kMlpHidden; ++r) dst[base + r * pitch] -= mean;
+    }
+}
+
+__device__ __forceinline__ void load_register_weights(RegisterWeights& w, const float* w_in, int lane, bool centred) {
+    const GlobalWeights global = uniform_weights(w_in);
+    load_forward_weights(global, lane, w.fw, centred);
+    load_backward_weights(global, lane, w.bw);
+}
+
+// Register j of lane (g, m) of a staged tile, back in the layout stage_tile took it from.
+__device__ __forceinline__ f32x4 unstage_tile(LdsFloats tile, int lane) {
+    const LdsFloats src = tile + (lane >> 4) * 4 * kTilePitch + (lane & 15);
+    return f32x4{src[0], src[kTilePitch], src[2 * kTilePitch], src[3 * kTilePitch]};
+}
+
+// Adjoint of residual_forward at the wave's local positions p: res_bar = dL/d residual, (gbx, gby, gbz) = dL/d(grad_p residual).
+// Accumulates dL/dw into `s`; `scratch`: the wave's transposition scratch; returns dL/dp per lane.
+// kStash: the encoder features and their tangent wait in LDS (tiles 4..9 of a 10-tile scratch) from the first layer to the first
+// layer's adjoint instead of in 36 registers (they have to be staged there for the weight adjoint anyway).
+template <bool kStash, typename Weights>
+__device__ __forceinline__ ResidualAdjoint mlp_adjoint_points(MlpAdjoint& s, const Weights& wt, float px, float py, float pz, float res_bar,
+                                                              float gbx, float gby, float gbz, LdsFloats scratch, int lane, unsigned tiles_in) {
+    const int g = lane >> 4;
+    const unsigned tiles = __builtin_amdgcn_readfirstlane(tiles_in);
     const float fold = (px > 0.0f) ? 1.0f : ((px < 0.0f) ? -1.0f : 0.0f);
     const float inv = 1.0f / kPositionScale;
     const float f0 = fabsf(px) * inv, f1 = py * inv, f2 = pz * inv;
     // the direction of the single tangent, per point: delta = gl_bar * fold / 100 (header comment of this section)
     const float d0 = gbx * fold * inv, d1 = gby * inv, d2 = gbz * inv;
     const float base = (g == 0) ? 1.0f : ((g == 1) ? 4.0f : ((g == 2) ? 16.0f : 64.0f));
-    const float omega_sq[2] = {(base * kPi) * (base * kPi), (2.0f * base * kPi) * (2.0f * base * kPi)};
-    f32x4 acc_w[3], acc_w0[3], acc_b[3], acc_b0 = splat4(0.0f), acc_w4 = splat4(0.0f);
-    float acc_b4 = 0.0f;
-#pragma unroll
-    for (int l = 0; l < 3; ++l) { acc_w[l] = splat4(0.0f); acc_w0[l] = splat4(0.0f); acc_b[l] = splat4(0.0f); }
+    const float omega[2] = {base * kPi, 2.0f * base * kPi};
+    constexpr int kFeatureTile = kStash ? 4 : 2;             // first of the six tiles (f_0, tangent_0, f_1, tangent_1, f_2, tangent_2)
     ResidualAdjoint mine = {0.0f, 0.0f, 0.0f};
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
@@ -444,34 +529,51 @@ __device__ __forceinline__ ResidualAdjoint residual_backward(const float* w_in, 
         const float tfold = from_row(fold, q, lane);
         const float delta[3] = {from_row(d0, q, lane), from_row(d1, q, lane), from_row(d2, q, lane)};
         const float t_res_bar = from_row(res_bar, q, lane);
-        TileFeatures e;
-        encode_tile(from_row(f0, q, lane), from_row(f1, q, lane), from_row(f2, q, lane), g, e);
-        f32x4 tangent[3];                                        // d features / d epsilon along delta, per coordinate block
-#pragma unroll
-        for (int c = 0; c < 3; ++c) tangent[c] = e.d[c] * splat4(delta[c]);
         // ---- forward, keeping the [LayerNorm -> GELU] state of every layer ----------------------------------------------------
         TileState st[4];
+        TileFeatures e;                                          // (kStash: dead after the first layer)
+        f32x4 tangent[3];                                        // d features / d epsilon along delta, per coordinate block
         {
+            encode_tile(from_row(f0, q, lane), from_row(f1, q, lane), from_row(f2, q, lane), g, e);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) tangent[c] = e.d[c] * splat4(delta[c]);
             TileJet1 z;
-            z.v = fw.b0;
+            z.v = wt.b0();
             z.t = splat4(0.0f);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    z.v = mfma4(fw.a0[4 * c + s], e.f[c][s], z.v);
-                    z.t = mfma4(fw.a0[4 * c + s], tangent[c][s], z.t);
+                for (int k = 0; k < 4; ++k) {
+                    const float a = wt.a0(c, k);
+                    z.v = mfma4(a, e.f[c][k], z.v);
+                    z.t = mfma4(a, tangent[c][k], z.t);
+                }
+            }
+            if (kStash) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    stage_tile(scratch + (kFeatureTile + 2 * c) * kTileFloats, e.f[c], lane);
+                    stage_tile(scratch + (kFeatureTile + 2 * c + 1) * kTileFloats, tangent[c], lane);
                 }
             }
 #pragma unroll
             for (int l = 0; l < 3; ++l) {
                 tile_state(z, st[l]);
-                linear_tile(fw.a[l], fw.b[l], st[l].a, st[l].da(), z);
+                const f32x4 in_t = st[l].da();
+                z.v = wt.b(l);
+                z.t = splat4(0.0f);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float a = wt.a(l, k);
+                    z.v = mfma4(a, st[l].a[k], z.v);
+                    z.t = mfma4(a, in_t[k], z.t);
+                }
             }
             tile_state(z, st[3]);
         }
-        const float out_v = rows_sum(dot4(fw.w4, st[3].a)) + fw.b4;
-        const float out_t = rows_sum(dot4(fw.w4, st[3].da()));   // tangent of the MLP output along delta  (= kappa_bar of the 3-tangent form)
+        const f32x4 w4 = wt.w4();
+        const float out_v = rows_sum(dot4(w4, st[3].a)) + wt.b4();
+        const float out_t = rows_sum(dot4(w4, st[3].da()));      // tangent of the MLP output along delta  (= kappa_bar of the 3-tangent form)
         // ---- sigmoid head:  L = res_bar * res + kappa * out_t,  res = sigmoid(out - 1),  kappa = res (1 - res) ------------------------------
         const float res = fast_rcp(1.0f + fast_exp(-(out_v - 1.0f)));
         const float kappa = res * (1.0f - res);
@@ -479,13 +581,13 @@ __device__ __forceinline__ ResidualAdjoint residual_backward(const float* w_in, 
         const float zb_v = (t_res_bar + out_t * (1.0f - 2.0f * res)) * kappa;
         // ---- block 4: LayerNorm -> GELU -> Linear(16 -> 1) -----------------------------------------------------------------
         TileJet1 zb;
-        acc_w4 += splat4(zb_v) * st[3].a + splat4(zb_t) * st[3].da();
-        acc_b4 += zb_v;
-        gelu_norm_adjoint_tile(st[3], fw.w4 * splat4(zb_v), fw.w4 * splat4(zb_t), zb);
+        s.acc_w4 += splat4(zb_v) * st[3].a + splat4(zb_t) * st[3].da();
+        s.acc_b4 += zb_v;
+        gelu_norm_adjoint_tile(st[3], w4 * splat4(zb_v), w4 * splat4(zb_t), zb);
         // ---- blocks 3..1: LayerNorm -> GELU -> Linear(16 -> 16); zb is the adjoint of the linear's output ------------------
 #pragma unroll
         for (int l = 2; l >= 0; --l) {
-            acc_b[l] += zb.v;
+            s.acc_b[l] += zb.v;
             stage_tile(scratch + 0 * kTileFloats, zb.v, lane);
             stage_tile(scratch + 1 * kTileFloats, st[l].a, lane);
             stage_tile(scratch + 2 * kTileFloats, zb.t, lane);
@@ -495,77 +597,105 @@ __device__ __forceinline__ ResidualAdjoint residual_backward(const float* w_in, 
             for (int k = 0; k < 2; ++k) {
                 const f32x4 xt = fetch_tile(scratch + (2 * k) * kTileFloats, lane), yt = fetch_tile(scratch + (2 * k + 1) * kTileFloats, lane);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc_w[l] = mfma4(xt[s], yt[s], acc_w[l]);
+                for (int j = 0; j < 4; ++j) s.acc_w[l] = mfma4(xt[j], yt[j], s.acc_w[l]);
             }
             wave_lds_order();
             f32x4 a_bar = splat4(0.0f), da_bar = splat4(0.0f);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                a_bar = mfma4(bw.at[l][s], zb.v[s], a_bar);
-                da_bar = mfma4(bw.at[l][s], zb.t[s], da_bar);
+            for (int k = 0; k < 4; ++k) {
+                const float a = wt.at(l, k);
+                a_bar = mfma4(a, zb.v[k], a_bar);
+                da_bar = mfma4(a, zb.t[k], da_bar);
             }
             TileJet1 zin_bar;
             gelu_norm_adjoint_tile(st[l], a_bar, da_bar, zin_bar);
             zb = zin_bar;
         }
         // ---- first layer + encoder; zb is the adjoint of z[0] -----------------------------------------------------------------
-        acc_b0 += zb.v;
+        s.acc_b0 += zb.v;
         stage_tile(scratch + 0 * kTileFloats, zb.v, lane);
         stage_tile(scratch + 1 * kTileFloats, zb.t, lane);
+        if (!kStash) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            stage_tile(scratch + (2 + 2 * c) * kTileFloats, e.f[c], lane);
-            stage_tile(scratch + (3 + 2 * c) * kTileFloats, tangent[c], lane);
+            for (int c = 0; c < 3; ++c) {
+                stage_tile(scratch + (kFeatureTile + 2 * c) * kTileFloats, e.f[c], lane);
+                stage_tile(scratch + (kFeatureTile + 2 * c + 1) * kTileFloats, tangent[c], lane);
+            }
         }
         wave_lds_order();
         const f32x4 xv = fetch_tile(scratch + 0 * kTileFloats, lane), xt = fetch_tile(scratch + 1 * kTileFloats, lane);
-        f32x4 ft[3], dt[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            ft[c] = fetch_tile(scratch + (2 + 2 * c) * kTileFloats, lane);
-            dt[c] = fetch_tile(scratch + (3 + 2 * c) * kTileFloats, lane);
-        }
-        wave_lds_order();
         float f_bar[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
+            const f32x4 ft = fetch_tile(scratch + (kFeatureTile + 2 * c) * kTileFloats, lane);
+            const f32x4 dt = fetch_tile(scratch + (kFeatureTile + 2 * c + 1) * kTileFloats, lane);
+            const f32x4 feat = kStash ? unstage_tile(scratch + (kFeatureTile + 2 * c) * kTileFloats, lane) : e.f[c];
             f32x4 feat_bar = splat4(0.0f), tangent_bar = splat4(0.0f);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc_w0[c] = mfma4(xv[s], ft[c][s], acc_w0[c]);
-                acc_w0[c] = mfma4(xt[s], dt[c][s], acc_w0[c]);
-                feat_bar = mfma4(bw.at0[c][s], zb.v[s], feat_bar);
-                tangent_bar = mfma4(bw.at0[c][s], zb.t[s], tangent_bar);
+            for (int k = 0; k < 4; ++k) {
+                const float a = wt.at0(c, k);
+                s.acc_w0[c] = mfma4(xv[k], ft[k], s.acc_w0[c]);
+                s.acc_w0[c] = mfma4(xt[k], dt[k], s.acc_w0[c]);
+                feat_bar = mfma4(a, zb.v[k], feat_bar);
+                tangent_bar = mfma4(a, zb.t[k], tangent_bar);
             }
-            // d feat / d f = dfeat;  d (delta dfeat) / d f = -delta omega^2 feat   (feature j of this row: octave j >> 1)
+            // features of this row: (cos, sin) of octaves 2 g and 2 g + 1;  d cos = -omega sin,  d sin = omega cos;
+            // d (delta dfeat) / d f = -delta omega^2 feat
             float part = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) part += feat_bar[j] * e.d[c][j] - tangent_bar[j] * (delta[c] * omega_sq[j >> 1]) * e.f[c][j];
+            for (int kk = 0; kk < 2; ++kk) {
+                const float co = feat[2 * kk], si = feat[2 * kk + 1], om = omega[kk];
+                part += om * (feat_bar[2 * kk + 1] * co - feat_bar[2 * kk] * si) - (delta[c] * om * om) * (tangent_bar[2 * kk] * co + tangent_bar[2 * kk + 1] * si);
+            }
             f_bar[c] = rows_sum(part);
         }
+        wave_lds_order();
         if (g == q) { mine.px = f_bar[0] * tfold * inv; mine.py = f_bar[1] * inv; mine.pz = f_bar[2] * inv; }
     }
-    // ---- flush the accumulators into the wave's LDS row (row-major weight blocks; every lane owns its addresses) -------------
+    return mine;
+}
+
+// Add the accumulators into a row-major weight row `dst` [1617] (LDS or global; every lane owns its addresses, so plain read-add-write)
+// and clear them.
+// kAssign: store instead of add (every one of the 1617 entries is owned by exactly one lane, so a row is fully written).
+template <bool kAssign = false, typename Row>
+__device__ __forceinline__ void mlp_adjoint_flush(MlpAdjoint& s, Row dst, int lane) {
+    const int g = lane >> 4, m = lane & 15;
+    auto put = [&](int index, float value) { dst[index] = kAssign ? value : dst[index] + value; };
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
-        for (int l = 0; l < 3; ++l) wbar[kMlpLayer1 + l * kMlpBlock + (4 * g + j) * kMlpRow + m] += acc_w[l][j];
+        for (int l = 0; l < 3; ++l) put(kMlpLayer1 + l * kMlpBlock + (4 * g + j) * kMlpRow + m, s.acc_w[l][j]);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) wbar[(4 * g + j) * kMlpRow0 + 16 * c + m] += acc_w0[c][j];
+        for (int c = 0; c < 3; ++c) put((4 * g + j) * kMlpRow0 + 16 * c + m, s.acc_w0[c][j]);
     }
     // biases / head weights: sum over the 16 points of the row, lane m < 4 of row g stores channel 4 g + m
-    const float b0 = pick4(row_sum16(acc_b0), m), w4 = pick4(row_sum16(acc_w4), m);
+    const float b0 = pick4(row_sum16(s.acc_b0), m), w4 = pick4(row_sum16(s.acc_w4), m);
     float bl[3];
 #pragma unroll
-    for (int l = 0; l < 3; ++l) bl[l] = pick4(row_sum16(acc_b[l]), m);
-    const float b4 = row_sum16(acc_b4);
+    for (int l = 0; l < 3; ++l) bl[l] = pick4(row_sum16(s.acc_b[l]), m);
+    const float b4 = row_sum16(s.acc_b4);
     if (m < 4) {
-        wbar[(4 * g + m) * kMlpRow0 + kMlpFeatures] += b0;
-        wbar[kMlpHead + 4 * g + m] += w4;
+        put((4 * g + m) * kMlpRow0 + kMlpFeatures, b0);
+        put(kMlpHead + 4 * g + m, w4);
 #pragma unroll
-        for (int l = 0; l < 3; ++l) wbar[kMlpLayer1 + l * kMlpBlock + (4 * g + m) * kMlpRow + kMlpHidden] += bl[l];
+        for (int l = 0; l < 3; ++l) put(kMlpLayer1 + l * kMlpBlock + (4 * g + m) * kMlpRow + kMlpHidden, bl[l]);
     }
-    if (lane == 0) wbar[kMlpHead + kMlpHidden] += b4;
+    if (lane == 0) put(kMlpHead + kMlpHidden, b4);
+    s.clear();
+}
+
+// One point set of one instance, start to finish: adds dL/dw into `mlp_lds` (the wave's LDS: wbar [1617], then the transposition
+// scratch); returns dL/dp per lane.  (residual_mlp_adjoint_kernel, with many point sets per instance, uses the pieces directly.)
+__device__ __forceinline__ ResidualAdjoint residual_backward(const float* w_in, float px, float py, float pz,
+                                                             float res_bar, float gbx, float gby, float gbz, float* mlp_lds, int lane, unsigned tiles_in) {
+    const LdsFloats wbar = (LdsFloats)mlp_lds;
+    MlpAdjoint s;
+    s.clear();
+    RegisterWeights wt;
+    load_register_weights(wt, w_in, lane, (__builtin_amdgcn_readfirstlane(tiles_in) & kMlpCentredBit) != 0u);
+    const ResidualAdjoint mine = mlp_adjoint_points<false>(s, wt, px, py, pz, res_bar, gbx, gby, gbz, wbar + kMlpWbarFloats, lane, tiles_in);
+    mlp_adjoint_flush(s, wbar, lane);
     return mine;
 }
 

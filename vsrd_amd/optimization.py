@@ -90,7 +90,7 @@ class FrameOptimizer:
         # sizes it for the residual phase up front: a captured graph holds the buffer's address
         self.workspace = rendering.Workspace()
         if self.graph:
-            self.workspace.reserve(self.device, N, residual=True)
+            self.workspace.reserve(self.device, N, residual=True, step_shape=(config.num_samples, config.num_rays))
         self._graphs = {}
         self._capture_stream = None
         self._eager_graph_steps = {}
@@ -190,7 +190,7 @@ class FrameOptimizer:
             flags |= _lib.FLAG_MLP_WEIGHTS_CENTRED
         elif cfg.skip_exact_misses:
             flags |= _lib.FLAG_SKIP_EXACT_MISSES
-        workspace = self.workspace.adjoint(self.device, N, residual)
+        workspace = self.workspace.adjoint(self.device, N, residual, step_shape=(cfg.num_samples, R))
         field = _lib.make_field(b["instances"], 1.0, centred)          # (the temperature comes from the device schedule)
         config = _lib.make_config(R, cfg.num_samples, cfg.distance_range, 1.0, 1.0, 1.0e-6, 3, seed=cfg.seed, stream_offset=self.step_tensor, flags=flags,
                                   schedule=self.schedule, gather=(ray_indices, self.pixels_per_view, b["target_columns"], N))

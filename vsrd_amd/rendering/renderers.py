@@ -38,8 +38,11 @@ class Workspace:
         self._retired = []      # outgrown buffers that captured graphs may still reference (only kept when asked to)
         self.keep_outgrown = False
 
-    def adjoint(self, device, num_instances, residual=False):
+    def adjoint(self, device, num_instances, residual=False, step_shape=None):
+        """``step_shape = (num_samples, num_rays)``: scratch of vsrd_render_residual_step for that launch (seeds of a chunk of rays)."""
         need = _lib.load().vsrd_workspace_bytes(int(num_instances), 1 if residual else 0)
+        if residual and step_shape is not None:
+            need = max(need, _lib.load().vsrd_residual_step_workspace_bytes(int(num_instances), int(step_shape[0]), int(step_shape[1])))
         buf = self._adjoint.get(device)
         if buf is None or buf.numel() < need:
             if buf is not None and self.keep_outgrown:
@@ -47,9 +50,9 @@ class Workspace:
             buf = self._adjoint[device] = torch.empty(need, dtype=torch.uint8, device=device)
         return buf
 
-    def reserve(self, device, num_instances, residual=True):
+    def reserve(self, device, num_instances, residual=True, step_shape=None):
         """Allocate now what the largest later launch will need (a hipGraph captures the buffer's address)."""
-        return self.adjoint(device, num_instances, residual)
+        return self.adjoint(device, num_instances, residual, step_shape)
 
     def sampler(self, device):
         buf = self._sampler.get(device)
@@ -117,8 +120,8 @@ def _mlp_flag(centred_weights):
     return _lib.FLAG_MLP_WEIGHTS_CENTRED if centred_weights is not None else 0
 
 
-def _workspace(device, num_instances, residual=False):
-    return current_workspace().adjoint(device, num_instances, residual)
+def _workspace(device, num_instances, residual=False, step_shape=None):
+    return current_workspace().adjoint(device, num_instances, residual, step_shape)
 
 
 def _prepare_rays(ray_positions, ray_directions):
@@ -575,7 +578,7 @@ class _ResidualStep(torch.autograd.Function):
         losses = torch.empty(2, dtype=torch.float32, device=dev)
         grad, grad_mlp = torch.empty_like(instances), torch.empty_like(centred)
         labels = torch.empty(R, N, dtype=torch.float32, device=dev) if want_labels else None
-        workspace = _workspace(dev, N, True)
+        workspace = _workspace(dev, N, True, step_shape=(S, R))
         field = _lib.make_field(instances, temperature, centred)
         config = _lib.make_config(R, S, (near, far), std, ratio, eps, origin_stride, seed, stream_offset, flags | _mlp_flag(centred), schedule=schedule)
         with profiling.timed("vsrd_render_residual_step"):
