@@ -320,7 +320,7 @@ int32_t vsrd_render_forward(const vsrd_field* field, const vsrd_render_config* c
     if (!origins || !directions || !distances || !labels) return VSRD_E_INVALID_ARGUMENT;
     const bool residual = field->mlp_weights != nullptr;
     Geometry g;
-    if (!plan(config->num_rays, static_cast<size_t>(forward_lds_floats(num_distances, field->num_instances)), &g)) return VSRD_E_UNSUPPORTED;
+    if (!plan(config->num_rays, static_cast<size_t>(forward_lds_floats(num_distances, field->num_instances, residual)), &g)) return VSRD_E_UNSUPPORTED;
     const FieldArgs f = field_args(field);
     RenderArgs c = render_args(config);
     c.sh.inv_t = f.inv_t;
@@ -429,7 +429,7 @@ int32_t vsrd_render_hierarchical_forward(const vsrd_field* field, const vsrd_ren
     if ((config->flags & VSRD_FLAG_SKIP_EXACT_MISSES) && (gradients || weights)) return VSRD_E_INVALID_ARGUMENT;
     const int S = config->num_samples;
     Geometry g;
-    if (!plan(config->num_rays, wave_lds_floats(S, field->num_instances), &g)) return VSRD_E_UNSUPPORTED;
+    if (!plan(config->num_rays, static_cast<size_t>(hierarchical_lds_floats(S, field->num_instances, residual)), &g)) return VSRD_E_UNSUPPORTED;
     const FieldArgs f = field_args(field);
     RenderArgs c = render_args(config);
     c.sh.inv_t = f.inv_t;

@@ -35,6 +35,9 @@ __global__ __launch_bounds__(256) void field_eval_kernel(FieldArgs f, const floa
                                                          const float* __restrict__ positions, long long num_points,
                                                          float* __restrict__ distances, float* __restrict__ gradients,
                                                          float* __restrict__ labels, int hard_union) {
+    // residual fields: this wave's staging area for residual_forward's weight operands (static LDS: 4 waves x 6.5 KB)
+    __shared__ float forward_weights_all[kResidual ? (256 / kWave) * kMlpWbarFloats : 1];
+    float* forward_weights = forward_weights_all + (kResidual ? wave_in_block() * kMlpWbarFloats : 0);
     // whole waves stay in the loop (the residual MLP is wave-cooperative): tail lanes evaluate the last point and store nothing
     for (long long base = static_cast<long long>(blockIdx.x) * blockDim.x + (threadIdx.x & ~(kWave - 1)); base < num_points;
          base += static_cast<long long>(gridDim.x) * blockDim.x) {
@@ -44,7 +47,7 @@ __global__ __launch_bounds__(256) void field_eval_kernel(FieldArgs f, const floa
         if (hard_union) {
             float best = 3.0e38f, bx = 0.0f, by = 0.0f, bz = 0.0f;
             for (int i = 0; i < f.num_instances; ++i) {
-                const BoxEval e = eval_instance<kResidual>(load_instance(instances, i), kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z);
+                const BoxEval e = eval_instance<kResidual>(load_instance(instances, i), kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z, forward_weights);
                 if (e.d < best) { best = e.d; bx = e.gwx; by = e.gwy; bz = e.gwz; }   // argmin: first minimum
             }
             if (distances && valid) distances[idx] = best;
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256) void field_eval_kernel(FieldArgs f, const floa
         }
         UnionSums sums = union_init();
         for (int i = 0; i < f.num_instances; ++i) {
-            const BoxEval e = eval_instance<kResidual>(load_instance(instances, i), kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z);
+            const BoxEval e = eval_instance<kResidual>(load_instance(instances, i), kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z, forward_weights);
             union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, 0.0f, f.inv_t);
         }
         const UnionValue v = union_finish(sums, f.inv_t);
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(256) void field_eval_kernel(FieldArgs f, const floa
         if (gradients && valid) { gradients[idx * 3 + 0] = v.gx; gradients[idx * 3 + 1] = v.gy; gradients[idx * 3 + 2] = v.gz; }
         if (labels) {
             for (int i = 0; i < f.num_instances; ++i) {
-                const BoxEval e = eval_instance<kResidual>(load_instance(instances, i), kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z);
+                const BoxEval e = eval_instance<kResidual>(load_instance(instances, i), kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z, forward_weights);
                 if (valid) labels[idx * f.num_instances + i] = fast_exp(-(e.d - v.m) * f.inv_t) * v.inv_z;
             }
         }
@@ -81,6 +84,8 @@ __global__ __launch_bounds__(kBlockThreads) void field_eval_backward_kernel(
     const float* __restrict__ grad_distances, const float* __restrict__ grad_labels, int hard_union,
     float* __restrict__ grad_positions, float* __restrict__ partials, float* __restrict__ mlp_partials) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float forward_weights_all[kResidual ? kMaxWavesPerBlock * kMlpWbarFloats : 1];      // residual_forward's staged weights
+    float* forward_weights = forward_weights_all + (kResidual ? wave_in_block() * kMlpWbarFloats : 0);
     const int wave = wave_in_block();
     const int lane = lane_id();
     const int N = f.num_instances;
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(kBlockThreads) void field_eval_backward_kernel(
         float best = 3.0e38f;
         int best_index = 0;
         for (int i = 0; i < N; ++i) {
-            const BoxEval e = eval_instance<kResidual>(load_instance(instances, i), kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z);
+            const BoxEval e = eval_instance<kResidual>(load_instance(instances, i), kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z, forward_weights);
             const float lambda = (valid && grad_labels && !hard_union) ? grad_labels[idx * N + i] : 0.0f;
             union_accumulate(sums, e.d, e.gwx, e.gwy, e.gwz, lambda, f.inv_t);
             if (e.d < best) { best = e.d; best_index = i; }                   // argmin: first minimum
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(kBlockThreads) void field_eval_backward_kernel(
         float xb = 0.0f, yb = 0.0f, zb = 0.0f;
         for (int i = 0; i < N; ++i) {
             const Instance in = load_instance(instances, i);
-            const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z);
+            const BoxEval e = eval_instance<kResidual>(in, kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z, forward_weights);
             float d_bar;
             if (hard_union) {
                 d_bar = (i == best_index) ? u_bar : 0.0f;
@@ -159,10 +164,10 @@ __global__ __launch_bounds__(kBlockThreads) void field_eval_backward_kernel(
 // Union distance only (no normal): what sphere tracing evaluates per step.
 template <bool kResidual>
 __device__ __forceinline__ float union_distance(const FieldArgs& f, const float* __restrict__ instances, const float* __restrict__ mlp,
-                                                float x, float y, float z, int hard_union) {
+                                                float x, float y, float z, int hard_union, float* forward_weights) {
     float m = 3.0e38f, Z = 0.0f, S1 = 0.0f;           // online soft-min (field.h), value part only
     for (int i = 0; i < f.num_instances; ++i) {
-        const BoxEval e = eval_instance<kResidual>(load_instance(instances, i), kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z);
+        const BoxEval e = eval_instance<kResidual>(load_instance(instances, i), kResidual ? mlp + i * kMlpWeights : nullptr, x, y, z, forward_weights);
         const float d = e.d;
         if (hard_union) { m = fminf(m, d); continue; }
         const bool lower = d < m;
@@ -188,6 +193,9 @@ __global__ __launch_bounds__(256) void sphere_trace_kernel(FieldArgs f, const fl
                                                            long long num_rays, int num_iterations, float criteria, float bounding_radius,
                                                            int initialise, int hard_union,
                                                            float* __restrict__ positions, unsigned char* __restrict__ converged) {
+    // residual fields: this wave's staging area for residual_forward's weight operands (static LDS: 4 waves x 6.5 KB)
+    __shared__ float forward_weights_all[kResidual ? (256 / kWave) * kMlpWbarFloats : 1];
+    float* forward_weights = forward_weights_all + (kResidual ? wave_in_block() * kMlpWbarFloats : 0);
     for (long long base = static_cast<long long>(blockIdx.x) * blockDim.x + (threadIdx.x & ~(kWave - 1)); base < num_rays;
          base += static_cast<long long>(gridDim.x) * blockDim.x) {                 // whole waves (see field_eval_kernel)
         const bool valid = base + lane_id() < num_rays;
@@ -208,7 +216,7 @@ __global__ __launch_bounds__(256) void sphere_trace_kernel(FieldArgs f, const fl
         }
         bool conv = false, done = !valid;
         for (int it = 0; it < num_iterations; ++it) {
-            const float sd = union_distance<kResidual>(f, instances, mlp, px, py, pz, hard_union);     // all lanes, stopped or not
+            const float sd = union_distance<kResidual>(f, instances, mlp, px, py, pz, hard_union, forward_weights);     // all lanes, stopped or not
             if (!done) {
                 if (fg && !conv) { px += dx * sd; py += dy * sd; pz += dz * sd; }
                 if (bounding_radius > 0.0f) fg = fg && (sqrtf(px * px + py * py + pz * pz) < bounding_radius);

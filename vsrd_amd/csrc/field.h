@@ -133,11 +133,11 @@ __device__ __forceinline__ void add_residual(BoxEval& e, const Instance& in, con
 // of the other rows get residual 0 -- their soft-min weight is below exp(-tau) on the box distance alone (culling, below).
 // `keep`: where to leave the residual jet for the adjoint (render_backward_kernel caches it instead of re-evaluating the MLP).
 template <bool kResidual>
-__device__ __forceinline__ BoxEval eval_instance(const Instance& in, const float* __restrict__ mlp, float x, float y, float z, unsigned tiles = 0xFu,
-                                                 Residual* keep = nullptr) {
+__device__ __forceinline__ BoxEval eval_instance(const Instance& in, const float* __restrict__ mlp, float x, float y, float z, float* mlp_lds,
+                                                 unsigned tiles = 0xFu, Residual* keep = nullptr) {
     BoxEval e = eval_box(in, x, y, z);
     if (kResidual) {
-        const Residual r = residual_forward(mlp, e.px, e.py, e.pz, tiles);      // wave-cooperative: all 64 lanes active
+        const Residual r = residual_forward(mlp, e.px, e.py, e.pz, tiles, mlp_lds);      // wave-cooperative: all 64 lanes active
         add_residual(e, in, r);
         if (keep) *keep = r;
     }

@@ -13,15 +13,23 @@ constexpr int kGradStride = kInstanceStride;   // grad_instances rows are [t(3) 
 constexpr int kSeedFloats = 10;                // per sample: local position (3), d_bar, gl_bar (3), x - t (3)
 constexpr int kMlpBatch = 8;                   // rays whose MLP adjoints are run together, instance-major (adjoint_phase_mlp)
 
+// residual fields: every wave also owns kMlpWbarFloats floats for residual_forward's staged weight operands (Shading::mlp_lds)
+__host__ __device__ constexpr int forward_weights_floats(bool residual) { return residual ? kMlpWbarFloats : 0; }
+
 // Floats of LDS one wave of render_backward_kernel owns (a multiple of 4: the partitions stay 16-byte aligned).
 __host__ __device__ constexpr int backward_lds_floats(int num_distances, int num_instances, bool residual) {
-    return ((residual ? kMlpLdsFloats + kMlpBatch * 4 * num_instances : 0) + num_distances + num_instances + num_instances * kGradStride +
-            cull_coef_floats(num_instances) + 3) & ~3;
+    return (forward_weights_floats(residual) + (residual ? kMlpLdsFloats + kMlpBatch * 4 * num_instances : 0) + num_distances + num_instances +
+            num_instances * kGradStride + cull_coef_floats(num_instances) + 3) & ~3;
 }
 
 // Floats of LDS one wave of render_forward_kernel owns: sorted distances, [N][64] distance cache, culling coefficients.
-__host__ __device__ constexpr int forward_lds_floats(int num_distances, int num_instances) {
-    return num_distances + num_instances * kWave + cull_coef_floats(num_instances);
+__host__ __device__ constexpr int forward_lds_floats(int num_distances, int num_instances, bool residual = false) {
+    return (forward_weights_floats(residual) + num_distances + num_instances * kWave + cull_coef_floats(num_instances) + 3) & ~3;
+}
+
+// ... and of render_hierarchical_kernel.
+__host__ __device__ constexpr int hierarchical_lds_floats(int num_samples, int num_instances, bool residual) {
+    return (forward_weights_floats(residual) + wave_lds_floats(num_samples, num_instances) + 3) & ~3;
 }
 
 // The instance block [N,16] travels as its own `const float* __restrict__` kernel argument (not inside this
@@ -125,11 +133,12 @@ __global__ __launch_bounds__(kBlockThreads) void render_forward_kernel(
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = wave_in_block();
     const int lane = lane_id();
-    const int per_wave = forward_lds_floats(num_distances, f.num_instances);
-    float* dist = lds + wave * per_wave;
+    const int per_wave = forward_lds_floats(num_distances, f.num_instances, kResidual);
+    float* dist = lds + wave * per_wave + forward_weights_floats(kResidual);
     float* dcache = dist + num_distances;
     float* coef = dcache + f.num_instances * kWave;
     Shading sh = c.sh;
+    sh.mlp_lds = lds + wave * per_wave;
     const FieldBounds bounds = field_bounds(instances, f.num_instances, f.inv_t, kResidual, c.flags);
     sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
     sh.mlp_bits = (c.flags & 8u) ? kMlpCentredBit : 0u;
@@ -228,9 +237,11 @@ __global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
     const int wave = wave_in_block();
     const int lane = lane_id();
     const int S = c.num_samples;
-    const WaveLds l = carve_lds(lds + wave * wave_lds_floats(S, f.num_instances), S, f.num_instances);
+    float* mine = lds + wave * hierarchical_lds_floats(S, f.num_instances, kResidual);
+    const WaveLds l = carve_lds(mine + forward_weights_floats(kResidual), S, f.num_instances);
     const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
     Shading sh = c.sh;
+    sh.mlp_lds = mine;
     const FieldBounds bounds = field_bounds(instances, f.num_instances, f.inv_t, kResidual, c.flags);
     sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
     sh.mlp_bits = (c.flags & 8u) ? kMlpCentredBit : 0u;
@@ -317,7 +328,7 @@ __device__ __forceinline__ UnionSums sweep_union_loop(RayAdjoint<kRounds>& st, i
         if (kResidual) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) st.near_rows[k][q] |= ((near >> (16 * q)) & 0xFFFFull) ? (1ull << i) : 0ull;
-            const Residual res = residual_forward(mlp + i * kMlpWeights, e.px, e.py, e.pz, rows_with(near) | sh.mlp_bits);
+            const Residual res = residual_forward(mlp + i * kMlpWeights, e.px, e.py, e.pz, rows_with(near) | sh.mlp_bits, sh.mlp_lds);
             add_residual<kYaw>(e, in, res);
             if (rcache) rcache[(k * N + i) * kWave + lane] = make_float4(res.value, res.gx, res.gy, res.gz);
         }
@@ -656,7 +667,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
     const int N = f.num_instances;
     const int num_points = num_distances - 1;
     const int per_wave = backward_lds_floats(num_distances, N, kResidual);
-    float* wbar = lds + wave * per_wave;                                 // residual only: [1617] MLP weight adjoints of the current
+    float* wbar = lds + wave * per_wave + forward_weights_floats(kResidual);   // residual only: [1617] MLP weight adjoints of the current
     float* dist = wbar + (kResidual ? kMlpLdsFloats : 0);                // instance + the transposition scratch (residual.h), 16 B aligned
     float* lam = dist + num_distances;
     float* G = lam + N;
@@ -673,6 +684,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
         for (int idx = lane; idx < kMlpWeights; idx += kWave) wbar[idx] = 0.0f;
     }
     Shading sh = c.sh;
+    sh.mlp_lds = lds + wave * per_wave;
     const FieldBounds bounds = field_bounds(instances, N, f.inv_t, kResidual, c.flags);
     sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
     sh.mlp_bits = (c.flags & 8u) ? kMlpCentredBit : 0u;
@@ -749,6 +761,7 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
     const FieldBounds bounds = field_bounds(instances, N, f.inv_t, false, c.flags);
     sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
     sh.mlp_bits = 0u;
+    sh.mlp_lds = nullptr;
     const float weight_lane = (lane < N) ? (instance_weights ? instance_weights[lane] : 1.0f) : 0.0f;
     float loss_acc = 0.0f;                                                  // lane n: this wave's BCE sum of instance n
     const int D = 2 * S, num_points = D - 1;
@@ -817,7 +830,7 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
 // afterwards, instance-major (adjoint_phase_mlp).  Loss = loss_partials[.][0] + eikonal_ratio * loss_partials[.][1] summed over waves.
 // ---------------------------------------------------------------------------------------------------
 __host__ __device__ constexpr int residual_step_lds_floats(int num_samples, int num_instances) {
-    return (kMlpLdsFloats + kMlpBatch * 4 * num_instances + wave_lds_floats(num_samples, num_instances) + num_instances + num_instances * kGradStride + 3) & ~3;
+    return (kMlpWbarFloats + kMlpLdsFloats + kMlpBatch * 4 * num_instances + wave_lds_floats(num_samples, num_instances) + num_instances + num_instances * kGradStride + 3) & ~3;
 }
 
 #ifndef VSRD_RESIDUAL_WAVES_PER_EU
@@ -837,7 +850,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(V
     const int lane = lane_id();
     const int S = c.num_samples;
     const int N = f.num_instances;
-    float* wbar = lds + wave * residual_step_lds_floats(S, N);            // [1617] + transposition scratch (residual.h), 16 B aligned
+    float* wbar = lds + wave * residual_step_lds_floats(S, N) + kMlpWbarFloats;   // [1617] + transposition scratch (residual.h), 16 B aligned
     unsigned* masks = reinterpret_cast<unsigned*>(wbar + kMlpLdsFloats);  // [kMlpBatch][kRounds][N]
     float* base = wbar + kMlpLdsFloats + kMlpBatch * 4 * N;
     WaveLds l = carve_lds(base, S, N);                                     // l.dcache: [N][64], one round at a time
@@ -852,6 +865,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(V
     for (int idx = lane; idx < kMlpWeights; idx += kWave) wbar[idx] = 0.0f;
     const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
     Shading sh = c.sh;
+    sh.mlp_lds = wbar - kMlpWbarFloats;
     const FieldBounds bounds = field_bounds(instances, N, f.inv_t, true, c.flags);
     sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
     sh.mlp_bits = (c.flags & 8u) ? kMlpCentredBit : 0u;
@@ -938,11 +952,12 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(V
 constexpr int kItemRowFloats = kMlpWbarFloats + kGradStride;         // 1632 + 16
 
 __host__ __device__ constexpr int residual_front_lds_floats(int num_samples, int num_instances) {
-    return (wave_lds_floats(num_samples, num_instances) + num_instances + num_instances * kGradStride + 3) & ~3;
+    return (kMlpWbarFloats + wave_lds_floats(num_samples, num_instances) + num_instances + num_instances * kGradStride + 3) & ~3;
 }
 
+// (four rounds -- S in (64, 128], the reference's own S = 100 -- hold twice the per-ray adjoint state and do not fit 256 registers)
 template <int kRounds>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void residual_step_front_kernel(
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(kRounds <= 2 ? 2 : 1, 2))) void residual_step_front_kernel(
     FieldArgs f, const float* __restrict__ instances, const float* __restrict__ mlp, RenderArgs c,
     const float* __restrict__ origins, const float* __restrict__ directions, const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
     const float* __restrict__ targets, const float* __restrict__ instance_weights, float loss_scale, float eikonal_scale, float eikonal_norm,
@@ -955,7 +970,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2
     const int lane = lane_id();
     const int S = c.num_samples;
     const int N = f.num_instances;
-    float* base = lds + wave * residual_front_lds_floats(S, N);
+    float* base = lds + wave * residual_front_lds_floats(S, N) + kMlpWbarFloats;
     WaveLds l = carve_lds(base, S, N);                                     // l.dcache: [N][64], one round at a time
     float* lam = base + wave_lds_floats(S, N);
     float* G = lam + N;
@@ -965,6 +980,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2
     float4* rcache = residual_cache + wave_global * (static_cast<size_t>(kRounds) * N * kWave);
     const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
     Shading sh = c.sh;
+    sh.mlp_lds = base - kMlpWbarFloats;
     const FieldBounds bounds = field_bounds(instances, N, f.inv_t, true, c.flags);
     sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
     sh.mlp_bits = (c.flags & 8u) ? kMlpCentredBit : 0u;

@@ -100,6 +100,13 @@ __device__ __forceinline__ GlobalWeights uniform_weights(const float* p) {
     return reinterpret_cast<GlobalWeights>((static_cast<unsigned long long>(hi) << 32) | lo);
 }
 
+__device__ __forceinline__ const float* uniform_weights_generic(const float* p) {
+    const unsigned long long bits = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(bits));
+    const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(bits >> 32));
+    return reinterpret_cast<const float*>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
 // Sum over the 16 lanes of each row (every lane of the row receives it).
 __device__ __forceinline__ float row_sum16(float v) {
     v += dpp_move<kDppQuadXor1>(0.0f, v);
@@ -173,16 +180,14 @@ __device__ __forceinline__ void encode_tile(float f0, float f1, float f2, int g,
     const float f[3] = {f0, f1, f2};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const float octave = kk ? 2.0f * base : base;
-            const float x = f[c] * octave;                       // exact scaling; sin(pi x), cos(pi x)
-            float s, co;
-            sincospi(x, s, co);
-            const float omega = octave * kPi;
-            e.f[c][2 * kk] = co; e.f[c][2 * kk + 1] = s;
-            e.d[c][2 * kk] = -omega * s; e.d[c][2 * kk + 1] = omega * co;
-        }
+        // octave 2 g through the exact range reduction of sincospi, octave 2 g + 1 = twice the angle by the double-angle formulas
+        // (3 instead of ~24 instructions; one doubling adds ~1e-7 to the 1e-7 of the pair it starts from)
+        float s0, c0;
+        sincospi(f[c] * base, s0, c0);                           // exact scaling; sin(pi x), cos(pi x)
+        const float s1 = 2.0f * s0 * c0, c1 = fmaf(-2.0f * s0, s0, 1.0f);
+        const float omega0 = base * kPi, omega1 = 2.0f * base * kPi;
+        e.f[c][0] = c0; e.f[c][1] = s0; e.f[c][2] = c1; e.f[c][3] = s1;
+        e.d[c][0] = -omega0 * s0; e.d[c][1] = omega0 * c0; e.d[c][2] = -omega1 * s1; e.d[c][3] = omega1 * c1;
     }
 }
 
@@ -236,47 +241,6 @@ __device__ __forceinline__ void norm_gelu_tile(TileJet& z) {
 }
 
 struct Residual { float value; float gx, gy, gz; };
-
-// residual(p) and d residual / d p for the local positions p of the wave's 64 points, instance weights w (wave-uniform).
-// NOT inlined: one copy per kernel keeps the residual kernels' code inside the instruction cache.
-// `tiles_in`: wave-uniform mask of the 16-point tiles to evaluate; lanes of the other tiles return 0.
-VSRD_RESIDUAL_FN Residual residual_forward(const float* w_in, float px, float py, float pz, unsigned tiles_in) {
-    const int lane = lane_id();
-    const int g = lane >> 4;
-    const unsigned tiles = __builtin_amdgcn_readfirstlane(tiles_in);
-    const GlobalWeights w = uniform_weights(w_in);
-    ForwardWeights fw;
-    load_forward_weights(w, lane, fw, (tiles & kMlpCentredBit) != 0u);
-    const float fold = (px > 0.0f) ? 1.0f : ((px < 0.0f) ? -1.0f : 0.0f);
-    const float inv = 1.0f / kPositionScale;
-    const float f0 = fabsf(px) * inv, f1 = py * inv, f2 = pz * inv;
-    float out_v = 0.0f, out_t0 = 0.0f, out_t1 = 0.0f, out_t2 = 0.0f;
-#pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
-        if (!((tiles >> q) & 1u)) continue;
-        TileFeatures e;
-        encode_tile(from_row(f0, q, lane), from_row(f1, q, lane), from_row(f2, q, lane), g, e);
-        TileJet z, n;
-        first_layer_tile(fw, e, z);
-#pragma unroll
-        for (int l = 0; l < 3; ++l) {
-            norm_gelu_tile(z);
-            linear_tile(fw.a[l], fw.b[l], z, n);
-            z = n;
-        }
-        norm_gelu_tile(z);
-        const float v = rows_sum(dot4(fw.w4, z.v)) + fw.b4;
-        const float t0 = rows_sum(dot4(fw.w4, z.t[0])), t1 = rows_sum(dot4(fw.w4, z.t[1])), t2 = rows_sum(dot4(fw.w4, z.t[2]));
-        const bool mine = (g == q);                              // row q of tile q holds point 16 q + m = this lane
-        out_v = mine ? v : out_v; out_t0 = mine ? t0 : out_t0; out_t1 = mine ? t1 : out_t1; out_t2 = mine ? t2 : out_t2;
-    }
-    Residual r;
-    r.value = ((tiles >> g) & 1u) ? fast_rcp(1.0f + fast_exp(-(out_v - 1.0f))) : 0.0f;
-    const float kappa = r.value * (1.0f - r.value) * inv;
-    r.gx = kappa * out_t0 * fold; r.gy = kappa * out_t1; r.gz = kappa * out_t2;
-    return r;
-}
-
 
 // ---- adjoint ------------------------------------------------------------------------------------------------------
 // Blueprint: oracle/analytic_mlp.py::backward (float64, checked against autograd).  Same tile layout as the forward.
@@ -497,6 +461,95 @@ __device__ __forceinline__ void load_register_weights(RegisterWeights& w, const 
     const GlobalWeights global = uniform_weights(w_in);
     load_forward_weights(global, lane, w.fw, centred);
     load_backward_weights(global, lane, w.bw);
+}
+
+// residual(p) and d residual / d p for the local positions p of the wave's 64 points, instance weights w (wave-uniform).
+// Value by one forward column, gradient by one REVERSE column (oracle/analytic_mlp.py: forward_reverse) instead of three forward
+// tangents:  a_bar_3 = w4,  z_bar_l = P_l(a_bar_l * gelu'(y_l)),  a_bar_{l-1} = W_l^T z_bar_l,  feat_bar = W_0^T z_bar_0,
+// d out / d f_c = sum_j feat_bar_{c,j} dfeat_{c,j}: 64 instead of 92 MFMAs per 16-point tile, and the LayerNorm / GELU algebra on two
+// columns instead of four.
+// NOT inlined: one copy per kernel keeps the residual kernels' code inside the instruction cache.
+// `tiles_in`: wave-uniform mask of the 16-point tiles to evaluate; lanes of the other tiles return 0.
+// `weights_lds`: kMlpWbarFloats floats of this wave's LDS.  The instance's weights are staged there (26 coalesced loads per lane
+// instead of 69 gathers of 64 scattered addresses each) and read operand by operand: held in registers they would cost the CALLERS
+// their second wave per SIMD (a callee's registers, and the AGPRs it parks callee-saved ones in, count towards its callers).
+VSRD_RESIDUAL_FN Residual residual_forward(const float* w_in, float px, float py, float pz, unsigned tiles_in, float* weights_lds) {
+    const int lane = lane_id();
+    const int g = lane >> 4;
+    const unsigned tiles = __builtin_amdgcn_readfirstlane(tiles_in);
+    const LdsFloats staged = (LdsFloats)weights_lds;
+    wave_lds_order();                                            // (the previous call's operand reads are done)
+    stage_centred_weights_wave(staged, uniform_weights_generic(w_in), (tiles & kMlpCentredBit) != 0u, lane);
+    wave_lds_order();
+    const LdsWeights wt = {staged, g, lane & 15};
+    const float fold = (px > 0.0f) ? 1.0f : ((px < 0.0f) ? -1.0f : 0.0f);
+    const float inv = 1.0f / kPositionScale;
+    const float f0 = fabsf(px) * inv, f1 = py * inv, f2 = pz * inv;
+    float out_v = 0.0f, out_t0 = 0.0f, out_t1 = 0.0f, out_t2 = 0.0f;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        if (!((tiles >> q) & 1u)) continue;
+        TileFeatures e;
+        encode_tile(from_row(f0, q, lane), from_row(f1, q, lane), from_row(f2, q, lane), g, e);
+        // ---- forward column ---------------------------------------------------------------------------------------------------
+        f32x4 z = wt.b0();
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) z = mfma4(wt.a0(c, k), e.f[c][k], z);
+        f32x4 y[4], g1[4];
+        float inv_s[4];
+        float v = 0.0f;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {                            // z has zero channel mean (load_forward_weights)
+            const float var = rows_sum(dot4(z, z)) * (1.0f / kMlpHidden);
+            inv_s[l] = __builtin_amdgcn_rsqf(var + kLayerNormEps);
+            y[l] = z * splat4(inv_s[l]);
+            f32x4 a;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const Gauss n = gauss(y[l][j]);
+                a[j] = y[l][j] * n.cdf;
+                g1[l][j] = n.cdf + y[l][j] * n.pdf;
+            }
+            if (l < 3) {
+                z = wt.b(l);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) z = mfma4(wt.a(l, k), a[k], z);
+            } else {
+                v = rows_sum(dot4(wt.w4(), a)) + wt.b4();
+            }
+        }
+        // ---- reverse column ---------------------------------------------------------------------------------------------------
+        f32x4 a_bar = wt.w4(), z_bar;
+#pragma unroll
+        for (int l = 3; l >= 0; --l) {
+            const f32x4 u = a_bar * g1[l];
+            const float m = rows_sum(hsum4(u)) * (1.0f / kMlpHidden);
+            const float my = rows_sum(dot4(u, y[l])) * (1.0f / kMlpHidden);
+            z_bar = (u - splat4(m) - y[l] * splat4(my)) * splat4(inv_s[l]);
+            if (l > 0) {
+                a_bar = splat4(0.0f);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a_bar = mfma4(wt.at(l - 1, k), z_bar[k], a_bar);
+            }
+        }
+        float t[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            f32x4 feat_bar = splat4(0.0f);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) feat_bar = mfma4(wt.at0(c, k), z_bar[k], feat_bar);
+            t[c] = rows_sum(dot4(feat_bar, e.d[c]));
+        }
+        const bool mine = (g == q);                              // row q of tile q holds point 16 q + m = this lane
+        out_v = mine ? v : out_v; out_t0 = mine ? t[0] : out_t0; out_t1 = mine ? t[1] : out_t1; out_t2 = mine ? t[2] : out_t2;
+    }
+    Residual r;
+    r.value = ((tiles >> g) & 1u) ? fast_rcp(1.0f + fast_exp(-(out_v - 1.0f))) : 0.0f;
+    const float kappa = r.value * (1.0f - r.value) * inv;
+    r.gx = kappa * out_t0 * fold; r.gy = kappa * out_t1; r.gz = kappa * out_t2;
+    return r;
 }
 
 // Register j of lane (g, m) of a staged tile, back in the layout stage_tile took it from.
