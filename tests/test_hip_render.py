@@ -718,6 +718,41 @@ def test_fused_residual_step_golden(dev, name):
         assert err < GRAD_TOL, f"{key}: relative error {err:.3e}"
 
 
+@pytest.mark.parametrize("name", [n for n in RESIDUAL_CASES if n.startswith("g17")])
+def test_residual_step_split_and_single_kernel_agree(dev, name):
+    """vsrd_render_residual_step runs as two kernels per chunk of rays by default (front part + MLP adjoint distributed by instance);
+    VSRD_FLAG_RESIDUAL_SINGLE_KERNEL keeps the one-kernel form.  Same arithmetic, different summation trees: losses, labels and
+    every gradient must agree to rounding, and each form must repeat itself bit for bit."""
+    from vsrd_amd import fields, rendering
+    from vsrd_amd.rendering import renderers
+    g = load_golden(name)
+    S, N = int(g["num_samples"]), g["locations"].shape[0]
+    std, ratio = float(g["sdf_std_deviation"]), float(g["cosine_ratio"])
+    keep = g["conditioned"].reshape(-1)
+    results = {}
+    for single in (False, True, False):
+        renderers.RESIDUAL_SINGLE_KERNEL = single
+        try:
+            inst = fields.pack_instances(g["locations"], g["orientations"], g["dimensions"]).to(dev).requires_grad_(True)
+            mlp = g["mlp_weights"].clone().to(dev).requires_grad_(True)
+            block = fields.FieldBlock(inst, float(g["temperature"]), mlp, None)
+            loss, terms, labels = rendering.silhouette_step(block, g["origins"][keep].to(dev), g["directions"][keep].to(dev), g["targets"][keep].to(dev),
+                                                            (0.0, 100.0), S, std, ratio, seed=11, stream_offset=3, eikonal_ratio=0.01,
+                                                            return_terms=True, return_labels=True)
+            out = (loss.detach(), terms, labels, torch.autograd.grad(loss, (inst, mlp)))
+        finally:
+            renderers.RESIDUAL_SINGLE_KERNEL = False
+        if single in results:                                     # the second default run: bit-identical to the first
+            first = results[single]
+            assert torch.equal(out[0], first[0]) and torch.equal(out[2], first[2]) and all(torch.equal(a, b) for a, b in zip(out[3], first[3]))
+        results[single] = out
+    split, one = results[False], results[True]
+    assert (split[2] - one[2]).abs().max() < 1e-6
+    torch.testing.assert_close(split[1], one[1], rtol=1e-5, atol=1e-7)
+    for a, b in zip(split[3], one[3]):
+        assert (a - b).abs().max() <= 2e-4 * max(float(b.abs().max()), 1e-6)
+
+
 def test_shadow_rendering(dev):
     """vsrd.rendering.shadow_rendering (renderers.py:149-174): a point is in shadow when the ray from just above it towards the light
     converges on geometry.  One box hovering over a plane of points, light straight down (+y is down in the camera frame)."""

@@ -109,11 +109,14 @@ CULLING = True
 RUNNING_MINIMUM = os.environ.get("VSRD_RUNNING_MINIMUM", "0") == "1"
 # A/B switch for the y-rotation fast path (field.h: box_value<true>): True sets VSRD_FLAG_GENERAL_ROTATIONS on every launch.
 GENERAL_ROTATIONS = os.environ.get("VSRD_GENERAL_ROTATIONS", "0") == "1"
+# A/B switch for the fused residual step: True sets VSRD_FLAG_RESIDUAL_SINGLE_KERNEL (one kernel, one wave per SIMD) instead of the
+# default two kernels per chunk of rays (render_kernels.h: residual_step_front_kernel + residual_mlp_adjoint_kernel).
+RESIDUAL_SINGLE_KERNEL = os.environ.get("VSRD_RESIDUAL_SINGLE_KERNEL", "0") == "1"
 
 
 def _base_flags():
     return ((0 if CULLING else _lib.FLAG_NO_CULLING) | (_lib.FLAG_RUNNING_MINIMUM if RUNNING_MINIMUM else 0)
-            | (_lib.FLAG_GENERAL_ROTATIONS if GENERAL_ROTATIONS else 0))
+            | (_lib.FLAG_GENERAL_ROTATIONS if GENERAL_ROTATIONS else 0) | (_lib.FLAG_RESIDUAL_SINGLE_KERNEL if RESIDUAL_SINGLE_KERNEL else 0))
 
 
 def _mlp_flag(centred_weights):
