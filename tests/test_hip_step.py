@@ -388,6 +388,10 @@ def test_graph_mode_replays_the_same_steps(dev, fused_glue):
             assert (a - b).abs().max() <= 1e-3 * max(float(a.abs().max()), 1e-6), step
         for a, b in zip(loops[0].detector.parameters(), loops[1].detector.parameters()):
             assert (a - b).detach().abs().max() <= 1e-4 * max(float(a.detach().abs().max()), 1e-3), step
+        for a, b in zip(loops[0].hyper_distance_field.parameters(), loops[1].hyper_distance_field.parameters()):
+            assert (a - b).detach().abs().max() <= 1e-4 * max(float(a.detach().abs().max()), 1e-3), step
+        for ge, gg in zip(loops[0].optimizer.param_groups, loops[1].optimizer.param_groups):      # ExponentialLR: same rate at every step
+            assert abs(float(ge["lr"]) - float(gg["lr"])) <= 1e-6 * float(ge["lr"]), step
     assert len(loops[1]._graphs) == 2 and loops[1].step_index == 12 and int(loops[1].step_tensor) == 12
     # sampling inside the graph: the loss keeps falling and every replay draws fresh rays
     torch.manual_seed(0)

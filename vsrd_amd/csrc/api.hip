@@ -633,6 +633,8 @@ bool plan_residual_step(int N, int S, int num_rays, ResidualStepPlan* p) {
     // items: enough of them to balance ~2000 waves, few enough that an item amortises its partial row (6.6 KB written and read once)
     long long per_item = (p->slots_per_instance * N) / 16384;
     per_item = per_item < 4 ? 4 : (per_item > 32 ? 32 : per_item);
+    static const int forced = [] { const char* e = getenv("VSRD_SLOTS_PER_ITEM"); return e ? atoi(e) : 0; }();     // experiment switch
+    if (forced >= 1 && forced <= 64) per_item = forced;
     p->slots_per_item = static_cast<int>(per_item);
     p->items_per_instance = static_cast<int>((p->slots_per_instance + per_item - 1) / per_item);
     size_t at = 0;

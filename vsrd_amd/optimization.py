@@ -206,13 +206,18 @@ class FrameOptimizer:
                                                        workspace.data_ptr(), workspace.numel(), _lib.ptr(b["render_losses"]), _lib.ptr(b["grad_instances"]),
                                                        None, stream))
         groups = self.optimizer.param_groups
+        # ExponentialLR decays every group's rate AFTER the optimiser step: the epilogue does it for the groups it steps itself (and, in
+        # the box-only phase, for the two that have nothing to step); in the residual phase those two are decayed after torch's step
+        others = (None, None) if residual else (_lib.ptr(groups[3]["lr"]), _lib.ptr(groups[4]["lr"]))
         _lib.check(lib.vsrd_frame_epilogue(frame, _lib.ptr(b["grad_instances"]), _lib.ptr(b["grad_raw"]), _lib.ptr(b["projection_losses"]),
                                            _lib.ptr(b["render_losses"]), float(eikonal_ratio), self._adam[0], self._adam[1], self._adam[2],
-                                           _lib.ptr(groups[3]["lr"]), _lib.ptr(groups[4]["lr"]), self.step_tensor.data_ptr(),
+                                           others[0], others[1], self.step_tensor.data_ptr(),
                                            _lib.ptr(b["record"]), _lib.ptr(b["raw_gradients"]), stream))
         if residual:      # the hypernetwork and the embeddings stay with autograd + torch.optim.Adam (the box tensors have no .grad: skipped)
             mlp_weights.backward(b["grad_mlp"] * weights["silhouette_loss"])
             self.optimizer.step()
+            groups[3]["lr"].mul_(cfg.lr_gamma)
+            groups[4]["lr"].mul_(cfg.lr_gamma)
         if count:
             self.step_index += 1
         record, raw = b["record"], b["raw_gradients"]
