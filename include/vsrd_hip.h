@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VSRD_ABI_VERSION 3
+#define VSRD_ABI_VERSION 4
 
 #define VSRD_OK 0
 #define VSRD_E_INVALID_ARGUMENT (-1) /* null pointer, non-positive size, unsupported N / S */
@@ -320,6 +320,39 @@ int32_t vsrd_frame_epilogue(const vsrd_frame_config* config, const float* grad_i
                             const vsrd_adam_tensors* locations, const vsrd_adam_tensors* dimensions, const vsrd_adam_tensors* orientations,
                             float* other_learning_rate_0, float* other_learning_rate_1, int64_t* step,
                             float* record, float* raw_gradients, void* stream);
+
+/* ---- the hypernetwork that generates the residual MLPs' weights (vsrd/models/fields/hyper_distance_field.py:27-55, 75-77) --------
+ * embeddings [N,256] -> (VSRD_HYPER_LAYERS - 1) x [weight_norm(Linear 256 -> 256) -> LayerNorm(256, affine) -> exact GELU]
+ * -> weight_norm(Linear 256 -> 1617) = mlp_weights [N,1617].  weight_norm over dim 0: W[o,:] = g[o] v[o,:] / |v[o,:]|.
+ * Every tensor is given with its torch.optim.Adam(capturable=True) state: the backward entry point also takes the Adam step
+ * (main.py:860-865; embeddings and hypernetwork are parameter groups 3 and 4 with their own rates) and decays the two rates.
+ * With ATen this is ~130 launches of a few microseconds per step; here 6 forwards and 11 backwards. */
+#define VSRD_HYPER_LAYERS 5
+#define VSRD_HYPER_WIDTH 256
+typedef struct vsrd_hypernetwork {
+    int32_t num_instances;                                   /* N <= 64                                                       */
+    int32_t num_outputs;                                     /* 1617                                                          */
+    float beta1, beta2, adam_epsilon, lr_gamma;
+    vsrd_adam_tensors embeddings;                            /* [N,256]                                                       */
+    vsrd_adam_tensors weight_v[VSRD_HYPER_LAYERS];           /* [256,256] x 4, [1617,256]                                     */
+    vsrd_adam_tensors weight_g[VSRD_HYPER_LAYERS];           /* [256] x 4, [1617]                                             */
+    vsrd_adam_tensors bias[VSRD_HYPER_LAYERS];
+    vsrd_adam_tensors norm_weight[VSRD_HYPER_LAYERS - 1];    /* LayerNorm gamma [256]                                         */
+    vsrd_adam_tensors norm_bias[VSRD_HYPER_LAYERS - 1];
+} vsrd_hypernetwork;
+
+size_t vsrd_hypernetwork_workspace_bytes(int32_t num_instances);
+
+/* mlp_weights [N,1617] (what HyperDistanceField.hypernetwork(embeddings) returns); centred [N,1617] or NULL: the same with the
+ * column means of the four LayerNorm-feeding linears removed (VSRD_FLAG_MLP_WEIGHTS_CENTRED).  The workspace keeps the
+ * activations for the backward call. */
+int32_t vsrd_hypernetwork_forward(const vsrd_hypernetwork* net, void* workspace, size_t workspace_bytes,
+                                  float* mlp_weights, float* centred, void* stream);
+
+/* grad_mlp_weights [N,1617], multiplied by grad_scale (the loss weight) on the way in.  Backward through the hypernetwork, Adam on
+ * every tensor of `net` (in place, torch's update), step counters + 1, both learning rates * lr_gamma.  Deterministic. */
+int32_t vsrd_hypernetwork_backward_step(const vsrd_hypernetwork* net, void* workspace, size_t workspace_bytes,
+                                        const float* grad_mlp_weights, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -337,6 +337,64 @@ def test_frame_prologue_matches_the_torch_path(dev, seed, V, N):
     torch.testing.assert_close(loop.schedule.cpu(), torch.tensor([temperature, std, ratio]), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("N", [1, 5, 40])          # 40: the backward's two LDS slabs (80 KB) need the opt-in above 64 KB
+def test_hypernetwork_kernels_match_torch(dev, N):
+    """csrc/hypernetwork.h against the torch module it shadows (hyper_distance_field.py:27-55): generated weights, their centred copy,
+    and three Adam steps driven by the same weight gradients -- first and second moments, step counters, parameters, decayed rates."""
+    from vsrd_amd import _lib, models, optimization
+    from vsrd_amd.rendering import renderers
+    lib = _lib.load()
+    torch.manual_seed(N)
+    gamma, scale = 0.99, 3.0
+    ref_net = models.HyperDistanceField(48, [16, 16, 16, 16], 256, [256, 256, 256, 256]).to(dev)
+    with torch.no_grad():      # non-trivial LayerNorm affines
+        for block in list(ref_net.hypernetwork)[:-1]:
+            block[1].weight.add_(0.2 * torch.randn_like(block[1].weight)), block[1].bias.add_(0.2 * torch.randn_like(block[1].bias))
+    ref_emb = torch.nn.Parameter(torch.randn(1, N, 256, device=dev))
+    net = models.HyperDistanceField(48, [16, 16, 16, 16], 256, [256, 256, 256, 256]).to(dev)
+    net.load_state_dict(ref_net.state_dict())
+    emb = torch.nn.Parameter(ref_emb.detach().clone())
+
+    def optimiser(e, n):
+        lr = lambda v: torch.tensor(v, dtype=torch.float32, device=dev)
+        return torch.optim.Adam([dict(params=[e], lr=lr(1e-3)), dict(params=list(n.parameters()), lr=lr(1e-4))], lr=lr(1e-3), capturable=True)
+    ref_opt, opt = optimiser(ref_emb, ref_net), optimiser(emb, net)
+    tensors = optimization.hypernetwork_tensors(net, emb, opt, gamma)
+    workspace = torch.empty(lib.vsrd_hypernetwork_workspace_bytes(N), dtype=torch.uint8, device=dev)
+    out, centred = torch.zeros(N, _lib.MLP_WEIGHTS, device=dev), torch.zeros(N, _lib.MLP_WEIGHTS, device=dev)
+    for step in range(3):
+        want = ref_net(ref_emb)[0]
+        _lib.check(lib.vsrd_hypernetwork_forward(tensors, workspace.data_ptr(), workspace.numel(), _lib.ptr(out), _lib.ptr(centred), _lib.stream()))
+        torch.testing.assert_close(out, want.detach(), rtol=2e-5, atol=2e-6)
+        torch.testing.assert_close(centred, renderers._centre_mlp(want.detach()), rtol=2e-5, atol=2e-6)
+        grad = torch.randn(N, _lib.MLP_WEIGHTS, device=dev) * 0.01
+        before = [p.detach().clone() for p in [emb, *net.parameters()]]
+        rates = [float(group["lr"]) for group in opt.param_groups]
+        ref_opt.zero_grad(set_to_none=True)
+        want.backward(grad * scale)
+        ref_opt.step()
+        for group in ref_opt.param_groups:
+            group["lr"].mul_(gamma)
+        _lib.check(lib.vsrd_hypernetwork_backward_step(tensors, workspace.data_ptr(), workspace.numel(), _lib.ptr(grad), scale, _lib.stream()))
+        with torch.no_grad():
+            pairs = [(ref_emb, emb, rates[0])] + [(a, b, rates[1]) for a, b in zip(ref_net.parameters(), net.parameters())]
+            for (a, b, lr), old in zip(pairs, before):
+                sa, sb = ref_opt.state[a], opt.state[b]
+                assert float(sa["step"]) == float(sb["step"]) == step + 1
+                for key in ("exp_avg", "exp_avg_sq"):      # moments = the gradients themselves (first step: 0.1 g and 0.001 g^2)
+                    assert (sa[key] - sb[key]).abs().max() <= 2e-4 * float(sa[key].abs().max()) + 1e-12, (step, key, tuple(a.shape))
+                # the update is Adam's, of the kernel's own moments (where a gradient vanishes, m / sqrt(v) amplifies its rounding: the
+                # parameters themselves are compared with torch's only on average)
+                bc1, bc2 = 1.0 - 0.9 ** (step + 1), 1.0 - 0.999 ** (step + 1)
+                expected = old - (lr / bc1) * sb["exp_avg"] / (sb["exp_avg_sq"].sqrt() / bc2 ** 0.5 + 1e-8)
+                assert (expected - b).abs().max() <= 1e-3 * lr + 1e-7 * float(old.abs().max()), (step, tuple(a.shape))
+                assert (a - b).abs().mean() <= 0.01 * lr, (step, tuple(a.shape))
+                # keep the two trajectories on the same point (Adam amplifies rounding where a gradient vanishes)
+                b.copy_(a), sb["exp_avg"].copy_(sa["exp_avg"]), sb["exp_avg_sq"].copy_(sa["exp_avg_sq"])
+            for ga, gb in zip(ref_opt.param_groups, opt.param_groups):
+                assert abs(float(ga["lr"]) - float(gb["lr"])) <= 1e-6 * float(ga["lr"])
+
+
 @pytest.mark.parametrize("fused_glue", [True, False])
 def test_graph_mode_replays_the_same_steps(dev, fused_glue):
     """hipGraph mode (FrameOptimizer(graph=True)): the captured step reads its schedules, Philox counter, Adam step and learning
@@ -370,26 +428,37 @@ def test_graph_mode_replays_the_same_steps(dev, fused_glue):
         loops[1].detector.embeddings.copy_(loops[0].detector.embeddings)
     weights = soft.reshape(-1, N).max(-1).values
 
-    def tensors(loop):      # parameters and Adam moments, in a fixed order
+    def tensors(loop):      # parameters, and Adam moments where the optimiser has created them, in a fixed order
         params = list(loop.detector.parameters()) + list(loop.hyper_distance_field.parameters())
-        moments = [loop.optimizer.state[p][k] for p in params if p in loop.optimizer.state for k in ("exp_avg", "exp_avg_sq")]
+        moments = [[loop.optimizer.state[p][k] for k in ("exp_avg", "exp_avg_sq")] if loop.optimizer.state.get(p) else None for p in params]
         return params, moments
 
     for step in range(12):                                  # 6 box-only steps (3 eager + capture + 2 replays), then 6 residual ones
         idx = torch.multinomial((weights > 0.5).float(), R, replacement=False, generator=None)
         with torch.no_grad():   # Adam turns 1e-7 gradient differences into 1e-2 steps when gradients vanish: compare step by step
             (pe, me), (pg, mg) = tensors(loops[0]), tensors(loops[1])
-            for a, b in zip(pe + (me if len(me) == len(mg) else []), pg + (mg if len(me) == len(mg) else [])):
+            for a, b in zip(pe, pg):
                 b.copy_(a)
+            for a, b in zip(me, mg):
+                if a is not None and b is not None:
+                    b[0].copy_(a[0]), b[1].copy_(a[1])
         eager, replayed = loops[0].step(idx), loops[1].step(idx)
         for key in ("silhouette_loss", "iou_projection_loss", "l1_projection_loss", "loss"):
             torch.testing.assert_close(replayed[key], eager[key], rtol=1e-4, atol=1e-6), (step, key)
         for a, b in zip(eager["raw_gradients"], replayed["raw_gradients"]):
             assert (a - b).abs().max() <= 1e-3 * max(float(a.abs().max()), 1e-6), step
-        for a, b in zip(loops[0].detector.parameters(), loops[1].detector.parameters()):
-            assert (a - b).detach().abs().max() <= 1e-4 * max(float(a.detach().abs().max()), 1e-3), step
-        for a, b in zip(loops[0].hyper_distance_field.parameters(), loops[1].hyper_distance_field.parameters()):
-            assert (a - b).detach().abs().max() <= 1e-4 * max(float(a.detach().abs().max()), 1e-3), step
+        for name in ("locations", "dimensions", "orientations"):
+            a, b = getattr(loops[0].detector, name), getattr(loops[1].detector, name)
+            assert (a - b).detach().abs().max() <= 1e-4 * max(float(a.detach().abs().max()), 1e-3), (step, name)
+        # hypernetwork and embeddings: Adam's first moments are the gradients (compared tightly); the parameters themselves move by
+        # ~lr whatever the gradient's size, so where a gradient vanishes its rounding decides the direction: compared on average
+        hyper = [(loops[0].detector.embeddings, loops[1].detector.embeddings)]
+        hyper += list(zip(loops[0].hyper_distance_field.parameters(), loops[1].hyper_distance_field.parameters()))
+        for a, b in hyper:
+            sa, sb = loops[0].optimizer.state.get(a), loops[1].optimizer.state.get(b)
+            if sa and sb:
+                assert (sa["exp_avg"] - sb["exp_avg"]).abs().max() <= 1e-3 * float(sa["exp_avg"].abs().max()) + 1e-12, (step, tuple(a.shape))
+            assert (a - b).detach().abs().mean() <= 2e-6, (step, tuple(a.shape))            # 2 % of a hypernetwork step (lr 1e-4)
         for ge, gg in zip(loops[0].optimizer.param_groups, loops[1].optimizer.param_groups):      # ExponentialLR: same rate at every step
             assert abs(float(ge["lr"]) - float(gg["lr"])) <= 1e-6 * float(ge["lr"]), step
     assert len(loops[1]._graphs) == 2 and loops[1].step_index == 12 and int(loops[1].step_tensor) == 12

@@ -46,6 +46,7 @@ def test_struct_layout_matches_header():
     assert _lib.RenderConfig.target_columns.offset == 88 and _lib.RenderConfig.target_stride.offset == 96
     assert ctypes.sizeof(_lib.FrameConfig) == 116 and _lib.FrameConfig.num_steps.offset == 68 and _lib.FrameConfig.lr_gamma.offset == 112
     assert ctypes.sizeof(_lib.AdamTensors) == 40
+    assert ctypes.sizeof(_lib.Hypernetwork) == 24 + 24 * 40 and _lib.Hypernetwork.embeddings.offset == 24 and _lib.Hypernetwork.norm_bias.offset == 24 + 20 * 40   # ABI 4
     assert _lib.RenderConfig.seed.offset == 32 and _lib.RenderConfig.stream_offset.offset == 40 and _lib.RenderConfig.flags.offset == 48
     assert _lib.RenderConfig.device_schedule.offset == 56 and _lib.RenderConfig.device_stream_offset.offset == 64
 

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VSRD_HIP_LIBRARY: an experiment build of the same ABI (tools/phase_timers.py, A/B macros); the product path is the in-tree default
 LIBRARY_PATH = os.environ.get("VSRD_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libvsrd_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_INSTANCES = 64
 MAX_SAMPLES = 256
 INSTANCE_STRIDE = 16
@@ -97,6 +97,26 @@ class AdamTensors(ctypes.Structure):
     ]
 
 
+HYPER_LAYERS = 5
+
+
+class Hypernetwork(ctypes.Structure):
+    _fields_ = [
+        ("num_instances", ctypes.c_int32),
+        ("num_outputs", ctypes.c_int32),
+        ("beta1", ctypes.c_float),
+        ("beta2", ctypes.c_float),
+        ("adam_epsilon", ctypes.c_float),
+        ("lr_gamma", ctypes.c_float),
+        ("embeddings", AdamTensors),
+        ("weight_v", AdamTensors * HYPER_LAYERS),
+        ("weight_g", AdamTensors * HYPER_LAYERS),
+        ("bias", AdamTensors * HYPER_LAYERS),
+        ("norm_weight", AdamTensors * (HYPER_LAYERS - 1)),
+        ("norm_bias", AdamTensors * (HYPER_LAYERS - 1)),
+    ]
+
+
 # symbol -> (restype, argtypes); mirrors include/vsrd_hip.h one to one
 SIGNATURES = {
     "vsrd_abi_version": (ctypes.c_int32, []),
@@ -144,6 +164,10 @@ SIGNATURES = {
     "vsrd_frame_epilogue": (ctypes.c_int32, [ctypes.POINTER(FrameConfig), c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_float,
                                              ctypes.POINTER(AdamTensors), ctypes.POINTER(AdamTensors), ctypes.POINTER(AdamTensors),
                                              c_float_p, c_float_p, ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_void_p]),
+    "vsrd_hypernetwork_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32]),
+    "vsrd_hypernetwork_forward": (ctypes.c_int32, [ctypes.POINTER(Hypernetwork), ctypes.c_void_p, ctypes.c_size_t, c_float_p, c_float_p, ctypes.c_void_p]),
+    "vsrd_hypernetwork_backward_step": (ctypes.c_int32, [ctypes.POINTER(Hypernetwork), ctypes.c_void_p, ctypes.c_size_t, c_float_p, ctypes.c_float,
+                                                         ctypes.c_void_p]),
     "vsrd_project_boxes_backward": (ctypes.c_int32, [c_float_p, c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                                      ctypes.c_int32, ctypes.c_float, c_float_p, ctypes.c_void_p, c_float_p,
                                                      ctypes.c_void_p]),

@@ -7,6 +7,7 @@
 #include "ray_sampling.h"
 #include "projection.h"
 #include "frame_step.h"
+#include "hypernetwork.h"
 
 namespace {
 
@@ -616,7 +617,7 @@ struct ResidualStepPlan {
     size_t box_partials, loss_partials, jets, box_extra, counter, segment_sums, seeds, item_rows, masks, item_flags, total_bytes;
 };
 
-bool plan_residual_step(int N, int S, int num_rays, ResidualStepPlan* p) {
+static bool plan_residual_step(int N, int S, int num_rays, ResidualStepPlan* p) {
     p->rounds = rounds_for(2 * S - 1);
     if (p->rounds < 1 || p->rounds > 4) return false;
     p->front_lds = static_cast<size_t>(residual_front_lds_floats(S, N)) * sizeof(float) * kMaxWavesPerBlock;
@@ -737,7 +738,7 @@ size_t vsrd_frame_scratch_bytes(int32_t num_views, int32_t num_boxes) {
 }
 
 namespace {
-bool frame_args(const vsrd_frame_config* c, FrameStepArgs* a) {
+static bool frame_args(const vsrd_frame_config* c, FrameStepArgs* a) {
     if (!c || c->num_boxes < 1 || c->num_boxes > kFrameMaxBoxes || c->num_views < 1 || c->num_views > kFrameMaxViews || c->num_steps < 1) return false;
     a->num_boxes = c->num_boxes; a->num_views = c->num_views;
     a->height = c->height; a->width = c->width; a->epsilon = c->epsilon;
@@ -798,6 +799,121 @@ int32_t vsrd_frame_epilogue(const vsrd_frame_config* config, const float* grad_i
     e.other_learning_rates[0] = other_learning_rate_0; e.other_learning_rates[1] = other_learning_rate_1;
     e.step = reinterpret_cast<long long*>(step); e.record = record; e.raw_gradients = raw_gradients;
     hipLaunchKernelGGL(frame_epilogue_kernel, dim3(1), dim3(kFrameMaxBoxes), 0, static_cast<hipStream_t>(stream), a, e);
+    return launch_status();
+}
+
+namespace {
+struct HyperPlan {
+    size_t activations;        // float offset of z[l] = activations + l * N * 256, l < 4
+    size_t inv_norm;           // 4 x 256 + 1632
+    size_t gz;                 // 2 x N x 256
+    size_t partials;           // final_blocks x N x 256
+    size_t norm_partials;      // 4 x N x 2 x 256
+    size_t total;
+    int final_blocks;
+};
+static HyperPlan plan_hypernetwork(int num_instances) {
+    const size_t slab = static_cast<size_t>(num_instances) * kHyperWidth;
+    HyperPlan p;
+    p.final_blocks = (kMlpWeights + kHyperWaves - 1) / kHyperWaves;
+    p.activations = 0;
+    p.inv_norm = p.activations + (VSRD_HYPER_LAYERS - 1) * slab;
+    p.gz = p.inv_norm + (VSRD_HYPER_LAYERS - 1) * kHyperWidth + kMlpWbarFloats;
+    p.partials = p.gz + 2 * slab;
+    p.norm_partials = p.partials + static_cast<size_t>(p.final_blocks) * slab;
+    p.total = p.norm_partials + (VSRD_HYPER_LAYERS - 1) * 2 * slab;
+    return p;
+}
+static bool valid_adam(const vsrd_adam_tensors& t) { return t.parameter && t.exp_avg && t.exp_avg_sq && t.step && t.learning_rate; }
+static AdamTensors adam_tensors(const vsrd_adam_tensors& t) { return AdamTensors{t.parameter, t.exp_avg, t.exp_avg_sq, t.step, t.learning_rate}; }
+static bool valid_hypernetwork(const vsrd_hypernetwork* net) {
+    if (!net || net->num_instances < 1 || net->num_instances > VSRD_MAX_INSTANCES || net->num_outputs != kMlpWeights) return false;
+    if (!valid_adam(net->embeddings)) return false;
+    for (int l = 0; l < VSRD_HYPER_LAYERS; ++l) {
+        if (!valid_adam(net->weight_v[l]) || !valid_adam(net->weight_g[l]) || !valid_adam(net->bias[l])) return false;
+        if (l + 1 < VSRD_HYPER_LAYERS && (!valid_adam(net->norm_weight[l]) || !valid_adam(net->norm_bias[l]))) return false;
+    }
+    return true;
+}
+}  // namespace
+
+size_t vsrd_hypernetwork_workspace_bytes(int32_t num_instances) {
+    if (num_instances < 1 || num_instances > VSRD_MAX_INSTANCES) return 0;
+    return plan_hypernetwork(num_instances).total * sizeof(float);
+}
+
+int32_t vsrd_hypernetwork_forward(const vsrd_hypernetwork* net, void* workspace, size_t workspace_bytes,
+                                  float* mlp_weights, float* centred, void* stream) {
+    if (!valid_hypernetwork(net) || !mlp_weights) return VSRD_E_INVALID_ARGUMENT;
+    const int N = net->num_instances;
+    const HyperPlan p = plan_hypernetwork(N);
+    if (!workspace || workspace_bytes < p.total * sizeof(float)) return VSRD_E_WORKSPACE;
+    float* ws = static_cast<float*>(workspace);
+    const hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t slab = static_cast<size_t>(N) * kHyperWidth, lds = slab * sizeof(float);
+    if (opt_in_lds(hyper_linear_forward_kernel, lds) != VSRD_OK) return VSRD_E_LAUNCH;
+    for (int l = 0; l < VSRD_HYPER_LAYERS; ++l) {
+        const bool last = l + 1 == VSRD_HYPER_LAYERS;
+        const int rows = last ? kMlpWeights : kHyperWidth;
+        const float* x = l == 0 ? net->embeddings.parameter : ws + p.activations + (l - 1) * slab;
+        const float* gamma = l == 0 ? nullptr : net->norm_weight[l - 1].parameter;
+        const float* beta = l == 0 ? nullptr : net->norm_bias[l - 1].parameter;
+        float* z = last ? mlp_weights : ws + p.activations + l * slab;
+        hipLaunchKernelGGL(hyper_linear_forward_kernel, dim3((rows + kHyperWaves - 1) / kHyperWaves), dim3(kHyperThreads), lds, s,
+                           x, gamma, beta, net->weight_v[l].parameter, net->weight_g[l].parameter, net->bias[l].parameter, rows, N, z,
+                           ws + p.inv_norm + l * kHyperWidth);
+    }
+    if (centred) hipLaunchKernelGGL(hyper_centre_kernel, dim3(N), dim3(128), 0, s, mlp_weights, N, centred);
+    return launch_status();
+}
+
+int32_t vsrd_hypernetwork_backward_step(const vsrd_hypernetwork* net, void* workspace, size_t workspace_bytes,
+                                        const float* grad_mlp_weights, float grad_scale, void* stream) {
+    if (!valid_hypernetwork(net) || !grad_mlp_weights) return VSRD_E_INVALID_ARGUMENT;
+    const int N = net->num_instances;
+    const HyperPlan p = plan_hypernetwork(N);
+    if (!workspace || workspace_bytes < p.total * sizeof(float)) return VSRD_E_WORKSPACE;
+    float* ws = static_cast<float*>(workspace);
+    const hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t slab = static_cast<size_t>(N) * kHyperWidth, lds = (slab + kHyperWaves * kHyperWidth + static_cast<size_t>(N) * kHyperWaves) * sizeof(float);
+    if (opt_in_lds(hyper_linear_backward_kernel, lds) != VSRD_OK) return VSRD_E_LAUNCH;
+    HyperNorms norms;
+    const HyperAdam adam{net->beta1, net->beta2, net->adam_epsilon};
+    HyperStepCounters counters;
+    counters.count = 0;
+    counters.step[counters.count++] = net->embeddings.step;
+    const float* gz = grad_mlp_weights;
+    float scale = grad_scale;
+    for (int l = VSRD_HYPER_LAYERS - 1; l >= 0; --l) {
+        const bool last = l + 1 == VSRD_HYPER_LAYERS;
+        const int rows = last ? kMlpWeights : kHyperWidth;
+        const int blocks = (rows + kHyperWaves - 1) / kHyperWaves;
+        const float* x = l == 0 ? net->embeddings.parameter : ws + p.activations + (l - 1) * slab;
+        const float* gamma = l == 0 ? nullptr : net->norm_weight[l - 1].parameter;
+        const float* beta = l == 0 ? nullptr : net->norm_bias[l - 1].parameter;
+        hipLaunchKernelGGL(hyper_linear_backward_kernel, dim3(blocks), dim3(kHyperThreads), lds, s, x, gamma, beta, gz, scale,
+                           ws + p.inv_norm + l * kHyperWidth, rows, N, adam_tensors(net->weight_v[l]), adam_tensors(net->weight_g[l]),
+                           adam_tensors(net->bias[l]), adam, ws + p.partials);
+        counters.step[counters.count++] = net->weight_v[l].step;
+        counters.step[counters.count++] = net->weight_g[l].step;
+        counters.step[counters.count++] = net->bias[l].step;
+        float* gz_out = ws + p.gz + (l & 1) * slab;
+        if (l > 0) {
+            hipLaunchKernelGGL(hyper_norm_backward_kernel, dim3(N), dim3(kHyperNormThreads), 0, s, ws + p.partials, blocks, x, N, gamma, beta,
+                               adam_tensors(net->embeddings), 0, adam, gz_out, ws + p.norm_partials + (l - 1) * 2 * slab);
+            norms.gamma[l - 1] = adam_tensors(net->norm_weight[l - 1]);
+            norms.beta[l - 1] = adam_tensors(net->norm_bias[l - 1]);
+            counters.step[counters.count++] = net->norm_weight[l - 1].step;
+            counters.step[counters.count++] = net->norm_bias[l - 1].step;
+        } else {
+            hipLaunchKernelGGL(hyper_norm_backward_kernel, dim3(N), dim3(kHyperNormThreads), 0, s, ws + p.partials, blocks, nullptr, N, nullptr, nullptr,
+                               adam_tensors(net->embeddings), 1, adam, gz_out, nullptr);
+        }
+        gz = gz_out;
+        scale = 1.0f;
+    }
+    hipLaunchKernelGGL(hyper_norm_adam_kernel, dim3(VSRD_HYPER_LAYERS - 1), dim3(kHyperNormThreads), 0, s, norms, ws + p.norm_partials, N, adam);
+    hipLaunchKernelGGL(hyper_finish_kernel, dim3(1), dim3(kWave), 0, s, counters, net->embeddings.learning_rate, net->weight_v[0].learning_rate, net->lr_gamma);
     return launch_status();
 }
 

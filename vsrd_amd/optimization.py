@@ -58,12 +58,46 @@ class OptimizationConfig:
     skip_exact_misses: bool = True
 
 
+def adam_state_tensors(optimizer, parameter, group):
+    """`parameter`'s torch.optim.Adam(capturable=True) state as the C ABI's pointer block, created now if the optimiser has not
+    stepped yet (torch creates it lazily): the kernels update the moments, the counter and the parameter in place."""
+    state = optimizer.state[parameter]
+    if not state:
+        state["step"] = torch.zeros((), dtype=torch.float32, device=parameter.device)
+        state["exp_avg"], state["exp_avg_sq"] = torch.zeros_like(parameter), torch.zeros_like(parameter)
+    return _lib.AdamTensors(parameter.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(), state["step"].data_ptr(),
+                            group["lr"].data_ptr())
+
+
+def hypernetwork_tensors(hyper_distance_field, embeddings, optimizer, lr_gamma):
+    """include/vsrd_hip.h::vsrd_hypernetwork over the torch module's own parameters and the optimiser's own state.  `optimizer`'s
+    groups: the one holding `embeddings` and the one holding the hypernetwork, learning rates as device tensors."""
+    def group_of(p):
+        return next(g for g in optimizer.param_groups if any(q is p for q in g["params"]))
+    net = _lib.Hypernetwork()
+    net.num_instances, net.num_outputs = int(embeddings.shape[-2]), _lib.MLP_WEIGHTS
+    betas = group_of(embeddings)["betas"]
+    net.beta1, net.beta2, net.adam_epsilon, net.lr_gamma = float(betas[0]), float(betas[1]), float(group_of(embeddings)["eps"]), float(lr_gamma)
+    net.embeddings = adam_state_tensors(optimizer, embeddings, group_of(embeddings))
+    blocks = list(hyper_distance_field.hypernetwork)
+    if len(blocks) != _lib.HYPER_LAYERS or embeddings.shape[-1] != 256 or not all(p.is_contiguous() for p in hyper_distance_field.parameters()):
+        raise ValueError("csrc/hypernetwork.h is built for config.json:143-156: 256-d embeddings, four hidden blocks of 256")
+    for l, block in enumerate(blocks):
+        linear = block[0]
+        net.weight_v[l], net.weight_g[l], net.bias[l] = (adam_state_tensors(optimizer, p, group_of(p)) for p in (linear.weight_v, linear.weight_g, linear.bias))
+        if l + 1 < len(blocks):
+            net.norm_weight[l] = adam_state_tensors(optimizer, block[1].weight, group_of(block[1].weight))
+            net.norm_bias[l] = adam_state_tensors(optimizer, block[1].bias, group_of(block[1].bias))
+    return net
+
+
 class FrameOptimizer:
     """``graph=True``: the step is captured in a hipGraph and replayed.  ``fused_glue`` (default: on in graph mode): everything around
     the render launch that concerns the boxes -- decode, projection, matching, projection losses and their gradients, schedules,
     the chain rule through the decode, Adam and the learning-rate decay -- runs as two single-workgroup HIP kernels
     (csrc/frame_step.h) instead of ~330 torch element-wise launches, and the render kernel gathers its rays from the
-    frame-resident tensors by index; torch keeps the hypernetwork (rocBLAS GEMMs) and its Adam in the residual phase."""
+    frame-resident tensors by index; in the residual phase the hypernetwork, its backward and its Adam are csrc/hypernetwork.h
+    (``fused_hypernetwork = False`` keeps them with torch: the A/B reference)."""
 
     def __init__(self, inputs: FrameInputs, config: OptimizationConfig, device, graph=False, fused_glue=None):
         self.inputs, self.config, self.device = inputs, config, torch.device(device)
@@ -151,15 +185,15 @@ class FrameOptimizer:
         # Adam's state for the three box tensors exactly as torch.optim.Adam(capturable=True) lays it out, created up front (torch
         # creates it lazily at a parameter's first step): the epilogue kernel updates these tensors in place, so checkpoints and
         # optimizer.state_dict() see them like any other state
-        adam = []
-        for group, p in zip(self.optimizer.param_groups[:3], (det.locations, det.dimensions, det.orientations)):
-            state = self.optimizer.state[p]
-            if not state:
-                state["step"] = torch.zeros((), **f32)
-                state["exp_avg"], state["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
-            adam.append(_lib.AdamTensors(p.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(), state["step"].data_ptr(),
-                                         group["lr"].data_ptr()))
-        self._adam = adam
+        self._adam = [adam_state_tensors(self.optimizer, p, group)
+                      for group, p in zip(self.optimizer.param_groups[:3], (det.locations, det.dimensions, det.orientations))]
+        # the hypernetwork and the embeddings (residual phase) run through csrc/hypernetwork.h on the same footing: torch's module
+        # owns the parameters, torch.optim.Adam owns the moments and counters, the kernels update both in place
+        self.fused_hypernetwork = True
+        net = hypernetwork_tensors(self.hyper_distance_field, det.embeddings, self.optimizer, cfg.lr_gamma)
+        self._hypernetwork = net
+        b["hyper_workspace"] = torch.empty(lib.vsrd_hypernetwork_workspace_bytes(N), dtype=torch.uint8, device=dev)
+        b["mlp_weights"], b["mlp_centred"] = torch.zeros(N, _lib.MLP_WEIGHTS, **f32), torch.zeros(N, _lib.MLP_WEIGHTS, **f32)
 
     def _fused_step(self, ray_indices, count=True):
         """One step with the box-side glue in frame_step.h.  Same arithmetic as `_step_in_scope` (the eager torch path is its
@@ -183,9 +217,16 @@ class FrameOptimizer:
         from .rendering import renderers
         flags = renderers._base_flags()
         mlp_weights = centred = None
-        if residual:
+        fused_net = residual and self.fused_hypernetwork
+        if fused_net:
+            hyper_ws = b["hyper_workspace"]
+            _lib.check(lib.vsrd_hypernetwork_forward(self._hypernetwork, hyper_ws.data_ptr(), hyper_ws.numel(), _lib.ptr(b["mlp_weights"]),
+                                                     _lib.ptr(b["mlp_centred"]), stream))
+            centred = b["mlp_centred"]
+            flags |= _lib.FLAG_MLP_WEIGHTS_CENTRED
+        elif residual:            # A/B: the hypernetwork through torch (rocBLAS GEMMs, autograd, torch.optim.Adam)
             self.optimizer.zero_grad(set_to_none=True)
-            mlp_weights = self.hyper_distance_field(det.embeddings)[0].contiguous()          # [N,1617] (torch: rocBLAS GEMMs)
+            mlp_weights = self.hyper_distance_field(det.embeddings)[0].contiguous()          # [N,1617]
             centred = renderers._centre_mlp(mlp_weights)
             flags |= _lib.FLAG_MLP_WEIGHTS_CENTRED
         elif cfg.skip_exact_misses:
@@ -213,7 +254,10 @@ class FrameOptimizer:
                                            _lib.ptr(b["render_losses"]), float(eikonal_ratio), self._adam[0], self._adam[1], self._adam[2],
                                            others[0], others[1], self.step_tensor.data_ptr(),
                                            _lib.ptr(b["record"]), _lib.ptr(b["raw_gradients"]), stream))
-        if residual:      # the hypernetwork and the embeddings stay with autograd + torch.optim.Adam (the box tensors have no .grad: skipped)
+        if fused_net:     # backward through the hypernetwork, Adam on it and on the embeddings, both rates decayed
+            _lib.check(lib.vsrd_hypernetwork_backward_step(self._hypernetwork, hyper_ws.data_ptr(), hyper_ws.numel(), _lib.ptr(b["grad_mlp"]),
+                                                           float(weights["silhouette_loss"]), stream))
+        elif residual:    # autograd + torch.optim.Adam (the box tensors have no .grad: skipped)
             mlp_weights.backward(b["grad_mlp"] * weights["silhouette_loss"])
             self.optimizer.step()
             groups[3]["lr"].mul_(cfg.lr_gamma)
