@@ -22,10 +22,13 @@ def main():
     parser.add_argument("--steps", type=int, default=200)
     parser.add_argument("--instances", type=int, default=8)
     parser.add_argument("--views", type=int, default=17)
+    parser.add_argument("--rays", type=int, default=1000, help="rays per step (the reference: 1000)")
     parser.add_argument("--graph", action="store_true", help="capture the step in a hipGraph and replay it")
     parser.add_argument("--concurrent", type=int, default=1, help="frames optimised at the same time (one host thread and stream each)")
     parser.add_argument("--residual", action="store_true", help="post-warm-up phase: residual MLP + eikonal loss (steps 1000-3000)")
     parser.add_argument("--json", action="store_true", help="also print one JSON line (tools/regimes.py)")
+    parser.add_argument("--whole-frame", action="store_true", help="time one whole frame as the reference runs it: steps 0..2999 with the real schedules "
+                        "(1000 box-only warm-up steps, then 2000 residual steps), set-up and graph captures included")
     args = parser.parse_args()
     import __graft_entry__
     __graft_entry__.build()
@@ -45,6 +48,32 @@ def main():
                                              skip_exact_misses=True)["labels"].clamp(0, 1).reshape(V, H, W, N).contiguous()
         gt_boxes, _ = operations.project_boxes_multi_view(out["boxes_3d"][0], E.to(dev), K.to(dev), (H, W))
     inputs = optimization.FrameInputs((H, W), K.to(dev), E.to(dev), soft, gt_boxes, torch.ones(V, N, dtype=torch.bool, device=dev))
+    if args.whole_frame:
+        def frame(slot):
+            loop = optimization.FrameOptimizer(inputs, optimization.OptimizationConfig(seed=slot, num_rays=args.rays), dev, graph=args.graph)
+            marks = []
+            for step in range(loop.config.num_steps):
+                if step == loop.config.warmup_steps:
+                    torch.cuda.synchronize(); marks.append(time.perf_counter())
+                losses = loop.step()
+            torch.cuda.synchronize(); marks.append(time.perf_counter())
+            return marks, float(losses["loss"]), loop
+        frame(0)[2].close()                                  # warm the allocator and the code objects
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        marks, loss, loop = frame(1)
+        warm, total = marks[0] - t0, marks[1] - t0
+        cfg = loop.config
+        print(f"native mode, whole frame ({cfg.num_steps} steps = {cfg.warmup_steps} box-only + {cfg.num_steps - cfg.warmup_steps} residual, real schedules, "
+              f"{args.rays} rays x {cfg.num_samples} samples, V={V}, N={N}{', hipGraph replay' if args.graph else ''}): {total:.2f} s "
+              f"({warm:.2f} s warm-up phase, {total - warm:.2f} s residual phase = {(total - warm) / (cfg.num_steps - cfg.warmup_steps) * 1e3:.2f} ms/step); "
+              f"reference: about 15 minutes on a V100 (README.md:128); final loss {loss:.4f}")
+        if args.json:
+            import json
+            print(json.dumps(dict(mode="native", phase="whole frame", graph=bool(args.graph), seconds_per_frame=total, warmup_phase_seconds=warm,
+                                  residual_phase_seconds=total - warm, steps=cfg.num_steps, rays_per_step=args.rays, samples_per_ray=cfg.num_samples,
+                                  views=V, instances=N, final_loss=loss)))
+        return
     import threading
     # Frames are independent (README.md:128: no exchange): several can be optimised at once, each on its own stream with its own
     # replayed graph, and fill each other's idle SIMDs.  Set-up and capture are serial (stream capture is process-global).
@@ -52,7 +81,7 @@ def main():
     for slot in range(args.concurrent):
         stream = torch.cuda.Stream(device=dev)
         with torch.cuda.stream(stream):
-            loop = optimization.FrameOptimizer(inputs, optimization.OptimizationConfig(seed=slot), dev, graph=args.graph)
+            loop = optimization.FrameOptimizer(inputs, optimization.OptimizationConfig(seed=slot, num_rays=args.rays), dev, graph=args.graph)
             if args.residual:
                 loop.step_index = loop.config.warmup_steps
                 loop.step_tensor.fill_(loop.step_index)
@@ -83,13 +112,13 @@ def main():
     total = args.steps * args.concurrent
     print(f"native mode ({'residual' if args.residual else 'box-only'} phase{', hipGraph replay' if args.graph else ''}"
           f"{', %d frames at once' % args.concurrent if args.concurrent > 1 else ''}): {total / dt:.1f} steps/s ({dt / total * 1e3:.2f} ms/step, "
-          f"1000 rays x 100 samples, V={V}, N={N}); 3000-step frame = {3000 * dt / total:.1f} s; reference: ~3.3 steps/s on a V100 "
+          f"{args.rays} rays x 100 samples, V={V}, N={N}); 3000-step frame = {3000 * dt / total:.1f} s; reference: ~3.3 steps/s on a V100 "
           f"(README.md:128); final loss {results[0]:.4f}")
     if args.json:
         import json
         print(json.dumps(dict(mode="native", phase="residual" if args.residual else "box-only", graph=bool(args.graph), frames_at_once=args.concurrent,
                               steps_per_s=total / dt, ms_per_step=dt / total * 1e3, seconds_per_3000_step_frame=3000 * dt / total,
-                              rays_per_step=1000, samples_per_ray=100, views=V, instances=N, final_loss=results[0])))
+                              rays_per_step=args.rays, samples_per_ray=100, views=V, instances=N, final_loss=results[0])))
 
 
 if __name__ == "__main__":

@@ -6,7 +6,8 @@
     BASELINE config 2 at the start / mid / end of the schedule, culling on and off (worst case: every instance at every sample),
     BASELINE config 3 (residual MLP + eikonal) at full size, BASELINE config 5 (stress sizes) on one GPU,
     the two-launch (API-faithful) path of config 2;
-  whole per-frame loop in the reference's native mode (tools/native_mode_bench.py): eager / hipGraph, box-only / residual phase.
+  whole per-frame loop in the reference's native mode (tools/native_mode_bench.py): eager / hipGraph, box-only / residual phase, and one
+  whole 3000-step frame with the real schedules.
 
   python tools/regimes.py [--tag r02] [--quick]
 """
@@ -59,12 +60,13 @@ def main():
         table["dense"].append(record)
         print(f"{name}: {record.get('value', 0) / 1e6:.2f} Mrays/s, {record.get('ms_per_step', 0):.1f} ms/step {record.get('error', '')}", flush=True)
     native = [("box-only, eager", []), ("box-only, hipGraph", ["--graph"]), ("residual, eager", ["--residual"]), ("residual, hipGraph", ["--residual", "--graph"]),
-              ("box-only, hipGraph, 2 frames at once", ["--graph", "--concurrent", "2"]), ("residual, hipGraph, 2 frames at once", ["--residual", "--graph", "--concurrent", "2"])]
+              ("box-only, hipGraph, 2 frames at once", ["--graph", "--concurrent", "2"]), ("residual, hipGraph, 2 frames at once", ["--residual", "--graph", "--concurrent", "2"]),
+              ("whole frame (3000 steps, real schedules), hipGraph", ["--graph", "--whole-frame"])]
     for name, flags in native:
         record = run(["tools/native_mode_bench.py", "--json", "--steps", "300", *flags], 1800)
         record["regime"] = name
         table["native"].append(record)
-        print(f"native {name}: {record.get('steps_per_s', 0):.0f} steps/s {record.get('error', '')}", flush=True)
+        print(f"native {name}: {record.get('steps_per_s', 0):.0f} steps/s {record.get('seconds_per_frame', '')} {record.get('error', '')}", flush=True)
     with open(os.path.join(out_dir, "regimes.json"), "w") as f:
         json.dump(table, f, indent=1)
 

@@ -33,6 +33,28 @@ __device__ __forceinline__ Instance load_instance(const float* __restrict__ inst
     return v;
 }
 
+// A/B experiment (-DVSRD_INSTANCE_VGPR, box-only loops): the parameters as VGPRs (vector loads of one address) instead of SGPR
+// operands -- a VALU instruction with an SGPR operand issues in 4.3 cycles, the same one on VGPRs in 2.5 (tools/micro/pk_rate.hip).
+template <bool kVector>
+__device__ __forceinline__ Instance load_instance_as(const float* __restrict__ instances, int i) {
+#ifdef VSRD_INSTANCE_VGPR
+    if (kVector) {
+        int zero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+        const float4* p = reinterpret_cast<const float4*>(instances + i * kInstanceStride + zero);
+        const float4 a = p[0], b = p[1], c = p[2], d = p[3];
+        Instance v;
+        v.tx = a.x; v.ty = a.y; v.tz = a.z;
+        v.r00 = a.w; v.r01 = b.x; v.r02 = b.y;
+        v.r10 = b.z; v.r11 = b.w; v.r12 = c.x;
+        v.r20 = c.y; v.r21 = c.z; v.r22 = c.w;
+        v.dx = d.x; v.dy = d.y; v.dz = d.z;
+        return v;
+    }
+#endif
+    return load_instance(instances, i);
+}
+
 // Everything phase B of the backward needs about one (sample, instance) pair.
 struct BoxEval {
     float relx, rely, relz;   // x - t

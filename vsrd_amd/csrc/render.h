@@ -87,7 +87,7 @@ __device__ __forceinline__ UnionSums union_loop(const float* __restrict__ instan
     float best = cull.nearest_hi;                                               // upper bound of the smallest box distance, per lane
     for (unsigned long long todo = evaluated; todo != 0ull; todo &= todo - 1ull) {    // wave-uniform: the instances that survive
         const int i = __builtin_ctzll(todo);
-        const Instance in = load_instance(instances, i);
+        const Instance in = load_instance_as<!kResidual>(instances, i);
         BoxEval e = box_value<kYaw>(in, x, y, z);
         const unsigned long long near = __ballot(!(e.d - best > sh.cull));      // (NaN-safe: an undecidable comparison keeps the instance)
         if (near == 0ull) { evaluated &= ~(1ull << i); continue; }

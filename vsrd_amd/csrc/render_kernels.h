@@ -488,7 +488,7 @@ __device__ __forceinline__ void adjoint_label_mix(RayAdjoint<kRounds>& st, const
             for (unsigned long long todo = st.near_any[k]; todo != 0ull; todo &= todo - 1ull) {   // the instances the forward sweep evaluated
                 const int i = __builtin_ctzll(todo);
                 if (lam[i] == 0.0f) continue;                               // wave-uniform
-                const Instance in = load_instance(instances, i);
+                const Instance in = load_instance_as<!kResidual>(instances, i);
                 float d = box_value<kYaw>(in, st.sa[k].x, st.sa[k].y, st.sa[k].z).d;
                 if (kResidual) d += rcache[(k * N + i) * kWave + lane].x;
                 acc += lam[i] * fast_exp(-(d - st.sa[k].m) * inv_t);
@@ -548,7 +548,7 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
             else sink.masks8[at] = static_cast<unsigned char>(mine);
         }
         if (!any_active) continue;                                            // negligible for this ray (field.h culling)
-        const Instance in = load_instance(instances, i);
+        const Instance in = load_instance_as<!kResidual>(instances, i);
         const float lam_i = lam[i];
         float at0 = 0, at1 = 0, at2 = 0, ad0 = 0, ad1 = 0, ad2 = 0;
         float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
