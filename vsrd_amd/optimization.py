@@ -193,6 +193,12 @@ class FrameOptimizer:
         net = hypernetwork_tensors(self.hyper_distance_field, det.embeddings, self.optimizer, cfg.lr_gamma)
         self._hypernetwork = net
         b["hyper_workspace"] = torch.empty(lib.vsrd_hypernetwork_workspace_bytes(N), dtype=torch.uint8, device=dev)
+        # the three things a step needs before its render launch -- its rays, the boxes' side (prologue) and the generated MLP weights --
+        # do not depend on each other: they run as three branches (two side streams, forked from and joined to the step's stream), and
+        # so do the two things after it (epilogue, hypernetwork backward).  Captured, they become parallel branches of the hipGraph
+        self._branches = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        b["picks"] = torch.zeros(cfg.num_rays, dtype=torch.int64, device=dev)
+        b["ray_indices"] = torch.zeros(cfg.num_rays, dtype=torch.int64, device=dev)
         b["mlp_weights"], b["mlp_centred"] = torch.zeros(N, _lib.MLP_WEIGHTS, **f32), torch.zeros(N, _lib.MLP_WEIGHTS, **f32)
 
     def _fused_step(self, ray_indices, count=True):
@@ -202,14 +208,32 @@ class FrameOptimizer:
         det = self.detector
         N = self.num_instances
         residual = self.step_index >= cfg.warmup_steps
+        main = torch.cuda.current_stream(self.device)
         stream = _lib.stream()
+        rays_branch, net_branch = self._branches
+        fused_net = residual and self.fused_hypernetwork
+        sampled = ray_indices is None
+        if sampled:                     # branch 1: this step's rays (device sampler keyed by the step counter, ray_sampling.h)
+            rays_branch.wait_stream(main)
+            with torch.cuda.stream(rays_branch):
+                rendering.sample_rays(self.positive_weights, cfg.num_rays, seed=cfg.seed + 1, stream_offset=self.step_tensor, out=b["picks"])
+                torch.index_select(self.positive_pixels, 0, b["picks"], out=b["ray_indices"])
+            ray_indices = b["ray_indices"]
+        if fused_net:                   # branch 2: embeddings -> MLP weights
+            hyper_ws = b["hyper_workspace"]
+            net_branch.wait_stream(main)
+            with torch.cuda.stream(net_branch):
+                _lib.check(lib.vsrd_hypernetwork_forward(self._hypernetwork, hyper_ws.data_ptr(), hyper_ws.numel(), _lib.ptr(b["mlp_weights"]),
+                                                         _lib.ptr(b["mlp_centred"]), _lib.stream()))
         _lib.check(lib.vsrd_frame_prologue(frame, _lib.ptr(det.locations.data), _lib.ptr(det.dimensions.data), _lib.ptr(det.orientations.data),
                                            _lib.ptr(b["extrinsics"]), _lib.ptr(b["intrinsics"]), _lib.ptr(b["gt_boxes"]), b["visible"].data_ptr(),
                                            self.step_tensor.data_ptr(), b["scratch"].data_ptr(), b["scratch"].numel(), _lib.ptr(b["instances"]),
                                            b["pd_indices"].data_ptr(), b["gt_indices"].data_ptr(), b["target_columns"].data_ptr(),
                                            _lib.ptr(b["instance_weights"]), _lib.ptr(self.schedule), _lib.ptr(b["projection_losses"]), _lib.ptr(b["grad_raw"]), stream))
-        if ray_indices is None:
-            ray_indices = self.sample_rays()
+        if sampled:
+            main.wait_stream(rays_branch)
+        if fused_net:
+            main.wait_stream(net_branch)
         ray_indices = ray_indices.contiguous()
         R = int(ray_indices.numel())
         weights = cfg.loss_weights
@@ -217,11 +241,7 @@ class FrameOptimizer:
         from .rendering import renderers
         flags = renderers._base_flags()
         mlp_weights = centred = None
-        fused_net = residual and self.fused_hypernetwork
         if fused_net:
-            hyper_ws = b["hyper_workspace"]
-            _lib.check(lib.vsrd_hypernetwork_forward(self._hypernetwork, hyper_ws.data_ptr(), hyper_ws.numel(), _lib.ptr(b["mlp_weights"]),
-                                                     _lib.ptr(b["mlp_centred"]), stream))
             centred = b["mlp_centred"]
             flags |= _lib.FLAG_MLP_WEIGHTS_CENTRED
         elif residual:            # A/B: the hypernetwork through torch (rocBLAS GEMMs, autograd, torch.optim.Adam)
@@ -246,6 +266,11 @@ class FrameOptimizer:
                                                        _lib.ptr(b["masks"]), _lib.ptr(b["instance_weights"]), loss_scale,
                                                        workspace.data_ptr(), workspace.numel(), _lib.ptr(b["render_losses"]), _lib.ptr(b["grad_instances"]),
                                                        None, stream))
+        if fused_net:     # branch: backward through the hypernetwork, Adam on it and on the embeddings, both rates decayed (next to the epilogue)
+            net_branch.wait_stream(main)
+            with torch.cuda.stream(net_branch):
+                _lib.check(lib.vsrd_hypernetwork_backward_step(self._hypernetwork, hyper_ws.data_ptr(), hyper_ws.numel(), _lib.ptr(b["grad_mlp"]),
+                                                               float(weights["silhouette_loss"]), _lib.stream()))
         groups = self.optimizer.param_groups
         # ExponentialLR decays every group's rate AFTER the optimiser step: the epilogue does it for the groups it steps itself (and, in
         # the box-only phase, for the two that have nothing to step); in the residual phase those two are decayed after torch's step
@@ -254,14 +279,13 @@ class FrameOptimizer:
                                            _lib.ptr(b["render_losses"]), float(eikonal_ratio), self._adam[0], self._adam[1], self._adam[2],
                                            others[0], others[1], self.step_tensor.data_ptr(),
                                            _lib.ptr(b["record"]), _lib.ptr(b["raw_gradients"]), stream))
-        if fused_net:     # backward through the hypernetwork, Adam on it and on the embeddings, both rates decayed
-            _lib.check(lib.vsrd_hypernetwork_backward_step(self._hypernetwork, hyper_ws.data_ptr(), hyper_ws.numel(), _lib.ptr(b["grad_mlp"]),
-                                                           float(weights["silhouette_loss"]), stream))
-        elif residual:    # autograd + torch.optim.Adam (the box tensors have no .grad: skipped)
+        if residual and not fused_net:    # autograd + torch.optim.Adam (the box tensors have no .grad: skipped)
             mlp_weights.backward(b["grad_mlp"] * weights["silhouette_loss"])
             self.optimizer.step()
             groups[3]["lr"].mul_(cfg.lr_gamma)
             groups[4]["lr"].mul_(cfg.lr_gamma)
+        if fused_net:
+            main.wait_stream(net_branch)
         if count:
             self.step_index += 1
         record, raw = b["record"], b["raw_gradients"]

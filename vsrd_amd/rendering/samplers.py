@@ -64,16 +64,18 @@ def inverse_transform_sampler(bins, weights, num_samples, deterministic=False, u
     return fine.reshape(*lead, S)
 
 
-def sample_rays(weights, num_samples, seed=0, stream_offset=0):
+def sample_rays(weights, num_samples, seed=0, stream_offset=0, out=None):
     """scripts/main.py:620-627: ``torch.multinomial(weights, num_samples, replacement=False)`` as a few streaming launches
     (vsrd_sample_rays: ATen's exponential-race algorithm with Philox keyed by (seed, stream_offset; index), no full sort).
     Deterministic in its arguments; ``stream_offset`` may be a device int64 tensor (read on the device: hipGraph replay).
-    Returns int64 indices [num_samples], best key first."""
+    Returns int64 indices [num_samples], best key first (written into ``out`` when given)."""
     lib = _lib.load()
     weights = weights.detach().reshape(-1).to(torch.float32).contiguous()
     from .renderers import current_workspace
     buf = current_workspace().sampler(weights.device)       # owned by the caller's Workspace (renderers.py), freed with it
-    indices = torch.empty(int(num_samples), dtype=torch.int64, device=weights.device)
+    indices = torch.empty(int(num_samples), dtype=torch.int64, device=weights.device) if out is None else out
+    if indices.dtype != torch.int64 or indices.numel() != int(num_samples) or not indices.is_contiguous() or indices.device != weights.device:
+        raise ValueError("out must be a contiguous int64 tensor of num_samples elements on the weights' device")
     offset_ptr = None
     if isinstance(stream_offset, torch.Tensor):
         offset_ptr, stream_offset = stream_offset.data_ptr(), 0
