@@ -719,10 +719,12 @@ def test_fused_residual_step_golden(dev, name):
 
 
 @pytest.mark.parametrize("name", [n for n in RESIDUAL_CASES if n.startswith("g17")])
-def test_residual_step_split_and_single_kernel_agree(dev, name):
-    """vsrd_render_residual_step runs as two kernels per chunk of rays by default (front part + MLP adjoint distributed by instance);
-    VSRD_FLAG_RESIDUAL_SINGLE_KERNEL keeps the one-kernel form.  Same arithmetic, different summation trees: losses, labels and
-    every gradient must agree to rounding, and each form must repeat itself bit for bit."""
+def test_residual_step_forms_agree(dev, name):
+    """vsrd_render_residual_step has three forms.  Default: two kernels per chunk of rays (front part + MLP adjoint distributed by
+    instance), and for launches of <= 2048 rays -- these goldens -- a front kernel that splits every ray over the two waves of a workgroup
+    (residual_step_pair_kernel).  VSRD_FLAG_RESIDUAL_WAVE_PER_RAY keeps one wave per ray (what large launches run);
+    VSRD_FLAG_RESIDUAL_SINGLE_KERNEL keeps the one-kernel form.  Same arithmetic, different summation trees: losses, labels and every
+    gradient must agree to rounding, and the default form must repeat itself bit for bit."""
     from vsrd_amd import fields, rendering
     from vsrd_amd.rendering import renderers
     g = load_golden(name)
@@ -730,8 +732,8 @@ def test_residual_step_split_and_single_kernel_agree(dev, name):
     std, ratio = float(g["sdf_std_deviation"]), float(g["cosine_ratio"])
     keep = g["conditioned"].reshape(-1)
     results = {}
-    for single in (False, True, False):
-        renderers.RESIDUAL_SINGLE_KERNEL = single
+    for form in ("default", "single_kernel", "wave_per_ray", "default"):
+        renderers.RESIDUAL_SINGLE_KERNEL, renderers.RESIDUAL_WAVE_PER_RAY = form == "single_kernel", form == "wave_per_ray"
         try:
             inst = fields.pack_instances(g["locations"], g["orientations"], g["dimensions"]).to(dev).requires_grad_(True)
             mlp = g["mlp_weights"].clone().to(dev).requires_grad_(True)
@@ -741,16 +743,18 @@ def test_residual_step_split_and_single_kernel_agree(dev, name):
                                                             return_terms=True, return_labels=True)
             out = (loss.detach(), terms, labels, torch.autograd.grad(loss, (inst, mlp)))
         finally:
-            renderers.RESIDUAL_SINGLE_KERNEL = False
-        if single in results:                                     # the second default run: bit-identical to the first
-            first = results[single]
+            renderers.RESIDUAL_SINGLE_KERNEL = renderers.RESIDUAL_WAVE_PER_RAY = False
+        if form in results:                                       # the second default run: bit-identical to the first
+            first = results[form]
             assert torch.equal(out[0], first[0]) and torch.equal(out[2], first[2]) and all(torch.equal(a, b) for a, b in zip(out[3], first[3]))
-        results[single] = out
-    split, one = results[False], results[True]
-    assert (split[2] - one[2]).abs().max() < 1e-6
-    torch.testing.assert_close(split[1], one[1], rtol=1e-5, atol=1e-7)
-    for a, b in zip(split[3], one[3]):
-        assert (a - b).abs().max() <= 2e-4 * max(float(b.abs().max()), 1e-6)
+        results[form] = out
+    default = results["default"]
+    for form in ("single_kernel", "wave_per_ray"):
+        other = results[form]
+        assert (default[2] - other[2]).abs().max() < 1e-6, form
+        torch.testing.assert_close(default[1], other[1], rtol=1e-5, atol=1e-7)
+        for a, b in zip(default[3], other[3]):
+            assert (a - b).abs().max() <= 2e-4 * max(float(b.abs().max()), 1e-6), form
 
 
 def test_shadow_rendering(dev):

@@ -26,6 +26,7 @@ FLAG_MLP_WEIGHTS_CENTRED = 8
 FLAG_RUNNING_MINIMUM = 16
 FLAG_GENERAL_ROTATIONS = 32
 FLAG_RESIDUAL_SINGLE_KERNEL = 64
+FLAG_RESIDUAL_WAVE_PER_RAY = 128
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 

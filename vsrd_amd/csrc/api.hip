@@ -608,16 +608,24 @@ namespace {
 constexpr size_t kSeedBudgetBytes = size_t(6) << 30;     // seeds of one chunk of rays: N x chunk x rounds x 2560 B (a launch is cut into chunks that fit)
 constexpr int kFrontBlocks = 512;                        // x 4 waves = two waves on each of the 1024 SIMDs
 constexpr int kMlpAdjointBlocks = 4096;                  // single-wave workgroups, dynamic item fetch (two per SIMD are resident)
+constexpr int kPairBlocks = 1024;                        // residual_step_pair_kernel: x 2 waves = two waves on each of the 1024 SIMDs
+constexpr int kPairMaxRays = 2048;                       // launches of at most this many rays split each ray over two waves
+
+int pair_max_rays() {                                    // experiment switch: 0 turns the pair kernel off
+    static const int value = [] { const char* e = getenv("VSRD_PAIR_MAX_RAYS"); return e ? atoi(e) : kPairMaxRays; }();
+    return value;
+}
 
 struct ResidualStepPlan {
     int rounds, chunk, front_blocks, front_waves, slots_per_item, items_per_instance;
+    bool pair;                     // few rays: residual_step_pair_kernel (a ray split over the two waves of a workgroup)
     long long slots_per_instance;
     size_t front_lds;
     // workspace layout, in floats from the base
     size_t box_partials, loss_partials, jets, box_extra, counter, segment_sums, seeds, item_rows, masks, item_flags, total_bytes;
 };
 
-static bool plan_residual_step(int N, int S, int num_rays, ResidualStepPlan* p) {
+static bool plan_residual_step(int N, int S, int num_rays, bool allow_pair, ResidualStepPlan* p) {
     p->rounds = rounds_for(2 * S - 1);
     if (p->rounds < 1 || p->rounds > 4) return false;
     p->front_lds = static_cast<size_t>(residual_front_lds_floats(S, N)) * sizeof(float) * kMaxWavesPerBlock;
@@ -630,6 +638,12 @@ static bool plan_residual_step(int N, int S, int num_rays, ResidualStepPlan* p) 
     const long long want = (chunk + kMaxWavesPerBlock - 1) / kMaxWavesPerBlock;
     p->front_blocks = static_cast<int>(want > kFrontBlocks ? kFrontBlocks : want);
     p->front_waves = p->front_blocks * kMaxWavesPerBlock;
+    p->pair = allow_pair && (p->rounds == 2 || p->rounds == 4) && num_rays >= 1 && num_rays <= pair_max_rays() && chunk == num_rays;
+    if (p->pair) {
+        p->front_blocks = static_cast<int>(chunk > kPairBlocks ? kPairBlocks : chunk);
+        p->front_waves = p->front_blocks * kPairWaves;
+        p->front_lds = static_cast<size_t>(residual_pair_lds_floats(S, N)) * sizeof(float);
+    }
     p->slots_per_instance = chunk * p->rounds;
     // items: enough of them to balance ~2000 waves, few enough that an item amortises its partial row (6.6 KB written and read once)
     long long per_item = (p->slots_per_instance * N) / 16384;
@@ -660,7 +674,8 @@ size_t vsrd_residual_step_workspace_bytes(int32_t num_instances, int32_t num_sam
     if (num_instances < 1 || num_instances > VSRD_MAX_INSTANCES || num_samples < 2 || num_samples > VSRD_MAX_SAMPLES || num_rays < 0) return 0;
     ResidualStepPlan p;
     size_t need = vsrd_workspace_bytes(num_instances, 1);                 // (VSRD_FLAG_RESIDUAL_SINGLE_KERNEL and shapes the split form does not take)
-    if (plan_residual_step(num_instances, num_samples, num_rays, &p) && p.total_bytes > need) need = p.total_bytes;
+    for (int allow_pair = 0; allow_pair < 2; ++allow_pair)                // (either front kernel: VSRD_FLAG_RESIDUAL_WAVE_PER_RAY)
+        if (plan_residual_step(num_instances, num_samples, num_rays, allow_pair != 0, &p) && p.total_bytes > need) need = p.total_bytes;
     return need;
 }
 
@@ -673,7 +688,8 @@ int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_con
     if (field->mlp_weights == nullptr) return VSRD_E_INVALID_ARGUMENT;       // box-only fields: vsrd_render_silhouette_step
     const int N = field->num_instances, S = config->num_samples;
     ResidualStepPlan p;
-    if ((config->flags & VSRD_FLAG_RESIDUAL_SINGLE_KERNEL) || config->num_rays == 0 || !plan_residual_step(N, S, config->num_rays, &p))
+    const bool allow_pair = !(config->flags & VSRD_FLAG_RESIDUAL_WAVE_PER_RAY);
+    if ((config->flags & VSRD_FLAG_RESIDUAL_SINGLE_KERNEL) || config->num_rays == 0 || !plan_residual_step(N, S, config->num_rays, allow_pair, &p))
         return residual_step_single_kernel(field, config, origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, eikonal_ratio,
                                            workspace, workspace_bytes, losses, grad_instances, grad_mlp_weights, labels, stream);
     if (workspace_bytes < p.total_bytes) return VSRD_E_WORKSPACE;
@@ -705,18 +721,30 @@ int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_con
         const long long used_slots = static_cast<long long>(rays) * p.rounds;
         if (hipMemsetAsync(masks, 0, static_cast<size_t>(N) * p.slots_per_instance, s) != hipSuccess) return VSRD_E_LAUNCH;
         if (hipMemsetAsync(counter, 0, sizeof(unsigned), s) != hipSuccess) return VSRD_E_LAUNCH;
-#define VSRD_LAUNCH(K)                                                                                                                   \
-        hipLaunchKernelGGL(residual_step_front_kernel<K>, dim3(p.front_blocks), dim3(kBlockThreads), p.front_lds, s, f, field->instances,    \
-                           field->mlp_weights, c, origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, eikonal_scale, \
-                           eikonal_norm, labels, box_partials, jets, loss_partials, seeds, masks, p.slots_per_instance, first, rays,           \
-                           chunk_index > 0 ? 1 : 0)
-        switch (p.rounds) {
-            case 1: VSRD_LAUNCH(1); break;
-            case 2: VSRD_LAUNCH(2); break;
-            case 4: VSRD_LAUNCH(4); break;
-            default: return VSRD_E_UNSUPPORTED;
+#define VSRD_FRONT_ARGS                                                                                                                  \
+        f, field->instances, field->mlp_weights, c, origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, eikonal_scale, \
+        eikonal_norm, labels, box_partials, jets, loss_partials, seeds, masks, p.slots_per_instance, first, rays, chunk_index > 0 ? 1 : 0
+#define VSRD_LAUNCH(K) hipLaunchKernelGGL(residual_step_front_kernel<K>, dim3(p.front_blocks), dim3(kBlockThreads), p.front_lds, s, VSRD_FRONT_ARGS)
+#define VSRD_LAUNCH_PAIR(K)                                                                                                              \
+        if (opt_in_lds(residual_step_pair_kernel<K>, p.front_lds) != VSRD_OK) return VSRD_E_LAUNCH;                                      \
+        hipLaunchKernelGGL(residual_step_pair_kernel<K>, dim3(p.front_blocks), dim3(kPairWaves * kWave), p.front_lds, s, VSRD_FRONT_ARGS)
+        if (p.pair) {
+            switch (p.rounds) {
+                case 2: VSRD_LAUNCH_PAIR(2); break;
+                case 4: VSRD_LAUNCH_PAIR(4); break;
+                default: return VSRD_E_UNSUPPORTED;
+            }
+        } else {
+            switch (p.rounds) {
+                case 1: VSRD_LAUNCH(1); break;
+                case 2: VSRD_LAUNCH(2); break;
+                case 4: VSRD_LAUNCH(4); break;
+                default: return VSRD_E_UNSUPPORTED;
+            }
         }
 #undef VSRD_LAUNCH
+#undef VSRD_LAUNCH_PAIR
+#undef VSRD_FRONT_ARGS
         hipLaunchKernelGGL(residual_mlp_adjoint_kernel, dim3(kMlpAdjointBlocks), dim3(kWave), adjoint_lds, s, field->instances,
                            field->mlp_weights, N, mlp_bits, seeds, masks, p.slots_per_instance, used_slots, p.items_per_instance, p.slots_per_item,
                            counter, item_rows, item_flags);

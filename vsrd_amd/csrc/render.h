@@ -127,10 +127,13 @@ __device__ __forceinline__ UnionValue eval_union(const float* __restrict__ insta
 //   weights[k]  <- compositing weight of sample (k*64 + lane)         (0 for padding lanes)
 //   return      <- lane i holds label i (sum_s w_s * softmin weight)  when kLabels
 //   grad_out / weight_out: this ray's [D-1,3] / [D-1] rows in HBM, or nullptr.
+// first_point / carry_out: a ray split over the waves of a workgroup (render_kernels.h: residual_step_pair_kernel) -- this wave renders
+// the kRounds rounds from point `first_point` on with an entering transmittance of 1 and reports what its rounds let through.
 template <int kRounds, bool kLabels, bool kResidual>
 __device__ __forceinline__ float render_pass(const float* __restrict__ instances, const float* __restrict__ mlp, int num_instances, const Shading& sh,
                                              const Ray& ray, const RayCull& rc, const float* dist, int num_distances, float* dcache,
-                                             float (&weights)[kRounds], float* grad_out, float* weight_out) {
+                                             float (&weights)[kRounds], float* grad_out, float* weight_out,
+                                             int first_point = 0, float* carry_out = nullptr) {
     const int lane = lane_id();
     const int num_points = num_distances - 1;
     float carry = 1.0f;       // transmittance entering this round (wave-uniform)
@@ -138,8 +141,8 @@ __device__ __forceinline__ float render_pass(const float* __restrict__ instances
 #pragma unroll
     for (int k = 0; k < kRounds; ++k) {
         weights[k] = 0.0f;
-        if (k * kWave >= num_points) continue;                       // wave-uniform
-        const int s = k * kWave + lane;
+        if (first_point + k * kWave >= num_points) continue;         // wave-uniform
+        const int s = first_point + k * kWave + lane;
         const bool valid = s < num_points;
         const int s0 = valid ? s : (num_points - 1);
         const float d0 = dist[s0], d1 = dist[s0 + 1];
@@ -169,6 +172,7 @@ __device__ __forceinline__ float render_pass(const float* __restrict__ instances
             }
         }
     }
+    if (carry_out != nullptr) *carry_out = carry;      // (rays split over waves: the transmittance this wave's rounds let through)
     return label_acc;
 }
 

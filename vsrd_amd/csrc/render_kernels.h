@@ -345,13 +345,14 @@ __device__ __forceinline__ UnionSums sweep_union_loop(RayAdjoint<kRounds>& st, i
 template <int kRounds, bool kResidual, bool kCacheD>
 __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, const float* __restrict__ instances, const float* __restrict__ mlp,
                                                        int N, const Shading& sh, const Ray& r, const RayCull& rc, const float* dist, int num_points,
-                                                       const float* lam, float* dcache, int lane, float4* rcache = nullptr) {
+                                                       const float* lam, float* dcache, int lane, float4* rcache = nullptr,
+                                                       int first_point = 0, float* carry_out = nullptr) {
     const float inv_t = sh.inv_t;
     float label = 0.0f;
     float carry = 1.0f;
 #pragma unroll
     for (int k = 0; k < kRounds; ++k) {
-        const int s = k * kWave + lane;
+        const int s = first_point + k * kWave + lane;
         const bool valid = s < num_points;
         const int s0 = valid ? s : (num_points - 1);
         const float d0 = dist[s0], d1 = dist[s0 + 1];
@@ -384,7 +385,7 @@ __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, 
         st.gx[k] = v.gx; st.gy[k] = v.gy; st.gz[k] = v.gz;
         // B needs sum_i w_i grad d_i: stash it in (gbx,gby,gbz) until the reverse sweep
         st.sa[k].gbx = v.b0x; st.sa[k].gby = v.b0y; st.sa[k].gbz = v.b0z;
-        if (kCacheD && k * kWave < num_points) {
+        if (kCacheD && first_point + k * kWave < num_points) {
             const float scale = st.sa[k].wgt * v.inv_z;
             if (k == kRounds - 1) st.last_running = running;
             if (running) {                                                   // the cache holds distances
@@ -402,6 +403,7 @@ __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, 
             }
         }
     }
+    if (carry_out != nullptr) *carry_out = carry;
     return label;
 }
 
@@ -409,12 +411,11 @@ __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, 
 template <int kRounds>
 __device__ __forceinline__ bool adjoint_reverse_sweep(RayAdjoint<kRounds>& st, const Shading& sh, const Ray& r, int num_points,
                                                       const float* grad_weights_row, const float* grad_gradients_row, int lane,
-                                                      float eikonal_scale = 0.0f) {
-    float suffix_carry = 0.0f;
+                                                      float eikonal_scale = 0.0f, int first_point = 0, float suffix_carry = 0.0f) {
     bool any_flow = false;
 #pragma unroll
     for (int k = kRounds - 1; k >= 0; --k) {
-        const int s = k * kWave + lane;
+        const int s = first_point + k * kWave + lane;
         const bool valid = s < num_points;
         float w_bar = st.sa[k].lam_z;
         if (grad_weights_row != nullptr && valid) w_bar += grad_weights_row[s];
@@ -467,10 +468,10 @@ __device__ __forceinline__ bool adjoint_reverse_sweep(RayAdjoint<kRounds>& st, c
 // per CU; residual fields add the residual value the sweep left in its jet cache.
 template <int kRounds, bool kResidual, bool kYaw>
 __device__ __forceinline__ void adjoint_label_mix(RayAdjoint<kRounds>& st, const float* __restrict__ instances, int N, float inv_t, int num_points,
-                                                  const float* lam, int lane, const float4* rcache, const float* dcache) {
+                                                  const float* lam, int lane, const float4* rcache, const float* dcache, int first_point = 0) {
 #pragma unroll
     for (int k = 0; k < kRounds; ++k) {
-        if (k * kWave >= num_points) continue;
+        if (first_point + k * kWave >= num_points) continue;
         float acc = 0.0f;
         if (k == kRounds - 1) {
             if (st.last_running) {
@@ -519,10 +520,10 @@ __device__ __forceinline__ SeedSink batch_seed_sink(float* ray_seeds, unsigned* 
 template <int kRounds, bool kResidual, bool kYaw>
 __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, const float* __restrict__ instances, const float* __restrict__ mlp,
                                                 int N, float inv_t, int num_points, const float* lam, float* G, int lane,
-                                                const float4* rcache, const SeedSink& sink) {
+                                                const float4* rcache, const SeedSink& sink, int first_point = 0) {
     unsigned long long todo = 0ull;                                           // instances evaluated in some round of this ray
 #pragma unroll
-    for (int k = 0; k < kRounds; ++k) todo |= (k * kWave < num_points) ? st.near_any[k] : 0ull;
+    for (int k = 0; k < kRounds; ++k) todo |= (first_point + k * kWave < num_points) ? st.near_any[k] : 0ull;
     for (; todo != 0ull; todo &= todo - 1ull) {
         const int i = __builtin_ctzll(todo);
         bool active[kRounds];
@@ -536,7 +537,7 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
 #pragma unroll
                 for (int q = 0; q < 4; ++q) tiles[k] |= static_cast<unsigned>((st.near_rows[k][q] >> i) & 1ull) << q;
             }
-            active[k] = (k * kWave < num_points) && tiles[k] != 0u;
+            active[k] = (first_point + k * kWave < num_points) && tiles[k] != 0u;
             any_active = any_active || active[k];
         }
         if (kResidual && lane < kRounds) {                                    // which tiles of which rounds the MLP adjoint has to visit
@@ -1032,6 +1033,153 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(k
         float* mine = loss_partials + 2 * wave_global;
         mine[0] = (accumulate ? mine[0] : 0.0f) + loss_total * loss_scale;
         mine[1] = (accumulate ? mine[1] : 0.0f) + eikonal_total * eikonal_norm;
+    }
+}
+
+// The front kernel for FEW rays (the reference's own regime: 1000 rays per step): a ray is split over the two waves of a workgroup,
+// each wave taking half of its rounds -- pass 1, pass 2 and the adjoint of a ray then take half as long, and 1000 rays put two waves
+// on every SIMD instead of one (at one wave per SIMD a VALU instruction issues every ~5 cycles, at two every ~2.7).  The rounds of a
+// ray are coupled only through three scalars, exchanged in LDS: the transmittance entering a round (a product over the rounds
+// before it), the labels (a sum over rounds) and the reverse sweep's suffix sum (over the rounds after it); importance sampling
+// stays with wave 0.  Outputs as residual_step_front_kernel (seed slot = ray * kRounds + round; one partial row per wave).
+constexpr int kPairWaves = 2;
+
+__host__ __device__ constexpr int residual_pair_wave_floats(int num_instances) {
+    return (kMlpWbarFloats + num_instances * kWave + cull_coef_floats(num_instances) + num_instances + num_instances * kGradStride + 3) & ~3;
+}
+__host__ __device__ constexpr int residual_pair_lds_floats(int num_samples, int num_instances) {
+    return ((7 * num_samples + 3) & ~3) + 16 + kPairWaves * kWave + kPairWaves * residual_pair_wave_floats(num_instances);
+}
+
+template <int kRounds>
+__global__ __launch_bounds__(kPairWaves * kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void residual_step_pair_kernel(
+    FieldArgs f, const float* __restrict__ instances, const float* __restrict__ mlp, RenderArgs c,
+    const float* __restrict__ origins, const float* __restrict__ directions, const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
+    const float* __restrict__ targets, const float* __restrict__ instance_weights, float loss_scale, float eikonal_scale, float eikonal_norm,
+    float* __restrict__ labels_out, float* __restrict__ partials, float4* __restrict__ residual_cache, float* __restrict__ loss_partials,
+    float* __restrict__ seed_table, unsigned char* __restrict__ mask_table, long long slots_per_instance, int chunk_base, int chunk_rays, int accumulate) {
+    static_assert(kRounds % kPairWaves == 0, "a wave takes kRounds / 2 rounds of pass 2");
+    apply_device_schedule(f, c);
+    constexpr int kRoundsS = (kRounds + 1) / 2;                               // rounds of pass 1 (all of them staged and merged by wave 0)
+    constexpr int kMine = kRounds / kPairWaves;                               // rounds of pass 2 per wave
+    constexpr int kMineS = (kRoundsS + kPairWaves - 1) / kPairWaves;          // rounds of pass 1 per wave
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = wave_in_block();
+    const int lane = lane_id();
+    const int S = c.num_samples;
+    const int N = f.num_instances;
+    // shared by the two waves: the ray's sample arrays, the exchange scalars, the label halves
+    WaveLds l = carve_lds(lds, S, 0);
+    float* xchg = lds + ((7 * S + 3) & ~3);                                   // [0..1] pass-1 products, [2..3] pass-2 products, [4..5] suffix sums
+    float* label_half = xchg + 16;                                            // [2][64]
+    float* mine = label_half + kPairWaves * kWave + wave * residual_pair_wave_floats(N);
+    l.dcache = mine + kMlpWbarFloats;
+    l.cull = l.dcache + N * kWave;
+    float* lam = l.cull + cull_coef_floats(N);
+    float* G = lam + N;
+    const size_t wave_global = static_cast<size_t>(blockIdx.x) * kPairWaves + wave;
+    float* out = partials + wave_global * (N * kGradStride);
+    for (int idx = lane; idx < N * kGradStride; idx += kWave) G[idx] = accumulate ? out[idx] : 0.0f;
+    float4* rcache = residual_cache + wave_global * (static_cast<size_t>(kRounds) * N * kWave);
+    const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
+    Shading sh = c.sh;
+    sh.mlp_lds = mine;
+    const FieldBounds bounds = field_bounds(instances, N, f.inv_t, true, c.flags);
+    sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
+    sh.mlp_bits = (c.flags & 8u) ? kMlpCentredBit : 0u;
+    const float weight_lane = (lane < N) ? (instance_weights ? instance_weights[lane] : 1.0f) : 0.0f;
+    float loss_acc = 0.0f, eikonal_acc = 0.0f;
+    const int D = 2 * S, num_points = D - 1;
+    const int first_coarse = wave * kMineS * kWave, first_point = wave * kMine * kWave;
+    for (int local = static_cast<int>(blockIdx.x); local < chunk_rays; local += static_cast<int>(gridDim.x)) {
+        const int ray = chunk_base + local;
+        __syncthreads();                                                      // the previous ray's arrays are no longer read
+        const long long row = source_row(c, ray);
+        const Ray r = load_ray_gathered(c, origins, directions, row);
+        const float target = load_target(c, targets, row, lane, N);
+        const RayCull rc = cull_ray_setup(instances, N, r.ox, r.oy, r.oz, r.rx, r.ry, r.rz, l.cull, lane);
+        if (wave == 0) stage_ray_samples<kRoundsS>(l, c, S, ray, u_coarse, u_fine, nullptr, nullptr, sorted_input, lane);
+        __syncthreads();
+        // ---- pass 1: each wave its coarse rounds; the compositing weights meet in l.fine (free until the merge writes it) ----------
+        float w1[kMineS];
+        float through = 1.0f;
+        render_pass<kMineS, false, true>(instances, mlp, N, sh, r, rc, l.coarse, S, l.dcache, w1, nullptr, nullptr, first_coarse, &through);
+        if (lane == 0) xchg[wave] = through;
+        __syncthreads();
+        {
+            const float entering = (wave == 0) ? 1.0f : xchg[0];
+#pragma unroll
+            for (int k = 0; k < kMineS; ++k) {
+                const int idx = first_coarse + k * kWave + lane;
+                if (idx < S) l.fine[idx] = w1[k] * entering;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float weights[kRoundsS];
+#pragma unroll
+            for (int k = 0; k < kRoundsS; ++k) weights[k] = (k * kWave + lane < S) ? l.fine[k * kWave + lane] : 0.0f;
+            wave_lds_sync();
+            importance_merge<kRoundsS>(l, S, weights);
+        }
+        __syncthreads();
+        // ---- pass 2: each wave its rounds of the merged samples, with the adjoint's state kept in registers ------------------------
+        RayAdjoint<kMine> st;
+        float label = adjoint_forward_sweep<kMine, true, true>(st, instances, mlp, N, sh, r, rc, l.merged, num_points, nullptr, l.dcache, lane, rcache,
+                                                                 first_point, &through);
+        if (lane == 0) xchg[2 + wave] = through;
+        __syncthreads();
+        if (wave != 0) {
+            const float entering = xchg[2];
+#pragma unroll
+            for (int k = 0; k < kMine; ++k) { st.trans[k] *= entering; st.sa[k].wgt *= entering; }
+            label *= entering;
+        }
+        label_half[wave * kWave + lane] = label;
+        __syncthreads();
+        label = label_half[lane] + label_half[kWave + lane];
+        if (wave == 0 && labels_out != nullptr && lane < N) labels_out[static_cast<size_t>(ray) * N + lane] = label;
+        // silhouette BCE and its gradient (as render_silhouette_kernel); the loss is counted by wave 0
+        const float p = fminf(fmaxf(label, 1.0e-6f), 1.0f - 1.0e-6f);
+        const float bce = -(target * logf(p) + (1.0f - target) * logf(1.0f - p));
+        loss_acc += (wave == 0 && lane < N) ? weight_lane * bce : 0.0f;
+        const bool inside_clamp = (label >= 1.0e-6f) && (label <= 1.0f - 1.0e-6f);
+        const float lam_lane = (lane < N && inside_clamp) ? weight_lane * loss_scale * (p - target) / fmaxf(p * (1.0f - p), 1.0e-12f) : 0.0f;
+        if (lane < N) lam[lane] = lam_lane;
+        wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < kMine; ++k) {
+            if (first_point + k * kWave >= num_points) continue;
+            const float norm = fast_sqrt(st.gx[k] * st.gx[k] + st.gy[k] * st.gy[k] + st.gz[k] * st.gz[k]);
+            eikonal_acc += (first_point + k * kWave + lane < num_points) ? (norm - 1.0f) * (norm - 1.0f) : 0.0f;
+        }
+        if (sh.yaw) adjoint_label_mix<kMine, true, true>(st, instances, N, sh.inv_t, num_points, lam, lane, rcache, l.dcache, first_point);
+        else adjoint_label_mix<kMine, true, false>(st, instances, N, sh.inv_t, num_points, lam, lane, rcache, l.dcache, first_point);
+        // the reverse sweep's sum over LATER samples: wave 0 needs the total of wave 1's rounds
+        float later = 0.0f;
+#pragma unroll
+        for (int k = kMine - 1; k >= 0; --k) {
+            const bool valid = first_point + k * kWave + lane < num_points;
+            later += wave_sum(valid ? st.sa[k].lam_z * st.sa[k].wgt : 0.0f);
+        }
+        if (lane == 0) xchg[4 + wave] = later;
+        __syncthreads();
+        const float suffix = (wave == 0) ? xchg[5] : 0.0f;
+        if (adjoint_reverse_sweep<kMine>(st, sh, r, num_points, nullptr, nullptr, lane, eikonal_scale, first_point, suffix)) {      // (else: masks stay 0)
+            const long long slot0 = static_cast<long long>(local) * kRounds + wave * kMine;
+            const SeedSink sink = {seed_table + slot0 * (kSeedFloats * kWave), slots_per_instance * (kSeedFloats * kWave), static_cast<long long>(kSeedFloats) * kWave,
+                                   nullptr, mask_table + slot0, slots_per_instance, 1};
+            if (sh.yaw) adjoint_phase_b<kMine, true, true>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink, first_point);
+            else adjoint_phase_b<kMine, true, false>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink, first_point);
+        }
+    }
+    wave_lds_sync();
+    for (int idx = lane; idx < N * kGradStride; idx += kWave) out[idx] = G[idx];
+    const float loss_total = wave_sum(loss_acc), eikonal_total = wave_sum(eikonal_acc);
+    if (lane == 0) {
+        float* row = loss_partials + 2 * wave_global;
+        row[0] = (accumulate ? row[0] : 0.0f) + loss_total * loss_scale;
+        row[1] = (accumulate ? row[1] : 0.0f) + eikonal_total * eikonal_norm;
     }
 }
 

@@ -112,11 +112,15 @@ GENERAL_ROTATIONS = os.environ.get("VSRD_GENERAL_ROTATIONS", "0") == "1"
 # A/B switch for the fused residual step: True sets VSRD_FLAG_RESIDUAL_SINGLE_KERNEL (one kernel, one wave per SIMD) instead of the
 # default two kernels per chunk of rays (render_kernels.h: residual_step_front_kernel + residual_mlp_adjoint_kernel).
 RESIDUAL_SINGLE_KERNEL = os.environ.get("VSRD_RESIDUAL_SINGLE_KERNEL", "0") == "1"
+# A/B switch for the front kernel of small residual steps (<= 2048 rays): True sets VSRD_FLAG_RESIDUAL_WAVE_PER_RAY (one wave per ray, as
+# for large launches) instead of splitting every ray over the two waves of a workgroup (render_kernels.h: residual_step_pair_kernel).
+RESIDUAL_WAVE_PER_RAY = os.environ.get("VSRD_RESIDUAL_WAVE_PER_RAY", "0") == "1"
 
 
 def _base_flags():
     return ((0 if CULLING else _lib.FLAG_NO_CULLING) | (_lib.FLAG_RUNNING_MINIMUM if RUNNING_MINIMUM else 0)
-            | (_lib.FLAG_GENERAL_ROTATIONS if GENERAL_ROTATIONS else 0) | (_lib.FLAG_RESIDUAL_SINGLE_KERNEL if RESIDUAL_SINGLE_KERNEL else 0))
+            | (_lib.FLAG_GENERAL_ROTATIONS if GENERAL_ROTATIONS else 0) | (_lib.FLAG_RESIDUAL_SINGLE_KERNEL if RESIDUAL_SINGLE_KERNEL else 0)
+            | (_lib.FLAG_RESIDUAL_WAVE_PER_RAY if RESIDUAL_WAVE_PER_RAY else 0))
 
 
 def _mlp_flag(centred_weights):
