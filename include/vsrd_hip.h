@@ -106,9 +106,11 @@ typedef struct vsrd_render_config {
                                              kernels per chunk of rays (front part + MLP adjoint distributed by instance, two waves per
                                              SIMD each); the results agree to rounding (A/B switch)                         */
 
-#define VSRD_FLAG_RESIDUAL_WAVE_PER_RAY 128u /* vsrd_render_residual_step: keep one wave per ray in the front kernel even for launches of
-                                             <= 2048 rays, which by default split every ray over the two waves of a workgroup (the
-                                             reference's own 1000 rays per step then put two waves on every SIMD).  A/B switch.      */
+#define VSRD_FLAG_RESIDUAL_WAVE_PER_RAY 128u /* vsrd_render_residual_step: keep one wave per ray in the front kernel.  By default every
+                                             ray is split over the two waves of a workgroup when num_samples > 64 (four wave rounds: the
+                                             split kernel fits two waves per SIMD, the unsplit one does not) and, for num_samples in
+                                             (32, 64], when the launch has <= 2048 rays (the reference's own 1000 rays per step then put
+                                             two waves on every SIMD).  A/B switch.                                                   */
 
 #define VSRD_FLAG_GENERAL_ROTATIONS 32u     /* do not use the shortened rotation products the kernels select by themselves when every
                                              instance's rotation is exactly one about the y axis (r01 = r10 = r12 = r21 = 0, r11 = 1,

@@ -609,7 +609,7 @@ constexpr size_t kSeedBudgetBytes = size_t(6) << 30;     // seeds of one chunk o
 constexpr int kFrontBlocks = 512;                        // x 4 waves = two waves on each of the 1024 SIMDs
 constexpr int kMlpAdjointBlocks = 4096;                  // single-wave workgroups, dynamic item fetch (two per SIMD are resident)
 constexpr int kPairBlocks = 1024;                        // residual_step_pair_kernel: x 2 waves = two waves on each of the 1024 SIMDs
-constexpr int kPairMaxRays = 2048;                       // launches of at most this many rays split each ray over two waves
+constexpr int kPairMaxRays = 2048;                       // two-round launches of at most this many rays split each ray over two waves
 
 int pair_max_rays() {                                    // experiment switch: 0 turns the pair kernel off
     static const int value = [] { const char* e = getenv("VSRD_PAIR_MAX_RAYS"); return e ? atoi(e) : kPairMaxRays; }();
@@ -638,7 +638,9 @@ static bool plan_residual_step(int N, int S, int num_rays, bool allow_pair, Resi
     const long long want = (chunk + kMaxWavesPerBlock - 1) / kMaxWavesPerBlock;
     p->front_blocks = static_cast<int>(want > kFrontBlocks ? kFrontBlocks : want);
     p->front_waves = p->front_blocks * kMaxWavesPerBlock;
-    p->pair = allow_pair && (p->rounds == 2 || p->rounds == 4) && num_rays >= 1 && num_rays <= pair_max_rays() && chunk == num_rays;
+    // four rounds (S in (64, 128]): the one-wave-per-ray kernel needs 308 registers (one wave per SIMD), the pair kernel 256 -- the pair
+    // kernel wins at every launch size (132 k rays, S = 100: 90.3 against 97.9 ms); two rounds: only while a launch cannot fill the SIMDs
+    p->pair = allow_pair && num_rays >= 1 && (p->rounds == 4 || (p->rounds == 2 && num_rays <= pair_max_rays()));
     if (p->pair) {
         p->front_blocks = static_cast<int>(chunk > kPairBlocks ? kPairBlocks : chunk);
         p->front_waves = p->front_blocks * kPairWaves;

@@ -1036,12 +1036,13 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(k
     }
 }
 
-// The front kernel for FEW rays (the reference's own regime: 1000 rays per step): a ray is split over the two waves of a workgroup,
-// each wave taking half of its rounds -- pass 1, pass 2 and the adjoint of a ray then take half as long, and 1000 rays put two waves
-// on every SIMD instead of one (at one wave per SIMD a VALU instruction issues every ~5 cycles, at two every ~2.7).  The rounds of a
-// ray are coupled only through three scalars, exchanged in LDS: the transmittance entering a round (a product over the rounds
-// before it), the labels (a sum over rounds) and the reverse sweep's suffix sum (over the rounds after it); importance sampling
-// stays with wave 0.  Outputs as residual_step_front_kernel (seed slot = ray * kRounds + round; one partial row per wave).
+// The front kernel with a ray split over the two waves of a workgroup, each wave taking half of its rounds.  Used (api.hip:
+// plan_residual_step) for four-round launches (S in (64, 128], the reference's own S = 100: half the per-ray adjoint state per wave
+// fits 256 registers -- two waves per SIMD -- where residual_step_front_kernel<4> needs 308) and for small two-round launches (1000 rays
+// then put two waves on every SIMD instead of one; at one wave per SIMD a VALU instruction issues every ~5 cycles, at two every ~2.7).
+// The rounds of a ray are coupled only through three scalars, exchanged in LDS: the transmittance entering a round (a product over
+// the rounds before it), the labels (a sum over rounds) and the reverse sweep's suffix sum (over the rounds after it); importance
+// sampling stays with wave 0.  Outputs as residual_step_front_kernel (seed slot = ray * kRounds + round; one partial row per wave).
 constexpr int kPairWaves = 2;
 
 __host__ __device__ constexpr int residual_pair_wave_floats(int num_instances) {

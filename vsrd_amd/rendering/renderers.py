@@ -112,8 +112,8 @@ GENERAL_ROTATIONS = os.environ.get("VSRD_GENERAL_ROTATIONS", "0") == "1"
 # A/B switch for the fused residual step: True sets VSRD_FLAG_RESIDUAL_SINGLE_KERNEL (one kernel, one wave per SIMD) instead of the
 # default two kernels per chunk of rays (render_kernels.h: residual_step_front_kernel + residual_mlp_adjoint_kernel).
 RESIDUAL_SINGLE_KERNEL = os.environ.get("VSRD_RESIDUAL_SINGLE_KERNEL", "0") == "1"
-# A/B switch for the front kernel of small residual steps (<= 2048 rays): True sets VSRD_FLAG_RESIDUAL_WAVE_PER_RAY (one wave per ray, as
-# for large launches) instead of splitting every ray over the two waves of a workgroup (render_kernels.h: residual_step_pair_kernel).
+# A/B switch for the front kernel of residual steps: True sets VSRD_FLAG_RESIDUAL_WAVE_PER_RAY (one wave per ray) where the default splits
+# every ray over the two waves of a workgroup (render_kernels.h: residual_step_pair_kernel; S > 64, or <= 2048 rays).
 RESIDUAL_WAVE_PER_RAY = os.environ.get("VSRD_RESIDUAL_WAVE_PER_RAY", "0") == "1"
 
 
