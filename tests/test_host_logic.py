@@ -92,6 +92,36 @@ def _main_py_style_field(loc, dim, rot, temperature, mlp=None, hyper=None):
     return soft_union(distance_fields=members, temperature=temperature)
 
 
+def test_hypernetwork_pointer_block_follows_the_module_and_the_optimiser(lib):
+    """optimization.hypernetwork_tensors: the vsrd_hypernetwork block points at the torch module's own parameters and at
+    torch.optim.Adam's own state (created on the spot), group by group; other architectures are refused, and the entry points reject
+    what they cannot run (no compute here: there is no GPU)."""
+    from vsrd_amd import _lib, models, optimization
+    net = models.HyperDistanceField(48, [16, 16, 16, 16], 256, [256, 256, 256, 256])
+    embeddings = torch.nn.Parameter(torch.randn(1, 5, 256))
+    lr = lambda v: torch.tensor(v)
+    optimiser = torch.optim.Adam([dict(params=[embeddings], lr=lr(1e-3)), dict(params=list(net.parameters()), lr=lr(1e-4))], lr=lr(1e-3))
+    block = optimization.hypernetwork_tensors(net, embeddings, optimiser, 0.99)
+    assert (block.num_instances, block.num_outputs) == (5, _lib.MLP_WEIGHTS) and abs(block.lr_gamma - 0.99) < 1e-7
+    assert (block.beta1, block.beta2) == (ctypes.c_float(0.9).value, ctypes.c_float(0.999).value)
+    assert block.embeddings.parameter == embeddings.data_ptr() and block.embeddings.learning_rate == optimiser.param_groups[0]["lr"].data_ptr()
+    linears = [b[0] for b in net.hypernetwork]
+    for l, linear in enumerate(linears):
+        state = optimiser.state[linear.weight_v]
+        assert block.weight_v[l].parameter == linear.weight_v.data_ptr() and block.weight_g[l].parameter == linear.weight_g.data_ptr()
+        assert block.weight_v[l].exp_avg == state["exp_avg"].data_ptr() and block.weight_v[l].step == state["step"].data_ptr()
+        assert block.bias[l].learning_rate == optimiser.param_groups[1]["lr"].data_ptr()
+    assert block.norm_weight[3].parameter == net.hypernetwork[3][1].weight.data_ptr()
+    assert len(optimiser.state) == 1 + 5 * 3 + 4 * 2 and all(float(s["step"]) == 0.0 for s in optimiser.state.values())
+    with pytest.raises(ValueError):                                   # not the reference's hypernetwork
+        optimization.hypernetwork_tensors(models.HyperDistanceField(48, [16, 16, 16, 16], 256, [256, 256]), embeddings, optimiser, 0.99)
+    assert lib.vsrd_hypernetwork_workspace_bytes(0) == 0 and lib.vsrd_hypernetwork_workspace_bytes(65) == 0
+    assert lib.vsrd_hypernetwork_workspace_bytes(8) > 8 * 256 * 4 * 100
+    assert lib.vsrd_hypernetwork_forward(block, None, 0, None, None, None) == -1           # VSRD_E_INVALID_ARGUMENT: no output buffer
+    block.num_outputs = 100
+    assert lib.vsrd_hypernetwork_backward_step(block, None, 0, None, 1.0, None) == -1
+
+
 def test_recogniser_flattens_main_py_closures():
     from vsrd_amd import fields
     g = torch.Generator().manual_seed(0)
