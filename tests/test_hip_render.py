@@ -833,6 +833,40 @@ def test_paths_the_kernel_selects_by_itself_match_the_oracle(dev, case):
         assert (a - b).abs().max() <= 5e-3 * max(float(b.abs().max()), 1e-6)
 
 
+@pytest.mark.parametrize("N,S,R", [(64, 128, 200), (33, 40, 130), (2, 65, 3)])
+def test_residual_step_forms_agree_at_the_size_limits(dev, N, S, R):
+    """The three forms of vsrd_render_residual_step (test_residual_step_forms_agree) away from the golden shapes: the largest field and
+    sample count the fused step takes (two waves per ray, 60 KB of LDS per workgroup), an odd instance count with a partial last
+    round, and a launch with fewer rays than a workgroup has waves.  The one-kernel form is the reference (itself checked against the
+    oracle and the goldens at other shapes)."""
+    from vsrd_amd import fields, rendering
+    from vsrd_amd.rendering import renderers
+    sc = _random_scene(5 + N, N, R, S, general_rotations=False)
+    g = torch.Generator().manual_seed(N)
+    mlp0 = torch.randn(N, 1617, generator=g) * 0.3
+    results = {}
+    for form in ("default", "single_kernel", "wave_per_ray"):
+        renderers.RESIDUAL_SINGLE_KERNEL, renderers.RESIDUAL_WAVE_PER_RAY = form == "single_kernel", form == "wave_per_ray"
+        try:
+            inst = fields.pack_instances(sc["loc"], sc["rot"], sc["dim"]).to(dev).requires_grad_(True)
+            mlp = mlp0.clone().to(dev).requires_grad_(True)
+            block = fields.FieldBlock(inst, 0.3, mlp, None)
+            loss, terms, labels = rendering.silhouette_step(block, sc["origins"].to(dev), sc["directions"].to(dev), sc["targets"].to(dev),
+                                                            (0.0, 100.0), S, 0.3, 0.6, seed=4, stream_offset=9, eikonal_ratio=0.01,
+                                                            return_terms=True, return_labels=True)
+            results[form] = (loss.detach(), terms, labels, torch.autograd.grad(loss, (inst, mlp)))
+        finally:
+            renderers.RESIDUAL_SINGLE_KERNEL = renderers.RESIDUAL_WAVE_PER_RAY = False
+    reference = results["single_kernel"]
+    assert float(reference[2].max()) > 0.05                      # the scene is seen
+    for form in ("default", "wave_per_ray"):
+        other = results[form]
+        assert (other[2] - reference[2]).abs().max() < 2e-6, form
+        torch.testing.assert_close(other[1], reference[1], rtol=2e-5, atol=1e-7)
+        for a, b in zip(other[3], reference[3]):
+            assert (a - b).abs().max() <= 3e-4 * max(float(b.abs().max()), 1e-6), form
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_culling_bounds_hold_far_from_the_benchmark_scene(dev, seed):
     """The culling bounds are compared in squares with an error term for the quadratic form along the ray; these scenes stress
