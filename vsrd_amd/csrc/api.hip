@@ -628,8 +628,12 @@ struct ResidualStepPlan {
 static bool plan_residual_step(int N, int S, int num_rays, bool allow_pair, ResidualStepPlan* p) {
     p->rounds = rounds_for(2 * S - 1);
     if (p->rounds < 1 || p->rounds > 4) return false;
-    p->front_lds = static_cast<size_t>(residual_front_lds_floats(S, N)) * sizeof(float) * kMaxWavesPerBlock;
-    if (p->front_lds > kLdsDefault) return false;        // (N = 64, S = 128: 81 KB -- the single-kernel form has the same limit at two waves)
+    // four rounds (S in (64, 128]): the one-wave-per-ray kernel needs 308 registers (one wave per SIMD), the pair kernel 256 -- the pair
+    // kernel wins at every launch size (132 k rays, S = 100: 90.3 against 97.9 ms); two rounds: only while a launch cannot fill the SIMDs
+    p->pair = allow_pair && num_rays >= 1 && (p->rounds == 4 || (p->rounds == 2 && num_rays <= pair_max_rays()));
+    p->front_lds = p->pair ? static_cast<size_t>(residual_pair_lds_floats(S, N)) * sizeof(float)
+                           : static_cast<size_t>(residual_front_lds_floats(S, N)) * sizeof(float) * kMaxWavesPerBlock;
+    if (p->front_lds > (p->pair ? kLdsLimit / 2 : kLdsDefault)) return false;     // (one wave per ray at N = 64, S = 128: 81 KB -> the single-kernel form)
     const size_t per_ray = static_cast<size_t>(N) * p->rounds * kSeedFloats * kWave * sizeof(float);
     long long chunk = static_cast<long long>(kSeedBudgetBytes / per_ray);
     if (chunk < 256) chunk = 256;
@@ -638,13 +642,9 @@ static bool plan_residual_step(int N, int S, int num_rays, bool allow_pair, Resi
     const long long want = (chunk + kMaxWavesPerBlock - 1) / kMaxWavesPerBlock;
     p->front_blocks = static_cast<int>(want > kFrontBlocks ? kFrontBlocks : want);
     p->front_waves = p->front_blocks * kMaxWavesPerBlock;
-    // four rounds (S in (64, 128]): the one-wave-per-ray kernel needs 308 registers (one wave per SIMD), the pair kernel 256 -- the pair
-    // kernel wins at every launch size (132 k rays, S = 100: 90.3 against 97.9 ms); two rounds: only while a launch cannot fill the SIMDs
-    p->pair = allow_pair && num_rays >= 1 && (p->rounds == 4 || (p->rounds == 2 && num_rays <= pair_max_rays()));
     if (p->pair) {
         p->front_blocks = static_cast<int>(chunk > kPairBlocks ? kPairBlocks : chunk);
         p->front_waves = p->front_blocks * kPairWaves;
-        p->front_lds = static_cast<size_t>(residual_pair_lds_floats(S, N)) * sizeof(float);
     }
     p->slots_per_instance = chunk * p->rounds;
     // items: enough of them to balance ~2000 waves, few enough that an item amortises its partial row (6.6 KB written and read once)
