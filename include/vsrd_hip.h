@@ -332,7 +332,7 @@ int32_t vsrd_frame_epilogue(const vsrd_frame_config* config, const float* grad_i
  * -> weight_norm(Linear 256 -> 1617) = mlp_weights [N,1617].  weight_norm over dim 0: W[o,:] = g[o] v[o,:] / |v[o,:]|.
  * Every tensor is given with its torch.optim.Adam(capturable=True) state: the backward entry point also takes the Adam step
  * (main.py:860-865; embeddings and hypernetwork are parameter groups 3 and 4 with their own rates) and decays the two rates.
- * With ATen this is ~130 launches of a few microseconds per step; here 6 forwards and 11 backwards. */
+ * With ATen this is ~130 launches of a few microseconds per step; here 6 forwards and 12 backwards. */
 #define VSRD_HYPER_LAYERS 5
 #define VSRD_HYPER_WIDTH 256
 typedef struct vsrd_hypernetwork {
