@@ -79,10 +79,11 @@ __device__ __forceinline__ bool wave_any(bool pred) { return __ballot(pred) != 0
 // dcache[i][lane] holds d_i for those instances.
 // The instance loop of eval_union: the instances of `evaluated` (bound test, field.h) that also pass the exact test -- the others
 // are cleared from the mask --, accumulated with a fixed soft-min shift `floor` or (kRunning) the running minimum.
+// `live`: the lanes that hold a point of their own (the others repeat the last one and carry no weight): only their tiles run the MLP.
 template <bool kCacheDistances, bool kResidual, bool kRunning, bool kYaw>
 __device__ __forceinline__ UnionSums union_loop(const float* __restrict__ instances, const float* __restrict__ mlp, unsigned long long& evaluated,
                                                 const Shading& sh, const RoundCull& cull, float floor, float x, float y, float z,
-                                                float* dcache, int lane, const float* lam) {
+                                                float* dcache, int lane, const float* lam, unsigned long long live = ~0ull) {
     UnionSums sums = union_init(kRunning, floor);
     float best = cull.nearest_hi;                                               // upper bound of the smallest box distance, per lane
     for (unsigned long long todo = evaluated; todo != 0ull; todo &= todo - 1ull) {    // wave-uniform: the instances that survive
@@ -93,7 +94,7 @@ __device__ __forceinline__ UnionSums union_loop(const float* __restrict__ instan
         if (near == 0ull) { evaluated &= ~(1ull << i); continue; }
         best = fminf(best, e.d);
         box_gradient<kYaw>(e, in);
-        if (kResidual) add_residual<kYaw>(e, in, residual_forward(mlp + i * kMlpWeights, e.px, e.py, e.pz, rows_with(near) | sh.mlp_bits, sh.mlp_lds));
+        if (kResidual) add_residual<kYaw>(e, in, residual_forward(mlp + i * kMlpWeights, e.px, e.py, e.pz, rows_with(near & live) | sh.mlp_bits, sh.mlp_lds));
         if (kCacheDistances) dcache[i * kWave + lane] = e.d;
         union_accumulate<kRunning>(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, sh.inv_t);
     }
@@ -103,7 +104,7 @@ __device__ __forceinline__ UnionSums union_loop(const float* __restrict__ instan
 template <bool kCacheDistances, bool kResidual>
 __device__ __forceinline__ UnionValue eval_union(const float* __restrict__ instances, const float* __restrict__ mlp, int num_instances,
                                                  const Shading& sh, const RayCull& rc, float t, float x, float y, float z, float* dcache, int lane,
-                                                 const float* lam, unsigned long long* near_out, float* lam_z_out) {
+                                                 const float* lam, unsigned long long* near_out, float* lam_z_out, unsigned long long live = ~0ull) {
     RoundCull cull;
     unsigned long long evaluated = cull_round_mask<true>(rc, num_instances, t, sh.cull, dcache, lane, &cull);
     UnionSums sums;
@@ -112,11 +113,11 @@ __device__ __forceinline__ UnionValue eval_union(const float* __restrict__ insta
     const float floor = cull.nearest_lo - sh.reach;
     bool running = sh.reach < 0.0f || wave_any(!((cull.nearest_hi + 1.0f - floor) * sh.inv_t <= kUnionFloorSpan));
     if (!running) {
-        sums = sh.yaw ? union_loop<kCacheDistances, kResidual, false, true>(instances, mlp, evaluated, sh, cull, floor, x, y, z, dcache, lane, lam)
-                      : union_loop<kCacheDistances, kResidual, false, false>(instances, mlp, evaluated, sh, cull, floor, x, y, z, dcache, lane, lam);
+        sums = sh.yaw ? union_loop<kCacheDistances, kResidual, false, true>(instances, mlp, evaluated, sh, cull, floor, x, y, z, dcache, lane, lam, live)
+                      : union_loop<kCacheDistances, kResidual, false, false>(instances, mlp, evaluated, sh, cull, floor, x, y, z, dcache, lane, lam, live);
         running = wave_any(!(sums.Z >= kUnionTinyZ));                           // the fixed shift underflowed somewhere: repeat the round
     }
-    if (running) sums = union_loop<kCacheDistances, kResidual, true, false>(instances, mlp, evaluated, sh, cull, 0.0f, x, y, z, dcache, lane, lam);
+    if (running) sums = union_loop<kCacheDistances, kResidual, true, false>(instances, mlp, evaluated, sh, cull, 0.0f, x, y, z, dcache, lane, lam, live);
     const UnionValue v = union_finish(sums, sh.inv_t);
     if (near_out) *near_out = evaluated;
     if (lam_z_out) *lam_z_out = sums.L * v.inv_z;
@@ -150,7 +151,10 @@ __device__ __forceinline__ float render_pass(const float* __restrict__ instances
         const float mid = (d0 + d1) / 2.0f;
         const float x = ray.ox + ray.rx * mid, y = ray.oy + ray.ry * mid, z = ray.oz + ray.rz * mid;
         unsigned long long evaluated;
-        const UnionValue v = eval_union<kLabels, kResidual>(instances, mlp, num_instances, sh, rc, mid, x, y, z, dcache, lane, nullptr, &evaluated, nullptr);
+        // (padding lanes repeat the last point: the residual MLP skips 16-lane tiles that hold nothing else -- at the reference's S = 100
+        //  the last round of either pass is mostly padding)
+        const UnionValue v = eval_union<kLabels, kResidual>(instances, mlp, num_instances, sh, rc, mid, x, y, z, dcache, lane, nullptr, &evaluated, nullptr,
+                                                            __ballot(valid));
         const Opacity op = opacity_of(v, ray, delta, sh);
         const float alpha = valid ? op.alpha : 0.0f;
         const float inclusive = wave_inclusive_product(1.0f - alpha);

@@ -314,7 +314,7 @@ struct RayAdjoint {
 template <int kRounds, bool kResidual, bool kCacheD, bool kRunning, bool kYaw>
 __device__ __forceinline__ UnionSums sweep_union_loop(RayAdjoint<kRounds>& st, int k, const float* __restrict__ instances, const float* __restrict__ mlp, int N,
                                                       const Shading& sh, const RoundCull& cull, float floor, const float* lam,
-                                                      float* dcache, int lane, float4* rcache) {
+                                                      float* dcache, int lane, float4* rcache, unsigned long long live) {
     UnionSums sums = union_init(kRunning, floor);
     float best = cull.nearest_hi;
     for (unsigned long long todo = st.near_any[k]; todo != 0ull; todo &= todo - 1ull) {
@@ -327,8 +327,8 @@ __device__ __forceinline__ UnionSums sweep_union_loop(RayAdjoint<kRounds>& st, i
         box_gradient<kYaw>(e, in);
         if (kResidual) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) st.near_rows[k][q] |= ((near >> (16 * q)) & 0xFFFFull) ? (1ull << i) : 0ull;
-            const Residual res = residual_forward(mlp + i * kMlpWeights, e.px, e.py, e.pz, rows_with(near) | sh.mlp_bits, sh.mlp_lds);
+            for (int q = 0; q < 4; ++q) st.near_rows[k][q] |= (((near & live) >> (16 * q)) & 0xFFFFull) ? (1ull << i) : 0ull;
+            const Residual res = residual_forward(mlp + i * kMlpWeights, e.px, e.py, e.pz, rows_with(near & live) | sh.mlp_bits, sh.mlp_lds);
             add_residual<kYaw>(e, in, res);
             if (rcache) rcache[(k * N + i) * kWave + lane] = make_float4(res.value, res.gx, res.gy, res.gz);
         }
@@ -363,15 +363,16 @@ __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, 
         RoundCull cull;
         st.near_any[k] = cull_round_mask<kCacheD>(rc, N, mid, sh.cull, dcache, lane, &cull);
         if (kResidual) st.near_rows[k][0] = st.near_rows[k][1] = st.near_rows[k][2] = st.near_rows[k][3] = 0ull;
+        const unsigned long long live = __ballot(valid);                    // padding lanes repeat the last point: their tiles skip the MLP
         UnionSums sums;
         const float floor = cull.nearest_lo - sh.reach;
         bool running = sh.reach < 0.0f || wave_any(!((cull.nearest_hi + 1.0f - floor) * sh.inv_t <= kUnionFloorSpan));   // wave-uniform (render.h: eval_union)
         if (!running) {
-            sums = sh.yaw ? sweep_union_loop<kRounds, kResidual, kCacheD, false, true>(st, k, instances, mlp, N, sh, cull, floor, lam, dcache, lane, rcache)
-                          : sweep_union_loop<kRounds, kResidual, kCacheD, false, false>(st, k, instances, mlp, N, sh, cull, floor, lam, dcache, lane, rcache);
+            sums = sh.yaw ? sweep_union_loop<kRounds, kResidual, kCacheD, false, true>(st, k, instances, mlp, N, sh, cull, floor, lam, dcache, lane, rcache, live)
+                          : sweep_union_loop<kRounds, kResidual, kCacheD, false, false>(st, k, instances, mlp, N, sh, cull, floor, lam, dcache, lane, rcache, live);
             running = wave_any(!(sums.Z >= kUnionTinyZ));                    // the fixed shift underflowed somewhere: repeat the round
         }
-        if (running) sums = sweep_union_loop<kRounds, kResidual, kCacheD, true, false>(st, k, instances, mlp, N, sh, cull, 0.0f, lam, dcache, lane, rcache);
+        if (running) sums = sweep_union_loop<kRounds, kResidual, kCacheD, true, false>(st, k, instances, mlp, N, sh, cull, 0.0f, lam, dcache, lane, rcache, live);
         const UnionValue v = union_finish(sums, inv_t);
         st.op[k] = opacity_of(v, r, st.delta[k], sh);
         const float alpha = valid ? st.op[k].alpha : 0.0f;
