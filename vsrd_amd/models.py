@@ -90,7 +90,8 @@ class SinusoidalEncoder(nn.Module):
 
 
 class HyperDistanceField(nn.Module):
-    """Hypernetwork embeddings [.,256] -> per-instance MLP weights [.,1617] (rocBLAS GEMMs through torch)."""
+    """Hypernetwork embeddings [.,256] -> per-instance MLP weights [.,1617].  A plain torch module (eager paths: rocBLAS GEMMs); the graph loop
+    of optimization.FrameOptimizer runs its forward, backward and Adam through csrc/hypernetwork.h on this module's own parameter tensors."""
 
     def __init__(self, in_channels, out_channels_list, hyper_in_channels, hyper_out_channels_list):
         super().__init__()
