@@ -220,3 +220,41 @@ def test_config3_full_size_fused_step(dev):
     """BASELINE config 3 at its full size: 9 views x 376 x 1408 = 4.76 M rays, 16 instances, 64 samples per ray, residual MLP from
     the hypernetwork + eikonal term (render_residual_step_kernel<2>; arithmetic pinned by golden g17_render_residual_n16_s64_mid)."""
     _fused_step_properties(dev, N=16, S=64, V=9, H=376, W=1408, residual=True, seed=3)
+
+
+def test_chunked_residual_step_adds_up(dev):
+    """A residual step whose MLP-adjoint seeds exceed the 6 GiB budget is cut into chunks of rays that accumulate into the same
+    partial rows (api.hip: plan_residual_step).  At the reference's S = 100 (four rounds: residual_step_pair_kernel<4>) and N = 16 a
+    chunk is 39 321 rays, so 45 056 rays run as two chunks; the one-kernel form (VSRD_FLAG_RESIDUAL_SINGLE_KERNEL) takes them in
+    one piece.  Loss, labels and every gradient of the two must agree."""
+    import bench
+    from vsrd_amd import models, rendering
+    from vsrd_amd.rendering import renderers
+    N, S, V, H, W = 16, 100, 1, 176, 256
+    det, cam, dirs = scene(dev, N, V, H, W, seed=4)
+    directions = dirs.reshape(-1, 3)
+    origins = cam[:, None, None, :].expand(V, H, W, 3).reshape(-1, 3).contiguous()
+    with torch.no_grad():
+        targets = rendering.render_hierarchical(bench.build_union(det, 0.1), origins, directions, (0.0, 100.0), S, 0.1, 1.0, seed=99,
+                                                skip_exact_misses=True)["labels"].clamp(0.0, 1.0).contiguous()
+        det.locations.add_(0.02)
+    torch.manual_seed(0)
+    hyper = models.HyperDistanceField(48, [16, 16, 16, 16], 256, [256, 256, 256, 256]).to(dev)
+    results = {}
+    for form in ("chunked", "single_kernel"):
+        renderers.RESIDUAL_SINGLE_KERNEL = form == "single_kernel"
+        try:
+            union = bench.build_union(det, 0.55)
+            union.mlp_weights = hyper(det.embeddings)[0].contiguous()
+            loss, terms, labels = rendering.silhouette_step(union, origins, directions, targets, (0.0, 100.0), S, 0.55, 0.5, seed=5, stream_offset=11,
+                                                            eikonal_ratio=0.01, return_terms=True, return_labels=True)
+            params = [det.locations, det.dimensions, det.orientations, det.embeddings]
+            results[form] = (loss.detach().clone(), terms.clone(), labels, torch.autograd.grad(loss, params))
+        finally:
+            renderers.RESIDUAL_SINGLE_KERNEL = False
+    chunked, single = results["chunked"], results["single_kernel"]
+    assert torch.isfinite(chunked[0]) and float(chunked[2].max()) > 0.5
+    assert (chunked[2] - single[2]).abs().max() < 2e-6
+    torch.testing.assert_close(chunked[1], single[1], rtol=2e-5, atol=1e-7)
+    for a, b in zip(chunked[3], single[3]):
+        assert (a - b).abs().max() <= 5e-4 * max(float(b.abs().max()), 1e-9)
