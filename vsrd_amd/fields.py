@@ -263,8 +263,14 @@ def flatten(field) -> FieldBlock:
     labels = [p[4] for p in parts]
     label_indices = None
     if any(l is not None for l in labels):
-        ints = [int(l) if l is not None else i for i, l in enumerate(labels)]
-        if ints != list(range(len(ints))):
-            label_indices = torch.tensor(ints, dtype=torch.long, device=locations.device)
+        if all(isinstance(l, torch.Tensor) and l.device == locations.device for l in labels):
+            # main.py's instance labels are device tensors: one comparison (one synchronisation) instead of one int() per instance
+            stacked = torch.stack([l.reshape(()).to(torch.long) for l in labels])
+            if not torch.equal(stacked, torch.arange(len(labels), dtype=torch.long, device=locations.device)):
+                label_indices = stacked
+        else:
+            ints = [int(l) if l is not None else i for i, l in enumerate(labels)]
+            if ints != list(range(len(ints))):
+                label_indices = torch.tensor(ints, dtype=torch.long, device=locations.device)
     temperature = float(temperature.detach()) if isinstance(temperature, torch.Tensor) else float(temperature)
     return FieldBlock(pack_instances(locations, rotations, dimensions), temperature, mlp_weights, label_indices, hard)
