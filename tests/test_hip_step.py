@@ -337,7 +337,7 @@ def test_frame_prologue_matches_the_torch_path(dev, seed, V, N):
     torch.testing.assert_close(loop.schedule.cpu(), torch.tensor([temperature, std, ratio]), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("N", [1, 5, 40])          # 40: the backward's two LDS slabs (80 KB) need the opt-in above 64 KB
+@pytest.mark.parametrize("N", [1, 5, 40, 64])      # 40 and 64: the LDS of the linears (activations of all instances) needs the opt-in above 64 KB
 def test_hypernetwork_kernels_match_torch(dev, N):
     """csrc/hypernetwork.h against the torch module it shadows (hyper_distance_field.py:27-55): generated weights, their centred copy,
     and three Adam steps driven by the same weight gradients -- first and second moments, step counters, parameters, decayed rates."""
