@@ -329,7 +329,9 @@ def run_rank(args):
         from vsrd_amd import models, rendering, profiling
         from vsrd_amd.rendering import renderers
         renderers.CULLING = not args.no_culling
-        frame = synthetic_frame(seed=rank, num_views=V, height=H, width=W, num_instances=N)   # one frame per rank
+        # one frame per rank, and every rank a replica of the same synthetic frame (the scaling curve then isolates the
+        # launcher; frames of a real shard differ in cost, which is load imbalance, not scaling); the Philox streams differ by rank
+        frame = synthetic_frame(seed=0, num_views=V, height=H, width=W, num_instances=N)
         K, E, raw_loc, raw_dim, raw_ori = frame
         # ---- resident inputs (untimed) -------------------------------------------------------------------------------
         cam, dirs = rendering.ray_casting((H, W), K.to(dev), E.to(dev))                 # [V,3], [V,H,W,3]
@@ -427,7 +429,7 @@ def run_rank(args):
                 "workload": workload, "workload_key": workload_key(args),
                 "schedule": f"{args.schedule}: T=std={sched['std']:.3f}, cosine_ratio={sched['cosine_ratio']:.2f}",
                 "culling": not args.no_culling, "skip_exact_misses": skip, "rng": "in-kernel Philox4x32-10", "rays_per_gpu": R,
-                "requested_gpus": args.gpus, "parallelism": f"frames sharded over {ranks_through} rank(s), no data-path collective",
+                "requested_gpus": args.gpus, "parallelism": f"frames sharded over {ranks_through} rank(s) (replicas of one synthetic frame), no data-path collective",
                 "loss": ("silhouette BCE" + (" + 0.01 eikonal" if args.residual else "") + (" fused into the render kernel" if fused else " (torch elementwise)")) + " + Adam",
                 "launches_per_step": "1 fused (render + loss + adjoint) + partial reductions" if fused else "forward, torch loss, backward",
                 "final_loss": float(loss.detach()), "target_empty_fraction": float((targets.sum(-1) == 0).float().mean()),
