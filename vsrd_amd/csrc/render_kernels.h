@@ -1092,7 +1092,10 @@ __global__ __launch_bounds__(kPairWaves * kWave) __attribute__((amdgpu_waves_per
     const float weight_lane = (lane < N) ? (instance_weights ? instance_weights[lane] : 1.0f) : 0.0f;
     float loss_acc = 0.0f, eikonal_acc = 0.0f;
     const int D = 2 * S, num_points = D - 1;
-    const int first_coarse = wave * kMineS * kWave, first_point = wave * kMine * kWave;
+    // pass 2: the ray's 16-point tiles are divided evenly (S = 100: 199 points = 13 tiles -> 7 + 6, not the 8 + 5 of a split at point
+    // 128); a wave renders [first_point, my_points) and passes my_points where the helpers expect the ray's number of points
+    const int split = ((num_points + 31) / 32) * 16;
+    const int first_coarse = wave * kMineS * kWave, first_point = wave == 0 ? 0 : split, my_points = wave == 0 ? split : num_points;
     for (int local = static_cast<int>(blockIdx.x); local < chunk_rays; local += static_cast<int>(gridDim.x)) {
         const int ray = chunk_base + local;
         __syncthreads();                                                      // the previous ray's arrays are no longer read
@@ -1127,7 +1130,7 @@ __global__ __launch_bounds__(kPairWaves * kWave) __attribute__((amdgpu_waves_per
         __syncthreads();
         // ---- pass 2: each wave its rounds of the merged samples, with the adjoint's state kept in registers ------------------------
         RayAdjoint<kMine> st;
-        float label = adjoint_forward_sweep<kMine, true, true>(st, instances, mlp, N, sh, r, rc, l.merged, num_points, nullptr, l.dcache, lane, rcache,
+        float label = adjoint_forward_sweep<kMine, true, true>(st, instances, mlp, N, sh, r, rc, l.merged, my_points, nullptr, l.dcache, lane, rcache,
                                                                  first_point, &through);
         if (lane == 0) xchg[2 + wave] = through;
         __syncthreads();
@@ -1151,28 +1154,28 @@ __global__ __launch_bounds__(kPairWaves * kWave) __attribute__((amdgpu_waves_per
         wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < kMine; ++k) {
-            if (first_point + k * kWave >= num_points) continue;
+            if (first_point + k * kWave >= my_points) continue;
             const float norm = fast_sqrt(st.gx[k] * st.gx[k] + st.gy[k] * st.gy[k] + st.gz[k] * st.gz[k]);
-            eikonal_acc += (first_point + k * kWave + lane < num_points) ? (norm - 1.0f) * (norm - 1.0f) : 0.0f;
+            eikonal_acc += (first_point + k * kWave + lane < my_points) ? (norm - 1.0f) * (norm - 1.0f) : 0.0f;
         }
-        if (sh.yaw) adjoint_label_mix<kMine, true, true>(st, instances, N, sh.inv_t, num_points, lam, lane, rcache, l.dcache, first_point);
-        else adjoint_label_mix<kMine, true, false>(st, instances, N, sh.inv_t, num_points, lam, lane, rcache, l.dcache, first_point);
+        if (sh.yaw) adjoint_label_mix<kMine, true, true>(st, instances, N, sh.inv_t, my_points, lam, lane, rcache, l.dcache, first_point);
+        else adjoint_label_mix<kMine, true, false>(st, instances, N, sh.inv_t, my_points, lam, lane, rcache, l.dcache, first_point);
         // the reverse sweep's sum over LATER samples: wave 0 needs the total of wave 1's rounds
         float later = 0.0f;
 #pragma unroll
         for (int k = kMine - 1; k >= 0; --k) {
-            const bool valid = first_point + k * kWave + lane < num_points;
+            const bool valid = first_point + k * kWave + lane < my_points;
             later += wave_sum(valid ? st.sa[k].lam_z * st.sa[k].wgt : 0.0f);
         }
         if (lane == 0) xchg[4 + wave] = later;
         __syncthreads();
         const float suffix = (wave == 0) ? xchg[5] : 0.0f;
-        if (adjoint_reverse_sweep<kMine>(st, sh, r, num_points, nullptr, nullptr, lane, eikonal_scale, first_point, suffix)) {      // (else: masks stay 0)
+        if (adjoint_reverse_sweep<kMine>(st, sh, r, my_points, nullptr, nullptr, lane, eikonal_scale, first_point, suffix)) {      // (else: masks stay 0)
             const long long slot0 = static_cast<long long>(local) * kRounds + wave * kMine;
             const SeedSink sink = {seed_table + slot0 * (kSeedFloats * kWave), slots_per_instance * (kSeedFloats * kWave), static_cast<long long>(kSeedFloats) * kWave,
                                    nullptr, mask_table + slot0, slots_per_instance, 1};
-            if (sh.yaw) adjoint_phase_b<kMine, true, true>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink, first_point);
-            else adjoint_phase_b<kMine, true, false>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink, first_point);
+            if (sh.yaw) adjoint_phase_b<kMine, true, true>(st, instances, mlp, N, f.inv_t, my_points, lam, G, lane, rcache, sink, first_point);
+            else adjoint_phase_b<kMine, true, false>(st, instances, mlp, N, f.inv_t, my_points, lam, G, lane, rcache, sink, first_point);
         }
     }
     wave_lds_sync();
