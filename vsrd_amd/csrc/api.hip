@@ -538,8 +538,7 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
     }
 #undef VSRD_LAUNCH
     if (launch_status() != VSRD_OK) return VSRD_E_LAUNCH;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(row), dim3(256), 0, s, partials, num_waves, row, grad_instances);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, loss_partials, num_waves, 1, loss);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(row + 1), dim3(256), 0, s, partials, num_waves, row, grad_instances, nullptr, loss_partials, 1, loss);
     return launch_status();
 }
 
@@ -660,11 +659,11 @@ static bool plan_residual_step(int N, int S, int num_rays, bool allow_pair, Resi
     p->loss_partials = take(static_cast<size_t>(p->front_waves) * 2);
     p->jets = take(static_cast<size_t>(p->front_waves) * p->rounds * N * kWave * 4);
     p->box_extra = take(static_cast<size_t>(N) * kGradStride);
-    p->counter = take(4);
     p->segment_sums = take(static_cast<size_t>(N) * kItemSegments * kItemRowFloats);
     p->seeds = take(static_cast<size_t>(N) * p->slots_per_instance * kSeedFloats * kWave);
     p->item_rows = take(static_cast<size_t>(N) * p->items_per_instance * kItemRowFloats);
     p->masks = take((static_cast<size_t>(N) * p->slots_per_instance + 3) / 4);
+    p->counter = take(4);                                // right behind the masks: one memset clears both
     p->item_flags = take((static_cast<size_t>(N) * p->items_per_instance + 3) / 4);
     p->total_bytes = at * sizeof(float);
     return true;
@@ -721,8 +720,7 @@ int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_con
     for (int first = 0; first < config->num_rays; first += p.chunk, ++chunk_index) {
         const int rays = std::min(p.chunk, config->num_rays - first);
         const long long used_slots = static_cast<long long>(rays) * p.rounds;
-        if (hipMemsetAsync(masks, 0, static_cast<size_t>(N) * p.slots_per_instance, s) != hipSuccess) return VSRD_E_LAUNCH;
-        if (hipMemsetAsync(counter, 0, sizeof(unsigned), s) != hipSuccess) return VSRD_E_LAUNCH;
+        if (hipMemsetAsync(masks, 0, (p.counter - p.masks) * sizeof(float) + sizeof(unsigned), s) != hipSuccess) return VSRD_E_LAUNCH;   // tile masks + item counter
 #define VSRD_FRONT_ARGS                                                                                                                  \
         f, field->instances, field->mlp_weights, c, origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, eikonal_scale, \
         eikonal_norm, labels, box_partials, jets, loss_partials, seeds, masks, p.slots_per_instance, first, rays, chunk_index > 0 ? 1 : 0
@@ -757,8 +755,7 @@ int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_con
         if (launch_status() != VSRD_OK) return VSRD_E_LAUNCH;
     }
     (void)mlp_row;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(row), dim3(256), 0, s, box_partials, p.front_waves, row, grad_instances, box_extra);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), dim3(256), 0, s, loss_partials, p.front_waves, 2, losses, nullptr);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(row + 2), dim3(256), 0, s, box_partials, p.front_waves, row, grad_instances, box_extra, loss_partials, 2, losses);
     return launch_status();
 }
 

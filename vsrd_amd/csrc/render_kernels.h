@@ -1296,20 +1296,26 @@ __global__ __launch_bounds__(256) void reduce_item_segments_kernel(const float* 
     }
 }
 
-// Deterministic second stage: grad[idx] = sum over waves of partials[wave][idx].
+// Deterministic second stage: grad[idx] = sum over waves of partials[wave][idx].  A second table (the loss partials of the fused steps:
+// rows of `row2` numbers, summed into out2) rides in the same launch: workgroups row .. row + row2 - 1.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int num_waves, int row, float* __restrict__ out,
-                                                              const float* __restrict__ extra = nullptr) {
+                                                              const float* __restrict__ extra = nullptr,
+                                                              const float* __restrict__ partials2 = nullptr, int row2 = 0, float* __restrict__ out2 = nullptr) {
     __shared__ float scratch[256 / kWave];
-    const int idx = blockIdx.x;
+    const bool second = static_cast<int>(blockIdx.x) >= row;
+    const int idx = second ? static_cast<int>(blockIdx.x) - row : static_cast<int>(blockIdx.x);
+    const float* table = second ? partials2 : partials;
+    const int pitch = second ? row2 : row;
     float acc = 0.0f;
-    for (int w = threadIdx.x; w < num_waves; w += blockDim.x) acc += partials[static_cast<size_t>(w) * row + idx];
+    for (int w = threadIdx.x; w < num_waves; w += blockDim.x) acc += table[static_cast<size_t>(w) * pitch + idx];
     acc = wave_sum(acc);
     if (lane_id() == 0) scratch[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
         float total = 0.0f;
         for (int k = 0; k < 256 / kWave; ++k) total += scratch[k];
-        out[idx] = total + (extra ? extra[idx] : 0.0f);
+        if (second) out2[idx] = total;
+        else out[idx] = total + (extra ? extra[idx] : 0.0f);
     }
 }
 
