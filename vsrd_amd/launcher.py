@@ -69,8 +69,8 @@ def run_frames(frames: Sequence, optimise: Callable, checkpoint_path: Callable[[
     """Optimise this rank's frames; a frame whose final checkpoint exists is skipped (main.py:134-136).
 
     ``frames_in_flight`` > 1 runs that many frames at the same time on this rank's GPU, one host thread and one stream each: at the
-    reference's 1000 rays per step a single frame leaves SIMDs idle, and independent frames fill them (2 is the sweet spot,
-    DESIGN.md §6).  ``optimise`` is then called from worker threads, inside ``torch.cuda.stream(<own stream>)``; a
+    reference's 1000 rays per step the launch-bound box-only phase runs twice as fast with two frames, the compute-bound residual
+    phase about 10 % faster; more than two host threads lose to the GIL.  ``optimise`` is then called from worker threads, inside ``torch.cuda.stream(<own stream>)``; a
     ``FrameOptimizer(graph=True)`` built there is safe (own scratch, own capture stream, captures serialised).
     The returned list keeps the order of ``frames``."""
     pending = []
