@@ -116,6 +116,12 @@ typedef struct vsrd_render_config {
                                              instance's rotation is exactly one about the y axis (r01 = r10 = r12 = r21 = 0, r11 = 1,
                                              what rotation_matrix_y produces); the results agree to rounding (A/B switch)              */
 
+#define VSRD_FLAG_STEP_WAVE_PER_RAY 256u    /* vsrd_render_silhouette_step: keep one wave per ray.  By default dense launches
+                                             (ray_indices == NULL) with num_samples <= 64 and <= 16 instances put FOUR consecutive rays
+                                             in a wave (16 sample points of each per round): the wave-uniform instance culling then
+                                             works on a quarter of the depth range, and one parameter-adjoint reduction serves four
+                                             rays; the results agree to rounding (A/B switch)                              */
+
 int32_t vsrd_abi_version(void);
 const char* vsrd_error_string(int32_t code);
 

@@ -833,6 +833,49 @@ def test_paths_the_kernel_selects_by_itself_match_the_oracle(dev, case):
         assert (a - b).abs().max() <= 5e-3 * max(float(b.abs().max()), 1e-6)
 
 
+@pytest.mark.parametrize("N,S,R,case", [(16, 64, 203, "yaw"), (4, 32, 64, "yaw"), (3, 20, 61, "yaw"), (16, 17, 5, "yaw"), (1, 8, 1, "yaw"),
+                                        (7, 33, 130, "general"), (5, 64, 97, "tiny_temperature"), (12, 48, 256, "misses"), (16, 64, 64, "philox")])
+def test_quad_step_matches_wave_per_ray(dev, N, S, R, case):
+    """vsrd_render_silhouette_step in its two mappings: four consecutive rays per wave (quad_step.h, the default for dense launches with
+    S <= 64 and N <= 16) against one ray per wave (VSRD_FLAG_STEP_WAVE_PER_RAY; itself checked against the goldens and the oracle).  Ray
+    counts that are not multiples of four, sample counts that are not multiples of 16, general rotations, a temperature that forces
+    the running minimum, rays that miss everything (rows of a wave that drop out after pass 1), matched-instance weights, and the
+    in-kernel Philox stream (same (seed, ray, sample) keys in both mappings)."""
+    from vsrd_amd import fields, rendering
+    from vsrd_amd.rendering import renderers
+    sc = _random_scene(31 + N + S, N, R, S, general_rotations=(case == "general"))
+    T, std, ratio = (0.02, 0.3, 0.7) if case == "tiny_temperature" else ((0.1, 0.1, 0.9) if case == "misses" else (0.4, 0.4, 0.4))
+    directions = sc["directions"].clone()
+    if case == "misses":                                     # every third ray looks away from the scene
+        directions[::3] = torch.nn.functional.normalize(torch.tensor([[0.3, -0.9, -0.4]]), dim=-1)
+    uni = {} if case == "philox" else dict(u_coarse=sc["u_coarse"].to(dev), u_fine=sc["u_fine"].to(dev))
+    pd = torch.arange(0, N, 2, device=dev) if N >= 4 else None
+    gt = torch.arange(pd.numel() - 1, -1, -1, device=dev) if pd is not None else None
+    targets = sc["targets"][:, :pd.numel()].contiguous() if pd is not None else sc["targets"]
+    results = {}
+    for mode in ("quad", "wave"):
+        renderers.STEP_WAVE_PER_RAY = mode == "wave"
+        try:
+            inst = fields.pack_instances(sc["loc"], sc["rot"], sc["dim"]).to(dev).requires_grad_(True)
+            block = fields.FieldBlock(inst, T, None, None)
+            loss, labels = rendering.silhouette_step(block, sc["origins"].to(dev), directions.to(dev), targets.to(dev), (0.0, 100.0), S, std, ratio,
+                                                     pd_indices=pd, gt_indices=gt, seed=3, stream_offset=11, return_labels=True, **uni)
+            results[mode] = (loss.detach(), labels, torch.autograd.grad(loss, inst)[0])
+        finally:
+            renderers.STEP_WAVE_PER_RAY = False
+    quad, wave = results["quad"], results["wave"]
+    assert torch.isfinite(quad[2]).all()
+    if case != "misses":
+        assert float(wave[1].max()) > 0.05                  # the scene is seen
+    # (Philox: the sorted fine uniforms are partial sums of exponential spacings, summed in a different order by the two mappings)
+    # (misses: T = std = 0.1 -- the two mappings cull different instance sets (e^-18 terms), and the importance sampler's division by cdf
+    #  differences amplifies that on ill-conditioned rays, as in test_culling_bounds_hold_far_from_the_benchmark_scene)
+    label_tolerance, gradient_tolerance = (2e-4, 5e-3) if case == "philox" else ((2e-5, 1e-3) if case == "misses" else (5e-6, 2e-4))
+    assert (quad[1] - wave[1]).abs().max() < label_tolerance
+    torch.testing.assert_close(quad[0], wave[0], rtol=1e-5 if case != "philox" else 1e-3, atol=1e-7)
+    assert (quad[2] - wave[2]).abs().max() <= gradient_tolerance * max(float(wave[2].abs().max()), 1e-6)
+
+
 @pytest.mark.parametrize("N,S,R", [(64, 128, 200), (33, 40, 130), (2, 65, 3)])
 def test_residual_step_forms_agree_at_the_size_limits(dev, N, S, R):
     """The three forms of vsrd_render_residual_step (test_residual_step_forms_agree) away from the golden shapes: the largest field and

@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include "../../include/vsrd_hip.h"
 #include "aux_kernels.h"
+#include "quad_step.h"
 #include "matching.h"
 #include "ray_sampling.h"
 #include "projection.h"
@@ -511,9 +512,12 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
     const int S = config->num_samples;
     const int rounds = rounds_for(2 * S - 1);
     if (rounds < 1 || rounds > 4) return VSRD_E_UNSUPPORTED;
+    // dense launches of the benchmark shapes: four neighbouring rays per wave (quad_step.h).  Gathered rays (the reference's 1000
+    // importance-sampled rays per step) are neither neighbours nor enough to fill the chip four to a wave.
+    const bool quad = S <= kQuadMaxSamples && N <= kQuadMaxInstances && config->ray_indices == nullptr && !(config->flags & VSRD_FLAG_STEP_WAVE_PER_RAY);
     Geometry g;
-    const size_t per_wave = static_cast<size_t>(wave_lds_floats(S, N)) + N + row;
-    if (!plan(config->num_rays, per_wave, &g)) return VSRD_E_UNSUPPORTED;
+    const size_t per_wave = quad ? static_cast<size_t>(quad_lds_floats(S, N)) : static_cast<size_t>(wave_lds_floats(S, N)) + N + row;
+    if (!plan(quad ? (config->num_rays + kQuadRays - 1) / kQuadRays : config->num_rays, per_wave, &g)) return VSRD_E_UNSUPPORTED;
     // the partial buffer holds one gradient row per wave; the loss partials live in the tail of the same row budget
     const int max_waves_for_loss = static_cast<int>(vsrd_workspace_bytes(N, 0) / sizeof(float) / (row + 1));
     if (g.blocks * (g.threads / kWave) > max_waves_for_loss) g.blocks = max_waves_for_loss / (g.threads / kWave);
@@ -530,13 +534,27 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
                            origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, labels, partials,        \
                            loss_partials);                                                                                       \
     } while (0)
-    switch (rounds) {
-        case 1: VSRD_LAUNCH(1); break;
-        case 2: VSRD_LAUNCH(2); break;
-        case 4: VSRD_LAUNCH(4); break;
-        default: return VSRD_E_UNSUPPORTED;
+#define VSRD_LAUNCH_QUAD(K)                                                                                                     \
+    do {                                                                                                                          \
+        if (opt_in_lds(render_silhouette_quad_kernel<K>, g.lds_bytes) != VSRD_OK) return VSRD_E_LAUNCH;                          \
+        hipLaunchKernelGGL(render_silhouette_quad_kernel<K>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, \
+                           origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, labels, partials,        \
+                           loss_partials);                                                                                       \
+    } while (0)
+    if (quad) {
+        if (S <= 16) VSRD_LAUNCH_QUAD(1);
+        else if (S <= 32) VSRD_LAUNCH_QUAD(2);
+        else VSRD_LAUNCH_QUAD(4);
+    } else {
+        switch (rounds) {
+            case 1: VSRD_LAUNCH(1); break;
+            case 2: VSRD_LAUNCH(2); break;
+            case 4: VSRD_LAUNCH(4); break;
+            default: return VSRD_E_UNSUPPORTED;
+        }
     }
 #undef VSRD_LAUNCH
+#undef VSRD_LAUNCH_QUAD
     if (launch_status() != VSRD_OK) return VSRD_E_LAUNCH;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(row + 1), dim3(256), 0, s, partials, num_waves, row, grad_instances, nullptr, loss_partials, 1, loss);
     return launch_status();

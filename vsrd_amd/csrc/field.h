@@ -362,7 +362,8 @@ __device__ __forceinline__ UnionSums union_init(bool running = true, float floor
 //  inside the loop costs eight register copies per instance where the two paths meet.)
 // Returns the instance's soft-min term exp(-(d - s.m)/T) when the shift is fixed (kRunning = false; with the running minimum the
 // term is relative to a shift that may still move, and the return value is d itself).
-template <bool kRunning = true>
+// kLambda = false: the caller has no label adjoints to mix (s.L stays untouched: one multiply-add fewer per instance).
+template <bool kRunning = true, bool kLambda = true>
 __device__ __forceinline__ float union_accumulate(UnionSums& s, float d, float gwx, float gwy, float gwz, float lambda, float inv_t) {
     if (!kRunning) {
         const float dd = d - s.m;
@@ -371,7 +372,7 @@ __device__ __forceinline__ float union_accumulate(UnionSums& s, float d, float g
         s.Z += e; s.S1 += edd;
         s.g0x += e * gwx; s.g0y += e * gwy; s.g0z += e * gwz;
         s.g1x += edd * gwx; s.g1y += edd * gwy; s.g1z += edd * gwz;
-        s.L += e * lambda;
+        if (kLambda) s.L += e * lambda;
         return e;
     }
     const bool lower = d < s.m;
@@ -388,7 +389,7 @@ __device__ __forceinline__ float union_accumulate(UnionSums& s, float d, float g
     s.g0x = scale * s.g0x + e * gwx;
     s.g0y = scale * s.g0y + e * gwy;
     s.g0z = scale * s.g0z + e * gwz;
-    s.L = scale * s.L + e * lambda;
+    if (kLambda) s.L = scale * s.L + e * lambda;
     s.Z = scale * s.Z + e;
     s.m = lower ? d : s.m;
     return d;

@@ -1,0 +1,629 @@
+// Fused optimisation step for box-only fields with FOUR NEIGHBOURING RAYS PER WAVE (BASELINE config 2: S <= 64, N <= 16).
+//
+// Same arithmetic and semantics as render_silhouette_kernel (render_kernels.h; scripts/main.py:511-523, 653-671,
+// vsrd/rendering/renderers.py:177-270, samplers.py:5-36), different mapping:
+//   render_silhouette_kernel   one wave = one ray,   lane = sample,                        rounds of 64 consecutive samples
+//   render_silhouette_quad     one wave = four rays, lane = (ray = lane >> 4, sample = lane & 15), rounds of 4 x 16 samples
+// Why: the instance culling (field.h) is wave-uniform, so its granularity is what one round covers.  64 consecutive samples span
+// half a ray and keep 11.1 (pass 1) / 7.4 (pass 2) of 16 instances at the mid schedule; 16 consecutive samples of four neighbouring
+// pixels cover a quarter of that depth range at nearly the same place and keep 5.8 / 4.8 (tests/cull_statistics.py): the instance
+// loops -- 78 % of the step -- shrink by 35-48 %, and one parameter-adjoint butterfly serves four rays instead of one.
+// What it costs: the per-ray state of the adjoint (9 floats per sample) lives in registers for the 8 rounds of pass 2 (72 VGPRs),
+// so everything else about a sample is re-derived where it is needed (opacity in the reverse sweep, the sample position from the
+// sorted distances), compositing scans are row scans (4 DPP steps) with per-row carries, and the per-ray constants are VGPRs.
+#pragma once
+#include "render_kernels.h"
+
+namespace vsrd {
+
+constexpr int kQuadRays = 4;             // rays per wave
+constexpr int kRowLanes = 16;            // lanes (sample points) per ray and round
+constexpr int kQuadMaxInstances = 16;    // lane (ray, n) owns label n of its ray
+constexpr int kQuadMaxSamples = 64;
+
+// ---- 16-lane row primitives (DPP; every lane of a row receives the row's result) --------------------------------------------------
+constexpr int kDppRowShl1 = 0x101, kDppRowShl2 = 0x102, kDppRowShl4 = 0x104, kDppRowShl8 = 0x108;
+
+__device__ __forceinline__ float row_sum(float v) {
+    v += dpp_move<kDppQuadXor1>(0.0f, v);
+    v += dpp_move<kDppQuadXor2>(0.0f, v);
+    v += dpp_move<kDppRowHalfMirror>(0.0f, v);
+    v += dpp_move<kDppRowMirror>(0.0f, v);
+    return v;
+}
+__device__ __forceinline__ float row_max(float v) {
+    v = fmaxf(v, dpp_move<kDppQuadXor1>(v, v));
+    v = fmaxf(v, dpp_move<kDppQuadXor2>(v, v));
+    v = fmaxf(v, dpp_move<kDppRowHalfMirror>(v, v));
+    v = fmaxf(v, dpp_move<kDppRowMirror>(v, v));
+    return v;
+}
+__device__ __forceinline__ float row_inclusive_sum(float v) {          // prefix over the row, lane 0 of the row first
+    v += dpp_move<kDppRowShr1>(0.0f, v);
+    v += dpp_move<kDppRowShr2>(0.0f, v);
+    v += dpp_move<kDppRowShr4>(0.0f, v);
+    v += dpp_move<kDppRowShr8>(0.0f, v);
+    return v;
+}
+__device__ __forceinline__ float row_inclusive_product(float v) {
+    v *= dpp_move<kDppRowShr1>(1.0f, v);
+    v *= dpp_move<kDppRowShr2>(1.0f, v);
+    v *= dpp_move<kDppRowShr4>(1.0f, v);
+    v *= dpp_move<kDppRowShr8>(1.0f, v);
+    return v;
+}
+__device__ __forceinline__ float row_inclusive_max(float v) {
+    v = fmaxf(v, dpp_move<kDppRowShr1>(v, v));
+    v = fmaxf(v, dpp_move<kDppRowShr2>(v, v));
+    v = fmaxf(v, dpp_move<kDppRowShr4>(v, v));
+    v = fmaxf(v, dpp_move<kDppRowShr8>(v, v));
+    return v;
+}
+__device__ __forceinline__ float row_suffix_sum(float v) {             // inclusive sum over this and the LATER lanes of the row
+    v += dpp_move<kDppRowShl1>(0.0f, v);
+    v += dpp_move<kDppRowShl2>(0.0f, v);
+    v += dpp_move<kDppRowShl4>(0.0f, v);
+    v += dpp_move<kDppRowShl8>(0.0f, v);
+    return v;
+}
+// value of the previous lane of the row, `first` for the row's lane 0
+__device__ __forceinline__ float row_shift_up(float v, float first) { return dpp_move<kDppRowShr1>(first, v); }
+// value of a fixed lane of the row (byte address of that lane for ds_bpermute: RowLanes::first / ::last)
+__device__ __forceinline__ float lane_gather(float v, int byte_address) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_address, __builtin_bit_cast(int, v)));
+}
+
+struct RowLanes {
+    int lane, row, col;
+    int first, last;          // ds_bpermute addresses of the row's lane 0 / lane 15
+};
+__device__ __forceinline__ RowLanes row_lanes() {
+    RowLanes r;
+    r.lane = lane_id(); r.row = r.lane >> 4; r.col = r.lane & 15;
+    r.first = (r.lane & 48) << 2; r.last = (r.lane | 15) << 2;
+    return r;
+}
+
+// ---- per-wave LDS ------------------------------------------------------------------------------------------------------------------
+//   4 x [ coarse S | fine S (first the sorted uniforms) | 16 pad | merged 2S (first: raw uniforms | cdf) ]   the pad skews the rows by 16 banks
+//       and takes the tail of the per-point array below when 2S - 1 points are padded to whole rounds of 16
+//   dcache [N][64]     soft-min terms of the current round (label sums; the last round's serve the label mix)
+//   4 x [ N x (a, b, radius, lambda) | 4 pad ]  culling coefficients of (ray, instance) (field.h: RayCull) + the ray's label adjoints
+// After importance_merge the coarse | fine part of a row holds, per pass-2 point, first the transmittance (forward sweep -> reverse
+// sweep) and then the interval mid-point (reverse sweep -> per-instance phase).
+__host__ __device__ constexpr int quad_row_floats(int num_samples) { return 4 * num_samples + kRowLanes; }
+__host__ __device__ constexpr int quad_merged_offset(int num_samples) { return 2 * num_samples + kRowLanes; }
+__host__ __device__ constexpr int quad_coef_floats(int num_instances) { return kCullCoefs * num_instances + 4; }
+__host__ __device__ constexpr int quad_rounds_s(int num_samples) { return num_samples <= 16 ? 1 : (num_samples <= 32 ? 2 : 4); }   // rounds of 16 coarse points
+__host__ __device__ constexpr int quad_cache_rows(int num_samples, int num_instances) {        // [rows][64]: soft-min terms of a round, later C1 / C3 of every pass-2 round
+    return num_instances > 4 * quad_rounds_s(num_samples) ? num_instances : 4 * quad_rounds_s(num_samples);
+}
+__host__ __device__ constexpr int quad_lds_floats(int num_samples, int num_instances) {
+    return kQuadRays * quad_row_floats(num_samples) + quad_cache_rows(num_samples, num_instances) * kWave + kQuadRays * quad_coef_floats(num_instances);
+}
+
+// Stratified distances and sorted fine uniforms of the lane's ray (render_kernels.h: stage_ray_samples, per 16-lane row).
+template <int kRoundsS>
+__device__ __forceinline__ void quad_stage_samples(float* rowbase, const RenderArgs& c, int S, int ray, const float* __restrict__ u_coarse,
+                                                   const float* __restrict__ u_fine, bool sorted_input, const RowLanes& rl) {
+    float* coarse = rowbase;
+    float* usorted = rowbase + S;
+    float* uraw = rowbase + quad_merged_offset(S);
+    const size_t urow = static_cast<size_t>(ray) * S;
+    const bool philox = (u_coarse == nullptr || u_fine == nullptr);
+    float spacing[kRoundsS];
+    float running = 0.0f, extra_spacing = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kRoundsS; ++k) {
+        const int idx = k * kRowLanes + rl.col;
+        spacing[k] = 0.0f;
+        if (k * kRowLanes >= S) continue;
+        float uc = 0.0f, uf = 0.0f;
+        if (philox) {
+            const Philox4 rnd = philox4x32_10(static_cast<uint32_t>(ray), static_cast<uint32_t>(idx),
+                                              static_cast<uint32_t>(c.stream_offset), static_cast<uint32_t>(c.stream_offset >> 32),
+                                              static_cast<uint32_t>(c.seed), static_cast<uint32_t>(c.seed >> 32));
+            uc = uniform_from_bits(rnd.x);
+            uf = uniform_from_bits(rnd.y);
+            if (k == 0) extra_spacing = -fast_log(1.0f - lane_gather(uniform_from_bits(rnd.z), rl.first));   // the (S+1)-th spacing
+        }
+        const bool valid = idx < S;
+        if (u_coarse != nullptr && valid) uc = u_coarse[urow + idx];
+        if (u_fine != nullptr && valid) uf = u_fine[urow + idx];
+        if (valid) {
+            const float lo = torch_linspace(c.near, c.far, S + 1, idx);
+            const float hi = torch_linspace(c.near, c.far, S + 1, idx + 1);
+            coarse[idx] = torch_lerp(lo, hi, uc);
+        }
+        if (u_fine == nullptr) {
+            const float e = valid ? -fast_log(1.0f - uf) : 0.0f;
+            const float inclusive = row_inclusive_sum(e) + running;
+            spacing[k] = inclusive;
+            running = lane_gather(inclusive, rl.last);
+        } else if (valid) {
+            (sorted_input ? usorted : uraw)[idx] = uf;
+        }
+    }
+    if (u_fine == nullptr) {
+        const float inv_total = fast_rcp(running + extra_spacing);
+#pragma unroll
+        for (int k = 0; k < kRoundsS; ++k) {
+            const int idx = k * kRowLanes + rl.col;
+            if (idx < S) usorted[idx] = fminf(spacing[k] * inv_total, 0.99999994f);
+        }
+    }
+    wave_lds_sync();
+    if (u_fine != nullptr && !sorted_input) {             // rank sort of the row's raw draws (parity tests, the API-faithful path)
+#pragma unroll
+        for (int k = 0; k < kRoundsS; ++k) {
+            if (k * kRowLanes >= S) continue;
+            const int idx = k * kRowLanes + rl.col;
+            const bool valid = idx < S;
+            const float v = uraw[valid ? idx : 0];
+            int rank = 0;
+            for (int j = 0; j < S; ++j) {
+                const float o = uraw[j];
+                rank += ((o < v) || (o == v && j < idx)) ? 1 : 0;
+            }
+            if (valid) usorted[rank] = v;
+        }
+        wave_lds_sync();
+    }
+}
+
+// samplers.py:11-36 + renderers.py:198-210 for the lane's ray (render.h: importance_merge, per row): w[k] = coarse weight of point
+// k * 16 + col (0 beyond S - 2); on return merged[0..2S) is the sorted union of the coarse and the fine distances.
+template <int kRoundsS>
+__device__ __forceinline__ void quad_importance_merge(float* rowbase, int S, const float (&w)[kRoundsS], const RowLanes& rl) {
+    float* coarse = rowbase;
+    float* fine = rowbase + S;                    // holds the sorted uniforms on entry: lane j turns u[j] into fine[j] in place
+    float* merged = rowbase + quad_merged_offset(S);
+    float* cdf = merged + S;                      // dead before the merge writes there
+    float total = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kRoundsS; ++k) total += row_sum(fabsf(w[k]));
+    const float denom = fmaxf(total, 1.0e-12f);
+    float running = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kRoundsS; ++k) {
+        if (k * kRowLanes >= S - 1) continue;
+        const int idx = k * kRowLanes + rl.col;
+        const float inclusive = row_inclusive_sum(w[k] / denom) + running;
+        if (idx < S - 1) cdf[idx + 1] = inclusive;
+        running = lane_gather(inclusive, rl.last);
+    }
+    if (rl.col == 0) cdf[0] = 0.0f;
+    wave_lds_sync();
+    const int iters = search_iterations(S);
+    float fine_max = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < kRoundsS; ++k) {
+        if (k * kRowLanes >= S) continue;
+        const int j = k * kRowLanes + rl.col;
+        const bool valid = j < S;
+        const float u = fine[valid ? j : (S - 1)];
+        int upper = count_below<true>(cdf, S, u, iters);
+        upper = min(max(upper, 1), S - 1);
+        const float c_lo = cdf[upper - 1], c_hi = cdf[upper];
+        const float b_lo = coarse[upper - 1], b_hi = coarse[upper];
+        const float t = (u - c_lo) / (c_hi - c_lo + 1.0e-6f);
+        float sample = torch_lerp(b_lo, b_hi, t);
+        const float scan = row_inclusive_max(valid ? sample : -3.0e38f);     // running maximum: see render.h
+        sample = fmaxf(scan, fine_max);
+        fine_max = fmaxf(fine_max, lane_gather(scan, rl.last));
+        wave_lds_sync();                                                     // (padding lanes read the last lane's uniform above)
+        if (valid) fine[j] = sample;
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < kRoundsS; ++k) {
+        if (k * kRowLanes >= S) continue;
+        const int j = k * kRowLanes + rl.col;
+        const bool valid = j < S;
+        const int jj = valid ? j : (S - 1);
+        const float a = coarse[jj], b = fine[jj];
+        const int rank_a = jj + count_below<true>(fine, S, a, iters);
+        const int rank_b = jj + count_below<false>(coarse, S, b, iters);
+        if (valid) { merged[rank_a] = a; merged[rank_b] = b; }
+    }
+    wave_lds_sync();
+}
+
+// Culling coefficients of (lane's ray, instance col, col + 16, ...) (field.h: cull_ray_setup, per row).
+__device__ __forceinline__ RayCull quad_cull_setup(const float* __restrict__ instances, int N, const Ray& r, float* coef, const RowLanes& rl) {
+    float amax = 0.0f;
+    for (int i = rl.col; i < N; i += kRowLanes) {
+        const float* p = instances + i * kInstanceStride;
+        const float ex = r.ox - p[0], ey = r.oy - p[1], ez = r.oz - p[2];
+        const float a = ex * ex + ey * ey + ez * ez;
+        coef[kCullCoefs * i + 0] = a;
+        coef[kCullCoefs * i + 1] = 2.0f * (ex * r.rx + ey * r.ry + ez * r.rz);
+        coef[kCullCoefs * i + 2] = fast_sqrt(p[12] * p[12] + p[13] * p[13] + p[14] * p[14]) * (1.0f / (1.0f - kCullSlack));
+        coef[kCullCoefs * i + 3] = 0.0f;                                        // the ray's label adjoint of instance i, set after pass 2
+        amax = fmaxf(amax, a);
+    }
+    RayCull rc;
+    rc.coef = coef;
+    rc.c2 = r.rx * r.rx + r.ry * r.ry + r.rz * r.rz;
+    rc.rnorm = fast_sqrt(rc.c2);
+    rc.reach = fast_sqrt(fmaxf(row_max(amax), r.ox * r.ox + r.oy * r.oy + r.oz * r.oz));
+    wave_lds_sync();
+    return rc;
+}
+
+// The instance loop of one round (render.h: union_loop): the instances of `evaluated` that also pass the exact test; the soft-min
+// term of every surviving instance is left in dcache[i][lane] (fixed shift: exp(-(d_i - m)/T); running minimum: d_i).
+template <bool kCache, bool kRunning, bool kYaw>
+__device__ __forceinline__ UnionSums quad_union_loop(const float* __restrict__ instances, unsigned long long& evaluated, const Shading& sh,
+                                                     const RoundCull& cull, float floor, float x, float y, float z, float* dcache, int lane) {
+    UnionSums sums = union_init(kRunning, floor);
+    float best = cull.nearest_hi;
+    for (unsigned long long todo = evaluated; todo != 0ull; todo &= todo - 1ull) {
+        const int i = __builtin_ctzll(todo);
+        const Instance in = load_instance(instances, i);
+        BoxEval e = box_value<kYaw>(in, x, y, z);
+        const unsigned long long near = __ballot(!(e.d - best > sh.cull));
+        if (near == 0ull) { evaluated &= ~(1ull << i); continue; }
+        best = fminf(best, e.d);
+        box_gradient<kYaw>(e, in);
+        const float term = union_accumulate<kRunning, false>(sums, e.d, e.gwx, e.gwy, e.gwz, 0.0f, sh.inv_t);
+        if (kCache) dcache[i * kWave + lane] = term;
+    }
+    return sums;
+}
+
+// One point per lane: the interval [dist[s], dist[s + 1]] of the lane's ray.
+struct QuadPoint { float delta, mid, x, y, z; bool valid; };
+__device__ __forceinline__ QuadPoint quad_point(const float* dist, int num_points, int round, const Ray& ray, bool live, const RowLanes& rl) {
+    QuadPoint p;
+    const int s = round * kRowLanes + rl.col;
+    p.valid = live && s < num_points;
+    const int s0 = (s < num_points) ? s : (num_points - 1);                    // padding lanes repeat the last point
+    const float d0 = dist[s0], d1 = dist[s0 + 1];
+    p.delta = d1 - d0;
+    p.mid = (d0 + d1) / 2.0f;
+    p.x = ray.ox + ray.rx * p.mid; p.y = ray.oy + ray.ry * p.mid; p.z = ray.oz + ray.rz * p.mid;
+    return p;
+}
+
+// Pass 1 of the four rays: coarse compositing weights w[k] of point k * 16 + col (render.h: render_pass without labels).
+// Returns false when the fixed soft-min shift cannot serve some round (field.h: union_accumulate): the caller repeats the pass with
+// the running minimum.
+template <int kRoundsS, bool kYaw, bool kRunning>
+__device__ __forceinline__ bool quad_pass_one(const float* __restrict__ instances, int N, const Shading& sh, const Ray& ray, const RayCull& rc,
+                                              const float* coarse, int S, float (&w)[kRoundsS], const RowLanes& rl) {
+    const int num_points = S - 1;
+    float carry = 1.0f;
+#pragma unroll
+    for (int k = 0; k < kRoundsS; ++k) {
+        w[k] = 0.0f;
+        if (k * kRowLanes >= num_points) continue;
+        const QuadPoint p = quad_point(coarse, num_points, k, ray, true, rl);
+        RoundCull cull;
+        unsigned long long evaluated = cull_round_mask<false>(rc, N, p.mid, sh.cull, nullptr, rl.lane, &cull);
+        const float floor = cull.nearest_lo - sh.reach;
+        if (!kRunning && wave_any(!((cull.nearest_hi + 1.0f - floor) * sh.inv_t <= kUnionFloorSpan))) return false;
+        const UnionSums sums = quad_union_loop<false, kRunning, kYaw>(instances, evaluated, sh, cull, floor, p.x, p.y, p.z, nullptr, rl.lane);
+        if (!kRunning && wave_any(!(sums.Z >= kUnionTinyZ))) return false;
+        const UnionValue v = union_finish(sums, sh.inv_t);
+        const Opacity op = opacity_of(v, ray, p.delta, sh);
+        const float alpha = p.valid ? op.alpha : 0.0f;
+        const float inclusive = row_inclusive_product(1.0f - alpha);
+        w[k] = carry * row_shift_up(inclusive, 1.0f) * alpha;
+        carry *= lane_gather(inclusive, rl.last);
+    }
+    return true;
+}
+
+// Per-sample state of the adjoint, one pass-2 point per lane and round, in registers:
+//   after the forward sweep:  m, inv_z (soft-min shift, 1/Z), s = u - m, a = grad u, c = r . b, d = (grad u) . b  with b = sum_i w_i grad d_i
+//   after the reverse sweep:  m, inv_z, s = 1 + (u - m) / T, a = g_bar, c = C2; C1 and C3 wait in the wave's LDS (the distance cache
+//   is free by then: two lane-private floats per round), d is dead.  With them (render_kernels.h: adjoint_phase_b)
+//     d_bar_i = cc_i (C1 - beta_i / T) + w_i (C2 - beta_i / T - C3 lambda_i),   cc_i = w_i (s - (d_i - m) / T)
+//     C1 = u_bar + B / T,  C2 = (A + w_s Lambda_s / Z_s) / T,  C3 = w_s / T,   A = g_bar . grad u,  B = g_bar . b
+template <int kRounds>
+struct QuadAdjoint {
+    float m[kRounds], inv_z[kRounds], s[kRounds];
+    float ax[kRounds], ay[kRounds], az[kRounds];
+    float c[kRounds], d[kRounds];
+    unsigned long long near[kRounds];            // instances evaluated in the round (wave-uniform)
+};
+
+// Pass 2, forward: union, opacity, transmittance, labels.  label: lane (ray, n) accumulates label n of its ray.  The transmittance of
+// every point is left in trans[round * 16 + col] (LDS) for the reverse sweep.  Returns false when a round needs the running minimum.
+template <int kRounds, bool kYaw, bool kRunning>
+__device__ __forceinline__ bool quad_forward_sweep(QuadAdjoint<kRounds>& st, const float* __restrict__ instances, int N, const Shading& sh,
+                                                   const Ray& ray, const RayCull& rc, const float* merged, int num_points, bool live,
+                                                   float* dcache, float* trans, float& label, const RowLanes& rl) {
+    float carry = 1.0f;
+    label = 0.0f;
+#pragma unroll
+    for (int q = 0; q < kRounds; ++q) {
+        st.near[q] = 0ull;
+        if (q * kRowLanes >= num_points) continue;
+        const QuadPoint p = quad_point(merged, num_points, q, ray, live, rl);
+        RoundCull cull;
+        st.near[q] = cull_round_mask<false>(rc, N, p.mid, sh.cull, nullptr, rl.lane, &cull);
+        const float floor = cull.nearest_lo - sh.reach;
+        if (!kRunning && wave_any(!((cull.nearest_hi + 1.0f - floor) * sh.inv_t <= kUnionFloorSpan))) return false;
+        const UnionSums sums = quad_union_loop<true, kRunning, kYaw>(instances, st.near[q], sh, cull, floor, p.x, p.y, p.z, dcache, rl.lane);
+        if (!kRunning && wave_any(!(sums.Z >= kUnionTinyZ))) return false;
+        const UnionValue v = union_finish(sums, sh.inv_t);
+        const Opacity op = opacity_of(v, ray, p.delta, sh);
+        const float alpha = p.valid ? op.alpha : 0.0f;
+        const float inclusive = row_inclusive_product(1.0f - alpha);
+        const float t = carry * row_shift_up(inclusive, 1.0f);
+        carry *= lane_gather(inclusive, rl.last);
+        trans[q * kRowLanes + rl.col] = t;
+        st.m[q] = v.m; st.inv_z[q] = v.inv_z; st.s[q] = v.us;
+        st.ax[q] = v.gx; st.ay[q] = v.gy; st.az[q] = v.gz;
+        st.c[q] = ray.rx * v.b0x + ray.ry * v.b0y + ray.rz * v.b0z;
+        st.d[q] = v.gx * v.b0x + v.gy * v.b0y + v.gz * v.b0z;
+        const float scale = t * alpha * v.inv_z;
+        for (unsigned long long todo = st.near[q]; todo != 0ull; todo &= todo - 1ull) {
+            const int i = __builtin_ctzll(todo);
+            const float cached = dcache[i * kWave + rl.lane];
+            const float e = kRunning ? fast_exp(-(cached - v.m) * sh.inv_t) : cached;
+            const float total = row_sum(e * scale);
+            label = (rl.col == i) ? (label + total) : label;
+        }
+    }
+    return true;
+}
+
+// Reverse sweep over the rounds of pass 2 (render_kernels.h: adjoint_label_mix + adjoint_reverse_sweep): label-adjoint mix
+// Lambda_s, opacity (recomputed from u, grad u and the interval), suffix sums of w_bar w, chain to (u_bar, g_bar), and the
+// per-sample constants of the per-instance phase.  coef_own: the lane's OWN ray's (a, b, radius, lambda) rows; last_cached: the
+// distance cache still holds the soft-min terms of the last round (fixed shift).  On return cbuf (= the distance cache) holds C1 and
+// C3 of every point, trans_mid the interval mid-points.  Returns the rounds (bit q) in which some lane carries a non-zero adjoint.
+template <int kRounds, bool kYaw>
+__device__ __forceinline__ unsigned quad_reverse_sweep(QuadAdjoint<kRounds>& st, const float* __restrict__ instances, const Shading& sh, const Ray& ray,
+                                                       const float* merged, int num_points, bool live, unsigned long long lam_any, bool last_cached,
+                                                       const float* coef_own, float* cbuf, float* trans_mid, const RowLanes& rl) {
+    unsigned flow = 0u;
+    float suffix_carry = 0.0f;
+#pragma unroll
+    for (int q = kRounds - 1; q >= 0; --q) {
+        if (q * kRowLanes >= num_points) continue;
+        const QuadPoint p = quad_point(merged, num_points, q, ray, live, rl);
+        // Lambda_s / Z_s = sum_n lambda_n w_{s,n} over the instances the forward sweep evaluated (culled ones: weight < exp(-18))
+        float acc = 0.0f;
+        if (last_cached && q == (num_points - 1) / kRowLanes) {                    // wave-uniform
+            for (unsigned long long todo = st.near[q] & lam_any; todo != 0ull; todo &= todo - 1ull) {
+                const int i = __builtin_ctzll(todo);
+                acc += coef_own[kCullCoefs * i + 3] * cbuf[i * kWave + rl.lane];
+            }
+        } else {
+            for (unsigned long long todo = st.near[q] & lam_any; todo != 0ull; todo &= todo - 1ull) {
+                const int i = __builtin_ctzll(todo);
+                const Instance in = load_instance(instances, i);
+                acc += coef_own[kCullCoefs * i + 3] * fast_exp(-(box_value<kYaw>(in, p.x, p.y, p.z).d - st.m[q]) * sh.inv_t);
+            }
+        }
+        const float lam_z = p.valid ? acc * st.inv_z[q] : 0.0f;
+        UnionValue v;
+        v.u = st.m[q] + st.s[q]; v.gx = st.ax[q]; v.gy = st.ay[q]; v.gz = st.az[q];
+        const Opacity op = opacity_of(v, ray, p.delta, sh);
+        const float alpha = p.valid ? op.alpha : 0.0f;
+        const float t = trans_mid[q * kRowLanes + rl.col];
+        trans_mid[q * kRowLanes + rl.col] = p.mid;                                 // (same lane, same slot: no hazard)
+        const float wgt = t * alpha;
+        const float contrib = lam_z * wgt;
+        const float suffix_inclusive = row_suffix_sum(contrib);
+        const float Q = suffix_inclusive - contrib + suffix_carry;                 // sum over the later samples of the ray
+        suffix_carry += lane_gather(suffix_inclusive, rl.first);
+        const float alpha_bar = lam_z * t - Q * fast_rcp(1.0f - alpha);
+        const float x_bar = (p.valid && op.xx > 0.0f) ? alpha_bar : 0.0f;
+        const float inv_pe = fast_rcp(op.phi_p + sh.eps);
+        const float phi_p_bar = x_bar * (op.phi_n + sh.eps) * inv_pe * inv_pe;
+        const float phi_n_bar = -x_bar * inv_pe;
+        const float sp_bar = phi_p_bar * op.phi_p * (1.0f - op.phi_p) * sh.inv_std;
+        const float sn_bar = phi_n_bar * op.phi_n * (1.0f - op.phi_n) * sh.inv_std;
+        const float u_bar = sp_bar + sn_bar;                                       // (x_bar = 0 on padding lanes)
+        const float cprime_bar = (sn_bar - sp_bar) * p.delta / 2.0f;
+        const float slope = (1.0f - sh.ratio) * ((0.5f - 0.5f * op.cosine > 0.0f) ? 0.5f : 0.0f) + sh.ratio * ((-op.cosine > 0.0f) ? 1.0f : 0.0f);
+        const float cos_bar = cprime_bar * slope;
+        const float nbx = cos_bar * ray.rx, nby = cos_bar * ray.ry, nbz = cos_bar * ray.rz;
+        const float n_dot = op.nx * nbx + op.ny * nby + op.nz * nbz;
+        const float gbx = (nbx - op.nx * n_dot) * op.inv_gn, gby = (nby - op.ny * n_dot) * op.inv_gn, gbz = (nbz - op.nz * n_dot) * op.inv_gn;
+        // B = g_bar . b from r . b and (grad u) . b:  g_bar = cos_bar / |g| (r - n (n . r)),  n = grad u / |g|
+        const float B = cos_bar * op.inv_gn * (st.c[q] - st.d[q] * op.inv_gn * op.cosine);
+        const float A = gbx * st.ax[q] + gby * st.ay[q] + gbz * st.az[q];
+        st.ax[q] = gbx; st.ay[q] = gby; st.az[q] = gbz;
+        st.s[q] = 1.0f + st.s[q] * sh.inv_t;
+        st.c[q] = sh.inv_t * (A + wgt * lam_z);
+        cbuf[(2 * q) * kWave + rl.lane] = u_bar + sh.inv_t * B;
+        cbuf[(2 * q + 1) * kWave + rl.lane] = sh.inv_t * wgt;
+        const bool any = (u_bar != 0.0f) || (gbx != 0.0f) || (gby != 0.0f) || (gbz != 0.0f) || (wgt != 0.0f);
+        flow |= (__ballot(any) != 0ull) ? (1u << q) : 0u;
+    }
+    return flow;
+}
+
+// Per-instance phase for the four rays (render_kernels.h: adjoint_phase_b): instance-outer, rounds inner, one reduce-scatter butterfly
+// per (wave, instance).  G[s]: lane (row r, col c) accumulates parameter c of instance 4 s + r.
+template <int kRounds, bool kYaw>
+__device__ __forceinline__ void quad_phase_b(const QuadAdjoint<kRounds>& st, const float* __restrict__ instances, const Shading& sh, const Ray& ray,
+                                             unsigned flow, const float* coef_own, const float* cbuf, const float* mids, float (&G)[4], const RowLanes& rl) {
+    const float inv_t = sh.inv_t;
+    unsigned long long todo = 0ull;
+#pragma unroll
+    for (int q = 0; q < kRounds; ++q) todo |= ((flow >> q) & 1u) ? st.near[q] : 0ull;
+    for (; todo != 0ull; todo &= todo - 1ull) {
+        const int i = __builtin_ctzll(todo);
+        const Instance in = load_instance(instances, i);
+        const float lam_i = coef_own[kCullCoefs * i + 3];
+        float at0 = 0, at1 = 0, at2 = 0, ad0 = 0, ad1 = 0, ad2 = 0;
+        float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
+#pragma unroll
+        for (int q = 0; q < kRounds; ++q) {
+            if (!(((st.near[q] >> i) & 1ull) && ((flow >> q) & 1u))) continue;       // wave-uniform
+            const float mid = mids[q * kRowLanes + rl.col];
+            const float c1 = cbuf[(2 * q) * kWave + rl.lane], c3 = cbuf[(2 * q + 1) * kWave + rl.lane];
+            const BoxEval e = eval_box<kYaw>(in, ray.ox + ray.rx * mid, ray.oy + ray.ry * mid, ray.oz + ray.rz * mid);
+            const float ds = e.d - st.m[q];
+            const float w = fast_exp(-ds * inv_t) * st.inv_z[q];
+            const float cc = w * (st.s[q] - ds * inv_t);
+            const float gx_ = st.ax[q], gy_ = st.ay[q], gz_ = st.az[q];
+            const float rgx = kYaw ? fmaf(in.r20, gz_, in.r00 * gx_) : fmaf(in.r20, gz_, fmaf(in.r10, gy_, in.r00 * gx_));
+            const float rgy = kYaw ? gy_ : fmaf(in.r21, gz_, fmaf(in.r11, gy_, in.r01 * gx_));
+            const float rgz = kYaw ? fmaf(in.r22, gz_, in.r02 * gx_) : fmaf(in.r22, gz_, fmaf(in.r12, gy_, in.r02 * gx_));
+            const float tb = inv_t * (rgx * e.glx + rgy * e.gly + rgz * e.glz);
+            const float d_bar = cc * (c1 - tb) + w * (st.c[q] - tb - c3 * lam_i);
+            const float gwbx = cc * gx_, gwby = cc * gy_, gwbz = cc * gz_;
+            const float glbx = cc * rgx, glby = cc * rgy, glbz = cc * rgz;
+            const float sx = sign_of(e.px), sy = sign_of(e.py), sz = sign_of(e.pz);
+            const float vx = sx * glbx, vy = sy * glby, vz = sz * glbz;
+            const float inv_n = fast_rcp(e.nrm);
+            const float hx = fmaxf(e.qx, 0.0f) * inv_n, hy = fmaxf(e.qy, 0.0f) * inv_n, hz = fmaxf(e.qz, 0.0f) * inv_n;
+            const float hv = hx * vx + hy * vy + hz * vz;
+            const float qbx = d_bar * e.hx + ((e.qx > 0.0f) ? (vx - hx * hv) * inv_n : 0.0f);
+            const float qby = d_bar * e.hy + ((e.qy > 0.0f) ? (vy - hy * hv) * inv_n : 0.0f);
+            const float qbz = d_bar * e.hz + ((e.qz > 0.0f) ? (vz - hz * hv) * inv_n : 0.0f);
+            const float pbx = sx * qbx, pby = sy * qby, pbz = sz * qbz;
+            ad0 -= qbx; ad1 -= qby; ad2 -= qbz;
+            r00 += e.relx * pbx + gwbx * e.glx; r01 += e.relx * pby + gwbx * e.gly; r02 += e.relx * pbz + gwbx * e.glz;
+            r10 += e.rely * pbx + gwby * e.glx; r11 += e.rely * pby + gwby * e.gly; r12 += e.rely * pbz + gwby * e.glz;
+            r20 += e.relz * pbx + gwbz * e.glx; r21 += e.relz * pby + gwbz * e.gly; r22 += e.relz * pbz + gwbz * e.glz;
+            if (kYaw) {
+                at0 -= in.r00 * pbx + in.r02 * pbz; at1 -= pby; at2 -= in.r20 * pbx + in.r22 * pbz;
+            } else {
+                at0 -= in.r00 * pbx + in.r01 * pby + in.r02 * pbz;
+                at1 -= in.r10 * pbx + in.r11 * pby + in.r12 * pbz;
+                at2 -= in.r20 * pbx + in.r21 * pby + in.r22 * pbz;
+            }
+        }
+        const float packed[16] = {at0, at1, at2, r00, r01, r02, r10, r11, r12, r20, r21, r22, ad0, ad1, ad2, 0.0f};
+        const float mine = wave_reduce16_scatter(packed, rl.lane);            // every lane: the wave's sum of parameter (lane & 15)
+        const float add = (rl.row == (i & 3)) ? mine : 0.0f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) G[s] += ((i >> 2) == s) ? add : 0.0f;
+    }
+}
+
+// Everything one wave does for one group of four rays: sampling, pass 1, pass 2, silhouette BCE (main.py:653-671; torch clamp /
+// binary_cross_entropy backward), label adjoints, reverse sweep, per-instance phase.  One soft-min mode per instantiation (kRunning:
+// the running minimum; else the shift known before the instance loop, field.h); returns false -- before any side effect other than
+// LDS staging -- when the fixed shift cannot serve some round of the group (samples extrapolated to 1e6 m): the caller then runs
+// the group again with kRunning.  The three instantiations share no state, so none of it crosses a control-flow merge.
+template <int kRoundsS, bool kYaw, bool kRunning>
+__device__ __forceinline__ bool quad_step_body(const float* __restrict__ instances, int N, const RenderArgs& c, const Shading& sh, int first_ray,
+                                               const float* __restrict__ origins, const float* __restrict__ directions,
+                                               const float* __restrict__ u_coarse, const float* __restrict__ u_fine, bool sorted_input,
+                                               const float* __restrict__ targets, float weight_lane, float loss_scale, float* __restrict__ labels_out,
+                                               float* stage, float* dcache, float* coefs, float (&G)[4], float& loss_acc, const RowLanes& rl) {
+    constexpr int kRounds = 2 * kRoundsS;
+    const int S = c.num_samples;
+    const int num_points = 2 * S - 1;
+    const int my_ray = first_ray + rl.row;
+    const bool alive = my_ray < c.num_rays;
+    const int ray = alive ? my_ray : (c.num_rays - 1);                    // rows beyond the launch repeat its last ray and contribute nothing
+    const long long src = source_row(c, ray);
+    Ray r;
+    {
+        const long long origin_row = (c.ray_indices && c.rays_per_origin > 0) ? src / c.rays_per_origin : src;
+        const float* o = origins + origin_row * c.origin_stride;
+        const float* d = directions + src * 3;
+        r.ox = o[0]; r.oy = o[1]; r.oz = o[2]; r.rx = d[0]; r.ry = d[1]; r.rz = d[2];
+    }
+    float* rowbase = stage + rl.row * quad_row_floats(S);
+    float* coef_own = coefs + rl.row * quad_coef_floats(N);
+    RayCull rc = quad_cull_setup(instances, N, r, coef_own, rl);
+    quad_stage_samples<kRoundsS>(rowbase, c, S, ray, u_coarse, u_fine, sorted_input, rl);
+    // ---- pass 1 ----------------------------------------------------------------------------------------------------------------
+    float w1[kRoundsS];
+    if (!quad_pass_one<kRoundsS, kYaw, kRunning>(instances, N, sh, r, rc, rowbase, S, w1, rl)) return false;
+    float coarse_total = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kRoundsS; ++k) coarse_total += row_sum(w1[k]);
+    // exact misses (VSRD_FLAG_SKIP_EXACT_MISSES): labels exactly 0, adjoint exactly 0
+    const bool live = alive && !((c.flags & 2u) && coarse_total == 0.0f);
+    const unsigned long long live_lanes = __ballot(live);
+    float label = 0.0f;
+    QuadAdjoint<kRounds> st;
+    const float* merged = rowbase + quad_merged_offset(S);
+    float* trans_mid = rowbase;
+    if (live_lanes != 0ull) {
+        quad_importance_merge<kRoundsS>(rowbase, S, w1, rl);
+        // rows that do not take part shadow the first live row (same points, same votes in the culling ballots, zero weight)
+        const int donor = __builtin_ctzll(live_lanes) & 48;
+        if (!live) {
+            r.ox = read_lane(r.ox, donor); r.oy = read_lane(r.oy, donor); r.oz = read_lane(r.oz, donor);
+            r.rx = read_lane(r.rx, donor); r.ry = read_lane(r.ry, donor); r.rz = read_lane(r.rz, donor);
+            rc.c2 = read_lane(rc.c2, donor); rc.rnorm = read_lane(rc.rnorm, donor); rc.reach = read_lane(rc.reach, donor);
+            rc.coef = coefs + (donor >> 4) * quad_coef_floats(N);
+            merged = stage + (donor >> 4) * quad_row_floats(S) + quad_merged_offset(S);       // (trans_mid stays the row's own: its transmittances are all 1)
+        }
+        if (!quad_forward_sweep<kRounds, kYaw, kRunning>(st, instances, N, sh, r, rc, merged, num_points, live, dcache, trans_mid, label, rl)) return false;
+        if (!live) label = 0.0f;
+    }
+    // ---- loss and label adjoints -------------------------------------------------------------------------------------------------
+    const bool mine = alive && rl.col < N;
+    if (labels_out != nullptr && mine) labels_out[static_cast<size_t>(my_ray) * N + rl.col] = label;
+    const float target = mine ? load_target(c, targets, src, rl.col, N) : 0.0f;
+    const float p = fminf(fmaxf(label, 1.0e-6f), 1.0f - 1.0e-6f);
+    const float bce = -(target * logf(p) + (1.0f - target) * logf(1.0f - p));
+    loss_acc += mine ? weight_lane * bce : 0.0f;
+    const bool inside_clamp = (label >= 1.0e-6f) && (label <= 1.0f - 1.0e-6f);
+    const float lam_lane = (mine && live && inside_clamp) ? weight_lane * loss_scale * (p - target) / fmaxf(p * (1.0f - p), 1.0e-12f) : 0.0f;
+    unsigned long long lam_any = __ballot(lam_lane != 0.0f);                 // bit n: some ray has a label adjoint for instance n
+    lam_any |= lam_any >> 32; lam_any |= lam_any >> 16; lam_any &= 0xFFFFull;
+    if (live_lanes == 0ull || lam_any == 0ull) return true;
+    if (rl.col < N) coef_own[kCullCoefs * rl.col + 3] = lam_lane;
+    wave_lds_sync();
+    // ---- adjoint -------------------------------------------------------------------------------------------------------------------
+    const unsigned flow = quad_reverse_sweep<kRounds, kYaw>(st, instances, sh, r, merged, num_points, live, lam_any, !kRunning, coef_own, dcache, trans_mid, rl);
+    if (flow != 0u) quad_phase_b<kRounds, kYaw>(st, instances, sh, r, flow, coef_own, dcache, trans_mid, G, rl);
+    return true;
+}
+
+template <int kRoundsS>
+__global__ __launch_bounds__(kBlockThreads, 4) void render_silhouette_quad_kernel(
+    FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
+    const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
+    const float* __restrict__ targets, const float* __restrict__ instance_weights, float loss_scale,
+    float* __restrict__ labels_out, float* __restrict__ partials, float* __restrict__ loss_partials) {
+    apply_device_schedule(f, c);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = wave_in_block();
+    const RowLanes rl = row_lanes();
+    const int S = c.num_samples;
+    const int N = f.num_instances;
+    float* stage = lds + wave * quad_lds_floats(S, N);
+    float* dcache = stage + kQuadRays * quad_row_floats(S);
+    float* coefs = dcache + quad_cache_rows(S, N) * kWave;
+    const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
+    Shading sh = c.sh;
+    const FieldBounds bounds = field_bounds(instances, N, f.inv_t, false, c.flags);
+    sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
+    sh.mlp_bits = 0u;
+    sh.mlp_lds = nullptr;
+    const float weight_lane = (rl.col < N) ? (instance_weights ? instance_weights[rl.col] : 1.0f) : 0.0f;
+    float loss_acc = 0.0f;
+    float G[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int num_waves = static_cast<int>(gridDim.x) * waves_per_block();
+    const int wave_global = static_cast<int>(blockIdx.x) * waves_per_block() + wave;
+    const int num_quads = (c.num_rays + kQuadRays - 1) / kQuadRays;
+    for (int quad = wave_global; quad < num_quads; quad += num_waves) {
+        const int first_ray = quad * kQuadRays;
+        wave_lds_sync();
+        bool done = false;
+        if (sh.reach >= 0.0f) {
+            done = sh.yaw ? quad_step_body<kRoundsS, true, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
+                                                                  weight_lane, loss_scale, labels_out, stage, dcache, coefs, G, loss_acc, rl)
+                          : quad_step_body<kRoundsS, false, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
+                                                                   weight_lane, loss_scale, labels_out, stage, dcache, coefs, G, loss_acc, rl);
+            if (!done) wave_lds_sync();
+        }
+        if (!done) quad_step_body<kRoundsS, false, true>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
+                                                         weight_lane, loss_scale, labels_out, stage, dcache, coefs, G, loss_acc, rl);
+    }
+    float* out = partials + static_cast<size_t>(wave_global) * (N * kGradStride);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (s * kWave + rl.lane < N * kGradStride) out[s * kWave + rl.lane] = G[s];
+    const float loss_total = wave_sum(loss_acc);
+    if (rl.lane == 0) loss_partials[wave_global] = loss_total * loss_scale;
+}
+
+}  // namespace vsrd
