@@ -251,6 +251,54 @@ __device__ __forceinline__ RayCull quad_cull_setup(const float* __restrict__ ins
     return rc;
 }
 
+// The culling pre-pass of one round (field.h: cull_round_mask) in two steps, so that a round can leave between them.
+// Step 1: the bounds of the nearest centre distance of every lane's point (RoundCull).
+__device__ __forceinline__ RoundCull quad_round_bounds(const RayCull& rc, int num_instances, float t, float margin) {
+    const float ct = rc.c2 * t;
+    float nearest2 = 3.0e38f;
+    int i = 0;
+    for (; i + 4 <= num_instances; i += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nearest2 = fminf(nearest2, centre_distance2(rc, i + j, t, ct));
+    }
+    for (; i < num_instances; ++i) nearest2 = fminf(nearest2, centre_distance2(rc, i, t, ct));
+    return cull_round(rc, t, nearest2, margin);
+}
+// Step 2: bit i = instance i may matter on some lane (wave-uniform).
+__device__ __forceinline__ unsigned long long quad_round_mask(const RayCull& rc, const RoundCull& cull, int num_instances, float t) {
+    const float ct = rc.c2 * t;
+    unsigned long long mask = 0ull;
+    int i = 0;
+    for (; i + 4 <= num_instances; i += 4) {
+        float d2[4], radius[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            d2[j] = centre_distance2(rc, i + j, t, ct);
+            radius[j] = rc.coef[kCullCoefs * (i + j) + 2];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float reach = cull.limit + radius[j];
+            mask |= (__ballot(!(d2[j] > fmaf(reach, reach, cull.err))) != 0ull) ? (1ull << (i + j)) : 0ull;
+        }
+    }
+    for (; i < num_instances; ++i) mask |= (cull_near(rc, cull, i, centre_distance2(rc, i, t, ct)) != 0ull) ? (1ull << i) : 0ull;
+    return mask;
+}
+
+// Rounds that see nothing (wave-uniform, exact).  Every box distance of the round's points is >= floor = (nearest centre distance)
+// (1 - k) - max_i |dim_i| (field.h: field_bounds), the soft-min union is a convex combination of them, and the section points of the
+// opacity (renderers.py:228-248) lie within |c'| delta / 2 <= max(1, |r|) delta / 2 of it.  Once (floor - that) / sigma >= 17 both
+// logistic cdfs are EXACTLY 1 in fp32 (exp(-17) < 2^-24 vanishes in 1 + exp(-x), v_rcp(1) = 1), so alpha = 0 on every lane: no
+// weight, no label, no adjoint -- the round leaves before its instance loop.  (Fine samples extrapolated to 1e6 m end here too.)
+// VSRD_FLAG_NO_CULLING (every instance at every sample) switches this off as well.
+constexpr float kLogisticOne = 17.5f;
+__device__ __forceinline__ bool quad_round_is_empty(const RayCull& rc, const RoundCull& cull, const Shading& sh, float delta) {
+    const float floor = cull.nearest_lo - sh.reach;
+    const float half = 0.5f * fmaxf(1.0f, rc.rnorm) * fabsf(delta);
+    return sh.reach >= 0.0f && sh.cull < 1.0e38f && !wave_any(!((floor - half) * sh.inv_std >= kLogisticOne));
+}
+
 // The instance loop of one round (render.h: union_loop): the instances of `evaluated` that also pass the exact test; the soft-min
 // term of every surviving instance is left in dcache[i][lane] (fixed shift: exp(-(d_i - m)/T); running minimum: d_i).
 template <bool kCache, bool kRunning, bool kYaw>
@@ -299,8 +347,9 @@ __device__ __forceinline__ bool quad_pass_one(const float* __restrict__ instance
         w[k] = 0.0f;
         if (k * kRowLanes >= num_points) continue;
         const QuadPoint p = quad_point(coarse, num_points, k, ray, true, rl);
-        RoundCull cull;
-        unsigned long long evaluated = cull_round_mask<false>(rc, N, p.mid, sh.cull, nullptr, rl.lane, &cull);
+        const RoundCull cull = quad_round_bounds(rc, N, p.mid, sh.cull);
+        if (quad_round_is_empty(rc, cull, sh, p.delta)) continue;                // alpha = 0 exactly: the transmittance passes unchanged
+        unsigned long long evaluated = quad_round_mask(rc, cull, N, p.mid);
         const float floor = cull.nearest_lo - sh.reach;
         if (!kRunning && wave_any(!((cull.nearest_hi + 1.0f - floor) * sh.inv_t <= kUnionFloorSpan))) return false;
         const UnionSums sums = quad_union_loop<false, kRunning, kYaw>(instances, evaluated, sh, cull, floor, p.x, p.y, p.z, nullptr, rl.lane);
@@ -330,23 +379,28 @@ struct QuadAdjoint {
 };
 
 // Pass 2, forward: union, opacity, transmittance, labels.  label: lane (ray, n) accumulates label n of its ray.  The transmittance of
-// every point is left in trans[round * 16 + col] (LDS) for the reverse sweep.  Returns false when a round needs the running minimum.
+// every point of an active round is left in trans[round * 16 + col] (LDS) for the reverse sweep.  Returns false when a round needs
+// the running minimum.
 template <int kRounds, bool kYaw, bool kRunning>
 __device__ __forceinline__ bool quad_forward_sweep(QuadAdjoint<kRounds>& st, const float* __restrict__ instances, int N, const Shading& sh,
                                                    const Ray& ray, const RayCull& rc, const float* merged, int num_points, bool live,
-                                                   float* dcache, float* trans, float& label, const RowLanes& rl) {
+                                                   float* dcache, float* trans, float& label, unsigned& active, int& cached_round, const RowLanes& rl) {
     float carry = 1.0f;
     label = 0.0f;
+    cached_round = -1;                                                           // the round whose soft-min terms the distance cache holds at the end
+    active = 0u;                                                                 // bit q: some point of round q has a weight
 #pragma unroll
     for (int q = 0; q < kRounds; ++q) {
         st.near[q] = 0ull;
         if (q * kRowLanes >= num_points) continue;
         const QuadPoint p = quad_point(merged, num_points, q, ray, live, rl);
-        RoundCull cull;
-        st.near[q] = cull_round_mask<false>(rc, N, p.mid, sh.cull, nullptr, rl.lane, &cull);
+        const RoundCull cull = quad_round_bounds(rc, N, p.mid, sh.cull);
+        if (quad_round_is_empty(rc, cull, sh, p.delta)) continue;                // alpha = 0 exactly: no weight, no label, no adjoint
+        st.near[q] = quad_round_mask(rc, cull, N, p.mid);
         const float floor = cull.nearest_lo - sh.reach;
         if (!kRunning && wave_any(!((cull.nearest_hi + 1.0f - floor) * sh.inv_t <= kUnionFloorSpan))) return false;
         const UnionSums sums = quad_union_loop<true, kRunning, kYaw>(instances, st.near[q], sh, cull, floor, p.x, p.y, p.z, dcache, rl.lane);
+        cached_round = q;
         if (!kRunning && wave_any(!(sums.Z >= kUnionTinyZ))) return false;
         const UnionValue v = union_finish(sums, sh.inv_t);
         const Opacity op = opacity_of(v, ray, p.delta, sh);
@@ -359,6 +413,8 @@ __device__ __forceinline__ bool quad_forward_sweep(QuadAdjoint<kRounds>& st, con
         st.ax[q] = v.gx; st.ay[q] = v.gy; st.az[q] = v.gz;
         st.c[q] = ray.rx * v.b0x + ray.ry * v.b0y + ray.rz * v.b0z;
         st.d[q] = v.gx * v.b0x + v.gy * v.b0y + v.gz * v.b0z;
+        if (__ballot(alpha > 0.0f) == 0ull) continue;                            // (a round without weight: nothing for the labels, nothing flows back)
+        active |= 1u << q;
         const float scale = t * alpha * v.inv_z;
         for (unsigned long long todo = st.near[q]; todo != 0ull; todo &= todo - 1ull) {
             const int i = __builtin_ctzll(todo);
@@ -373,22 +429,22 @@ __device__ __forceinline__ bool quad_forward_sweep(QuadAdjoint<kRounds>& st, con
 
 // Reverse sweep over the rounds of pass 2 (render_kernels.h: adjoint_label_mix + adjoint_reverse_sweep): label-adjoint mix
 // Lambda_s, opacity (recomputed from u, grad u and the interval), suffix sums of w_bar w, chain to (u_bar, g_bar), and the
-// per-sample constants of the per-instance phase.  coef_own: the lane's OWN ray's (a, b, radius, lambda) rows; last_cached: the
-// distance cache still holds the soft-min terms of the last round (fixed shift).  On return cbuf (= the distance cache) holds C1 and
+// per-sample constants of the per-instance phase.  coef_own: the lane's OWN ray's (a, b, radius, lambda) rows; cached_round:
+// the round whose soft-min terms the distance cache still holds (fixed shift; -1: none).  On return cbuf (= the distance cache) holds C1 and
 // C3 of every point, trans_mid the interval mid-points.  Returns the rounds (bit q) in which some lane carries a non-zero adjoint.
 template <int kRounds, bool kYaw>
 __device__ __forceinline__ unsigned quad_reverse_sweep(QuadAdjoint<kRounds>& st, const float* __restrict__ instances, const Shading& sh, const Ray& ray,
-                                                       const float* merged, int num_points, bool live, unsigned long long lam_any, bool last_cached,
+                                                       const float* merged, int num_points, bool live, unsigned active, unsigned long long lam_any, int cached_round,
                                                        const float* coef_own, float* cbuf, float* trans_mid, const RowLanes& rl) {
     unsigned flow = 0u;
     float suffix_carry = 0.0f;
 #pragma unroll
     for (int q = kRounds - 1; q >= 0; --q) {
-        if (q * kRowLanes >= num_points) continue;
+        if (!((active >> q) & 1u)) continue;                                       // no weight in the round: nothing flows back (exact)
         const QuadPoint p = quad_point(merged, num_points, q, ray, live, rl);
         // Lambda_s / Z_s = sum_n lambda_n w_{s,n} over the instances the forward sweep evaluated (culled ones: weight < exp(-18))
         float acc = 0.0f;
-        if (last_cached && q == (num_points - 1) / kRowLanes) {                    // wave-uniform
+        if (q == cached_round) {                                                   // wave-uniform: the soft-min terms are still in the distance cache
             for (unsigned long long todo = st.near[q] & lam_any; todo != 0ull; todo &= todo - 1ull) {
                 const int i = __builtin_ctzll(todo);
                 acc += coef_own[kCullCoefs * i + 3] * cbuf[i * kWave + rl.lane];
@@ -501,6 +557,14 @@ __device__ __forceinline__ void quad_phase_b(const QuadAdjoint<kRounds>& st, con
     }
 }
 
+#ifdef VSRD_PHASE_TIMERS
+#define VSRD_QUAD_CLOCK_PARAM , PhaseClock& phase_clock
+#define VSRD_QUAD_CLOCK_ARG , phase_clock
+#else
+#define VSRD_QUAD_CLOCK_PARAM
+#define VSRD_QUAD_CLOCK_ARG
+#endif
+
 // Everything one wave does for one group of four rays: sampling, pass 1, pass 2, silhouette BCE (main.py:653-671; torch clamp /
 // binary_cross_entropy backward), label adjoints, reverse sweep, per-instance phase.  One soft-min mode per instantiation (kRunning:
 // the running minimum; else the shift known before the instance loop, field.h); returns false -- before any side effect other than
@@ -511,8 +575,9 @@ __device__ __forceinline__ bool quad_step_body(const float* __restrict__ instanc
                                                const float* __restrict__ origins, const float* __restrict__ directions,
                                                const float* __restrict__ u_coarse, const float* __restrict__ u_fine, bool sorted_input,
                                                const float* __restrict__ targets, float weight_lane, float loss_scale, float* __restrict__ labels_out,
-                                               float* stage, float* dcache, float* coefs, float (&G)[4], float& loss_acc, const RowLanes& rl) {
+                                               float* stage, float* dcache, float* coefs, float (&G)[4], float& loss_acc, const RowLanes& rl VSRD_QUAD_CLOCK_PARAM) {
     constexpr int kRounds = 2 * kRoundsS;
+    VSRD_PHASE(7);
     const int S = c.num_samples;
     const int num_points = 2 * S - 1;
     const int my_ray = first_ray + rl.row;
@@ -530,9 +595,11 @@ __device__ __forceinline__ bool quad_step_body(const float* __restrict__ instanc
     float* coef_own = coefs + rl.row * quad_coef_floats(N);
     RayCull rc = quad_cull_setup(instances, N, r, coef_own, rl);
     quad_stage_samples<kRoundsS>(rowbase, c, S, ray, u_coarse, u_fine, sorted_input, rl);
+    VSRD_PHASE(0);
     // ---- pass 1 ----------------------------------------------------------------------------------------------------------------
     float w1[kRoundsS];
     if (!quad_pass_one<kRoundsS, kYaw, kRunning>(instances, N, sh, r, rc, rowbase, S, w1, rl)) return false;
+    VSRD_PHASE(1);
     float coarse_total = 0.0f;
 #pragma unroll
     for (int k = 0; k < kRoundsS; ++k) coarse_total += row_sum(w1[k]);
@@ -540,11 +607,14 @@ __device__ __forceinline__ bool quad_step_body(const float* __restrict__ instanc
     const bool live = alive && !((c.flags & 2u) && coarse_total == 0.0f);
     const unsigned long long live_lanes = __ballot(live);
     float label = 0.0f;
+    unsigned active = 0u;
+    int cached_round = -1;
     QuadAdjoint<kRounds> st;
     const float* merged = rowbase + quad_merged_offset(S);
     float* trans_mid = rowbase;
     if (live_lanes != 0ull) {
         quad_importance_merge<kRoundsS>(rowbase, S, w1, rl);
+        VSRD_PHASE(2);
         // rows that do not take part shadow the first live row (same points, same votes in the culling ballots, zero weight)
         const int donor = __builtin_ctzll(live_lanes) & 48;
         if (!live) {
@@ -554,8 +624,9 @@ __device__ __forceinline__ bool quad_step_body(const float* __restrict__ instanc
             rc.coef = coefs + (donor >> 4) * quad_coef_floats(N);
             merged = stage + (donor >> 4) * quad_row_floats(S) + quad_merged_offset(S);       // (trans_mid stays the row's own: its transmittances are all 1)
         }
-        if (!quad_forward_sweep<kRounds, kYaw, kRunning>(st, instances, N, sh, r, rc, merged, num_points, live, dcache, trans_mid, label, rl)) return false;
+        if (!quad_forward_sweep<kRounds, kYaw, kRunning>(st, instances, N, sh, r, rc, merged, num_points, live, dcache, trans_mid, label, active, cached_round, rl)) return false;
         if (!live) label = 0.0f;
+        VSRD_PHASE(3);
     }
     // ---- loss and label adjoints -------------------------------------------------------------------------------------------------
     const bool mine = alive && rl.col < N;
@@ -572,8 +643,11 @@ __device__ __forceinline__ bool quad_step_body(const float* __restrict__ instanc
     if (rl.col < N) coef_own[kCullCoefs * rl.col + 3] = lam_lane;
     wave_lds_sync();
     // ---- adjoint -------------------------------------------------------------------------------------------------------------------
-    const unsigned flow = quad_reverse_sweep<kRounds, kYaw>(st, instances, sh, r, merged, num_points, live, lam_any, !kRunning, coef_own, dcache, trans_mid, rl);
+    if (active == 0u) return true;
+    const unsigned flow = quad_reverse_sweep<kRounds, kYaw>(st, instances, sh, r, merged, num_points, live, active, lam_any, kRunning ? -1 : cached_round, coef_own, dcache, trans_mid, rl);
+    VSRD_PHASE(4);
     if (flow != 0u) quad_phase_b<kRounds, kYaw>(st, instances, sh, r, flow, coef_own, dcache, trans_mid, G, rl);
+    VSRD_PHASE(5);
     return true;
 }
 
@@ -604,20 +678,23 @@ __global__ __launch_bounds__(kBlockThreads, 4) void render_silhouette_quad_kerne
     const int num_waves = static_cast<int>(gridDim.x) * waves_per_block();
     const int wave_global = static_cast<int>(blockIdx.x) * waves_per_block() + wave;
     const int num_quads = (c.num_rays + kQuadRays - 1) / kQuadRays;
+    VSRD_PHASE_CLOCK();
     for (int quad = wave_global; quad < num_quads; quad += num_waves) {
         const int first_ray = quad * kQuadRays;
         wave_lds_sync();
         bool done = false;
         if (sh.reach >= 0.0f) {
             done = sh.yaw ? quad_step_body<kRoundsS, true, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
-                                                                  weight_lane, loss_scale, labels_out, stage, dcache, coefs, G, loss_acc, rl)
+                                                                  weight_lane, loss_scale, labels_out, stage, dcache, coefs, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG)
                           : quad_step_body<kRoundsS, false, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
-                                                                   weight_lane, loss_scale, labels_out, stage, dcache, coefs, G, loss_acc, rl);
+                                                                   weight_lane, loss_scale, labels_out, stage, dcache, coefs, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
             if (!done) wave_lds_sync();
         }
         if (!done) quad_step_body<kRoundsS, false, true>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
-                                                         weight_lane, loss_scale, labels_out, stage, dcache, coefs, G, loss_acc, rl);
+                                                         weight_lane, loss_scale, labels_out, stage, dcache, coefs, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
     }
+    VSRD_PHASE(7);
+    VSRD_PHASE_FLUSH(rl.lane);
     float* out = partials + static_cast<size_t>(wave_global) * (N * kGradStride);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
