@@ -77,11 +77,19 @@ struct RowLanes {
     int lane, row, col;
     int first, last;          // ds_bpermute addresses of the row's lane 0 / lane 15
 };
-__device__ __forceinline__ RowLanes row_lanes() {
+__device__ __forceinline__ RowLanes row_lanes(int lane) {
     RowLanes r;
-    r.lane = lane_id(); r.row = r.lane >> 4; r.col = r.lane & 15;
+    r.lane = lane; r.row = r.lane >> 4; r.col = r.lane & 15;
     r.first = (r.lane & 48) << 2; r.last = (r.lane | 15) << 2;
     return r;
+}
+// The lane id as a value the optimiser cannot see through: what is derived from it inside a loop iteration (LDS addresses, sample
+// indices, stratification bounds ...) is re-derived there in a few integer instructions instead of being hoisted out of the loop
+// and held -- or spilled -- over all of it (render_silhouette_quad_kernel: ~50 such registers).
+__device__ __forceinline__ int opaque_lane_id() {
+    int lane = lane_id();
+    asm volatile("" : "+v"(lane));
+    return lane;
 }
 
 // ---- per-wave LDS ------------------------------------------------------------------------------------------------------------------
@@ -89,6 +97,7 @@ __device__ __forceinline__ RowLanes row_lanes() {
 //       and takes the tail of the per-point array below when 2S - 1 points are padded to whole rounds of 16
 //   dcache [N][64]     soft-min terms of the current round (label sums; the last round's serve the label mix)
 //   4 x [ N x (a, b, radius, lambda) | 4 pad ]  culling coefficients of (ray, instance) (field.h: RayCull) + the ray's label adjoints
+//   4 x [ ox oy oz rx | ry rz reach pad ]       the rays themselves: re-read where they are needed instead of living in 9 registers
 // After importance_merge the coarse | fine part of a row holds, per pass-2 point, first the transmittance (forward sweep -> reverse
 // sweep) and then the interval mid-point (reverse sweep -> per-instance phase).
 __host__ __device__ constexpr int quad_row_floats(int num_samples) { return 4 * num_samples + kRowLanes; }
@@ -99,7 +108,7 @@ __host__ __device__ constexpr int quad_cache_rows(int num_samples, int num_insta
     return num_instances > 4 * quad_rounds_s(num_samples) ? num_instances : 4 * quad_rounds_s(num_samples);
 }
 __host__ __device__ constexpr int quad_lds_floats(int num_samples, int num_instances) {
-    return kQuadRays * quad_row_floats(num_samples) + quad_cache_rows(num_samples, num_instances) * kWave + kQuadRays * quad_coef_floats(num_instances);
+    return kQuadRays * quad_row_floats(num_samples) + quad_cache_rows(num_samples, num_instances) * kWave + kQuadRays * quad_coef_floats(num_instances) + kQuadRays * 8;
 }
 
 // Stratified distances and sorted fine uniforms of the lane's ray (render_kernels.h: stage_ray_samples, per 16-lane row).
@@ -229,8 +238,27 @@ __device__ __forceinline__ void quad_importance_merge(float* rowbase, int S, con
     wave_lds_sync();
 }
 
-// Culling coefficients of (lane's ray, instance col, col + 16, ...) (field.h: cull_ray_setup, per row).
-__device__ __forceinline__ RayCull quad_cull_setup(const float* __restrict__ instances, int N, const Ray& r, float* coef, const RowLanes& rl) {
+// The lane's ray as the wave keeps it in LDS (8 floats per row): origin, direction, and the scale of the culling error bound.
+struct RowRay { Ray ray; float reach; };
+__device__ __forceinline__ RowRay load_row_ray(const float* rp) {
+    const float4 a = *reinterpret_cast<const float4*>(rp), b = *reinterpret_cast<const float4*>(rp + 4);
+    RowRay r;
+    r.ray.ox = a.x; r.ray.oy = a.y; r.ray.oz = a.z; r.ray.rx = a.w; r.ray.ry = b.x; r.ray.rz = b.y; r.reach = b.z;
+    return r;
+}
+__device__ __forceinline__ RayCull row_cull(const float* coef, const RowRay& r) {
+    RayCull rc;
+    rc.coef = coef;
+    rc.c2 = r.ray.rx * r.ray.rx + r.ray.ry * r.ray.ry + r.ray.rz * r.ray.rz;
+    rc.rnorm = fast_sqrt(rc.c2);
+    rc.reach = r.reach;
+    return rc;
+}
+// (a compiler-only fence: LDS values re-read after it are loaded again instead of being kept in registers across a loop)
+__device__ __forceinline__ void reload_fence() { asm volatile("" ::: "memory"); }
+
+// Culling coefficients of (lane's ray, instance col, col + 16, ...) (field.h: cull_ray_setup, per row) and the ray itself, into LDS.
+__device__ __forceinline__ void quad_ray_setup(const float* __restrict__ instances, int N, const Ray& r, float* coef, float* rayp, const RowLanes& rl) {
     float amax = 0.0f;
     for (int i = rl.col; i < N; i += kRowLanes) {
         const float* p = instances + i * kInstanceStride;
@@ -242,13 +270,12 @@ __device__ __forceinline__ RayCull quad_cull_setup(const float* __restrict__ ins
         coef[kCullCoefs * i + 3] = 0.0f;                                        // the ray's label adjoint of instance i, set after pass 2
         amax = fmaxf(amax, a);
     }
-    RayCull rc;
-    rc.coef = coef;
-    rc.c2 = r.rx * r.rx + r.ry * r.ry + r.rz * r.rz;
-    rc.rnorm = fast_sqrt(rc.c2);
-    rc.reach = fast_sqrt(fmaxf(row_max(amax), r.ox * r.ox + r.oy * r.oy + r.oz * r.oz));
+    const float reach = fast_sqrt(fmaxf(row_max(amax), r.ox * r.ox + r.oy * r.oy + r.oz * r.oz));
+    if (rl.col == 0) {
+        *reinterpret_cast<float4*>(rayp) = make_float4(r.ox, r.oy, r.oz, r.rx);
+        *reinterpret_cast<float4*>(rayp + 4) = make_float4(r.ry, r.rz, reach, 0.0f);
+    }
     wave_lds_sync();
-    return rc;
 }
 
 // The culling pre-pass of one round (field.h: cull_round_mask) in two steps, so that a round can leave between them.
@@ -335,10 +362,10 @@ __device__ __forceinline__ QuadPoint quad_point(const float* dist, int num_point
 }
 
 // Pass 1 of the four rays: coarse compositing weights w[k] of point k * 16 + col (render.h: render_pass without labels).
-// Returns false when the fixed soft-min shift cannot serve some round (field.h: union_accumulate): the caller repeats the pass with
+// Returns false when the fixed soft-min shift cannot serve some round (field.h: union_accumulate): the caller repeats the group with
 // the running minimum.
 template <int kRoundsS, bool kYaw, bool kRunning>
-__device__ __forceinline__ bool quad_pass_one(const float* __restrict__ instances, int N, const Shading& sh, const Ray& ray, const RayCull& rc,
+__device__ __forceinline__ bool quad_pass_one(const float* __restrict__ instances, int N, const Shading& sh, const float* rayp, const float* coef,
                                               const float* coarse, int S, float (&w)[kRoundsS], const RowLanes& rl) {
     const int num_points = S - 1;
     float carry = 1.0f;
@@ -346,7 +373,9 @@ __device__ __forceinline__ bool quad_pass_one(const float* __restrict__ instance
     for (int k = 0; k < kRoundsS; ++k) {
         w[k] = 0.0f;
         if (k * kRowLanes >= num_points) continue;
-        const QuadPoint p = quad_point(coarse, num_points, k, ray, true, rl);
+        const RowRay rr = load_row_ray(rayp);
+        const RayCull rc = row_cull(coef, rr);
+        const QuadPoint p = quad_point(coarse, num_points, k, rr.ray, true, rl);
         const RoundCull cull = quad_round_bounds(rc, N, p.mid, sh.cull);
         if (quad_round_is_empty(rc, cull, sh, p.delta)) continue;                // alpha = 0 exactly: the transmittance passes unchanged
         unsigned long long evaluated = quad_round_mask(rc, cull, N, p.mid);
@@ -355,7 +384,7 @@ __device__ __forceinline__ bool quad_pass_one(const float* __restrict__ instance
         const UnionSums sums = quad_union_loop<false, kRunning, kYaw>(instances, evaluated, sh, cull, floor, p.x, p.y, p.z, nullptr, rl.lane);
         if (!kRunning && wave_any(!(sums.Z >= kUnionTinyZ))) return false;
         const UnionValue v = union_finish(sums, sh.inv_t);
-        const Opacity op = opacity_of(v, ray, p.delta, sh);
+        const Opacity op = opacity_of(v, rr.ray, p.delta, sh);
         const float alpha = p.valid ? op.alpha : 0.0f;
         const float inclusive = row_inclusive_product(1.0f - alpha);
         w[k] = carry * row_shift_up(inclusive, 1.0f) * alpha;
@@ -365,16 +394,18 @@ __device__ __forceinline__ bool quad_pass_one(const float* __restrict__ instance
 }
 
 // Per-sample state of the adjoint, one pass-2 point per lane and round, in registers:
-//   after the forward sweep:  m, inv_z (soft-min shift, 1/Z), s = u - m, a = grad u, c = r . b, d = (grad u) . b  with b = sum_i w_i grad d_i
+//   after the forward sweep:  m, inv_z (soft-min shift, 1/Z), s = u - m, a = grad u, c = B' with B = g_bar . b = cos_bar B'
+//                             (b = sum_i w_i grad d_i;  g_bar = cos_bar / |g| (r - n (n . r)), n = grad u / |g|, so
+//                              B' = (r . b - (grad u . b) (n . r) / |g|) / |g|)
 //   after the reverse sweep:  m, inv_z, s = 1 + (u - m) / T, a = g_bar, c = C2; C1 and C3 wait in the wave's LDS (the distance cache
-//   is free by then: two lane-private floats per round), d is dead.  With them (render_kernels.h: adjoint_phase_b)
+//   is free by then: two lane-private floats per round).  With them (render_kernels.h: adjoint_phase_b)
 //     d_bar_i = cc_i (C1 - beta_i / T) + w_i (C2 - beta_i / T - C3 lambda_i),   cc_i = w_i (s - (d_i - m) / T)
-//     C1 = u_bar + B / T,  C2 = (A + w_s Lambda_s / Z_s) / T,  C3 = w_s / T,   A = g_bar . grad u,  B = g_bar . b
+//     C1 = u_bar + B / T,  C2 = (A + w_s Lambda_s / Z_s) / T,  C3 = w_s / T,   A = g_bar . grad u
 template <int kRounds>
 struct QuadAdjoint {
     float m[kRounds], inv_z[kRounds], s[kRounds];
     float ax[kRounds], ay[kRounds], az[kRounds];
-    float c[kRounds], d[kRounds];
+    float c[kRounds];
     unsigned long long near[kRounds];            // instances evaluated in the round (wave-uniform)
 };
 
@@ -383,7 +414,7 @@ struct QuadAdjoint {
 // the running minimum.
 template <int kRounds, bool kYaw, bool kRunning>
 __device__ __forceinline__ bool quad_forward_sweep(QuadAdjoint<kRounds>& st, const float* __restrict__ instances, int N, const Shading& sh,
-                                                   const Ray& ray, const RayCull& rc, const float* merged, int num_points, bool live,
+                                                   const float* rayp, const float* coef, const float* merged, int num_points, bool live,
                                                    float* dcache, float* trans, float& label, unsigned& active, int& cached_round, const RowLanes& rl) {
     float carry = 1.0f;
     label = 0.0f;
@@ -393,28 +424,43 @@ __device__ __forceinline__ bool quad_forward_sweep(QuadAdjoint<kRounds>& st, con
     for (int q = 0; q < kRounds; ++q) {
         st.near[q] = 0ull;
         if (q * kRowLanes >= num_points) continue;
-        const QuadPoint p = quad_point(merged, num_points, q, ray, live, rl);
-        const RoundCull cull = quad_round_bounds(rc, N, p.mid, sh.cull);
-        if (quad_round_is_empty(rc, cull, sh, p.delta)) continue;                // alpha = 0 exactly: no weight, no label, no adjoint
-        st.near[q] = quad_round_mask(rc, cull, N, p.mid);
-        const float floor = cull.nearest_lo - sh.reach;
-        if (!kRunning && wave_any(!((cull.nearest_hi + 1.0f - floor) * sh.inv_t <= kUnionFloorSpan))) return false;
-        const UnionSums sums = quad_union_loop<true, kRunning, kYaw>(instances, st.near[q], sh, cull, floor, p.x, p.y, p.z, dcache, rl.lane);
-        cached_round = q;
-        if (!kRunning && wave_any(!(sums.Z >= kUnionTinyZ))) return false;
-        const UnionValue v = union_finish(sums, sh.inv_t);
-        const Opacity op = opacity_of(v, ray, p.delta, sh);
-        const float alpha = p.valid ? op.alpha : 0.0f;
+        float delta, bprime;
+        UnionValue v;
+        Opacity op;
+        bool valid;
+        {
+            const RowRay rr = load_row_ray(rayp);
+            const RayCull rc = row_cull(coef, rr);
+            const QuadPoint p = quad_point(merged, num_points, q, rr.ray, live, rl);
+            const RoundCull cull = quad_round_bounds(rc, N, p.mid, sh.cull);
+            if (quad_round_is_empty(rc, cull, sh, p.delta)) continue;            // alpha = 0 exactly: no weight, no label, no adjoint
+            st.near[q] = quad_round_mask(rc, cull, N, p.mid);
+            const float floor = cull.nearest_lo - sh.reach;
+            if (!kRunning && wave_any(!((cull.nearest_hi + 1.0f - floor) * sh.inv_t <= kUnionFloorSpan))) return false;
+            const UnionSums sums = quad_union_loop<true, kRunning, kYaw>(instances, st.near[q], sh, cull, floor, p.x, p.y, p.z, dcache, rl.lane);
+            cached_round = q;
+            if (!kRunning && wave_any(!(sums.Z >= kUnionTinyZ))) return false;
+            v = union_finish(sums, sh.inv_t);
+            delta = p.delta; valid = p.valid;
+        }
+        reload_fence();
+        {
+            const RowRay rr = load_row_ray(rayp);                                // (re-read: the ray does not live in registers across the instance loop)
+            op = opacity_of(v, rr.ray, delta, sh);
+            const float rb = rr.ray.rx * v.b0x + rr.ray.ry * v.b0y + rr.ray.rz * v.b0z;
+            const float gb = v.gx * v.b0x + v.gy * v.b0y + v.gz * v.b0z;
+            bprime = (rb - gb * op.inv_gn * op.cosine) * op.inv_gn;
+        }
+        const float alpha = valid ? op.alpha : 0.0f;
         const float inclusive = row_inclusive_product(1.0f - alpha);
         const float t = carry * row_shift_up(inclusive, 1.0f);
         carry *= lane_gather(inclusive, rl.last);
-        trans[q * kRowLanes + rl.col] = t;
         st.m[q] = v.m; st.inv_z[q] = v.inv_z; st.s[q] = v.us;
         st.ax[q] = v.gx; st.ay[q] = v.gy; st.az[q] = v.gz;
-        st.c[q] = ray.rx * v.b0x + ray.ry * v.b0y + ray.rz * v.b0z;
-        st.d[q] = v.gx * v.b0x + v.gy * v.b0y + v.gz * v.b0z;
+        st.c[q] = bprime;
         if (__ballot(alpha > 0.0f) == 0ull) continue;                            // (a round without weight: nothing for the labels, nothing flows back)
         active |= 1u << q;
+        trans[q * kRowLanes + rl.col] = t;
         const float scale = t * alpha * v.inv_z;
         for (unsigned long long todo = st.near[q]; todo != 0ull; todo &= todo - 1ull) {
             const int i = __builtin_ctzll(todo);
@@ -430,10 +476,10 @@ __device__ __forceinline__ bool quad_forward_sweep(QuadAdjoint<kRounds>& st, con
 // Reverse sweep over the rounds of pass 2 (render_kernels.h: adjoint_label_mix + adjoint_reverse_sweep): label-adjoint mix
 // Lambda_s, opacity (recomputed from u, grad u and the interval), suffix sums of w_bar w, chain to (u_bar, g_bar), and the
 // per-sample constants of the per-instance phase.  coef_own: the lane's OWN ray's (a, b, radius, lambda) rows; cached_round:
-// the round whose soft-min terms the distance cache still holds (fixed shift; -1: none).  On return cbuf (= the distance cache) holds C1 and
-// C3 of every point, trans_mid the interval mid-points.  Returns the rounds (bit q) in which some lane carries a non-zero adjoint.
+// the round whose soft-min terms the distance cache still holds (fixed shift; -1: none).  On return cbuf (= the distance cache) holds
+// C1 and C3 of every point, trans_mid the interval mid-points.  Returns the rounds (bit q) in which some lane carries a non-zero adjoint.
 template <int kRounds, bool kYaw>
-__device__ __forceinline__ unsigned quad_reverse_sweep(QuadAdjoint<kRounds>& st, const float* __restrict__ instances, const Shading& sh, const Ray& ray,
+__device__ __forceinline__ unsigned quad_reverse_sweep(QuadAdjoint<kRounds>& st, const float* __restrict__ instances, const Shading& sh, const float* rayp,
                                                        const float* merged, int num_points, bool live, unsigned active, unsigned long long lam_any, int cached_round,
                                                        const float* coef_own, float* cbuf, float* trans_mid, const RowLanes& rl) {
     unsigned flow = 0u;
@@ -441,7 +487,8 @@ __device__ __forceinline__ unsigned quad_reverse_sweep(QuadAdjoint<kRounds>& st,
 #pragma unroll
     for (int q = kRounds - 1; q >= 0; --q) {
         if (!((active >> q) & 1u)) continue;                                       // no weight in the round: nothing flows back (exact)
-        const QuadPoint p = quad_point(merged, num_points, q, ray, live, rl);
+        const RowRay rr = load_row_ray(rayp);
+        const QuadPoint p = quad_point(merged, num_points, q, rr.ray, live, rl);
         // Lambda_s / Z_s = sum_n lambda_n w_{s,n} over the instances the forward sweep evaluated (culled ones: weight < exp(-18))
         float acc = 0.0f;
         if (q == cached_round) {                                                   // wave-uniform: the soft-min terms are still in the distance cache
@@ -459,7 +506,7 @@ __device__ __forceinline__ unsigned quad_reverse_sweep(QuadAdjoint<kRounds>& st,
         const float lam_z = p.valid ? acc * st.inv_z[q] : 0.0f;
         UnionValue v;
         v.u = st.m[q] + st.s[q]; v.gx = st.ax[q]; v.gy = st.ay[q]; v.gz = st.az[q];
-        const Opacity op = opacity_of(v, ray, p.delta, sh);
+        const Opacity op = opacity_of(v, rr.ray, p.delta, sh);
         const float alpha = p.valid ? op.alpha : 0.0f;
         const float t = trans_mid[q * kRowLanes + rl.col];
         trans_mid[q * kRowLanes + rl.col] = p.mid;                                 // (same lane, same slot: no hazard)
@@ -479,11 +526,10 @@ __device__ __forceinline__ unsigned quad_reverse_sweep(QuadAdjoint<kRounds>& st,
         const float cprime_bar = (sn_bar - sp_bar) * p.delta / 2.0f;
         const float slope = (1.0f - sh.ratio) * ((0.5f - 0.5f * op.cosine > 0.0f) ? 0.5f : 0.0f) + sh.ratio * ((-op.cosine > 0.0f) ? 1.0f : 0.0f);
         const float cos_bar = cprime_bar * slope;
-        const float nbx = cos_bar * ray.rx, nby = cos_bar * ray.ry, nbz = cos_bar * ray.rz;
+        const float nbx = cos_bar * rr.ray.rx, nby = cos_bar * rr.ray.ry, nbz = cos_bar * rr.ray.rz;
         const float n_dot = op.nx * nbx + op.ny * nby + op.nz * nbz;
         const float gbx = (nbx - op.nx * n_dot) * op.inv_gn, gby = (nby - op.ny * n_dot) * op.inv_gn, gbz = (nbz - op.nz * n_dot) * op.inv_gn;
-        // B = g_bar . b from r . b and (grad u) . b:  g_bar = cos_bar / |g| (r - n (n . r)),  n = grad u / |g|
-        const float B = cos_bar * op.inv_gn * (st.c[q] - st.d[q] * op.inv_gn * op.cosine);
+        const float B = cos_bar * st.c[q];
         const float A = gbx * st.ax[q] + gby * st.ay[q] + gbz * st.az[q];
         st.ax[q] = gbx; st.ay[q] = gby; st.az[q] = gbz;
         st.s[q] = 1.0f + st.s[q] * sh.inv_t;
@@ -497,11 +543,13 @@ __device__ __forceinline__ unsigned quad_reverse_sweep(QuadAdjoint<kRounds>& st,
 }
 
 // Per-instance phase for the four rays (render_kernels.h: adjoint_phase_b): instance-outer, rounds inner, one reduce-scatter butterfly
-// per (wave, instance).  G[s]: lane (row r, col c) accumulates parameter c of instance 4 s + r.
+// per (wave, instance), added to the wave's row of the partial-gradient table with fire-and-forget atomics (the row belongs to this
+// wave alone and a wave's atomics on one address keep program order: the sums stay deterministic).
 template <int kRounds, bool kYaw>
-__device__ __forceinline__ void quad_phase_b(const QuadAdjoint<kRounds>& st, const float* __restrict__ instances, const Shading& sh, const Ray& ray,
-                                             unsigned flow, const float* coef_own, const float* cbuf, const float* mids, float (&G)[4], const RowLanes& rl) {
+__device__ __forceinline__ void quad_phase_b(const QuadAdjoint<kRounds>& st, const float* __restrict__ instances, const Shading& sh, const float* rayp,
+                                             unsigned flow, const float* coef_own, const float* cbuf, const float* mids, float* __restrict__ out, const RowLanes& rl) {
     const float inv_t = sh.inv_t;
+    const Ray ray = load_row_ray(rayp).ray;
     unsigned long long todo = 0ull;
 #pragma unroll
     for (int q = 0; q < kRounds; ++q) todo |= ((flow >> q) & 1u) ? st.near[q] : 0ull;
@@ -551,9 +599,7 @@ __device__ __forceinline__ void quad_phase_b(const QuadAdjoint<kRounds>& st, con
         }
         const float packed[16] = {at0, at1, at2, r00, r01, r02, r10, r11, r12, r20, r21, r22, ad0, ad1, ad2, 0.0f};
         const float mine = wave_reduce16_scatter(packed, rl.lane);            // every lane: the wave's sum of parameter (lane & 15)
-        const float add = (rl.row == (i & 3)) ? mine : 0.0f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) G[s] += ((i >> 2) == s) ? add : 0.0f;
+        if (rl.lane < kGradStride) __hip_atomic_fetch_add(out + i * kGradStride + rl.lane, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -568,14 +614,15 @@ __device__ __forceinline__ void quad_phase_b(const QuadAdjoint<kRounds>& st, con
 // Everything one wave does for one group of four rays: sampling, pass 1, pass 2, silhouette BCE (main.py:653-671; torch clamp /
 // binary_cross_entropy backward), label adjoints, reverse sweep, per-instance phase.  One soft-min mode per instantiation (kRunning:
 // the running minimum; else the shift known before the instance loop, field.h); returns false -- before any side effect other than
-// LDS staging -- when the fixed shift cannot serve some round of the group (samples extrapolated to 1e6 m): the caller then runs
-// the group again with kRunning.  The three instantiations share no state, so none of it crosses a control-flow merge.
+// LDS staging -- when the fixed shift cannot serve some round of the group: the caller then runs the group again with kRunning.
+// The three instantiations share no state, so none of it crosses a control-flow merge.
 template <int kRoundsS, bool kYaw, bool kRunning>
 __device__ __forceinline__ bool quad_step_body(const float* __restrict__ instances, int N, const RenderArgs& c, const Shading& sh, int first_ray,
                                                const float* __restrict__ origins, const float* __restrict__ directions,
                                                const float* __restrict__ u_coarse, const float* __restrict__ u_fine, bool sorted_input,
-                                               const float* __restrict__ targets, float weight_lane, float loss_scale, float* __restrict__ labels_out,
-                                               float* stage, float* dcache, float* coefs, float (&G)[4], float& loss_acc, const RowLanes& rl VSRD_QUAD_CLOCK_PARAM) {
+                                               const float* __restrict__ targets, const float* __restrict__ instance_weights, float loss_scale,
+                                               float* __restrict__ labels_out, float* stage, float* dcache, float* coefs, float* rays,
+                                               float* __restrict__ out, float& loss_acc, const RowLanes& rl VSRD_QUAD_CLOCK_PARAM) {
     constexpr int kRounds = 2 * kRoundsS;
     VSRD_PHASE(7);
     const int S = c.num_samples;
@@ -584,21 +631,21 @@ __device__ __forceinline__ bool quad_step_body(const float* __restrict__ instanc
     const bool alive = my_ray < c.num_rays;
     const int ray = alive ? my_ray : (c.num_rays - 1);                    // rows beyond the launch repeat its last ray and contribute nothing
     const long long src = source_row(c, ray);
-    Ray r;
+    float* rowbase = stage + rl.row * quad_row_floats(S);
+    float* coef_own = coefs + rl.row * quad_coef_floats(N);
     {
         const long long origin_row = (c.ray_indices && c.rays_per_origin > 0) ? src / c.rays_per_origin : src;
         const float* o = origins + origin_row * c.origin_stride;
         const float* d = directions + src * 3;
+        Ray r;
         r.ox = o[0]; r.oy = o[1]; r.oz = o[2]; r.rx = d[0]; r.ry = d[1]; r.rz = d[2];
+        quad_ray_setup(instances, N, r, coef_own, rays + rl.row * 8, rl);
     }
-    float* rowbase = stage + rl.row * quad_row_floats(S);
-    float* coef_own = coefs + rl.row * quad_coef_floats(N);
-    RayCull rc = quad_cull_setup(instances, N, r, coef_own, rl);
     quad_stage_samples<kRoundsS>(rowbase, c, S, ray, u_coarse, u_fine, sorted_input, rl);
     VSRD_PHASE(0);
     // ---- pass 1 ----------------------------------------------------------------------------------------------------------------
     float w1[kRoundsS];
-    if (!quad_pass_one<kRoundsS, kYaw, kRunning>(instances, N, sh, r, rc, rowbase, S, w1, rl)) return false;
+    if (!quad_pass_one<kRoundsS, kYaw, kRunning>(instances, N, sh, rays + rl.row * 8, coef_own, rowbase, S, w1, rl)) return false;
     VSRD_PHASE(1);
     float coarse_total = 0.0f;
 #pragma unroll
@@ -610,21 +657,16 @@ __device__ __forceinline__ bool quad_step_body(const float* __restrict__ instanc
     unsigned active = 0u;
     int cached_round = -1;
     QuadAdjoint<kRounds> st;
-    const float* merged = rowbase + quad_merged_offset(S);
-    float* trans_mid = rowbase;
+    // rows that do not take part shadow the first live row (same points, same votes in the culling ballots, zero weight)
+    const int data_row = live ? rl.row : (live_lanes != 0ull ? (__builtin_ctzll(live_lanes) >> 4) : rl.row);
+    const float* rayp = rays + data_row * 8;
+    const float* merged = stage + data_row * quad_row_floats(S) + quad_merged_offset(S);
+    float* trans_mid = rowbase;                                              // (the row's own: a shadow row's transmittances are all 1)
     if (live_lanes != 0ull) {
         quad_importance_merge<kRoundsS>(rowbase, S, w1, rl);
         VSRD_PHASE(2);
-        // rows that do not take part shadow the first live row (same points, same votes in the culling ballots, zero weight)
-        const int donor = __builtin_ctzll(live_lanes) & 48;
-        if (!live) {
-            r.ox = read_lane(r.ox, donor); r.oy = read_lane(r.oy, donor); r.oz = read_lane(r.oz, donor);
-            r.rx = read_lane(r.rx, donor); r.ry = read_lane(r.ry, donor); r.rz = read_lane(r.rz, donor);
-            rc.c2 = read_lane(rc.c2, donor); rc.rnorm = read_lane(rc.rnorm, donor); rc.reach = read_lane(rc.reach, donor);
-            rc.coef = coefs + (donor >> 4) * quad_coef_floats(N);
-            merged = stage + (donor >> 4) * quad_row_floats(S) + quad_merged_offset(S);       // (trans_mid stays the row's own: its transmittances are all 1)
-        }
-        if (!quad_forward_sweep<kRounds, kYaw, kRunning>(st, instances, N, sh, r, rc, merged, num_points, live, dcache, trans_mid, label, active, cached_round, rl)) return false;
+        if (!quad_forward_sweep<kRounds, kYaw, kRunning>(st, instances, N, sh, rayp, coefs + data_row * quad_coef_floats(N), merged, num_points, live, dcache,
+                                                         trans_mid, label, active, cached_round, rl)) return false;
         if (!live) label = 0.0f;
         VSRD_PHASE(3);
     }
@@ -632,27 +674,31 @@ __device__ __forceinline__ bool quad_step_body(const float* __restrict__ instanc
     const bool mine = alive && rl.col < N;
     if (labels_out != nullptr && mine) labels_out[static_cast<size_t>(my_ray) * N + rl.col] = label;
     const float target = mine ? load_target(c, targets, src, rl.col, N) : 0.0f;
+    const float weight_lane = mine ? (instance_weights ? instance_weights[rl.col] : 1.0f) : 0.0f;
     const float p = fminf(fmaxf(label, 1.0e-6f), 1.0f - 1.0e-6f);
     const float bce = -(target * logf(p) + (1.0f - target) * logf(1.0f - p));
-    loss_acc += mine ? weight_lane * bce : 0.0f;
+    loss_acc += weight_lane * bce;
     const bool inside_clamp = (label >= 1.0e-6f) && (label <= 1.0f - 1.0e-6f);
-    const float lam_lane = (mine && live && inside_clamp) ? weight_lane * loss_scale * (p - target) / fmaxf(p * (1.0f - p), 1.0e-12f) : 0.0f;
+    const float lam_lane = (live && inside_clamp) ? weight_lane * loss_scale * (p - target) / fmaxf(p * (1.0f - p), 1.0e-12f) : 0.0f;
     unsigned long long lam_any = __ballot(lam_lane != 0.0f);                 // bit n: some ray has a label adjoint for instance n
     lam_any |= lam_any >> 32; lam_any |= lam_any >> 16; lam_any &= 0xFFFFull;
-    if (live_lanes == 0ull || lam_any == 0ull) return true;
+    if (active == 0u || lam_any == 0ull) return true;
     if (rl.col < N) coef_own[kCullCoefs * rl.col + 3] = lam_lane;
     wave_lds_sync();
     // ---- adjoint -------------------------------------------------------------------------------------------------------------------
-    if (active == 0u) return true;
-    const unsigned flow = quad_reverse_sweep<kRounds, kYaw>(st, instances, sh, r, merged, num_points, live, active, lam_any, kRunning ? -1 : cached_round, coef_own, dcache, trans_mid, rl);
+    const unsigned flow = quad_reverse_sweep<kRounds, kYaw>(st, instances, sh, rayp, merged, num_points, live, active, lam_any, kRunning ? -1 : cached_round,
+                                                            coef_own, dcache, trans_mid, rl);
     VSRD_PHASE(4);
-    if (flow != 0u) quad_phase_b<kRounds, kYaw>(st, instances, sh, r, flow, coef_own, dcache, trans_mid, G, rl);
+    if (flow != 0u) quad_phase_b<kRounds, kYaw>(st, instances, sh, rayp, flow, coef_own, dcache, trans_mid, out, rl);
     VSRD_PHASE(5);
     return true;
 }
 
+#ifndef VSRD_QUAD_WAVES_PER_EU
+#define VSRD_QUAD_WAVES_PER_EU 4
+#endif
 template <int kRoundsS>
-__global__ __launch_bounds__(kBlockThreads, 4) void render_silhouette_quad_kernel(
+__global__ __launch_bounds__(kBlockThreads, VSRD_QUAD_WAVES_PER_EU) void render_silhouette_quad_kernel(
     FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
     const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
     const float* __restrict__ targets, const float* __restrict__ instance_weights, float loss_scale,
@@ -660,47 +706,52 @@ __global__ __launch_bounds__(kBlockThreads, 4) void render_silhouette_quad_kerne
     apply_device_schedule(f, c);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = wave_in_block();
-    const RowLanes rl = row_lanes();
+    const int lane0 = lane_id();
     const int S = c.num_samples;
     const int N = f.num_instances;
     float* stage = lds + wave * quad_lds_floats(S, N);
     float* dcache = stage + kQuadRays * quad_row_floats(S);
     float* coefs = dcache + quad_cache_rows(S, N) * kWave;
+    float* rays = coefs + kQuadRays * quad_coef_floats(N);
     const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
     Shading sh = c.sh;
     const FieldBounds bounds = field_bounds(instances, N, f.inv_t, false, c.flags);
     sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
     sh.mlp_bits = 0u;
     sh.mlp_lds = nullptr;
-    const float weight_lane = (rl.col < N) ? (instance_weights ? instance_weights[rl.col] : 1.0f) : 0.0f;
     float loss_acc = 0.0f;
-    float G[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const int num_waves = static_cast<int>(gridDim.x) * waves_per_block();
     const int wave_global = static_cast<int>(blockIdx.x) * waves_per_block() + wave;
     const int num_quads = (c.num_rays + kQuadRays - 1) / kQuadRays;
+    // the wave's row of the partial-gradient table: cleared here, accumulated by quad_phase_b, summed over the waves by reduce_partials_kernel
+    float* out = partials + static_cast<size_t>(wave_global) * (N * kGradStride);
+    for (int idx = lane0; idx < N * kGradStride; idx += kWave) out[idx] = 0.0f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     VSRD_PHASE_CLOCK();
     for (int quad = wave_global; quad < num_quads; quad += num_waves) {
         const int first_ray = quad * kQuadRays;
+        const RowLanes rl = row_lanes(opaque_lane_id());
         wave_lds_sync();
         bool done = false;
+#ifdef VSRD_QUAD_EXPERIMENT_YAW_ONLY       // register-pressure experiments: one body only
+        done = quad_step_body<kRoundsS, true, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
+                                                     instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, out, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
+        continue;
+#endif
         if (sh.reach >= 0.0f) {
             done = sh.yaw ? quad_step_body<kRoundsS, true, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
-                                                                  weight_lane, loss_scale, labels_out, stage, dcache, coefs, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG)
+                                                                  instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, out, loss_acc, rl VSRD_QUAD_CLOCK_ARG)
                           : quad_step_body<kRoundsS, false, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
-                                                                   weight_lane, loss_scale, labels_out, stage, dcache, coefs, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
+                                                                   instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, out, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
             if (!done) wave_lds_sync();
         }
         if (!done) quad_step_body<kRoundsS, false, true>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
-                                                         weight_lane, loss_scale, labels_out, stage, dcache, coefs, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
+                                                         instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, out, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
     }
     VSRD_PHASE(7);
-    VSRD_PHASE_FLUSH(rl.lane);
-    float* out = partials + static_cast<size_t>(wave_global) * (N * kGradStride);
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-        if (s * kWave + rl.lane < N * kGradStride) out[s * kWave + rl.lane] = G[s];
+    VSRD_PHASE_FLUSH(lane0);
     const float loss_total = wave_sum(loss_acc);
-    if (rl.lane == 0) loss_partials[wave_global] = loss_total * loss_scale;
+    if (lane0 == 0) loss_partials[wave_global] = loss_total * loss_scale;
 }
 
 }  // namespace vsrd
