@@ -180,6 +180,23 @@ __device__ __forceinline__ void quad_stage_samples(float* rowbase, const RenderA
     }
 }
 
+// Number of elements of the sorted LDS array a[0..n), n <= 64, that are < v (kStrict) or <= v: the same count as render.h's
+// count_below, by binary lifting (strides 32 ... 1, then the one element a stride-1 step can leave open): four vector instructions
+// and one LDS read per step where the lo / hi interval form takes ten.  Probes beyond n read the largest element a[n - 1]: if that
+// one is below, all n are, and the final clamp returns n.
+template <bool kStrict>
+__device__ __forceinline__ int count_below_64(const float* a, int n, float v) {
+    int pos = 0;
+#pragma unroll
+    for (int stride = 32; stride >= 1; stride >>= 1) {
+        const float probe = a[min(pos + stride - 1, n - 1)];
+        pos += (kStrict ? (probe < v) : (probe <= v)) ? stride : 0;
+    }
+    const float probe = a[min(pos, n - 1)];
+    pos += (kStrict ? (probe < v) : (probe <= v)) ? 1 : 0;
+    return min(pos, n);
+}
+
 // samplers.py:11-36 + renderers.py:198-210 for the lane's ray (render.h: importance_merge, per row): w[k] = coarse weight of point
 // k * 16 + col (0 beyond S - 2); on return merged[0..2S) is the sorted union of the coarse and the fine distances.
 template <int kRoundsS>
@@ -203,7 +220,6 @@ __device__ __forceinline__ void quad_importance_merge(float* rowbase, int S, con
     }
     if (rl.col == 0) cdf[0] = 0.0f;
     wave_lds_sync();
-    const int iters = search_iterations(S);
     float fine_max = -3.0e38f;
 #pragma unroll
     for (int k = 0; k < kRoundsS; ++k) {
@@ -211,7 +227,7 @@ __device__ __forceinline__ void quad_importance_merge(float* rowbase, int S, con
         const int j = k * kRowLanes + rl.col;
         const bool valid = j < S;
         const float u = fine[valid ? j : (S - 1)];
-        int upper = count_below<true>(cdf, S, u, iters);
+        int upper = count_below_64<true>(cdf, S, u);
         upper = min(max(upper, 1), S - 1);
         const float c_lo = cdf[upper - 1], c_hi = cdf[upper];
         const float b_lo = coarse[upper - 1], b_hi = coarse[upper];
@@ -231,8 +247,8 @@ __device__ __forceinline__ void quad_importance_merge(float* rowbase, int S, con
         const bool valid = j < S;
         const int jj = valid ? j : (S - 1);
         const float a = coarse[jj], b = fine[jj];
-        const int rank_a = jj + count_below<true>(fine, S, a, iters);
-        const int rank_b = jj + count_below<false>(coarse, S, b, iters);
+        const int rank_a = jj + count_below_64<true>(fine, S, a);
+        const int rank_b = jj + count_below_64<false>(coarse, S, b);
         if (valid) { merged[rank_a] = a; merged[rank_b] = b; }
     }
     wave_lds_sync();
@@ -599,7 +615,9 @@ __device__ __forceinline__ void quad_phase_b(const QuadAdjoint<kRounds>& st, con
         }
         const float packed[16] = {at0, at1, at2, r00, r01, r02, r10, r11, r12, r20, r21, r22, ad0, ad1, ad2, 0.0f};
         const float mine = wave_reduce16_scatter(packed, rl.lane);            // every lane: the wave's sum of parameter (lane & 15)
-        if (rl.lane < kGradStride) __hip_atomic_fetch_add(out + i * kGradStride + rl.lane, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (wavefront scope: no other wave touches the row before the kernel ends, so the add need not leave this XCD's L2 -- at agent
+        //  scope every one of them went out to the fabric: 8 GB of writes per launch)
+        if (rl.lane < kGradStride) __hip_atomic_fetch_add(out + i * kGradStride + rl.lane, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
 }
 
@@ -726,7 +744,7 @@ __global__ __launch_bounds__(kBlockThreads, VSRD_QUAD_WAVES_PER_EU) void render_
     // the wave's row of the partial-gradient table: cleared here, accumulated by quad_phase_b, summed over the waves by reduce_partials_kernel
     float* out = partials + static_cast<size_t>(wave_global) * (N * kGradStride);
     for (int idx = lane0; idx < N * kGradStride; idx += kWave) out[idx] = 0.0f;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // the cleared row is in place before the first add to it
     VSRD_PHASE_CLOCK();
     for (int quad = wave_global; quad < num_quads; quad += num_waves) {
         const int first_ray = quad * kQuadRays;

@@ -180,22 +180,22 @@ __device__ __forceinline__ float render_pass(const float* __restrict__ instances
     return label_acc;
 }
 
-// Number of elements of the sorted LDS array a[0..n) that are  < v  (kStrict) or <= v.
+// Number of elements of the sorted LDS array a[0..n), n >= 1, that are  < v  (kStrict) or <= v, by binary lifting: the count is
+// built from its highest bit down (`top` = the largest power of two <= n, wave-uniform), four vector instructions and one LDS read per
+// step (the lo / hi interval form took ten).  Probes beyond n read the largest element a[n - 1]: if that one is below, all n are, and
+// the final clamp returns n; otherwise they answer "not below", as elements beyond the end would.
 template <bool kStrict>
-__device__ __forceinline__ int count_below(const float* a, int n, float v, int iterations) {
-    int lo = 0, hi = n;
-    for (int it = 0; it < iterations; ++it) {
-        const bool open = lo < hi;
-        const int mid = (lo + hi) >> 1;
-        const float probe = a[open ? mid : 0];
-        const bool below = kStrict ? (probe < v) : (probe <= v);
-        lo = (open && below) ? (mid + 1) : lo;
-        hi = (open && !below) ? mid : hi;
+__device__ __forceinline__ int count_below(const float* a, int n, float v, int top) {
+    int pos = 0;
+    for (int stride = top; stride >= 1; stride >>= 1) {
+        const float probe = a[min(pos + stride - 1, n - 1)];
+        pos += (kStrict ? (probe < v) : (probe <= v)) ? stride : 0;
     }
-    return lo;
+    return min(pos, n);
 }
 
-__device__ __forceinline__ int search_iterations(int n) { return 33 - __builtin_clz(static_cast<unsigned>(n)); }
+// `top` of count_below for arrays of n elements.
+__device__ __forceinline__ int search_iterations(int n) { return 1 << (31 - __builtin_clz(static_cast<unsigned>(n))); }
 
 // Per-wave LDS partition, in floats.
 struct WaveLds {
