@@ -59,6 +59,8 @@ def parse_args(argv=None):
     parser.add_argument("--cpu-chunk", type=int, default=0, help="rays per oracle call (default: one image row; 352 with --residual)")
     parser.add_argument("--cpu-threads", type=int, default=16)   # best of {8,16,32,64} on the 2x64-core EPYC 9575F GPU host (r01)
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--no-extra-regimes", action="store_true",
+                        help="default run only: skip the `extra_regimes` object (config 3 / config 5 at full size and the reference's native mode, measured after the headline)")
     parser.add_argument("--launcher-selftest", action="store_true", help="no rendering: exercise the N-rank launch/report path (gloo, CPU)")
     parser.add_argument("--master-port", type=int, default=0)
     return parser.parse_args(argv)
@@ -241,9 +243,14 @@ def cpu_baseline(args, sched, frame, targets_of, hyper_state, cores):
 # committed rocprofv3 summaries (profiles/rNN*/counters.json, written by tools/summarize_profile.py)
 # ---------------------------------------------------------------------------------------------------------------------
 
-def committed_counters(kernel_symbol, key):
-    """Per-launch PMC counters of `kernel_symbol` from the newest committed profile of exactly this workload, or (None, None)."""
+def committed_counters(kernel_symbols, key):
+    """Per-STEP PMC counters summed over the kernels of one step (`kernel_symbols`: substrings of their names) from the newest committed
+    profile of exactly this workload, or (None, None).  A step of the fused box kernel is one launch; a residual step is a front kernel
+    and an MLP-adjoint kernel per chunk of rays plus the row reductions (tools/summarize_profile.py stores, per kernel, the sum over
+    its dispatches divided by the steps of the profiled command as `<counter>_per_step`)."""
     import glob
+    if isinstance(kernel_symbols, str):
+        kernel_symbols = [kernel_symbols]
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "counters.json")), reverse=True):
         try:
             data = json.load(open(path))
@@ -251,9 +258,21 @@ def committed_counters(kernel_symbol, key):
             continue
         if data.get("workload_key") != key:
             continue
+        total, used = {}, []
         for name, entry in data.get("kernels", {}).items():
-            if kernel_symbol in name:
-                return entry, os.path.relpath(path, ROOT)
+            if not any(symbol in name for symbol in kernel_symbols):
+                continue
+            used.append(name)
+            for counter, value in entry.items():
+                if counter.endswith("_per_step"):
+                    total[counter[:-len("_per_step")]] = total.get(counter[:-len("_per_step")], 0.0) + value
+            if not any(c.endswith("_per_step") for c in entry):          # profiles written before round 3: one launch per step
+                for counter, value in entry.items():
+                    if isinstance(value, float) and counter != "rocprof_avg_ms":
+                        total[counter] = total.get(counter, 0.0) + value
+        if used:
+            total["kernels"] = used
+            return total, os.path.relpath(path, ROOT)
     return None, None
 
 
@@ -438,35 +457,55 @@ def run_rank(args):
             if world == 1 and not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(args, sched, frame, lambda a, b: targets[a:b].cpu(), hyper_state,
                                                       min(args.cpu_threads, os.cpu_count() or 1))
+            default_workload = (V, H, W, N, S) == (9, 376, 1408, 16, 64) and not args.residual and fused and args.schedule == "mid" \
+                and not args.no_culling and not args.no_skip_misses
+            if world == 1 and default_workload and not args.no_extra_regimes:
+                del targets, directions, origins
+                torch.cuda.empty_cache()
+                result["extra_regimes"] = extra_regimes()
         print(json.dumps(result), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def step_kernel_symbols(args, fused):
+    """(C-ABI entry that dominates a step, names of the kernels it launches) -- what `roofline` is about."""
+    N, S = args.instances, args.samples
+    if not fused:
+        return None, None
+    if args.residual:
+        return "vsrd_render_residual_step", ["residual_step_front_kernel", "residual_step_pair_kernel", "residual_mlp_adjoint_kernel",
+                                             "render_residual_step_kernel", "reduce_item_rows_kernel", "reduce_item_segments_kernel"]
+    from vsrd_amd.rendering import renderers
+    quad = S <= 64 and N <= 16 and not renderers.STEP_WAVE_PER_RAY       # api.hip: vsrd_render_silhouette_step
+    return "vsrd_render_silhouette_step", ["render_silhouette_quad_kernel" if quad else "render_silhouette_kernel<"]
+
+
 def rooflines(args, kernels, R, fused):
-    """`roofline` (the mandated object, for the dominant kernel) and `roofline_valu` (the bound that actually applies to the fused
-    box kernel), both from launch durations measured live with HIP events on the launch stream (vsrd_amd/profiling.py).
+    """`roofline` (the mandated object, for the dominant kernel(s) of a step) and `roofline_valu`, from launch durations measured live
+    with HIP events on the launch stream (vsrd_amd/profiling.py) and the committed PMC counters of exactly this workload.
 
     Algorithmic bytes per ray: fused step = direction 12 + targets 4N (labels, label adjoints and the
     sorted distances never leave the chip); two-launch path = 12 + 4N per launch.
-    Algorithmic flops per ray: box-only F = 3.5 (3S-2)(63N+45); residual fields add (3S-2) N 2*1617*9 -- both count
-    every instance at every sample, i.e. work the kernels cull, so the hardware view (`executed`, from the committed PMC counters
-    of this exact workload and the live duration) is reported next to them."""
+    `frac` is only ever a measured quantity over a hardware peak: bytes / s over the HBM peak, or EXECUTED flops (PMC wave-instruction
+    counts x 64 lanes; MFMA 16x16x4 = 2048 flop) / s over the 157.3 TFLOP/s fp32 peak.  The SURVEY §8d flop model --
+    3.5 (3S-2)(63N+45) per ray, + (3S-2) N 2*1617*9 for residual fields -- counts every instance at every sample, i.e. work the kernels
+    cull: it is reported as `work_equivalent_tflops` (it can exceed the peak; it is a speed-up over a kernel that culls nothing, not a
+    utilisation)."""
     N, S = args.instances, args.samples
     if fused:
-        entry = "vsrd_render_residual_step" if args.residual else "vsrd_render_silhouette_step"
-        fwd_n, fwd_ms = kernels[entry]
+        dominant, symbols = step_kernel_symbols(args, fused)
+        fwd_n, fwd_ms = kernels[dominant]
         bwd_n, bwd_ms = 0, 0.0
-        dominant, dom_ms = entry, fwd_ms
-        symbol = "render_residual_step_kernel" if args.residual else "render_silhouette_kernel"
+        dom_ms = fwd_ms
     else:
         fwd_n, fwd_ms = kernels["vsrd_render_hierarchical_forward"]
         bwd_n, bwd_ms = kernels["vsrd_render_backward"]
-        dominant, dom_ms, symbol = ("vsrd_render_backward", bwd_ms, "render_backward_kernel") if bwd_ms >= fwd_ms else \
-                                   ("vsrd_render_hierarchical_forward", fwd_ms, "render_hierarchical_kernel")
+        dominant, dom_ms, symbols = ("vsrd_render_backward", bwd_ms, ["render_backward_kernel"]) if bwd_ms >= fwd_ms else \
+                                    ("vsrd_render_hierarchical_forward", fwd_ms, ["render_hierarchical_kernel"])
     dom_bytes = 12 + 4 * N
-    counters, source = committed_counters(symbol, workload_key(args))
+    counters, source = committed_counters(symbols, workload_key(args))
     traffic = None
     if counters and "FETCH_SIZE_bytes" in counters and "WRITE_SIZE_bytes" in counters:
         traffic = counters["FETCH_SIZE_bytes"] + counters["WRITE_SIZE_bytes"]
@@ -475,30 +514,65 @@ def rooflines(args, kernels, R, fused):
     mlp_flop = (3 * S - 2) * N * 2 * 1617 * 9 if args.residual else 0.0
     total_ms = fwd_ms + bwd_ms
     achieved_gbs = R * dom_bytes / (dom_ms * 1e-3) / 1e9
-    hbm = {"bound": "hbm", "kernel": dominant, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-           "traffic": traffic, "traffic_source": source, "algorithmic_bytes_per_ray": dom_bytes, "launch_ms": dom_ms,
-           "note": "the fused path is compute bound (arithmetic intensity ~1e4 flop/B), not HBM bound (SURVEY.md §8d); see roofline_valu / roofline_mfma"}
-    out = {}
-    model_tf = R * box_flop / (total_ms * 1e-3) / 1e12
-    valu = {"bound": "fp32-valu", "achieved": model_tf, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": model_tf / FP32_PEAK_TF,
-            "model_flop_per_ray": box_flop, "model_note": "SURVEY §8d box-only flop model: counts every instance at every sample (work-equivalent, not utilisation)",
-            "forward_ms": fwd_ms, "backward_ms": bwd_ms, "launches": [fwd_n, bwd_n], "executed": executed, "executed_source": source}
-    if args.residual:
-        # the residual kernels are bound by the matrix pipe + the jet algebra on the VALU (same 157 TF peak, no overlap on a SIMD):
-        # the mandated object carries the EXECUTED flops when the counters of this workload are committed, else the model figure
-        achieved = executed["tflops"] if executed else R * (box_flop + mlp_flop) / (total_ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
-                           "frac": achieved / FP32_PEAK_TF, "traffic": traffic, "traffic_source": source, "launch_ms": dom_ms,
-                           "basis": ("executed MFMA + VALU flops from the committed PMC counters of this workload / live launch duration" if executed
-                                     else "SURVEY §8d flop model (no committed counters for this workload): work-equivalent, includes culled work"),
-                           "mfma_tflops": executed["mfma_tflops"] if executed else None, "mfma_frac": executed["mfma_utilisation"] if executed else None,
-                           "model_flop_per_ray": box_flop + mlp_flop, "algorithmic_bytes_per_ray": dom_bytes, "traffic_bytes_per_ray": traffic / R if traffic else None}
-        out["roofline_hbm"] = hbm
-        valu["model_note"] += "; for residual fields see `roofline` (MFMA + VALU)"
-    else:
-        out["roofline"] = hbm
-    out["roofline_valu"] = valu
-    return out
+    hbm = {"bound": "hbm", "kernel": dominant, "kernels": counters.get("kernels") if counters else symbols, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
+           "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source, "algorithmic_bytes_per_ray": dom_bytes,
+           "launch_ms": dom_ms, "traffic_bytes_per_ray": traffic / R if traffic else None,
+           "note": "the fused path is compute bound (arithmetic intensity ~1e4 flop/B), not HBM bound (SURVEY.md §8d); see roofline_valu"}
+    model_tf = R * (box_flop + mlp_flop) / (total_ms * 1e-3) / 1e12
+    valu = {"bound": "fp32 VALU + MFMA (one datapath, 157.3 TFLOP/s)" if args.residual else "fp32-valu",
+            "achieved": executed["tflops"] if executed else None, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": executed["frac"] if executed else None,
+            "basis": ("executed flops: committed PMC counters of this workload (per step, all kernels of the step) / live step duration" if executed
+                      else "no committed counters for this workload: no utilisation figure (see work_equivalent_tflops)"),
+            "executed": executed, "executed_source": source,
+            "work_equivalent_tflops": model_tf, "work_equivalent_flop_per_ray": box_flop + mlp_flop,
+            "work_equivalent_note": "SURVEY §8d flop model: every instance at every sample, no culling -- a work rate, NOT a fraction of the peak",
+            "forward_ms": fwd_ms, "backward_ms": bwd_ms, "launches": [fwd_n, bwd_n]}
+    return {"roofline": hbm, "roofline_valu": valu}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# extra regimes of the default run: measured AFTER the headline, each in a child process
+# ---------------------------------------------------------------------------------------------------------------------
+
+def extra_regimes():
+    """Config 3 and config 5 at full size (bench.py itself with other sizes) and the reference's own regime -- 1000 importance-sampled
+    rays x 100 samples per step, 3000 steps per frame (scripts/main.py:525-578, 620-651; README.md:128: "about 15 minutes" per frame on
+    a V100) -- through FrameOptimizer as a replayed hipGraph (tools/native_mode_bench.py).  Children start after the parent's timed
+    region and its report are complete; the parent only waits."""
+    def child(cmd, keep, timeout=900):
+        t0 = time.time()
+        try:
+            out = subprocess.run([sys.executable, *cmd], capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+            lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+            if not lines:
+                return {"error": (out.stderr or out.stdout)[-300:], "command": "python " + " ".join(cmd)}
+            record = json.loads(lines[-1])
+        except (subprocess.TimeoutExpired, ValueError) as exc:
+            return {"error": repr(exc)[:300], "command": "python " + " ".join(cmd)}
+        small = {k: record[k] for k in keep if k in record}
+        if "config" in record:
+            small["workload"] = record["config"].get("workload")
+            small["schedule"] = record["config"].get("schedule")
+        for key in ("roofline", "roofline_valu"):
+            if key in record:
+                small[key] = {k: record[key].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "work_equivalent_tflops", "launch_ms")
+                              if k in record[key]}
+        small["command"] = "python " + " ".join(cmd)
+        small["wall_s"] = round(time.time() - t0, 1)
+        return small
+    dense = ["value", "unit", "ms_per_step", "steps", "warmup", "n_gpus"]
+    native = ["phase", "graph", "steps_per_s", "ms_per_step", "seconds_per_3000_step_frame", "seconds_per_frame", "warmup_phase_seconds",
+              "residual_phase_seconds", "steps", "rays_per_step", "samples_per_ray", "views", "instances", "final_loss"]
+    base = ["bench.py", "--no-cpu-baseline", "--no-extra-regimes"]
+    tool = os.path.join("tools", "native_mode_bench.py")
+    return {
+        "note": "measured after the headline's timed region, one child process each; config 2 above stays the metric's workload",
+        "config3_full_size": child(base + ["--residual", "--steps", "3", "--warmup", "1"], dense),
+        "config5_one_gpu": child(base + ["--views", "17", "--height", "752", "--width", "2816", "--instances", "64", "--samples", "128", "--steps", "2", "--warmup", "1"], dense),
+        "native_graph_box_only": child([tool, "--graph", "--steps", "300", "--json"], native),
+        "native_graph_residual": child([tool, "--graph", "--residual", "--steps", "300", "--json"], native),
+        "native_graph_whole_frame": child([tool, "--graph", "--whole-frame", "--json"], native),
+    }
 
 
 def main():

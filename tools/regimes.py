@@ -38,7 +38,7 @@ def main():
     args = parser.parse_args()
     out_dir = os.path.join(ROOT, "gpurun_out", args.tag)
     os.makedirs(out_dir, exist_ok=True)
-    base = ["bench.py", "--no-cpu-baseline"]
+    base = ["bench.py", "--no-cpu-baseline", "--no-extra-regimes"]
     dense = [("C2 mid (headline)", ["--steps", "10", "--warmup", "2"]),
              ("C2 start", ["--steps", "10", "--warmup", "2", "--schedule", "start"]),
              ("C2 end", ["--steps", "10", "--warmup", "2", "--schedule", "end"]),

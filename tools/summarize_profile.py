@@ -23,7 +23,7 @@ def kernel_stats(path, out):
                   f"{float(r['TotalDurationNs']) / 1e6:10.3f} {float(r['Percentage']):7.2f}\n")
 
 
-def counters(path, out, only=("render_", "sample_", "field_eval", "ray_directions", "reduce_partials", "project_")):
+def counters(path, out, only=("render_", "residual_", "reduce_item", "sample_", "field_eval", "ray_directions", "reduce_partials", "project_")):
     acc = defaultdict(lambda: defaultdict(list))
     meta = {}
     with open(path) as f:
@@ -80,6 +80,15 @@ def counters_json(src, dst):
         path = os.path.join(src, sub, "bench_counter_collection.csv")
         if not os.path.exists(path):
             continue
+        # steps the profiled command ran (warm-up + timed: every one of them launches the step's kernels once)
+        steps = 2
+        pass_log = os.path.join(src, sub + "_stdout.log")
+        if os.path.exists(pass_log):
+            for text in open(pass_log):
+                if text.startswith("{\"metric\""):
+                    record = json.loads(text)
+                    steps = int(record.get("steps", 1)) + int(record.get("warmup", 1))
+        sums = defaultdict(lambda: defaultdict(float))
         with open(path) as f:
             for r in csv.DictReader(f):
                 if "vsrd::" not in r["Kernel_Name"]:
@@ -88,7 +97,11 @@ def counters_json(src, dst):
                 if counter in ("FETCH_SIZE", "WRITE_SIZE"):
                     counter, value = counter + "_bytes", value * 1024.0
                 kernels[name][counter] = value                   # rows are in dispatch order: the last one (a timed step) stays
+                sums[name][counter] += value
                 kernels[name]["vgpr"], kernels[name]["agpr"] = int(r["VGPR_Count"]), int(r["Accum_VGPR_Count"])
+        for name, per in sums.items():                           # a step may launch a kernel many times (residual step: once per chunk of rays)
+            for counter, total in per.items():
+                kernels[name][counter + "_per_step"] = total / steps
     stats = os.path.join(src, "trace", "bench_kernel_stats.csv")
     if os.path.exists(stats):
         with open(stats) as f:
