@@ -683,9 +683,12 @@ def test_fused_residual_step_matches_two_launch_path(dev, name):
 
 
 @pytest.mark.parametrize("name", [n for n in RESIDUAL_CASES if n.startswith("g17")])
-def test_fused_residual_step_golden(dev, name):
-    """vsrd_render_residual_step at the shapes the benchmark times (BASELINE config 3: N = 16, S = 64 ->
-    render_residual_step_kernel<2>; S = 100 -> <4>) against the REFERENCE's outputs: silhouettes, loss terms, and the gradients
+@pytest.mark.parametrize("form", ["default", "wave_per_ray", "single_kernel"])
+def test_fused_residual_step_golden(dev, name, form):
+    """vsrd_render_residual_step at the shapes the benchmark times (BASELINE config 3: N = 16, S = 64; the reference's S = 100), in each
+    of its three forms -- default: residual_step_pair_kernel<2 / 4> + residual_mlp_adjoint_kernel (launches of <= 2048 rays split a ray
+    over two waves); wave_per_ray: residual_step_front_kernel<2 / 4> + residual_mlp_adjoint_kernel, WHAT DENSE LAUNCHES (bench.py's config
+    3) RUN; single_kernel: render_residual_step_kernel<2 / 4> -- against the REFERENCE's outputs: silhouettes, loss terms, and the gradients
     w.r.t. box parameters and per-instance MLP weights.  The launch takes the well-conditioned rays (no 1e6 m extrapolation); on
     those the step's loss is  mean BCE over R_c rays + ratio * eikonal, and the golden's two gradient terms (taken separately by
     the generator) combine to  (R / R_c) grad_bce + ratio * grad_eikonal  -- the dropped rays have clamped (zero) labels, whose
@@ -703,18 +706,23 @@ def test_fused_residual_step_golden(dev, name):
         rendering.sdfs.translation(rendering.sdfs.rotation(fields.instance_field(
             fields.residual_composition(rendering.sdfs.box(dim[i]), fields.ResidualField(mlp[i])), i, N), rot[i]), loc[i])
         for i in range(N)], float(g["temperature"]))
-    loss, terms, labels = rendering.silhouette_step(union, g["origins"][keep].to(dev), g["directions"][keep].to(dev), g["targets"][keep].to(dev),
-                                                    (0.0, 100.0), S, std, ratio, u_coarse=g["u_coarse"][keep].to(dev), u_fine=g["u_fine"][keep].to(dev),
-                                                    eikonal_ratio=eikonal_ratio, return_terms=True, return_labels=True)
+    from vsrd_amd.rendering import renderers
+    renderers.RESIDUAL_SINGLE_KERNEL, renderers.RESIDUAL_WAVE_PER_RAY = form == "single_kernel", form == "wave_per_ray"
+    try:
+        loss, terms, labels = rendering.silhouette_step(union, g["origins"][keep].to(dev), g["directions"][keep].to(dev), g["targets"][keep].to(dev),
+                                                        (0.0, 100.0), S, std, ratio, u_coarse=g["u_coarse"][keep].to(dev), u_fine=g["u_fine"][keep].to(dev),
+                                                        eikonal_ratio=eikonal_ratio, return_terms=True, return_labels=True)
+        grads = torch.autograd.grad(loss, [loc, dim, rot, mlp])
+    finally:
+        renderers.RESIDUAL_SINGLE_KERNEL = renderers.RESIDUAL_WAVE_PER_RAY = False
     assert (labels.cpu() - g["fine_labels"][keep]).abs().max() < LABEL_TOL
     want_bce = torch.nn.functional.binary_cross_entropy(g["fine_labels"][keep].clamp(1.0e-6, 1.0 - 1.0e-6), g["targets"][keep], reduction="none").mean()
     torch.testing.assert_close(terms[0].cpu(), want_bce, rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(terms[1].cpu(), g["eikonal_conditioned"], rtol=1e-2, atol=5e-6)
-    grads = torch.autograd.grad(loss, [loc, dim, rot, mlp])
     for got, key in zip(grads, ("locations", "dimensions", "orientations", "mlp_weights")):
         want = (R / Rc) * g["grad_bce_" + key] + eikonal_ratio * g["grad_eikonal_" + key]
         err = (got.cpu() - want).abs().max().item() / max(float(want.abs().max()), 1e-6)
-        print(f"[fused residual step vs reference] {name} {key}: rel err {err:.3e}")
+        print(f"[fused residual step vs reference] {name} {form} {key}: rel err {err:.3e}")
         assert err < GRAD_TOL, f"{key}: relative error {err:.3e}"
 
 

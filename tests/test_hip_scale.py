@@ -216,6 +216,27 @@ def test_config5_full_size_fused_step(dev):
     _fused_step_properties(dev, N=64, S=128, V=17, H=752, W=2816, residual=False, seed=2)
 
 
+@pytest.mark.parametrize("mapping", ["four_rays_per_wave", "one_ray_per_wave"])
+def test_config2_full_size_fused_step(dev, mapping):
+    """BASELINE config 2 at its full size through the FUSED step -- what bench.py times: 9 views x 376 x 1408 = 4.76 M rays, 16
+    instances, 64 samples per ray, in both mappings of vsrd_render_silhouette_step (render_silhouette_quad_kernel<4>, the default, and
+    render_silhouette_kernel<2>; arithmetic pinned by golden g4_render_n16_s64_mid and test_quad_step_matches_wave_per_ray).  The two
+    mappings share the Philox keys, so their losses over the 4.76 M rays agree to rounding."""
+    from vsrd_amd.rendering import renderers
+    renderers.STEP_WAVE_PER_RAY = mapping == "one_ray_per_wave"
+    try:
+        loss = _fused_step_properties(dev, N=16, S=64, V=9, H=376, W=1408, residual=False, seed=4)
+    finally:
+        renderers.STEP_WAVE_PER_RAY = False
+    _config2_losses[mapping] = loss
+    if len(_config2_losses) == 2:
+        a, b = _config2_losses.values()
+        assert abs(a - b) <= 2e-4 * max(abs(a), 1e-6), _config2_losses
+
+
+_config2_losses = {}
+
+
 def test_config3_full_size_fused_step(dev):
     """BASELINE config 3 at its full size: 9 views x 376 x 1408 = 4.76 M rays, 16 instances, 64 samples per ray, residual MLP from
     the hypernetwork + eikonal term (render_residual_step_kernel<2>; arithmetic pinned by golden g17_render_residual_n16_s64_mid)."""

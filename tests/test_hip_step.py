@@ -188,16 +188,39 @@ def test_residual_phase_step_matches_oracle(dev, S):
     weights = soft.reshape(-1, N).max(-1).values
     idx = torch.multinomial((weights > 0.5).float(), R, replacement=False)
     u1, u2 = torch.rand(R, S, generator=g), torch.rand(R, S, generator=g)
+    # the same step in float64: how far the float32 evaluation of the reference's own formulas is from the exact answer on this frame
+    # (the eikonal term weighs every sample, including those on a kink of a box SDF).  The device step has to be within 5e-3 of the
+    # float64 answer, or within twice the float32 oracle's own distance from it -- whichever is larger (test_residual_field_backward_golden).
+    exact_loop = ostep.OracleFrame((H, W), K.double(), E.double(), soft.cpu().double(), gt_boxes.double(), visible, S)
+    exact_loop.step_index = 1500
+    with torch.no_grad():
+        for q, v in zip(exact_loop.raw, start):
+            q.data = v.double()
+    hyper_exact = models.HyperDistanceField(48, [16, 16, 16, 16], 256, [256, 256, 256, 256])
+    hyper_exact.load_state_dict({k: v.cpu() for k, v in device_loop.hyper_distance_field.state_dict().items()})
+    hyper_exact = hyper_exact.double()
+    emb_exact = device_loop.detector.embeddings.detach().cpu()[0].double().clone().requires_grad_(True)
+    exact_loop.enable_residual(hyper_exact, emb_exact)
     got = device_loop.step(idx, u1.to(dev), u2.to(dev))
     want = oracle_loop.step(idx.cpu(), u1, u2, residual=True)
+    exact = exact_loop.step(idx.cpu(), u1.double(), u2.double(), residual=True)
     for key in ("iou_projection_loss", "l1_projection_loss", "silhouette_loss", "eikonal_loss", "loss"):
         torch.testing.assert_close(got[key].cpu(), want[key], rtol=5e-3, atol=1e-5), key
-    for k, (gg, gw) in enumerate(zip(got["raw_gradients"], want["raw_gradients"])):
-        assert (gg.cpu()[0] - gw).abs().max() <= 1e-2 * float(gw.abs().max()), k
-    ge = device_loop.detector.embeddings.grad.cpu()[0]
-    assert (ge - emb_cpu.grad).abs().max() <= 2e-2 * float(emb_cpu.grad.abs().max())
-    for pd, pc in zip(device_loop.hyper_distance_field.parameters(), hyper_cpu.parameters()):
-        assert (pd.grad.cpu() - pc.grad).abs().max() <= 2e-2 * max(float(pc.grad.abs().max()), 1e-8)
+
+    def check(name, device_grad, oracle_grad, exact_grad):
+        scale = max(float(exact_grad.abs().max()), 1e-12)
+        err = float((device_grad.double() - exact_grad).abs().max()) / scale
+        floor = float((oracle_grad.double() - exact_grad).abs().max()) / scale
+        print(f"[residual phase step, S={S}] {name}: device vs float64 oracle {err:.3e} (float32 oracle vs float64: {floor:.3e})")
+        assert err <= max(5e-3, 2.0 * floor), f"{name}: {err:.3e} (float32 oracle {floor:.3e})"
+
+    for k, (gg, gw, gx) in enumerate(zip(got["raw_gradients"], want["raw_gradients"], exact["raw_gradients"])):
+        check(("raw locations", "raw dimensions", "raw orientations")[k], gg.cpu()[0], gw, gx)
+    check("embeddings", device_loop.detector.embeddings.grad.cpu()[0], emb_cpu.grad, emb_exact.grad)
+    worst = (0.0, None)
+    for (pname, pd), pc, px in zip(device_loop.hyper_distance_field.named_parameters(), hyper_cpu.parameters(), hyper_exact.parameters()):
+        if float(px.grad.abs().max()) > 1e-10:
+            check("hypernetwork " + pname, pd.grad.cpu(), pc.grad, px.grad)
 
 
 def test_device_hungarian_matches_scipy(dev):
