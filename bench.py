@@ -62,6 +62,9 @@ def parse_args(argv=None):
     parser.add_argument("--no-extra-regimes", action="store_true",
                         help="default run only: skip the `extra_regimes` object (config 3 / config 5 at full size and the reference's native mode, measured after the headline)")
     parser.add_argument("--launcher-selftest", action="store_true", help="no rendering: exercise the N-rank launch/report path (gloo, CPU)")
+    parser.add_argument("--ranks-share-gpu", action="store_true",
+                        help="TEST ONLY: all ranks render on cuda:0 and rendezvous over gloo -- runs the real step under the multi-rank "
+                             "build / barrier / gather / report path on a one-GPU box; the line says that it is not a scaling measurement")
     parser.add_argument("--master-port", type=int, default=0)
     return parser.parse_args(argv)
 
@@ -109,7 +112,7 @@ def spawn_ranks(args):
     The parent initialises no GPU (counting devices does not, on this image) and returns the worst child exit code."""
     import socket
     import torch
-    if not args.launcher_selftest:
+    if not args.launcher_selftest and not args.ranks_share_gpu:
         have = torch.cuda.device_count()
         if have < args.gpus:
             raise SystemExit(f"bench.py --gpus {args.gpus}: this node has {have} visible GPU(s); one rank per GPU, no oversubscription")
@@ -313,17 +316,18 @@ def run_rank(args):
     if not use_gpu and not selftest:
         raise SystemExit("bench.py measures the HIP path and needs a HIP device: there is no CPU fallback (the CPU oracle is only the "
                          "`cpu_baseline` leg).  `--launcher-selftest` exercises the multi-rank launch path without rendering.")
-    dev = torch.device("cuda", local_rank) if use_gpu else torch.device("cpu")
+    share = args.ranks_share_gpu and use_gpu
+    dev = torch.device("cuda", 0 if share else local_rank) if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(dev)
     dist = None
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if use_gpu:
+        if use_gpu and not share:
             dist.init_process_group(backend="nccl", device_id=dev)     # RCCL; barrier / max-reduce / gather of the timings only
         else:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo")                    # (RCCL refuses two ranks on one device)
 
     def fence():
         if distributed:
@@ -422,12 +426,13 @@ def run_rank(args):
     per_rank_ms = [own / args.steps * 1e3]
     ranks_through = 1
     if distributed:
-        mine = torch.tensor([elapsed, own], device=dev, dtype=torch.float64)
+        wire = torch.device("cpu") if share else dev
+        mine = torch.tensor([elapsed, own], device=wire, dtype=torch.float64)
         gathered = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
         per_rank_ms = [float(t[1].item()) / args.steps * 1e3 for t in gathered]
         elapsed = max(float(t[0].item()) for t in gathered)           # MAX over ranks of the barrier-to-barrier time
-        count = torch.ones(1, device=dev, dtype=torch.float64)
+        count = torch.ones(1, device=wire, dtype=torch.float64)
         dist.all_reduce(count)                                        # ranks that got here = ranks that passed every barrier
         ranks_through = int(round(float(count.item())))
 
@@ -453,6 +458,8 @@ def run_rank(args):
                 "launches_per_step": "1 fused (render + loss + adjoint) + partial reductions" if fused else "forward, torch loss, backward",
                 "final_loss": float(loss.detach()), "target_empty_fraction": float((targets.sum(-1) == 0).float().mean()),
             }
+            if share:
+                result["metric"] = "ranks share ONE GPU (--ranks-share-gpu): a test of the multi-rank path, NOT a scaling measurement; " + result["metric"]
             result.update(rooflines(args, kernels, R, fused))
             if world == 1 and not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(args, sched, frame, lambda a, b: targets[a:b].cpu(), hyper_state,

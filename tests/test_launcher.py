@@ -1,7 +1,10 @@
 """Frame sharding and the launcher's collectives with 2 gloo ranks on CPU (the N > 1 path of bench.py / the launcher)."""
+import math
 import os
 import socket
 import tempfile
+
+import pytest
 
 import torch
 import torch.multiprocessing as mp
@@ -106,3 +109,28 @@ def test_bench_spawns_its_own_ranks_and_reports_what_ran():
         refused = subprocess.run([sys.executable, bench, "--steps", "1"], capture_output=True, text=True, timeout=300, env=env)
         assert refused.returncode != 0 and "no CPU fallback" in refused.stderr
         assert not [l for l in refused.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_with_the_real_step_on_one_gpu():
+    """The multi-rank path of bench.py with the REAL render step: two ranks spawned by bench.py itself, both on
+    cuda:0 (--ranks-share-gpu: gloo rendezvous, since RCCL refuses two ranks on one device), build on rank 0 behind a barrier, W warm-up
+    + K timed steps between barriers, all_gather of the per-rank times, rank 0's single JSON line.  What the driver's 8-GPU run
+    exercises except for the transport: there the line must show n_gpus = 8 and a per_rank_ms_per_step spread of a few per cent."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--ranks-share-gpu", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                          "--views", "2", "--height", "94", "--width", "352"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and "NOT a scaling measurement" in line["metric"]
+    rays = 2 * 94 * 352
+    assert len(line["per_rank_ms_per_step"]) == 2 and min(line["per_rank_ms_per_step"]) > 0.0
+    assert abs(line["value"] - 2 * rays / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]     # whole-job rays/s = both ranks' rays / slowest time
+    assert line["ms_per_step"] >= max(line["per_rank_ms_per_step"]) - 0.05
+    assert line["config"]["rays_per_gpu"] == rays and math.isfinite(line["config"]["final_loss"])
