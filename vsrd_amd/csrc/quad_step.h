@@ -99,8 +99,9 @@ __device__ __forceinline__ int opaque_lane_id() {
 //   4 x [ N x (a, b, radius, lambda) | 4 pad ]  culling coefficients of (ray, instance) (field.h: RayCull) + the ray's label adjoints
 //   4 x [ ox oy oz rx | ry rz reach pad ]       the rays themselves: re-read where they are needed instead of living in 9 registers
 // After importance_merge the coarse | fine part of a row holds, per pass-2 point, first the transmittance (forward sweep -> reverse
-// sweep) and then the interval mid-point (reverse sweep -> per-instance phase).
-__host__ __device__ constexpr int quad_row_floats(int num_samples) { return 4 * num_samples + kRowLanes; }
+// sweep) and then the interval mid-point (reverse sweep -> per-instance phase); the reverse sweep also turns merged[s + 1] into C2 of
+// point s once the distances of its round have been read (the rounds run backwards, so merged[16 q] stays for round q - 1).
+__host__ __device__ constexpr int quad_row_floats(int num_samples) { return 4 * num_samples + kRowLanes + 4; }   // (+ 4: C2 of the last point, below)
 __host__ __device__ constexpr int quad_merged_offset(int num_samples) { return 2 * num_samples + kRowLanes; }
 __host__ __device__ constexpr int quad_coef_floats(int num_instances) { return kCullCoefs * num_instances + 4; }
 __host__ __device__ constexpr int quad_rounds_s(int num_samples) { return num_samples <= 16 ? 1 : (num_samples <= 32 ? 2 : 4); }   // rounds of 16 coarse points
@@ -413,8 +414,8 @@ __device__ __forceinline__ bool quad_pass_one(const float* __restrict__ instance
 //   after the forward sweep:  m, inv_z (soft-min shift, 1/Z), s = u - m, a = grad u, c = B' with B = g_bar . b = cos_bar B'
 //                             (b = sum_i w_i grad d_i;  g_bar = cos_bar / |g| (r - n (n . r)), n = grad u / |g|, so
 //                              B' = (r . b - (grad u . b) (n . r) / |g|) / |g|)
-//   after the reverse sweep:  m, inv_z, s = 1 + (u - m) / T, a = g_bar, c = C2; C1 and C3 wait in the wave's LDS (the distance cache
-//   is free by then: two lane-private floats per round).  With them (render_kernels.h: adjoint_phase_b)
+//   after the reverse sweep:  m, inv_z, s = 1 + (u - m) / T, a = g_bar; C1, C2 and C3 wait in the wave's LDS (the distance cache is
+//   free by then: two lane-private floats per round; the third takes the place of the sorted distances).  With them (adjoint_phase_b)
 //     d_bar_i = cc_i (C1 - beta_i / T) + w_i (C2 - beta_i / T - C3 lambda_i),   cc_i = w_i (s - (d_i - m) / T)
 //     C1 = u_bar + B / T,  C2 = (A + w_s Lambda_s / Z_s) / T,  C3 = w_s / T,   A = g_bar . grad u
 template <int kRounds>
@@ -493,11 +494,12 @@ __device__ __forceinline__ bool quad_forward_sweep(QuadAdjoint<kRounds>& st, con
 // Lambda_s, opacity (recomputed from u, grad u and the interval), suffix sums of w_bar w, chain to (u_bar, g_bar), and the
 // per-sample constants of the per-instance phase.  coef_own: the lane's OWN ray's (a, b, radius, lambda) rows; cached_round:
 // the round whose soft-min terms the distance cache still holds (fixed shift; -1: none).  On return cbuf (= the distance cache) holds
-// C1 and C3 of every point, trans_mid the interval mid-points.  Returns the rounds (bit q) in which some lane carries a non-zero adjoint.
+// C1 and C3 of every point, trans_mid the interval mid-points, c2buf (= the row's OWN sorted distances, shifted by one) C2.  Returns the
+// rounds (bit q) in which some lane carries a non-zero adjoint.
 template <int kRounds, bool kYaw>
 __device__ __forceinline__ unsigned quad_reverse_sweep(QuadAdjoint<kRounds>& st, const float* __restrict__ instances, const Shading& sh, const float* rayp,
                                                        const float* merged, int num_points, bool live, unsigned active, unsigned long long lam_any, int cached_round,
-                                                       const float* coef_own, float* cbuf, float* trans_mid, const RowLanes& rl) {
+                                                       const float* coef_own, float* cbuf, float* trans_mid, float* c2buf, const RowLanes& rl) {
     unsigned flow = 0u;
     float suffix_carry = 0.0f;
 #pragma unroll
@@ -549,7 +551,7 @@ __device__ __forceinline__ unsigned quad_reverse_sweep(QuadAdjoint<kRounds>& st,
         const float A = gbx * st.ax[q] + gby * st.ay[q] + gbz * st.az[q];
         st.ax[q] = gbx; st.ay[q] = gby; st.az[q] = gbz;
         st.s[q] = 1.0f + st.s[q] * sh.inv_t;
-        st.c[q] = sh.inv_t * (A + wgt * lam_z);
+        c2buf[q * kRowLanes + rl.col + 1] = sh.inv_t * (A + wgt * lam_z);
         cbuf[(2 * q) * kWave + rl.lane] = u_bar + sh.inv_t * B;
         cbuf[(2 * q + 1) * kWave + rl.lane] = sh.inv_t * wgt;
         const bool any = (u_bar != 0.0f) || (gbx != 0.0f) || (gby != 0.0f) || (gbz != 0.0f) || (wgt != 0.0f);
@@ -559,11 +561,11 @@ __device__ __forceinline__ unsigned quad_reverse_sweep(QuadAdjoint<kRounds>& st,
 }
 
 // Per-instance phase for the four rays (render_kernels.h: adjoint_phase_b): instance-outer, rounds inner, one reduce-scatter butterfly
-// per (wave, instance), added to the wave's row of the partial-gradient table with fire-and-forget atomics (the row belongs to this
-// wave alone and a wave's atomics on one address keep program order: the sums stay deterministic).
+// per (wave, instance).  G[s]: lane (row r, col c) accumulates parameter c of instance 4 s + r (four registers for N <= 16; float
+// atomics on the wave's row of the partial table instead cost 6.5 GB of L2 write-through per launch).
 template <int kRounds, bool kYaw>
 __device__ __forceinline__ void quad_phase_b(const QuadAdjoint<kRounds>& st, const float* __restrict__ instances, const Shading& sh, const float* rayp,
-                                             unsigned flow, const float* coef_own, const float* cbuf, const float* mids, float* __restrict__ out, const RowLanes& rl) {
+                                             unsigned flow, const float* coef_own, const float* cbuf, const float* mids, const float* c2buf, float (&G)[4], const RowLanes& rl) {
     const float inv_t = sh.inv_t;
     const Ray ray = load_row_ray(rayp).ray;
     unsigned long long todo = 0ull;
@@ -579,7 +581,7 @@ __device__ __forceinline__ void quad_phase_b(const QuadAdjoint<kRounds>& st, con
         for (int q = 0; q < kRounds; ++q) {
             if (!(((st.near[q] >> i) & 1ull) && ((flow >> q) & 1u))) continue;       // wave-uniform
             const float mid = mids[q * kRowLanes + rl.col];
-            const float c1 = cbuf[(2 * q) * kWave + rl.lane], c3 = cbuf[(2 * q + 1) * kWave + rl.lane];
+            const float c1 = cbuf[(2 * q) * kWave + rl.lane], c3 = cbuf[(2 * q + 1) * kWave + rl.lane], c2 = c2buf[q * kRowLanes + rl.col + 1];
             const BoxEval e = eval_box<kYaw>(in, ray.ox + ray.rx * mid, ray.oy + ray.ry * mid, ray.oz + ray.rz * mid);
             const float ds = e.d - st.m[q];
             const float w = fast_exp(-ds * inv_t) * st.inv_z[q];
@@ -589,7 +591,7 @@ __device__ __forceinline__ void quad_phase_b(const QuadAdjoint<kRounds>& st, con
             const float rgy = kYaw ? gy_ : fmaf(in.r21, gz_, fmaf(in.r11, gy_, in.r01 * gx_));
             const float rgz = kYaw ? fmaf(in.r22, gz_, in.r02 * gx_) : fmaf(in.r22, gz_, fmaf(in.r12, gy_, in.r02 * gx_));
             const float tb = inv_t * (rgx * e.glx + rgy * e.gly + rgz * e.glz);
-            const float d_bar = cc * (c1 - tb) + w * (st.c[q] - tb - c3 * lam_i);
+            const float d_bar = cc * (c1 - tb) + w * (c2 - tb - c3 * lam_i);
             const float gwbx = cc * gx_, gwby = cc * gy_, gwbz = cc * gz_;
             const float glbx = cc * rgx, glby = cc * rgy, glbz = cc * rgz;
             const float sx = sign_of(e.px), sy = sign_of(e.py), sz = sign_of(e.pz);
@@ -615,9 +617,9 @@ __device__ __forceinline__ void quad_phase_b(const QuadAdjoint<kRounds>& st, con
         }
         const float packed[16] = {at0, at1, at2, r00, r01, r02, r10, r11, r12, r20, r21, r22, ad0, ad1, ad2, 0.0f};
         const float mine = wave_reduce16_scatter(packed, rl.lane);            // every lane: the wave's sum of parameter (lane & 15)
-        // (wavefront scope: no other wave touches the row before the kernel ends, so the add need not leave this XCD's L2 -- at agent
-        //  scope every one of them went out to the fabric: 8 GB of writes per launch)
-        if (rl.lane < kGradStride) __hip_atomic_fetch_add(out + i * kGradStride + rl.lane, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const float add = (rl.row == (i & 3)) ? mine : 0.0f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) G[s] += ((i >> 2) == s) ? add : 0.0f;
     }
 }
 
@@ -640,7 +642,7 @@ __device__ __forceinline__ bool quad_step_body(const float* __restrict__ instanc
                                                const float* __restrict__ u_coarse, const float* __restrict__ u_fine, bool sorted_input,
                                                const float* __restrict__ targets, const float* __restrict__ instance_weights, float loss_scale,
                                                float* __restrict__ labels_out, float* stage, float* dcache, float* coefs, float* rays,
-                                               float* __restrict__ out, float& loss_acc, const RowLanes& rl VSRD_QUAD_CLOCK_PARAM) {
+                                               float (&G)[4], float& loss_acc, const RowLanes& rl VSRD_QUAD_CLOCK_PARAM) {
     constexpr int kRounds = 2 * kRoundsS;
     VSRD_PHASE(7);
     const int S = c.num_samples;
@@ -705,9 +707,9 @@ __device__ __forceinline__ bool quad_step_body(const float* __restrict__ instanc
     wave_lds_sync();
     // ---- adjoint -------------------------------------------------------------------------------------------------------------------
     const unsigned flow = quad_reverse_sweep<kRounds, kYaw>(st, instances, sh, rayp, merged, num_points, live, active, lam_any, kRunning ? -1 : cached_round,
-                                                            coef_own, dcache, trans_mid, rl);
+                                                            coef_own, dcache, trans_mid, rowbase + quad_merged_offset(S), rl);
     VSRD_PHASE(4);
-    if (flow != 0u) quad_phase_b<kRounds, kYaw>(st, instances, sh, rayp, flow, coef_own, dcache, trans_mid, out, rl);
+    if (flow != 0u) quad_phase_b<kRounds, kYaw>(st, instances, sh, rayp, flow, coef_own, dcache, trans_mid, rowbase + quad_merged_offset(S), G, rl);
     VSRD_PHASE(5);
     return true;
 }
@@ -741,10 +743,7 @@ __global__ __launch_bounds__(kBlockThreads, VSRD_QUAD_WAVES_PER_EU) void render_
     const int num_waves = static_cast<int>(gridDim.x) * waves_per_block();
     const int wave_global = static_cast<int>(blockIdx.x) * waves_per_block() + wave;
     const int num_quads = (c.num_rays + kQuadRays - 1) / kQuadRays;
-    // the wave's row of the partial-gradient table: cleared here, accumulated by quad_phase_b, summed over the waves by reduce_partials_kernel
-    float* out = partials + static_cast<size_t>(wave_global) * (N * kGradStride);
-    for (int idx = lane0; idx < N * kGradStride; idx += kWave) out[idx] = 0.0f;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // the cleared row is in place before the first add to it
+    float G[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     VSRD_PHASE_CLOCK();
     for (int quad = wave_global; quad < num_quads; quad += num_waves) {
         const int first_ray = quad * kQuadRays;
@@ -753,21 +752,26 @@ __global__ __launch_bounds__(kBlockThreads, VSRD_QUAD_WAVES_PER_EU) void render_
         bool done = false;
 #ifdef VSRD_QUAD_EXPERIMENT_YAW_ONLY       // register-pressure experiments: one body only
         done = quad_step_body<kRoundsS, true, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
-                                                     instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, out, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
+                                                     instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
         continue;
 #endif
         if (sh.reach >= 0.0f) {
             done = sh.yaw ? quad_step_body<kRoundsS, true, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
-                                                                  instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, out, loss_acc, rl VSRD_QUAD_CLOCK_ARG)
+                                                                  instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG)
                           : quad_step_body<kRoundsS, false, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
-                                                                   instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, out, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
+                                                                   instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
             if (!done) wave_lds_sync();
         }
         if (!done) quad_step_body<kRoundsS, false, true>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
-                                                         instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, out, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
+                                                         instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
     }
     VSRD_PHASE(7);
     VSRD_PHASE_FLUSH(lane0);
+    // the wave's row of the partial-gradient table (summed over the waves by reduce_partials_kernel): instance 4 s + row, parameter col
+    float* out = partials + static_cast<size_t>(wave_global) * (N * kGradStride);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (s * kWave + lane0 < N * kGradStride) out[s * kWave + lane0] = G[s];
     const float loss_total = wave_sum(loss_acc);
     if (lane0 == 0) loss_partials[wave_global] = loss_total * loss_scale;
 }
