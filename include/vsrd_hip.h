@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VSRD_ABI_VERSION 4
+#define VSRD_ABI_VERSION 5
 
 #define VSRD_OK 0
 #define VSRD_E_INVALID_ARGUMENT (-1) /* null pointer, non-positive size, unsupported N / S */
@@ -127,6 +127,13 @@ const char* vsrd_error_string(int32_t code);
 
 /* Bytes of scratch vsrd_render_backward needs for a field of N instances (residual != 0: with per-instance MLP). */
 size_t vsrd_workspace_bytes(int32_t num_instances, int32_t residual);
+
+/* Bytes of scratch with which vsrd_render_backward runs its fastest form for a launch of num_rays rays with num_distances sorted
+ * distances each (>= vsrd_workspace_bytes).  Residual fields: the adjoint of renderers.py:177-270 through the per-instance MLPs
+ * (scripts/main.py:433-458) runs as two kernels per chunk of rays -- the renderer's part, then the MLP adjoints by instance over the
+ * whole chunk, as in vsrd_render_residual_step -- when the workspace holds the seeds of at least min(num_rays, 64) rays (2560 bytes per
+ * (ray, instance, 64-sample round)); with less it keeps the one-kernel form (one wave per SIMD). */
+size_t vsrd_render_backward_workspace_bytes(int32_t num_instances, int32_t residual, int32_t num_distances, int32_t num_rays);
 
 /* The same fusion for RESIDUAL fields (BASELINE config 3; the reference's steps after warm-up): two-pass render + silhouette BCE
  * (scripts/main.py:653-671) + eikonal term (main.py:679-687: mean over all R (2S-1) samples of (|grad sdf| - 1)^2) + adjoint, one

@@ -765,6 +765,43 @@ def test_residual_step_forms_agree(dev, name):
             assert (a - b).abs().max() <= 2e-4 * max(float(b.abs().max()), 1e-6), form
 
 
+@pytest.mark.parametrize("name", [n for n in RESIDUAL_CASES if n.startswith("g17")])
+def test_residual_backward_forms_agree(dev, name):
+    """vsrd_render_backward on residual fields -- what hierarchical_volumetric_rendering(...).backward() of an unchanged main.py runs -- has
+    two forms: two kernels per chunk of rays (render_backward_front_kernel + residual_mlp_adjoint_kernel, the default when the workspace
+    holds a chunk's seeds) and the one-kernel form of round 1 (VSRD_FLAG_RESIDUAL_SINGLE_KERNEL; itself golden-checked by
+    test_residual_field_backward_golden in round 1 and 2).  Random adjoints of labels, SDF gradients and weights: the gradients w.r.t.
+    boxes and MLP weights must agree to rounding, and the default form must repeat itself bit for bit."""
+    from vsrd_amd import fields, rendering
+    from vsrd_amd.rendering import renderers
+    g = load_golden(name)
+    N = g["locations"].shape[0]
+    std, ratio = float(g["sdf_std_deviation"]), float(g["cosine_ratio"])
+    keep = g["conditioned"].reshape(-1)
+    dist = g["fine_distances"].t().contiguous()[keep].to(dev)
+    gen = torch.Generator().manual_seed(3)
+    results = {}
+    for form in ("default", "single_kernel", "default"):
+        renderers.RESIDUAL_SINGLE_KERNEL = form == "single_kernel"
+        try:
+            inst = fields.pack_instances(g["locations"], g["orientations"], g["dimensions"]).to(dev).requires_grad_(True)
+            mlp = g["mlp_weights"].clone().to(dev).requires_grad_(True)
+            block = fields.FieldBlock(inst, float(g["temperature"]), mlp, None)
+            labels, gradients, weights = rendering.render_at_distances(block, g["origins"][keep].to(dev), g["directions"][keep].to(dev), dist, std, ratio)
+            if "adjoints" not in results:
+                results["adjoints"] = (torch.randn(labels.shape, generator=gen).to(dev), (torch.randn(gradients.shape, generator=gen) * 0.05).to(dev),
+                                       (torch.randn(weights.shape, generator=gen) * 0.1).to(dev))
+            out = torch.autograd.grad([labels, gradients, weights], [inst, mlp], list(results["adjoints"]))
+        finally:
+            renderers.RESIDUAL_SINGLE_KERNEL = False
+        if form in results:
+            assert all(torch.equal(a, b) for a, b in zip(out, results[form]))
+        results[form] = out
+    for a, b in zip(results["default"], results["single_kernel"]):
+        assert torch.isfinite(a).all() and float(b.abs().max()) > 0
+        assert (a - b).abs().max() <= 2e-4 * max(float(b.abs().max()), 1e-6)
+
+
 def test_shadow_rendering(dev):
     """vsrd.rendering.shadow_rendering (renderers.py:149-174): a point is in shadow when the ray from just above it towards the light
     converges on geometry.  One box hovering over a plane of points, light straight down (+y is down in the camera frame)."""

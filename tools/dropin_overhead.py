@@ -67,6 +67,30 @@ def main():
         total = time.perf_counter() - t0
         print(f"{'residual' if residual else 'box-only'}: {total / args.iterations * 1e3:.2f} ms per main.py-shaped render + backward "
               f"(host side alone {host / args.iterations * 1e3:.2f} ms), {R} rays x {S} samples, N = {N}")
+        # GPU time of the library calls of one iteration (HIP events around each C-ABI call), and of the fused step on the same rays
+        from vsrd_amd import profiling, fields as vfields, rendering as vrendering
+        from vsrd_amd.rendering import renderers
+        for form in (("two kernels per chunk", False), ("one kernel (round 1)", True)) if residual else (("", False),):
+            renderers.RESIDUAL_SINGLE_KERNEL = form[1]
+            try:
+                with profiling.kernel_timer() as timer:
+                    for _ in range(20):
+                        iteration()
+                    torch.cuda.synchronize()
+                calls = timer.summary()
+            finally:
+                renderers.RESIDUAL_SINGLE_KERNEL = False
+            per_iteration = sum(n * ms for n, ms in calls.values()) / 20
+            detail = ", ".join(f"{name} {n // 20} x {ms:.3f} ms" for name, (n, ms) in sorted(calls.items()))
+            print(f"    GPU time of the library calls per iteration{' [backward: ' + form[0] + ']' if form[0] else ''}: {per_iteration:.3f} ms ({detail})")
+        block = vfields.FieldBlock(vfields.pack_instances(leaves[0].detach(), leaves[2].detach(), leaves[1].detach()), 0.5, weights.detach() if residual else None, None)
+        with profiling.kernel_timer() as timer:
+            for k in range(20):
+                vrendering.silhouette_step(block, origins, directions, targets, (0.0, 100.0), S, 0.5, 0.5, seed=1, stream_offset=k,
+                                           eikonal_ratio=0.01 if residual else 0.0)
+            torch.cuda.synchronize()
+        fused = sum(n * ms for n, ms in timer.summary().values()) / 20
+        print(f"    fused step on the same rays (vsrd_render_{'residual' if residual else 'silhouette'}_step): {fused:.3f} ms")
 
 
 if __name__ == "__main__":

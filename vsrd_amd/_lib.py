@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VSRD_HIP_LIBRARY: an experiment build of the same ABI (tools/phase_timers.py, A/B macros); the product path is the in-tree default
 LIBRARY_PATH = os.environ.get("VSRD_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libvsrd_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_INSTANCES = 64
 MAX_SAMPLES = 256
 INSTANCE_STRIDE = 16
@@ -124,6 +124,7 @@ SIGNATURES = {
     "vsrd_abi_version": (ctypes.c_int32, []),
     "vsrd_error_string": (ctypes.c_char_p, [ctypes.c_int32]),
     "vsrd_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
+    "vsrd_render_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "vsrd_ray_directions": (ctypes.c_int32, [c_float_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_float_p, ctypes.c_void_p]),
     "vsrd_field_eval": (ctypes.c_int32, [ctypes.POINTER(Field), c_float_p, ctypes.c_int64, c_float_p, c_float_p, c_float_p,
                                          ctypes.c_int32, ctypes.c_void_p]),

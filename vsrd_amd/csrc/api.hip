@@ -355,6 +355,14 @@ int32_t vsrd_render_forward(const vsrd_field* field, const vsrd_render_config* c
     return launch_status();
 }
 
+namespace {
+// (defined with the residual step's launch plan, below)
+int32_t render_backward_split(const vsrd_field* field, const vsrd_render_config* config, const float* origins, const float* directions,
+                              const float* distances, int32_t num_distances, const float* grad_labels, const float* grad_gradients,
+                              const float* grad_weights, void* workspace, size_t workspace_bytes, float* grad_instances, float* grad_mlp_weights,
+                              void* stream, bool* taken);
+}
+
 int32_t vsrd_render_backward(const vsrd_field* field, const vsrd_render_config* config,
                              const float* origins, const float* directions,
                              const float* distances, int32_t num_distances,
@@ -369,6 +377,13 @@ int32_t vsrd_render_backward(const vsrd_field* field, const vsrd_render_config* 
     if (residual && !grad_mlp_weights) return VSRD_E_INVALID_ARGUMENT;
     const int N = field->num_instances;
     if (workspace_bytes < vsrd_workspace_bytes(N, residual)) return VSRD_E_WORKSPACE;
+    if (residual && config->num_rays > 0 && !(config->flags & VSRD_FLAG_RESIDUAL_SINGLE_KERNEL)) {
+        // two kernels per chunk of rays (front part + MLP adjoint by instance) when the workspace holds a chunk's seeds
+        bool taken = false;
+        const int32_t status = render_backward_split(field, config, origins, directions, distances, num_distances, grad_labels, grad_gradients,
+                                                     grad_weights, workspace, workspace_bytes, grad_instances, grad_mlp_weights, stream, &taken);
+        if (taken) return status;
+    }
     const hipStream_t s = static_cast<hipStream_t>(stream);
     const int row = N * kGradStride;
     const int mlp_row = N * kMlpWeights;
@@ -687,7 +702,109 @@ static bool plan_residual_step(int N, int S, int num_rays, bool allow_pair, Resi
     return true;
 }
 
+// vsrd_render_backward on residual fields in the split form.  The plan is the residual step's, with the chunk of rays sized to what the
+// caller's workspace holds (at least min(num_rays, 64) rays, else the caller falls back to render_backward_kernel<K, true>).
+bool plan_backward_split(int N, int num_distances, int num_rays, size_t budget_bytes, ResidualStepPlan* p) {
+    p->rounds = rounds_for(num_distances - 1);
+    if (p->rounds < 1 || p->rounds > 4) return false;
+    p->pair = false;
+    p->front_lds = static_cast<size_t>(backward_front_lds_floats(num_distances, N)) * sizeof(float) * kMaxWavesPerBlock;
+    if (p->front_lds > kLdsDefault) return false;
+    const size_t per_ray = static_cast<size_t>(N) * p->rounds * kSeedFloats * kWave * sizeof(float);
+    long long chunk = static_cast<long long>(kSeedBudgetBytes / per_ray);
+    if (chunk > num_rays) chunk = num_rays < 1 ? 1 : num_rays;
+    for (;; chunk = chunk * 3 / 4) {                                       // the largest chunk whose whole layout fits the budget
+        if (chunk < (num_rays < 64 ? num_rays : 64)) return false;
+        p->chunk = static_cast<int>(chunk);
+        const long long want = (chunk + kMaxWavesPerBlock - 1) / kMaxWavesPerBlock;
+        p->front_blocks = static_cast<int>(want > kFrontBlocks ? kFrontBlocks : want);
+        p->front_waves = p->front_blocks * kMaxWavesPerBlock;
+        p->slots_per_instance = chunk * p->rounds;
+        long long per_item = (p->slots_per_instance * N) / 16384;
+        per_item = per_item < 4 ? 4 : (per_item > 32 ? 32 : per_item);
+        p->slots_per_item = static_cast<int>(per_item);
+        p->items_per_instance = static_cast<int>((p->slots_per_instance + per_item - 1) / per_item);
+        size_t at = 0;
+        auto take = [&](size_t floats) { const size_t here = at; at += (floats + 3) & ~size_t(3); return here; };
+        p->box_partials = take(static_cast<size_t>(p->front_waves) * N * kGradStride);
+        p->loss_partials = take(4);
+        p->jets = take(static_cast<size_t>(p->front_waves) * p->rounds * N * kWave * 4);
+        p->box_extra = take(static_cast<size_t>(N) * kGradStride);
+        p->segment_sums = take(static_cast<size_t>(N) * kItemSegments * kItemRowFloats);
+        p->seeds = take(static_cast<size_t>(N) * p->slots_per_instance * kSeedFloats * kWave);
+        p->item_rows = take(static_cast<size_t>(N) * p->items_per_instance * kItemRowFloats);
+        p->masks = take((static_cast<size_t>(N) * p->slots_per_instance + 3) / 4);
+        p->counter = take(4);
+        p->item_flags = take((static_cast<size_t>(N) * p->items_per_instance + 3) / 4);
+        p->total_bytes = at * sizeof(float);
+        if (p->total_bytes <= budget_bytes) return true;
+        if (chunk <= 1) return false;
+    }
+}
+
+int32_t render_backward_split(const vsrd_field* field, const vsrd_render_config* config, const float* origins, const float* directions,
+                              const float* distances, int32_t num_distances, const float* grad_labels, const float* grad_gradients,
+                              const float* grad_weights, void* workspace, size_t workspace_bytes, float* grad_instances, float* grad_mlp_weights,
+                              void* stream, bool* taken) {
+    const int N = field->num_instances;
+    ResidualStepPlan p;
+    *taken = plan_backward_split(N, num_distances, config->num_rays, workspace_bytes, &p);
+    if (!*taken) return VSRD_OK;
+    const hipStream_t s = static_cast<hipStream_t>(stream);
+    const int row = N * kGradStride;
+    const FieldArgs f = field_args(field);
+    RenderArgs c = render_args(config);
+    c.sh.inv_t = f.inv_t;
+    float* base = static_cast<float*>(workspace);
+    float* box_partials = base + p.box_partials;
+    float4* jets = reinterpret_cast<float4*>(base + p.jets);
+    float* box_extra = base + p.box_extra;
+    unsigned* counter = reinterpret_cast<unsigned*>(base + p.counter);
+    float* segment_sums = base + p.segment_sums;
+    float* seeds = base + p.seeds;
+    float* item_rows = base + p.item_rows;
+    unsigned char* masks = reinterpret_cast<unsigned char*>(base + p.masks);
+    unsigned char* item_flags = reinterpret_cast<unsigned char*>(base + p.item_flags);
+    const unsigned mlp_bits = (config->flags & VSRD_FLAG_MLP_WEIGHTS_CENTRED) ? kMlpCentredBit : 0u;
+    const size_t adjoint_lds = (static_cast<size_t>(kMlpWbarFloats) + static_cast<size_t>(kMlpStashTiles) * kTileFloats) * sizeof(float);
+    int chunk_index = 0;
+    for (int first = 0; first < config->num_rays; first += p.chunk, ++chunk_index) {
+        const int rays = std::min(p.chunk, config->num_rays - first);
+        const long long used_slots = static_cast<long long>(rays) * p.rounds;
+        if (hipMemsetAsync(masks, 0, (p.counter - p.masks) * sizeof(float) + sizeof(unsigned), s) != hipSuccess) return VSRD_E_LAUNCH;   // tile masks + item counter
+#define VSRD_LAUNCH(K)                                                                                                                   \
+        hipLaunchKernelGGL(render_backward_front_kernel<K>, dim3(p.front_blocks), dim3(kBlockThreads), p.front_lds, s, f, field->instances, \
+                           field->mlp_weights, c, origins, directions, distances, num_distances, grad_labels, grad_gradients, grad_weights,  \
+                           box_partials, jets, seeds, masks, p.slots_per_instance, first, rays, chunk_index > 0 ? 1 : 0)
+        switch (p.rounds) {
+            case 1: VSRD_LAUNCH(1); break;
+            case 2: VSRD_LAUNCH(2); break;
+            case 4: VSRD_LAUNCH(4); break;
+            default: return VSRD_E_UNSUPPORTED;
+        }
+#undef VSRD_LAUNCH
+        hipLaunchKernelGGL(residual_mlp_adjoint_kernel, dim3(kMlpAdjointBlocks), dim3(kWave), adjoint_lds, s, field->instances,
+                           field->mlp_weights, N, mlp_bits, seeds, masks, p.slots_per_instance, used_slots, p.items_per_instance, p.slots_per_item,
+                           counter, item_rows, item_flags);
+        hipLaunchKernelGGL(reduce_item_rows_kernel, dim3(N, (kItemRowFloats + 255) / 256, kItemSegments), dim3(256), 0, s, item_rows, item_flags,
+                           p.items_per_instance, segment_sums);
+        hipLaunchKernelGGL(reduce_item_segments_kernel, dim3(N, (kItemRowFloats + 255) / 256), dim3(256), 0, s, segment_sums, grad_mlp_weights, box_extra,
+                           chunk_index > 0 ? 1 : 0);
+        if (launch_status() != VSRD_OK) return VSRD_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(row), dim3(256), 0, s, box_partials, p.front_waves, row, grad_instances, box_extra);
+    return launch_status();
+}
+
 }  // namespace
+
+size_t vsrd_render_backward_workspace_bytes(int32_t num_instances, int32_t residual, int32_t num_distances, int32_t num_rays) {
+    if (num_instances < 1 || num_instances > VSRD_MAX_INSTANCES || num_distances < 2 || num_distances > 2 * VSRD_MAX_SAMPLES || num_rays < 0) return 0;
+    size_t need = vsrd_workspace_bytes(num_instances, residual);
+    ResidualStepPlan p;
+    if (residual && num_rays > 0 && plan_backward_split(num_instances, num_distances, num_rays, ~size_t(0), &p) && p.total_bytes > need) need = p.total_bytes;
+    return need;
+}
 
 size_t vsrd_residual_step_workspace_bytes(int32_t num_instances, int32_t num_samples, int32_t num_rays) {
     if (num_instances < 1 || num_instances > VSRD_MAX_INSTANCES || num_samples < 2 || num_samples > VSRD_MAX_SAMPLES || num_rays < 0) return 0;

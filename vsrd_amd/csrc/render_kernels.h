@@ -1037,6 +1037,70 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(k
     }
 }
 
+// vsrd_render_backward for RESIDUAL fields as two kernels per chunk of rays (round 3; what an unchanged main.py reaches through
+// hierarchical_volumetric_rendering(...).backward(), scripts/main.py:511-523, 629-687): this front part -- forward sweep at the saved
+// distances, reverse sweep on the incoming adjoints (labels, SDF gradients for the eikonal term, weights), per-instance box adjoint --
+// leaves the MLP adjoint's seeds in the dense table, and residual_mlp_adjoint_kernel runs them by instance over the whole chunk, exactly
+// as in vsrd_render_residual_step.  render_backward_kernel<K, true> kept the r01 structure (seeds in wave-private batches, the MLP
+// adjoint in the same kernel: 393 registers, one wave per SIMD); it remains the fallback when the workspace cannot hold a chunk.
+__host__ __device__ constexpr int backward_front_lds_floats(int num_distances, int num_instances) {
+    return (kMlpWbarFloats + num_distances + num_instances + num_instances * kGradStride + cull_coef_floats(num_instances) + 3) & ~3;
+}
+
+template <int kRounds>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(kRounds <= 2 ? 2 : 1, 2))) void render_backward_front_kernel(
+    FieldArgs f, const float* __restrict__ instances, const float* __restrict__ mlp, RenderArgs c,
+    const float* __restrict__ origins, const float* __restrict__ directions, const float* __restrict__ distances, int num_distances,
+    const float* __restrict__ grad_labels, const float* __restrict__ grad_gradients, const float* __restrict__ grad_weights,
+    float* __restrict__ partials, float4* __restrict__ residual_cache, float* __restrict__ seed_table, unsigned char* __restrict__ mask_table,
+    long long slots_per_instance, int chunk_base, int chunk_rays, int accumulate) {
+    apply_device_schedule(f, c);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = wave_in_block();
+    const int lane = lane_id();
+    const int N = f.num_instances;
+    const int num_points = num_distances - 1;
+    float* mine = lds + wave * backward_front_lds_floats(num_distances, N);
+    float* dist = mine + kMlpWbarFloats;
+    float* lam = dist + num_distances;
+    float* G = lam + N;
+    float* coef = G + N * kGradStride;
+    const size_t wave_global = static_cast<size_t>(blockIdx.x) * waves_per_block() + wave;
+    float* out = partials + wave_global * (N * kGradStride);
+    for (int idx = lane; idx < N * kGradStride; idx += kWave) G[idx] = accumulate ? out[idx] : 0.0f;      // chunks of one call add up
+    float4* rcache = residual_cache + wave_global * (static_cast<size_t>(kRounds) * N * kWave);
+    Shading sh = c.sh;
+    sh.mlp_lds = mine;
+    const FieldBounds bounds = field_bounds(instances, N, f.inv_t, true, c.flags);
+    sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
+    sh.mlp_bits = (c.flags & 8u) ? kMlpCentredBit : 0u;
+    const int stride = static_cast<int>(gridDim.x) * waves_per_block();
+    for (int local = static_cast<int>(wave_global); local < chunk_rays; local += stride) {
+        const int ray = chunk_base + local;
+        wave_lds_sync();
+        const float lam_lane = (lane < N) ? grad_labels[static_cast<size_t>(ray) * N + lane] : 0.0f;
+        if (grad_gradients == nullptr && grad_weights == nullptr && wave_max(fabsf(lam_lane)) == 0.0f) continue;   // nothing flows back (masks stay 0)
+        const Ray r = load_ray(origins, directions, c.origin_stride, ray);
+        const float* src = distances + static_cast<size_t>(ray) * num_distances;
+        for (int idx = lane; idx < num_distances; idx += kWave) dist[idx] = src[idx];
+        if (lane < N) lam[lane] = lam_lane;
+        const RayCull rc = cull_ray_setup(instances, N, r.ox, r.oy, r.oz, r.rx, r.ry, r.rz, coef, lane);           // (syncs the wave's LDS)
+        if (dist[0] != dist[0]) continue;                                    // NaN sentinel: ray skipped by the forward
+        RayAdjoint<kRounds> st;
+        adjoint_forward_sweep<kRounds, true, false>(st, instances, mlp, N, sh, r, rc, dist, num_points, lam, nullptr, lane, rcache);
+        const float* gw_row = grad_weights ? grad_weights + static_cast<size_t>(ray) * num_points : nullptr;
+        const float* gg_row = grad_gradients ? grad_gradients + static_cast<size_t>(ray) * num_points * 3 : nullptr;
+        if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, gw_row, gg_row, lane)) continue;
+        const long long slot0 = static_cast<long long>(local) * kRounds;
+        const SeedSink sink = {seed_table + slot0 * (kSeedFloats * kWave), slots_per_instance * (kSeedFloats * kWave), static_cast<long long>(kSeedFloats) * kWave,
+                               nullptr, mask_table + slot0, slots_per_instance, 1};
+        if (sh.yaw) adjoint_phase_b<kRounds, true, true>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink);
+        else adjoint_phase_b<kRounds, true, false>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink);
+    }
+    wave_lds_sync();
+    for (int idx = lane; idx < N * kGradStride; idx += kWave) out[idx] = G[idx];
+}
+
 // The front kernel with a ray split over the two waves of a workgroup, each wave taking half of its rounds.  Used (api.hip:
 // plan_residual_step) for four-round launches (S in (64, 128], the reference's own S = 100: half the per-ray adjoint state per wave
 // fits 256 registers -- two waves per SIMD -- where residual_step_front_kernel<4> needs 308) and for small two-round launches (1000 rays

@@ -38,11 +38,14 @@ class Workspace:
         self._retired = []      # outgrown buffers that captured graphs may still reference (only kept when asked to)
         self.keep_outgrown = False
 
-    def adjoint(self, device, num_instances, residual=False, step_shape=None):
-        """``step_shape = (num_samples, num_rays)``: scratch of vsrd_render_residual_step for that launch (seeds of a chunk of rays)."""
+    def adjoint(self, device, num_instances, residual=False, step_shape=None, backward_shape=None):
+        """``step_shape = (num_samples, num_rays)``: scratch of vsrd_render_residual_step for that launch (seeds of a chunk of rays);
+        ``backward_shape = (num_distances, num_rays)``: scratch with which vsrd_render_backward runs its two-kernel form on residual fields."""
         need = _lib.load().vsrd_workspace_bytes(int(num_instances), 1 if residual else 0)
         if residual and step_shape is not None:
             need = max(need, _lib.load().vsrd_residual_step_workspace_bytes(int(num_instances), int(step_shape[0]), int(step_shape[1])))
+        if residual and backward_shape is not None:
+            need = max(need, _lib.load().vsrd_render_backward_workspace_bytes(int(num_instances), 1, int(backward_shape[0]), int(backward_shape[1])))
         buf = self._adjoint.get(device)
         if buf is None or buf.numel() < need:
             if buf is not None and self.keep_outgrown:
@@ -130,8 +133,8 @@ def _mlp_flag(centred_weights):
     return _lib.FLAG_MLP_WEIGHTS_CENTRED if centred_weights is not None else 0
 
 
-def _workspace(device, num_instances, residual=False, step_shape=None):
-    return current_workspace().adjoint(device, num_instances, residual, step_shape)
+def _workspace(device, num_instances, residual=False, step_shape=None, backward_shape=None):
+    return current_workspace().adjoint(device, num_instances, residual, step_shape, backward_shape)
 
 
 def _prepare_rays(ray_positions, ray_directions):
@@ -216,7 +219,7 @@ def _backward(instances, mlp_weights, origins, directions, distances, temperatur
     grad_weights = None if grad_weights is None else grad_weights.to(torch.float32).contiguous()
     grad_instances = torch.empty_like(instances)
     grad_mlp = None if mlp_weights is None else torch.empty_like(mlp_weights)
-    workspace = _workspace(distances.device, N, mlp_weights is not None)
+    workspace = _workspace(distances.device, N, mlp_weights is not None, backward_shape=(D, R))
     field = _lib.make_field(instances, temperature, mlp_weights)
     config = _lib.make_config(R, num_samples, (near, far), std, ratio, eps, origin_stride, flags=_base_flags() | _mlp_flag(mlp_weights),
                               schedule=schedule)
