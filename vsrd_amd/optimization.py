@@ -101,6 +101,8 @@ class FrameOptimizer:
 
     def __init__(self, inputs: FrameInputs, config: OptimizationConfig, device, graph=False, fused_glue=None):
         self.inputs, self.config, self.device = inputs, config, torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:      # the scratch buffers are keyed by device: one spelling of it
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.graph = bool(graph)
         self.fused_glue = self.graph if fused_glue is None else bool(fused_glue)
         if self.fused_glue and not self.graph:
@@ -124,6 +126,7 @@ class FrameOptimizer:
         # sizes it for the residual phase up front: a captured graph holds the buffer's address
         self.workspace = rendering.Workspace()
         if self.graph:
+            self.workspace.keep_outgrown = True          # a captured graph holds the buffer's address: an outgrown buffer must outlive it
             self.workspace.reserve(self.device, N, residual=True, step_shape=(config.num_samples, config.num_rays))
         self._graphs = {}
         self._capture_stream = None
@@ -164,7 +167,8 @@ class FrameOptimizer:
         frame.max_temperature, frame.min_temperature = cfg.max_sdf_union_temperature, cfg.min_sdf_union_temperature
         frame.max_std, frame.min_std = cfg.max_sdf_std_deviation, cfg.min_sdf_std_deviation
         frame.weight_iou, frame.weight_l1, frame.weight_silhouette = w["iou_projection_loss"], w["l1_projection_loss"], w["silhouette_loss"]
-        frame.beta1, frame.beta2, frame.adam_epsilon, frame.lr_gamma = 0.9, 0.999, 1.0e-8, cfg.lr_gamma
+        betas, eps = self.optimizer.param_groups[0]["betas"], self.optimizer.param_groups[0]["eps"]      # the box tensors' Adam constants
+        frame.beta1, frame.beta2, frame.adam_epsilon, frame.lr_gamma = float(betas[0]), float(betas[1]), float(eps), cfg.lr_gamma
         self._frame = frame
         f32 = dict(dtype=torch.float32, device=dev)
         b = self._glue = {}
@@ -329,6 +333,9 @@ class FrameOptimizer:
                                        anneal * (cfg.max_sdf_std_deviation - cfg.min_sdf_std_deviation) + cfg.min_sdf_std_deviation, x]))
 
     def _graph_step(self, ray_indices):
+        if ray_indices is not None and int(ray_indices.numel()) > self.config.num_rays:
+            # the captured graphs hold the address of scratch sized for config.num_rays rays; a larger launch would outgrow it
+            raise ValueError(f"graph mode replays steps of at most config.num_rays = {self.config.num_rays} rays, got {int(ray_indices.numel())}")
         """Three eager steps per (phase, ray source) on a side stream warm the allocator and the lazy initialisations, then the step is
         captured once and replayed.  The eager steps run the same device-side code, so they are ordinary optimisation steps."""
         residual = self.step_index >= self.config.warmup_steps
@@ -434,7 +441,13 @@ class FrameOptimizer:
             return self.detector()
 
     def close(self):
-        """Drop the captured graphs and the scratch buffers (also happens when the optimizer is garbage-collected)."""
+        """Drop the captured graphs and the scratch buffers (also happens when the optimizer is garbage-collected).  Once per frame
+        this is also where the device ray sampler's sticky overflow flag is read back (a host synchronisation, so not per step): a
+        draw whose threshold bin held more candidate keys than the sampler lists was incomplete and not reproducible."""
+        if self.graph and self.workspace.sampler_overflowed(self.device):
+            import warnings
+            warnings.warn("vsrd_sample_rays overflowed its candidate list in some step of this frame: those draws were incomplete "
+                          "(many equal importance weights in one histogram bin); see csrc/ray_sampling.h", RuntimeWarning)
         self._graphs.clear()
         self.workspace.release()
 
