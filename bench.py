@@ -55,6 +55,8 @@ def parse_args(argv=None):
                         help="render forward, torch loss, render backward as separate launches instead of the fused step kernel")
     parser.add_argument("--no-culling", action="store_true", help="VSRD_FLAG_NO_CULLING: every instance at every sample (worst case)")
     parser.add_argument("--no-skip-misses", action="store_true")
+    parser.add_argument("--wave-per-ray", action="store_true",
+                        help="VSRD_FLAG_STEP_WAVE_PER_RAY: one ray per wave for the fused box-only step (A/B against four rays per wave)")
     parser.add_argument("--cpu-rays", type=int, default=0, help="rays of the CPU-baseline sample (default 16384; 1408 with --residual)")
     parser.add_argument("--cpu-chunk", type=int, default=0, help="rays per oracle call (default: one image row; 352 with --residual)")
     parser.add_argument("--cpu-threads", type=int, default=16)   # best of {8,16,32,64} on the 2x64-core EPYC 9575F GPU host (r01)
@@ -79,7 +81,7 @@ def workload_key(args):
     """Identifies the per-launch work: a committed rocprof summary is only quoted for the workload it was measured on."""
     return (f"V{args.views}_H{args.height}_W{args.width}_N{args.instances}_S{args.samples}_{args.schedule}_"
             f"{'residual' if args.residual else 'box'}_{'twolaunch' if args.two_launch else 'fused'}"
-            f"{'_nocull' if args.no_culling else ''}{'_noskip' if args.no_skip_misses else ''}")
+            f"{'_nocull' if args.no_culling else ''}{'_noskip' if args.no_skip_misses else ''}{'_waveperray' if args.wave_per_ray else ''}")
 
 
 def describe_workload(args):
@@ -352,6 +354,7 @@ def run_rank(args):
         from vsrd_amd import models, rendering, profiling
         from vsrd_amd.rendering import renderers
         renderers.CULLING = not args.no_culling
+        renderers.STEP_WAVE_PER_RAY = renderers.STEP_WAVE_PER_RAY or args.wave_per_ray
         # one frame per rank, and every rank a replica of the same synthetic frame (the scaling curve then isolates the
         # launcher; frames of a real shard differ in cost, which is load imbalance, not scaling); the Philox streams differ by rank
         frame = synthetic_frame(seed=0, num_views=V, height=H, width=W, num_instances=N)
@@ -465,7 +468,7 @@ def run_rank(args):
                 result["cpu_baseline"] = cpu_baseline(args, sched, frame, lambda a, b: targets[a:b].cpu(), hyper_state,
                                                       min(args.cpu_threads, os.cpu_count() or 1))
             default_workload = (V, H, W, N, S) == (9, 376, 1408, 16, 64) and not args.residual and fused and args.schedule == "mid" \
-                and not args.no_culling and not args.no_skip_misses
+                and not args.no_culling and not args.no_skip_misses and not args.wave_per_ray
             if world == 1 and default_workload and not args.no_extra_regimes:
                 del targets, directions, origins
                 torch.cuda.empty_cache()

@@ -33,7 +33,7 @@ def run(cmd, timeout):
 
 def main():
     parser = argparse.ArgumentParser()
-    parser.add_argument("--tag", default="r02")
+    parser.add_argument("--tag", default="r03")
     parser.add_argument("--quick", action="store_true", help="skip the two multi-second-per-step full-size runs (C3, C5)")
     args = parser.parse_args()
     out_dir = os.path.join(ROOT, "gpurun_out", args.tag)
@@ -47,6 +47,7 @@ def main():
              ("C2 end, no culling", ["--steps", "5", "--warmup", "1", "--schedule", "end", "--no-culling"]),
              ("C2 mid, exact misses not skipped", ["--steps", "5", "--warmup", "1", "--no-skip-misses"]),
              ("C2 mid, two-launch (API-faithful) path", ["--steps", "5", "--warmup", "1", "--two-launch"]),
+             ("C2 mid, one ray per wave (VSRD_STEP_WAVE_PER_RAY=1: the round-2 mapping)", ["--steps", "10", "--warmup", "2", "--wave-per-ray"]),
              ("C3-shaped frame (1 view 188x704, residual)", ["--steps", "5", "--warmup", "1", "--residual", "--views", "1", "--height", "188", "--width", "704"])]
     if not args.quick:
         dense += [("C3 full size (residual)", ["--steps", "2", "--warmup", "1", "--residual"]),

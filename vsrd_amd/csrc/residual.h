@@ -481,6 +481,11 @@ VSRD_RESIDUAL_FN Residual residual_forward(const float* w_in, float px, float py
     wave_lds_order();                                            // (the previous call's operand reads are done)
     stage_centred_weights_wave(staged, uniform_weights_generic(w_in), (tiles & kMlpCentredBit) != 0u, lane);
     wave_lds_order();
+#ifdef VSRD_PROBE_STAGE_TWICE          // probe: what one staging costs (the difference to the normal build)
+    asm volatile("" ::: "memory");
+    stage_centred_weights_wave(staged, uniform_weights_generic(w_in) + (tiles >> 30), (tiles & kMlpCentredBit) != 0u, lane);
+    wave_lds_order();
+#endif
     const LdsWeights wt = {staged, g, lane & 15};
     const float fold = (px > 0.0f) ? 1.0f : ((px < 0.0f) ? -1.0f : 0.0f);
     const float inv = 1.0f / kPositionScale;
