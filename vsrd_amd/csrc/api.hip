@@ -529,10 +529,14 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
     if (rounds < 1 || rounds > 4) return VSRD_E_UNSUPPORTED;
     // dense launches of the benchmark shapes: four neighbouring rays per wave (quad_step.h).  Gathered rays (the reference's 1000
     // importance-sampled rays per step) are neither neighbours nor enough to fill the chip four to a wave.
-    const bool quad = S <= kQuadMaxSamples && N <= kQuadMaxInstances && config->ray_indices == nullptr && !(config->flags & VSRD_FLAG_STEP_WAVE_PER_RAY);
+    const bool dense = config->ray_indices == nullptr && !(config->flags & VSRD_FLAG_STEP_WAVE_PER_RAY);
+    const bool quad = dense && S <= kQuadMaxSamples && N <= kQuadMaxInstances;
+    // ... and for more instances or samples than that (BASELINE config 5: N = 64, S = 128) two rays per wave, 32 lanes each
+    const bool pair = dense && !quad && S <= kPairMaxSamples && N <= kPairMaxInstances;
+    const int lanes = quad ? kRowLanes : 32, rays_per_wave = kWave / lanes;
     Geometry g;
-    const size_t per_wave = quad ? static_cast<size_t>(quad_lds_floats(S, N)) : static_cast<size_t>(wave_lds_floats(S, N)) + N + row;
-    if (!plan(quad ? (config->num_rays + kQuadRays - 1) / kQuadRays : config->num_rays, per_wave, &g)) return VSRD_E_UNSUPPORTED;
+    const size_t per_wave = (quad || pair) ? static_cast<size_t>(quad_lds_floats(S, N, lanes)) : static_cast<size_t>(wave_lds_floats(S, N)) + N + row;
+    if (!plan((quad || pair) ? (config->num_rays + rays_per_wave - 1) / rays_per_wave : config->num_rays, per_wave, &g)) return VSRD_E_UNSUPPORTED;
     // the partial buffer holds one gradient row per wave; the loss partials live in the tail of the same row budget
     const int max_waves_for_loss = static_cast<int>(vsrd_workspace_bytes(N, 0) / sizeof(float) / (row + 1));
     if (g.blocks * (g.threads / kWave) > max_waves_for_loss) g.blocks = max_waves_for_loss / (g.threads / kWave);
@@ -556,10 +560,20 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
                            origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, labels, partials,        \
                            loss_partials);                                                                                       \
     } while (0)
+#define VSRD_LAUNCH_PAIR(K)                                                                                                     \
+    do {                                                                                                                          \
+        if (opt_in_lds(render_silhouette_pair_kernel<K>, g.lds_bytes) != VSRD_OK) return VSRD_E_LAUNCH;                          \
+        hipLaunchKernelGGL(render_silhouette_pair_kernel<K>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, \
+                           origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, labels, partials,        \
+                           loss_partials);                                                                                       \
+    } while (0)
     if (quad) {
         if (S <= 16) VSRD_LAUNCH_QUAD(1);
         else if (S <= 32) VSRD_LAUNCH_QUAD(2);
         else VSRD_LAUNCH_QUAD(4);
+    } else if (pair) {
+        if (S <= 64) VSRD_LAUNCH_PAIR(2);
+        else VSRD_LAUNCH_PAIR(4);
     } else {
         switch (rounds) {
             case 1: VSRD_LAUNCH(1); break;
@@ -570,6 +584,7 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
     }
 #undef VSRD_LAUNCH
 #undef VSRD_LAUNCH_QUAD
+#undef VSRD_LAUNCH_PAIR
     if (launch_status() != VSRD_OK) return VSRD_E_LAUNCH;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(row + 1), dim3(256), 0, s, partials, num_waves, row, grad_instances, nullptr, loss_partials, 1, loss);
     return launch_status();

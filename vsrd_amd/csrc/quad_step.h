@@ -16,73 +16,101 @@
 
 namespace vsrd {
 
-constexpr int kQuadRays = 4;             // rays per wave
-constexpr int kRowLanes = 16;            // lanes (sample points) per ray and round
-constexpr int kQuadMaxInstances = 16;    // lane (ray, n) owns label n of its ray
+constexpr int kQuadRays = 4;             // rays per wave of the 16-lane shape (BASELINE config 2)
+constexpr int kRowLanes = 16;
+constexpr int kQuadMaxInstances = 16;    // 16-lane shape: lane (ray, n) owns label n of its ray
 constexpr int kQuadMaxSamples = 64;
+constexpr int kPairMaxInstances = 64;    // 32-lane shape (two rays per wave): lane (ray, c) owns labels c and 32 + c
+constexpr int kPairMaxSamples = 128;
 
-// ---- 16-lane row primitives (DPP; every lane of a row receives the row's result) --------------------------------------------------
+// ---- primitives over the kL lanes of one ray (kL = 16: a DPP row; kL = 32: two rows); every lane receives its ray's result -------------
 constexpr int kDppRowShl1 = 0x101, kDppRowShl2 = 0x102, kDppRowShl4 = 0x104, kDppRowShl8 = 0x108;
 
-__device__ __forceinline__ float row_sum(float v) {
-    v += dpp_move<kDppQuadXor1>(0.0f, v);
-    v += dpp_move<kDppQuadXor2>(0.0f, v);
-    v += dpp_move<kDppRowHalfMirror>(0.0f, v);
-    v += dpp_move<kDppRowMirror>(0.0f, v);
-    return v;
+__device__ __forceinline__ float max_xor16(float v) {          // max with the lane 16 away (wave.h: add_xor16)
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
 }
-__device__ __forceinline__ float row_max(float v) {
-    v = fmaxf(v, dpp_move<kDppQuadXor1>(v, v));
-    v = fmaxf(v, dpp_move<kDppQuadXor2>(v, v));
-    v = fmaxf(v, dpp_move<kDppRowHalfMirror>(v, v));
-    v = fmaxf(v, dpp_move<kDppRowMirror>(v, v));
-    return v;
-}
-__device__ __forceinline__ float row_inclusive_sum(float v) {          // prefix over the row, lane 0 of the row first
-    v += dpp_move<kDppRowShr1>(0.0f, v);
-    v += dpp_move<kDppRowShr2>(0.0f, v);
-    v += dpp_move<kDppRowShr4>(0.0f, v);
-    v += dpp_move<kDppRowShr8>(0.0f, v);
-    return v;
-}
-__device__ __forceinline__ float row_inclusive_product(float v) {
-    v *= dpp_move<kDppRowShr1>(1.0f, v);
-    v *= dpp_move<kDppRowShr2>(1.0f, v);
-    v *= dpp_move<kDppRowShr4>(1.0f, v);
-    v *= dpp_move<kDppRowShr8>(1.0f, v);
-    return v;
-}
-__device__ __forceinline__ float row_inclusive_max(float v) {
-    v = fmaxf(v, dpp_move<kDppRowShr1>(v, v));
-    v = fmaxf(v, dpp_move<kDppRowShr2>(v, v));
-    v = fmaxf(v, dpp_move<kDppRowShr4>(v, v));
-    v = fmaxf(v, dpp_move<kDppRowShr8>(v, v));
-    return v;
-}
-__device__ __forceinline__ float row_suffix_sum(float v) {             // inclusive sum over this and the LATER lanes of the row
-    v += dpp_move<kDppRowShl1>(0.0f, v);
-    v += dpp_move<kDppRowShl2>(0.0f, v);
-    v += dpp_move<kDppRowShl4>(0.0f, v);
-    v += dpp_move<kDppRowShl8>(0.0f, v);
-    return v;
-}
-// value of the previous lane of the row, `first` for the row's lane 0
-__device__ __forceinline__ float row_shift_up(float v, float first) { return dpp_move<kDppRowShr1>(first, v); }
-// value of a fixed lane of the row (byte address of that lane for ds_bpermute: RowLanes::first / ::last)
+// value of a fixed lane of the wave (byte address of that lane for ds_bpermute: RowLanes::first / ::last)
 __device__ __forceinline__ float lane_gather(float v, int byte_address) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_address, __builtin_bit_cast(int, v)));
 }
 
 struct RowLanes {
-    int lane, row, col;
-    int first, last;          // ds_bpermute addresses of the row's lane 0 / lane 15
+    int lane, row, col;       // row = ray of the wave, col = lane within the ray
+    int first, last;          // ds_bpermute addresses of the ray's first / last lane
 };
+template <int kL>
 __device__ __forceinline__ RowLanes row_lanes(int lane) {
     RowLanes r;
-    r.lane = lane; r.row = r.lane >> 4; r.col = r.lane & 15;
-    r.first = (r.lane & 48) << 2; r.last = (r.lane | 15) << 2;
+    r.lane = lane; r.row = r.lane / kL; r.col = r.lane % kL;
+    r.first = (r.lane & ~(kL - 1)) << 2; r.last = (r.lane | (kL - 1)) << 2;
     return r;
 }
+
+template <int kL>
+__device__ __forceinline__ float seg_sum(float v) {
+    v += dpp_move<kDppQuadXor1>(0.0f, v);
+    v += dpp_move<kDppQuadXor2>(0.0f, v);
+    v += dpp_move<kDppRowHalfMirror>(0.0f, v);
+    v += dpp_move<kDppRowMirror>(0.0f, v);
+    return kL == 32 ? add_xor16(v) : v;
+}
+template <int kL>
+__device__ __forceinline__ float seg_max(float v) {
+    v = fmaxf(v, dpp_move<kDppQuadXor1>(v, v));
+    v = fmaxf(v, dpp_move<kDppQuadXor2>(v, v));
+    v = fmaxf(v, dpp_move<kDppRowHalfMirror>(v, v));
+    v = fmaxf(v, dpp_move<kDppRowMirror>(v, v));
+    return kL == 32 ? max_xor16(v) : v;
+}
+template <int kL>
+__device__ __forceinline__ float seg_inclusive_sum(float v) {          // prefix over the ray's lanes, its first lane first
+    v += dpp_move<kDppRowShr1>(0.0f, v);
+    v += dpp_move<kDppRowShr2>(0.0f, v);
+    v += dpp_move<kDppRowShr4>(0.0f, v);
+    v += dpp_move<kDppRowShr8>(0.0f, v);
+    if (kL == 32) v += dpp_move<kDppRowBcast15, 0xa>(0.0f, v);         // rows 1, 3 += the last lane of rows 0, 2
+    return v;
+}
+template <int kL>
+__device__ __forceinline__ float seg_inclusive_product(float v) {
+    v *= dpp_move<kDppRowShr1>(1.0f, v);
+    v *= dpp_move<kDppRowShr2>(1.0f, v);
+    v *= dpp_move<kDppRowShr4>(1.0f, v);
+    v *= dpp_move<kDppRowShr8>(1.0f, v);
+    if (kL == 32) v *= dpp_move<kDppRowBcast15, 0xa>(1.0f, v);
+    return v;
+}
+template <int kL>
+__device__ __forceinline__ float seg_inclusive_max(float v) {
+    v = fmaxf(v, dpp_move<kDppRowShr1>(v, v));
+    v = fmaxf(v, dpp_move<kDppRowShr2>(v, v));
+    v = fmaxf(v, dpp_move<kDppRowShr4>(v, v));
+    v = fmaxf(v, dpp_move<kDppRowShr8>(v, v));
+    if (kL == 32) v = fmaxf(v, dpp_move<kDppRowBcast15, 0xa>(v, v));
+    return v;
+}
+template <int kL>
+__device__ __forceinline__ float seg_suffix_sum(float v, const RowLanes& rl) {     // inclusive sum over this and the LATER lanes of the ray
+    v += dpp_move<kDppRowShl1>(0.0f, v);
+    v += dpp_move<kDppRowShl2>(0.0f, v);
+    v += dpp_move<kDppRowShl4>(0.0f, v);
+    v += dpp_move<kDppRowShl8>(0.0f, v);
+    if (kL == 32) {                                                                // the first row of the ray += the second row's total
+        const float upper = lane_gather(v, ((rl.lane | 31) - 15) << 2);           // lane 16 of the ray holds its second row's total
+        v += (rl.col < 16) ? upper : 0.0f;
+    }
+    return v;
+}
+// value of the previous lane of the ray, `first` for the ray's first lane
+template <int kL>
+__device__ __forceinline__ float seg_shift_up(float v, float first, const RowLanes& rl) {
+    if (kL == 16) return dpp_move<kDppRowShr1>(first, v);
+    const float previous = lane_gather(v, (rl.lane - 1) << 2);
+    return rl.col == 0 ? first : previous;
+}
+
 // The lane id as a value the optimiser cannot see through: what is derived from it inside a loop iteration (LDS addresses, sample
 // indices, stratification bounds ...) is re-derived there in a few integer instructions instead of being hoisted out of the loop
 // and held -- or spilled -- over all of it (render_silhouette_quad_kernel: ~50 such registers).
@@ -101,33 +129,36 @@ __device__ __forceinline__ int opaque_lane_id() {
 // After importance_merge the coarse | fine part of a row holds, per pass-2 point, first the transmittance (forward sweep -> reverse
 // sweep) and then the interval mid-point (reverse sweep -> per-instance phase); the reverse sweep also turns merged[s + 1] into C2 of
 // point s once the distances of its round have been read (the rounds run backwards, so merged[16 q] stays for round q - 1).
-__host__ __device__ constexpr int quad_row_floats(int num_samples) { return 4 * num_samples + kRowLanes + 4; }   // (+ 4: C2 of the last point, below)
-__host__ __device__ constexpr int quad_merged_offset(int num_samples) { return 2 * num_samples + kRowLanes; }
+__host__ __device__ constexpr int quad_row_floats(int num_samples, int lanes = kRowLanes) { return 4 * num_samples + lanes + 4; }   // (+ 4: C2 of the last point, below)
+__host__ __device__ constexpr int quad_merged_offset(int num_samples, int lanes = kRowLanes) { return 2 * num_samples + lanes; }
 __host__ __device__ constexpr int quad_coef_floats(int num_instances) { return kCullCoefs * num_instances + 4; }
-__host__ __device__ constexpr int quad_rounds_s(int num_samples) { return num_samples <= 16 ? 1 : (num_samples <= 32 ? 2 : 4); }   // rounds of 16 coarse points
-__host__ __device__ constexpr int quad_cache_rows(int num_samples, int num_instances) {        // [rows][64]: soft-min terms of a round, later C1 / C3 of every pass-2 round
-    return num_instances > 4 * quad_rounds_s(num_samples) ? num_instances : 4 * quad_rounds_s(num_samples);
+__host__ __device__ constexpr int quad_rounds_s(int num_samples, int lanes = kRowLanes) {          // rounds of `lanes` coarse points: 1, 2 or 4
+    return num_samples <= lanes ? 1 : (num_samples <= 2 * lanes ? 2 : 4);
 }
-__host__ __device__ constexpr int quad_lds_floats(int num_samples, int num_instances) {
-    return kQuadRays * quad_row_floats(num_samples) + quad_cache_rows(num_samples, num_instances) * kWave + kQuadRays * quad_coef_floats(num_instances) + kQuadRays * 8;
+constexpr int kCacheSlots = 16;          // shapes with more instances than lanes per ray: soft-min terms of the first 16 survivors of a round
+__host__ __device__ constexpr int quad_cache_rows(int num_samples, int num_instances, int lanes = kRowLanes) {   // [rows][64]: soft-min terms of a round, later C1 / C3 of every pass-2 round
+    return lanes == kRowLanes ? (num_instances > 4 * quad_rounds_s(num_samples, lanes) ? num_instances : 4 * quad_rounds_s(num_samples, lanes)) : kCacheSlots;
+}
+__host__ __device__ constexpr int quad_lds_floats(int num_samples, int num_instances, int lanes = kRowLanes) {
+    return (kWave / lanes) * (quad_row_floats(num_samples, lanes) + quad_coef_floats(num_instances) + 8) + quad_cache_rows(num_samples, num_instances, lanes) * kWave;
 }
 
 // Stratified distances and sorted fine uniforms of the lane's ray (render_kernels.h: stage_ray_samples, per 16-lane row).
-template <int kRoundsS>
+template <int kL, int kRoundsS>
 __device__ __forceinline__ void quad_stage_samples(float* rowbase, const RenderArgs& c, int S, int ray, const float* __restrict__ u_coarse,
                                                    const float* __restrict__ u_fine, bool sorted_input, const RowLanes& rl) {
     float* coarse = rowbase;
     float* usorted = rowbase + S;
-    float* uraw = rowbase + quad_merged_offset(S);
+    float* uraw = rowbase + quad_merged_offset(S, kL);
     const size_t urow = static_cast<size_t>(ray) * S;
     const bool philox = (u_coarse == nullptr || u_fine == nullptr);
     float spacing[kRoundsS];
     float running = 0.0f, extra_spacing = 0.0f;
 #pragma unroll
     for (int k = 0; k < kRoundsS; ++k) {
-        const int idx = k * kRowLanes + rl.col;
+        const int idx = k * kL + rl.col;
         spacing[k] = 0.0f;
-        if (k * kRowLanes >= S) continue;
+        if (k * kL >= S) continue;
         float uc = 0.0f, uf = 0.0f;
         if (philox) {
             const Philox4 rnd = philox4x32_10(static_cast<uint32_t>(ray), static_cast<uint32_t>(idx),
@@ -147,7 +178,7 @@ __device__ __forceinline__ void quad_stage_samples(float* rowbase, const RenderA
         }
         if (u_fine == nullptr) {
             const float e = valid ? -fast_log(1.0f - uf) : 0.0f;
-            const float inclusive = row_inclusive_sum(e) + running;
+            const float inclusive = seg_inclusive_sum<kL>(e) + running;
             spacing[k] = inclusive;
             running = lane_gather(inclusive, rl.last);
         } else if (valid) {
@@ -158,7 +189,7 @@ __device__ __forceinline__ void quad_stage_samples(float* rowbase, const RenderA
         const float inv_total = fast_rcp(running + extra_spacing);
 #pragma unroll
         for (int k = 0; k < kRoundsS; ++k) {
-            const int idx = k * kRowLanes + rl.col;
+            const int idx = k * kL + rl.col;
             if (idx < S) usorted[idx] = fminf(spacing[k] * inv_total, 0.99999994f);
         }
     }
@@ -166,8 +197,8 @@ __device__ __forceinline__ void quad_stage_samples(float* rowbase, const RenderA
     if (u_fine != nullptr && !sorted_input) {             // rank sort of the row's raw draws (parity tests, the API-faithful path)
 #pragma unroll
         for (int k = 0; k < kRoundsS; ++k) {
-            if (k * kRowLanes >= S) continue;
-            const int idx = k * kRowLanes + rl.col;
+            if (k * kL >= S) continue;
+            const int idx = k * kL + rl.col;
             const bool valid = idx < S;
             const float v = uraw[valid ? idx : 0];
             int rank = 0;
@@ -198,24 +229,30 @@ __device__ __forceinline__ int count_below_64(const float* a, int n, float v) {
     return min(pos, n);
 }
 
+template <int kL, bool kStrict>
+__device__ __forceinline__ int seg_count_below(const float* a, int n, float v) {
+    if (kL == kRowLanes) return count_below_64<kStrict>(a, n, v);                 // S <= 64
+    return count_below<kStrict>(a, n, v, search_iterations(n));                    // render.h: any n
+}
+
 // samplers.py:11-36 + renderers.py:198-210 for the lane's ray (render.h: importance_merge, per row): w[k] = coarse weight of point
 // k * 16 + col (0 beyond S - 2); on return merged[0..2S) is the sorted union of the coarse and the fine distances.
-template <int kRoundsS>
+template <int kL, int kRoundsS>
 __device__ __forceinline__ void quad_importance_merge(float* rowbase, int S, const float (&w)[kRoundsS], const RowLanes& rl) {
     float* coarse = rowbase;
     float* fine = rowbase + S;                    // holds the sorted uniforms on entry: lane j turns u[j] into fine[j] in place
-    float* merged = rowbase + quad_merged_offset(S);
+    float* merged = rowbase + quad_merged_offset(S, kL);
     float* cdf = merged + S;                      // dead before the merge writes there
     float total = 0.0f;
 #pragma unroll
-    for (int k = 0; k < kRoundsS; ++k) total += row_sum(fabsf(w[k]));
+    for (int k = 0; k < kRoundsS; ++k) total += seg_sum<kL>(fabsf(w[k]));
     const float denom = fmaxf(total, 1.0e-12f);
     float running = 0.0f;
 #pragma unroll
     for (int k = 0; k < kRoundsS; ++k) {
-        if (k * kRowLanes >= S - 1) continue;
-        const int idx = k * kRowLanes + rl.col;
-        const float inclusive = row_inclusive_sum(w[k] / denom) + running;
+        if (k * kL >= S - 1) continue;
+        const int idx = k * kL + rl.col;
+        const float inclusive = seg_inclusive_sum<kL>(w[k] / denom) + running;
         if (idx < S - 1) cdf[idx + 1] = inclusive;
         running = lane_gather(inclusive, rl.last);
     }
@@ -224,17 +261,17 @@ __device__ __forceinline__ void quad_importance_merge(float* rowbase, int S, con
     float fine_max = -3.0e38f;
 #pragma unroll
     for (int k = 0; k < kRoundsS; ++k) {
-        if (k * kRowLanes >= S) continue;
-        const int j = k * kRowLanes + rl.col;
+        if (k * kL >= S) continue;
+        const int j = k * kL + rl.col;
         const bool valid = j < S;
         const float u = fine[valid ? j : (S - 1)];
-        int upper = count_below_64<true>(cdf, S, u);
+        int upper = seg_count_below<kL, true>(cdf, S, u);
         upper = min(max(upper, 1), S - 1);
         const float c_lo = cdf[upper - 1], c_hi = cdf[upper];
         const float b_lo = coarse[upper - 1], b_hi = coarse[upper];
         const float t = (u - c_lo) / (c_hi - c_lo + 1.0e-6f);
         float sample = torch_lerp(b_lo, b_hi, t);
-        const float scan = row_inclusive_max(valid ? sample : -3.0e38f);     // running maximum: see render.h
+        const float scan = seg_inclusive_max<kL>(valid ? sample : -3.0e38f);     // running maximum: see render.h
         sample = fmaxf(scan, fine_max);
         fine_max = fmaxf(fine_max, lane_gather(scan, rl.last));
         wave_lds_sync();                                                     // (padding lanes read the last lane's uniform above)
@@ -243,13 +280,13 @@ __device__ __forceinline__ void quad_importance_merge(float* rowbase, int S, con
     wave_lds_sync();
 #pragma unroll
     for (int k = 0; k < kRoundsS; ++k) {
-        if (k * kRowLanes >= S) continue;
-        const int j = k * kRowLanes + rl.col;
+        if (k * kL >= S) continue;
+        const int j = k * kL + rl.col;
         const bool valid = j < S;
         const int jj = valid ? j : (S - 1);
         const float a = coarse[jj], b = fine[jj];
-        const int rank_a = jj + count_below_64<true>(fine, S, a);
-        const int rank_b = jj + count_below_64<false>(coarse, S, b);
+        const int rank_a = jj + seg_count_below<kL, true>(fine, S, a);
+        const int rank_b = jj + seg_count_below<kL, false>(coarse, S, b);
         if (valid) { merged[rank_a] = a; merged[rank_b] = b; }
     }
     wave_lds_sync();
@@ -275,9 +312,10 @@ __device__ __forceinline__ RayCull row_cull(const float* coef, const RowRay& r) 
 __device__ __forceinline__ void reload_fence() { asm volatile("" ::: "memory"); }
 
 // Culling coefficients of (lane's ray, instance col, col + 16, ...) (field.h: cull_ray_setup, per row) and the ray itself, into LDS.
+template <int kL>
 __device__ __forceinline__ void quad_ray_setup(const float* __restrict__ instances, int N, const Ray& r, float* coef, float* rayp, const RowLanes& rl) {
     float amax = 0.0f;
-    for (int i = rl.col; i < N; i += kRowLanes) {
+    for (int i = rl.col; i < N; i += kL) {
         const float* p = instances + i * kInstanceStride;
         const float ex = r.ox - p[0], ey = r.oy - p[1], ez = r.oz - p[2];
         const float a = ex * ex + ey * ey + ez * ez;
@@ -287,7 +325,7 @@ __device__ __forceinline__ void quad_ray_setup(const float* __restrict__ instanc
         coef[kCullCoefs * i + 3] = 0.0f;                                        // the ray's label adjoint of instance i, set after pass 2
         amax = fmaxf(amax, a);
     }
-    const float reach = fast_sqrt(fmaxf(row_max(amax), r.ox * r.ox + r.oy * r.oy + r.oz * r.oz));
+    const float reach = fast_sqrt(fmaxf(seg_max<kL>(amax), r.ox * r.ox + r.oy * r.oy + r.oz * r.oz));
     if (rl.col == 0) {
         *reinterpret_cast<float4*>(rayp) = make_float4(r.ox, r.oy, r.oz, r.rx);
         *reinterpret_cast<float4*>(rayp + 4) = make_float4(r.ry, r.rz, reach, 0.0f);
@@ -345,11 +383,14 @@ __device__ __forceinline__ bool quad_round_is_empty(const RayCull& rc, const Rou
 
 // The instance loop of one round (render.h: union_loop): the instances of `evaluated` that also pass the exact test; the soft-min
 // term of every surviving instance is left in dcache[i][lane] (fixed shift: exp(-(d_i - m)/T); running minimum: d_i).
-template <bool kCache, bool kRunning, bool kYaw>
+// kBySlot (shapes with up to 64 instances): the k-th surviving instance of the round takes cache row k while k < kCacheSlots; later
+// survivors are re-evaluated where their term is needed (quad_cached_term).
+template <bool kCache, bool kBySlot, bool kRunning, bool kYaw>
 __device__ __forceinline__ UnionSums quad_union_loop(const float* __restrict__ instances, unsigned long long& evaluated, const Shading& sh,
                                                      const RoundCull& cull, float floor, float x, float y, float z, float* dcache, int lane) {
     UnionSums sums = union_init(kRunning, floor);
     float best = cull.nearest_hi;
+    int slot = 0;
     for (unsigned long long todo = evaluated; todo != 0ull; todo &= todo - 1ull) {
         const int i = __builtin_ctzll(todo);
         const Instance in = load_instance(instances, i);
@@ -359,16 +400,29 @@ __device__ __forceinline__ UnionSums quad_union_loop(const float* __restrict__ i
         best = fminf(best, e.d);
         box_gradient<kYaw>(e, in);
         const float term = union_accumulate<kRunning, false>(sums, e.d, e.gwx, e.gwy, e.gwz, 0.0f, sh.inv_t);
-        if (kCache) dcache[i * kWave + lane] = term;
+        if (kCache && (!kBySlot || slot < kCacheSlots)) dcache[(kBySlot ? slot : i) * kWave + lane] = term;
+        ++slot;
     }
     return sums;
 }
 
+// The cached soft-min term of surviving instance i (the slot-th survivor of its round): exp(-(d_i - m)/T) (fixed shift) or d_i
+// (running minimum); survivors beyond the cache are re-evaluated.
+template <bool kBySlot, bool kRunning, bool kYaw>
+__device__ __forceinline__ float quad_cached_term(const float* __restrict__ instances, int i, int slot, const float* dcache, int lane, float x, float y, float z,
+                                                  float m, float inv_t) {
+    if (!kBySlot) return dcache[i * kWave + lane];
+    if (slot < kCacheSlots) return dcache[slot * kWave + lane];
+    const float d = box_value<kYaw>(load_instance(instances, i), x, y, z).d;
+    return kRunning ? d : fast_exp(-(d - m) * inv_t);
+}
+
 // One point per lane: the interval [dist[s], dist[s + 1]] of the lane's ray.
 struct QuadPoint { float delta, mid, x, y, z; bool valid; };
+template <int kL>
 __device__ __forceinline__ QuadPoint quad_point(const float* dist, int num_points, int round, const Ray& ray, bool live, const RowLanes& rl) {
     QuadPoint p;
-    const int s = round * kRowLanes + rl.col;
+    const int s = round * kL + rl.col;
     p.valid = live && s < num_points;
     const int s0 = (s < num_points) ? s : (num_points - 1);                    // padding lanes repeat the last point
     const float d0 = dist[s0], d1 = dist[s0 + 1];
@@ -381,7 +435,7 @@ __device__ __forceinline__ QuadPoint quad_point(const float* dist, int num_point
 // Pass 1 of the four rays: coarse compositing weights w[k] of point k * 16 + col (render.h: render_pass without labels).
 // Returns false when the fixed soft-min shift cannot serve some round (field.h: union_accumulate): the caller repeats the group with
 // the running minimum.
-template <int kRoundsS, bool kYaw, bool kRunning>
+template <int kL, int kRoundsS, bool kYaw, bool kRunning>
 __device__ __forceinline__ bool quad_pass_one(const float* __restrict__ instances, int N, const Shading& sh, const float* rayp, const float* coef,
                                               const float* coarse, int S, float (&w)[kRoundsS], const RowLanes& rl) {
     const int num_points = S - 1;
@@ -389,22 +443,22 @@ __device__ __forceinline__ bool quad_pass_one(const float* __restrict__ instance
 #pragma unroll
     for (int k = 0; k < kRoundsS; ++k) {
         w[k] = 0.0f;
-        if (k * kRowLanes >= num_points) continue;
+        if (k * kL >= num_points) continue;
         const RowRay rr = load_row_ray(rayp);
         const RayCull rc = row_cull(coef, rr);
-        const QuadPoint p = quad_point(coarse, num_points, k, rr.ray, true, rl);
+        const QuadPoint p = quad_point<kL>(coarse, num_points, k, rr.ray, true, rl);
         const RoundCull cull = quad_round_bounds(rc, N, p.mid, sh.cull);
         if (quad_round_is_empty(rc, cull, sh, p.delta)) continue;                // alpha = 0 exactly: the transmittance passes unchanged
         unsigned long long evaluated = quad_round_mask(rc, cull, N, p.mid);
         const float floor = cull.nearest_lo - sh.reach;
         if (!kRunning && wave_any(!((cull.nearest_hi + 1.0f - floor) * sh.inv_t <= kUnionFloorSpan))) return false;
-        const UnionSums sums = quad_union_loop<false, kRunning, kYaw>(instances, evaluated, sh, cull, floor, p.x, p.y, p.z, nullptr, rl.lane);
+        const UnionSums sums = quad_union_loop<false, false, kRunning, kYaw>(instances, evaluated, sh, cull, floor, p.x, p.y, p.z, nullptr, rl.lane);
         if (!kRunning && wave_any(!(sums.Z >= kUnionTinyZ))) return false;
         const UnionValue v = union_finish(sums, sh.inv_t);
         const Opacity op = opacity_of(v, rr.ray, p.delta, sh);
         const float alpha = p.valid ? op.alpha : 0.0f;
-        const float inclusive = row_inclusive_product(1.0f - alpha);
-        w[k] = carry * row_shift_up(inclusive, 1.0f) * alpha;
+        const float inclusive = seg_inclusive_product<kL>(1.0f - alpha);
+        w[k] = carry * seg_shift_up<kL>(inclusive, 1.0f, rl) * alpha;
         carry *= lane_gather(inclusive, rl.last);
     }
     return true;
@@ -429,36 +483,39 @@ struct QuadAdjoint {
 // Pass 2, forward: union, opacity, transmittance, labels.  label: lane (ray, n) accumulates label n of its ray.  The transmittance of
 // every point of an active round is left in trans[round * 16 + col] (LDS) for the reverse sweep.  Returns false when a round needs
 // the running minimum.
-template <int kRounds, bool kYaw, bool kRunning>
+template <int kL, int kRounds, bool kYaw, bool kRunning>
 __device__ __forceinline__ bool quad_forward_sweep(QuadAdjoint<kRounds>& st, const float* __restrict__ instances, int N, const Shading& sh,
                                                    const float* rayp, const float* coef, const float* merged, int num_points, bool live,
-                                                   float* dcache, float* trans, float& label, unsigned& active, int& cached_round, const RowLanes& rl) {
+                                                   float* dcache, float* trans, float (&label)[kL == kRowLanes ? 1 : 2], unsigned& active, int& cached_round,
+                                                   const RowLanes& rl) {
+    constexpr int kSlots = kL == kRowLanes ? 1 : 2;                            // lane (ray, c) owns labels c, kL + c
     float carry = 1.0f;
-    label = 0.0f;
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) label[s] = 0.0f;
     cached_round = -1;                                                           // the round whose soft-min terms the distance cache holds at the end
     active = 0u;                                                                 // bit q: some point of round q has a weight
 #pragma unroll
     for (int q = 0; q < kRounds; ++q) {
         st.near[q] = 0ull;
-        if (q * kRowLanes >= num_points) continue;
-        float delta, bprime;
+        if (q * kL >= num_points) continue;
+        float delta, bprime, px, py, pz;
         UnionValue v;
         Opacity op;
         bool valid;
         {
             const RowRay rr = load_row_ray(rayp);
             const RayCull rc = row_cull(coef, rr);
-            const QuadPoint p = quad_point(merged, num_points, q, rr.ray, live, rl);
+            const QuadPoint p = quad_point<kL>(merged, num_points, q, rr.ray, live, rl);
             const RoundCull cull = quad_round_bounds(rc, N, p.mid, sh.cull);
             if (quad_round_is_empty(rc, cull, sh, p.delta)) continue;            // alpha = 0 exactly: no weight, no label, no adjoint
             st.near[q] = quad_round_mask(rc, cull, N, p.mid);
             const float floor = cull.nearest_lo - sh.reach;
             if (!kRunning && wave_any(!((cull.nearest_hi + 1.0f - floor) * sh.inv_t <= kUnionFloorSpan))) return false;
-            const UnionSums sums = quad_union_loop<true, kRunning, kYaw>(instances, st.near[q], sh, cull, floor, p.x, p.y, p.z, dcache, rl.lane);
+            const UnionSums sums = quad_union_loop<true, (kL > kRowLanes), kRunning, kYaw>(instances, st.near[q], sh, cull, floor, p.x, p.y, p.z, dcache, rl.lane);
             cached_round = q;
             if (!kRunning && wave_any(!(sums.Z >= kUnionTinyZ))) return false;
             v = union_finish(sums, sh.inv_t);
-            delta = p.delta; valid = p.valid;
+            delta = p.delta; valid = p.valid; px = p.x; py = p.y; pz = p.z;
         }
         reload_fence();
         {
@@ -469,22 +526,24 @@ __device__ __forceinline__ bool quad_forward_sweep(QuadAdjoint<kRounds>& st, con
             bprime = (rb - gb * op.inv_gn * op.cosine) * op.inv_gn;
         }
         const float alpha = valid ? op.alpha : 0.0f;
-        const float inclusive = row_inclusive_product(1.0f - alpha);
-        const float t = carry * row_shift_up(inclusive, 1.0f);
+        const float inclusive = seg_inclusive_product<kL>(1.0f - alpha);
+        const float t = carry * seg_shift_up<kL>(inclusive, 1.0f, rl);
         carry *= lane_gather(inclusive, rl.last);
         st.m[q] = v.m; st.inv_z[q] = v.inv_z; st.s[q] = v.us;
         st.ax[q] = v.gx; st.ay[q] = v.gy; st.az[q] = v.gz;
         st.c[q] = bprime;
         if (__ballot(alpha > 0.0f) == 0ull) continue;                            // (a round without weight: nothing for the labels, nothing flows back)
         active |= 1u << q;
-        trans[q * kRowLanes + rl.col] = t;
+        trans[q * kL + rl.col] = t;
         const float scale = t * alpha * v.inv_z;
-        for (unsigned long long todo = st.near[q]; todo != 0ull; todo &= todo - 1ull) {
+        int slot = 0;
+        for (unsigned long long todo = st.near[q]; todo != 0ull; todo &= todo - 1ull, ++slot) {
             const int i = __builtin_ctzll(todo);
-            const float cached = dcache[i * kWave + rl.lane];
+            const float cached = quad_cached_term<(kL > kRowLanes), kRunning, kYaw>(instances, i, slot, dcache, rl.lane, px, py, pz, v.m, sh.inv_t);
             const float e = kRunning ? fast_exp(-(cached - v.m) * sh.inv_t) : cached;
-            const float total = row_sum(e * scale);
-            label = (rl.col == i) ? (label + total) : label;
+            const float total = seg_sum<kL>(e * scale);
+#pragma unroll
+            for (int s = 0; s < kSlots; ++s) label[s] = (i == s * kL + rl.col) ? (label[s] + total) : label[s];
         }
     }
     return true;
@@ -496,7 +555,7 @@ __device__ __forceinline__ bool quad_forward_sweep(QuadAdjoint<kRounds>& st, con
 // the round whose soft-min terms the distance cache still holds (fixed shift; -1: none).  On return cbuf (= the distance cache) holds
 // C1 and C3 of every point, trans_mid the interval mid-points, c2buf (= the row's OWN sorted distances, shifted by one) C2.  Returns the
 // rounds (bit q) in which some lane carries a non-zero adjoint.
-template <int kRounds, bool kYaw>
+template <int kL, int kRounds, bool kYaw>
 __device__ __forceinline__ unsigned quad_reverse_sweep(QuadAdjoint<kRounds>& st, const float* __restrict__ instances, const Shading& sh, const float* rayp,
                                                        const float* merged, int num_points, bool live, unsigned active, unsigned long long lam_any, int cached_round,
                                                        const float* coef_own, float* cbuf, float* trans_mid, float* c2buf, const RowLanes& rl) {
@@ -506,13 +565,15 @@ __device__ __forceinline__ unsigned quad_reverse_sweep(QuadAdjoint<kRounds>& st,
     for (int q = kRounds - 1; q >= 0; --q) {
         if (!((active >> q) & 1u)) continue;                                       // no weight in the round: nothing flows back (exact)
         const RowRay rr = load_row_ray(rayp);
-        const QuadPoint p = quad_point(merged, num_points, q, rr.ray, live, rl);
+        const QuadPoint p = quad_point<kL>(merged, num_points, q, rr.ray, live, rl);
         // Lambda_s / Z_s = sum_n lambda_n w_{s,n} over the instances the forward sweep evaluated (culled ones: weight < exp(-18))
         float acc = 0.0f;
         if (q == cached_round) {                                                   // wave-uniform: the soft-min terms are still in the distance cache
-            for (unsigned long long todo = st.near[q] & lam_any; todo != 0ull; todo &= todo - 1ull) {
+            int slot = 0;
+            for (unsigned long long todo = st.near[q]; todo != 0ull; todo &= todo - 1ull, ++slot) {
                 const int i = __builtin_ctzll(todo);
-                acc += coef_own[kCullCoefs * i + 3] * cbuf[i * kWave + rl.lane];
+                if (!((lam_any >> i) & 1ull)) continue;                            // wave-uniform: no ray has a label adjoint for it
+                acc += coef_own[kCullCoefs * i + 3] * quad_cached_term<(kL > kRowLanes), false, kYaw>(instances, i, slot, cbuf, rl.lane, p.x, p.y, p.z, st.m[q], sh.inv_t);
             }
         } else {
             for (unsigned long long todo = st.near[q] & lam_any; todo != 0ull; todo &= todo - 1ull) {
@@ -526,11 +587,11 @@ __device__ __forceinline__ unsigned quad_reverse_sweep(QuadAdjoint<kRounds>& st,
         v.u = st.m[q] + st.s[q]; v.gx = st.ax[q]; v.gy = st.ay[q]; v.gz = st.az[q];
         const Opacity op = opacity_of(v, rr.ray, p.delta, sh);
         const float alpha = p.valid ? op.alpha : 0.0f;
-        const float t = trans_mid[q * kRowLanes + rl.col];
-        trans_mid[q * kRowLanes + rl.col] = p.mid;                                 // (same lane, same slot: no hazard)
+        const float t = trans_mid[q * kL + rl.col];
+        trans_mid[q * kL + rl.col] = p.mid;                                 // (same lane, same slot: no hazard)
         const float wgt = t * alpha;
         const float contrib = lam_z * wgt;
-        const float suffix_inclusive = row_suffix_sum(contrib);
+        const float suffix_inclusive = seg_suffix_sum<kL>(contrib, rl);
         const float Q = suffix_inclusive - contrib + suffix_carry;                 // sum over the later samples of the ray
         suffix_carry += lane_gather(suffix_inclusive, rl.first);
         const float alpha_bar = lam_z * t - Q * fast_rcp(1.0f - alpha);
@@ -551,7 +612,7 @@ __device__ __forceinline__ unsigned quad_reverse_sweep(QuadAdjoint<kRounds>& st,
         const float A = gbx * st.ax[q] + gby * st.ay[q] + gbz * st.az[q];
         st.ax[q] = gbx; st.ay[q] = gby; st.az[q] = gbz;
         st.s[q] = 1.0f + st.s[q] * sh.inv_t;
-        c2buf[q * kRowLanes + rl.col + 1] = sh.inv_t * (A + wgt * lam_z);
+        c2buf[q * kL + rl.col + 1] = sh.inv_t * (A + wgt * lam_z);
         cbuf[(2 * q) * kWave + rl.lane] = u_bar + sh.inv_t * B;
         cbuf[(2 * q + 1) * kWave + rl.lane] = sh.inv_t * wgt;
         const bool any = (u_bar != 0.0f) || (gbx != 0.0f) || (gby != 0.0f) || (gbz != 0.0f) || (wgt != 0.0f);
@@ -563,9 +624,9 @@ __device__ __forceinline__ unsigned quad_reverse_sweep(QuadAdjoint<kRounds>& st,
 // Per-instance phase for the four rays (render_kernels.h: adjoint_phase_b): instance-outer, rounds inner, one reduce-scatter butterfly
 // per (wave, instance).  G[s]: lane (row r, col c) accumulates parameter c of instance 4 s + r (four registers for N <= 16; float
 // atomics on the wave's row of the partial table instead cost 6.5 GB of L2 write-through per launch).
-template <int kRounds, bool kYaw>
+template <int kL, int kRounds, bool kYaw>
 __device__ __forceinline__ void quad_phase_b(const QuadAdjoint<kRounds>& st, const float* __restrict__ instances, const Shading& sh, const float* rayp,
-                                             unsigned flow, const float* coef_own, const float* cbuf, const float* mids, const float* c2buf, float (&G)[4], const RowLanes& rl) {
+                                             unsigned flow, const float* coef_own, const float* cbuf, const float* mids, const float* c2buf, float (&G)[kL == kRowLanes ? 4 : 16], const RowLanes& rl) {
     const float inv_t = sh.inv_t;
     const Ray ray = load_row_ray(rayp).ray;
     unsigned long long todo = 0ull;
@@ -580,8 +641,8 @@ __device__ __forceinline__ void quad_phase_b(const QuadAdjoint<kRounds>& st, con
 #pragma unroll
         for (int q = 0; q < kRounds; ++q) {
             if (!(((st.near[q] >> i) & 1ull) && ((flow >> q) & 1u))) continue;       // wave-uniform
-            const float mid = mids[q * kRowLanes + rl.col];
-            const float c1 = cbuf[(2 * q) * kWave + rl.lane], c3 = cbuf[(2 * q + 1) * kWave + rl.lane], c2 = c2buf[q * kRowLanes + rl.col + 1];
+            const float mid = mids[q * kL + rl.col];
+            const float c1 = cbuf[(2 * q) * kWave + rl.lane], c3 = cbuf[(2 * q + 1) * kWave + rl.lane], c2 = c2buf[q * kL + rl.col + 1];
             const BoxEval e = eval_box<kYaw>(in, ray.ox + ray.rx * mid, ray.oy + ray.ry * mid, ray.oz + ray.rz * mid);
             const float ds = e.d - st.m[q];
             const float w = fast_exp(-ds * inv_t) * st.inv_z[q];
@@ -617,9 +678,9 @@ __device__ __forceinline__ void quad_phase_b(const QuadAdjoint<kRounds>& st, con
         }
         const float packed[16] = {at0, at1, at2, r00, r01, r02, r10, r11, r12, r20, r21, r22, ad0, ad1, ad2, 0.0f};
         const float mine = wave_reduce16_scatter(packed, rl.lane);            // every lane: the wave's sum of parameter (lane & 15)
-        const float add = (rl.row == (i & 3)) ? mine : 0.0f;
+        const float add = ((rl.lane >> 4) == (i & 3)) ? mine : 0.0f;             // lane (16-lane row r, c) owns parameter c of instances r, 4 + r, ...
 #pragma unroll
-        for (int s = 0; s < 4; ++s) G[s] += ((i >> 2) == s) ? add : 0.0f;
+        for (int s = 0; s < (kL == kRowLanes ? 4 : 16); ++s) G[s] += ((i >> 2) == s) ? add : 0.0f;
     }
 }
 
@@ -636,14 +697,15 @@ __device__ __forceinline__ void quad_phase_b(const QuadAdjoint<kRounds>& st, con
 // the running minimum; else the shift known before the instance loop, field.h); returns false -- before any side effect other than
 // LDS staging -- when the fixed shift cannot serve some round of the group: the caller then runs the group again with kRunning.
 // The three instantiations share no state, so none of it crosses a control-flow merge.
-template <int kRoundsS, bool kYaw, bool kRunning>
+template <int kL, int kRoundsS, bool kYaw, bool kRunning>
 __device__ __forceinline__ bool quad_step_body(const float* __restrict__ instances, int N, const RenderArgs& c, const Shading& sh, int first_ray,
                                                const float* __restrict__ origins, const float* __restrict__ directions,
                                                const float* __restrict__ u_coarse, const float* __restrict__ u_fine, bool sorted_input,
                                                const float* __restrict__ targets, const float* __restrict__ instance_weights, float loss_scale,
                                                float* __restrict__ labels_out, float* stage, float* dcache, float* coefs, float* rays,
-                                               float (&G)[4], float& loss_acc, const RowLanes& rl VSRD_QUAD_CLOCK_PARAM) {
+                                               float (&G)[kL == kRowLanes ? 4 : 16], float& loss_acc, const RowLanes& rl VSRD_QUAD_CLOCK_PARAM) {
     constexpr int kRounds = 2 * kRoundsS;
+    constexpr int kSlots = kL == kRowLanes ? 1 : 2;                          // lane (ray, c) owns the labels of instances c, kL + c
     VSRD_PHASE(7);
     const int S = c.num_samples;
     const int num_points = 2 * S - 1;
@@ -651,7 +713,7 @@ __device__ __forceinline__ bool quad_step_body(const float* __restrict__ instanc
     const bool alive = my_ray < c.num_rays;
     const int ray = alive ? my_ray : (c.num_rays - 1);                    // rows beyond the launch repeat its last ray and contribute nothing
     const long long src = source_row(c, ray);
-    float* rowbase = stage + rl.row * quad_row_floats(S);
+    float* rowbase = stage + rl.row * quad_row_floats(S, kL);
     float* coef_own = coefs + rl.row * quad_coef_floats(N);
     {
         const long long origin_row = (c.ray_indices && c.rays_per_origin > 0) ? src / c.rays_per_origin : src;
@@ -659,59 +721,140 @@ __device__ __forceinline__ bool quad_step_body(const float* __restrict__ instanc
         const float* d = directions + src * 3;
         Ray r;
         r.ox = o[0]; r.oy = o[1]; r.oz = o[2]; r.rx = d[0]; r.ry = d[1]; r.rz = d[2];
-        quad_ray_setup(instances, N, r, coef_own, rays + rl.row * 8, rl);
+        quad_ray_setup<kL>(instances, N, r, coef_own, rays + rl.row * 8, rl);
     }
-    quad_stage_samples<kRoundsS>(rowbase, c, S, ray, u_coarse, u_fine, sorted_input, rl);
+    quad_stage_samples<kL, kRoundsS>(rowbase, c, S, ray, u_coarse, u_fine, sorted_input, rl);
     VSRD_PHASE(0);
     // ---- pass 1 ----------------------------------------------------------------------------------------------------------------
     float w1[kRoundsS];
-    if (!quad_pass_one<kRoundsS, kYaw, kRunning>(instances, N, sh, rays + rl.row * 8, coef_own, rowbase, S, w1, rl)) return false;
+    if (!quad_pass_one<kL, kRoundsS, kYaw, kRunning>(instances, N, sh, rays + rl.row * 8, coef_own, rowbase, S, w1, rl)) return false;
     VSRD_PHASE(1);
     float coarse_total = 0.0f;
 #pragma unroll
-    for (int k = 0; k < kRoundsS; ++k) coarse_total += row_sum(w1[k]);
+    for (int k = 0; k < kRoundsS; ++k) coarse_total += seg_sum<kL>(w1[k]);
     // exact misses (VSRD_FLAG_SKIP_EXACT_MISSES): labels exactly 0, adjoint exactly 0
     const bool live = alive && !((c.flags & 2u) && coarse_total == 0.0f);
     const unsigned long long live_lanes = __ballot(live);
-    float label = 0.0f;
+    float label[kSlots];
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) label[s] = 0.0f;
     unsigned active = 0u;
     int cached_round = -1;
     QuadAdjoint<kRounds> st;
     // rows that do not take part shadow the first live row (same points, same votes in the culling ballots, zero weight)
-    const int data_row = live ? rl.row : (live_lanes != 0ull ? (__builtin_ctzll(live_lanes) >> 4) : rl.row);
+    const int data_row = live ? rl.row : (live_lanes != 0ull ? (__builtin_ctzll(live_lanes) / kL) : rl.row);
     const float* rayp = rays + data_row * 8;
-    const float* merged = stage + data_row * quad_row_floats(S) + quad_merged_offset(S);
+    const float* merged = stage + data_row * quad_row_floats(S, kL) + quad_merged_offset(S, kL);
     float* trans_mid = rowbase;                                              // (the row's own: a shadow row's transmittances are all 1)
     if (live_lanes != 0ull) {
-        quad_importance_merge<kRoundsS>(rowbase, S, w1, rl);
+        quad_importance_merge<kL, kRoundsS>(rowbase, S, w1, rl);
         VSRD_PHASE(2);
-        if (!quad_forward_sweep<kRounds, kYaw, kRunning>(st, instances, N, sh, rayp, coefs + data_row * quad_coef_floats(N), merged, num_points, live, dcache,
+        if (!quad_forward_sweep<kL, kRounds, kYaw, kRunning>(st, instances, N, sh, rayp, coefs + data_row * quad_coef_floats(N), merged, num_points, live, dcache,
                                                          trans_mid, label, active, cached_round, rl)) return false;
-        if (!live) label = 0.0f;
         VSRD_PHASE(3);
     }
     // ---- loss and label adjoints -------------------------------------------------------------------------------------------------
-    const bool mine = alive && rl.col < N;
-    if (labels_out != nullptr && mine) labels_out[static_cast<size_t>(my_ray) * N + rl.col] = label;
-    const float target = mine ? load_target(c, targets, src, rl.col, N) : 0.0f;
-    const float weight_lane = mine ? (instance_weights ? instance_weights[rl.col] : 1.0f) : 0.0f;
-    const float p = fminf(fmaxf(label, 1.0e-6f), 1.0f - 1.0e-6f);
-    const float bce = -(target * logf(p) + (1.0f - target) * logf(1.0f - p));
-    loss_acc += weight_lane * bce;
-    const bool inside_clamp = (label >= 1.0e-6f) && (label <= 1.0f - 1.0e-6f);
-    const float lam_lane = (live && inside_clamp) ? weight_lane * loss_scale * (p - target) / fmaxf(p * (1.0f - p), 1.0e-12f) : 0.0f;
-    unsigned long long lam_any = __ballot(lam_lane != 0.0f);                 // bit n: some ray has a label adjoint for instance n
-    lam_any |= lam_any >> 32; lam_any |= lam_any >> 16; lam_any &= 0xFFFFull;
+    unsigned long long lam_any = 0ull;                                       // bit n: some ray has a label adjoint for instance n
+    float lam_lane[kSlots];
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+        const int n = s * kL + rl.col;
+        const bool mine = alive && n < N;
+        const float lab = live ? label[s] : 0.0f;
+        if (labels_out != nullptr && mine) labels_out[static_cast<size_t>(my_ray) * N + n] = lab;
+        const float target = mine ? load_target(c, targets, src, n, N) : 0.0f;
+        const float weight_lane = mine ? (instance_weights ? instance_weights[n] : 1.0f) : 0.0f;
+        const float p = fminf(fmaxf(lab, 1.0e-6f), 1.0f - 1.0e-6f);
+        const float bce = -(target * logf(p) + (1.0f - target) * logf(1.0f - p));
+        loss_acc += weight_lane * bce;
+        const bool inside_clamp = (lab >= 1.0e-6f) && (lab <= 1.0f - 1.0e-6f);
+        lam_lane[s] = (live && inside_clamp) ? weight_lane * loss_scale * (p - target) / fmaxf(p * (1.0f - p), 1.0e-12f) : 0.0f;
+        unsigned long long any = __ballot(lam_lane[s] != 0.0f);              // lane (ray r, c): bit kL r + c -> fold the rays
+        any |= any >> 32;
+        if (kL == kRowLanes) { any |= any >> 16; any &= 0xFFFFull; } else { any &= 0xFFFFFFFFull; }
+        lam_any |= any << (s * kL);
+    }
     if (active == 0u || lam_any == 0ull) return true;
-    if (rl.col < N) coef_own[kCullCoefs * rl.col + 3] = lam_lane;
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s)
+        if (s * kL + rl.col < N) coef_own[kCullCoefs * (s * kL + rl.col) + 3] = lam_lane[s];
     wave_lds_sync();
     // ---- adjoint -------------------------------------------------------------------------------------------------------------------
-    const unsigned flow = quad_reverse_sweep<kRounds, kYaw>(st, instances, sh, rayp, merged, num_points, live, active, lam_any, kRunning ? -1 : cached_round,
-                                                            coef_own, dcache, trans_mid, rowbase + quad_merged_offset(S), rl);
+    const unsigned flow = quad_reverse_sweep<kL, kRounds, kYaw>(st, instances, sh, rayp, merged, num_points, live, active, lam_any, kRunning ? -1 : cached_round,
+                                                            coef_own, dcache, trans_mid, rowbase + quad_merged_offset(S, kL), rl);
     VSRD_PHASE(4);
-    if (flow != 0u) quad_phase_b<kRounds, kYaw>(st, instances, sh, rayp, flow, coef_own, dcache, trans_mid, rowbase + quad_merged_offset(S), G, rl);
+    if (flow != 0u) quad_phase_b<kL, kRounds, kYaw>(st, instances, sh, rayp, flow, coef_own, dcache, trans_mid, rowbase + quad_merged_offset(S, kL), G, rl);
     VSRD_PHASE(5);
     return true;
+}
+
+#ifndef VSRD_QUAD_WAVES_PER_EU
+#define VSRD_QUAD_WAVES_PER_EU 4
+#endif
+// kL = lanes per ray: 16 (four rays per wave; N <= 16, S <= 64: BASELINE config 2) or 32 (two rays per wave; N <= 64, S <= 128: BASELINE
+// config 5, and config-2-shaped frames with more than 16 instances).
+template <int kL, int kRoundsS>
+__device__ __forceinline__ void silhouette_rows_kernel_body(
+    FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
+    const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
+    const float* __restrict__ targets, const float* __restrict__ instance_weights, float loss_scale,
+    float* __restrict__ labels_out, float* __restrict__ partials, float* __restrict__ loss_partials) {
+    constexpr int kRays = kWave / kL;
+    constexpr int kG = kL == kRowLanes ? 4 : 16;
+    apply_device_schedule(f, c);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = wave_in_block();
+    const int lane0 = lane_id();
+    const int S = c.num_samples;
+    const int N = f.num_instances;
+    float* stage = lds + wave * quad_lds_floats(S, N, kL);
+    float* dcache = stage + kRays * quad_row_floats(S, kL);
+    float* coefs = dcache + quad_cache_rows(S, N, kL) * kWave;
+    float* rays = coefs + kRays * quad_coef_floats(N);
+    const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
+    Shading sh = c.sh;
+    const FieldBounds bounds = field_bounds(instances, N, f.inv_t, false, c.flags);
+    sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
+    sh.mlp_bits = 0u;
+    sh.mlp_lds = nullptr;
+    float loss_acc = 0.0f;
+    float G[kG];
+#pragma unroll
+    for (int s = 0; s < kG; ++s) G[s] = 0.0f;
+    const int num_waves = static_cast<int>(gridDim.x) * waves_per_block();
+    const int wave_global = static_cast<int>(blockIdx.x) * waves_per_block() + wave;
+    const int num_groups = (c.num_rays + kRays - 1) / kRays;
+    VSRD_PHASE_CLOCK();
+    for (int group = wave_global; group < num_groups; group += num_waves) {
+        const int first_ray = group * kRays;
+        const RowLanes rl = row_lanes<kL>(opaque_lane_id());
+        wave_lds_sync();
+        bool done = false;
+#ifdef VSRD_QUAD_EXPERIMENT_YAW_ONLY       // register-pressure experiments: one body only
+        done = quad_step_body<kL, kRoundsS, true, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
+                                                         instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
+        continue;
+#endif
+        if (sh.reach >= 0.0f) {
+            done = sh.yaw ? quad_step_body<kL, kRoundsS, true, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
+                                                                      instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG)
+                          : quad_step_body<kL, kRoundsS, false, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
+                                                                       instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
+            if (!done) wave_lds_sync();
+        }
+        if (!done) quad_step_body<kL, kRoundsS, false, true>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
+                                                             instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
+    }
+    VSRD_PHASE(7);
+    VSRD_PHASE_FLUSH(lane0);
+    // the wave's row of the partial-gradient table (summed over the waves by reduce_partials_kernel): lane (16-lane row r, c) of register s
+    // holds parameter c of instance 4 s + r
+    float* out = partials + static_cast<size_t>(wave_global) * (N * kGradStride);
+#pragma unroll
+    for (int s = 0; s < kG; ++s)
+        if (s * kWave + lane0 < N * kGradStride) out[s * kWave + lane0] = G[s];
+    const float loss_total = wave_sum(loss_acc);
+    if (lane0 == 0) loss_partials[wave_global] = loss_total * loss_scale;
 }
 
 #ifndef VSRD_QUAD_WAVES_PER_EU
@@ -723,57 +866,22 @@ __global__ __launch_bounds__(kBlockThreads, VSRD_QUAD_WAVES_PER_EU) void render_
     const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
     const float* __restrict__ targets, const float* __restrict__ instance_weights, float loss_scale,
     float* __restrict__ labels_out, float* __restrict__ partials, float* __restrict__ loss_partials) {
-    apply_device_schedule(f, c);
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int wave = wave_in_block();
-    const int lane0 = lane_id();
-    const int S = c.num_samples;
-    const int N = f.num_instances;
-    float* stage = lds + wave * quad_lds_floats(S, N);
-    float* dcache = stage + kQuadRays * quad_row_floats(S);
-    float* coefs = dcache + quad_cache_rows(S, N) * kWave;
-    float* rays = coefs + kQuadRays * quad_coef_floats(N);
-    const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
-    Shading sh = c.sh;
-    const FieldBounds bounds = field_bounds(instances, N, f.inv_t, false, c.flags);
-    sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
-    sh.mlp_bits = 0u;
-    sh.mlp_lds = nullptr;
-    float loss_acc = 0.0f;
-    const int num_waves = static_cast<int>(gridDim.x) * waves_per_block();
-    const int wave_global = static_cast<int>(blockIdx.x) * waves_per_block() + wave;
-    const int num_quads = (c.num_rays + kQuadRays - 1) / kQuadRays;
-    float G[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    VSRD_PHASE_CLOCK();
-    for (int quad = wave_global; quad < num_quads; quad += num_waves) {
-        const int first_ray = quad * kQuadRays;
-        const RowLanes rl = row_lanes(opaque_lane_id());
-        wave_lds_sync();
-        bool done = false;
-#ifdef VSRD_QUAD_EXPERIMENT_YAW_ONLY       // register-pressure experiments: one body only
-        done = quad_step_body<kRoundsS, true, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
-                                                     instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
-        continue;
+    silhouette_rows_kernel_body<kRowLanes, kRoundsS>(f, instances, c, origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, labels_out,
+                                                     partials, loss_partials);
+}
+
+// Two rays per wave, 32 lanes each (kRoundsS = 2: S <= 64; 4: S <= 128).
+#ifndef VSRD_PAIR_WAVES_PER_EU
+#define VSRD_PAIR_WAVES_PER_EU 3
 #endif
-        if (sh.reach >= 0.0f) {
-            done = sh.yaw ? quad_step_body<kRoundsS, true, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
-                                                                  instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG)
-                          : quad_step_body<kRoundsS, false, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
-                                                                   instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
-            if (!done) wave_lds_sync();
-        }
-        if (!done) quad_step_body<kRoundsS, false, true>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
-                                                         instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
-    }
-    VSRD_PHASE(7);
-    VSRD_PHASE_FLUSH(lane0);
-    // the wave's row of the partial-gradient table (summed over the waves by reduce_partials_kernel): instance 4 s + row, parameter col
-    float* out = partials + static_cast<size_t>(wave_global) * (N * kGradStride);
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-        if (s * kWave + lane0 < N * kGradStride) out[s * kWave + lane0] = G[s];
-    const float loss_total = wave_sum(loss_acc);
-    if (lane0 == 0) loss_partials[wave_global] = loss_total * loss_scale;
+template <int kRoundsS>
+__global__ __launch_bounds__(kBlockThreads, VSRD_PAIR_WAVES_PER_EU) void render_silhouette_pair_kernel(
+    FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
+    const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
+    const float* __restrict__ targets, const float* __restrict__ instance_weights, float loss_scale,
+    float* __restrict__ labels_out, float* __restrict__ partials, float* __restrict__ loss_partials) {
+    silhouette_rows_kernel_body<32, kRoundsS>(f, instances, c, origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, labels_out,
+                                              partials, loss_partials);
 }
 
 }  // namespace vsrd
