@@ -488,8 +488,12 @@ def step_kernel_symbols(args, fused):
         return "vsrd_render_residual_step", ["residual_step_front_kernel", "residual_step_pair_kernel", "residual_mlp_adjoint_kernel",
                                              "render_residual_step_kernel", "reduce_item_rows_kernel", "reduce_item_segments_kernel"]
     from vsrd_amd.rendering import renderers
-    quad = S <= 64 and N <= 16 and not renderers.STEP_WAVE_PER_RAY       # api.hip: vsrd_render_silhouette_step
-    return "vsrd_render_silhouette_step", ["render_silhouette_quad_kernel" if quad else "render_silhouette_kernel<"]
+    dense = not renderers.STEP_WAVE_PER_RAY                              # api.hip: vsrd_render_silhouette_step
+    if dense and S <= 64 and N <= 16:
+        return "vsrd_render_silhouette_step", ["render_silhouette_quad_kernel"]          # four rays per wave
+    if dense and S <= 128 and N <= 64:
+        return "vsrd_render_silhouette_step", ["render_silhouette_pair_kernel"]          # two rays per wave
+    return "vsrd_render_silhouette_step", ["render_silhouette_kernel<"]
 
 
 def rooflines(args, kernels, R, fused):
