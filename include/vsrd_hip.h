@@ -86,7 +86,10 @@ typedef struct vsrd_render_config {
 #define VSRD_FLAG_FINE_UNIFORMS_SORTED 1u /* u_fine is already sorted ascending per ray     */
 #define VSRD_FLAG_SKIP_EXACT_MISSES 2u    /* rays whose coarse weights are all exactly 0 skip pass 2:
                                              labels = 0 (exact); distances/gradients/weights of such
-                                             rays are NOT produced (fused-loss mode only)        */
+                                             rays are NOT produced (fused-loss mode only).  In the kernels
+                                             that put several rays in a wave (dense box-only launches) the
+                                             rays of a wave share the soft-min mode, so the OTHER rays of a
+                                             wave agree with the un-skipped run to rounding, not bit for bit */
 
 #define VSRD_FLAG_MLP_WEIGHTS_CENTRED 8u   /* residual fields: the caller guarantees that, in each of the four linears that feed a
                                              LayerNorm (rows [out][in+1] of mlp_weights), every column -- bias column included -- has

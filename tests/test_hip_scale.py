@@ -81,10 +81,15 @@ def test_config5_shapes_band(dev):
     from vsrd_amd.rendering import renderers
     renderers.CULLING = False
     try:
-        ref = rendering.render_hierarchical(union, cam[0], rows, (0.0, 100.0), S, 0.55, 0.5, seed=3)
+        ref = rendering.render_hierarchical(union, cam[0], rows, (0.0, 100.0), S, 0.55, 0.5, seed=3, return_weights=True)    # (the same kernel)
     finally:
         renderers.CULLING = True
     assert (ref["labels"] - out["labels"]).abs().max() < 2e-6
+    # labels / distances only: two rays per wave (render_hierarchical_pair_kernel) against the one-ray kernel above (same Philox keys; the
+    # sorted fine uniforms are partial sums taken in a different order)
+    rows_kernel = rendering.render_hierarchical(union, cam[0], rows, (0.0, 100.0), S, 0.55, 0.5, seed=3)
+    assert (rows_kernel["labels"] - out["labels"]).abs().max() < 2e-4
+    check_properties(rows_kernel, N, S)
 
 
 def test_config3_shapes_many_instances(dev):

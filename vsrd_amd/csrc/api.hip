@@ -446,11 +446,25 @@ int32_t vsrd_render_hierarchical_forward(const vsrd_field* field, const vsrd_ren
     if ((config->flags & VSRD_FLAG_SKIP_EXACT_MISSES) && (gradients || weights)) return VSRD_E_INVALID_ARGUMENT;
     const int S = config->num_samples;
     Geometry g;
-    if (!plan(config->num_rays, static_cast<size_t>(hierarchical_lds_floats(S, field->num_instances, residual)), &g)) return VSRD_E_UNSUPPORTED;
     const FieldArgs f = field_args(field);
     RenderArgs c = render_args(config);
     c.sh.inv_t = f.inv_t;
     const hipStream_t s = static_cast<hipStream_t>(stream);
+    // labels (and distances) only, box-only field: the forward in the mappings of the fused step (quad_step.h) -- four rays per wave for
+    // N <= 16 and S <= 64, two for N <= 64 and S <= 128
+    if (!residual && !gradients && !weights && !u_coarse_out && !u_fine_out && !(config->flags & VSRD_FLAG_STEP_WAVE_PER_RAY) &&
+        S <= kPairMaxSamples && field->num_instances <= kPairMaxInstances) {
+        const bool quad = S <= kQuadMaxSamples && field->num_instances <= kQuadMaxInstances;
+        const int lanes = quad ? kRowLanes : 32, rays_per_wave = kWave / lanes;
+        if (!plan((config->num_rays + rays_per_wave - 1) / rays_per_wave, static_cast<size_t>(quad_lds_floats(S, field->num_instances, lanes)), &g))
+            return VSRD_E_UNSUPPORTED;
+        if (quad) hipLaunchKernelGGL(render_hierarchical_quad_kernel, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins,
+                                     directions, u_coarse, u_fine, labels, distances);
+        else hipLaunchKernelGGL(render_hierarchical_pair_kernel, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins,
+                                directions, u_coarse, u_fine, labels, distances);
+        return launch_status();
+    }
+    if (!plan(config->num_rays, static_cast<size_t>(hierarchical_lds_floats(S, field->num_instances, residual)), &g)) return VSRD_E_UNSUPPORTED;
 #define VSRD_LAUNCH(K, RES)                                                                                                  \
     do {                                                                                                                       \
         if (opt_in_lds(render_hierarchical_kernel<K, RES>, g.lds_bytes) != VSRD_OK) return VSRD_E_LAUNCH;                    \

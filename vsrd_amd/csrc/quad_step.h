@@ -870,6 +870,121 @@ __global__ __launch_bounds__(kBlockThreads, VSRD_QUAD_WAVES_PER_EU) void render_
                                                      partials, loss_partials);
 }
 
+// ---- the two-pass forward alone (vsrd_render_hierarchical_forward: scripts/main.py:511-523 as one launch) in the same mappings -----------
+// Labels [R,N] and, when asked for, the sorted pass-2 distances [R,2S] the backward works from (rays skipped as exact misses get the
+// NaN sentinel render_backward_kernel looks for).  Launches that also want the per-sample gradients / weights or the uniforms back keep
+// the one-ray kernel (render_hierarchical_kernel).
+template <int kL, int kRoundsS, bool kYaw, bool kRunning>
+__device__ __forceinline__ bool rows_forward_body(const float* __restrict__ instances, int N, const RenderArgs& c, const Shading& sh, int first_ray,
+                                                  const float* __restrict__ origins, const float* __restrict__ directions,
+                                                  const float* __restrict__ u_coarse, const float* __restrict__ u_fine, bool sorted_input,
+                                                  float* __restrict__ labels_out, float* __restrict__ distances_out,
+                                                  float* stage, float* dcache, float* coefs, float* rays, const RowLanes& rl) {
+    constexpr int kRounds = 2 * kRoundsS;
+    constexpr int kSlots = kL == kRowLanes ? 1 : 2;
+    const int S = c.num_samples;
+    const int num_points = 2 * S - 1;
+    const int my_ray = first_ray + rl.row;
+    const bool alive = my_ray < c.num_rays;
+    const int ray = alive ? my_ray : (c.num_rays - 1);
+    float* rowbase = stage + rl.row * quad_row_floats(S, kL);
+    float* coef_own = coefs + rl.row * quad_coef_floats(N);
+    {
+        const float* o = origins + static_cast<size_t>(ray) * c.origin_stride;
+        const float* d = directions + static_cast<size_t>(ray) * 3;
+        Ray r;
+        r.ox = o[0]; r.oy = o[1]; r.oz = o[2]; r.rx = d[0]; r.ry = d[1]; r.rz = d[2];
+        quad_ray_setup<kL>(instances, N, r, coef_own, rays + rl.row * 8, rl);
+    }
+    quad_stage_samples<kL, kRoundsS>(rowbase, c, S, ray, u_coarse, u_fine, sorted_input, rl);
+    float w1[kRoundsS];
+    if (!quad_pass_one<kL, kRoundsS, kYaw, kRunning>(instances, N, sh, rays + rl.row * 8, coef_own, rowbase, S, w1, rl)) return false;
+    float coarse_total = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kRoundsS; ++k) coarse_total += seg_sum<kL>(w1[k]);
+    const bool live = alive && !((c.flags & 2u) && coarse_total == 0.0f);
+    const unsigned long long live_lanes = __ballot(live);
+    float label[kSlots];
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) label[s] = 0.0f;
+    if (live_lanes != 0ull) {
+        unsigned active = 0u;
+        int cached_round = -1;
+        QuadAdjoint<kRounds> st;
+        const int data_row = live ? rl.row : (__builtin_ctzll(live_lanes) / kL);
+        quad_importance_merge<kL, kRoundsS>(rowbase, S, w1, rl);
+        if (!quad_forward_sweep<kL, kRounds, kYaw, kRunning>(st, instances, N, sh, rays + data_row * 8, coefs + data_row * quad_coef_floats(N),
+                                                              stage + data_row * quad_row_floats(S, kL) + quad_merged_offset(S, kL), num_points, live, dcache,
+                                                              rowbase, label, active, cached_round, rl)) return false;
+    }
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+        const int n = s * kL + rl.col;
+        if (alive && n < N) labels_out[static_cast<size_t>(my_ray) * N + n] = live ? label[s] : 0.0f;
+    }
+    if (distances_out != nullptr && alive) {
+        float* dst = distances_out + static_cast<size_t>(my_ray) * (2 * S);
+        if (live) {
+            const float* merged = rowbase + quad_merged_offset(S, kL);
+            for (int idx = rl.col; idx < 2 * S; idx += kL) dst[idx] = merged[idx];
+        } else if (rl.col == 0) {
+            dst[0] = __builtin_nanf("");                                     // sentinel row: the backward skips it (exact miss: exact zero adjoint)
+        }
+    }
+    return true;
+}
+
+template <int kL, int kRoundsS>
+__device__ __forceinline__ void hierarchical_rows_kernel_body(
+    FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
+    const float* __restrict__ u_coarse, const float* __restrict__ u_fine, float* __restrict__ labels_out, float* __restrict__ distances_out) {
+    constexpr int kRays = kWave / kL;
+    apply_device_schedule(f, c);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = wave_in_block();
+    const int S = c.num_samples;
+    const int N = f.num_instances;
+    float* stage = lds + wave * quad_lds_floats(S, N, kL);
+    float* dcache = stage + kRays * quad_row_floats(S, kL);
+    float* coefs = dcache + quad_cache_rows(S, N, kL) * kWave;
+    float* rays = coefs + kRays * quad_coef_floats(N);
+    const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
+    Shading sh = c.sh;
+    const FieldBounds bounds = field_bounds(instances, N, f.inv_t, false, c.flags);
+    sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
+    sh.mlp_bits = 0u;
+    sh.mlp_lds = nullptr;
+    const int num_waves = static_cast<int>(gridDim.x) * waves_per_block();
+    const int wave_global = static_cast<int>(blockIdx.x) * waves_per_block() + wave;
+    const int num_groups = (c.num_rays + kRays - 1) / kRays;
+    for (int group = wave_global; group < num_groups; group += num_waves) {
+        const int first_ray = group * kRays;
+        const RowLanes rl = row_lanes<kL>(opaque_lane_id());
+        wave_lds_sync();
+        bool done = false;
+        if (sh.reach >= 0.0f) {
+            done = sh.yaw ? rows_forward_body<kL, kRoundsS, true, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input,
+                                                                         labels_out, distances_out, stage, dcache, coefs, rays, rl)
+                          : rows_forward_body<kL, kRoundsS, false, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input,
+                                                                          labels_out, distances_out, stage, dcache, coefs, rays, rl);
+            if (!done) wave_lds_sync();
+        }
+        if (!done) rows_forward_body<kL, kRoundsS, false, true>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input,
+                                                                labels_out, distances_out, stage, dcache, coefs, rays, rl);
+    }
+}
+
+__global__ __launch_bounds__(kBlockThreads, 4) void render_hierarchical_quad_kernel(
+    FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
+    const float* __restrict__ u_coarse, const float* __restrict__ u_fine, float* __restrict__ labels_out, float* __restrict__ distances_out) {
+    hierarchical_rows_kernel_body<kRowLanes, 4>(f, instances, c, origins, directions, u_coarse, u_fine, labels_out, distances_out);
+}
+__global__ __launch_bounds__(kBlockThreads, 4) void render_hierarchical_pair_kernel(
+    FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
+    const float* __restrict__ u_coarse, const float* __restrict__ u_fine, float* __restrict__ labels_out, float* __restrict__ distances_out) {
+    hierarchical_rows_kernel_body<32, 4>(f, instances, c, origins, directions, u_coarse, u_fine, labels_out, distances_out);
+}
+
 // Two rays per wave, 32 lanes each (kRoundsS = 2: S <= 64; 4: S <= 128).
 #ifndef VSRD_PAIR_WAVES_PER_EU
 #define VSRD_PAIR_WAVES_PER_EU 3
