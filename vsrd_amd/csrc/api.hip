@@ -392,6 +392,25 @@ int32_t vsrd_render_backward(const vsrd_field* field, const vsrd_render_config* 
         return hipMemsetAsync(grad_instances, 0, row * sizeof(float), s) == hipSuccess ? VSRD_OK : VSRD_E_LAUNCH;
     }
     Geometry g;
+    // box-only fields, label adjoints only: the mappings of the fused step (quad_step.h) -- four rays per wave for N <= 16 and <= 128
+    // distances, two for N <= 64 and <= 256
+    if (!residual && !grad_gradients && !grad_weights && !(config->flags & VSRD_FLAG_STEP_WAVE_PER_RAY) && N <= kPairMaxInstances &&
+        num_distances <= 2 * kPairMaxSamples) {
+        const bool quad = N <= kQuadMaxInstances && num_distances <= 2 * kQuadMaxSamples;
+        const int lanes = quad ? kRowLanes : 32, rays_per_wave = kWave / lanes, half = (num_distances + 1) / 2;
+        if (!plan((config->num_rays + rays_per_wave - 1) / rays_per_wave, static_cast<size_t>(quad_lds_floats(half, N, lanes)), &g)) return VSRD_E_UNSUPPORTED;
+        const FieldArgs f = field_args(field);
+        RenderArgs c = render_args(config);
+        c.sh.inv_t = f.inv_t;
+        float* partials = static_cast<float*>(workspace);
+        if (quad) hipLaunchKernelGGL(render_backward_quad_kernel, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins, directions,
+                                     distances, num_distances, grad_labels, partials);
+        else hipLaunchKernelGGL(render_backward_pair_kernel, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins, directions,
+                                distances, num_distances, grad_labels, partials);
+        if (launch_status() != VSRD_OK) return VSRD_E_LAUNCH;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(row), dim3(256), 0, s, partials, g.blocks * (g.threads / kWave), row, grad_instances);
+        return launch_status();
+    }
     if (!plan(config->num_rays, static_cast<size_t>(backward_lds_floats(num_distances, N, residual)), &g)) return VSRD_E_UNSUPPORTED;
     if (residual && g.threads > kResidualWaves * kWave) return VSRD_E_UNSUPPORTED;      // cannot happen (LDS per wave), but the scratch is sized for it
     if (residual && g.blocks > kMaxBlocksResidual) g.blocks = kMaxBlocksResidual;

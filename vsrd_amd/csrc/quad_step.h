@@ -985,6 +985,133 @@ __global__ __launch_bounds__(kBlockThreads, 4) void render_hierarchical_pair_ker
     hierarchical_rows_kernel_body<32, 4>(f, instances, c, origins, directions, u_coarse, u_fine, labels_out, distances_out);
 }
 
+// ---- the adjoint at saved distances (vsrd_render_backward, box-only fields, label adjoints only) in the same mappings ------------------
+// renderers.py:212-270 backwards for the rays of one wave: sorted distances [R,D] from the forward, grad_labels [R,N]; what
+// hierarchical_volumetric_rendering(...).backward() of the reference reaches for a box-only field (scripts/main.py:511-523, 629-671).
+// Launches that also carry adjoints of the per-sample gradients / weights keep the one-ray kernel (render_backward_kernel).
+template <int kL, int kRounds, bool kYaw, bool kRunning>
+__device__ __forceinline__ bool rows_backward_body(const float* __restrict__ instances, int N, const RenderArgs& c, const Shading& sh, int first_ray,
+                                                   const float* __restrict__ origins, const float* __restrict__ directions,
+                                                   const float* __restrict__ distances, int num_distances, const float* __restrict__ grad_labels,
+                                                   float* stage, float* dcache, float* coefs, float* rays, float (&G)[kL == kRowLanes ? 4 : 16], const RowLanes& rl) {
+    constexpr int kSlots = kL == kRowLanes ? 1 : 2;
+    const int half = (num_distances + 1) / 2;                                // the row layout of the step kernels for S = ceil(D / 2)
+    const int num_points = num_distances - 1;
+    const int my_ray = first_ray + rl.row;
+    const bool alive = my_ray < c.num_rays;
+    const int ray = alive ? my_ray : (c.num_rays - 1);
+    float* rowbase = stage + rl.row * quad_row_floats(half, kL);
+    float* coef_own = coefs + rl.row * quad_coef_floats(N);
+    {
+        const float* o = origins + static_cast<size_t>(ray) * c.origin_stride;
+        const float* d = directions + static_cast<size_t>(ray) * 3;
+        Ray r;
+        r.ox = o[0]; r.oy = o[1]; r.oz = o[2]; r.rx = d[0]; r.ry = d[1]; r.rz = d[2];
+        quad_ray_setup<kL>(instances, N, r, coef_own, rays + rl.row * 8, rl);       // (clears the label adjoints, syncs)
+    }
+    const float* src = distances + static_cast<size_t>(ray) * num_distances;
+    float* own_merged = rowbase + quad_merged_offset(half, kL);
+    for (int idx = rl.col; idx < num_distances; idx += kL) own_merged[idx] = src[idx];
+    float lam_lane[kSlots];
+    float biggest = 0.0f;
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+        const int n = s * kL + rl.col;
+        lam_lane[s] = (alive && n < N) ? grad_labels[static_cast<size_t>(my_ray) * N + n] : 0.0f;
+        biggest = fmaxf(biggest, fabsf(lam_lane[s]));
+    }
+    const float first_distance = src[0];
+    // rays the forward skipped (NaN sentinel) and rays without a label adjoint: nothing flows back
+    const bool live = alive && first_distance == first_distance && seg_max<kL>(biggest) > 0.0f;
+    const unsigned long long live_lanes = __ballot(live);
+    if (live_lanes == 0ull) return true;
+    unsigned long long lam_any = 0ull;
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+        if (!live) lam_lane[s] = 0.0f;
+        unsigned long long any = __ballot(lam_lane[s] != 0.0f);
+        any |= any >> 32;
+        if (kL == kRowLanes) { any |= any >> 16; any &= 0xFFFFull; } else { any &= 0xFFFFFFFFull; }
+        lam_any |= any << (s * kL);
+        if (s * kL + rl.col < N) coef_own[kCullCoefs * (s * kL + rl.col) + 3] = lam_lane[s];
+    }
+    wave_lds_sync();
+    const int data_row = live ? rl.row : (__builtin_ctzll(live_lanes) / kL);
+    const float* rayp = rays + data_row * 8;
+    const float* merged = stage + data_row * quad_row_floats(half, kL) + quad_merged_offset(half, kL);
+    float label[kSlots];
+    unsigned active = 0u;
+    int cached_round = -1;
+    QuadAdjoint<kRounds> st;
+    if (!quad_forward_sweep<kL, kRounds, kYaw, kRunning>(st, instances, N, sh, rayp, coefs + data_row * quad_coef_floats(N), merged, num_points, live, dcache,
+                                                          rowbase, label, active, cached_round, rl)) return false;
+    if (active == 0u) return true;
+    const unsigned flow = quad_reverse_sweep<kL, kRounds, kYaw>(st, instances, sh, rayp, merged, num_points, live, active, lam_any, kRunning ? -1 : cached_round,
+                                                                coef_own, dcache, rowbase, own_merged, rl);
+    if (flow != 0u) quad_phase_b<kL, kRounds, kYaw>(st, instances, sh, rayp, flow, coef_own, dcache, rowbase, own_merged, G, rl);
+    return true;
+}
+
+template <int kL>
+__device__ __forceinline__ void backward_rows_kernel_body(
+    FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
+    const float* __restrict__ distances, int num_distances, const float* __restrict__ grad_labels, float* __restrict__ partials) {
+    constexpr int kRays = kWave / kL;
+    constexpr int kG = kL == kRowLanes ? 4 : 16;
+    constexpr int kRounds = 8;                                               // up to 8 kL points
+    apply_device_schedule(f, c);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = wave_in_block();
+    const int lane0 = lane_id();
+    const int half = (num_distances + 1) / 2;
+    const int N = f.num_instances;
+    float* stage = lds + wave * quad_lds_floats(half, N, kL);
+    float* dcache = stage + kRays * quad_row_floats(half, kL);
+    float* coefs = dcache + quad_cache_rows(half, N, kL) * kWave;
+    float* rays = coefs + kRays * quad_coef_floats(N);
+    Shading sh = c.sh;
+    const FieldBounds bounds = field_bounds(instances, N, f.inv_t, false, c.flags);
+    sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
+    sh.mlp_bits = 0u;
+    sh.mlp_lds = nullptr;
+    float G[kG];
+#pragma unroll
+    for (int s = 0; s < kG; ++s) G[s] = 0.0f;
+    const int num_waves = static_cast<int>(gridDim.x) * waves_per_block();
+    const int wave_global = static_cast<int>(blockIdx.x) * waves_per_block() + wave;
+    const int num_groups = (c.num_rays + kRays - 1) / kRays;
+    for (int group = wave_global; group < num_groups; group += num_waves) {
+        const int first_ray = group * kRays;
+        const RowLanes rl = row_lanes<kL>(opaque_lane_id());
+        wave_lds_sync();
+        bool done = false;
+        if (sh.reach >= 0.0f) {
+            done = sh.yaw ? rows_backward_body<kL, kRounds, true, false>(instances, N, c, sh, first_ray, origins, directions, distances, num_distances, grad_labels,
+                                                                         stage, dcache, coefs, rays, G, rl)
+                          : rows_backward_body<kL, kRounds, false, false>(instances, N, c, sh, first_ray, origins, directions, distances, num_distances, grad_labels,
+                                                                          stage, dcache, coefs, rays, G, rl);
+            if (!done) wave_lds_sync();
+        }
+        if (!done) rows_backward_body<kL, kRounds, false, true>(instances, N, c, sh, first_ray, origins, directions, distances, num_distances, grad_labels,
+                                                                stage, dcache, coefs, rays, G, rl);
+    }
+    float* out = partials + static_cast<size_t>(wave_global) * (N * kGradStride);
+#pragma unroll
+    for (int s = 0; s < kG; ++s)
+        if (s * kWave + lane0 < N * kGradStride) out[s * kWave + lane0] = G[s];
+}
+
+__global__ __launch_bounds__(kBlockThreads, 4) void render_backward_quad_kernel(
+    FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
+    const float* __restrict__ distances, int num_distances, const float* __restrict__ grad_labels, float* __restrict__ partials) {
+    backward_rows_kernel_body<kRowLanes>(f, instances, c, origins, directions, distances, num_distances, grad_labels, partials);
+}
+__global__ __launch_bounds__(kBlockThreads, 3) void render_backward_pair_kernel(
+    FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
+    const float* __restrict__ distances, int num_distances, const float* __restrict__ grad_labels, float* __restrict__ partials) {
+    backward_rows_kernel_body<32>(f, instances, c, origins, directions, distances, num_distances, grad_labels, partials);
+}
+
 // Two rays per wave, 32 lanes each (kRoundsS = 2: S <= 64; 4: S <= 128).
 #ifndef VSRD_PAIR_WAVES_PER_EU
 #define VSRD_PAIR_WAVES_PER_EU 3
