@@ -1,16 +1,20 @@
-// Fused optimisation step for box-only fields with FOUR NEIGHBOURING RAYS PER WAVE (BASELINE config 2: S <= 64, N <= 16).
+// Box-only fields with SEVERAL NEIGHBOURING RAYS PER WAVE: the fused optimisation step (vsrd_render_silhouette_step), the two-pass
+// forward (vsrd_render_hierarchical_forward, labels / distances only) and the adjoint at saved distances (vsrd_render_backward, label
+// adjoints only) for dense launches.
 //
-// Same arithmetic and semantics as render_silhouette_kernel (render_kernels.h; scripts/main.py:511-523, 653-671,
+// Same arithmetic and semantics as the one-ray kernels of render_kernels.h (scripts/main.py:511-523, 653-671,
 // vsrd/rendering/renderers.py:177-270, samplers.py:5-36), different mapping:
-//   render_silhouette_kernel   one wave = one ray,   lane = sample,                        rounds of 64 consecutive samples
-//   render_silhouette_quad     one wave = four rays, lane = (ray = lane >> 4, sample = lane & 15), rounds of 4 x 16 samples
+//   render_silhouette_kernel        one wave = one ray,   lane = sample,                              rounds of 64 consecutive samples
+//   render_silhouette_quad_kernel   one wave = four rays, lane = (ray = lane / 16, sample = lane % 16),  rounds of 4 x 16 samples   (N <= 16, S <= 64)
+//   render_silhouette_pair_kernel   one wave = two rays,  lane = (ray = lane / 32, sample = lane % 32),  rounds of 2 x 32 samples   (N <= 64, S <= 128)
 // Why: the instance culling (field.h) is wave-uniform, so its granularity is what one round covers.  64 consecutive samples span
-// half a ray and keep 11.1 (pass 1) / 7.4 (pass 2) of 16 instances at the mid schedule; 16 consecutive samples of four neighbouring
-// pixels cover a quarter of that depth range at nearly the same place and keep 5.8 / 4.8 (tests/cull_statistics.py): the instance
-// loops -- 78 % of the step -- shrink by 35-48 %, and one parameter-adjoint butterfly serves four rays instead of one.
-// What it costs: the per-ray state of the adjoint (9 floats per sample) lives in registers for the 8 rounds of pass 2 (72 VGPRs),
-// so everything else about a sample is re-derived where it is needed (opacity in the reverse sweep, the sample position from the
-// sorted distances), compositing scans are row scans (4 DPP steps) with per-row carries, and the per-ray constants are VGPRs.
+// half a ray and keep 11.1 (pass 1) / 7.4 (pass 2) of 16 instances at the mid schedule of BASELINE config 2; 16 consecutive samples of
+// four neighbouring pixels cover a quarter of that depth range at nearly the same place and keep 5.8 / 4.8 (tests/cull_statistics.py):
+// the instance loops -- 78 % of the step -- shrink by 35-48 %, and one parameter-adjoint butterfly serves four rays instead of one.
+// What it costs: the per-ray state of the adjoint lives in registers for all rounds of pass 2 (8 rounds x 6-7 floats), so everything
+// else about a sample is re-derived where it is needed (opacity in the reverse sweep, the sample position from the sorted distances)
+// or waits in LDS (transmittance, C1..C3); compositing scans are scans over a ray's lanes (DPP) with per-ray carries; the per-ray
+// constants live in LDS.  DESIGN.md section 2b.
 #pragma once
 #include "render_kernels.h"
 
