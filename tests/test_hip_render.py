@@ -941,6 +941,55 @@ def test_quad_step_matches_wave_per_ray(dev, N, S, R, case):
     assert (quad[2] - wave[2]).abs().max() <= gradient_tolerance * max(float(wave[2].abs().max()), 1e-6)
 
 
+def _shape_sweep():
+    """24 seeded random shapes over the whole range of the multi-ray kernels (N <= 64, S <= 128), edge sizes included."""
+    g = torch.Generator().manual_seed(2024)
+    shapes = [(1, 2, 1), (2, 3, 5), (16, 16, 4), (16, 17, 7), (17, 16, 3), (64, 2, 9), (3, 65, 6), (33, 127, 10), (64, 128, 2)]
+    while len(shapes) < 24:
+        shapes.append((int(torch.randint(1, 65, (1,), generator=g)), int(torch.randint(2, 129, (1,), generator=g)), int(torch.randint(1, 90, (1,), generator=g))))
+    return shapes
+
+
+@pytest.mark.parametrize("N,S,R", _shape_sweep())
+def test_multi_ray_kernels_match_one_ray_kernels_over_shapes(dev, N, S, R):
+    """The three entry points that have several-rays-per-wave forms on box-only fields -- vsrd_render_silhouette_step,
+    vsrd_render_hierarchical_forward (labels / distances) and vsrd_render_backward (label adjoints) -- against their one-ray-per-wave
+    forms (VSRD_FLAG_STEP_WAVE_PER_RAY) on seeded random shapes: instance counts on both sides of 16 and 32, sample counts on both sides of
+    16 / 32 / 64 and not multiples of the lanes per ray, ray counts that do not fill the last wave.  The parity tolerance of the path
+    (silhouettes 1e-4; gradients 5e-3 of the largest entry): the mappings cull different e^-18 terms and the coarse sample counts of
+    some shapes make the importance sampler ill-conditioned."""
+    from vsrd_amd import fields, rendering
+    from vsrd_amd.rendering import renderers
+    sc = _random_scene(1000 + 7 * N + S, N, R, S, general_rotations=(N % 3 == 0))
+    T, std, ratio = 0.3 + 0.02 * (S % 7), 0.35, 0.5
+    lam = torch.randn(R, N, generator=torch.Generator().manual_seed(N + S)).to(dev)
+    results = {}
+    for mode in ("rows", "wave"):
+        renderers.STEP_WAVE_PER_RAY = mode == "wave"
+        try:
+            inst = fields.pack_instances(sc["loc"], sc["rot"], sc["dim"]).to(dev).requires_grad_(True)
+            block = fields.FieldBlock(inst, T, None, None)
+            rays = (sc["origins"].to(dev), sc["directions"].to(dev))
+            uni = dict(u_coarse=sc["u_coarse"].to(dev), u_fine=sc["u_fine"].to(dev))
+            loss, labels = rendering.silhouette_step(block, *rays, sc["targets"].to(dev), (0.0, 100.0), S, std, ratio, return_labels=True, **uni)
+            step_grad = torch.autograd.grad(loss, inst)[0]
+            out = rendering.render_hierarchical(block, *rays, (0.0, 100.0), S, std, ratio, **uni)
+            api_grad = torch.autograd.grad((out["labels"] * lam).sum(), inst)[0]
+            results[mode] = (loss.detach(), labels, step_grad, out["labels"].detach(), out["distances"], api_grad)
+        finally:
+            renderers.STEP_WAVE_PER_RAY = False
+    rows, wave = results["rows"], results["wave"]
+    assert all(torch.isfinite(t).all() for t in rows[:4]) and torch.isfinite(rows[5]).all()
+    assert (rows[1] - wave[1]).abs().max() < LABEL_TOL and (rows[3] - wave[3]).abs().max() < LABEL_TOL
+    assert (rows[1] - rows[3]).abs().max() < 2e-6                  # the step and the forward of one mapping see the same silhouettes
+    torch.testing.assert_close(rows[0], wave[0], rtol=2e-4, atol=1e-6)
+    assert_sampled_distances_close(rows[4], wave[4], S) if S >= 8 else None
+    # (two float32 implementations, each within the parity tolerance of the exact answer -- on shape (36, 72, 61) the fused step of the
+    #  one-ray kernel is 2.9e-3 from the float64 oracle, the multi-ray one 1.0e-3, the float32 oracle 1.0e-3 --: twice the tolerance apart)
+    for a, b in ((rows[2], wave[2]), (rows[5], wave[5])):
+        assert (a - b).abs().max() <= 2.0 * GRAD_TOL * max(float(b.abs().max()), 1e-6)
+
+
 @pytest.mark.parametrize("N,S,R", [(64, 128, 200), (33, 40, 130), (2, 65, 3)])
 def test_residual_step_forms_agree_at_the_size_limits(dev, N, S, R):
     """The three forms of vsrd_render_residual_step (test_residual_step_forms_agree) away from the golden shapes: the largest field and

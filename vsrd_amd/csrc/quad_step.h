@@ -125,15 +125,18 @@ __device__ __forceinline__ int opaque_lane_id() {
 }
 
 // ---- per-wave LDS ------------------------------------------------------------------------------------------------------------------
-//   4 x [ coarse S | fine S (first the sorted uniforms) | 16 pad | merged 2S (first: raw uniforms | cdf) ]   the pad skews the rows by 16 banks
-//       and takes the tail of the per-point array below when 2S - 1 points are padded to whole rounds of 16
+//   4 x [ coarse S | fine S (first the sorted uniforms) | 16 pad | merged 2S (first: raw uniforms | cdf) | 16 + 4 pad ]   the first pad takes
+//       the tail of the per-point array below when 2S - 1 points are padded to whole rounds of 16, the second the tail of C2
 //   dcache [N][64]     soft-min terms of the current round (label sums; the last round's serve the label mix)
 //   4 x [ N x (a, b, radius, lambda) | 4 pad ]  culling coefficients of (ray, instance) (field.h: RayCull) + the ray's label adjoints
 //   4 x [ ox oy oz rx | ry rz reach pad ]       the rays themselves: re-read where they are needed instead of living in 9 registers
 // After importance_merge the coarse | fine part of a row holds, per pass-2 point, first the transmittance (forward sweep -> reverse
 // sweep) and then the interval mid-point (reverse sweep -> per-instance phase); the reverse sweep also turns merged[s + 1] into C2 of
 // point s once the distances of its round have been read (the rounds run backwards, so merged[16 q] stays for round q - 1).
-__host__ __device__ constexpr int quad_row_floats(int num_samples, int lanes = kRowLanes) { return 4 * num_samples + lanes + 4; }   // (+ 4: C2 of the last point, below)
+// (the sorted distances are followed by `lanes` + 4 floats: the reverse sweep writes C2 of point s at merged[s + 1] for EVERY lane of a
+//  round, padding lanes included, i.e. up to index roundup(2S - 1, lanes) -- without the room a row's padding lanes overwrote the next
+//  row's transmittances of round 0 whenever 2S - 1 is not just below a multiple of `lanes`: found by the shape sweep of round 3)
+__host__ __device__ constexpr int quad_row_floats(int num_samples, int lanes = kRowLanes) { return 4 * num_samples + 2 * lanes + 4; }
 __host__ __device__ constexpr int quad_merged_offset(int num_samples, int lanes = kRowLanes) { return 2 * num_samples + lanes; }
 __host__ __device__ constexpr int quad_coef_floats(int num_instances) { return kCullCoefs * num_instances + 4; }
 __host__ __device__ constexpr int quad_rounds_s(int num_samples, int lanes = kRowLanes) {          // rounds of `lanes` coarse points: 1, 2 or 4
