@@ -686,8 +686,18 @@ __device__ __forceinline__ void quad_phase_b(const QuadAdjoint<kRounds>& st, con
         const float packed[16] = {at0, at1, at2, r00, r01, r02, r10, r11, r12, r20, r21, r22, ad0, ad1, ad2, 0.0f};
         const float mine = wave_reduce16_scatter(packed, rl.lane);            // every lane: the wave's sum of parameter (lane & 15)
         const float add = ((rl.lane >> 4) == (i & 3)) ? mine : 0.0f;             // lane (16-lane row r, c) owns parameter c of instances r, 4 + r, ...
+        if (kL == kRowLanes) {
 #pragma unroll
-        for (int s = 0; s < (kL == kRowLanes ? 4 : 16); ++s) G[s] += ((i >> 2) == s) ? add : 0.0f;
+            for (int s = 0; s < 4; ++s) G[s] += ((i >> 2) == s) ? add : 0.0f;
+        } else {                                                                  // 16 registers: branch on the (wave-uniform) register index
+            switch (i >> 2) {
+#define VSRD_G_CASE(s) case s: G[s] += add; break;
+                VSRD_G_CASE(0) VSRD_G_CASE(1) VSRD_G_CASE(2) VSRD_G_CASE(3) VSRD_G_CASE(4) VSRD_G_CASE(5) VSRD_G_CASE(6) VSRD_G_CASE(7)
+                VSRD_G_CASE(8) VSRD_G_CASE(9) VSRD_G_CASE(10) VSRD_G_CASE(11) VSRD_G_CASE(12) VSRD_G_CASE(13) VSRD_G_CASE(14) VSRD_G_CASE(15)
+#undef VSRD_G_CASE
+                default: break;
+            }
+        }
     }
 }
 
