@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VSRD_ABI_VERSION 5
+#define VSRD_ABI_VERSION 6
 
 #define VSRD_OK 0
 #define VSRD_E_INVALID_ARGUMENT (-1) /* null pointer, non-positive size, unsupported N / S */
@@ -173,6 +173,23 @@ int32_t vsrd_linear_sum_assignment(const float* cost, int32_t num_rows, int32_t 
 size_t vsrd_sample_rays_workspace_bytes(void);
 int32_t vsrd_sample_rays(const float* weights, int64_t count, int32_t num_samples, uint64_t seed, uint64_t stream_offset,
                          const uint64_t* device_stream_offset, void* workspace, size_t workspace_bytes, int64_t* indices, void* stream);
+
+/* The same draw for weights that stay fixed over many calls (a frame's soft masks do not change over its 3000 steps,
+ * scripts/main.py:204-265, 620-627): vsrd_ray_table_build turns weights [count] into a table once (fixed-point weights and their
+ * 64-bit integer prefix sums: exact, so the table does not depend on the order of summation), and vsrd_sample_rays_table draws from it
+ * in ONE single-workgroup launch: i.i.d. picks from the table in a fixed order, Philox4x32-10 keyed by (seed, stream_offset; pick
+ * number), repeats skipped, the first num_samples (<= 2048) distinct picks kept -- successive sampling without replacement, the
+ * distribution of torch.multinomial(replacement=False) and of vsrd_sample_rays (the sequences themselves differ from theirs).
+ * remap (may be NULL): indices[i] = remap[pick] (the caller's compaction of the positive weights).  Skipping repeats needs about
+ * num_samples / (weight mass outside the num_samples - 1 heaviest entries) picks; a call gives up after 32768, fills the rest with
+ * repeats of its first picks and sets a sticky flag in the table (the uint32 at byte 28; reading it back is a host
+ * synchronisation), so callers check that mass once per table and keep vsrd_sample_rays for weights that fail it
+ * (vsrd_amd/rendering/samplers.py::RayTable.suits).
+ * count < 2^32 - 1.  Fewer than num_samples positive weights: -1 fills the tail, as above. */
+size_t vsrd_ray_table_bytes(int64_t count);
+int32_t vsrd_ray_table_build(const float* weights, int64_t count, void* table, size_t table_bytes, void* stream);
+int32_t vsrd_sample_rays_table(void* table, int64_t count, int32_t num_samples, uint64_t seed, uint64_t stream_offset,
+                               const uint64_t* device_stream_offset, const int64_t* remap, int64_t* indices, void* stream);
 
 /* vsrd.rendering.ray_casting (vsrd/rendering/utils.py:5-18), the per-pixel part:
  * directions[v,y,x,:] = normalize(inverse_projection[v] @ (x, y, 1)), integer pixel centres.

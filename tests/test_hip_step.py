@@ -272,10 +272,20 @@ def test_soft_rasterizer_g11(dev):
         torch.testing.assert_close(soft[k].cpu(), g[f"soft_{k}"], rtol=1e-5, atol=1e-5)
 
 
-def test_ray_sampler_matches_multinomial_statistics(dev):
-    """a17: vsrd_sample_rays against torch.multinomial(weights, k, replacement=False): distinct indices, only positive weights,
-    deterministic in (seed, step), different across steps, and the same inclusion frequencies (exponential race = ATen's algorithm)."""
+@pytest.mark.parametrize("sampler", ["race", "table"])
+def test_ray_sampler_matches_multinomial_statistics(dev, sampler, monkeypatch):
+    """a17: vsrd_sample_rays (per-step exponential race = ATen's algorithm) and vsrd_sample_rays_table (per-frame table, one launch per
+    draw) against torch.multinomial(weights, k, replacement=False): distinct indices, only positive weights, deterministic in (seed,
+    step), different across steps, and the same inclusion frequencies."""
     from vsrd_amd import rendering
+    if sampler == "table":
+        tables = {}
+        def through_table(weights, num_samples, seed=0, stream_offset=0, out=None):
+            key = (weights.data_ptr(), weights.numel())
+            if key not in tables:
+                tables[key] = (rendering.RayTable(weights), weights)
+            return tables[key][0].sample(num_samples, seed=seed, stream_offset=stream_offset, out=out)
+        monkeypatch.setattr(rendering, "sample_rays", through_table)
     gen = torch.Generator().manual_seed(0)
     M, k, draws = 512, 64, 600
     weights = torch.rand(M, generator=gen) ** 3
@@ -305,6 +315,66 @@ def test_ray_sampler_matches_multinomial_statistics(dev):
     few = torch.zeros(1000, device=dev); few[:10] = 1.0
     idx = rendering.sample_rays(few, 32, seed=1)
     assert sorted(idx[:10].cpu().tolist()) == list(range(10)) and bool((idx[10:] == -1).all())
+
+
+def test_ray_table_is_exact_and_bounded(dev):
+    """csrc/ray_sampling.h, the per-frame table: its prefix sums are the integer sums of the fixed-point weights (bit-exact against
+    numpy, whatever the scan order), a remap is applied to the picks, the first pick alone follows the weights, weights that
+    concentrate in fewer entries than a draw needs are refused by `suits`, and a draw that runs out of picks anyway stays inside the
+    index range and raises the sticky flag."""
+    import numpy as np
+    from vsrd_amd import rendering
+    gen = torch.Generator().manual_seed(3)
+    for M in (1, 17, 4096, 4097, 70001):
+        weights = torch.rand(M, generator=gen) ** 4 * 3.0
+        weights[torch.rand(M, generator=gen) < 0.4] = 0.0
+        weights[M // 2] = 2.5
+        table = rendering.RayTable(weights.to(dev))
+        raw = table.table.cpu().numpy()
+        header = raw[:64].view(np.uint64)
+        w = weights.numpy().astype(np.float64)
+        bits = min(62 - int(np.ceil(np.log2(M))) if M > 1 else 62, 52)
+        scale = np.ldexp(1.0, bits) / float(weights.max())
+        fixed = np.where(w > 0, np.maximum((w * scale).astype(np.uint64), 1), 0).astype(np.uint64)
+        expected = np.cumsum(fixed, dtype=np.uint64)
+        assert np.array_equal(raw[64:64 + 8 * M].view(np.uint64), expected)
+        assert int(header[0]) == int(expected[-1]) and int(header[1]) == int((w > 0).sum()) and int(header[2]) == int(np.nonzero(w > 0)[0][-1])
+        guide_bits = min(max(10, int(np.ceil(np.log2(M))) if M > 1 else 10), 26)
+        blocks = (M + 4095) // 4096
+        guide = raw[64 + 8 * (M + blocks):64 + 8 * (M + blocks) + 4 * ((1 << guide_bits) + 1)].view(np.uint32)
+        total = int(expected[-1])
+        firsts = np.array([((g << (64 - guide_bits)) * total) >> 64 for g in range(1 << guide_bits)], dtype=np.uint64)
+        assert np.array_equal(guide[:-1], np.searchsorted(expected, firsts, side="right").astype(np.uint32)) and int(guide[-1]) == int(header[2])
+    # remap: the same draw through a permutation
+    M, k = 5000, 300
+    weights = (torch.rand(M, generator=gen) - 0.3).clamp_min(0).to(dev)
+    table = rendering.RayTable(weights)
+    assert table.suits(k)
+    plain = table.sample(k, seed=11, stream_offset=4)
+    remap = torch.randperm(M, generator=gen).to(dev)
+    assert torch.equal(table.sample(k, seed=11, stream_offset=4, remap=remap), remap[plain])
+    assert plain.unique().numel() == k and bool((weights[plain] > 0).all()) and not table.incomplete()
+    # the first pick is one multinomial draw: its frequencies over many steps follow the weights
+    M, draws = 64, 4000
+    weights = torch.rand(M, generator=gen) ** 2
+    weights[::5] = 0.0
+    table = rendering.RayTable(weights.to(dev))
+    counts = torch.zeros(M)
+    for d in range(draws):
+        counts[int(table.sample(4, seed=5, stream_offset=d)[0])] += 1
+    p = weights / weights.sum()
+    sigma = (p * (1 - p) / draws).clamp_min(1e-8).sqrt()
+    assert float(counts[weights == 0].max()) == 0.0 and float(((counts / draws - p).abs() / sigma).max()) < 5.0
+    # one entry holds (nearly) all the weight: not suited; the draw gives up after 32768 picks, stays in range and says so
+    weights = torch.full((200,), 1.0e-9); weights[7] = 1.0
+    table = rendering.RayTable(weights.to(dev))
+    assert not table.suits(5) and not table.incomplete()
+    idx = table.sample(5, seed=1)
+    assert int(idx[0]) == 7 and bool(((idx >= 0) & (idx < 200)).all()) and table.incomplete()
+    with pytest.raises(Exception):
+        rendering.RayTable(torch.ones(16))                                            # host tensor
+    with pytest.raises(Exception):
+        rendering.RayTable(torch.ones(10000, device=dev)).sample(4096)                # more than 2048 samples
 
 
 def _c1_inputs(dev, V=3, H=128, W=128, N=4, S=32, all_visible=False, seed=0):

@@ -1,13 +1,15 @@
 #!/bin/bash
 # Kernel timeline of ONE replayed step of the reference's native mode (1000 rays x 100 samples, residual phase), from a rocprofv3
 # kernel trace: start / end / duration / queue of every kernel between two frame_epilogue launches.  GPU box, via gpurun:
-#   bash tools/native_timeline.sh [extra native_mode_bench.py flags]  > gpurun_out/native_step_timeline.txt
+#   bash tools/native_timeline.sh [box-only] [extra native_mode_bench.py flags]  > gpurun_out/native_step_timeline.txt
 set -u
+PHASE=--residual
+if [ "${1:-}" = "box-only" ]; then PHASE=; shift; fi
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$(mktemp -d /tmp/native_timeline.XXXXXX)
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d "$OUT" -o native -- python3 "$ROOT/tools/native_mode_bench.py" --graph --residual --steps 40 "$@" > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d "$OUT" -o native -- python3 "$ROOT/tools/native_mode_bench.py" --graph $PHASE --steps 40 "$@" > /dev/null 2>&1
 cd "$ROOT"
 python3 - "$OUT" <<'PY'
 import csv, glob, sys

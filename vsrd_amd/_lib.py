@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VSRD_HIP_LIBRARY: an experiment build of the same ABI (tools/phase_timers.py, A/B macros); the product path is the in-tree default
 LIBRARY_PATH = os.environ.get("VSRD_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libvsrd_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_INSTANCES = 64
 MAX_SAMPLES = 256
 INSTANCE_STRIDE = 16
@@ -158,6 +158,10 @@ SIGNATURES = {
     "vsrd_sample_rays_workspace_bytes": (ctypes.c_size_t, []),
     "vsrd_sample_rays": (ctypes.c_int32, [c_float_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
+    "vsrd_ray_table_bytes": (ctypes.c_size_t, [ctypes.c_int64]),
+    "vsrd_ray_table_build": (ctypes.c_int32, [c_float_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "vsrd_sample_rays_table": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p,
+                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "vsrd_match_boxes": (ctypes.c_int32, [c_float_p, c_float_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "vsrd_linear_sum_assignment": (ctypes.c_int32, [c_float_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "vsrd_frame_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),

@@ -1147,6 +1147,34 @@ int32_t vsrd_sample_rays(const float* weights, int64_t count, int32_t num_sample
     return launch_status();
 }
 
+size_t vsrd_ray_table_bytes(int64_t count) { return count < 1 ? 0 : ray_table_bytes(count); }
+
+int32_t vsrd_ray_table_build(const float* weights, int64_t count, void* table, size_t table_bytes, void* stream) {
+    if (!weights || !table || count < 1 || count >= 0xffffffffll) return VSRD_E_INVALID_ARGUMENT;
+    if (table_bytes < ray_table_bytes(count)) return VSRD_E_WORKSPACE;
+    const hipStream_t s = static_cast<hipStream_t>(stream);
+    RayTableHeader* header = static_cast<RayTableHeader*>(table);
+    if (hipMemsetAsync(header, 0, sizeof(RayTableHeader), s) != hipSuccess) return VSRD_E_LAUNCH;
+    const long long blocks = ray_table_blocks(count);
+    hipLaunchKernelGGL(ray_table_max_kernel, dim3(static_cast<unsigned>(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, s, weights, static_cast<long long>(count), header);
+    hipLaunchKernelGGL(ray_table_sums_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, weights, static_cast<long long>(count), header);
+    hipLaunchKernelGGL(ray_table_offsets_kernel, dim3(1), dim3(1024), 0, s, static_cast<long long>(count), header);
+    hipLaunchKernelGGL(ray_table_fill_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, weights, static_cast<long long>(count), header);
+    const long long boundaries = (1ll << ray_table_guide_bits(count)) + 1;
+    hipLaunchKernelGGL(ray_table_guide_kernel, dim3(static_cast<unsigned>((boundaries + 255) / 256)), dim3(256), 0, s, static_cast<long long>(count), header);
+    return launch_status();
+}
+
+int32_t vsrd_sample_rays_table(void* table, int64_t count, int32_t num_samples, uint64_t seed, uint64_t stream_offset,
+                               const uint64_t* device_stream_offset, const int64_t* remap, int64_t* indices, void* stream) {
+    if (!table || !indices || count < 1 || count >= 0xffffffffll || num_samples < 1 || num_samples > kSampleMax) return VSRD_E_INVALID_ARGUMENT;
+    if (opt_in_lds(sample_table_kernel, kTableLdsBytes) != VSRD_OK) return VSRD_E_LAUNCH;
+    hipLaunchKernelGGL(sample_table_kernel, dim3(1), dim3(kTableThreads), kTableLdsBytes, static_cast<hipStream_t>(stream), static_cast<RayTableHeader*>(table),
+                       static_cast<long long>(count), num_samples, seed, stream_offset, reinterpret_cast<const unsigned long long*>(device_stream_offset),
+                       reinterpret_cast<const long long*>(remap), reinterpret_cast<long long*>(indices));
+    return launch_status();
+}
+
 int32_t vsrd_match_boxes(const float* pd_boxes, const float* gt_boxes, int32_t num_pd, int32_t num_gt,
                          int64_t* pd_indices, int64_t* gt_indices, void* stream) {
     if (!pd_boxes || !gt_boxes || !pd_indices || !gt_indices || num_pd < 1 || num_gt < 1 || num_pd > 64 || num_gt > 64) return VSRD_E_INVALID_ARGUMENT;

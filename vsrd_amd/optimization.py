@@ -145,6 +145,14 @@ class FrameOptimizer:
         if int(self.positive_pixels.numel()) < config.num_rays:
             raise ValueError(f"only {int(self.positive_pixels.numel())} pixels have a positive soft mask, fewer than num_rays = {config.num_rays} "
                              "(torch.multinomial without replacement raises in the reference as well)")
+        # graph mode draws the rays on the device.  The weights are fixed for the frame, so the sampler's table is built once here and a
+        # step's draw is one launch (csrc/ray_sampling.h); frames whose weight sits in fewer entries than a draw needs keep the
+        # per-step exponential race (`ray_table` None)
+        self.ray_table = None
+        if self.graph and self.device.type == "cuda":
+            table = rendering.RayTable(self.positive_weights)
+            if table.suits(config.num_rays):
+                self.ray_table = table
         self.pixels_per_view = H * W
         self.step_index = 0
         if self.fused_glue:
@@ -220,8 +228,7 @@ class FrameOptimizer:
         if sampled:                     # branch 1: this step's rays (device sampler keyed by the step counter, ray_sampling.h)
             rays_branch.wait_stream(main)
             with torch.cuda.stream(rays_branch):
-                rendering.sample_rays(self.positive_weights, cfg.num_rays, seed=cfg.seed + 1, stream_offset=self.step_tensor, out=b["picks"])
-                torch.index_select(self.positive_pixels, 0, b["picks"], out=b["ray_indices"])
+                self._draw_rays(b["ray_indices"], b["picks"])
             ray_indices = b["ray_indices"]
         if fused_net:                   # branch 2: embeddings -> MLP weights
             hyper_ws = b["hyper_workspace"]
@@ -305,9 +312,16 @@ class FrameOptimizer:
         uses the library's own sampler (same algorithm, Philox keyed by the device-side step counter): ATen's captured multinomial
         faults on replay with this torch build, and it sorts all V*H*W keys every step."""
         if self.graph:
-            picks = rendering.sample_rays(self.positive_weights, self.config.num_rays, seed=self.config.seed + 1, stream_offset=self.step_tensor)
-            return self.positive_pixels[picks]
+            return self._draw_rays(torch.empty(self.config.num_rays, dtype=torch.int64, device=self.device))
         return torch.multinomial(self.sampling_weights, self.config.num_rays, replacement=False)
+
+    def _draw_rays(self, out, picks=None):
+        """Graph mode's draw of this step's rays into `out` (pixel indices over all views), keyed by the device-side step counter."""
+        cfg = self.config
+        if self.ray_table is not None:
+            return self.ray_table.sample(cfg.num_rays, seed=cfg.seed + 1, stream_offset=self.step_tensor, out=out, remap=self.positive_pixels)
+        picks = rendering.sample_rays(self.positive_weights, cfg.num_rays, seed=cfg.seed + 1, stream_offset=self.step_tensor, out=picks)
+        return torch.index_select(self.positive_pixels, 0, picks, out=out)
 
     def field_block(self, outputs, temperature, mlp_weights=None):
         return fields.FieldBlock(fields.pack_instances(outputs["locations"][0], outputs["orientations"][0], outputs["dimensions"][0]),
@@ -444,6 +458,10 @@ class FrameOptimizer:
         """Drop the captured graphs and the scratch buffers (also happens when the optimizer is garbage-collected).  Once per frame
         this is also where the device ray sampler's sticky overflow flag is read back (a host synchronisation, so not per step): a
         draw whose threshold bin held more candidate keys than the sampler lists was incomplete and not reproducible."""
+        if self.graph and self.ray_table is not None and self.ray_table.incomplete():
+            import warnings
+            warnings.warn("vsrd_sample_rays_table ran out of picks in some step of this frame: those draws repeat some rays "
+                          "(see csrc/ray_sampling.h and RayTable.suits)", RuntimeWarning)
         if self.graph and self.workspace.sampler_overflowed(self.device):
             import warnings
             warnings.warn("vsrd_sample_rays overflowed its candidate list in some step of this frame: those draws were incomplete "

@@ -82,3 +82,54 @@ def sample_rays(weights, num_samples, seed=0, stream_offset=0, out=None):
     _lib.check(lib.vsrd_sample_rays(_lib.ptr(weights), weights.numel(), int(num_samples), int(seed) & 0xFFFFFFFFFFFFFFFF,
                                     int(stream_offset) & 0xFFFFFFFFFFFFFFFF, offset_ptr, buf.data_ptr(), buf.numel(), indices.data_ptr(), _lib.stream()))
     return indices
+
+
+class RayTable:
+    """``torch.multinomial(weights, k, replacement=False)`` for weights that stay fixed over many draws (a frame's importance weights,
+    scripts/main.py:204-265, 620-627): the table is built once (vsrd_ray_table_build) and every draw is one launch
+    (vsrd_sample_rays_table) instead of the five of ``sample_rays``.  Same distribution over ordered samples (successive sampling
+    without replacement); the sequences for a given seed differ from ``sample_rays``'s."""
+
+    MAX_PICKS = 32768          # csrc/ray_sampling.h: kTableRounds x 2048 candidates per draw
+
+    def __init__(self, weights):
+        lib = _lib.load()
+        self.weights = weights.detach().reshape(-1).to(torch.float32).contiguous()
+        if not self.weights.is_cuda:
+            raise _lib.VsrdHipError("RayTable needs device weights (there is no CPU path)")
+        self.count = int(self.weights.numel())
+        self.table = torch.empty(lib.vsrd_ray_table_bytes(self.count), dtype=torch.uint8, device=self.weights.device)
+        _lib.check(lib.vsrd_ray_table_build(_lib.ptr(self.weights), self.count, self.table.data_ptr(), self.table.numel(), _lib.stream()))
+
+    def suits(self, num_samples, margin=4.0):
+        """Whether ``num_samples`` distinct picks arrive well inside the kernel's budget: skipping repeats needs about
+        num_samples / (share of the weight outside the num_samples - 1 heaviest entries) picks.  One host synchronisation: call it once."""
+        positive = self.weights.clamp_min(0).double()
+        total = float(positive.sum())
+        if total <= 0.0 or num_samples < 1:
+            return False
+        heaviest = float(torch.topk(positive, min(max(int(num_samples) - 1, 1), self.count)).values.sum()) if num_samples > 1 else 0.0
+        outside = max(1.0 - heaviest / total, 0.0)
+        return outside > 0.0 and margin * num_samples / outside <= self.MAX_PICKS
+
+    def sample(self, num_samples, seed=0, stream_offset=0, out=None, remap=None):
+        """int64 indices [num_samples] in the order they were drawn (``remap[index]`` when a remap table is given); ``stream_offset`` may
+        be a device int64 tensor (hipGraph replay).  -1 fills the tail when fewer than num_samples weights are positive."""
+        lib = _lib.load()
+        device = self.weights.device
+        indices = torch.empty(int(num_samples), dtype=torch.int64, device=device) if out is None else out
+        if indices.dtype != torch.int64 or indices.numel() != int(num_samples) or not indices.is_contiguous() or indices.device != device:
+            raise ValueError("out must be a contiguous int64 tensor of num_samples elements on the weights' device")
+        if remap is not None and (remap.dtype != torch.int64 or remap.numel() != self.count or not remap.is_contiguous() or remap.device != device):
+            raise ValueError("remap must be a contiguous int64 tensor with one entry per weight on the weights' device")
+        offset_ptr = None
+        if isinstance(stream_offset, torch.Tensor):
+            offset_ptr, stream_offset = stream_offset.data_ptr(), 0
+        _lib.check(lib.vsrd_sample_rays_table(self.table.data_ptr(), self.count, int(num_samples), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                              int(stream_offset) & 0xFFFFFFFFFFFFFFFF, offset_ptr, None if remap is None else remap.data_ptr(),
+                                              indices.data_ptr(), _lib.stream()))
+        return indices
+
+    def incomplete(self):
+        """True when some draw ran out of picks and filled its tail with repeats (sticky; a host synchronisation)."""
+        return bool(self.table[28:32].view(torch.int32).item() != 0)
