@@ -1016,7 +1016,7 @@ namespace {
 struct HyperPlan {
     size_t activations;        // float offset of z[l] = activations + l * N * 256, l < 4
     size_t inv_norm;           // 4 x 256 + 1632
-    size_t gz;                 // 2 x N x 256
+    size_t gz;                 // 5 x N x 256: the output adjoints of the four hidden linears, then the embeddings' gradient
     size_t partials;           // final_blocks x N x 256
     size_t norm_partials;      // 4 x N x 2 x 256
     size_t total;
@@ -1029,7 +1029,7 @@ static HyperPlan plan_hypernetwork(int num_instances) {
     p.activations = 0;
     p.inv_norm = p.activations + (VSRD_HYPER_LAYERS - 1) * slab;
     p.gz = p.inv_norm + (VSRD_HYPER_LAYERS - 1) * kHyperWidth + kMlpWbarFloats;
-    p.partials = p.gz + 2 * slab;
+    p.partials = p.gz + (VSRD_HYPER_LAYERS) * slab;
     p.norm_partials = p.partials + static_cast<size_t>(p.final_blocks) * slab;
     p.total = p.norm_partials + (VSRD_HYPER_LAYERS - 1) * 2 * slab;
     return p;
@@ -1062,17 +1062,20 @@ int32_t vsrd_hypernetwork_forward(const vsrd_hypernetwork* net, void* workspace,
     const hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t slab = static_cast<size_t>(N) * kHyperWidth, lds = slab * sizeof(float);
     if (opt_in_lds(hyper_linear_forward_kernel, lds) != VSRD_OK) return VSRD_E_LAUNCH;
-    for (int l = 0; l < VSRD_HYPER_LAYERS; ++l) {
-        const bool last = l + 1 == VSRD_HYPER_LAYERS;
-        const int rows = last ? kMlpWeights : kHyperWidth;
-        const float* x = l == 0 ? net->embeddings.parameter : ws + p.activations + (l - 1) * slab;
-        const float* gamma = l == 0 ? nullptr : net->norm_weight[l - 1].parameter;
-        const float* beta = l == 0 ? nullptr : net->norm_bias[l - 1].parameter;
-        float* z = last ? mlp_weights : ws + p.activations + l * slab;
-        hipLaunchKernelGGL(hyper_linear_forward_kernel, dim3((rows + kHyperWaves - 1) / kHyperWaves), dim3(kHyperThreads), lds, s,
-                           x, gamma, beta, net->weight_v[l].parameter, net->weight_g[l].parameter, net->bias[l].parameter, rows, N, z,
-                           ws + p.inv_norm + l * kHyperWidth);
+    constexpr int kLast = VSRD_HYPER_LAYERS - 1;
+    static_assert(kLast == kHyperHidden, "csrc/hypernetwork.h is written for four hidden blocks");
+    HyperHiddenForward hidden;
+    for (int l = 0; l < kLast; ++l) {
+        hidden.v[l] = net->weight_v[l].parameter; hidden.g[l] = net->weight_g[l].parameter; hidden.b[l] = net->bias[l].parameter;
+        hidden.z[l] = ws + p.activations + l * slab;
+        hidden.inv_norm[l] = ws + p.inv_norm + l * kHyperWidth;
+        if (l + 1 < kLast) { hidden.gamma[l] = net->norm_weight[l].parameter; hidden.beta[l] = net->norm_bias[l].parameter; }
     }
+    hipLaunchKernelGGL(hyper_hidden_forward_kernel, dim3(N), dim3(kHyperChainThreads), 0, s, net->embeddings.parameter, hidden);
+    hipLaunchKernelGGL(hyper_linear_forward_kernel, dim3((kMlpWeights + kHyperWaves - 1) / kHyperWaves), dim3(kHyperThreads), lds, s,
+                       ws + p.activations + (kLast - 1) * slab, net->norm_weight[kLast - 1].parameter, net->norm_bias[kLast - 1].parameter,
+                       net->weight_v[kLast].parameter, net->weight_g[kLast].parameter, net->bias[kLast].parameter, kMlpWeights, N, mlp_weights,
+                       ws + p.inv_norm + kLast * kHyperWidth);
     if (centred) hipLaunchKernelGGL(hyper_centre_kernel, dim3(N), dim3(128), 0, s, mlp_weights, N, centred);
     return launch_status();
 }
@@ -1086,44 +1089,50 @@ int32_t vsrd_hypernetwork_backward_step(const vsrd_hypernetwork* net, void* work
     float* ws = static_cast<float*>(workspace);
     const hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t slab = static_cast<size_t>(N) * kHyperWidth, lds = (slab + kHyperWaves * kHyperWidth + static_cast<size_t>(N) * kHyperWaves) * sizeof(float);
-    if (opt_in_lds(hyper_linear_backward_kernel, lds) != VSRD_OK) return VSRD_E_LAUNCH;
-    HyperNorms norms;
+    if (opt_in_lds(hyper_linear_backward_kernel, lds) != VSRD_OK || opt_in_lds(hyper_hidden_update_kernel, lds) != VSRD_OK) return VSRD_E_LAUNCH;
+    constexpr int kLast = VSRD_HYPER_LAYERS - 1;
     const HyperAdam adam{net->beta1, net->beta2, net->adam_epsilon};
+    auto z = [&](int l) { return ws + p.activations + l * slab; };              // output of linear l (l < 4)
+    auto gz = [&](int l) { return ws + p.gz + l * slab; };                       // its adjoint; gz(4): the embeddings' gradient
+    auto inv_norm = [&](int l) { return ws + p.inv_norm + l * kHyperWidth; };
+    auto norm_shares = [&](int k) { return ws + p.norm_partials + k * 2 * slab; };
+    // the final linear: its own update and its workgroups' shares of the input adjoint; their sum through the norm behind linear 3
+    const int final_blocks = (kMlpWeights + kHyperWaves - 1) / kHyperWaves;
+    hipLaunchKernelGGL(hyper_linear_backward_kernel, dim3(final_blocks), dim3(kHyperThreads), lds, s, z(kLast - 1), net->norm_weight[kLast - 1].parameter,
+                       net->norm_bias[kLast - 1].parameter, grad_mlp_weights, grad_scale, inv_norm(kLast), kMlpWeights, N, adam_tensors(net->weight_v[kLast]),
+                       adam_tensors(net->weight_g[kLast]), adam_tensors(net->bias[kLast]), adam, ws + p.partials);
+    hipLaunchKernelGGL(hyper_norm_backward_kernel, dim3(N), dim3(kHyperNormThreads), 0, s, ws + p.partials, final_blocks, z(kLast - 1), N,
+                       net->norm_weight[kLast - 1].parameter, net->norm_bias[kLast - 1].parameter, gz(kLast - 1), norm_shares(kLast - 1));
+    // the chain through the hidden blocks (one workgroup per instance), then every hidden linear's own update
+    HyperHiddenBackward chain;
+    HyperHiddenUpdate update;
+    HyperNorms norms;
     HyperStepCounters counters;
     counters.count = 0;
     counters.step[counters.count++] = net->embeddings.step;
-    const float* gz = grad_mlp_weights;
-    float scale = grad_scale;
-    for (int l = VSRD_HYPER_LAYERS - 1; l >= 0; --l) {
-        const bool last = l + 1 == VSRD_HYPER_LAYERS;
-        const int rows = last ? kMlpWeights : kHyperWidth;
-        const int blocks = (rows + kHyperWaves - 1) / kHyperWaves;
-        const float* x = l == 0 ? net->embeddings.parameter : ws + p.activations + (l - 1) * slab;
-        const float* gamma = l == 0 ? nullptr : net->norm_weight[l - 1].parameter;
-        const float* beta = l == 0 ? nullptr : net->norm_bias[l - 1].parameter;
-        hipLaunchKernelGGL(hyper_linear_backward_kernel, dim3(blocks), dim3(kHyperThreads), lds, s, x, gamma, beta, gz, scale,
-                           ws + p.inv_norm + l * kHyperWidth, rows, N, adam_tensors(net->weight_v[l]), adam_tensors(net->weight_g[l]),
-                           adam_tensors(net->bias[l]), adam, ws + p.partials);
+    for (int l = 0; l < VSRD_HYPER_LAYERS; ++l) {
         counters.step[counters.count++] = net->weight_v[l].step;
         counters.step[counters.count++] = net->weight_g[l].step;
         counters.step[counters.count++] = net->bias[l].step;
-        float* gz_out = ws + p.gz + (l & 1) * slab;
-        if (l > 0) {
-            hipLaunchKernelGGL(hyper_norm_backward_kernel, dim3(N), dim3(kHyperNormThreads), 0, s, ws + p.partials, blocks, x, N, gamma, beta,
-                               adam_tensors(net->embeddings), 0, adam, gz_out, ws + p.norm_partials + (l - 1) * 2 * slab);
-            norms.gamma[l - 1] = adam_tensors(net->norm_weight[l - 1]);
-            norms.beta[l - 1] = adam_tensors(net->norm_bias[l - 1]);
-            counters.step[counters.count++] = net->norm_weight[l - 1].step;
-            counters.step[counters.count++] = net->norm_bias[l - 1].step;
-        } else {
-            hipLaunchKernelGGL(hyper_norm_backward_kernel, dim3(N), dim3(kHyperNormThreads), 0, s, ws + p.partials, blocks, nullptr, N, nullptr, nullptr,
-                               adam_tensors(net->embeddings), 1, adam, gz_out, nullptr);
-        }
-        gz = gz_out;
-        scale = 1.0f;
+        if (l == kLast) break;
+        counters.step[counters.count++] = net->norm_weight[l].step;
+        counters.step[counters.count++] = net->norm_bias[l].step;
+        norms.gamma[l] = adam_tensors(net->norm_weight[l]);
+        norms.beta[l] = adam_tensors(net->norm_bias[l]);
+        chain.v[l] = net->weight_v[l].parameter; chain.g[l] = net->weight_g[l].parameter; chain.inv_norm[l] = inv_norm(l);
+        chain.gz[l] = gz(l);
+        if (l + 1 < kLast) { chain.gamma[l] = net->norm_weight[l].parameter; chain.beta[l] = net->norm_bias[l].parameter; chain.z[l] = z(l); chain.norm_partials[l] = norm_shares(l); }
+        update.x[l] = l == 0 ? net->embeddings.parameter : z(l - 1);
+        update.gamma[l] = l == 0 ? nullptr : net->norm_weight[l - 1].parameter;
+        update.beta[l] = l == 0 ? nullptr : net->norm_bias[l - 1].parameter;
+        update.gz[l] = gz(l); update.inv_norm[l] = inv_norm(l);
+        update.v[l] = adam_tensors(net->weight_v[l]); update.g[l] = adam_tensors(net->weight_g[l]); update.b[l] = adam_tensors(net->bias[l]);
     }
-    hipLaunchKernelGGL(hyper_norm_adam_kernel, dim3(VSRD_HYPER_LAYERS - 1), dim3(kHyperNormThreads), 0, s, norms, ws + p.norm_partials, N, adam);
-    hipLaunchKernelGGL(hyper_finish_kernel, dim3(1), dim3(kWave), 0, s, counters, net->embeddings.learning_rate, net->weight_v[0].learning_rate, net->lr_gamma);
+    chain.embedding_bar = gz(kLast);
+    hipLaunchKernelGGL(hyper_hidden_backward_kernel, dim3(N), dim3(kHyperChainThreads), 0, s, chain);
+    hipLaunchKernelGGL(hyper_hidden_update_kernel, dim3(kHyperHidden * (kHyperWidth / kHyperWaves)), dim3(kHyperThreads), lds, s, update, N, adam);
+    hipLaunchKernelGGL(hyper_finish_kernel, dim3(1), dim3(kHyperChainThreads), 0, s, norms, ws + p.norm_partials, adam_tensors(net->embeddings), gz(kLast), N, adam,
+                       counters, net->embeddings.learning_rate, net->weight_v[0].learning_rate, net->lr_gamma);
     return launch_status();
 }
 

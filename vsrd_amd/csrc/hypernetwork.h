@@ -6,7 +6,8 @@
 //   weight_norm (dim = 0):  W[o, :] = g[o] v[o, :] / |v[o, :]|
 //   torch.optim.Adam on every tensor (embeddings 1e-3, hypernetwork 1e-4), ExponentialLR
 // With torch these are ~130 element-wise / GEMM / reduction launches of 3-5 us per step for <= 64 rows of 256 numbers (0.4 of the
-// 1.56 ms of a residual step at 1000 rays); here 6 launches forwards and 12 backwards.  The parameters, Adam's moments and step
+// 1.56 ms of a residual step at 1000 rays); here 3 launches forwards and 5 backwards (round 2: 6 and 12, one per layer -- but the
+// instances only meet in the parameter gradients, so the four hidden blocks run as ONE workgroup per instance in either direction).  The parameters, Adam's moments and step
 // counters are the torch module's and torch.optim.Adam's own device tensors, updated in place (state dicts stay what they are).
 //
 // Mapping: one wave = one output row of a linear at a time, the lane holds 4 of its 256 inputs; the activations of all N instances
@@ -93,6 +94,91 @@ __global__ __launch_bounds__(kHyperThreads) void hyper_linear_forward_kernel(
     if (lane == 0) inv_norm[o] = inv;
 }
 
+// The four hidden blocks of ONE instance per workgroup (the instances do not meet before the losses): four dependent launches of the
+// kernel above become one.  16 waves, one output row per wave at a time (16 rows each, all 16 row loads in flight at once); the
+// LayerNorm + GELU between two linears is one wave's work (4 channels per lane).  z[l] [N][256]: the linears' outputs, kept for the
+// backward; inv_norm[l] [256] likewise (every workgroup computes the same values; the first one stores them).
+constexpr int kHyperChainThreads = 1024;
+constexpr int kHyperChainWaves = kHyperChainThreads / kWave;
+constexpr int kHyperHidden = 4;
+
+struct HyperHiddenForward {
+    const float* v[kHyperHidden]; const float* g[kHyperHidden]; const float* b[kHyperHidden];
+    const float* gamma[kHyperHidden - 1]; const float* beta[kHyperHidden - 1];        // the norm BEHIND linear l feeds linear l + 1
+    float* z[kHyperHidden]; float* inv_norm[kHyperHidden];
+};
+
+__global__ __launch_bounds__(kHyperChainThreads) void hyper_hidden_forward_kernel(const float* __restrict__ embeddings, HyperHiddenForward net) {
+    __shared__ __attribute__((aligned(16))) float h[kHyperWidth];
+    __shared__ __attribute__((aligned(16))) float out[kHyperWidth];
+    const int n = blockIdx.x, wave = static_cast<int>(threadIdx.x) >> 6, lane = lane_id();
+    constexpr int kWorkers = kHyperChainWaves - 1;                 // waves 1 .. 15 hold the rows: o = (wave - 1) + 15 r
+    constexpr int kRows = (kHyperWidth + kWorkers - 1) / kWorkers; // 18 (the last ones of some waves fall off the end)
+    // A global load is ~2 us away from a lone workgroup, so nothing is requested where it is needed: the rows (and their g, b: lane r
+    // holds row r's) of a layer are requested while the layer before finishes; wave 0, which owns the part between two linears, holds
+    // the norms' affines from the start and no rows (the erf code next to 64 row registers spilled).
+    float4 row[kRows];
+    float g_row = 0.0f, b_row = 0.0f;
+    auto request = [&](int l) {
+        if (wave == 0) return;
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+            const int o = (wave - 1) + kWorkers * r;
+            row[r] = o < kHyperWidth ? *reinterpret_cast<const float4*>(net.v[l] + static_cast<size_t>(o) * kHyperWidth + 4 * lane) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        const int mine = (wave - 1) + kWorkers * lane;
+        if (lane < kRows && mine < kHyperWidth) { g_row = net.g[l][mine]; b_row = net.b[l][mine]; }
+    };
+    request(0);
+    float4 gamma[kHyperHidden - 1], beta[kHyperHidden - 1];
+    if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < kHyperHidden - 1; ++k) {
+            gamma[k] = *reinterpret_cast<const float4*>(net.gamma[k] + 4 * lane);
+            beta[k] = *reinterpret_cast<const float4*>(net.beta[k] + 4 * lane);
+        }
+        *reinterpret_cast<float4*>(h + 4 * lane) = *reinterpret_cast<const float4*>(embeddings + static_cast<size_t>(n) * kHyperWidth + 4 * lane);
+    }
+#pragma unroll
+    for (int l = 0; l < kHyperHidden; ++l) {
+        __syncthreads();                                           // h of this layer is complete
+        if (wave != 0) {
+            const float4 a = *reinterpret_cast<const float4*>(h + 4 * lane);
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) {
+                const int o = (wave - 1) + kWorkers * r;
+                const float inv = rsqrtf(wave_sum(row[r].x * row[r].x + row[r].y * row[r].y + row[r].z * row[r].z + row[r].w * row[r].w));
+                const float dot = wave_sum(row[r].x * a.x + row[r].y * a.y + row[r].z * a.z + row[r].w * a.w);
+                const float value = dot * __shfl(g_row, r, kWave) * inv + __shfl(b_row, r, kWave);
+                if (lane == 0 && o < kHyperWidth) {
+                    out[o] = value;
+                    if (n == 0) net.inv_norm[l][o] = inv;
+                }
+            }
+            if (l + 1 < kHyperHidden) request(l + 1);
+        }
+        __syncthreads();                                           // out is complete; nobody reads h any more
+        if (wave == 0) {
+            const float4 zv = *reinterpret_cast<const float4*>(out + 4 * lane);
+            *reinterpret_cast<float4*>(net.z[l] + static_cast<size_t>(n) * kHyperWidth + 4 * lane) = zv;
+            if (l + 1 < kHyperHidden) {                            // (the norm behind the last hidden linear belongs to the final linear's staging)
+                constexpr int kNorms = kHyperHidden - 1;
+                const float4 gv = gamma[l < kNorms ? l : 0], bv = beta[l < kNorms ? l : 0];
+                float y[4] = {zv.x, zv.y, zv.z, zv.w};
+                const float gam[4] = {gv.x, gv.y, gv.z, gv.w}, bet[4] = {bv.x, bv.y, bv.z, bv.w};
+                const float mean = wave_sum(y[0] + y[1] + y[2] + y[3]) * (1.0f / kHyperWidth);
+                float var = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { y[j] -= mean; var += y[j] * y[j]; }
+                const float inv_std = rsqrtf(wave_sum(var) * (1.0f / kHyperWidth) + kHyperNormEps);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = gelu_exact(y[j] * inv_std * gam[j] + bet[j]);
+                *reinterpret_cast<float4*>(h + 4 * lane) = make_float4(y[0], y[1], y[2], y[3]);
+            }
+        }
+    }
+}
+
 // Centre the generated weights for the render kernels (VSRD_FLAG_MLP_WEIGHTS_CENTRED; rendering/renderers.py::_centre_mlp): in the
 // four linears of the per-instance MLP that feed a LayerNorm, remove each column's mean over the 16 output channels.
 __global__ __launch_bounds__(128) void hyper_centre_kernel(const float* __restrict__ weights, int num_instances, float* __restrict__ centred) {
@@ -117,16 +203,16 @@ __global__ __launch_bounds__(128) void hyper_centre_kernel(const float* __restri
 // and this workgroup's share of the input adjoint  partial_gh[block][n, :] = sum_{o in block} gz[n, o] W[o, :]  (W before the update):
 // the waves leave their W rows and gz columns in LDS and all threads sum the 8 rows in a fixed order.  gz is scaled by
 // `grad_scale` on the way in.  LDS: h [N][256] | rows [8][256] | zbar [N][8].
-__global__ __launch_bounds__(kHyperThreads) void hyper_linear_backward_kernel(
+// (partial_gh == nullptr: the rows' own update only -- hyper_hidden_update_kernel, whose input adjoints come from hyper_hidden_backward_kernel.)
+__device__ __forceinline__ void hyper_rows_backward(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ gz, float grad_scale,
-    const float* __restrict__ inv_norm, int num_rows, int num_instances, AdamTensors v, AdamTensors g, AdamTensors b, HyperAdam adam,
-    float* __restrict__ partial_gh) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const float* __restrict__ inv_norm, int num_rows, int num_instances, const AdamTensors& v, const AdamTensors& g, const AdamTensors& b,
+    const HyperAdam& adam, float* __restrict__ partial_gh, int block, float* lds) {
     float* h = lds;
     float* rows = lds + num_instances * kHyperWidth;
     float* zbar = rows + kHyperWaves * kHyperWidth;
     const int wave = static_cast<int>(threadIdx.x) >> 6, lane = lane_id();
-    const int o = static_cast<int>(blockIdx.x) * kHyperWaves + wave;
+    const int o = block * kHyperWaves + wave;
     const bool live = o < num_rows;
     float4 row = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (live) row = *reinterpret_cast<const float4*>(v.parameter + static_cast<size_t>(o) * kHyperWidth + 4 * lane);
@@ -156,19 +242,43 @@ __global__ __launch_bounds__(kHyperThreads) void hyper_linear_backward_kernel(
     } else if (lane == 0) {
         for (int n = 0; n < num_instances; ++n) zbar[n * kHyperWaves + wave] = 0.0f;
     }
+    if (partial_gh == nullptr) return;                             // (uniform over the workgroup)
     *reinterpret_cast<float4*>(rows + wave * kHyperWidth + 4 * lane) = make_float4(scale * row.x, scale * row.y, scale * row.z, scale * row.w);
     __syncthreads();
     const int channel = static_cast<int>(threadIdx.x) & (kHyperWidth - 1);
     float column[kHyperWaves];
 #pragma unroll
     for (int w = 0; w < kHyperWaves; ++w) column[w] = rows[w * kHyperWidth + channel];
-    float* out = partial_gh + static_cast<size_t>(blockIdx.x) * num_instances * kHyperWidth;
+    float* out = partial_gh + static_cast<size_t>(block) * num_instances * kHyperWidth;
     for (int n = static_cast<int>(threadIdx.x) >> 8; n < num_instances; n += kHyperThreads / kHyperWidth) {
         float acc = 0.0f;
 #pragma unroll
         for (int w = 0; w < kHyperWaves; ++w) acc += zbar[n * kHyperWaves + w] * column[w];
         out[n * kHyperWidth + channel] = acc;
     }
+}
+
+__global__ __launch_bounds__(kHyperThreads) void hyper_linear_backward_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ gz, float grad_scale,
+    const float* __restrict__ inv_norm, int num_rows, int num_instances, AdamTensors v, AdamTensors g, AdamTensors b, HyperAdam adam,
+    float* __restrict__ partial_gh) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    hyper_rows_backward(x, gamma, beta, gz, grad_scale, inv_norm, num_rows, num_instances, v, g, b, adam, partial_gh, static_cast<int>(blockIdx.x), lds);
+}
+
+// The four hidden linears' own updates in one launch (32 workgroups of 8 rows each): their output adjoints gz[l] are all known once
+// hyper_hidden_backward_kernel has walked the chain.  LDS: h [N][256] | rows [8][256] | zbar [N][8] (as above).
+struct HyperHiddenUpdate {
+    const float* x[4]; const float* gamma[4]; const float* beta[4]; const float* gz[4]; const float* inv_norm[4];
+    AdamTensors v[4], g[4], b[4];
+};
+
+__global__ __launch_bounds__(kHyperThreads) void hyper_hidden_update_kernel(HyperHiddenUpdate u, int num_instances, HyperAdam adam) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int kBlocksPerLayer = kHyperWidth / kHyperWaves;
+    const int l = static_cast<int>(blockIdx.x) / kBlocksPerLayer, block = static_cast<int>(blockIdx.x) % kBlocksPerLayer;
+    hyper_rows_backward(u.x[l], u.gamma[l], u.beta[l], u.gz[l], 1.0f, u.inv_norm[l], kHyperWidth, num_instances, u.v[l], u.g[l], u.b[l], adam,
+                        nullptr, block, lds);
 }
 
 __device__ __forceinline__ float block_sum_256(float value, float* scratch) {       // 4 waves; scratch [4]; fixed order
@@ -182,12 +292,11 @@ __device__ __forceinline__ float block_sum_256(float value, float* scratch) {   
 // Backward of [LayerNorm(affine) -> GELU] that produced the input of the linear above, for one instance per workgroup, one channel
 // per thread: sums the workgroups' partial input adjoints, chains through GELU and LayerNorm.
 //   a = gamma y + beta, h = gelu(a):  a_bar = h_bar gelu'(a),  y_bar = a_bar gamma,  z_bar = (y_bar - mean(y_bar) - y mean(y_bar y)) / std
-// and leaves this instance's share of gamma_bar = a_bar y, beta_bar = a_bar in norm_partials [N][2][256] (hyper_norm_adam_kernel sums
-// them at the end of the step).  is_embedding: the input was the embeddings themselves; h_bar is their gradient and they are stepped.
+// and leaves this instance's share of gamma_bar = a_bar y, beta_bar = a_bar in norm_partials [N][2][256] (hyper_finish_kernel sums
+// them at the end of the step).  Used behind the final linear, whose 203 workgroups' shares have to be summed across workgroups.
 __global__ __launch_bounds__(kHyperNormThreads) void hyper_norm_backward_kernel(
     const float* __restrict__ partial_gh, int num_partials, const float* __restrict__ z_prev, int num_instances,
-    const float* __restrict__ gamma, const float* __restrict__ beta, AdamTensors embeddings, int is_embedding, HyperAdam adam,
-    float* __restrict__ gz_out, float* __restrict__ norm_partials) {
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ gz_out, float* __restrict__ norm_partials) {
     __shared__ float scratch[4];
     const int n = blockIdx.x, c = threadIdx.x;
     const size_t stride = static_cast<size_t>(num_instances) * kHyperWidth;
@@ -195,11 +304,6 @@ __global__ __launch_bounds__(kHyperNormThreads) void hyper_norm_backward_kernel(
     float hb = 0.0f;
 #pragma unroll 8
     for (int p = 0; p < num_partials; ++p) hb += src[p * stride];
-    if (is_embedding) {
-        const AdamStep step(embeddings, adam);
-        step.apply(embeddings, static_cast<size_t>(n) * kHyperWidth + c, hb);
-        return;
-    }
     float y = z_prev[static_cast<size_t>(n) * kHyperWidth + c];
     const float mean = block_sum_256(y, scratch) * (1.0f / kHyperWidth);
     y -= mean;
@@ -215,31 +319,141 @@ __global__ __launch_bounds__(kHyperNormThreads) void hyper_norm_backward_kernel(
     norm_partials[(static_cast<size_t>(n) * 2 + 1) * kHyperWidth + c] = a_bar;
 }
 
-// Adam on the LayerNorm affines, all four norms in one launch (workgroup = norm, thread = channel) after the whole backward chain has
-// read them: gamma_bar / beta_bar = the instances' shares summed in instance order.
-struct HyperNorms { AdamTensors gamma[4], beta[4]; };
+// The adjoint chain through the four hidden blocks of ONE instance per workgroup: eight dependent launches (linear backward, norm
+// backward, four times) become this one plus hyper_hidden_update_kernel.  Given gz[3] = the adjoint of the last hidden linear's output
+// (hyper_norm_backward_kernel behind the final linear), for l = 3 .. 0:
+//   a_bar[i] = sum_o gz[l][o] g_l[o] / |v_l[o]| v_l[o, i]      twelve waves sum 22 rows each (4 channels per lane), twelve partial sums
+//   l > 0:  through [LayerNorm -> GELU] behind linear l - 1 (one wave, 4 channels per lane; the arithmetic of hyper_norm_backward_kernel)
+//           -> gz[l - 1], and this instance's share of that norm's gamma_bar / beta_bar
+//   l = 0:  a_bar is the gradient of the embedding row -> embedding_bar [N][256] (stepped by hyper_finish_kernel, after every reader)
+struct HyperHiddenBackward {
+    const float* v[kHyperHidden]; const float* g[kHyperHidden]; const float* inv_norm[kHyperHidden];
+    const float* gamma[kHyperHidden - 1]; const float* beta[kHyperHidden - 1]; const float* z[kHyperHidden - 1];
+    float* gz[kHyperHidden];                  // [N][256] each; gz[3] is the input
+    float* norm_partials[kHyperHidden - 1];   // [N][2][256] each
+    float* embedding_bar;                     // [N][256]
+};
 
-__global__ __launch_bounds__(kHyperNormThreads) void hyper_norm_adam_kernel(HyperNorms norms, const float* __restrict__ norm_partials, int num_instances, HyperAdam adam) {
-    const int k = blockIdx.x, c = threadIdx.x;
-    const float* src = norm_partials + static_cast<size_t>(k) * num_instances * 2 * kHyperWidth;
-    float dgamma = 0.0f, dbeta = 0.0f;
-    for (int n = 0; n < num_instances; ++n) {
-        dgamma += src[(static_cast<size_t>(n) * 2 + 0) * kHyperWidth + c];
-        dbeta += src[(static_cast<size_t>(n) * 2 + 1) * kHyperWidth + c];
+__global__ __launch_bounds__(kHyperChainThreads) void hyper_hidden_backward_kernel(HyperHiddenBackward net) {
+    constexpr int kWorkers = kHyperChainWaves - kHyperHidden;      // waves 4 .. 15 hold the weights: rows o = (wave - 4) + 12 r, 4 input channels per lane
+    constexpr int kRows = (kHyperWidth + kWorkers - 1) / kWorkers; // 22 (the last ones of some waves fall off the end)
+    __shared__ __attribute__((aligned(16))) float scaled[kWorkers * kRows];         // gz[l][o] g[o] / |v[o]|, zero behind row 255
+    __shared__ __attribute__((aligned(16))) float partial[kWorkers][kHyperWidth];
+    const int n = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = lane_id();
+    // A global load is ~2 us away from a lone workgroup, so nothing is requested where it is needed: a layer's weights are requested
+    // while the layer before finishes, and the one-wave part of step l is the work of wave l (l = 0 .. 3: waves that hold no weights),
+    // which has held everything it needs (z, gamma, beta of the norm behind linear l - 1 and that linear's g / |v|) since the start.
+    // Two code paths with the same two barriers per layer: in one path the register allocator keeps the weights alive across the erf code.
+    if (wave >= kHyperHidden) {                                    // ---- the workers
+        const int first = __builtin_amdgcn_readfirstlane(wave) - kHyperHidden;      // (wave-uniform row addresses: scalar base, one lane offset)
+        float4 row[kRows];
+        auto request = [&](int l) {
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) {
+                const int o = first + kWorkers * r;
+                row[r] = o < kHyperWidth ? *reinterpret_cast<const float4*>(net.v[l] + static_cast<size_t>(o) * kHyperWidth + 4 * lane) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        };
+        request(kHyperHidden - 1);
+#pragma unroll 1
+        for (int l = kHyperHidden - 1; l >= 0; --l) {
+            __syncthreads();                                       // scaled is complete
+            float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) {
+                const float weight = scaled[first + kWorkers * r];
+                acc.x += weight * row[r].x; acc.y += weight * row[r].y; acc.z += weight * row[r].z; acc.w += weight * row[r].w;
+            }
+            *reinterpret_cast<float4*>(&partial[first][4 * lane]) = acc;
+            __builtin_amdgcn_sched_barrier(0);                     // (the next layer's loads must not be hoisted above this layer's sums)
+            if (l > 0) request(l - 1);
+            __syncthreads();                                       // partial is complete; nobody reads scaled any more
+        }
+        return;
     }
-    const AdamStep step_gamma(norms.gamma[k], adam), step_beta(norms.beta[k], adam);
-    step_gamma.apply(norms.gamma[k], c, dgamma);
-    step_beta.apply(norms.beta[k], c, dbeta);
+    // ---- waves 0 .. 3
+    float4 zv = make_float4(0.0f, 0.0f, 0.0f, 0.0f), gam = zv, bet = zv, weight_scale = zv;
+    if (wave >= 1) {                                               // wave l: the norm behind linear k = l - 1
+        const int k = wave - 1;
+        zv = *reinterpret_cast<const float4*>(net.z[k] + static_cast<size_t>(n) * kHyperWidth + 4 * lane);
+        gam = *reinterpret_cast<const float4*>(net.gamma[k] + 4 * lane);
+        bet = *reinterpret_cast<const float4*>(net.beta[k] + 4 * lane);
+        const float4 g = *reinterpret_cast<const float4*>(net.g[k] + 4 * lane), inv = *reinterpret_cast<const float4*>(net.inv_norm[k] + 4 * lane);
+        weight_scale = make_float4(g.x * inv.x, g.y * inv.y, g.z * inv.z, g.w * inv.w);
+    }
+    scaled[tid] = net.gz[kHyperHidden - 1][static_cast<size_t>(n) * kHyperWidth + tid] * net.g[kHyperHidden - 1][tid] * net.inv_norm[kHyperHidden - 1][tid];
+    if (tid < kWorkers * kRows - kHyperWidth) scaled[kHyperWidth + tid] = 0.0f;
+#pragma unroll
+    for (int l = kHyperHidden - 1; l >= 0; --l) {
+        __syncthreads();
+        __syncthreads();
+        if (wave != l) continue;
+        float hb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int p = 0; p < kWorkers; ++p) {                       // fixed order
+            const float4 share = *reinterpret_cast<const float4*>(&partial[p][4 * lane]);
+            hb[0] += share.x; hb[1] += share.y; hb[2] += share.z; hb[3] += share.w;
+        }
+        if (l == 0) {
+            *reinterpret_cast<float4*>(net.embedding_bar + static_cast<size_t>(n) * kHyperWidth + 4 * lane) = make_float4(hb[0], hb[1], hb[2], hb[3]);
+            continue;
+        }
+        const int k = l - 1;                                       // the norm behind linear k
+        float y[4] = {zv.x, zv.y, zv.z, zv.w};
+        const float gamma[4] = {gam.x, gam.y, gam.z, gam.w}, beta[4] = {bet.x, bet.y, bet.z, bet.w};
+        const float next_scale[4] = {weight_scale.x, weight_scale.y, weight_scale.z, weight_scale.w};
+        const float mean = wave_sum(y[0] + y[1] + y[2] + y[3]) * (1.0f / kHyperWidth);
+        float var = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { y[j] -= mean; var += y[j] * y[j]; }
+        const float inv_std = rsqrtf(wave_sum(var) * (1.0f / kHyperWidth) + kHyperNormEps);
+        float a_bar[4], y_bar[4], s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            y[j] *= inv_std;
+            a_bar[j] = hb[j] * gelu_exact_derivative(y[j] * gamma[j] + beta[j]);
+            y_bar[j] = a_bar[j] * gamma[j];
+            s1 += y_bar[j]; s2 += y_bar[j] * y[j];
+        }
+        const float m1 = wave_sum(s1) * (1.0f / kHyperWidth), m2 = wave_sum(s2) * (1.0f / kHyperWidth);
+        float out[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { out[j] = (y_bar[j] - m1 - y[j] * m2) * inv_std; scaled[4 * lane + j] = out[j] * next_scale[j]; }
+        *reinterpret_cast<float4*>(net.gz[k] + static_cast<size_t>(n) * kHyperWidth + 4 * lane) = make_float4(out[0], out[1], out[2], out[3]);
+        float* shares = net.norm_partials[k] + static_cast<size_t>(n) * 2 * kHyperWidth;
+        *reinterpret_cast<float4*>(shares + 4 * lane) = make_float4(a_bar[0] * y[0], a_bar[1] * y[1], a_bar[2] * y[2], a_bar[3] * y[3]);
+        *reinterpret_cast<float4*>(shares + kHyperWidth + 4 * lane) = make_float4(a_bar[0], a_bar[1], a_bar[2], a_bar[3]);
+    }
 }
 
-// After every kernel of the step has read them: advance the step counters of all the tensors stepped above and decay the two
-// learning rates (ExponentialLR steps after the optimiser).
+// The end of the step, one workgroup, after every other kernel has read what it changes: Adam on the LayerNorm affines (gamma_bar /
+// beta_bar = the instances' shares summed in instance order) and on the embeddings, then -- behind a barrier, so that every thread has
+// read the counters and the rates -- the step counters of all the tensors stepped in this backward advance and the two learning
+// rates decay (ExponentialLR steps after the optimiser).
+struct HyperNorms { AdamTensors gamma[4], beta[4]; };
 struct HyperStepCounters { float* step[32]; int count; };
 
-__global__ void hyper_finish_kernel(HyperStepCounters counters, float* embedding_lr, float* hyper_lr, float gamma) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < counters.count) *counters.step[idx] += 1.0f;
-    if (idx == 0) { *embedding_lr *= gamma; *hyper_lr *= gamma; }
+__global__ __launch_bounds__(kHyperChainThreads) void hyper_finish_kernel(HyperNorms norms, const float* __restrict__ norm_partials, AdamTensors embeddings,
+                                                                          const float* __restrict__ embedding_bar, int num_instances, HyperAdam adam,
+                                                                          HyperStepCounters counters, float* embedding_lr, float* hyper_lr, float gamma) {
+    const int tid = threadIdx.x;
+    {
+        const int k = tid >> 8, c = tid & (kHyperWidth - 1);      // 4 norms x 256 channels
+        const float* src = norm_partials + static_cast<size_t>(k) * num_instances * 2 * kHyperWidth;
+        float dgamma = 0.0f, dbeta = 0.0f;
+        for (int n = 0; n < num_instances; ++n) {
+            dgamma += src[(static_cast<size_t>(n) * 2 + 0) * kHyperWidth + c];
+            dbeta += src[(static_cast<size_t>(n) * 2 + 1) * kHyperWidth + c];
+        }
+        const AdamStep step_gamma(norms.gamma[k], adam), step_beta(norms.beta[k], adam);
+        step_gamma.apply(norms.gamma[k], c, dgamma);
+        step_beta.apply(norms.beta[k], c, dbeta);
+    }
+    const AdamStep step_embeddings(embeddings, adam);
+    for (int idx = tid; idx < num_instances * kHyperWidth; idx += kHyperChainThreads) step_embeddings.apply(embeddings, idx, embedding_bar[idx]);
+    __syncthreads();
+    if (tid < counters.count) *counters.step[tid] += 1.0f;
+    if (tid == 0) { *embedding_lr *= gamma; *hyper_lr *= gamma; }
 }
 
 }  // namespace vsrd
