@@ -134,11 +134,27 @@ __global__ __launch_bounds__(kFrameThreads) void frame_prologue_kernel(FrameStep
     __shared__ float partial[kFrameThreads / kWave][3];
     const int tid = static_cast<int>(threadIdx.x);
     const int N = a.num_boxes, V = a.num_views;
+#ifdef VSRD_PHASE_TIMERS
+    const unsigned long long t_start = wall_clock64();                 // 100 MHz; mark k = time of the k-th barrier (tools/prologue_timers.py)
+    int mark = 8;
+#define VSRD_PROLOGUE_MARK() do { if (tid == 0 && mark < 16) g_phase_cycles[mark] = wall_clock64() - t_start; ++mark; } while (0)
+#else
+#define VSRD_PROLOGUE_MARK() do { } while (0)
+#endif
     const int edges[kBoxEdges][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};   // main.py:26-30
-    float* boxes_2d = b.scratch;
-    int* selection = reinterpret_cast<int*>(b.scratch + static_cast<size_t>(V) * N * 4);
-    float* grad_boxes = b.scratch + static_cast<size_t>(V) * N * 8;
-    float* grad_world = b.scratch + static_cast<size_t>(V) * N * 12;
+    // What the phases hand each other -- 2-D boxes, which edge end gave each extreme, their gradients, the corner gradients of every
+    // (view, box) -- goes through LDS while V N <= 256 (the reference's 17 views x 8 boxes: 136), through the global scratch above
+    // that: a global store -> barrier -> load is a ~2 us round trip for this lone workgroup, and there were four of them.  (The corner
+    // gradients reuse the cost matrix, which is dead once the matching is done.)
+    __shared__ float small_boxes[kFrameThreads * 4];
+    __shared__ int small_selection[kFrameThreads * 4];
+    __shared__ float small_grad_boxes[kFrameThreads * 4];
+    static_assert(sizeof(cost) >= sizeof(float) * kFrameThreads * 24, "the corner gradients of 256 (view, box) pairs fit the cost matrix");
+    const bool small = V * N <= kFrameThreads;
+    float* boxes_2d = small ? small_boxes : b.scratch;
+    int* selection = small ? small_selection : reinterpret_cast<int*>(b.scratch + static_cast<size_t>(V) * N * 4);
+    float* grad_boxes = small ? small_grad_boxes : b.scratch + static_cast<size_t>(V) * N * 8;
+    float* grad_world = small ? reinterpret_cast<float*>(cost) : b.scratch + static_cast<size_t>(V) * N * 12;
     // ---- schedules (main.py:420-431) ----------------------------------------------------------------------------------------
     if (tid == 0) {
         const float x = static_cast<float>(*b.step) / static_cast<float>(a.num_steps);
@@ -165,6 +181,7 @@ __global__ __launch_bounds__(kFrameThreads) void frame_prologue_kernel(FrameStep
         }
     }
     __syncthreads();
+    VSRD_PROLOGUE_MARK();
     // ---- projection of every (view, box) (projection.h: project_boxes_kernel) -------------------------------------------------
     for (int idx = tid; idx < V * N; idx += kFrameThreads) {
         const int v = idx / N, n = idx - v * N;
@@ -181,6 +198,7 @@ __global__ __launch_bounds__(kFrameThreads) void frame_prologue_kernel(FrameStep
         float lo_u = 0.0f, lo_v = 0.0f, hi_u = 0.0f, hi_v = 0.0f;
         int s_lo_u = -1, s_lo_v = -1, s_hi_u = -1, s_hi_v = -1;
         bool any = false;
+#pragma unroll                                                   // (static corner indices: a rolled loop indexes cam[] dynamically, i.e. through scratch memory)
         for (int e = 0; e < kBoxEdges; ++e) {
             const ClippedEdge c = clip_edge(cam[edges[e][0]], cam[edges[e][1]], a.epsilon);
             if (!c.front) continue;
@@ -213,6 +231,7 @@ __global__ __launch_bounds__(kFrameThreads) void frame_prologue_kernel(FrameStep
         }
     }
     __syncthreads();
+    VSRD_PROLOGUE_MARK();
     // ---- matching on the target view (matching.h) -------------------------------------------------------------------------------
     for (int idx = tid; idx < N * N; idx += kFrameThreads) {
         const int p = idx / N, g = idx - p * N;
@@ -221,6 +240,7 @@ __global__ __launch_bounds__(kFrameThreads) void frame_prologue_kernel(FrameStep
         cost[p * N + g] = static_cast<double>(c);
     }
     __syncthreads();
+    VSRD_PROLOGUE_MARK();
     if (tid < kWave) {                                     // wave 0 (all 64 lanes take part in the wave-cooperative solver)
         const int col4row = lsap_rows_le_cols(cost, N, N);
         if (tid < N) {
@@ -232,6 +252,7 @@ __global__ __launch_bounds__(kFrameThreads) void frame_prologue_kernel(FrameStep
         }
     }
     __syncthreads();
+    VSRD_PROLOGUE_MARK();
     // ---- projection losses over kept (view, matched pair)s and their gradient w.r.t. the predicted 2-D boxes (main.py:391-415) ----
     float iou_sum = 0.0f, l1_sum = 0.0f, kept = 0.0f;
     for (int idx = tid; idx < V * N; idx += kFrameThreads) {
@@ -258,6 +279,7 @@ __global__ __launch_bounds__(kFrameThreads) void frame_prologue_kernel(FrameStep
     iou_sum = wave_sum(iou_sum); l1_sum = wave_sum(l1_sum); kept = wave_sum(kept);
     if ((tid & (kWave - 1)) == 0) { partial[tid >> 6][0] = iou_sum; partial[tid >> 6][1] = l1_sum; partial[tid >> 6][2] = kept; }
     __syncthreads();
+    VSRD_PROLOGUE_MARK();
     float count = 0.0f, iou_total = 0.0f, l1_total = 0.0f;
     for (int w = 0; w < kFrameThreads / kWave; ++w) { iou_total += partial[w][0]; l1_total += partial[w][1]; count += partial[w][2]; }
     count = fmaxf(count, 1.0f);
@@ -278,41 +300,63 @@ __global__ __launch_bounds__(kFrameThreads) void frame_prologue_kernel(FrameStep
                 gcam[k][j] = 0.0f;
             }
         }
+        // Which corners an extreme came from is data: cam[] / gcam[] indexed by it would live in scratch memory (a ~2 us round trip per
+        // access from this lone workgroup: 14 of the kernel's 42 us).  The two corners of the selected edge are picked out of the
+        // registers by compare-and-select chains instead, and their gradients go back the same way.
+        constexpr unsigned kEdgeFirst = 0x76543210u, kEdgeSecondLow = 0x47650321u;       // edges[e][0] / edges[e][1] of e = 0 .. 7, 4 bits each
+        constexpr unsigned kEdgeFirstHigh = 0x3210u, kEdgeSecondHigh = 0x7654u;          // e = 8 .. 11
+#pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int sel = selection[idx * 4 + k];
             const float g = grad_boxes[idx * 4 + k] / count;
             if (sel < 0 || g == 0.0f) continue;
             const int e = sel >> 1;
             const bool near_end = (sel & 1) != 0;
-            const int ia = edges[e][0], ib = edges[e][1];
-            const ClippedEdge c = clip_edge(cam[ia], cam[ib], a.epsilon);
+            const int ia = static_cast<int>(((e < 8 ? kEdgeFirst : kEdgeFirstHigh) >> (4 * (e & 7))) & 7u);
+            const int ib = static_cast<int>(((e < 8 ? kEdgeSecondLow : kEdgeSecondHigh) >> (4 * (e & 7))) & 7u);
+            float pa[3] = {0.0f, 0.0f, 0.0f}, pb[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { pa[j] = (c8 == ia) ? cam[c8][j] : pa[j]; pb[j] = (c8 == ib) ? cam[c8][j] : pb[j]; }
+            }
+            const ClippedEdge c = clip_edge(pa, pb, a.epsilon);
             const int i_far = c.a_is_far ? ia : ib, i_near = c.a_is_far ? ib : ia;
             const float px = near_end ? c.nx : c.fx, py = near_end ? c.ny : c.fy, pz = near_end ? c.nz : c.fz;
             float w; bool w_clamped;
             const EdgePoint pt = project_point(K, px, py, pz, a.epsilon, &w, &w_clamped);
             const int r = k & 1;
             const float coord = r ? pt.v : pt.u;
-            float gp[3];
+            float gp[3], to_far[3], to_near[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int j = 0; j < 3; ++j) gp[j] = g * (K[3 * r + j] - (w_clamped ? 0.0f : coord * K[6 + j])) / w;
             if (!near_end) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) gcam[i_far][j] += gp[j];
+                for (int j = 0; j < 3; ++j) to_far[j] = gp[j];
             } else {
                 float gt = 0.0f;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    gcam[i_far][j] += gp[j] * (1.0f - c.t);
-                    gcam[i_near][j] += gp[j] * c.t;
-                    gt += gp[j] * (cam[i_near][j] - cam[i_far][j]);
+                    const float far_j = c.a_is_far ? pa[j] : pb[j], near_j = c.a_is_far ? pb[j] : pa[j];
+                    to_far[j] = gp[j] * (1.0f - c.t);
+                    to_near[j] = gp[j] * c.t;
+                    gt += gp[j] * (near_j - far_j);
                 }
                 if (!c.t_clamped) {
-                    const float zf = cam[i_far][2], zn = cam[i_near][2];
+                    const float zf = c.a_is_far ? pa[2] : pb[2], zn = c.a_is_far ? pb[2] : pa[2];
                     const float den = c.den_clamped ? a.epsilon : (zf - zn);
                     float dzf = 1.0f / den, dzn = 0.0f;
                     if (!c.den_clamped) { dzf -= zf / (den * den); dzn = zf / (den * den); }
-                    gcam[i_far][2] += gt * dzf;
-                    gcam[i_near][2] += gt * dzn;
+                    to_far[2] += gt * dzf;
+                    to_near[2] += gt * dzn;
+                }
+            }
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    gcam[c8][j] += (c8 == i_far) ? to_far[j] : 0.0f;
+                    gcam[c8][j] += (c8 == i_near) ? to_near[j] : 0.0f;
                 }
             }
         }
@@ -329,6 +373,7 @@ __global__ __launch_bounds__(kFrameThreads) void frame_prologue_kernel(FrameStep
         }
     }
     __syncthreads();
+    VSRD_PROLOGUE_MARK();
     // ---- sum over the views in a fixed order, then corners -> decoded parameters -> raw parameters ------------------------------
     for (int idx = tid; idx < N * 24; idx += kFrameThreads) {
         float acc = 0.0f;
@@ -336,6 +381,7 @@ __global__ __launch_bounds__(kFrameThreads) void frame_prologue_kernel(FrameStep
         gcorners[idx] = acc;
     }
     __syncthreads();
+    VSRD_PROLOGUE_MARK();
     if (tid < N) {
         const DecodedBox d = decode_box(a, b.raw_locations + 3 * tid, b.raw_dimensions + 3 * tid, b.raw_orientations + 2 * tid);
         float g_loc[3] = {0.0f, 0.0f, 0.0f}, g_dim[3] = {0.0f, 0.0f, 0.0f}, g_c = 0.0f, g_s = 0.0f;
@@ -363,7 +409,9 @@ __global__ __launch_bounds__(kFrameThreads) void frame_prologue_kernel(FrameStep
         out[6] = (g_c - d.c * dot) / d.norm;
         out[7] = (g_s - d.s * dot) / d.norm;
     }
+    VSRD_PROLOGUE_MARK();
 }
+#undef VSRD_PROLOGUE_MARK
 
 struct AdamTensors {                   // torch.optim.Adam(capturable=True) state of one parameter tensor, all on the device
     float* parameter;

@@ -24,20 +24,46 @@ __device__ __forceinline__ double shuffle_double(double v, int src_lane) {
     return __builtin_bit_cast(double, (static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
 }
 
+// Lane `src_lane` (wave-uniform) of an int / a double: v_readlane with a scalar lane index instead of a ds_bpermute round trip.
+__device__ __forceinline__ int read_lane_int(int v, int src_lane) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src_lane)); }
+__device__ __forceinline__ double read_lane_double(double v, int src_lane) {
+    const long long bits = __builtin_bit_cast(long long, v);
+    const int lo = read_lane_int(static_cast<int>(bits), src_lane), hi = read_lane_int(static_cast<int>(bits >> 32), src_lane);
+    return __builtin_bit_cast(double, (static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+
+// Wave-wide minimum / maximum by DPP (quad swaps, row mirrors, row broadcasts; the result is read from lane 63): the solver below runs
+// ~n^2 / 2 of each, and through __shfl (ds_bpermute) one 64-bit minimum alone was 12 LDS round trips.
+template <int kCtrl, int kRowMask = 0xf>
+__device__ __forceinline__ int dpp_int(int v) { return __builtin_amdgcn_update_dpp(v, v, kCtrl, kRowMask, 0xf, false); }
+template <int kCtrl, int kRowMask = 0xf>
+__device__ __forceinline__ double dpp_double(double v) {
+    const long long bits = __builtin_bit_cast(long long, v);
+    const int lo = dpp_int<kCtrl, kRowMask>(static_cast<int>(bits)), hi = dpp_int<kCtrl, kRowMask>(static_cast<int>(bits >> 32));
+    return __builtin_bit_cast(double, (static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+// kSmall: every lane that matters sits in the first row of 16 (the others hold the neutral element): four steps, read from lane 0.
+template <bool kSmall = false>
 __device__ __forceinline__ double wave_min_double(double v) {
-#pragma unroll
-    for (int offset = 32; offset >= 1; offset >>= 1) v = fmin(v, shuffle_double(v, lane_id() ^ offset));
-    return v;
+    v = fmin(v, dpp_double<kDppQuadXor1>(v));
+    v = fmin(v, dpp_double<kDppQuadXor2>(v));
+    v = fmin(v, dpp_double<kDppRowHalfMirror>(v));
+    v = fmin(v, dpp_double<kDppRowMirror>(v));
+    if (kSmall) return read_lane_double(v, 0);
+    v = fmin(v, dpp_double<kDppRowBcast15, 0xa>(v));
+    v = fmin(v, dpp_double<kDppRowBcast31, 0xc>(v));
+    return read_lane_double(v, 63);
 }
-__device__ __forceinline__ int wave_min_int(int v) {
-#pragma unroll
-    for (int offset = 32; offset >= 1; offset >>= 1) v = min(v, __shfl_xor(v, offset, kWave));
-    return v;
-}
+template <bool kSmall = false>
 __device__ __forceinline__ int wave_max_int(int v) {
-#pragma unroll
-    for (int offset = 32; offset >= 1; offset >>= 1) v = max(v, __shfl_xor(v, offset, kWave));
-    return v;
+    v = max(v, dpp_int<kDppQuadXor1>(v));
+    v = max(v, dpp_int<kDppQuadXor2>(v));
+    v = max(v, dpp_int<kDppRowHalfMirror>(v));
+    v = max(v, dpp_int<kDppRowMirror>(v));
+    if (kSmall) return read_lane_int(v, 0);
+    v = max(v, dpp_int<kDppRowBcast15, 0xa>(v));
+    v = max(v, dpp_int<kDppRowBcast31, 0xc>(v));
+    return read_lane_int(v, 63);
 }
 
 // -DIoU of predicted box i and ground-truth box j (vsrd_amd/losses.py::distance_box_iou, torchvision 0.14 formula).
@@ -55,7 +81,8 @@ __device__ __forceinline__ float negative_distance_iou(const float* a, const flo
 
 // Solve the nr x nc (nr <= nc <= 64) assignment problem on `cost` (LDS, row-major with pitch nc, float64).
 // Returns col4row of row `lane` (valid for lane < nr).
-__device__ __forceinline__ int lsap_rows_le_cols(const double* cost, int nr, int nc) {
+template <bool kSmall>
+__device__ __forceinline__ int lsap_rows_le_cols_impl(const double* cost, int nr, int nc) {
     const int lane = lane_id();
     // column state (lane = j)
     double v = 0.0, spc = kLsapInfinity;
@@ -75,23 +102,24 @@ __device__ __forceinline__ int lsap_rows_le_cols(const double* cost, int nr, int
         int i = cur_row, sink = -1;
         while (sink == -1) {
             if (lane == i) in_sr = true;
-            const double ui = shuffle_double(u, i);
+            const double ui = read_lane_double(u, i);
             if (!removed) {
                 const double r = min_val + cost[i * nc + lane] - ui - v;
                 if (r < spc) { path = i; spc = r; }
             }
             // scipy's sequential scan over remaining[0..num_remaining): strictly lower wins; on a tie a FREE column wins (the last
             // free one in scan order); otherwise the first column in scan order keeps the lead
-            const double lowest = wave_min_double(removed ? kLsapInfinity : spc);
+            const double lowest = wave_min_double<kSmall>(removed ? kLsapInfinity : spc);
             if (!(lowest < kLsapInfinity)) return -2;                 // infeasible (never for finite costs)
             const bool at_min = !removed && spc == lowest;
-            const int last_free = wave_max_int((at_min && row4col == -1) ? position : -1);
-            const int first_any = wave_min_int(at_min ? position : 0x7fffffff);
-            const int index = (last_free >= 0) ? last_free : first_any;
+            // one reduction for both rules: a free column at the minimum scores 64 + position (the last free one wins), any other
+            // column at the minimum 63 - position (the first one wins, and only if no free one is there)
+            const int score = wave_max_int<kSmall>(at_min ? ((row4col == -1) ? 64 + position : 63 - position) : -1);
+            const int index = (score >= 64) ? score - 64 : 63 - score;
             min_val = lowest;
             const unsigned long long chosen = __ballot(!removed && position == index);
             const int j = __ffsll(static_cast<long long>(chosen)) - 1;
-            const int owner = __shfl(row4col, j, kWave);
+            const int owner = read_lane_int(row4col, j);
             if (owner == -1) sink = j; else i = owner;
             // SC[j] = true; remaining[index] = remaining[--num_remaining]
             --num_remaining;
@@ -109,15 +137,19 @@ __device__ __forceinline__ int lsap_rows_le_cols(const double* cost, int nr, int
         // ---- augment along the path ---------------------------------------------------------------------------------------
         int j = sink;
         while (true) {
-            const int pi = __shfl(path, j, kWave);
+            const int pi = read_lane_int(path, j);
             if (lane == j) row4col = pi;
-            const int previous = __shfl(col4row, pi, kWave);
+            const int previous = read_lane_int(col4row, pi);
             if (lane == pi) col4row = j;
             j = previous;
             if (pi == cur_row) break;
         }
     }
     return col4row;
+}
+
+__device__ __forceinline__ int lsap_rows_le_cols(const double* cost, int nr, int nc) {
+    return nc <= 16 ? lsap_rows_le_cols_impl<true>(cost, nr, nc) : lsap_rows_le_cols_impl<false>(cost, nr, nc);
 }
 
 // cost [P,G] (float, row-major) or boxes -> matched (pd, gt) index pairs sorted by pd index, as scipy returns them.
