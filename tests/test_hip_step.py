@@ -488,6 +488,39 @@ def test_hypernetwork_kernels_match_torch(dev, N):
                 assert abs(float(ga["lr"]) - float(gb["lr"])) <= 1e-6 * float(ga["lr"])
 
 
+def test_run_replays_several_steps_per_graph(dev):
+    """FrameOptimizer.run(n, steps_per_graph=4): four consecutive steps of a phase in one hipGraph are the same launches in the same
+    order as four step() calls -- bit-identical parameters and step records, across the warm-up -> residual switch and with a
+    remainder that does not fill a graph."""
+    from vsrd_amd import optimization
+    inputs = _c1_inputs(dev, all_visible=True)
+    config = optimization.OptimizationConfig(num_samples=32, num_rays=128, warmup_steps=9, num_steps=40, seed=3)
+
+    def trajectory(run_many):
+        torch.manual_seed(0)
+        loop = optimization.FrameOptimizer(inputs, config, dev, graph=True)
+        if run_many:
+            out = loop.run(23, steps_per_graph=4)
+        else:
+            for _ in range(23):
+                out = loop.step()
+        torch.cuda.synchronize()
+        assert loop.step_index == 23 and int(loop.step_tensor) == 23
+        state = [p.detach().clone() for p in [loop.detector.locations, loop.detector.dimensions, loop.detector.orientations, loop.detector.embeddings,
+                                              *loop.hyper_distance_field.parameters()]]
+        record = {k: v.detach().clone() for k, v in out.items() if isinstance(v, torch.Tensor)}
+        graphs = sorted(k for k in loop._graphs)
+        loop.close()
+        return state, record, graphs
+    one, record_one, graphs_one = trajectory(False)
+    many, record_many, graphs_many = trajectory(True)
+    assert any(len(k) == 3 and k[2] == 4 for k in graphs_many) and not any(len(k) == 3 for k in graphs_one)      # the four-step graphs were used
+    for a, b in zip(one, many):
+        assert torch.equal(a, b)
+    for name in record_one:
+        assert torch.equal(record_one[name], record_many[name]), name
+
+
 @pytest.mark.parametrize("fused_glue", [True, False])
 def test_graph_mode_replays_the_same_steps(dev, fused_glue):
     """hipGraph mode (FrameOptimizer(graph=True)): the captured step reads its schedules, Philox counter, Adam step and learning

@@ -27,6 +27,7 @@ def main():
     parser.add_argument("--concurrent", type=int, default=1, help="frames optimised at the same time (one host thread and stream each)")
     parser.add_argument("--residual", action="store_true", help="post-warm-up phase: residual MLP + eikonal loss (steps 1000-3000)")
     parser.add_argument("--json", action="store_true", help="also print one JSON line (tools/regimes.py)")
+    parser.add_argument("--steps-per-graph", type=int, default=4, help="graph mode: consecutive steps replayed per hipGraph launch (FrameOptimizer.run); 1 = one launch per step")
     parser.add_argument("--whole-frame", action="store_true", help="time one whole frame as the reference runs it: steps 0..2999 with the real schedules "
                         "(1000 box-only warm-up steps, then 2000 residual steps), set-up and graph captures included")
     args = parser.parse_args()
@@ -52,10 +53,9 @@ def main():
         def frame(slot):
             loop = optimization.FrameOptimizer(inputs, optimization.OptimizationConfig(seed=slot, num_rays=args.rays), dev, graph=args.graph)
             marks = []
-            for step in range(loop.config.num_steps):
-                if step == loop.config.warmup_steps:
-                    torch.cuda.synchronize(); marks.append(time.perf_counter())
-                losses = loop.step()
+            loop.run(loop.config.warmup_steps, args.steps_per_graph)
+            torch.cuda.synchronize(); marks.append(time.perf_counter())
+            losses = loop.run(loop.config.num_steps - loop.config.warmup_steps, args.steps_per_graph)
             torch.cuda.synchronize(); marks.append(time.perf_counter())
             return marks, float(losses["loss"]), loop
         frame(0)[2].close()                                  # warm the allocator and the code objects
@@ -72,7 +72,7 @@ def main():
             import json
             print(json.dumps(dict(mode="native", phase="whole frame", graph=bool(args.graph), seconds_per_frame=total, warmup_phase_seconds=warm,
                                   residual_phase_seconds=total - warm, steps=cfg.num_steps, rays_per_step=args.rays, samples_per_ray=cfg.num_samples,
-                                  views=V, instances=N, final_loss=loss)))
+                                  views=V, instances=N, final_loss=loss, steps_per_graph=args.steps_per_graph if args.graph else None)))
         return
     import threading
     # Frames are independent (README.md:128: no exchange): several can be optimised at once, each on its own stream with its own
@@ -95,8 +95,7 @@ def main():
     def worker(slot):
         with torch.cuda.stream(streams[slot]):
             start_line.wait()
-            for _ in range(args.steps):
-                losses = loops[slot].step()
+            losses = loops[slot].run(args.steps, args.steps_per_graph)
             streams[slot].synchronize()
             results[slot] = float(losses["loss"])
 
@@ -118,7 +117,8 @@ def main():
         import json
         print(json.dumps(dict(mode="native", phase="residual" if args.residual else "box-only", graph=bool(args.graph), frames_at_once=args.concurrent,
                               steps_per_s=total / dt, ms_per_step=dt / total * 1e3, seconds_per_3000_step_frame=3000 * dt / total,
-                              rays_per_step=args.rays, samples_per_ray=100, views=V, instances=N, final_loss=results[0])))
+                              rays_per_step=args.rays, samples_per_ray=100, views=V, instances=N, final_loss=results[0],
+                              steps_per_graph=args.steps_per_graph if args.graph else None)))
 
 
 if __name__ == "__main__":

@@ -25,10 +25,18 @@ constexpr float kHyperNormEps = 1.0e-5f;
 
 struct HyperAdam { float beta1, beta2, epsilon; };
 
+// Exact (erf) GELU and its derivative through residual.h's normal cdf / pdf pair (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 on erf:
+// one f32 ulp of a cdf near 1; ~17 instructions).  libm's erff is ~300 instructions with divergent branches, and the part between two
+// linears is ONE wave's work while fifteen wait: 4 erff per lane were 4.5 of the 8 us per layer (tools/hyper_timers.py).
+#ifdef VSRD_LIBM_ERF
 __device__ __forceinline__ float gelu_exact(float a) { return 0.5f * a * (1.0f + erff(a * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_exact_derivative(float a) {
     return 0.5f * (1.0f + erff(a * 0.70710678118654752f)) + a * 0.39894228040143268f * expf(-0.5f * a * a);
 }
+#else
+__device__ __forceinline__ float gelu_exact(float a) { return a * gauss(a).cdf; }
+__device__ __forceinline__ float gelu_exact_derivative(float a) { const Gauss n = gauss(a); return n.cdf + a * n.pdf; }
+#endif
 
 // torch.optim.Adam's update of one tensor, the per-step scalars computed once per thread.  (The step counters are advanced by
 // hyper_finish_kernel, after every reader of the step.)
@@ -95,8 +103,8 @@ __global__ __launch_bounds__(kHyperThreads) void hyper_linear_forward_kernel(
 }
 
 // The four hidden blocks of ONE instance per workgroup (the instances do not meet before the losses): four dependent launches of the
-// kernel above become one.  16 waves, one output row per wave at a time (16 rows each, all 16 row loads in flight at once); the
-// LayerNorm + GELU between two linears is one wave's work (4 channels per lane).  z[l] [N][256]: the linears' outputs, kept for the
+// kernel above become one.  16 waves hold 16 output rows each (all 16 row loads in flight at once); the LayerNorm + GELU between two
+// linears is one wave's work (4 channels per lane).  z[l] [N][256]: the linears' outputs, kept for the
 // backward; inv_norm[l] [256] likewise (every workgroup computes the same values; the first one stores them).
 constexpr int kHyperChainThreads = 1024;
 constexpr int kHyperChainWaves = kHyperChainThreads / kWave;
@@ -111,59 +119,68 @@ struct HyperHiddenForward {
 __global__ __launch_bounds__(kHyperChainThreads) void hyper_hidden_forward_kernel(const float* __restrict__ embeddings, HyperHiddenForward net) {
     __shared__ __attribute__((aligned(16))) float h[kHyperWidth];
     __shared__ __attribute__((aligned(16))) float out[kHyperWidth];
-    const int n = blockIdx.x, wave = static_cast<int>(threadIdx.x) >> 6, lane = lane_id();
-    constexpr int kWorkers = kHyperChainWaves - 1;                 // waves 1 .. 15 hold the rows: o = (wave - 1) + 15 r
-    constexpr int kRows = (kHyperWidth + kWorkers - 1) / kWorkers; // 18 (the last ones of some waves fall off the end)
+    const int n = blockIdx.x, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6), lane = lane_id();    // (wave: scalar row addresses)
+#ifdef VSRD_PHASE_TIMERS
+    const unsigned long long t_start = wall_clock64();
+#define VSRD_HYPER_AT(slot, thread) do { if (threadIdx.x == (thread) && n == 0 && l == 0) g_phase_cycles[slot] = wall_clock64() - t_start; } while (0)   /* tools/hyper_timers.py */
+#else
+#define VSRD_HYPER_AT(slot, thread) do { } while (0)
+#endif
+    constexpr int kRows = kHyperWidth / kHyperChainWaves;         // 16 rows per wave: o = wave + 16 r
     // A global load is ~2 us away from a lone workgroup, so nothing is requested where it is needed: the rows (and their g, b: lane r
-    // holds row r's) of a layer are requested while the layer before finishes; wave 0, which owns the part between two linears, holds
-    // the norms' affines from the start and no rows (the erf code next to 64 row registers spilled).
+    // holds row r's) of a layer are requested while the layer before finishes, the norms' affines at the start.  The 32 sums over
+    // the lanes that a wave owes per layer (16 rows x {v . h, v . v}) are two reduce-scatters (wave.h: ~50 instructions for 16 sums,
+    // lane r ends up with row r's) instead of 32 DPP chains of 7: with the chains a layer took 7 us of which 4.5 were the slowest
+    // wave's chains (DPP and v_readlane issue every 4.4 cycles, tools/micro/op_rates.hip).
     float4 row[kRows];
     float g_row = 0.0f, b_row = 0.0f;
     auto request = [&](int l) {
-        if (wave == 0) return;
 #pragma unroll
-        for (int r = 0; r < kRows; ++r) {
-            const int o = (wave - 1) + kWorkers * r;
-            row[r] = o < kHyperWidth ? *reinterpret_cast<const float4*>(net.v[l] + static_cast<size_t>(o) * kHyperWidth + 4 * lane) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
-        const int mine = (wave - 1) + kWorkers * lane;
-        if (lane < kRows && mine < kHyperWidth) { g_row = net.g[l][mine]; b_row = net.b[l][mine]; }
+        for (int r = 0; r < kRows; ++r) row[r] = *reinterpret_cast<const float4*>(net.v[l] + static_cast<size_t>(wave + kHyperChainWaves * r) * kHyperWidth + 4 * lane);
+        if (lane < kRows) { g_row = net.g[l][wave + kHyperChainWaves * lane]; b_row = net.b[l][wave + kHyperChainWaves * lane]; }
     };
     request(0);
-    float4 gamma[kHyperHidden - 1], beta[kHyperHidden - 1];
-    if (wave == 0) {
-#pragma unroll
-        for (int k = 0; k < kHyperHidden - 1; ++k) {
-            gamma[k] = *reinterpret_cast<const float4*>(net.gamma[k] + 4 * lane);
-            beta[k] = *reinterpret_cast<const float4*>(net.beta[k] + 4 * lane);
-        }
-        *reinterpret_cast<float4*>(h + 4 * lane) = *reinterpret_cast<const float4*>(embeddings + static_cast<size_t>(n) * kHyperWidth + 4 * lane);
+    __shared__ __attribute__((aligned(16))) float affine[kHyperHidden - 1][2][kHyperWidth];      // gamma, beta of the three norms in between
+    if (wave < kHyperHidden - 1) {
+        *reinterpret_cast<float4*>(&affine[wave][0][4 * lane]) = *reinterpret_cast<const float4*>(net.gamma[wave] + 4 * lane);
+        *reinterpret_cast<float4*>(&affine[wave][1][4 * lane]) = *reinterpret_cast<const float4*>(net.beta[wave] + 4 * lane);
     }
-#pragma unroll
+    if (wave == kHyperHidden - 1)
+        *reinterpret_cast<float4*>(h + 4 * lane) = *reinterpret_cast<const float4*>(embeddings + static_cast<size_t>(n) * kHyperWidth + 4 * lane);
+#pragma unroll 1                                                   // (unrolled, the scheduler overlaps the layers and spills the rows)
     for (int l = 0; l < kHyperHidden; ++l) {
-        __syncthreads();                                           // h of this layer is complete
-        if (wave != 0) {
-            const float4 a = *reinterpret_cast<const float4*>(h + 4 * lane);
+        float inv;                                                 // 1 / |v[o]| of row o = wave + 16 lane: does not need h, so it is computed while wave 0 prepares h
+        {
+            float squares[kRows];
 #pragma unroll
-            for (int r = 0; r < kRows; ++r) {
-                const int o = (wave - 1) + kWorkers * r;
-                const float inv = rsqrtf(wave_sum(row[r].x * row[r].x + row[r].y * row[r].y + row[r].z * row[r].z + row[r].w * row[r].w));
-                const float dot = wave_sum(row[r].x * a.x + row[r].y * a.y + row[r].z * a.z + row[r].w * a.w);
-                const float value = dot * __shfl(g_row, r, kWave) * inv + __shfl(b_row, r, kWave);
-                if (lane == 0 && o < kHyperWidth) {
-                    out[o] = value;
-                    if (n == 0) net.inv_norm[l][o] = inv;
-                }
+            for (int r = 0; r < kRows; ++r) squares[r] = (row[r].x * row[r].x + row[r].y * row[r].y) + (row[r].z * row[r].z + row[r].w * row[r].w);
+            inv = rsqrtf(wave_reduce16_scatter(squares, lane));    // lane r (of every row of 16 lanes): row r's sum
+        }
+        __builtin_amdgcn_sched_barrier(0);                         // (both reductions in flight at once spill)
+        block_lds_barrier();                                       // h of this layer is complete
+        VSRD_HYPER_AT(8, 64);
+        {
+            const float4 a = *reinterpret_cast<const float4*>(h + 4 * lane);
+            float dots[kRows];
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) dots[r] = (row[r].x * a.x + row[r].y * a.y) + (row[r].z * a.z + row[r].w * a.w);
+            const float dot = wave_reduce16_scatter(dots, lane);
+            VSRD_HYPER_AT(9, 64);
+            if (lane < kRows) {
+                const int o = wave + kHyperChainWaves * lane;
+                out[o] = dot * g_row * inv + b_row;
+                if (n == 0) net.inv_norm[l][o] = inv;
             }
             if (l + 1 < kHyperHidden) request(l + 1);
+            VSRD_HYPER_AT(10, 64);
         }
-        __syncthreads();                                           // out is complete; nobody reads h any more
+        block_lds_barrier();                                       // out is complete; nobody reads h any more
+        VSRD_HYPER_AT(11, 0);
         if (wave == 0) {
             const float4 zv = *reinterpret_cast<const float4*>(out + 4 * lane);
             *reinterpret_cast<float4*>(net.z[l] + static_cast<size_t>(n) * kHyperWidth + 4 * lane) = zv;
             if (l + 1 < kHyperHidden) {                            // (the norm behind the last hidden linear belongs to the final linear's staging)
-                constexpr int kNorms = kHyperHidden - 1;
-                const float4 gv = gamma[l < kNorms ? l : 0], bv = beta[l < kNorms ? l : 0];
+                const float4 gv = *reinterpret_cast<const float4*>(&affine[l][0][4 * lane]), bv = *reinterpret_cast<const float4*>(&affine[l][1][4 * lane]);
                 float y[4] = {zv.x, zv.y, zv.z, zv.w};
                 const float gam[4] = {gv.x, gv.y, gv.z, gv.w}, bet[4] = {bv.x, bv.y, bv.z, bv.w};
                 const float mean = wave_sum(y[0] + y[1] + y[2] + y[3]) * (1.0f / kHyperWidth);
@@ -174,10 +191,12 @@ __global__ __launch_bounds__(kHyperChainThreads) void hyper_hidden_forward_kerne
 #pragma unroll
                 for (int j = 0; j < 4; ++j) y[j] = gelu_exact(y[j] * inv_std * gam[j] + bet[j]);
                 *reinterpret_cast<float4*>(h + 4 * lane) = make_float4(y[0], y[1], y[2], y[3]);
+                VSRD_HYPER_AT(12, 0);
             }
         }
     }
 }
+#undef VSRD_HYPER_AT
 
 // Centre the generated weights for the render kernels (VSRD_FLAG_MLP_WEIGHTS_CENTRED; rendering/renderers.py::_centre_mlp): in the
 // four linears of the per-instance MLP that feed a LayerNorm, remove each column's mean over the 16 output channels.
@@ -357,7 +376,7 @@ __global__ __launch_bounds__(kHyperChainThreads) void hyper_hidden_backward_kern
         request(kHyperHidden - 1);
 #pragma unroll 1
         for (int l = kHyperHidden - 1; l >= 0; --l) {
-            __syncthreads();                                       // scaled is complete
+            block_lds_barrier();                                       // scaled is complete
             float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
             for (int r = 0; r < kRows; ++r) {
@@ -367,7 +386,7 @@ __global__ __launch_bounds__(kHyperChainThreads) void hyper_hidden_backward_kern
             *reinterpret_cast<float4*>(&partial[first][4 * lane]) = acc;
             __builtin_amdgcn_sched_barrier(0);                     // (the next layer's loads must not be hoisted above this layer's sums)
             if (l > 0) request(l - 1);
-            __syncthreads();                                       // partial is complete; nobody reads scaled any more
+            block_lds_barrier();                                       // partial is complete; nobody reads scaled any more
         }
         return;
     }
@@ -385,8 +404,8 @@ __global__ __launch_bounds__(kHyperChainThreads) void hyper_hidden_backward_kern
     if (tid < kWorkers * kRows - kHyperWidth) scaled[kHyperWidth + tid] = 0.0f;
 #pragma unroll
     for (int l = kHyperHidden - 1; l >= 0; --l) {
-        __syncthreads();
-        __syncthreads();
+        block_lds_barrier();
+        block_lds_barrier();
         if (wave != l) continue;
         float hb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll

@@ -33,6 +33,11 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// Workgroup barrier for data handed over through LDS only: waits for this wave's LDS operations, not for its global loads and
+// stores (__syncthreads() drains vmcnt too -- a prefetch requested before the barrier would be waited for AT the barrier, and a
+// global store by one wave would hold everybody for its ~2 us round trip).
+__device__ __forceinline__ void block_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- DPP building blocks (gfx9 family: row_shr, row_bcast15/31 are available on gfx950) ----------
 template <int kCtrl, int kRowMask = 0xf, int kBankMask = 0xf>
 __device__ __forceinline__ float dpp_move(float identity, float v) {

@@ -386,6 +386,41 @@ class FrameOptimizer:
         self.step_index += 1
         return outputs
 
+    def run(self, num_steps, steps_per_graph=4):
+        """``num_steps`` optimisation steps, the last step's outputs returned.  In graph mode up to ``steps_per_graph`` consecutive
+        steps of one phase are captured in ONE hipGraph and replayed together: between two graph launches the GPU idles for ~20 us
+        (profiles/r03/native_step_timeline_residual.txt: the gap behind the last kernel of a replay), a fifth of a box-only step.  The
+        steps themselves are the same launches in the same order as ``step()``'s, so the trajectory is bit-identical
+        (tests/test_hip_step.py::test_run_replays_several_steps_per_graph)."""
+        outputs = None
+        remaining = int(num_steps)
+        while remaining > 0:
+            k = 1
+            if self.graph and self.fused_glue and steps_per_graph > 1:
+                residual = self.step_index >= self.config.warmup_steps
+                to_boundary = remaining if residual else self.config.warmup_steps - self.step_index
+                k = max(1, min(int(steps_per_graph), remaining, to_boundary))
+                if self._eager_graph_steps.get((residual, False), 0) < 3 or (residual, False) not in self._graphs:
+                    k = 1            # the phase's eager warm-up steps and its one-step graph come first (step() owns that protocol)
+            outputs = self._graph_replay_many(k) if k > 1 else self.step()
+            remaining -= k
+        return outputs
+
+    def _graph_replay_many(self, k):
+        residual = self.step_index >= self.config.warmup_steps
+        key = (residual, False, k)
+        if key not in self._graphs:
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize(self.device)
+            with _capture_lock, torch.cuda.graph(graph, stream=self._capture_stream, capture_error_mode="thread_local"):
+                for _ in range(k):
+                    outputs = self._step(None, None, None, count=False)
+            self._graphs[key] = (graph, None, outputs)
+        graph, _, outputs = self._graphs[key]
+        graph.replay()
+        self.step_index += k
+        return outputs
+
     def _step(self, ray_indices, u_coarse, u_fine, count=True):
         with rendering.workspace_scope(self.workspace):
             if self.fused_glue:
