@@ -1101,7 +1101,7 @@ int32_t vsrd_hypernetwork_backward_step(const vsrd_hypernetwork* net, void* work
     hipLaunchKernelGGL(hyper_linear_backward_kernel, dim3(final_blocks), dim3(kHyperThreads), lds, s, z(kLast - 1), net->norm_weight[kLast - 1].parameter,
                        net->norm_bias[kLast - 1].parameter, grad_mlp_weights, grad_scale, inv_norm(kLast), kMlpWeights, N, adam_tensors(net->weight_v[kLast]),
                        adam_tensors(net->weight_g[kLast]), adam_tensors(net->bias[kLast]), adam, ws + p.partials);
-    hipLaunchKernelGGL(hyper_norm_backward_kernel, dim3(N), dim3(kHyperNormThreads), 0, s, ws + p.partials, final_blocks, z(kLast - 1), N,
+    hipLaunchKernelGGL(hyper_norm_backward_kernel, dim3(N), dim3(kHyperNormThreads * kHyperNormSplit), 0, s, ws + p.partials, final_blocks, z(kLast - 1), N,
                        net->norm_weight[kLast - 1].parameter, net->norm_bias[kLast - 1].parameter, gz(kLast - 1), norm_shares(kLast - 1));
     // the chain through the hidden blocks (one workgroup per instance), then every hidden linear's own update
     HyperHiddenBackward chain;

@@ -21,6 +21,7 @@ constexpr int kHyperWidth = 256;
 constexpr int kHyperThreads = 512;           // the linears: 8 waves = 8 output rows per workgroup
 constexpr int kHyperWaves = kHyperThreads / kWave;
 constexpr int kHyperNormThreads = 256;       // the LayerNorm backward: one instance per workgroup, one channel per thread
+constexpr int kHyperNormSplit = 4;           // ... and four threads per channel for the sum over the final linear's workgroups
 constexpr float kHyperNormEps = 1.0e-5f;
 
 struct HyperAdam { float beta1, beta2, epsilon; };
@@ -51,11 +52,15 @@ struct AdamStep {
         epsilon = a.epsilon;
     }
     __device__ __forceinline__ void apply(const AdamTensors& t, size_t index, float grad) const {
-        const float m = t.exp_avg[index] + (grad - t.exp_avg[index]) * one_minus_beta1;
-        const float v = t.exp_avg_sq[index] * beta2 + (1.0f - beta2) * grad * grad;
+        apply(t, index, grad, t.exp_avg[index], t.exp_avg_sq[index], t.parameter[index]);
+    }
+    // (the old moments and the old parameter requested by the caller long before the gradient is known: a load is ~2 us away)
+    __device__ __forceinline__ void apply(const AdamTensors& t, size_t index, float grad, float old_m, float old_v, float old_p) const {
+        const float m = old_m + (grad - old_m) * one_minus_beta1;
+        const float v = old_v * beta2 + (1.0f - beta2) * grad * grad;
         t.exp_avg[index] = m;
         t.exp_avg_sq[index] = v;
-        t.parameter[index] -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + epsilon);
+        t.parameter[index] = old_p - step_size * m / (sqrtf(v) * inv_sqrt_bc2 + epsilon);
     }
 };
 
@@ -233,17 +238,28 @@ __device__ __forceinline__ void hyper_rows_backward(
     const int wave = static_cast<int>(threadIdx.x) >> 6, lane = lane_id();
     const int o = block * kHyperWaves + wave;
     const bool live = o < num_rows;
-    float4 row = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (live) row = *reinterpret_cast<const float4*>(v.parameter + static_cast<size_t>(o) * kHyperWidth + 4 * lane);
+    // Everything this row will need is requested up front, in one round trip (a global load is ~2 us away and the kernel is a chain of
+    // them otherwise): the row, Adam's moments of the row, the N output adjoints of the row (lane n holds instance n's), g, 1 / |v|.
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 row = zero4, old_m = zero4, old_v = zero4;
+    float z_bar_lane = 0.0f, inv = 0.0f, g_o = 0.0f;
+    if (live) {
+        const size_t at = static_cast<size_t>(o) * kHyperWidth + 4 * lane;
+        row = *reinterpret_cast<const float4*>(v.parameter + at);
+        old_m = *reinterpret_cast<const float4*>(v.exp_avg + at);
+        old_v = *reinterpret_cast<const float4*>(v.exp_avg_sq + at);
+        if (lane < num_instances) z_bar_lane = gz[static_cast<size_t>(lane) * num_rows + o] * grad_scale;
+        inv = inv_norm[o];
+        g_o = g.parameter[o];
+    }
     const AdamStep step_v(v, adam), step_g(g, adam), step_b(b, adam);
     stage_hyper_input(x, gamma, beta, num_instances, h);
     float scale = 0.0f;
     if (live) {
-        const float inv = inv_norm[o];
-        scale = g.parameter[o] * inv;
+        scale = g_o * inv;
         float gw[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gb = 0.0f;
         for (int n = 0; n < num_instances; ++n) {
-            const float z_bar = gz[static_cast<size_t>(n) * num_rows + o] * grad_scale;
+            const float z_bar = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z_bar_lane), __builtin_amdgcn_readfirstlane(n)));
             const float4 a = *reinterpret_cast<const float4*>(h + n * kHyperWidth + 4 * lane);
             gw[0] += z_bar * a.x; gw[1] += z_bar * a.y; gw[2] += z_bar * a.z; gw[3] += z_bar * a.w;
             gb += z_bar;
@@ -251,9 +267,9 @@ __device__ __forceinline__ void hyper_rows_backward(
         }
         const float dot = wave_sum(gw[0] * row.x + gw[1] * row.y + gw[2] * row.z + gw[3] * row.w);
         const float pull = dot * inv * inv;
-        const float rv[4] = {row.x, row.y, row.z, row.w};
+        const float rv[4] = {row.x, row.y, row.z, row.w}, mv[4] = {old_m.x, old_m.y, old_m.z, old_m.w}, vv[4] = {old_v.x, old_v.y, old_v.z, old_v.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) step_v.apply(v, static_cast<size_t>(o) * kHyperWidth + 4 * lane + j, scale * (gw[j] - rv[j] * pull));
+        for (int j = 0; j < 4; ++j) step_v.apply(v, static_cast<size_t>(o) * kHyperWidth + 4 * lane + j, scale * (gw[j] - rv[j] * pull), mv[j], vv[j], rv[j]);
         if (lane == 0) {
             step_g.apply(g, o, dot * inv);
             step_b.apply(b, o, gb);
@@ -313,16 +329,23 @@ __device__ __forceinline__ float block_sum_256(float value, float* scratch) {   
 //   a = gamma y + beta, h = gelu(a):  a_bar = h_bar gelu'(a),  y_bar = a_bar gamma,  z_bar = (y_bar - mean(y_bar) - y mean(y_bar y)) / std
 // and leaves this instance's share of gamma_bar = a_bar y, beta_bar = a_bar in norm_partials [N][2][256] (hyper_finish_kernel sums
 // them at the end of the step).  Used behind the final linear, whose 203 workgroups' shares have to be summed across workgroups.
-__global__ __launch_bounds__(kHyperNormThreads) void hyper_norm_backward_kernel(
+__global__ __launch_bounds__(kHyperNormThreads * kHyperNormSplit) void hyper_norm_backward_kernel(
     const float* __restrict__ partial_gh, int num_partials, const float* __restrict__ z_prev, int num_instances,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ gz_out, float* __restrict__ norm_partials) {
     __shared__ float scratch[4];
-    const int n = blockIdx.x, c = threadIdx.x;
+    __shared__ float quarter[kHyperNormSplit][kHyperWidth];
+    const int n = blockIdx.x, c = static_cast<int>(threadIdx.x) & (kHyperWidth - 1), q = static_cast<int>(threadIdx.x) >> 8;
     const size_t stride = static_cast<size_t>(num_instances) * kHyperWidth;
     const float* src = partial_gh + static_cast<size_t>(n) * kHyperWidth + c;
-    float hb = 0.0f;
-#pragma unroll 8
-    for (int p = 0; p < num_partials; ++p) hb += src[p * stride];
+    // 203 shares per channel behind the final linear: four threads per channel sum every fourth one (16 loads in flight each), then
+    // thread c adds the four in a fixed order and the other twelve waves leave
+    float part = 0.0f;
+#pragma unroll 16
+    for (int p = q; p < num_partials; p += kHyperNormSplit) part += src[p * stride];
+    quarter[q][c] = part;
+    __syncthreads();
+    if (q != 0) return;
+    const float hb = (quarter[0][c] + quarter[1][c]) + (quarter[2][c] + quarter[3][c]);
     float y = z_prev[static_cast<size_t>(n) * kHyperWidth + c];
     const float mean = block_sum_256(y, scratch) * (1.0f / kHyperWidth);
     y -= mean;
@@ -456,22 +479,38 @@ __global__ __launch_bounds__(kHyperChainThreads) void hyper_finish_kernel(HyperN
                                                                           const float* __restrict__ embedding_bar, int num_instances, HyperAdam adam,
                                                                           HyperStepCounters counters, float* embedding_lr, float* hyper_lr, float gamma) {
     const int tid = threadIdx.x;
-    {
-        const int k = tid >> 8, c = tid & (kHyperWidth - 1);      // 4 norms x 256 channels
-        const float* src = norm_partials + static_cast<size_t>(k) * num_instances * 2 * kHyperWidth;
-        float dgamma = 0.0f, dbeta = 0.0f;
-        for (int n = 0; n < num_instances; ++n) {
-            dgamma += src[(static_cast<size_t>(n) * 2 + 0) * kHyperWidth + c];
-            dbeta += src[(static_cast<size_t>(n) * 2 + 1) * kHyperWidth + c];
-        }
-        const AdamStep step_gamma(norms.gamma[k], adam), step_beta(norms.beta[k], adam);
-        step_gamma.apply(norms.gamma[k], c, dgamma);
-        step_beta.apply(norms.beta[k], c, dbeta);
+    const int k = tid >> 8, c = tid & (kHyperWidth - 1);          // 4 norms x 256 channels
+    // every operand is requested before anything is computed (one round trip of ~2 us instead of five)
+    constexpr int kMaxPerThread = VSRD_MAX_INSTANCES * kHyperWidth / kHyperChainThreads;          // 16 embedding entries per thread at N = 64
+    const float counter = (tid < counters.count) ? *counters.step[tid] : 0.0f;
+    const float old_gamma[3] = {norms.gamma[k].exp_avg[c], norms.gamma[k].exp_avg_sq[c], norms.gamma[k].parameter[c]};
+    const float old_beta[3] = {norms.beta[k].exp_avg[c], norms.beta[k].exp_avg_sq[c], norms.beta[k].parameter[c]};
+    float e_grad[kMaxPerThread], e_m[kMaxPerThread], e_v[kMaxPerThread], e_p[kMaxPerThread];
+#pragma unroll
+    for (int it = 0; it < kMaxPerThread; ++it) {
+        const int idx = tid + it * kHyperChainThreads;
+        const bool in = idx < num_instances * kHyperWidth;
+        e_grad[it] = in ? embedding_bar[idx] : 0.0f;
+        e_m[it] = in ? embeddings.exp_avg[idx] : 0.0f;
+        e_v[it] = in ? embeddings.exp_avg_sq[idx] : 0.0f;
+        e_p[it] = in ? embeddings.parameter[idx] : 0.0f;
     }
-    const AdamStep step_embeddings(embeddings, adam);
-    for (int idx = tid; idx < num_instances * kHyperWidth; idx += kHyperChainThreads) step_embeddings.apply(embeddings, idx, embedding_bar[idx]);
-    __syncthreads();
-    if (tid < counters.count) *counters.step[tid] += 1.0f;
+    const float* src = norm_partials + static_cast<size_t>(k) * num_instances * 2 * kHyperWidth;
+    float dgamma = 0.0f, dbeta = 0.0f;
+    for (int n = 0; n < num_instances; ++n) {
+        dgamma += src[(static_cast<size_t>(n) * 2 + 0) * kHyperWidth + c];
+        dbeta += src[(static_cast<size_t>(n) * 2 + 1) * kHyperWidth + c];
+    }
+    const AdamStep step_gamma(norms.gamma[k], adam), step_beta(norms.beta[k], adam), step_embeddings(embeddings, adam);
+    step_gamma.apply(norms.gamma[k], c, dgamma, old_gamma[0], old_gamma[1], old_gamma[2]);
+    step_beta.apply(norms.beta[k], c, dbeta, old_beta[0], old_beta[1], old_beta[2]);
+#pragma unroll
+    for (int it = 0; it < kMaxPerThread; ++it) {
+        const int idx = tid + it * kHyperChainThreads;
+        if (idx < num_instances * kHyperWidth) step_embeddings.apply(embeddings, idx, e_grad[it], e_m[it], e_v[it], e_p[it]);
+    }
+    block_lds_barrier();          // every thread has used the counters and the rates it read (an execution barrier: no need to drain the stores above)
+    if (tid < counters.count) *counters.step[tid] = counter + 1.0f;
     if (tid == 0) { *embedding_lr *= gamma; *hyper_lr *= gamma; }
 }
 
