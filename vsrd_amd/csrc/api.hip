@@ -819,7 +819,7 @@ int32_t render_backward_split(const vsrd_field* field, const vsrd_render_config*
     for (int first = 0; first < config->num_rays; first += p.chunk, ++chunk_index) {
         const int rays = std::min(p.chunk, config->num_rays - first);
         const long long used_slots = static_cast<long long>(rays) * p.rounds;
-        if (hipMemsetAsync(masks, 0, (p.counter - p.masks) * sizeof(float) + sizeof(unsigned), s) != hipSuccess) return VSRD_E_LAUNCH;   // tile masks + item counter
+        if (hipMemsetAsync(masks, 0, (p.counter - p.masks + 4) * sizeof(float), s) != hipSuccess) return VSRD_E_LAUNCH;   // tile masks + the item counter's 16-byte slot (a multiple of 16 bytes: one fill kernel, not two)
 #define VSRD_LAUNCH(K)                                                                                                                   \
         hipLaunchKernelGGL(render_backward_front_kernel<K>, dim3(p.front_blocks), dim3(kBlockThreads), p.front_lds, s, f, field->instances, \
                            field->mlp_weights, c, origins, directions, distances, num_distances, grad_labels, grad_gradients, grad_weights,  \
@@ -903,7 +903,7 @@ int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_con
     for (int first = 0; first < config->num_rays; first += p.chunk, ++chunk_index) {
         const int rays = std::min(p.chunk, config->num_rays - first);
         const long long used_slots = static_cast<long long>(rays) * p.rounds;
-        if (hipMemsetAsync(masks, 0, (p.counter - p.masks) * sizeof(float) + sizeof(unsigned), s) != hipSuccess) return VSRD_E_LAUNCH;   // tile masks + item counter
+        if (hipMemsetAsync(masks, 0, (p.counter - p.masks + 4) * sizeof(float), s) != hipSuccess) return VSRD_E_LAUNCH;   // tile masks + the item counter's 16-byte slot (a multiple of 16 bytes: one fill kernel, not two)
 #define VSRD_FRONT_ARGS                                                                                                                  \
         f, field->instances, field->mlp_weights, c, origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, eikonal_scale, \
         eikonal_norm, labels, box_partials, jets, loss_partials, seeds, masks, p.slots_per_instance, first, rays, chunk_index > 0 ? 1 : 0
