@@ -1160,21 +1160,23 @@ __global__ __launch_bounds__(kPairWaves * kWave) __attribute__((amdgpu_waves_per
     // 128); a wave renders [first_point, my_points) and passes my_points where the helpers expect the ray's number of points
     const int split = ((num_points + 31) / 32) * 16;
     const int first_coarse = wave * kMineS * kWave, first_point = wave == 0 ? 0 : split, my_points = wave == 0 ? split : num_points;
+    // (the two waves of a ray only meet in LDS: block_lds_barrier() does not wait for a wave's global stores -- the cached jets, the seeds
+    // of the ray before -- as __syncthreads() would)
     for (int local = static_cast<int>(blockIdx.x); local < chunk_rays; local += static_cast<int>(gridDim.x)) {
         const int ray = chunk_base + local;
-        __syncthreads();                                                      // the previous ray's arrays are no longer read
+        block_lds_barrier();                                                      // the previous ray's arrays are no longer read
         const long long row = source_row(c, ray);
         const Ray r = load_ray_gathered(c, origins, directions, row);
         const float target = load_target(c, targets, row, lane, N);
         const RayCull rc = cull_ray_setup(instances, N, r.ox, r.oy, r.oz, r.rx, r.ry, r.rz, l.cull, lane);
         if (wave == 0) stage_ray_samples<kRoundsS>(l, c, S, ray, u_coarse, u_fine, nullptr, nullptr, sorted_input, lane);
-        __syncthreads();
+        block_lds_barrier();
         // ---- pass 1: each wave its coarse rounds; the compositing weights meet in l.fine (free until the merge writes it) ----------
         float w1[kMineS];
         float through = 1.0f;
         render_pass<kMineS, false, true>(instances, mlp, N, sh, r, rc, l.coarse, S, l.dcache, w1, nullptr, nullptr, first_coarse, &through);
         if (lane == 0) xchg[wave] = through;
-        __syncthreads();
+        block_lds_barrier();
         {
             const float entering = (wave == 0) ? 1.0f : xchg[0];
 #pragma unroll
@@ -1183,7 +1185,7 @@ __global__ __launch_bounds__(kPairWaves * kWave) __attribute__((amdgpu_waves_per
                 if (idx < S) l.fine[idx] = w1[k] * entering;
             }
         }
-        __syncthreads();
+        block_lds_barrier();
         if (wave == 0) {
             float weights[kRoundsS];
 #pragma unroll
@@ -1191,13 +1193,13 @@ __global__ __launch_bounds__(kPairWaves * kWave) __attribute__((amdgpu_waves_per
             wave_lds_sync();
             importance_merge<kRoundsS>(l, S, weights);
         }
-        __syncthreads();
+        block_lds_barrier();
         // ---- pass 2: each wave its rounds of the merged samples, with the adjoint's state kept in registers ------------------------
         RayAdjoint<kMine> st;
         float label = adjoint_forward_sweep<kMine, true, true>(st, instances, mlp, N, sh, r, rc, l.merged, my_points, nullptr, l.dcache, lane, rcache,
                                                                  first_point, &through);
         if (lane == 0) xchg[2 + wave] = through;
-        __syncthreads();
+        block_lds_barrier();
         if (wave != 0) {
             const float entering = xchg[2];
 #pragma unroll
@@ -1205,7 +1207,7 @@ __global__ __launch_bounds__(kPairWaves * kWave) __attribute__((amdgpu_waves_per
             label *= entering;
         }
         label_half[wave * kWave + lane] = label;
-        __syncthreads();
+        block_lds_barrier();
         label = label_half[lane] + label_half[kWave + lane];
         if (wave == 0 && labels_out != nullptr && lane < N) labels_out[static_cast<size_t>(ray) * N + lane] = label;
         // silhouette BCE and its gradient (as render_silhouette_kernel); the loss is counted by wave 0
@@ -1232,7 +1234,7 @@ __global__ __launch_bounds__(kPairWaves * kWave) __attribute__((amdgpu_waves_per
             later += wave_sum(valid ? st.sa[k].lam_z * st.sa[k].wgt : 0.0f);
         }
         if (lane == 0) xchg[4 + wave] = later;
-        __syncthreads();
+        block_lds_barrier();
         const float suffix = (wave == 0) ? xchg[5] : 0.0f;
         if (adjoint_reverse_sweep<kMine>(st, sh, r, my_points, nullptr, nullptr, lane, eikonal_scale, first_point, suffix)) {      // (else: masks stay 0)
             const long long slot0 = static_cast<long long>(local) * kRounds + wave * kMine;
