@@ -393,6 +393,11 @@ int32_t vsrd_hypernetwork_forward(const vsrd_hypernetwork* net, void* workspace,
 int32_t vsrd_hypernetwork_backward_step(const vsrd_hypernetwork* net, void* workspace, size_t workspace_bytes,
                                         const float* grad_mlp_weights, float grad_scale, void* stream);
 
+/* The centred copy of per-instance MLP weights [N,1617] that VSRD_FLAG_MLP_WEIGHTS_CENTRED announces: in the four linears that feed a
+ * LayerNorm (hyper_distance_field.py:57-73) every column, bias column included, has its mean over the 16 output channels removed.
+ * LayerNorm makes the field invariant to it, and the adjoints w.r.t. the centred weights are the adjoints w.r.t. the originals. */
+int32_t vsrd_centre_mlp_weights(const float* mlp_weights, int32_t num_instances, float* centred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

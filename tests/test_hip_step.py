@@ -459,7 +459,8 @@ def test_hypernetwork_kernels_match_torch(dev, N):
         want = ref_net(ref_emb)[0]
         _lib.check(lib.vsrd_hypernetwork_forward(tensors, workspace.data_ptr(), workspace.numel(), _lib.ptr(out), _lib.ptr(centred), _lib.stream()))
         torch.testing.assert_close(out, want.detach(), rtol=2e-5, atol=2e-6)
-        torch.testing.assert_close(centred, renderers._centre_mlp(want.detach()), rtol=2e-5, atol=2e-6)
+        torch.testing.assert_close(centred, renderers._centre_mlp_torch(want.detach()), rtol=2e-5, atol=2e-6)
+        torch.testing.assert_close(renderers._centre_mlp(want.detach()), renderers._centre_mlp_torch(want.detach()), rtol=1e-6, atol=1e-7)   # vsrd_centre_mlp_weights
         grad = torch.randn(N, _lib.MLP_WEIGHTS, device=dev) * 0.01
         before = [p.detach().clone() for p in [emb, *net.parameters()]]
         rates = [float(group["lr"]) for group in opt.param_groups]

@@ -158,6 +158,7 @@ SIGNATURES = {
     "vsrd_sample_rays_workspace_bytes": (ctypes.c_size_t, []),
     "vsrd_sample_rays": (ctypes.c_int32, [c_float_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
+    "vsrd_centre_mlp_weights": (ctypes.c_int32, [c_float_p, ctypes.c_int32, c_float_p, ctypes.c_void_p]),
     "vsrd_ray_table_bytes": (ctypes.c_size_t, [ctypes.c_int64]),
     "vsrd_ray_table_build": (ctypes.c_int32, [c_float_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "vsrd_sample_rays_table": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p,

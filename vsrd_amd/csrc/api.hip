@@ -1080,6 +1080,12 @@ int32_t vsrd_hypernetwork_forward(const vsrd_hypernetwork* net, void* workspace,
     return launch_status();
 }
 
+int32_t vsrd_centre_mlp_weights(const float* mlp_weights, int32_t num_instances, float* centred, void* stream) {
+    if (!mlp_weights || !centred || num_instances < 1 || num_instances > VSRD_MAX_INSTANCES) return VSRD_E_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(hyper_centre_kernel, dim3(num_instances), dim3(128), 0, static_cast<hipStream_t>(stream), mlp_weights, num_instances, centred);
+    return launch_status();
+}
+
 int32_t vsrd_hypernetwork_backward_step(const vsrd_hypernetwork* net, void* workspace, size_t workspace_bytes,
                                         const float* grad_mlp_weights, float grad_scale, void* stream) {
     if (!valid_hypernetwork(net) || !grad_mlp_weights) return VSRD_E_INVALID_ARGUMENT;

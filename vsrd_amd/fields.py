@@ -19,6 +19,7 @@ A callable that cannot be flattened is rejected with ``UnsupportedFieldError``: 
 generic (per-op PyTorch) rendering path in this package.
 """
 import functools
+import threading
 from dataclasses import dataclass
 from typing import Optional
 
@@ -248,6 +249,25 @@ def flatten(field) -> FieldBlock:
     if len(members) > _lib.MAX_INSTANCES:
         raise UnsupportedFieldError(f"{len(members)} instances > VSRD_MAX_INSTANCES={_lib.MAX_INSTANCES}")
     parts = [_unwrap_instance(m) for m in members]
+    # main.py's hierarchical_wrapper (main.py:511-523) renders the SAME closure twice per step (pass 1 under no_grad, pass 2 with the
+    # samples of pass 1): the second call finds the block of the first, as long as every captured tensor is the same object at the
+    # same version (in-place updates bump the version that a view shares with its base).  The block is always built with autograd on,
+    # so that the call under no_grad leaves a block the differentiable call can use.
+    key = (hard, (id(temperature), temperature._version) if isinstance(temperature, torch.Tensor) else float(temperature),
+           tuple((id(t), t._version, t.requires_grad) if isinstance(t, torch.Tensor) else t for p in parts for t in p))
+    cached = getattr(_last_block, "entry", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    with torch.enable_grad():
+        block = _build_block(parts, temperature, hard)
+    _last_block.entry = (key, block, parts, temperature)          # (the parts stay referenced: their ids cannot be reused meanwhile)
+    return block
+
+
+_last_block = threading.local()
+
+
+def _build_block(parts, temperature, hard) -> FieldBlock:
     locations = torch.stack([p[0].reshape(3) for p in parts])
     rotations = torch.stack([p[1].reshape(3, 3) for p in parts])
     dimensions = torch.stack([p[2].reshape(3) for p in parts])

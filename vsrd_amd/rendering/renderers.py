@@ -188,6 +188,17 @@ def _centre_mlp(mlp_weights):
     LayerNorm makes the field invariant to it and the gradients w.r.t. the centred weights ARE the gradients w.r.t. the originals
     (the adjoint's z_bar has zero channel mean), so the kernels get VSRD_FLAG_MLP_WEIGHTS_CENTRED and skip centring the weight
     operands on each of their ~10^5..10^7 evaluations (residual.h: load_forward_weights)."""
+    weights = mlp_weights.detach()
+    if weights.is_cuda and weights.dtype == torch.float32 and weights.dim() == 2 and weights.shape[1] == _lib.MLP_WEIGHTS:
+        weights = weights.contiguous()
+        out = torch.empty_like(weights)            # one launch (csrc/hypernetwork.h: hyper_centre_kernel) instead of ten element-wise ones
+        _lib.check(_lib.load().vsrd_centre_mlp_weights(_lib.ptr(weights), weights.shape[0], _lib.ptr(out), _lib.stream()))
+        return out
+    return _centre_mlp_torch(weights)
+
+
+def _centre_mlp_torch(mlp_weights):
+    """`_centre_mlp` in torch operations: the reference the kernel is tested against (tests/test_hip_step.py)."""
     out = mlp_weights.detach().clone()
     n = out.shape[0]
     first = out[:, :784].view(n, 16, 49)
