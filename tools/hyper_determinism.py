@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Bitwise determinism of csrc/hypernetwork.h: twenty forward / backward steps from the same state, six times over -- every generated
+weight block and every parameter must be identical run to run.  GPU box; experiments only."""
 import sys, torch, copy
 sys.path.insert(0, '.')
 import __graft_entry__; __graft_entry__.build()

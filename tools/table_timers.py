@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Phase clock of sample_table_kernel (csrc/ray_sampling.h) at a frame-sized table: ticks of the 100 MHz s_memrealtime clock at the end
+of its set-up, its picks, its hash inserts and the whole draw, plus the back-to-back time per draw.  The ticks need a library built
+with  VSRD_HIPCC_EXTRA="-DVSRD_TABLE_TIMERS" python -c "import __graft_entry__ as g; g.build()"  (they sit in the table header's
+padding; an ordinary build prints zeros).  GPU box; experiments only."""
 import sys, torch
 sys.path.insert(0, '.')
 import __graft_entry__; __graft_entry__.build()
