@@ -125,6 +125,13 @@ typedef struct vsrd_render_config {
                                              works on a quarter of the depth range, and one parameter-adjoint reduction serves four
                                              rays; the results agree to rounding (A/B switch)                              */
 
+#define VSRD_FLAG_STEP_SPLIT_RAY 512u       /* vsrd_render_silhouette_step: split every ray over the two waves of a workgroup, half of its
+                                             rounds each (num_samples in (16, 128]).  By default launches of at most 2048 rays that are
+                                             not dense launches of the shapes above -- the reference's 1000 importance-sampled rays
+                                             per step -- do this by themselves (two waves on every SIMD instead of one: a small launch
+                                             is latency); the flag forces it for any launch, VSRD_FLAG_STEP_WAVE_PER_RAY forbids it; the
+                                             results agree to rounding (A/B switch)                                                     */
+
 int32_t vsrd_abi_version(void);
 const char* vsrd_error_string(int32_t code);
 

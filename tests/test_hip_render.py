@@ -941,6 +941,50 @@ def test_quad_step_matches_wave_per_ray(dev, N, S, R, case):
     assert (quad[2] - wave[2]).abs().max() <= gradient_tolerance * max(float(wave[2].abs().max()), 1e-6)
 
 
+@pytest.mark.parametrize("N,S,R,case", [(8, 100, 250, "yaw"), (16, 64, 203, "yaw"), (4, 32, 64, "yaw"), (3, 20, 61, "general"), (64, 128, 37, "yaw"), (5, 64, 97, "tiny_temperature"),
+                                        (12, 48, 256, "misses"), (8, 100, 130, "philox"), (1, 17, 1, "yaw"), (33, 65, 3, "misses")])
+def test_split_step_matches_wave_per_ray(dev, N, S, R, case):
+    """render_silhouette_split_kernel (VSRD_FLAG_STEP_SPLIT_RAY: a ray's rounds divided over the two waves of a workgroup -- what launches of
+    <= 2048 gathered rays, the reference's 1000 sampled rays per step, take by themselves) against one ray per wave, both forced by their
+    flags on the same dense launch: two and four rounds, general rotations, the running minimum, exact misses (skipped and not), matched-
+    instance weights, the in-kernel Philox stream."""
+    from vsrd_amd import fields, rendering
+    from vsrd_amd.rendering import renderers
+    sc = _random_scene(77 + N + S, N, R, S, general_rotations=(case == "general"))
+    T, std, ratio = (0.02, 0.3, 0.7) if case == "tiny_temperature" else ((0.1, 0.1, 0.9) if case == "misses" else (0.4, 0.4, 0.4))
+    directions = sc["directions"].clone()
+    if case == "misses":
+        directions[::3] = torch.nn.functional.normalize(torch.tensor([[0.3, -0.9, -0.4]]), dim=-1)
+    uni = {} if case == "philox" else dict(u_coarse=sc["u_coarse"].to(dev), u_fine=sc["u_fine"].to(dev))
+    pd = torch.arange(0, N, 2, device=dev) if N >= 4 else None
+    gt = torch.arange(pd.numel() - 1, -1, -1, device=dev) if pd is not None else None
+    targets = sc["targets"][:, :pd.numel()].contiguous() if pd is not None else sc["targets"]
+    results = {}
+    for mode in ("split", "wave", "split_no_skip"):
+        renderers.STEP_WAVE_PER_RAY, renderers.STEP_SPLIT_RAY = mode == "wave", mode != "wave"
+        try:
+            inst = fields.pack_instances(sc["loc"], sc["rot"], sc["dim"]).to(dev).requires_grad_(True)
+            block = fields.FieldBlock(inst, T, None, None)
+            loss, labels = rendering.silhouette_step(block, sc["origins"].to(dev), directions.to(dev), targets.to(dev), (0.0, 100.0), S, std, ratio,
+                                                     pd_indices=pd, gt_indices=gt, seed=3, stream_offset=11, return_labels=True,
+                                                     skip_exact_misses=(mode != "split_no_skip"), **uni)
+            results[mode] = (loss.detach(), labels, torch.autograd.grad(loss, inst)[0])
+        finally:
+            renderers.STEP_WAVE_PER_RAY = renderers.STEP_SPLIT_RAY = False
+    split, wave, unskipped = results["split"], results["wave"], results["split_no_skip"]
+    assert torch.isfinite(split[2]).all()
+    if case != "misses":
+        assert float(wave[1].max()) > 0.05                  # the scene is seen
+    label_tolerance, gradient_tolerance = (2e-4, 5e-3) if case in ("philox", "misses") else (2e-5, 2e-4)
+    if S <= 20:
+        gradient_tolerance = 1e-3
+    assert (split[1] - wave[1]).abs().max() < label_tolerance
+    torch.testing.assert_close(split[0], wave[0], rtol=1e-5 if case != "philox" else 1e-3, atol=1e-7)
+    assert (split[2] - wave[2]).abs().max() <= gradient_tolerance * max(float(wave[2].abs().max()), 1e-6)
+    # skipping exact misses is exact within one mapping: same kernel, the skipped rays contribute exact zeros
+    assert torch.equal(split[1], unskipped[1]) and torch.equal(split[0], unskipped[0]) and torch.equal(split[2], unskipped[2])
+
+
 def _shape_sweep():
     """24 seeded random shapes over the whole range of the multi-ray kernels (N <= 64, S <= 128), edge sizes included."""
     g = torch.Generator().manual_seed(2024)

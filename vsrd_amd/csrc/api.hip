@@ -541,6 +541,14 @@ int32_t vsrd_project_boxes_backward(const float* world_corners, const float* ext
     return launch_status();
 }
 
+namespace {
+constexpr int kSplitBlocks = 1024;                       // render_silhouette_split_kernel: x 2 waves = two waves on each of the 1024 SIMDs
+int split_max_rays() {                                   // box-only step: launches of at most this many rays split every ray over two waves (0: never)
+    static const int value = [] { const char* e = getenv("VSRD_SPLIT_MAX_RAYS"); return e ? atoi(e) : 2048; }();
+    return value;
+}
+}  // namespace
+
 int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_config* config,
                                     const float* origins, const float* directions, const float* u_coarse, const float* u_fine,
                                     const float* targets, const float* instance_weights, float loss_scale,
@@ -562,10 +570,38 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
     if (rounds < 1 || rounds > 4) return VSRD_E_UNSUPPORTED;
     // dense launches of the benchmark shapes: four neighbouring rays per wave (quad_step.h).  Gathered rays (the reference's 1000
     // importance-sampled rays per step) are neither neighbours nor enough to fill the chip four to a wave.
-    const bool dense = config->ray_indices == nullptr && !(config->flags & VSRD_FLAG_STEP_WAVE_PER_RAY);
+    const bool force_split = (config->flags & VSRD_FLAG_STEP_SPLIT_RAY) && !(config->flags & VSRD_FLAG_STEP_WAVE_PER_RAY);
+    const bool dense = config->ray_indices == nullptr && !(config->flags & VSRD_FLAG_STEP_WAVE_PER_RAY) && !force_split;
     const bool quad = dense && S <= kQuadMaxSamples && N <= kQuadMaxInstances;
     // ... and for more instances or samples than that (BASELINE config 5: N = 64, S = 128) two rays per wave, 32 lanes each
     const bool pair = dense && !quad && S <= kPairMaxSamples && N <= kPairMaxInstances;
+    // ... and for launches too small to put two waves on every SIMD one ray per wave (the reference's 1000 sampled rays per step: 1000
+    // waves on 1024 SIMDs, pure latency), a ray split over the two waves of a workgroup (render_silhouette_split_kernel)
+    const bool split = !quad && !pair && !(config->flags & VSRD_FLAG_STEP_WAVE_PER_RAY) && (rounds == 2 || rounds == 4) &&
+                       (force_split || config->num_rays <= split_max_rays()) &&
+                       static_cast<size_t>(split_lds_floats(S, N)) * sizeof(float) <= kLdsLimit / 2;
+    if (split) {
+        const int blocks = config->num_rays < kSplitBlocks ? config->num_rays : kSplitBlocks;
+        const int num_waves = blocks * kPairWaves;
+        if (static_cast<size_t>(num_waves) * (row + 1) * sizeof(float) > workspace_bytes) return VSRD_E_WORKSPACE;
+        const size_t lds_bytes = static_cast<size_t>(split_lds_floats(S, N)) * sizeof(float);
+        const FieldArgs f = field_args(field);
+        RenderArgs c = render_args(config);
+        c.sh.inv_t = f.inv_t;
+        float* partials = static_cast<float*>(workspace);
+        float* loss_partials = partials + static_cast<size_t>(num_waves) * row;
+#define VSRD_LAUNCH_SPLIT(K)                                                                                                    \
+        do {                                                                                                                      \
+            if (opt_in_lds(render_silhouette_split_kernel<K>, lds_bytes) != VSRD_OK) return VSRD_E_LAUNCH;                       \
+            hipLaunchKernelGGL(render_silhouette_split_kernel<K>, dim3(blocks), dim3(kPairWaves * kWave), lds_bytes, s, f, field->instances, c, \
+                               origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, labels, partials, loss_partials); \
+        } while (0)
+        if (rounds == 2) VSRD_LAUNCH_SPLIT(2); else VSRD_LAUNCH_SPLIT(4);
+#undef VSRD_LAUNCH_SPLIT
+        if (launch_status() != VSRD_OK) return VSRD_E_LAUNCH;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(row + 1), dim3(256), 0, s, partials, num_waves, row, grad_instances, nullptr, loss_partials, 1, loss);
+        return launch_status();
+    }
     const int lanes = quad ? kRowLanes : 32, rays_per_wave = kWave / lanes;
     Geometry g;
     const size_t per_wave = (quad || pair) ? static_cast<size_t>(quad_lds_floats(S, N, lanes)) : static_cast<size_t>(wave_lds_floats(S, N)) + N + row;

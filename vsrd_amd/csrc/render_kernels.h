@@ -1254,6 +1254,142 @@ __global__ __launch_bounds__(kPairWaves * kWave) __attribute__((amdgpu_waves_per
     }
 }
 
+// The same split for BOX-ONLY fields: render_silhouette_kernel's step with a ray's rounds divided over the two waves of a workgroup.
+// For the reference's own launches -- 1000 importance-sampled rays per step (main.py:620-651) -- one wave per ray leaves one wave on
+// each SIMD, where a VALU instruction issues every ~5 cycles instead of every ~2.7 and the launch is pure latency (53 us); two waves
+// per ray put two on every SIMD with half the rounds each.  Same helpers, same exchange through LDS as above; one partial row and
+// one loss partial per wave, as render_silhouette_kernel writes them.
+__host__ __device__ constexpr int split_wave_floats(int num_instances) {
+    return (num_instances * kWave + cull_coef_floats(num_instances) + num_instances + num_instances * kGradStride + 3) & ~3;
+}
+__host__ __device__ constexpr int split_lds_floats(int num_samples, int num_instances) {
+    return ((7 * num_samples + 3) & ~3) + 16 + kPairWaves * kWave + kPairWaves * split_wave_floats(num_instances);
+}
+
+template <int kRounds>
+__global__ __launch_bounds__(kPairWaves * kWave) void render_silhouette_split_kernel(
+    FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
+    const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
+    const float* __restrict__ targets, const float* __restrict__ instance_weights, float loss_scale,
+    float* __restrict__ labels_out, float* __restrict__ partials, float* __restrict__ loss_partials) {
+    static_assert(kRounds % kPairWaves == 0, "a wave takes kRounds / 2 rounds of pass 2");
+    apply_device_schedule(f, c);
+    constexpr int kRoundsS = (kRounds + 1) / 2;                               // rounds of pass 1 (all of them staged and merged by wave 0)
+    constexpr int kMine = kRounds / kPairWaves;                               // rounds of pass 2 per wave
+    constexpr int kMineS = (kRoundsS + kPairWaves - 1) / kPairWaves;          // rounds of pass 1 per wave
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = wave_in_block();
+    const int lane = lane_id();
+    const int S = c.num_samples;
+    const int N = f.num_instances;
+    WaveLds l = carve_lds(lds, S, 0);                                         // shared by the two waves: the ray's sample arrays
+    float* xchg = lds + ((7 * S + 3) & ~3);                                   // [0..1] pass-1 products, [2..3] pass-2 products, [4..5] suffix sums, [6..7] pass-1 weight sums
+    float* label_half = xchg + 16;                                            // [2][64]
+    float* mine = label_half + kPairWaves * kWave + wave * split_wave_floats(N);
+    l.dcache = mine;
+    l.cull = l.dcache + N * kWave;
+    float* lam = l.cull + cull_coef_floats(N);
+    float* G = lam + N;
+    for (int idx = lane; idx < N * kGradStride; idx += kWave) G[idx] = 0.0f;
+    const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
+    Shading sh = c.sh;
+    const FieldBounds bounds = field_bounds(instances, N, f.inv_t, false, c.flags);
+    sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
+    sh.mlp_bits = 0u;
+    sh.mlp_lds = nullptr;
+    const float weight_lane = (lane < N) ? (instance_weights ? instance_weights[lane] : 1.0f) : 0.0f;
+    float loss_acc = 0.0f;
+    const int D = 2 * S, num_points = D - 1;
+    const int split = ((num_points + 31) / 32) * 16;                          // the ray's 16-point tiles divided evenly, as above
+    const int first_coarse = wave * kMineS * kWave, first_point = wave == 0 ? 0 : split, my_points = wave == 0 ? split : num_points;
+    for (int ray = static_cast<int>(blockIdx.x); ray < c.num_rays; ray += static_cast<int>(gridDim.x)) {
+        block_lds_barrier();                                                  // the previous ray's arrays are no longer read
+        const long long row = source_row(c, ray);
+        const Ray r = load_ray_gathered(c, origins, directions, row);
+        const float target = load_target(c, targets, row, lane, N);
+        const RayCull rc = cull_ray_setup(instances, N, r.ox, r.oy, r.oz, r.rx, r.ry, r.rz, l.cull, lane);
+        if (wave == 0) stage_ray_samples<kRoundsS>(l, c, S, ray, u_coarse, u_fine, nullptr, nullptr, sorted_input, lane);
+        block_lds_barrier();
+        // ---- pass 1: each wave its coarse rounds; the compositing weights meet in l.fine (free until the merge writes it) ----------
+        float w1[kMineS];
+        float through = 1.0f;
+        render_pass<kMineS, false, false>(instances, nullptr, N, sh, r, rc, l.coarse, S, l.dcache, w1, nullptr, nullptr, first_coarse, &through);
+        float my_total = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kMineS; ++k) my_total += wave_sum(w1[k]);
+        if (lane == 0) { xchg[wave] = through; xchg[6 + wave] = my_total; }
+        block_lds_barrier();
+        // exact miss (VSRD_FLAG_SKIP_EXACT_MISSES): every coarse weight of the ray is exactly 0 -- labels exactly 0, adjoint exactly 0
+        const bool missed = (c.flags & 2u) && (xchg[6] == 0.0f) && (xchg[0] * xchg[7] == 0.0f);
+        float label = 0.0f;
+        RayAdjoint<kMine> st;
+        if (!missed) {                                                        // (uniform over the workgroup: both waves read the same sums)
+            const float entering = (wave == 0) ? 1.0f : xchg[0];
+#pragma unroll
+            for (int k = 0; k < kMineS; ++k) {
+                const int idx = first_coarse + k * kWave + lane;
+                if (idx < S) l.fine[idx] = w1[k] * entering;
+            }
+            block_lds_barrier();
+            if (wave == 0) {
+                float weights[kRoundsS];
+#pragma unroll
+                for (int k = 0; k < kRoundsS; ++k) weights[k] = (k * kWave + lane < S) ? l.fine[k * kWave + lane] : 0.0f;
+                wave_lds_sync();
+                importance_merge<kRoundsS>(l, S, weights);
+            }
+            block_lds_barrier();
+            // ---- pass 2: each wave its rounds of the merged samples, with the adjoint's state kept in registers --------------------
+            label = adjoint_forward_sweep<kMine, false, true>(st, instances, nullptr, N, sh, r, rc, l.merged, my_points, nullptr, l.dcache, lane, nullptr,
+                                                                first_point, &through);
+            if (lane == 0) xchg[2 + wave] = through;
+            block_lds_barrier();
+            if (wave != 0) {
+                const float entered = xchg[2];
+#pragma unroll
+                for (int k = 0; k < kMine; ++k) { st.trans[k] *= entered; st.sa[k].wgt *= entered; }
+                label *= entered;
+            }
+            label_half[wave * kWave + lane] = label;
+            block_lds_barrier();
+            label = label_half[lane] + label_half[kWave + lane];
+        }
+        if (wave == 0 && labels_out != nullptr && lane < N) labels_out[static_cast<size_t>(ray) * N + lane] = label;
+        // silhouette BCE and its gradient (as render_silhouette_kernel); the loss is counted by wave 0
+        const float p = fminf(fmaxf(label, 1.0e-6f), 1.0f - 1.0e-6f);
+        const float bce = -(target * logf(p) + (1.0f - target) * logf(1.0f - p));
+        loss_acc += (wave == 0 && lane < N) ? weight_lane * bce : 0.0f;
+        const bool inside_clamp = (label >= 1.0e-6f) && (label <= 1.0f - 1.0e-6f);
+        const float lam_lane = (lane < N && inside_clamp) ? weight_lane * loss_scale * (p - target) / fmaxf(p * (1.0f - p), 1.0e-12f) : 0.0f;
+        if (missed || wave_max(fabsf(lam_lane)) == 0.0f) continue;           // (uniform over the workgroup: label and target are)
+        if (lane < N) lam[lane] = lam_lane;
+        wave_lds_sync();
+        if (sh.yaw) adjoint_label_mix<kMine, false, true>(st, instances, N, sh.inv_t, my_points, lam, lane, nullptr, l.dcache, first_point);
+        else adjoint_label_mix<kMine, false, false>(st, instances, N, sh.inv_t, my_points, lam, lane, nullptr, l.dcache, first_point);
+        // the reverse sweep's sum over LATER samples: wave 0 needs the total of wave 1's rounds
+        float later = 0.0f;
+#pragma unroll
+        for (int k = kMine - 1; k >= 0; --k) {
+            const bool valid = first_point + k * kWave + lane < my_points;
+            later += wave_sum(valid ? st.sa[k].lam_z * st.sa[k].wgt : 0.0f);
+        }
+        if (lane == 0) xchg[4 + wave] = later;
+        block_lds_barrier();
+        const float suffix = (wave == 0) ? xchg[5] : 0.0f;
+        if (adjoint_reverse_sweep<kMine>(st, sh, r, my_points, nullptr, nullptr, lane, 0.0f, first_point, suffix)) {
+            const SeedSink no_sink = {};
+            if (sh.yaw) adjoint_phase_b<kMine, false, true>(st, instances, nullptr, N, f.inv_t, my_points, lam, G, lane, nullptr, no_sink, first_point);
+            else adjoint_phase_b<kMine, false, false>(st, instances, nullptr, N, f.inv_t, my_points, lam, G, lane, nullptr, no_sink, first_point);
+        }
+    }
+    wave_lds_sync();
+    const size_t wave_global = static_cast<size_t>(blockIdx.x) * kPairWaves + wave;
+    float* out = partials + wave_global * (N * kGradStride);
+    for (int idx = lane; idx < N * kGradStride; idx += kWave) out[idx] = G[idx];
+    const float loss_total = wave_sum(loss_acc);
+    if (lane == 0) loss_partials[wave_global] = loss_total * loss_scale;
+}
+
 // One wave = one workgroup (its own staged weights and transposition scratch: 19.3 KB of LDS, eight workgroups per CU), so waves
 // never wait for each other: the active fraction of an item varies from 0 to 1.  Work item = (instance, kSlotsPerItem consecutive
 // slots), fetched with one global atomic; ONE partial row per item and a flag whether it holds anything.

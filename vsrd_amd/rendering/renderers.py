@@ -121,12 +121,15 @@ RESIDUAL_WAVE_PER_RAY = os.environ.get("VSRD_RESIDUAL_WAVE_PER_RAY", "0") == "1"
 # A/B switch for the box-only fused step: True sets VSRD_FLAG_STEP_WAVE_PER_RAY (render_silhouette_kernel, one wave per ray) where the
 # default puts four consecutive rays in a wave for dense launches with S <= 64 and N <= 16 (quad_step.h: render_silhouette_quad_kernel).
 STEP_WAVE_PER_RAY = os.environ.get("VSRD_STEP_WAVE_PER_RAY", "0") == "1"
+# ... and True here sets VSRD_FLAG_STEP_SPLIT_RAY: every ray split over the two waves of a workgroup (render_silhouette_split_kernel), what
+# launches of <= 2048 gathered rays -- the reference's 1000 sampled rays per step -- do by themselves.
+STEP_SPLIT_RAY = os.environ.get("VSRD_STEP_SPLIT_RAY", "0") == "1"
 
 
 def _base_flags():
     return ((0 if CULLING else _lib.FLAG_NO_CULLING) | (_lib.FLAG_RUNNING_MINIMUM if RUNNING_MINIMUM else 0)
             | (_lib.FLAG_GENERAL_ROTATIONS if GENERAL_ROTATIONS else 0) | (_lib.FLAG_RESIDUAL_SINGLE_KERNEL if RESIDUAL_SINGLE_KERNEL else 0)
-            | (_lib.FLAG_RESIDUAL_WAVE_PER_RAY if RESIDUAL_WAVE_PER_RAY else 0) | (_lib.FLAG_STEP_WAVE_PER_RAY if STEP_WAVE_PER_RAY else 0))
+            | (_lib.FLAG_RESIDUAL_WAVE_PER_RAY if RESIDUAL_WAVE_PER_RAY else 0) | (_lib.FLAG_STEP_WAVE_PER_RAY if STEP_WAVE_PER_RAY else 0) | (_lib.FLAG_STEP_SPLIT_RAY if STEP_SPLIT_RAY else 0))
 
 
 def _mlp_flag(centred_weights):
