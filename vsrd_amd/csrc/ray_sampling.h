@@ -256,7 +256,13 @@ __global__ __launch_bounds__(256) void ray_table_sums_kernel(const float* __rest
     if (threadIdx.x == 0) (ray_table_sums(table) + count)[blockIdx.x] = lds[256];
     block_exclusive_sum_u64(positives, lds);
     if (threadIdx.x == 0 && lds[256] != 0ull) atomicAdd(&table->num_positive, lds[256]);
-    if (last >= 0) atomicMax(&table->last_positive, static_cast<unsigned long long>(last));
+    // the workgroup's last positive index: the threads' indices ascend with the thread number, so it is the last thread that has one
+    __shared__ int last_thread;
+    if (threadIdx.x == 0) last_thread = -1;
+    __syncthreads();
+    if (last >= 0) atomicMax(&last_thread, static_cast<int>(threadIdx.x));
+    __syncthreads();
+    if (last_thread == static_cast<int>(threadIdx.x)) atomicMax(&table->last_positive, static_cast<unsigned long long>(last));      // one global atomic per workgroup
 }
 
 // Pass 2 (one workgroup): chunk sums -> exclusive offsets, in place; the grand total.
