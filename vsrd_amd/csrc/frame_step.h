@@ -314,12 +314,9 @@ __global__ __launch_bounds__(kFrameThreads) void frame_prologue_kernel(FrameStep
             const bool near_end = (sel & 1) != 0;
             const int ia = static_cast<int>(((e < 8 ? kEdgeFirst : kEdgeFirstHigh) >> (4 * (e & 7))) & 7u);
             const int ib = static_cast<int>(((e < 8 ? kEdgeSecondLow : kEdgeSecondHigh) >> (4 * (e & 7))) & 7u);
-            float pa[3] = {0.0f, 0.0f, 0.0f}, pb[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int c8 = 0; c8 < 8; ++c8) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) { pa[j] = (c8 == ia) ? cam[c8][j] : pa[j]; pb[j] = (c8 == ib) ? cam[c8][j] : pb[j]; }
-            }
+            float pa[3], pb[3];
+            pick_corner(cam, ia, pa);                                  // (projection.h)
+            pick_corner(cam, ib, pb);
             const ClippedEdge c = clip_edge(pa, pb, a.epsilon);
             const int i_far = c.a_is_far ? ia : ib, i_near = c.a_is_far ? ib : ia;
             const float px = near_end ? c.nx : c.fx, py = near_end ? c.ny : c.fy, pz = near_end ? c.nz : c.fz;
@@ -351,14 +348,8 @@ __global__ __launch_bounds__(kFrameThreads) void frame_prologue_kernel(FrameStep
                     to_near[2] += gt * dzn;
                 }
             }
-#pragma unroll
-            for (int c8 = 0; c8 < 8; ++c8) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    gcam[c8][j] += (c8 == i_far) ? to_far[j] : 0.0f;
-                    gcam[c8][j] += (c8 == i_near) ? to_near[j] : 0.0f;
-                }
-            }
+            add_to_corner(gcam, i_far, to_far);
+            add_to_corner(gcam, i_near, to_near);
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {

@@ -58,6 +58,24 @@ __device__ __forceinline__ EdgePoint project_point(const float* K, float x, floa
     return {pu / w, pv / w};
 }
 
+// Corner `index` (data, 0..7) of a per-thread array of eight: register arrays indexed by data live in scratch memory (a memory round
+// trip per access), so the corner is picked / added to by compare-and-select chains over the eight instead.
+__device__ __forceinline__ void pick_corner(const float (&corners)[8][3], int index, float (&out)[3]) {
+    out[0] = out[1] = out[2] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) out[j] = (c == index) ? corners[c][j] : out[j];
+    }
+}
+__device__ __forceinline__ void add_to_corner(float (&corners)[8][3], int index, const float (&v)[3]) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) corners[c][j] += (c == index) ? v[j] : 0.0f;
+    }
+}
+
 // world corners [N,8,3], extrinsics [V,16], intrinsics [V,9], edges [E,2] ->
 //   boxes_2d [V,N,4] (x1,y1,x2,y2, clipped to the image), camera_corners [V,N,8,3] (optional), selection [V,N,4] (int32).
 __global__ __launch_bounds__(256) void project_boxes_kernel(
@@ -85,7 +103,10 @@ __global__ __launch_bounds__(256) void project_boxes_kernel(
     int s_lo_u = -1, s_lo_v = -1, s_hi_u = -1, s_hi_v = -1;
     bool any = false;
     for (int e = 0; e < num_edges; ++e) {
-        const ClippedEdge c = clip_edge(cam[edges[2 * e]], cam[edges[2 * e + 1]], eps);
+        float pa[3], pb[3];
+        pick_corner(cam, edges[2 * e], pa);
+        pick_corner(cam, edges[2 * e + 1], pb);
+        const ClippedEdge c = clip_edge(pa, pb, eps);
         if (!c.front) continue;
         const EdgePoint pf = project_point(K, c.fx, c.fy, c.fz, eps, nullptr, nullptr);
         const EdgePoint pn = project_point(K, c.nx, c.ny, c.nz, eps, nullptr, nullptr);
@@ -148,7 +169,10 @@ __global__ __launch_bounds__(256) void project_boxes_backward_kernel(
         const int e = sel >> 1;
         const bool near_end = (sel & 1) != 0;
         const int ia = edges[2 * e], ib = edges[2 * e + 1];
-        const ClippedEdge c = clip_edge(cam[ia], cam[ib], eps);
+        float pa[3], pb[3];
+        pick_corner(cam, ia, pa);
+        pick_corner(cam, ib, pb);
+        const ClippedEdge c = clip_edge(pa, pb, eps);
         const int i_far = c.a_is_far ? ia : ib, i_near = c.a_is_far ? ib : ia;
         const float px = near_end ? c.nx : c.fx, py = near_end ? c.ny : c.fy, pz = near_end ? c.nz : c.fz;
         float w; bool w_clamped;
@@ -159,27 +183,31 @@ __global__ __launch_bounds__(256) void project_boxes_backward_kernel(
         float gp[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) gp[j] = g * (K[3 * r + j] - (w_clamped ? 0.0f : coord * K[6 + j])) / w;
+        float to_far[3], to_near[3] = {0.0f, 0.0f, 0.0f};
         if (!near_end) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) gcam[i_far][j] += gp[j];
+            for (int j = 0; j < 3; ++j) to_far[j] = gp[j];
         } else {
             // near' = far + (near - far) * t
             float gt = 0.0f;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                gcam[i_far][j] += gp[j] * (1.0f - c.t);
-                gcam[i_near][j] += gp[j] * c.t;
-                gt += gp[j] * (cam[i_near][j] - cam[i_far][j]);
+                const float far_j = c.a_is_far ? pa[j] : pb[j], near_j = c.a_is_far ? pb[j] : pa[j];
+                to_far[j] = gp[j] * (1.0f - c.t);
+                to_near[j] = gp[j] * c.t;
+                gt += gp[j] * (near_j - far_j);
             }
             if (!c.t_clamped) {              // t = zf / den
-                const float zf = cam[i_far][2], zn = cam[i_near][2];
+                const float zf = c.a_is_far ? pa[2] : pb[2], zn = c.a_is_far ? pb[2] : pa[2];
                 const float den = c.den_clamped ? eps : (zf - zn);
                 float dzf = 1.0f / den, dzn = 0.0f;
                 if (!c.den_clamped) { dzf -= zf / (den * den); dzn = zf / (den * den); }
-                gcam[i_far][2] += gt * dzf;
-                gcam[i_near][2] += gt * dzn;
+                to_far[2] += gt * dzf;
+                to_near[2] += gt * dzn;
             }
         }
+        add_to_corner(gcam, i_far, to_far);
+        add_to_corner(gcam, i_near, to_near);
     }
     // camera -> world:  c_j = (E_j . ph) / w  =>  dc_j/dp_k = (E[j][k] - c_j E[3][k]) / w
 #pragma unroll
