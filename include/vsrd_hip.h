@@ -347,6 +347,16 @@ int32_t vsrd_frame_prologue(const vsrd_frame_config* config, const float* raw_lo
                             float* instances, int64_t* pd_indices, int64_t* gt_indices, int32_t* target_columns, float* instance_weights,
                             float* schedule, float* projection_losses, float* grad_raw, void* stream);
 
+/* vsrd_frame_prologue and the draw of the step's rays (vsrd_sample_rays_table keyed by the same device step counter `step`) in ONE launch
+ * of two workgroups: neither needs the other, and as two launches on two streams they meet again through a cross-queue dependency that
+ * costs as much as the draw itself.  ray_table / count / remap as for vsrd_sample_rays_table; ray_indices [num_rays] int64 out. */
+int32_t vsrd_frame_prologue_sample(const vsrd_frame_config* config, const float* raw_locations, const float* raw_dimensions,
+                                   const float* raw_orientations, const float* extrinsics, const float* intrinsics, const float* gt_boxes,
+                                   const uint8_t* visible, const int64_t* step, void* scratch, size_t scratch_bytes,
+                                   float* instances, int64_t* pd_indices, int64_t* gt_indices, int32_t* target_columns, float* instance_weights,
+                                   float* schedule, float* projection_losses, float* grad_raw,
+                                   void* ray_table, int64_t count, int32_t num_rays, uint64_t seed, const int64_t* remap, int64_t* ray_indices, void* stream);
+
 /* torch.optim.Adam(capturable=True) state of one parameter tensor: all device memory, updated in place. */
 typedef struct vsrd_adam_tensors {
     float* parameter;

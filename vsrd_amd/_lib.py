@@ -170,6 +170,10 @@ SIGNATURES = {
     "vsrd_frame_prologue": (ctypes.c_int32, [ctypes.POINTER(FrameConfig), c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, c_float_p, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
+    "vsrd_frame_prologue_sample": (ctypes.c_int32, [ctypes.POINTER(FrameConfig), c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
+                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, c_float_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p,
+                                                    ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "vsrd_frame_epilogue": (ctypes.c_int32, [ctypes.POINTER(FrameConfig), c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_float,
                                              ctypes.POINTER(AdamTensors), ctypes.POINTER(AdamTensors), ctypes.POINTER(AdamTensors),
                                              c_float_p, c_float_p, ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_void_p]),

@@ -1023,6 +1023,34 @@ int32_t vsrd_frame_prologue(const vsrd_frame_config* config, const float* raw_lo
     return launch_status();
 }
 
+int32_t vsrd_frame_prologue_sample(const vsrd_frame_config* config, const float* raw_locations, const float* raw_dimensions,
+                                   const float* raw_orientations, const float* extrinsics, const float* intrinsics, const float* gt_boxes,
+                                   const uint8_t* visible, const int64_t* step, void* scratch, size_t scratch_bytes,
+                                   float* instances, int64_t* pd_indices, int64_t* gt_indices, int32_t* target_columns, float* instance_weights,
+                                   float* schedule, float* projection_losses, float* grad_raw,
+                                   void* ray_table, int64_t count, int32_t num_rays, uint64_t seed, const int64_t* remap, int64_t* ray_indices, void* stream) {
+    FrameStepArgs a;
+    if (!frame_args(config, &a)) return VSRD_E_INVALID_ARGUMENT;
+    if (!raw_locations || !raw_dimensions || !raw_orientations || !extrinsics || !intrinsics || !gt_boxes || !visible || !step || !instances ||
+        !pd_indices || !gt_indices || !target_columns || !instance_weights || !schedule || !projection_losses || !grad_raw)
+        return VSRD_E_INVALID_ARGUMENT;
+    if (!ray_table || !ray_indices || count < 1 || count >= 0xffffffffll || num_rays < 1 || num_rays > kSampleMax) return VSRD_E_INVALID_ARGUMENT;
+    if (!scratch || scratch_bytes < vsrd_frame_scratch_bytes(a.num_views, a.num_boxes)) return VSRD_E_WORKSPACE;
+    FrameBuffers b;
+    b.raw_locations = raw_locations; b.raw_dimensions = raw_dimensions; b.raw_orientations = raw_orientations;
+    b.extrinsics = extrinsics; b.intrinsics = intrinsics; b.gt_boxes = gt_boxes; b.visible = visible;
+    b.step = reinterpret_cast<const long long*>(step);
+    b.scratch = static_cast<float*>(scratch);
+    b.instances = instances;
+    b.pd_indices = reinterpret_cast<long long*>(pd_indices); b.gt_indices = reinterpret_cast<long long*>(gt_indices);
+    b.target_map = target_columns; b.instance_weights = instance_weights; b.schedule = schedule; b.losses = projection_losses; b.grad_raw = grad_raw;
+    if (opt_in_lds(frame_prologue_sample_kernel, kTableLdsBytes) != VSRD_OK) return VSRD_E_LAUNCH;
+    hipLaunchKernelGGL(frame_prologue_sample_kernel, dim3(2), dim3(kTableThreads), kTableLdsBytes, static_cast<hipStream_t>(stream), a, b,
+                       static_cast<RayTableHeader*>(ray_table), static_cast<long long>(count), num_rays, seed, reinterpret_cast<const unsigned long long*>(step),
+                       reinterpret_cast<const long long*>(remap), reinterpret_cast<long long*>(ray_indices));
+    return launch_status();
+}
+
 int32_t vsrd_frame_epilogue(const vsrd_frame_config* config, const float* grad_instances, const float* grad_raw_projection,
                             const float* projection_losses, const float* render_losses, float eikonal_ratio,
                             const vsrd_adam_tensors* locations, const vsrd_adam_tensors* dimensions, const vsrd_adam_tensors* orientations,

@@ -126,12 +126,15 @@ struct FrameBuffers {
     float* grad_raw;                 // out [N,8]: weighted projection-loss gradient w.r.t. (raw loc 3, raw dim 3, raw ori 2)
 };
 
-__global__ __launch_bounds__(kFrameThreads) void frame_prologue_kernel(FrameStepArgs a, FrameBuffers b) {
+// (the body is a function of the workgroup's size: frame_prologue_kernel runs it with 256 threads, frame_prologue_sample_kernel --
+// prologue and the step's ray draw in ONE launch, see below -- with the 1024 of its sampling workgroup)
+template <int kThreads>
+__device__ __forceinline__ void frame_prologue_body(const FrameStepArgs& a, const FrameBuffers& b) {
     __shared__ double cost[kFrameMaxBoxes * kFrameMaxBoxes];
     __shared__ float corners[kFrameMaxBoxes * 24];
     __shared__ float gcorners[kFrameMaxBoxes * 24];
     __shared__ int match_gt[kFrameMaxBoxes];          // gt column of prediction n (every prediction is matched: the problem is square)
-    __shared__ float partial[kFrameThreads / kWave][3];
+    __shared__ float partial[kThreads / kWave][3];
     const int tid = static_cast<int>(threadIdx.x);
     const int N = a.num_boxes, V = a.num_views;
 #ifdef VSRD_PHASE_TIMERS
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(kFrameThreads) void frame_prologue_kernel(FrameStep
     __syncthreads();
     VSRD_PROLOGUE_MARK();
     // ---- projection of every (view, box) (projection.h: project_boxes_kernel) -------------------------------------------------
-    for (int idx = tid; idx < V * N; idx += kFrameThreads) {
+    for (int idx = tid; idx < V * N; idx += kThreads) {
         const int v = idx / N, n = idx - v * N;
         const float* E = b.extrinsics + v * 16;
         const float* K = b.intrinsics + v * 9;
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(kFrameThreads) void frame_prologue_kernel(FrameStep
     __syncthreads();
     VSRD_PROLOGUE_MARK();
     // ---- matching on the target view (matching.h) -------------------------------------------------------------------------------
-    for (int idx = tid; idx < N * N; idx += kFrameThreads) {
+    for (int idx = tid; idx < N * N; idx += kThreads) {
         const int p = idx / N, g = idx - p * N;
         float c = negative_distance_iou(boxes_2d + 4 * p, b.gt_boxes + 4 * g);
         if (!(c == c) || c < -3.0e38f || c > 3.0e38f) c = 3.0e38f;
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(kFrameThreads) void frame_prologue_kernel(FrameStep
     VSRD_PROLOGUE_MARK();
     // ---- projection losses over kept (view, matched pair)s and their gradient w.r.t. the predicted 2-D boxes (main.py:391-415) ----
     float iou_sum = 0.0f, l1_sum = 0.0f, kept = 0.0f;
-    for (int idx = tid; idx < V * N; idx += kFrameThreads) {
+    for (int idx = tid; idx < V * N; idx += kThreads) {
         const int v = idx / N, n = idx - v * N;
         const int g = match_gt[n];
         const bool keep = b.visible[v * N + g] != 0;
@@ -281,11 +284,11 @@ __global__ __launch_bounds__(kFrameThreads) void frame_prologue_kernel(FrameStep
     __syncthreads();
     VSRD_PROLOGUE_MARK();
     float count = 0.0f, iou_total = 0.0f, l1_total = 0.0f;
-    for (int w = 0; w < kFrameThreads / kWave; ++w) { iou_total += partial[w][0]; l1_total += partial[w][1]; count += partial[w][2]; }
+    for (int w = 0; w < kThreads / kWave; ++w) { iou_total += partial[w][0]; l1_total += partial[w][1]; count += partial[w][2]; }
     count = fmaxf(count, 1.0f);
     if (tid == 0) { b.losses[0] = iou_total / count; b.losses[1] = l1_total / (count * 4.0f); }
     // ---- adjoint of the projection: 2-D box gradients -> world corners, per view (projection.h: project_boxes_backward_kernel) ----
-    for (int idx = tid; idx < V * N; idx += kFrameThreads) {
+    for (int idx = tid; idx < V * N; idx += kThreads) {
         const int v = idx / N, n = idx - v * N;
         const float* E = b.extrinsics + v * 16;
         const float* K = b.intrinsics + v * 9;
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(kFrameThreads) void frame_prologue_kernel(FrameStep
     __syncthreads();
     VSRD_PROLOGUE_MARK();
     // ---- sum over the views in a fixed order, then corners -> decoded parameters -> raw parameters ------------------------------
-    for (int idx = tid; idx < N * 24; idx += kFrameThreads) {
+    for (int idx = tid; idx < N * 24; idx += kThreads) {
         float acc = 0.0f;
         for (int v = 0; v < V; ++v) acc += grad_world[(static_cast<size_t>(v) * N) * 24 + idx];
         gcorners[idx] = acc;
@@ -403,6 +406,17 @@ __global__ __launch_bounds__(kFrameThreads) void frame_prologue_kernel(FrameStep
     VSRD_PROLOGUE_MARK();
 }
 #undef VSRD_PROLOGUE_MARK
+
+__global__ __launch_bounds__(kFrameThreads) void frame_prologue_kernel(FrameStepArgs a, FrameBuffers b) { frame_prologue_body<kFrameThreads>(a, b); }
+
+// The prologue and the draw of the step's rays from the frame's sampling table (ray_sampling.h) in ONE launch of two workgroups: neither
+// needs the other, and as two launches on two streams they met again through a cross-queue dependency of ~10 us.
+__global__ __launch_bounds__(kTableThreads) void frame_prologue_sample_kernel(FrameStepArgs a, FrameBuffers b, RayTableHeader* table, long long count, int num_rays,
+                                                                              unsigned long long seed, const unsigned long long* __restrict__ device_step,
+                                                                              const long long* __restrict__ remap, long long* __restrict__ ray_indices) {
+    if (blockIdx.x == 0) frame_prologue_body<kTableThreads>(a, b);
+    else sample_table_body(table, count, num_rays, seed, 0ull, device_step, remap, ray_indices);
+}
 
 struct AdamTensors {                   // torch.optim.Adam(capturable=True) state of one parameter tensor, all on the device
     float* parameter;

@@ -344,9 +344,9 @@ __global__ __launch_bounds__(256) void ray_table_guide_kernel(long long count, R
 // LDS: keys [kTableSlots] (the index that owns a slot) | first [kTableSlots] (its earliest candidate number) | wave totals [16] | total
 constexpr size_t kTableLdsBytes = sizeof(unsigned) * (2 * kTableSlots + kTableThreads / kWave + 1);
 
-__global__ __launch_bounds__(kTableThreads) void sample_table_kernel(RayTableHeader* table, long long count, int k, unsigned long long seed,
-                                                                     unsigned long long step, const unsigned long long* __restrict__ device_step,
-                                                                     const long long* __restrict__ remap, long long* __restrict__ indices) {
+__device__ __forceinline__ void sample_table_body(RayTableHeader* table, long long count, int k, unsigned long long seed,
+                                                  unsigned long long step, const unsigned long long* __restrict__ device_step,
+                                                  const long long* __restrict__ remap, long long* __restrict__ indices) {
     extern __shared__ __attribute__((aligned(16))) unsigned table_lds[];
     unsigned* keys = table_lds;
     unsigned* first = table_lds + kTableSlots;
@@ -431,6 +431,12 @@ __global__ __launch_bounds__(kTableThreads) void sample_table_kernel(RayTableHea
         for (int i = accepted + tid; i < need; i += kTableThreads) indices[i] = indices[(i - accepted) % accepted];
         if (tid == 0) table->incomplete = 1u;
     }
+}
+
+__global__ __launch_bounds__(kTableThreads) void sample_table_kernel(RayTableHeader* table, long long count, int k, unsigned long long seed,
+                                                                     unsigned long long step, const unsigned long long* __restrict__ device_step,
+                                                                     const long long* __restrict__ remap, long long* __restrict__ indices) {
+    sample_table_body(table, count, k, seed, step, device_step, remap, indices);
 }
 
 }  // namespace vsrd

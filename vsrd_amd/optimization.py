@@ -225,10 +225,12 @@ class FrameOptimizer:
         rays_branch, net_branch = self._branches
         fused_net = residual and self.fused_hypernetwork
         sampled = ray_indices is None
-        if sampled:                     # branch 1: this step's rays (device sampler keyed by the step counter, ray_sampling.h)
+        with_prologue = sampled and self.ray_table is not None      # the draw rides in the prologue's launch (a second workgroup): no branch, no join
+        if sampled and not with_prologue:   # branch 1: this step's rays (device sampler keyed by the step counter, ray_sampling.h)
             rays_branch.wait_stream(main)
             with torch.cuda.stream(rays_branch):
                 self._draw_rays(b["ray_indices"], b["picks"])
+        if sampled:
             ray_indices = b["ray_indices"]
         if fused_net:                   # branch 2: embeddings -> MLP weights
             hyper_ws = b["hyper_workspace"]
@@ -236,12 +238,18 @@ class FrameOptimizer:
             with torch.cuda.stream(net_branch):
                 _lib.check(lib.vsrd_hypernetwork_forward(self._hypernetwork, hyper_ws.data_ptr(), hyper_ws.numel(), _lib.ptr(b["mlp_weights"]),
                                                          _lib.ptr(b["mlp_centred"]), _lib.stream()))
-        _lib.check(lib.vsrd_frame_prologue(frame, _lib.ptr(det.locations.data), _lib.ptr(det.dimensions.data), _lib.ptr(det.orientations.data),
-                                           _lib.ptr(b["extrinsics"]), _lib.ptr(b["intrinsics"]), _lib.ptr(b["gt_boxes"]), b["visible"].data_ptr(),
-                                           self.step_tensor.data_ptr(), b["scratch"].data_ptr(), b["scratch"].numel(), _lib.ptr(b["instances"]),
-                                           b["pd_indices"].data_ptr(), b["gt_indices"].data_ptr(), b["target_columns"].data_ptr(),
-                                           _lib.ptr(b["instance_weights"]), _lib.ptr(self.schedule), _lib.ptr(b["projection_losses"]), _lib.ptr(b["grad_raw"]), stream))
-        if sampled:
+        prologue_args = (frame, _lib.ptr(det.locations.data), _lib.ptr(det.dimensions.data), _lib.ptr(det.orientations.data),
+                         _lib.ptr(b["extrinsics"]), _lib.ptr(b["intrinsics"]), _lib.ptr(b["gt_boxes"]), b["visible"].data_ptr(),
+                         self.step_tensor.data_ptr(), b["scratch"].data_ptr(), b["scratch"].numel(), _lib.ptr(b["instances"]),
+                         b["pd_indices"].data_ptr(), b["gt_indices"].data_ptr(), b["target_columns"].data_ptr(),
+                         _lib.ptr(b["instance_weights"]), _lib.ptr(self.schedule), _lib.ptr(b["projection_losses"]), _lib.ptr(b["grad_raw"]))
+        if with_prologue:
+            table = self.ray_table
+            _lib.check(lib.vsrd_frame_prologue_sample(*prologue_args, table.table.data_ptr(), table.count, cfg.num_rays, (cfg.seed + 1) & 0xFFFFFFFFFFFFFFFF,
+                                                      self.positive_pixels.data_ptr(), b["ray_indices"].data_ptr(), stream))
+        else:
+            _lib.check(lib.vsrd_frame_prologue(*prologue_args, stream))
+        if sampled and not with_prologue:
             main.wait_stream(rays_branch)
         if fused_net:
             main.wait_stream(net_branch)
