@@ -213,7 +213,7 @@ class FrameOptimizer:
         b["ray_indices"] = torch.zeros(cfg.num_rays, dtype=torch.int64, device=dev)
         b["mlp_weights"], b["mlp_centred"] = torch.zeros(N, _lib.MLP_WEIGHTS, **f32), torch.zeros(N, _lib.MLP_WEIGHTS, **f32)
 
-    def _fused_step(self, ray_indices, count=True):
+    def _fused_step(self, ray_indices, count=True, joins=(True, True)):
         """One step with the box-side glue in frame_step.h.  Same arithmetic as `_step_in_scope` (the eager torch path is its
         parity reference: tests/test_hip_step.py)."""
         cfg, b, lib, frame = self.config, self._glue, _lib.load(), self._frame
@@ -234,7 +234,8 @@ class FrameOptimizer:
             ray_indices = b["ray_indices"]
         if fused_net:                   # branch 2: embeddings -> MLP weights
             hyper_ws = b["hyper_workspace"]
-            net_branch.wait_stream(main)
+            if joins[0]:                # (inside a several-step graph the branch simply continues behind the hypernetwork backward of the step
+                net_branch.wait_stream(main)     # before: nothing on the main stream concerns it until this step's render adjoint)
             with torch.cuda.stream(net_branch):
                 _lib.check(lib.vsrd_hypernetwork_forward(self._hypernetwork, hyper_ws.data_ptr(), hyper_ws.numel(), _lib.ptr(b["mlp_weights"]),
                                                          _lib.ptr(b["mlp_centred"]), _lib.stream()))
@@ -303,7 +304,7 @@ class FrameOptimizer:
             self.optimizer.step()
             groups[3]["lr"].mul_(cfg.lr_gamma)
             groups[4]["lr"].mul_(cfg.lr_gamma)
-        if fused_net:
+        if fused_net and joins[1]:
             main.wait_stream(net_branch)
         if count:
             self.step_index += 1
@@ -421,18 +422,19 @@ class FrameOptimizer:
             graph = torch.cuda.CUDAGraph()
             torch.cuda.synchronize(self.device)
             with _capture_lock, torch.cuda.graph(graph, stream=self._capture_stream, capture_error_mode="thread_local"):
-                for _ in range(k):
-                    outputs = self._step(None, None, None, count=False)
+                for j in range(k):      # the hypernetwork's branch is joined to the step's stream only at the ends of the graph: between two
+                    # steps the next prologue (which needs the epilogue only) overlaps the hypernetwork's backward and forward
+                    outputs = self._step(None, None, None, count=False, joins=(j == 0, j == k - 1))
             self._graphs[key] = (graph, None, outputs)
         graph, _, outputs = self._graphs[key]
         graph.replay()
         self.step_index += k
         return outputs
 
-    def _step(self, ray_indices, u_coarse, u_fine, count=True):
+    def _step(self, ray_indices, u_coarse, u_fine, count=True, joins=(True, True)):
         with rendering.workspace_scope(self.workspace):
             if self.fused_glue:
-                return self._fused_step(ray_indices, count)
+                return self._fused_step(ray_indices, count, joins)
             return self._step_in_scope(ray_indices, u_coarse, u_fine, count)
 
     def _step_in_scope(self, ray_indices, u_coarse, u_fine, count):
