@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Bitwise determinism of csrc/hypernetwork.h: twenty forward / backward steps from the same state, six times over -- every generated
 weight block and every parameter must be identical run to run.  GPU box; experiments only."""
-import sys, torch, copy
+import sys, torch
 sys.path.insert(0, '.')
 import __graft_entry__; __graft_entry__.build()
 from vsrd_amd import _lib, models, optimization

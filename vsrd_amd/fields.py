@@ -24,7 +24,6 @@ from dataclasses import dataclass
 from typing import Optional
 
 import torch
-import torch.nn.functional as F
 
 from . import _lib
 
