@@ -428,6 +428,30 @@ def test_frame_prologue_matches_the_torch_path(dev, seed, V, N):
     assert (b["grad_raw"] - want).abs().max() <= 2e-4 * float(want.abs().max()), (b["grad_raw"], want)
     ratio, temperature, std = losses.schedules(700, config.num_steps)
     torch.testing.assert_close(loop.schedule.cpu(), torch.tensor([temperature, std, ratio]), rtol=1e-5, atol=1e-6)
+    # vsrd_frame_prologue_sample = the same prologue (its body on the 1024 threads of the sampling workgroup) and the step's ray draw in
+    # one launch: every output of the prologue bit-identical (V N <= 256: the same threads hold the same pairs), the rays those of
+    # vsrd_sample_rays_table for the same (seed, step)
+    names = ("instances", "pd_indices", "gt_indices", "target_columns", "instance_weights", "projection_losses", "grad_raw")
+    alone = {name: b[name].clone() for name in names}
+    alone["schedule"] = loop.schedule.clone()
+    for name in names:
+        b[name].zero_()
+    loop.schedule.zero_()
+    assert loop.ray_table is not None
+    table = loop.ray_table
+    rays = torch.full((config.num_rays,), -7, dtype=torch.int64, device=dev)
+    _lib.check(lib.vsrd_frame_prologue_sample(loop._frame, _lib.ptr(det.locations.data), _lib.ptr(det.dimensions.data), _lib.ptr(det.orientations.data),
+                                              _lib.ptr(b["extrinsics"]), _lib.ptr(b["intrinsics"]), _lib.ptr(b["gt_boxes"]), b["visible"].data_ptr(),
+                                              loop.step_tensor.data_ptr(), b["scratch"].data_ptr(), b["scratch"].numel(), _lib.ptr(b["instances"]),
+                                              b["pd_indices"].data_ptr(), b["gt_indices"].data_ptr(), b["target_columns"].data_ptr(), _lib.ptr(b["instance_weights"]),
+                                              _lib.ptr(loop.schedule), _lib.ptr(b["projection_losses"]), _lib.ptr(b["grad_raw"]),
+                                              table.table.data_ptr(), table.count, config.num_rays, config.seed + 1, loop.positive_pixels.data_ptr(),
+                                              rays.data_ptr(), _lib.stream()))
+    for name in names:
+        assert torch.equal(b[name], alone[name]), name
+    assert torch.equal(loop.schedule, alone["schedule"])
+    assert torch.equal(rays, table.sample(config.num_rays, seed=config.seed + 1, stream_offset=loop.step_tensor, remap=loop.positive_pixels))
+    assert torch.equal(rays, loop.sample_rays())
 
 
 @pytest.mark.parametrize("N", [1, 5, 40, 64])      # 40 and 64: the LDS of the linears (activations of all instances) needs the opt-in above 64 KB
