@@ -512,6 +512,7 @@ class FrameOptimizer:
             warnings.warn("vsrd_sample_rays overflowed its candidate list in some step of this frame: those draws were incomplete "
                           "(many equal importance weights in one histogram bin); see csrc/ray_sampling.h", RuntimeWarning)
         self._graphs.clear()
+        self.ray_table = None                  # (43 MB per frame at the reference's size: the table and its guide)
         self.workspace.release()
 
     # ---- checkpoint views (scripts/main.py:1109-1121 saves optimizer.state_dict() and scheduler.state_dict()) ----------------
