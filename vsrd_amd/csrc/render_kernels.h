@@ -1413,8 +1413,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         const long long first = static_cast<long long>(item - i * items_per_instance) * slots_per_item;
         const unsigned char* item_masks = mask_table + static_cast<long long>(i) * slots_per_instance + first;
         // anything to do?  (lane k looks at slot k of the item; slots_per_item <= 64)
-        const bool mine_active = lane < slots_per_item && first + lane < used_slots && item_masks[lane] != 0;
-        const unsigned long long active = __ballot(mine_active);
+        const int my_mask = (lane < slots_per_item && first + lane < used_slots) ? static_cast<int>(item_masks[lane]) : 0;
+        const unsigned long long active = __ballot(my_mask != 0);
         if (active == 0ull) {
             if (lane == 0) item_flags[item] = 0;
             continue;
@@ -1433,7 +1433,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #pragma unroll 1
         for (unsigned long long todo = active; todo != 0ull; todo &= todo - 1ull) {
             const int k = __builtin_ctzll(todo);
-            const unsigned rows = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(item_masks[k]));
+            const unsigned rows = static_cast<unsigned>(__builtin_amdgcn_readlane(my_mask, k));      // (lane k read slot k's mask above: no second round trip)
             const float* src = seed_table + (static_cast<long long>(i) * slots_per_instance + first + k) * (kSeedFloats * kWave) + lane;
             const float relx = src[7 * kWave], rely = src[8 * kWave], relz = src[9 * kWave];
             const ResidualAdjoint ra = mlp_adjoint_points<true>(s, wt, src[0 * kWave], src[1 * kWave], src[2 * kWave], src[3 * kWave],
