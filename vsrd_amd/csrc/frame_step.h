@@ -158,6 +158,13 @@ __device__ __forceinline__ void frame_prologue_body(const FrameStepArgs& a, cons
     int* selection = small ? small_selection : reinterpret_cast<int*>(b.scratch + static_cast<size_t>(V) * N * 4);
     float* grad_boxes = small ? small_grad_boxes : b.scratch + static_cast<size_t>(V) * N * 8;
     float* grad_world = small ? reinterpret_cast<float*>(cost) : b.scratch + static_cast<size_t>(V) * N * 12;
+    // the views' matrices (16 + 9 floats each) into LDS while the boxes are decoded: both projection phases then start without a global
+    // round trip of their own
+    __shared__ float view_matrices[kFrameMaxViews * 25];
+    for (int idx = tid; idx < V * 25; idx += kThreads) {
+        const int v = idx / 25, r = idx - 25 * v;
+        view_matrices[idx] = r < 16 ? b.extrinsics[v * 16 + r] : b.intrinsics[v * 9 + (r - 16)];
+    }
     // ---- schedules (main.py:420-431) ----------------------------------------------------------------------------------------
     if (tid == 0) {
         const float x = static_cast<float>(*b.step) / static_cast<float>(a.num_steps);
@@ -188,8 +195,8 @@ __device__ __forceinline__ void frame_prologue_body(const FrameStepArgs& a, cons
     // ---- projection of every (view, box) (projection.h: project_boxes_kernel) -------------------------------------------------
     for (int idx = tid; idx < V * N; idx += kThreads) {
         const int v = idx / N, n = idx - v * N;
-        const float* E = b.extrinsics + v * 16;
-        const float* K = b.intrinsics + v * 9;
+        const float* E = view_matrices + v * 25;
+        const float* K = E + 16;
         float cam[8][3];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -290,8 +297,8 @@ __device__ __forceinline__ void frame_prologue_body(const FrameStepArgs& a, cons
     // ---- adjoint of the projection: 2-D box gradients -> world corners, per view (projection.h: project_boxes_backward_kernel) ----
     for (int idx = tid; idx < V * N; idx += kThreads) {
         const int v = idx / N, n = idx - v * N;
-        const float* E = b.extrinsics + v * 16;
-        const float* K = b.intrinsics + v * 9;
+        const float* E = view_matrices + v * 25;
+        const float* K = E + 16;
         float cam[8][3], hw[8], gcam[8][3];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
