@@ -546,6 +546,36 @@ def test_run_replays_several_steps_per_graph(dev):
         assert torch.equal(record_one[name], record_many[name]), name
 
 
+def test_graph_mode_keeps_the_race_sampler_for_concentrated_weights(dev):
+    """A frame whose importance weights sit in hardly more pixels than a step draws fails RayTable.suits: graph mode then keeps the
+    per-step exponential race on its own branch of the graph (vsrd_sample_rays), and the loop runs -- warm-up and residual phase,
+    single steps and several per graph -- with distinct, valid rays in every draw."""
+    from vsrd_amd import optimization
+    inputs = _c1_inputs(dev, all_visible=True)
+    soft = inputs.soft_masks
+    strongest = soft.reshape(-1, soft.shape[-1]).max(-1).values
+    keep = torch.zeros_like(strongest, dtype=torch.bool)
+    keep[torch.topk(strongest, 128).indices] = True                  # 128 pixels carry (almost) all the weight, 300 more a 1e-9 of it
+    faint = torch.zeros_like(keep)
+    faint[torch.topk(strongest * (~keep), 300).indices] = True
+    scale = (keep.float() + faint.float() * 1.0e-9).reshape(*soft.shape[:-1], 1)
+    inputs = optimization.FrameInputs(inputs.image_size, inputs.intrinsic_matrices, inputs.extrinsic_matrices, (soft * scale).contiguous(),
+                                      inputs.boxes_2d, inputs.visible_masks)
+    config = optimization.OptimizationConfig(num_samples=32, num_rays=128, warmup_steps=7, num_steps=40, seed=2)
+    loop = optimization.FrameOptimizer(inputs, config, dev, graph=True)
+    assert loop.ray_table is None and loop.fused_glue
+    for _ in range(5):
+        loop.step()
+        rays = loop._glue["ray_indices"]
+        assert rays.unique().numel() == config.num_rays and bool((loop.sampling_weights[rays] > 0).all())
+    out = loop.run(14, steps_per_graph=4)                             # across the phase switch
+    torch.cuda.synchronize()
+    assert loop.step_index == 19 and bool(torch.isfinite(out["loss"]))
+    rays = loop._glue["ray_indices"]
+    assert rays.unique().numel() == config.num_rays and bool((loop.sampling_weights[rays] > 0).all())
+    loop.close()
+
+
 @pytest.mark.parametrize("fused_glue", [True, False])
 def test_graph_mode_replays_the_same_steps(dev, fused_glue):
     """hipGraph mode (FrameOptimizer(graph=True)): the captured step reads its schedules, Philox counter, Adam step and learning
