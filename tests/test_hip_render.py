@@ -538,11 +538,22 @@ def test_sphere_tracing_and_surface_normal_g9(dev):
     assert torch.equal(conv2.reshape(-1, 1).cpu(), g["convergence_masks"])
 
 
+@pytest.fixture(params=["multi_ray", "wave_per_ray", "split_ray"])
+def step_mapping(request):
+    """The three mappings of vsrd_render_silhouette_step: four / two consecutive rays per wave (the default for these dense launches), one
+    ray per wave (VSRD_FLAG_STEP_WAVE_PER_RAY), a ray split over two waves (VSRD_FLAG_STEP_SPLIT_RAY: what small gathered launches take)."""
+    from vsrd_amd.rendering import renderers
+    renderers.STEP_WAVE_PER_RAY, renderers.STEP_SPLIT_RAY = request.param == "wave_per_ray", request.param == "split_ray"
+    yield request.param
+    renderers.STEP_WAVE_PER_RAY = renderers.STEP_SPLIT_RAY = False
+
+
 @pytest.mark.parametrize("name", ["g4_render_n4_s32_mid", "g4_render_n16_s64_mid", "g4_render_n4_s32_late", "g4_render_n3_s20_mid",
-                                  "g17_render_n64_s128_mid"])     # the last one: BASELINE config 5's shape, render_silhouette_kernel<4>
-def test_fused_silhouette_step_matches_two_launch_path_and_golden(dev, name):
-    """vsrd_render_silhouette_step (render + BCE + adjoint in one launch) against the reference's loss / gradients (golden, cases
-    without an eikonal term) and against the two-launch path with torch's BCE, including a Hungarian-style column permutation."""
+                                  "g17_render_n64_s128_mid"])     # the last one: BASELINE config 5's shape
+def test_fused_silhouette_step_matches_two_launch_path_and_golden(dev, name, step_mapping):
+    """vsrd_render_silhouette_step (render + BCE + adjoint in one launch), in each of its three mappings, against the reference's loss /
+    gradients (golden, cases without an eikonal term) and against the two-launch path with torch's BCE, including a Hungarian-style
+    column permutation."""
     from vsrd_amd import rendering
     g = load_golden(name)
     S = int(g["num_samples"])
