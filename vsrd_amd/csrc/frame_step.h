@@ -446,28 +446,51 @@ struct EpilogueBuffers {
     float* raw_gradients;              // out [N,8] (diagnostics / tests)
 };
 
-__device__ __forceinline__ void adam_update(const FrameStepArgs& a, const AdamTensors& t, int index, float grad, float step_new, float lr) {
-    const float m = t.exp_avg[index] + (grad - t.exp_avg[index]) * (1.0f - a.beta1);            // lerp_(grad, 1 - beta1)
-    const float v = t.exp_avg_sq[index] * a.beta2 + (1.0f - a.beta2) * grad * grad;
+// (old_m, old_v, old_p: the moments and the parameter as the caller read them -- together with everything else, in one round trip)
+__device__ __forceinline__ void adam_update(const FrameStepArgs& a, const AdamTensors& t, int index, float grad, float step_new, float lr,
+                                            float old_m, float old_v, float old_p) {
+    const float m = old_m + (grad - old_m) * (1.0f - a.beta1);                                    // lerp_(grad, 1 - beta1)
+    const float v = old_v * a.beta2 + (1.0f - a.beta2) * grad * grad;
     t.exp_avg[index] = m;
     t.exp_avg_sq[index] = v;
     const float bc1 = 1.0f - powf(a.beta1, step_new), bc2 = 1.0f - powf(a.beta2, step_new);
-    t.parameter[index] -= (lr / bc1) * m / (sqrtf(v) / sqrtf(bc2) + a.adam_epsilon);
+    t.parameter[index] = old_p - (lr / bc1) * m / (sqrtf(v) / sqrtf(bc2) + a.adam_epsilon);
 }
 
 __global__ __launch_bounds__(kFrameMaxBoxes) void frame_epilogue_kernel(FrameStepArgs a, EpilogueBuffers e) {
     const int tid = static_cast<int>(threadIdx.x);
     const int N = a.num_boxes;
-    // every thread reads the scalars before anyone updates them
+    // every thread reads the scalars before anyone updates them -- and with them everything else it will need (its box's raw
+    // parameters, their Adam moments, the two gradient rows; thread 0 the step counter, the losses, the other groups' rates): ONE global
+    // round trip of ~2 us for this lone workgroup instead of four in a row
     const float step_l = *e.locations.step + 1.0f, step_d = *e.dimensions.step + 1.0f, step_o = *e.orientations.step + 1.0f;
     const float lr_l = *e.locations.learning_rate, lr_d = *e.dimensions.learning_rate, lr_o = *e.orientations.learning_rate;
+    const int box = tid < N ? tid : 0;
+    float raw_loc[3], raw_dim[3], raw_ori[2], m_loc[3], v_loc[3], m_dim[3], v_dim[3], m_ori[2], v_ori[2], gi[16], projection[8];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        raw_loc[j] = e.locations.parameter[3 * box + j]; m_loc[j] = e.locations.exp_avg[3 * box + j]; v_loc[j] = e.locations.exp_avg_sq[3 * box + j];
+        raw_dim[j] = e.dimensions.parameter[3 * box + j]; m_dim[j] = e.dimensions.exp_avg[3 * box + j]; v_dim[j] = e.dimensions.exp_avg_sq[3 * box + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        raw_ori[j] = e.orientations.parameter[2 * box + j]; m_ori[j] = e.orientations.exp_avg[2 * box + j]; v_ori[j] = e.orientations.exp_avg_sq[2 * box + j];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) gi[k] = e.grad_instances[16 * box + k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) projection[k] = e.grad_raw_projection[8 * box + k];
+    float other_lr[2] = {0.0f, 0.0f};
+    long long step_counter = 0;
+    float iou = 0.0f, l1 = 0.0f, sil = 0.0f, eik = 0.0f;
+    if (tid == 0) {
+        for (int k = 0; k < 2; ++k) other_lr[k] = e.other_learning_rates[k] ? *e.other_learning_rates[k] : 0.0f;
+        step_counter = *e.step;
+        iou = e.projection_losses[0]; l1 = e.projection_losses[1]; sil = e.render_losses[0]; eik = e.render_losses[1];
+    }
     __syncthreads();
     if (tid < N) {
-        const float* raw_loc = e.locations.parameter + 3 * tid;
-        const float* raw_dim = e.dimensions.parameter + 3 * tid;
-        const float* raw_ori = e.orientations.parameter + 2 * tid;
         const DecodedBox d = decode_box(a, raw_loc, raw_dim, raw_ori);
-        const float* gi = e.grad_instances + 16 * tid;
         float grads[8];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -481,24 +504,23 @@ __global__ __launch_bounds__(kFrameMaxBoxes) void frame_epilogue_kernel(FrameSte
         grads[7] = (g_s - d.s * dot) / d.norm;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            grads[k] = a.weight_silhouette * grads[k] + e.grad_raw_projection[8 * tid + k];
+            grads[k] = a.weight_silhouette * grads[k] + projection[k];
             if (e.raw_gradients) e.raw_gradients[8 * tid + k] = grads[k];
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            adam_update(a, e.locations, 3 * tid + j, grads[j], step_l, lr_l);
-            adam_update(a, e.dimensions, 3 * tid + j, grads[3 + j], step_d, lr_d);
+            adam_update(a, e.locations, 3 * tid + j, grads[j], step_l, lr_l, m_loc[j], v_loc[j], raw_loc[j]);
+            adam_update(a, e.dimensions, 3 * tid + j, grads[3 + j], step_d, lr_d, m_dim[j], v_dim[j], raw_dim[j]);
         }
-        adam_update(a, e.orientations, 2 * tid + 0, grads[6], step_o, lr_o);
-        adam_update(a, e.orientations, 2 * tid + 1, grads[7], step_o, lr_o);
+        adam_update(a, e.orientations, 2 * tid + 0, grads[6], step_o, lr_o, m_ori[0], v_ori[0], raw_ori[0]);
+        adam_update(a, e.orientations, 2 * tid + 1, grads[7], step_o, lr_o, m_ori[1], v_ori[1], raw_ori[1]);
     }
     if (tid == 0) {
         *e.locations.step = step_l; *e.dimensions.step = step_d; *e.orientations.step = step_o;
         *e.locations.learning_rate = lr_l * a.lr_gamma; *e.dimensions.learning_rate = lr_d * a.lr_gamma; *e.orientations.learning_rate = lr_o * a.lr_gamma;
         for (int k = 0; k < 2; ++k)
-            if (e.other_learning_rates[k]) *e.other_learning_rates[k] *= a.lr_gamma;
-        *e.step += 1;
-        const float iou = e.projection_losses[0], l1 = e.projection_losses[1], sil = e.render_losses[0], eik = e.render_losses[1];
+            if (e.other_learning_rates[k]) *e.other_learning_rates[k] = other_lr[k] * a.lr_gamma;
+        *e.step = step_counter + 1;
         e.record[0] = iou; e.record[1] = l1; e.record[2] = sil; e.record[3] = eik;
         e.record[4] = a.weight_iou * iou + a.weight_l1 * l1 + a.weight_silhouette * (sil + e.eikonal_ratio * eik);
     }
