@@ -242,7 +242,7 @@ __device__ __forceinline__ void hyper_rows_backward(
     // them otherwise): the row, Adam's moments of the row, the N output adjoints of the row (lane n holds instance n's), g, 1 / |v|.
     const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float4 row = zero4, old_m = zero4, old_v = zero4;
-    float z_bar_lane = 0.0f, inv = 0.0f, g_o = 0.0f;
+    float z_bar_lane = 0.0f, inv = 0.0f, g_o = 0.0f, g_m = 0.0f, g_v = 0.0f, b_m = 0.0f, b_v = 0.0f, b_p = 0.0f;
     if (live) {
         const size_t at = static_cast<size_t>(o) * kHyperWidth + 4 * lane;
         row = *reinterpret_cast<const float4*>(v.parameter + at);
@@ -251,6 +251,10 @@ __device__ __forceinline__ void hyper_rows_backward(
         if (lane < num_instances) z_bar_lane = gz[static_cast<size_t>(lane) * num_rows + o] * grad_scale;
         inv = inv_norm[o];
         g_o = g.parameter[o];
+        if (lane == 0) {                                           // (g's and the bias's Adam state: stepped by lane 0 at the end)
+            g_m = g.exp_avg[o]; g_v = g.exp_avg_sq[o];
+            b_m = b.exp_avg[o]; b_v = b.exp_avg_sq[o]; b_p = b.parameter[o];
+        }
     }
     const AdamStep step_v(v, adam), step_g(g, adam), step_b(b, adam);
     stage_hyper_input(x, gamma, beta, num_instances, h);
@@ -271,8 +275,8 @@ __device__ __forceinline__ void hyper_rows_backward(
 #pragma unroll
         for (int j = 0; j < 4; ++j) step_v.apply(v, static_cast<size_t>(o) * kHyperWidth + 4 * lane + j, scale * (gw[j] - rv[j] * pull), mv[j], vv[j], rv[j]);
         if (lane == 0) {
-            step_g.apply(g, o, dot * inv);
-            step_b.apply(b, o, gb);
+            step_g.apply(g, o, dot * inv, g_m, g_v, g_o);
+            step_b.apply(b, o, gb, b_m, b_v, b_p);
         }
     } else if (lane == 0) {
         for (int n = 0; n < num_instances; ++n) zbar[n * kHyperWaves + wave] = 0.0f;
@@ -337,6 +341,7 @@ __global__ __launch_bounds__(kHyperNormThreads * kHyperNormSplit) void hyper_nor
     const int n = blockIdx.x, c = static_cast<int>(threadIdx.x) & (kHyperWidth - 1), q = static_cast<int>(threadIdx.x) >> 8;
     const size_t stride = static_cast<size_t>(num_instances) * kHyperWidth;
     const float* src = partial_gh + static_cast<size_t>(n) * kHyperWidth + c;
+    const float y_in = z_prev[static_cast<size_t>(n) * kHyperWidth + c], gam = gamma[c], bet = beta[c];      // (requested with the shares: one round trip)
     // 203 shares per channel behind the final linear: four threads per channel sum every fourth one (16 loads in flight each), then
     // thread c adds the four in a fixed order and the other twelve waves leave
     float part = 0.0f;
@@ -346,13 +351,12 @@ __global__ __launch_bounds__(kHyperNormThreads * kHyperNormSplit) void hyper_nor
     __syncthreads();
     if (q != 0) return;
     const float hb = (quarter[0][c] + quarter[1][c]) + (quarter[2][c] + quarter[3][c]);
-    float y = z_prev[static_cast<size_t>(n) * kHyperWidth + c];
+    float y = y_in;
     const float mean = block_sum_256(y, scratch) * (1.0f / kHyperWidth);
     y -= mean;
     const float inv_std = rsqrtf(block_sum_256(y * y, scratch) * (1.0f / kHyperWidth) + kHyperNormEps);
     y *= inv_std;
-    const float gam = gamma[c];
-    const float a_bar = hb * gelu_exact_derivative(y * gam + beta[c]);
+    const float a_bar = hb * gelu_exact_derivative(y * gam + bet);
     const float y_bar = a_bar * gam;
     const float m1 = block_sum_256(y_bar, scratch) * (1.0f / kHyperWidth);
     const float m2 = block_sum_256(y_bar * y, scratch) * (1.0f / kHyperWidth);
