@@ -40,3 +40,29 @@ RESIDUAL_CASES = [
     "g17_render_residual_n16_s64_mid",      # BASELINE config 3 shape: 2 wave rounds, 16 instances
     "g17_render_residual_n4_s100_late",     # the reference's own num_fine_samples: 4 wave rounds (199 points)
 ]
+
+# ---- observed error margins -----------------------------------------------------------------------------------------------
+# Parity tests call margin(...) with what they observed next to what they tolerate; the table is printed at the end of the run
+# (pytest -q shows it: it is part of the terminal summary, not captured output), so the record of a GPU test run carries the
+# margins and not only "passed".
+_MARGINS = []
+
+
+def margin(test, what, observed, tolerance):
+    """Record `observed` (a float) against `tolerance` under the label `test` / `what`; returns observed."""
+    _MARGINS.append((str(test), str(what), float(observed), float(tolerance)))
+    return observed
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not _MARGINS:
+        return
+    worst = {}
+    for test, what, observed, tolerance in _MARGINS:            # the worst case of every (test function, quantity) over its parametrisations
+        key = (test.split("[")[0], what)
+        ratio = observed / tolerance if tolerance > 0 else float("inf")
+        if key not in worst or ratio > worst[key][0]:
+            worst[key] = (ratio, test, observed, tolerance)
+    terminalreporter.write_line(f"observed error margins ({len(_MARGINS)} records; worst case per test and quantity)")
+    for (name, what), (ratio, test, observed, tolerance) in sorted(worst.items()):
+        terminalreporter.write_line(f"  {test[:70]:70s} {what[:26]:26s} {observed:9.2e} / {tolerance:8.1e} = {ratio:5.2f}")

@@ -3,6 +3,8 @@ N=64, S=128 on a band of a 752x2816 frame) where the CPU oracle cannot follow.  
 import pytest
 import torch
 
+from conftest import margin
+
 pytestmark = pytest.mark.gpu
 
 
@@ -284,3 +286,82 @@ def test_chunked_residual_step_adds_up(dev):
     torch.testing.assert_close(chunked[1], single[1], rtol=2e-5, atol=1e-7)
     for a, b in zip(chunked[3], single[3]):
         assert (a - b).abs().max() <= 5e-4 * max(float(b.abs().max()), 1e-9)
+
+
+@pytest.mark.parametrize("shape,schedule", [("quad", "start"), ("quad", "mid"), ("quad", "end"), ("pair", "mid")])
+def test_multi_ray_step_culling_is_invisible(dev, shape, schedule):
+    """The multi-ray step kernels' OWN culling A/B: one full 376 x 1408 view of the benchmark scene, default flags
+    against VSRD_FLAG_NO_CULLING -- which also switches off the two early-outs only these kernels have ("rounds that see nothing",
+    rounds without weight / flow; quad_step.h) -- at the start / mid / end of the schedules (scripts/main.py:420-431; 477-492: the soft
+    union the culling approximates; 653-671: the loss).  quad: render_silhouette_quad_kernel<4> (N = 16, S = 64, what bench.py times);
+    pair: render_silhouette_pair_kernel<4> (N = 64, S = 128).  Same Philox keys in both runs.
+
+    What can be demanded of such an A/B.  Culling changes a coarse weight in its last bits (the culled instances' exp(-18)); the importance
+    sampler divides by cdf differences + 1e-6 (samplers.py:33), so a few fine samples move by ~1e-5 m; and the box SDF's normal -- hence
+    the opacity -- is DISCONTINUOUS across a box's medial planes, so a sample that sits on one flips with such a move and its ray's label
+    changes by up to 2e-4 (tests/culling_ab_debug.py: the float64 oracle maps each mode's distances to that mode's labels within 6e-6 on
+    exactly those rays).  That is the reference algorithm's own conditioning, not the culling.  So:
+      (a) FUSED STEP, rays whose pass-2 distances are bit-identical in both modes: labels within 2e-6; the other rays are few (< 1e-3);
+      (b) FUSED STEP, all rays: loss within 1e-5 relative, every label within 1e-3;
+      (c) THE SAME SWEEP / ADJOINT CODE AT FIXED SAMPLES (render_backward_{quad,pair}_kernel = the step's forward sweep, reverse sweep and
+          per-instance phase on the distances the default mode saved, same label adjoints): gradients within 2e-4 of the largest entry;
+      (d) FUSED STEP gradients (moved samples included): within 2e-3 of the largest entry."""
+    import bench
+    from vsrd_amd import rendering
+    from vsrd_amd.rendering import renderers
+    N, S = (16, 64) if shape == "quad" else (64, 128)
+    H, W = 376, 1408
+    sched = bench.schedule_values(bench.SCHEDULES[schedule])
+    T, std, ratio = sched["temperature"], sched["std"], sched["cosine_ratio"]
+    det, cam, dirs = scene(dev, N, 1, H, W, seed=0)
+    directions = dirs.reshape(-1, 3)
+    origins = cam[:, None, None, :].expand(1, H, W, 3).reshape(-1, 3).contiguous()
+    with torch.no_grad():
+        targets = rendering.render_hierarchical(bench.build_union(det, 0.1), origins, directions, (0.0, 100.0), S, 0.1, 1.0, seed=99,
+                                                skip_exact_misses=True)["labels"].clamp(0.0, 1.0).contiguous()
+        det.locations.add_(0.02)
+    params = [det.locations, det.dimensions, det.orientations]
+    step, forward = {}, {}
+    for mode in ("default", "no_culling"):
+        renderers.CULLING = mode == "default"
+        try:
+            loss, labels = rendering.silhouette_step(bench.build_union(det, T), origins, directions, targets, (0.0, 100.0), S, std, ratio,
+                                                     seed=5, stream_offset=11, return_labels=True)
+            step[mode] = (float(loss.detach()), labels, torch.autograd.grad(loss, params))
+            forward[mode] = rendering.render_hierarchical(bench.build_union(det, T), origins, directions, (0.0, 100.0), S, std, ratio, seed=5,
+                                                          stream_offset=11, skip_exact_misses=True)
+        finally:
+            renderers.CULLING = True
+    tag = f"test_multi_ray_step_culling_is_invisible[{shape}-{schedule}]"
+    (loss_a, labels_a, grads_a), (loss_b, labels_b, grads_b) = step["default"], step["no_culling"]
+    assert float(labels_b.max()) > 0.5 and all(float(g.abs().max()) > 0 for g in grads_b)
+    # the forward launch walks the step's own sampling code with the step's keys: its labels are the step's
+    assert float((forward["default"]["labels"].detach() - labels_a).abs().max()) < 1e-6
+    da, db = forward["default"]["distances"], forward["no_culling"]["distances"]
+    miss_a, miss_b = torch.isnan(da[:, 0]), torch.isnan(db[:, 0])                  # NaN sentinel = ray skipped as an exact miss (rest of the row unwritten)
+    same = (miss_a & miss_b) | (~miss_a & ~miss_b & (da == db).all(-1))
+    moved = 1.0 - float(same.float().mean())
+    diff = (labels_a - labels_b).abs().max(-1).values
+    margin(tag, "labels, same samples", float(diff[same].max()), 2e-6)
+    margin(tag, "rays with moved samples", moved, 1e-3)
+    margin(tag, "labels, all rays", float(diff.max()), 1e-3)
+    margin(tag, "loss (relative)", abs(loss_a - loss_b) / max(abs(loss_b), 1e-12), 1e-5)
+    step_grad_err = max(float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12) for a, b in zip(grads_a, grads_b))
+    margin(tag, "step gradients / largest", step_grad_err, 2e-3)
+    assert float(diff[same].max()) < 2e-6 and moved < 1e-3 and float(diff.max()) < 1e-3
+    assert abs(loss_a - loss_b) <= 1e-5 * abs(loss_b) and step_grad_err < 2e-3
+    # (c) the adjoint at the default mode's saved samples, with and without culling, for the BCE label adjoints of the default labels
+    out = forward["default"]
+    probabilities = out["labels"].detach().clamp(1.0e-6, 1.0 - 1.0e-6).requires_grad_(True)
+    bce = torch.nn.functional.binary_cross_entropy(probabilities, targets, reduction="none").mean()
+    lam = torch.autograd.grad(bce, probabilities)[0] * ((out["labels"].detach() >= 1e-6) & (out["labels"].detach() <= 1 - 1e-6))
+    fixed = {}
+    for mode in ("default", "no_culling"):
+        renderers.CULLING = mode == "default"
+        try:
+            fixed[mode] = torch.autograd.grad(out["labels"], params, grad_outputs=lam, retain_graph=True)
+        finally:
+            renderers.CULLING = True
+    fixed_err = max(float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12) for a, b in zip(fixed["default"], fixed["no_culling"]))
+    margin(tag, "gradients, same samples", fixed_err, 2e-4)
+    assert all(float(g.abs().max()) > 0 for g in fixed["no_culling"]) and fixed_err < 2e-4

@@ -546,6 +546,59 @@ def test_run_replays_several_steps_per_graph(dev):
         assert torch.equal(record_one[name], record_many[name]), name
 
 
+@pytest.mark.parametrize("how", ["state_dict_clone", "checkpoint_view", "module_to_assign"])
+def test_rebind_after_tensors_are_replaced_mid_frame(dev, how):
+    """The captured graphs and the kernels' pointer blocks hold raw addresses of parameters, Adam's moments / counters and the learning
+    rates (optimization.py: adam_state_tensors, hypernetwork_tensors).  Replacing those tensors mid-frame -- `optimizer.load_state_dict`
+    (new moment tensors; with the checkpoint view also float rates and host counters), `load_state_dict(assign=True)` on the modules
+    (new parameter objects: the optimiser's groups and state follow them) -- must be noticed before the next replay (`_check_bindings` -> `rebind()`), and the loop must continue BIT-IDENTICALLY to a run that
+    was never interrupted, in both phases."""
+    import copy
+    from vsrd_amd import optimization
+    inputs = _c1_inputs(dev, all_visible=True)
+    config = optimization.OptimizationConfig(num_samples=32, num_rays=128, warmup_steps=9, num_steps=40, seed=3)
+
+    def disturb(loop):
+        if how == "state_dict_clone":
+            loop.optimizer.load_state_dict(copy.deepcopy(loop.optimizer.state_dict()))
+        elif how == "checkpoint_view":           # what formats.save_checkpoint writes: float rates, host step counters
+            loop.optimizer.load_state_dict(copy.deepcopy(loop.optimizer_state_dict()))
+            for group in loop.optimizer.param_groups:
+                group["capturable"] = True
+        else:
+            for module in (loop.detector, loop.hyper_distance_field):
+                module.load_state_dict({k: v.detach().clone() for k, v in module.state_dict().items()}, assign=True)
+
+    def trajectory(interrupt_at):
+        torch.manual_seed(0)
+        loop = optimization.FrameOptimizer(inputs, config, dev, graph=True)
+        rebinds = 0
+        for step in range(20):
+            if step in interrupt_at:
+                before = loop._bound_signature
+                disturb(loop)
+                out = loop.step()
+                rebinds += before != loop._bound_signature
+            else:
+                out = loop.step()
+        torch.cuda.synchronize()
+        state = [p.detach().clone() for p in [loop.detector.locations, loop.detector.dimensions, loop.detector.orientations, loop.detector.embeddings,
+                                              *loop.hyper_distance_field.parameters()]]
+        moments = [loop.optimizer.state[p]["exp_avg_sq"].detach().clone() for g in loop.optimizer.param_groups for p in g["params"]]
+        rates = [float(g["lr"]) for g in loop.optimizer.param_groups]
+        record = {k: v.detach().clone() for k, v in out.items() if isinstance(v, torch.Tensor)}
+        loop.close()
+        return state, moments, rates, record, rebinds
+    plain = trajectory(())
+    disturbed = trajectory((5, 14))               # once in the box-only phase (graph replaying since step 3), once in the residual phase
+    assert disturbed[4] == 2 and plain[4] == 0    # both replacements were noticed
+    for a, b in zip(plain[0] + plain[1], disturbed[0] + disturbed[1]):
+        assert torch.equal(a, b)
+    assert plain[2] == disturbed[2]
+    for name in plain[3]:
+        assert torch.equal(plain[3][name], disturbed[3][name]), name
+
+
 def test_graph_mode_keeps_the_race_sampler_for_concentrated_weights(dev):
     """A frame whose importance weights sit in hardly more pixels than a step draws fails RayTable.suits: graph mode then keeps the
     per-step exponential race on its own branch of the graph (vsrd_sample_rays), and the loop runs -- warm-up and residual phase,

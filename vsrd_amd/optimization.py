@@ -194,16 +194,8 @@ class FrameOptimizer:
         b["grad_instances"], b["grad_mlp"] = torch.zeros(N, 16, **f32), torch.zeros(N, _lib.MLP_WEIGHTS, **f32)
         b["record"] = torch.zeros(5, **f32)
         b["masks"] = self.flat_masks.to(**f32).contiguous()
-        # Adam's state for the three box tensors exactly as torch.optim.Adam(capturable=True) lays it out, created up front (torch
-        # creates it lazily at a parameter's first step): the epilogue kernel updates these tensors in place, so checkpoints and
-        # optimizer.state_dict() see them like any other state
-        self._adam = [adam_state_tensors(self.optimizer, p, group)
-                      for group, p in zip(self.optimizer.param_groups[:3], (det.locations, det.dimensions, det.orientations))]
-        # the hypernetwork and the embeddings (residual phase) run through csrc/hypernetwork.h on the same footing: torch's module
-        # owns the parameters, torch.optim.Adam owns the moments and counters, the kernels update both in place
         self.fused_hypernetwork = True
-        net = hypernetwork_tensors(self.hyper_distance_field, det.embeddings, self.optimizer, cfg.lr_gamma)
-        self._hypernetwork = net
+        self.rebind()
         b["hyper_workspace"] = torch.empty(lib.vsrd_hypernetwork_workspace_bytes(N), dtype=torch.uint8, device=dev)
         # the three things a step needs before its render launch -- its rays, the boxes' side (prologue) and the generated MLP weights --
         # do not depend on each other: they run as three branches (two side streams, forked from and joined to the step's stream), and
@@ -212,6 +204,72 @@ class FrameOptimizer:
         b["picks"] = torch.zeros(cfg.num_rays, dtype=torch.int64, device=dev)
         b["ray_indices"] = torch.zeros(cfg.num_rays, dtype=torch.int64, device=dev)
         b["mlp_weights"], b["mlp_centred"] = torch.zeros(N, _lib.MLP_WEIGHTS, **f32), torch.zeros(N, _lib.MLP_WEIGHTS, **f32)
+
+    # ---- the tensors whose addresses the kernels and the captured graphs hold ----------------------------------------------------
+    def _bound_tensors(self):
+        """Every tensor of the MODULES and the OPTIMISER whose address is handed to a kernel as a raw pointer (adam_state_tensors,
+        hypernetwork_tensors, the prologue's parameter pointers): parameters, Adam's moments and counters, the learning rates.  (The
+        frame's own buffers -- self._glue, step_tensor, schedule -- are created once and never replaced.)"""
+        tensors = []
+        for group, params in zip(self.optimizer.param_groups, self._module_parameters()):
+            tensors.append(group["lr"])
+            for p in params:
+                state = self.optimizer.state.get(p, {})
+                tensors += [p, state.get("exp_avg"), state.get("exp_avg_sq"), state.get("step")]
+        return tensors
+
+    def _module_parameters(self):
+        """The modules' CURRENT parameters in the order of the optimiser's groups (__init__)."""
+        det = self.detector
+        return [[det.locations], [det.dimensions], [det.orientations], [det.embeddings], list(self.hyper_distance_field.parameters())]
+
+    def rebind(self):
+        """(Re)build the pointer blocks the kernels read -- Adam's state for the box tensors, the hypernetwork's parameter / moment /
+        counter / rate pointers -- from the CURRENT tensors of the modules and the optimiser, and drop the captured graphs (they hold
+        the old addresses).  Called at construction and, through `_check_bindings`, by itself whenever a tensor was replaced behind
+        the loop's back: `optimizer.load_state_dict(...)` (new moment tensors; learning rates possibly plain floats again),
+        `module.to(...)`, `load_state_dict(assign=True)`.  Adam's state is created as torch.optim.Adam(capturable=True) lays it out
+        (torch creates it lazily at a parameter's first step): the kernels update these tensors in place, so checkpoints and
+        optimizer.state_dict() see them like any other state."""
+        cfg, det = self.config, self.detector
+        for group, params in zip(self.optimizer.param_groups, self._module_parameters()):
+            # load_state_dict(assign=True) swaps the parameter OBJECTS of a module: the optimiser follows them, state included
+            for old, new in zip(group["params"], params):
+                if old is not new and old in self.optimizer.state:
+                    self.optimizer.state[new] = self.optimizer.state.pop(old)
+            group["params"] = list(params)
+        for group in self.optimizer.param_groups:        # a loaded state dict may carry float rates: graph mode decays device tensors in place
+            lr = group["lr"]
+            if not (isinstance(lr, torch.Tensor) and lr.device == self.device and lr.dtype == torch.float32):
+                group["lr"] = torch.as_tensor(float(lr), dtype=torch.float32, device=self.device).clone()
+            for p in group["params"]:
+                state = self.optimizer.state.get(p)
+                if state and not (isinstance(state.get("step"), torch.Tensor) and state["step"].device == self.device and state["step"].dtype == torch.float32):
+                    state["step"] = torch.as_tensor(float(state["step"]), dtype=torch.float32, device=self.device).clone()
+        self._adam = [adam_state_tensors(self.optimizer, p, group)
+                      for group, p in zip(self.optimizer.param_groups[:3], (det.locations, det.dimensions, det.orientations))]
+        # the hypernetwork and the embeddings (residual phase) run through csrc/hypernetwork.h on the same footing: torch's module
+        # owns the parameters, torch.optim.Adam owns the moments and counters, the kernels update both in place
+        self._hypernetwork = hypernetwork_tensors(self.hyper_distance_field, det.embeddings, self.optimizer, cfg.lr_gamma)
+        self._graphs.clear()
+        # references keep every bound tensor alive until the next rebind: a replaced tensor's memory is not handed to somebody else
+        # while a graph that writes through its address may still be replayed
+        self._bound = self._bound_tensors()
+        self._bound_signature = tuple(t.data_ptr() for t in self._bound)
+
+    def _check_bindings(self):
+        """Before anything is launched or replayed: are the tensors the pointer blocks were built from still the ones the modules and
+        the optimiser hold?  (A tuple compare of ~130 addresses, ~10 us.)  If not, rebind -- the loop continues on the new tensors."""
+        if not self.fused_glue:
+            return
+        current = self._bound_tensors()
+        # (a loaded state dict may hold plain floats where the loop keeps device tensors, or lack a parameter's state: both rebind)
+        if (len(current) != len(self._bound) or not all(isinstance(t, torch.Tensor) for t in current)
+                or tuple(t.data_ptr() for t in current) != self._bound_signature):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("a tensor bound to the captured step was replaced during stream capture")
+            torch.cuda.synchronize(self.device)          # replays that still write through the old addresses finish first
+            self.rebind()
 
     def _fused_step(self, ray_indices, count=True, joins=(True, True)):
         """One step with the box-side glue in frame_step.h.  Same arithmetic as `_step_in_scope` (the eager torch path is its
@@ -356,11 +414,12 @@ class FrameOptimizer:
                                        anneal * (cfg.max_sdf_std_deviation - cfg.min_sdf_std_deviation) + cfg.min_sdf_std_deviation, x]))
 
     def _graph_step(self, ray_indices):
+        """Three eager steps per (phase, ray source) on a side stream warm the allocator and the lazy initialisations, then the step is
+        captured once and replayed.  The eager steps run the same device-side code, so they are ordinary optimisation steps."""
         if ray_indices is not None and int(ray_indices.numel()) > self.config.num_rays:
             # the captured graphs hold the address of scratch sized for config.num_rays rays; a larger launch would outgrow it
             raise ValueError(f"graph mode replays steps of at most config.num_rays = {self.config.num_rays} rays, got {int(ray_indices.numel())}")
-        """Three eager steps per (phase, ray source) on a side stream warm the allocator and the lazy initialisations, then the step is
-        captured once and replayed.  The eager steps run the same device-side code, so they are ordinary optimisation steps."""
+        self._check_bindings()
         residual = self.step_index >= self.config.warmup_steps
         key = (residual, ray_indices is not None)
         if key in self._graphs:
@@ -408,7 +467,9 @@ class FrameOptimizer:
             if self.graph and self.fused_glue and steps_per_graph > 1:
                 residual = self.step_index >= self.config.warmup_steps
                 to_boundary = remaining if residual else self.config.warmup_steps - self.step_index
-                k = max(1, min(int(steps_per_graph), remaining, to_boundary))
+                # whole groups of `steps_per_graph` only: a tail shorter than that replays the one-step graph (every distinct k would
+                # otherwise cost a capture of its own -- a synchronisation -- for one use)
+                k = int(steps_per_graph) if min(remaining, to_boundary) >= int(steps_per_graph) else 1
                 if self._eager_graph_steps.get((residual, False), 0) < 3 or (residual, False) not in self._graphs:
                     k = 1            # the phase's eager warm-up steps and its one-step graph come first (step() owns that protocol)
             outputs = self._graph_replay_many(k) if k > 1 else self.step()
@@ -416,6 +477,7 @@ class FrameOptimizer:
         return outputs
 
     def _graph_replay_many(self, k):
+        self._check_bindings()
         residual = self.step_index >= self.config.warmup_steps
         key = (residual, False, k)
         if key not in self._graphs:
@@ -434,6 +496,8 @@ class FrameOptimizer:
     def _step(self, ray_indices, u_coarse, u_fine, count=True, joins=(True, True)):
         with rendering.workspace_scope(self.workspace):
             if self.fused_glue:
+                if not torch.cuda.is_current_stream_capturing():
+                    self._check_bindings()
                 return self._fused_step(ray_indices, count, joins)
             return self._step_in_scope(ray_indices, u_coarse, u_fine, count)
 
