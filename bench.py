@@ -68,6 +68,10 @@ def parse_args(argv=None):
                         help="TEST ONLY: all ranks render on cuda:0 and rendezvous over gloo -- runs the real step under the multi-rank "
                              "build / barrier / gather / report path on a one-GPU box; the line says that it is not a scaling measurement")
     parser.add_argument("--master-port", type=int, default=0)
+    parser.add_argument("--native", action="store_true",
+                        help="frames/s instead of rays/s: every rank optimises its shard of synthetic frames in the reference's native mode; "
+                             "every other argument goes to vsrd_amd.launcher.main (--gpus, --frames, --frames-in-flight, --num-steps, --views, "
+                             "... -- see python -m vsrd_amd.launcher -h)")
     return parser.parse_args(argv)
 
 
@@ -590,6 +594,9 @@ def extra_regimes():
 
 
 def main():
+    if "--native" in sys.argv[1:]:      # the frames/s entry point: same launch contract (spawns its ranks itself, or is a rank under torchrun)
+        from vsrd_amd import launcher
+        return launcher.main([a for a in sys.argv[1:] if a != "--native"])
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))
@@ -597,4 +604,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

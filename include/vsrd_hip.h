@@ -126,7 +126,8 @@ typedef struct vsrd_render_config {
                                              rays; the results agree to rounding (A/B switch)                              */
 
 #define VSRD_FLAG_STEP_SPLIT_RAY 512u       /* vsrd_render_silhouette_step: split every ray over the two waves of a workgroup, half of its
-                                             rounds each (num_samples in (16, 128]).  By default launches of at most 2048 rays that are
+                                             rounds each (num_samples in (32, 128]: 2 or 4 rounds of 64 pass-2 points; for fewer samples the flag has no
+                                             effect and the launch keeps one wave per ray).  By default launches of at most 2048 rays that are
                                              not dense launches of the shapes above -- the reference's 1000 importance-sampled rays
                                              per step -- do this by themselves (two waves on every SIMD instead of one: a small launch
                                              is latency); the flag forces it for any launch, VSRD_FLAG_STEP_WAVE_PER_RAY forbids it; the

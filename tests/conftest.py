@@ -50,7 +50,8 @@ _MARGINS = []
 
 def margin(test, what, observed, tolerance):
     """Record `observed` (a float) against `tolerance` under the label `test` / `what`; returns observed."""
-    _MARGINS.append((str(test), str(what), float(observed), float(tolerance)))
+    observed = float(observed)
+    _MARGINS.append((str(test), str(what), observed, float(tolerance)))
     return observed
 
 
@@ -63,6 +64,11 @@ def pytest_terminal_summary(terminalreporter):
         ratio = observed / tolerance if tolerance > 0 else float("inf")
         if key not in worst or ratio > worst[key][0]:
             worst[key] = (ratio, test, observed, tolerance)
-    terminalreporter.write_line(f"observed error margins ({len(_MARGINS)} records; worst case per test and quantity)")
+    terminalreporter.write_line(f"observed error margins ({len(_MARGINS)} records; worst case per test and quantity, then every record above half its tolerance)")
     for (name, what), (ratio, test, observed, tolerance) in sorted(worst.items()):
         terminalreporter.write_line(f"  {test[:70]:70s} {what[:26]:26s} {observed:9.2e} / {tolerance:8.1e} = {ratio:5.2f}")
+    shown = {(entry[1], what) for (_, what), entry in worst.items()}
+    for test, what, observed, tolerance in _MARGINS:
+        ratio = observed / tolerance if tolerance > 0 else float("inf")
+        if ratio >= 0.5 and (test, what) not in shown:
+            terminalreporter.write_line(f"  {test[:70]:70s} {what[:26]:26s} {observed:9.2e} / {tolerance:8.1e} = {ratio:5.2f}")

@@ -4,7 +4,9 @@ benchmark scene, their distribution, and for the worst rays the pass-2 distances
 sampler's own ill-conditioning, samplers.py:33: division by cdf differences + 1e-6).
 The worst rays are then re-rendered by the float64 CPU oracle AT THE KERNEL'S OWN DISTANCES: which of the two modes is off?
 (test infrastructure: imports oracle/)
-    python tests/culling_ab_debug.py [start|mid|end]"""
+    python tests/culling_ab_debug.py [start|mid|end] [quad|pair]
+The labels are the FUSED STEP's (vsrd_render_silhouette_step: what bench.py times); the distances come from the forward launch with
+the same keys (informative: the step does not return its samples).  VSRD_NO_FULL_SHAPE=1 keeps the step on the generic kernels."""
 import os
 import sys
 
@@ -22,8 +24,10 @@ from test_hip_scale import scene
 
 def main():
     schedule = sys.argv[1] if len(sys.argv) > 1 else "start"
+    shape = sys.argv[2] if len(sys.argv) > 2 else "quad"
     dev = torch.device("cuda:0")
-    N, S, H, W = 16, 64, 376, 1408
+    N, S = (16, 64) if shape == "quad" else (64, 128)
+    H, W = 376, 1408
     sched = bench.schedule_values(bench.SCHEDULES[schedule])
     det, cam, dirs = scene(dev, N, 1, H, W, seed=0)
     directions = dirs.reshape(-1, 3)
@@ -37,10 +41,15 @@ def main():
             union = bench.build_union(det, sched["temperature"])
             out[mode] = rendering.render_hierarchical(union, origins, directions, (0.0, 100.0), S, sched["std"], sched["cosine_ratio"], seed=5, stream_offset=11,
                                                       skip_exact_misses=True)
+            _, step_labels = rendering.silhouette_step(union, origins, directions, torch.zeros(origins.shape[0], N, device=dev), (0.0, 100.0), S, sched["std"],
+                                                       sched["cosine_ratio"], seed=5, stream_offset=11, return_labels=True)
+            forward_labels = out[mode]["labels"]
+            out[mode] = dict(out[mode], labels=step_labels)
+            print(f"  [{mode}] fused step labels vs forward launch labels: max diff {float((step_labels - forward_labels).abs().max()):.3e}")
     renderers.CULLING = True
     a, b = out["default"], out["no_culling"]
     diff = (a["labels"] - b["labels"]).abs().max(-1).values
-    print(f"schedule {schedule}: rays {diff.numel()}  max label diff {float(diff.max()):.3e}")
+    print(f"schedule {schedule} ({shape}, N = {N}, S = {S}): rays {diff.numel()}  max label diff {float(diff.max()):.3e}")
     for tol in (1e-7, 1e-6, 2e-6, 1e-5, 1e-4):
         print(f"  rays with diff > {tol:g}: {int((diff > tol).sum())}")
     da, db = a["distances"], b["distances"]

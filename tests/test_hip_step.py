@@ -5,7 +5,7 @@ import math
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import load_golden, margin
 from oracle import geometry as ogeometry, step as ostep
 
 pytestmark = pytest.mark.gpu
@@ -452,6 +452,29 @@ def test_frame_prologue_matches_the_torch_path(dev, seed, V, N):
     assert torch.equal(loop.schedule, alone["schedule"])
     assert torch.equal(rays, table.sample(config.num_rays, seed=config.seed + 1, stream_offset=loop.step_tensor, remap=loop.positive_pixels))
     assert torch.equal(rays, loop.sample_rays())
+
+
+def test_hypernetwork_gelu_error_bound(dev):
+    """csrc/hypernetwork.h evaluates the erf-form GELU (hyper_distance_field.py:30-55: nn.GELU()) through an Abramowitz-Stegun erf
+    (an approximation, and named as one now).  Bound of the absolute error of the value and of the derivative against
+    float64 erf over [-8, 8] -- far below the 2e-5 the generated MLP weights are compared at."""
+    import ctypes
+    import math
+    from vsrd_amd import _lib
+    lib = _lib.load()
+    fn = lib.vsrd_selftest_gelu
+    fn.restype, fn.argtypes = ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    x = torch.linspace(-8.0, 8.0, 65537, dtype=torch.float32)
+    out = torch.zeros(2 * x.numel(), device=dev)
+    _lib.check(fn(_lib.ptr(x.to(dev)), x.numel(), _lib.ptr(out), _lib.stream()))
+    out = out.cpu().double()
+    x64 = x.double()
+    cdf = 0.5 * (1.0 + torch.erf(x64 / math.sqrt(2.0)))
+    value_error = float((out[:x.numel()] - x64 * cdf).abs().max())
+    slope_error = float((out[x.numel():] - (cdf + x64 * torch.exp(-0.5 * x64 * x64) / math.sqrt(2.0 * math.pi))).abs().max())
+    margin("test_hypernetwork_gelu_error_bound", "gelu |error|", value_error, 1e-6)
+    margin("test_hypernetwork_gelu_error_bound", "gelu' |error|", slope_error, 1e-6)
+    assert value_error < 1e-6 and slope_error < 1e-6
 
 
 @pytest.mark.parametrize("N", [1, 5, 40, 64])      # 40 and 64: the LDS of the linears (activations of all instances) needs the opt-in above 64 KB

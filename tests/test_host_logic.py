@@ -142,6 +142,35 @@ def test_recogniser_flattens_main_py_closures():
     assert torch.equal(block.mlp_weights, mlp)
 
 
+def test_block_hand_over_is_scoped_to_one_wrapper_call():
+    """fields.BlockHandOver (the module-level "last block" cache of round 3 could return a stale block): the block of
+    main.py's pass 1 serves pass 2 only for the same closure object with every captured tensor at the same version; flatten()
+    itself caches nothing, so a parameter update between steps -- through an optimiser, `.data` or a raw pointer -- is always seen."""
+    from vsrd_amd import fields
+    g = torch.Generator().manual_seed(1)
+    loc = torch.randn(4, 3, generator=g).requires_grad_(True)
+    dim = (torch.rand(4, 3, generator=g) + 0.5).requires_grad_(True)
+    rot = torch.randn(4, 3, 3, generator=g).requires_grad_(True)
+    field = _main_py_style_field(loc, dim, rot, 0.5)
+    with torch.no_grad():
+        block = fields.flatten(field)
+    assert block.instances.requires_grad                          # built with autograd on even under no_grad: pass 2 differentiates it
+    hand = fields.BlockHandOver(field, block)
+    assert hand.take(field) is block
+    assert hand.take(_main_py_style_field(loc, dim, rot, 0.5)) is None        # another closure object (the next step's): no reuse
+    with torch.no_grad():
+        loc.add_(1.0)                                             # an in-place update bumps the version
+    assert hand.take(field) is None
+    # flatten() has no memory: the step after a `.data` update (no version bump) sees the new values
+    loc.data.add_(5.0)
+    assert torch.equal(fields.flatten(field).instances[:, 0:3], loc)
+    fields.BLOCK_HAND_OVER = False
+    try:
+        assert fields.BlockHandOver(field, block).take(field) is None
+    finally:
+        fields.BLOCK_HAND_OVER = True
+
+
 def test_recogniser_objects_labels_and_rejections():
     from vsrd_amd import fields, rendering
     loc, dim, rot = torch.zeros(3, 3), torch.ones(3, 3), torch.eye(3).repeat(3, 1, 1)

@@ -134,3 +134,36 @@ def test_bench_two_ranks_with_the_real_step_on_one_gpu():
     assert abs(line["value"] - 2 * rays / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]     # whole-job rays/s = both ranks' rays / slowest time
     assert line["ms_per_step"] >= max(line["per_rank_ms_per_step"]) - 0.05
     assert line["config"]["rays_per_gpu"] == rays and math.isfinite(line["config"]["final_loss"])
+
+
+@pytest.mark.gpu
+def test_native_frames_entry_point_two_ranks_on_one_gpu(tmp_path):
+    """The frames/s entry point: `python bench.py --native --gpus 2` = vsrd_amd.launcher.main -- two ranks spawned
+    by the launcher itself (both on cuda:0: --ranks-share-gpu, gloo), manifest broadcast, ordered start-up barrier, every rank
+    optimising ITS frames with FrameOptimizer(graph=True) two at a time, atomic checkpoints in the reference's layout, gather of the
+    per-rank report, ONE JSON line from rank 0; a second run over the same directory finds every frame done and optimises nothing
+    (main.py:134-136).  The first 8-GPU node runs the same command without --ranks-share-gpu."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    command = [sys.executable, bench, "--native", "--gpus", "2", "--ranks-share-gpu", "--frames", "5", "--views", "3", "--instances", "4", "--height", "128",
+               "--width", "128", "--rays", "256", "--samples", "32", "--num-steps", "40", "--warmup-steps", "12", "--out", str(tmp_path)]
+    out = subprocess.run(command, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["unit"] == "frames/s" and line["n_gpus"] == 2 and line["frames"] == 5 and sorted(line["per_rank_frames"]) == [2, 3]
+    assert "NOT a scaling measurement" in line["metric"]
+    assert abs(line["value"] - 5 / line["seconds"]) <= 1e-9 * line["value"] and line["seconds"] >= max(line["per_rank_seconds"]) - 1e-3
+    assert all(math.isfinite(x) for x in line["mean_final_loss"])
+    files = sorted(p for p in os.listdir(tmp_path))
+    assert files == [f"frame_{k:06d}" for k in range(5)]
+    payload = torch.load(os.path.join(tmp_path, "frame_000003", "step_39.pt"), weights_only=False)
+    assert payload["step"] == 39 and set(payload["models"]) == {"detector", "hyper_distance_field"} and "optimizer" in payload and "scheduler" in payload
+    again = subprocess.run(command, capture_output=True, text=True, timeout=900, env=env)
+    assert again.returncode == 0, again.stderr[-3000:]
+    second = json.loads([l for l in again.stdout.splitlines() if l.startswith("{")][0])
+    assert second["frames"] == 0 and second["frames_skipped_as_done"] == 5

@@ -186,6 +186,8 @@ SIGNATURES = {
                                                      ctypes.c_void_p]),
 }
 
+E_INVALID_ARGUMENT, E_UNSUPPORTED, E_LAUNCH, E_WORKSPACE = -1, -2, -3, -4      # include/vsrd_hip.h: VSRD_E_*
+
 _lock = threading.Lock()
 _lib = None
 

@@ -1,5 +1,6 @@
 // C ABI of libvsrd_hip (include/vsrd_hip.h): argument validation, launch geometry, dispatch on the
 // number of 64-sample rounds.  No torch types, no global state, no allocation.
+#include <cstdio>
 #include <cstdlib>
 #include "../../include/vsrd_hip.h"
 #include "aux_kernels.h"
@@ -73,11 +74,17 @@ void fit_to_residency(Kernel kernel, Geometry* g) {
 template <typename Kernel>
 int opt_in_lds(Kernel kernel, size_t bytes) {
     if (bytes <= kLdsDefault) return VSRD_OK;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               static_cast<int>(bytes)) == hipSuccess ? VSRD_OK : VSRD_E_LAUNCH;
+    const hipError_t error = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    if (error != hipSuccess && getenv("VSRD_DEBUG")) fprintf(stderr, "libvsrd_hip: LDS opt-in of %zu bytes failed: %s\n", bytes, hipGetErrorString(error));
+    return error == hipSuccess ? VSRD_OK : VSRD_E_LAUNCH;
 }
 
-int launch_status() { return hipGetLastError() == hipSuccess ? VSRD_OK : VSRD_E_LAUNCH; }
+int launch_status() {
+    const hipError_t error = hipGetLastError();
+    if (error == hipSuccess) return VSRD_OK;
+    if (getenv("VSRD_DEBUG")) fprintf(stderr, "libvsrd_hip: launch failed: %s\n", hipGetErrorString(error));
+    return VSRD_E_LAUNCH;
+}
 
 bool valid_field(const vsrd_field* f) {
     return f != nullptr && f->instances != nullptr && f->num_instances >= 1 && f->num_instances <= VSRD_MAX_INSTANCES &&
@@ -603,11 +610,20 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
         return launch_status();
     }
     const int lanes = quad ? kRowLanes : 32, rays_per_wave = kWave / lanes;
+    // a launch that fills its shape (S = lanes x rounds of the shape, more than half of its instance slots: BASELINE configs 2 and 5)
+    // runs the hot kernel instantiated for that S with the instance tables padded to the shape's count (quad_step.h: kFull)
+    const int shape_instances = quad ? kQuadMaxInstances : kPairMaxInstances;
+    const bool full = (quad || pair) && S == lanes * quad_rounds_s(S, lanes) && S >= 2 * lanes && 2 * N > shape_instances &&
+                      !getenv("VSRD_NO_FULL_SHAPE");
     Geometry g;
-    const size_t per_wave = (quad || pair) ? static_cast<size_t>(quad_lds_floats(S, N, lanes)) : static_cast<size_t>(wave_lds_floats(S, N)) + N + row;
+    const size_t per_wave = (quad || pair) ? static_cast<size_t>(quad_lds_floats(S, full ? shape_instances : N, lanes)) : static_cast<size_t>(wave_lds_floats(S, N)) + N + row;
     if (!plan((quad || pair) ? (config->num_rays + rays_per_wave - 1) / rays_per_wave : config->num_rays, per_wave, &g)) return VSRD_E_UNSUPPORTED;
-    // the partial buffer holds one gradient row per wave; the loss partials live in the tail of the same row budget
-    const int max_waves_for_loss = static_cast<int>(vsrd_workspace_bytes(N, 0) / sizeof(float) / (row + 1));
+    // the partial buffer holds one gradient row per wave; the loss partials live in the tail of the same row budget, and behind them
+    // (multi-ray mappings) one byte per group of rays: "the hot kernel could not serve this group" (quad_step.h)
+    const size_t num_groups = (quad || pair) ? (static_cast<size_t>(config->num_rays) + rays_per_wave - 1) / rays_per_wave : 0;
+    const size_t flag_bytes = (num_groups + 15) & ~static_cast<size_t>(15);
+    if (flag_bytes + static_cast<size_t>(g.threads / kWave) * (row + 1) * sizeof(float) > vsrd_workspace_bytes(N, 0)) return VSRD_E_WORKSPACE;
+    const int max_waves_for_loss = static_cast<int>((vsrd_workspace_bytes(N, 0) - flag_bytes) / sizeof(float) / (row + 1));
     if (g.blocks * (g.threads / kWave) > max_waves_for_loss) g.blocks = max_waves_for_loss / (g.threads / kWave);
     const FieldArgs f = field_args(field);
     RenderArgs c = render_args(config);
@@ -615,6 +631,7 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
     const int num_waves = g.blocks * (g.threads / kWave);
     float* partials = static_cast<float*>(workspace);
     float* loss_partials = partials + static_cast<size_t>(num_waves) * row;
+    unsigned char* redo_flags = reinterpret_cast<unsigned char*>(loss_partials + num_waves);
 #define VSRD_LAUNCH(K)                                                                                                          \
     do {                                                                                                                          \
         if (opt_in_lds(render_silhouette_kernel<K>, g.lds_bytes) != VSRD_OK) return VSRD_E_LAUNCH;                               \
@@ -622,26 +639,27 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
                            origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, labels, partials,        \
                            loss_partials);                                                                                       \
     } while (0)
-#define VSRD_LAUNCH_QUAD(K)                                                                                                     \
+// two kernels on one grid: the hot body (rotations about y, fixed soft-min shift), then everything it left over (quad_step.h)
+#define VSRD_LAUNCH_ROWS(KERNEL, K, FULL)                                                                                         \
     do {                                                                                                                          \
-        if (opt_in_lds(render_silhouette_quad_kernel<K>, g.lds_bytes) != VSRD_OK) return VSRD_E_LAUNCH;                          \
-        hipLaunchKernelGGL(render_silhouette_quad_kernel<K>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, \
+        if (opt_in_lds(KERNEL<K, true, FULL>, g.lds_bytes) != VSRD_OK || opt_in_lds(KERNEL<K, false, false>, g.lds_bytes) != VSRD_OK) return VSRD_E_LAUNCH; \
+        hipLaunchKernelGGL((KERNEL<K, true, FULL>), dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c,        \
                            origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, labels, partials,        \
-                           loss_partials);                                                                                       \
-    } while (0)
-#define VSRD_LAUNCH_PAIR(K)                                                                                                     \
-    do {                                                                                                                          \
-        if (opt_in_lds(render_silhouette_pair_kernel<K>, g.lds_bytes) != VSRD_OK) return VSRD_E_LAUNCH;                          \
-        hipLaunchKernelGGL(render_silhouette_pair_kernel<K>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, \
+                           loss_partials, redo_flags);                                                                           \
+        hipLaunchKernelGGL((KERNEL<K, false, false>), dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c,      \
                            origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, labels, partials,        \
-                           loss_partials);                                                                                       \
+                           loss_partials, redo_flags);                                                                           \
     } while (0)
+#define VSRD_LAUNCH_QUAD(K) VSRD_LAUNCH_ROWS(render_silhouette_quad_kernel, K, false)
+#define VSRD_LAUNCH_PAIR(K) VSRD_LAUNCH_ROWS(render_silhouette_pair_kernel, K, false)
     if (quad) {
         if (S <= 16) VSRD_LAUNCH_QUAD(1);
         else if (S <= 32) VSRD_LAUNCH_QUAD(2);
+        else if (full) VSRD_LAUNCH_ROWS(render_silhouette_quad_kernel, 4, true);
         else VSRD_LAUNCH_QUAD(4);
     } else if (pair) {
         if (S <= 64) VSRD_LAUNCH_PAIR(2);
+        else if (full) VSRD_LAUNCH_ROWS(render_silhouette_pair_kernel, 4, true);
         else VSRD_LAUNCH_PAIR(4);
     } else {
         switch (rounds) {
@@ -654,6 +672,7 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
 #undef VSRD_LAUNCH
 #undef VSRD_LAUNCH_QUAD
 #undef VSRD_LAUNCH_PAIR
+#undef VSRD_LAUNCH_ROWS
     if (launch_status() != VSRD_OK) return VSRD_E_LAUNCH;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(row + 1), dim3(256), 0, s, partials, num_waves, row, grad_instances, nullptr, loss_partials, 1, loss);
     return launch_status();
@@ -1285,6 +1304,14 @@ int32_t vsrd_debug_phase_cycles(unsigned long long* out16, int32_t reset) {
 int32_t vsrd_selftest_wave(const float* in64, float* out512, void* stream) {
     if (!in64 || !out512) return VSRD_E_INVALID_ARGUMENT;
     hipLaunchKernelGGL(wave_selftest_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), in64, out512);  // writes 576 floats
+    return launch_status();
+}
+
+// erf_gelu / erf_gelu_derivative of csrc/hypernetwork.h at n points: out[0..n) values, out[n..2n) derivatives
+// (tests/test_hip_step.py::test_hypernetwork_gelu_error_bound).
+int32_t vsrd_selftest_gelu(const float* x, int32_t n, float* out, void* stream) {
+    if (!x || !out || n < 1) return VSRD_E_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(gelu_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), x, n, out);
     return launch_status();
 }
 

@@ -26,18 +26,26 @@ constexpr float kHyperNormEps = 1.0e-5f;
 
 struct HyperAdam { float beta1, beta2, epsilon; };
 
-// Exact (erf) GELU and its derivative through residual.h's normal cdf / pdf pair (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 on erf:
-// one f32 ulp of a cdf near 1; ~17 instructions).  libm's erff is ~300 instructions with divergent branches, and the part between two
+// The erf-form GELU (torch's default, hyper_distance_field.py:30-55) and its derivative through residual.h's normal cdf / pdf pair: erf
+// by Abramowitz & Stegun 7.1.26, an APPROXIMATION with |error| <= 1.5e-7 on erf -- one f32 ulp of a cdf near 1, ~17 instructions, but a
+// large RELATIVE error of the cdf in the far negative tail (a < -5, where a * cdf(a) < 2e-6 anyway).  Absolute error of the GELU and of
+// its derivative over [-8, 8]: < 4e-7 (tests/test_hip_step.py::test_hypernetwork_gelu_error_bound); -DVSRD_LIBM_ERF builds libm's erff
+// for parity runs.  libm's erff is ~300 instructions with divergent branches, and the part between two
 // linears is ONE wave's work while fifteen wait: 4 erff per lane were 4.5 of the 8 us per layer (tools/hyper_timers.py).
 #ifdef VSRD_LIBM_ERF
-__device__ __forceinline__ float gelu_exact(float a) { return 0.5f * a * (1.0f + erff(a * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_exact_derivative(float a) {
+__device__ __forceinline__ float erf_gelu(float a) { return 0.5f * a * (1.0f + erff(a * 0.70710678118654752f)); }
+__device__ __forceinline__ float erf_gelu_derivative(float a) {
     return 0.5f * (1.0f + erff(a * 0.70710678118654752f)) + a * 0.39894228040143268f * expf(-0.5f * a * a);
 }
 #else
-__device__ __forceinline__ float gelu_exact(float a) { return a * gauss(a).cdf; }
-__device__ __forceinline__ float gelu_exact_derivative(float a) { const Gauss n = gauss(a); return n.cdf + a * n.pdf; }
+__device__ __forceinline__ float erf_gelu(float a) { return a * gauss(a).cdf; }
+__device__ __forceinline__ float erf_gelu_derivative(float a) { const Gauss n = gauss(a); return n.cdf + a * n.pdf; }
 #endif
+
+__global__ void gelu_selftest_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+    const int i = static_cast<int>(blockIdx.x) * 256 + static_cast<int>(threadIdx.x);
+    if (i < n) { out[i] = erf_gelu(x[i]); out[n + i] = erf_gelu_derivative(x[i]); }
+}
 
 // torch.optim.Adam's update of one tensor, the per-step scalars computed once per thread.  (The step counters are advanced by
 // hyper_finish_kernel, after every reader of the step.)
@@ -79,7 +87,7 @@ __device__ __forceinline__ void stage_hyper_input(const float* __restrict__ x, c
             for (int j = 0; j < 4; ++j) { out[j] -= mean; var += out[j] * out[j]; }
             const float inv_std = rsqrtf(wave_sum(var) * (1.0f / kHyperWidth) + kHyperNormEps);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) out[j] = gelu_exact(out[j] * inv_std * gamma[4 * lane + j] + beta[4 * lane + j]);
+            for (int j = 0; j < 4; ++j) out[j] = erf_gelu(out[j] * inv_std * gamma[4 * lane + j] + beta[4 * lane + j]);
         }
         *reinterpret_cast<float4*>(h + n * kHyperWidth + 4 * lane) = make_float4(out[0], out[1], out[2], out[3]);
     }
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(kHyperChainThreads) void hyper_hidden_forward_kerne
                 for (int j = 0; j < 4; ++j) { y[j] -= mean; var += y[j] * y[j]; }
                 const float inv_std = rsqrtf(wave_sum(var) * (1.0f / kHyperWidth) + kHyperNormEps);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) y[j] = gelu_exact(y[j] * inv_std * gam[j] + bet[j]);
+                for (int j = 0; j < 4; ++j) y[j] = erf_gelu(y[j] * inv_std * gam[j] + bet[j]);
                 *reinterpret_cast<float4*>(h + 4 * lane) = make_float4(y[0], y[1], y[2], y[3]);
                 VSRD_HYPER_AT(12, 0);
             }
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(kHyperNormThreads * kHyperNormSplit) void hyper_nor
     y -= mean;
     const float inv_std = rsqrtf(block_sum_256(y * y, scratch) * (1.0f / kHyperWidth) + kHyperNormEps);
     y *= inv_std;
-    const float a_bar = hb * gelu_exact_derivative(y * gam + bet);
+    const float a_bar = hb * erf_gelu_derivative(y * gam + bet);
     const float y_bar = a_bar * gam;
     const float m1 = block_sum_256(y_bar, scratch) * (1.0f / kHyperWidth);
     const float m2 = block_sum_256(y_bar * y, scratch) * (1.0f / kHyperWidth);
@@ -457,7 +465,7 @@ __global__ __launch_bounds__(kHyperChainThreads) void hyper_hidden_backward_kern
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             y[j] *= inv_std;
-            a_bar[j] = hb[j] * gelu_exact_derivative(y[j] * gamma[j] + beta[j]);
+            a_bar[j] = hb[j] * erf_gelu_derivative(y[j] * gamma[j] + beta[j]);
             y_bar[j] = a_bar[j] * gamma[j];
             s1 += y_bar[j]; s2 += y_bar[j] * y[j];
         }

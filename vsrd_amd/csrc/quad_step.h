@@ -319,18 +319,22 @@ __device__ __forceinline__ RayCull row_cull(const float* coef, const RowRay& r) 
 __device__ __forceinline__ void reload_fence() { asm volatile("" ::: "memory"); }
 
 // Culling coefficients of (lane's ray, instance col, col + 16, ...) (field.h: cull_ray_setup, per row) and the ray itself, into LDS.
+// `padded` >= N: the table is filled up to `padded` rows with instances that can never matter (a = 3e38: never the nearest, never
+// inside a reach) -- the pre-pass of a kernel instantiated for a compile-time instance count walks all of them (quad_round_mask masks
+// them out again where culling is switched off).
 template <int kL>
-__device__ __forceinline__ void quad_ray_setup(const float* __restrict__ instances, int N, const Ray& r, float* coef, float* rayp, const RowLanes& rl) {
+__device__ __forceinline__ void quad_ray_setup(const float* __restrict__ instances, int N, int padded, const Ray& r, float* coef, float* rayp, const RowLanes& rl) {
     float amax = 0.0f;
-    for (int i = rl.col; i < N; i += kL) {
-        const float* p = instances + i * kInstanceStride;
+    for (int i = rl.col; i < padded; i += kL) {
+        const bool real = i < N;
+        const float* p = instances + (real ? i : 0) * kInstanceStride;
         const float ex = r.ox - p[0], ey = r.oy - p[1], ez = r.oz - p[2];
         const float a = ex * ex + ey * ey + ez * ez;
-        coef[kCullCoefs * i + 0] = a;
-        coef[kCullCoefs * i + 1] = 2.0f * (ex * r.rx + ey * r.ry + ez * r.rz);
-        coef[kCullCoefs * i + 2] = fast_sqrt(p[12] * p[12] + p[13] * p[13] + p[14] * p[14]) * (1.0f / (1.0f - kCullSlack));
+        coef[kCullCoefs * i + 0] = real ? a : 3.0e38f;
+        coef[kCullCoefs * i + 1] = real ? 2.0f * (ex * r.rx + ey * r.ry + ez * r.rz) : 0.0f;
+        coef[kCullCoefs * i + 2] = real ? fast_sqrt(p[12] * p[12] + p[13] * p[13] + p[14] * p[14]) * (1.0f / (1.0f - kCullSlack)) : 0.0f;
         coef[kCullCoefs * i + 3] = 0.0f;                                        // the ray's label adjoint of instance i, set after pass 2
-        amax = fmaxf(amax, a);
+        amax = fmaxf(amax, real ? a : 0.0f);
     }
     const float reach = fast_sqrt(fmaxf(seg_max<kL>(amax), r.ox * r.ox + r.oy * r.oy + r.oz * r.oz));
     if (rl.col == 0) {
@@ -341,38 +345,65 @@ __device__ __forceinline__ void quad_ray_setup(const float* __restrict__ instanc
 }
 
 // The culling pre-pass of one round (field.h: cull_round_mask) in two steps, so that a round can leave between them.
+// -DVSRD_CULL_PARTIAL (round 4, NOT the default): the term of the squared centre distance that all instances share leaves the
+// per-instance work,  |x(t) - t_i|^2 = (a_i + b_i t) + (r.r) t^2 = e_i + c:  min_i e_i + c for the nearest centre and
+// e_i > reach_i^2 + (E - c)  for the test, one instruction less per (sample, instance) in either loop.  +1 % on config 2 -- but with it
+// the culling A/B of the two-rays-per-wave kernels (tests/test_hip_scale.py: pair-mid) shows rays whose labels are off by up to 6.7e-3
+// (nested form: 2.2e-4, the sampler's own conditioning), although a float32 emulation of both bound tests over every (group, round,
+// instance) of that view (tests/culling_formulations_debug.py) finds their masks equal but for 6 of 1.4e8 triples and neither ever
+// dropping an instance that matters, and the bounds of the nearest distance intact.  Not understood, so not used.
 // Step 1: the bounds of the nearest centre distance of every lane's point (RoundCull).
+__device__ __forceinline__ float centre_partial(const RayCull& rc, int i, float t) {       // e_i = a_i + b_i t
+#ifndef VSRD_CULL_PARTIAL                            // the nested form: d2_i = a_i + t (b_i + c t) itself
+    return fmaf(t, rc.c2 * t + rc.coef[kCullCoefs * i + 1], rc.coef[kCullCoefs * i + 0]);
+#else
+    return fmaf(t, rc.coef[kCullCoefs * i + 1], rc.coef[kCullCoefs * i + 0]);
+#endif
+}
 __device__ __forceinline__ RoundCull quad_round_bounds(const RayCull& rc, int num_instances, float t, float margin) {
-    const float ct = rc.c2 * t;
-    float nearest2 = 3.0e38f;
+    float nearest = 3.0e38f;
     int i = 0;
+#pragma unroll 4                                     // (sixteen instances in flight at most, also where the count is a compile-time 64)
     for (; i + 4 <= num_instances; i += 4) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) nearest2 = fminf(nearest2, centre_distance2(rc, i + j, t, ct));
+        for (int j = 0; j < 4; ++j) nearest = fminf(nearest, centre_partial(rc, i + j, t));
     }
-    for (; i < num_instances; ++i) nearest2 = fminf(nearest2, centre_distance2(rc, i, t, ct));
-    return cull_round(rc, t, nearest2, margin);
+    for (; i < num_instances; ++i) nearest = fminf(nearest, centre_partial(rc, i, t));
+#ifndef VSRD_CULL_PARTIAL
+    return cull_round(rc, t, nearest, margin);
+#else
+    return cull_round(rc, t, fmaf(rc.c2 * t, t, nearest), margin);
+#endif
 }
-// Step 2: bit i = instance i may matter on some lane (wave-uniform).
-__device__ __forceinline__ unsigned long long quad_round_mask(const RayCull& rc, const RoundCull& cull, int num_instances, float t) {
-    const float ct = rc.c2 * t;
+// Step 2: bit i = instance i may matter on some lane (wave-uniform).  (NaN-safe: an undecidable comparison keeps the instance.)
+__device__ __forceinline__ unsigned long long quad_round_mask(const RayCull& rc, const RoundCull& cull, int num_instances, float t,
+                                                              unsigned long long real = ~0ull) {
+#ifndef VSRD_CULL_PARTIAL
+    const float shift = cull.err;
+#else
+    const float shift = cull.err - rc.c2 * t * t;                                       // E - c
+#endif
     unsigned long long mask = 0ull;
     int i = 0;
+#pragma unroll 4
     for (; i + 4 <= num_instances; i += 4) {
-        float d2[4], radius[4];
+        float e[4], radius[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            d2[j] = centre_distance2(rc, i + j, t, ct);
+            e[j] = centre_partial(rc, i + j, t);
             radius[j] = rc.coef[kCullCoefs * (i + j) + 2];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float reach = cull.limit + radius[j];
-            mask |= (__ballot(!(d2[j] > fmaf(reach, reach, cull.err))) != 0ull) ? (1ull << (i + j)) : 0ull;
+            mask |= (__ballot(!(e[j] > fmaf(reach, reach, shift))) != 0ull) ? (1ull << (i + j)) : 0ull;
         }
     }
-    for (; i < num_instances; ++i) mask |= (cull_near(rc, cull, i, centre_distance2(rc, i, t, ct)) != 0ull) ? (1ull << i) : 0ull;
-    return mask;
+    for (; i < num_instances; ++i) {
+        const float reach = cull.limit + rc.coef[kCullCoefs * i + 2];
+        mask |= (__ballot(!(centre_partial(rc, i, t) > fmaf(reach, reach, shift))) != 0ull) ? (1ull << i) : 0ull;
+    }
+    return mask & real;                                                                 // (padding rows of the table: quad_ray_setup)
 }
 
 // Rounds that see nothing (wave-uniform, exact).  Every box distance of the round's points is >= floor = (nearest centre distance)
@@ -444,7 +475,7 @@ __device__ __forceinline__ QuadPoint quad_point(const float* dist, int num_point
 // the running minimum.
 template <int kL, int kRoundsS, bool kYaw, bool kRunning>
 __device__ __forceinline__ bool quad_pass_one(const float* __restrict__ instances, int N, const Shading& sh, const float* rayp, const float* coef,
-                                              const float* coarse, int S, float (&w)[kRoundsS], const RowLanes& rl) {
+                                              const float* coarse, int S, float (&w)[kRoundsS], const RowLanes& rl, unsigned long long real = ~0ull) {
     const int num_points = S - 1;
     float carry = 1.0f;
 #pragma unroll
@@ -456,7 +487,7 @@ __device__ __forceinline__ bool quad_pass_one(const float* __restrict__ instance
         const QuadPoint p = quad_point<kL>(coarse, num_points, k, rr.ray, true, rl);
         const RoundCull cull = quad_round_bounds(rc, N, p.mid, sh.cull);
         if (quad_round_is_empty(rc, cull, sh, p.delta)) continue;                // alpha = 0 exactly: the transmittance passes unchanged
-        unsigned long long evaluated = quad_round_mask(rc, cull, N, p.mid);
+        unsigned long long evaluated = quad_round_mask(rc, cull, N, p.mid, real);
         const float floor = cull.nearest_lo - sh.reach;
         if (!kRunning && wave_any(!((cull.nearest_hi + 1.0f - floor) * sh.inv_t <= kUnionFloorSpan))) return false;
         const UnionSums sums = quad_union_loop<false, false, kRunning, kYaw>(instances, evaluated, sh, cull, floor, p.x, p.y, p.z, nullptr, rl.lane);
@@ -494,7 +525,7 @@ template <int kL, int kRounds, bool kYaw, bool kRunning>
 __device__ __forceinline__ bool quad_forward_sweep(QuadAdjoint<kRounds>& st, const float* __restrict__ instances, int N, const Shading& sh,
                                                    const float* rayp, const float* coef, const float* merged, int num_points, bool live,
                                                    float* dcache, float* trans, float (&label)[kL == kRowLanes ? 1 : 2], unsigned& active, int& cached_round,
-                                                   const RowLanes& rl) {
+                                                   const RowLanes& rl, unsigned long long real = ~0ull) {
     constexpr int kSlots = kL == kRowLanes ? 1 : 2;                            // lane (ray, c) owns labels c, kL + c
     float carry = 1.0f;
 #pragma unroll
@@ -515,7 +546,7 @@ __device__ __forceinline__ bool quad_forward_sweep(QuadAdjoint<kRounds>& st, con
             const QuadPoint p = quad_point<kL>(merged, num_points, q, rr.ray, live, rl);
             const RoundCull cull = quad_round_bounds(rc, N, p.mid, sh.cull);
             if (quad_round_is_empty(rc, cull, sh, p.delta)) continue;            // alpha = 0 exactly: no weight, no label, no adjoint
-            st.near[q] = quad_round_mask(rc, cull, N, p.mid);
+            st.near[q] = quad_round_mask(rc, cull, N, p.mid, real);
             const float floor = cull.nearest_lo - sh.reach;
             if (!kRunning && wave_any(!((cull.nearest_hi + 1.0f - floor) * sh.inv_t <= kUnionFloorSpan))) return false;
             const UnionSums sums = quad_union_loop<true, (kL > kRowLanes), kRunning, kYaw>(instances, st.near[q], sh, cull, floor, p.x, p.y, p.z, dcache, rl.lane);
@@ -715,7 +746,7 @@ __device__ __forceinline__ void quad_phase_b(const QuadAdjoint<kRounds>& st, con
 // LDS staging -- when the fixed shift cannot serve some round of the group: the caller then runs the group again with kRunning.
 // The three instantiations share no state, so none of it crosses a control-flow merge.
 template <int kL, int kRoundsS, bool kYaw, bool kRunning>
-__device__ __forceinline__ bool quad_step_body(const float* __restrict__ instances, int N, const RenderArgs& c, const Shading& sh, int first_ray,
+__device__ __forceinline__ bool quad_step_body(const float* __restrict__ instances, int N, int NP, const RenderArgs& c, const Shading& sh, int first_ray,
                                                const float* __restrict__ origins, const float* __restrict__ directions,
                                                const float* __restrict__ u_coarse, const float* __restrict__ u_fine, bool sorted_input,
                                                const float* __restrict__ targets, const float* __restrict__ instance_weights, float loss_scale,
@@ -731,20 +762,21 @@ __device__ __forceinline__ bool quad_step_body(const float* __restrict__ instanc
     const int ray = alive ? my_ray : (c.num_rays - 1);                    // rows beyond the launch repeat its last ray and contribute nothing
     const long long src = source_row(c, ray);
     float* rowbase = stage + rl.row * quad_row_floats(S, kL);
-    float* coef_own = coefs + rl.row * quad_coef_floats(N);
+    float* coef_own = coefs + rl.row * quad_coef_floats(NP);
+    const unsigned long long real = NP > N ? ((1ull << N) - 1ull) : ~0ull;            // (NP > N only in instantiations with NP <= 64 and N < NP)
     {
         const long long origin_row = (c.ray_indices && c.rays_per_origin > 0) ? src / c.rays_per_origin : src;
         const float* o = origins + origin_row * c.origin_stride;
         const float* d = directions + src * 3;
         Ray r;
         r.ox = o[0]; r.oy = o[1]; r.oz = o[2]; r.rx = d[0]; r.ry = d[1]; r.rz = d[2];
-        quad_ray_setup<kL>(instances, N, r, coef_own, rays + rl.row * 8, rl);
+        quad_ray_setup<kL>(instances, N, NP, r, coef_own, rays + rl.row * 8, rl);
     }
     quad_stage_samples<kL, kRoundsS>(rowbase, c, S, ray, u_coarse, u_fine, sorted_input, rl);
     VSRD_PHASE(0);
     // ---- pass 1 ----------------------------------------------------------------------------------------------------------------
     float w1[kRoundsS];
-    if (!quad_pass_one<kL, kRoundsS, kYaw, kRunning>(instances, N, sh, rays + rl.row * 8, coef_own, rowbase, S, w1, rl)) return false;
+    if (!quad_pass_one<kL, kRoundsS, kYaw, kRunning>(instances, NP, sh, rays + rl.row * 8, coef_own, rowbase, S, w1, rl, real)) return false;
     VSRD_PHASE(1);
     float coarse_total = 0.0f;
 #pragma unroll
@@ -766,8 +798,8 @@ __device__ __forceinline__ bool quad_step_body(const float* __restrict__ instanc
     if (live_lanes != 0ull) {
         quad_importance_merge<kL, kRoundsS>(rowbase, S, w1, rl);
         VSRD_PHASE(2);
-        if (!quad_forward_sweep<kL, kRounds, kYaw, kRunning>(st, instances, N, sh, rayp, coefs + data_row * quad_coef_floats(N), merged, num_points, live, dcache,
-                                                         trans_mid, label, active, cached_round, rl)) return false;
+        if (!quad_forward_sweep<kL, kRounds, kYaw, kRunning>(st, instances, NP, sh, rayp, coefs + data_row * quad_coef_floats(NP), merged, num_points, live, dcache,
+                                                         trans_mid, label, active, cached_round, rl, real)) return false;
         VSRD_PHASE(3);
     }
     // ---- loss and label adjoints -------------------------------------------------------------------------------------------------
@@ -810,30 +842,52 @@ __device__ __forceinline__ bool quad_step_body(const float* __restrict__ instanc
 #endif
 // kL = lanes per ray: 16 (four rays per wave; N <= 16, S <= 64: BASELINE config 2) or 32 (two rays per wave; N <= 64, S <= 128: BASELINE
 // config 5, and config-2-shaped frames with more than 16 instances).
-template <int kL, int kRoundsS>
+//
+// One launch of the step = TWO kernels on the same grid (round 4; one kernel with the three bodies inlined held the registers of all
+// of them: 114 spilled VGPRs and 2.8 GB of scratch write-through per launch at config 2):
+//   kHot   rotations about y + the soft-min shift known before the instance loop -- what BoxParameters3D produces at ordinary
+//          temperatures.  Runs every group when the field allows it (field_bounds: orthonormal, all rotations about y, reach / T small)
+//          and records per group whether the fixed shift served it (redo_flags[group]; 1 = some round needs the running minimum --
+//          samples extrapolated to 1e6 m next to ordinary ones); does nothing otherwise.
+//   !kHot  everything else: all groups when the hot kernel did not run (general rotations with the fixed shift, running minimum as
+//          its own fallback; or the running minimum throughout), else only the groups the hot kernel flagged.  The same wave owns the
+//          same groups in both kernels (same grid, same stride), so its partial row is written by the hot kernel and added to here:
+//          one fixed order of summation, bit-identical repeats.
+//
+// kFull (hot kernel only): the launch fills its shape -- S = kL * kRoundsS samples per ray (64 / 128: BASELINE configs 2 and 5) and
+// more than half of the kL-lane shape's instance slots (N in 9..16 / 33..64) -- so S is a compile-time constant and the instance
+// tables are padded to the shape's full count: every LDS offset, every loop bound of the culling pre-pass and the searches, the
+// stratification and the point counts fold into the code.  Measured on config 2: 190 -> 222 Mrays/s (S alone: 210) -- the kernel is
+// bound by VALU issue (profiles/r04), and a fifth of what it issued was address and bound arithmetic on two launch constants.
+template <int kL, int kRoundsS, bool kHot, bool kFull>
 __device__ __forceinline__ void silhouette_rows_kernel_body(
     FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
     const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
     const float* __restrict__ targets, const float* __restrict__ instance_weights, float loss_scale,
-    float* __restrict__ labels_out, float* __restrict__ partials, float* __restrict__ loss_partials) {
+    float* __restrict__ labels_out, float* __restrict__ partials, float* __restrict__ loss_partials, unsigned char* __restrict__ redo_flags) {
     constexpr int kRays = kWave / kL;
     constexpr int kG = kL == kRowLanes ? 4 : 16;
     apply_device_schedule(f, c);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = wave_in_block();
     const int lane0 = lane_id();
+    static_assert(kHot || !kFull, "only the hot kernel is instantiated for a full shape");
+    if (kFull) c.num_samples = kL * kRoundsS;                                   // (the host launches kFull for exactly this S)
     const int S = c.num_samples;
     const int N = f.num_instances;
-    float* stage = lds + wave * quad_lds_floats(S, N, kL);
+    const int NP = kFull ? (kL == kRowLanes ? kQuadMaxInstances : kPairMaxInstances) : N;      // rows of the instance tables
+    float* stage = lds + wave * quad_lds_floats(S, NP, kL);
     float* dcache = stage + kRays * quad_row_floats(S, kL);
-    float* coefs = dcache + quad_cache_rows(S, N, kL) * kWave;
-    float* rays = coefs + kRays * quad_coef_floats(N);
+    float* coefs = dcache + quad_cache_rows(S, NP, kL) * kWave;
+    float* rays = coefs + kRays * quad_coef_floats(NP);
     const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
     Shading sh = c.sh;
     const FieldBounds bounds = field_bounds(instances, N, f.inv_t, false, c.flags);
     sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
     sh.mlp_bits = 0u;
     sh.mlp_lds = nullptr;
+    const bool hot_runs = sh.reach >= 0.0f && sh.yaw;                          // (wave-uniform, the same in both kernels of the launch)
+    if (kHot && !hot_runs) return;
     float loss_acc = 0.0f;
     float G[kG];
 #pragma unroll
@@ -841,50 +895,53 @@ __device__ __forceinline__ void silhouette_rows_kernel_body(
     const int num_waves = static_cast<int>(gridDim.x) * waves_per_block();
     const int wave_global = static_cast<int>(blockIdx.x) * waves_per_block() + wave;
     const int num_groups = (c.num_rays + kRays - 1) / kRays;
+    bool touched = false;                                                       // !kHot behind the hot kernel: did this wave redo a group?
     VSRD_PHASE_CLOCK();
     for (int group = wave_global; group < num_groups; group += num_waves) {
         const int first_ray = group * kRays;
+        if (!kHot && hot_runs) {
+            if (__builtin_amdgcn_readfirstlane(static_cast<int>(redo_flags[group])) == 0) continue;
+            touched = true;
+        }
         const RowLanes rl = row_lanes<kL>(opaque_lane_id());
         wave_lds_sync();
-        bool done = false;
-#ifdef VSRD_QUAD_EXPERIMENT_YAW_ONLY       // register-pressure experiments: one body only
-        done = quad_step_body<kL, kRoundsS, true, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
-                                                         instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
-        continue;
-#endif
-        if (sh.reach >= 0.0f) {
-            done = sh.yaw ? quad_step_body<kL, kRoundsS, true, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
-                                                                      instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG)
-                          : quad_step_body<kL, kRoundsS, false, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
-                                                                       instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
-            if (!done) wave_lds_sync();
+        if (kHot) {
+            const bool done = quad_step_body<kL, kRoundsS, true, false>(instances, N, NP, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
+                                                                        instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
+            if (lane0 == 0) redo_flags[group] = done ? 0 : 1;
+        } else {
+            bool done = false;
+            if (sh.reach >= 0.0f && !hot_runs) {
+                done = quad_step_body<kL, kRoundsS, false, false>(instances, N, NP, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
+                                                                  instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
+                if (!done) wave_lds_sync();
+            }
+            if (!done) quad_step_body<kL, kRoundsS, false, true>(instances, N, NP, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
+                                                                 instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
         }
-        if (!done) quad_step_body<kL, kRoundsS, false, true>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input, targets,
-                                                             instance_weights, loss_scale, labels_out, stage, dcache, coefs, rays, G, loss_acc, rl VSRD_QUAD_CLOCK_ARG);
     }
     VSRD_PHASE(7);
     VSRD_PHASE_FLUSH(lane0);
+    if (!kHot && hot_runs && !touched) return;                                  // (the usual case: nothing was left over)
     // the wave's row of the partial-gradient table (summed over the waves by reduce_partials_kernel): lane (16-lane row r, c) of register s
     // holds parameter c of instance 4 s + r
+    const bool add = !kHot && hot_runs;
     float* out = partials + static_cast<size_t>(wave_global) * (N * kGradStride);
 #pragma unroll
     for (int s = 0; s < kG; ++s)
-        if (s * kWave + lane0 < N * kGradStride) out[s * kWave + lane0] = G[s];
+        if (s * kWave + lane0 < N * kGradStride) out[s * kWave + lane0] = add ? (out[s * kWave + lane0] + G[s]) : G[s];
     const float loss_total = wave_sum(loss_acc);
-    if (lane0 == 0) loss_partials[wave_global] = loss_total * loss_scale;
+    if (lane0 == 0) loss_partials[wave_global] = add ? (loss_partials[wave_global] + loss_total * loss_scale) : (loss_total * loss_scale);
 }
 
-#ifndef VSRD_QUAD_WAVES_PER_EU
-#define VSRD_QUAD_WAVES_PER_EU 4
-#endif
-template <int kRoundsS>
+template <int kRoundsS, bool kHot, bool kFull>
 __global__ __launch_bounds__(kBlockThreads, VSRD_QUAD_WAVES_PER_EU) void render_silhouette_quad_kernel(
     FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
     const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
     const float* __restrict__ targets, const float* __restrict__ instance_weights, float loss_scale,
-    float* __restrict__ labels_out, float* __restrict__ partials, float* __restrict__ loss_partials) {
-    silhouette_rows_kernel_body<kRowLanes, kRoundsS>(f, instances, c, origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, labels_out,
-                                                     partials, loss_partials);
+    float* __restrict__ labels_out, float* __restrict__ partials, float* __restrict__ loss_partials, unsigned char* __restrict__ redo_flags) {
+    silhouette_rows_kernel_body<kRowLanes, kRoundsS, kHot, kFull>(f, instances, c, origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, labels_out,
+                                                           partials, loss_partials, redo_flags);
 }
 
 // ---- the two-pass forward alone (vsrd_render_hierarchical_forward: scripts/main.py:511-523 as one launch) in the same mappings -----------
@@ -911,7 +968,7 @@ __device__ __forceinline__ bool rows_forward_body(const float* __restrict__ inst
         const float* d = directions + static_cast<size_t>(ray) * 3;
         Ray r;
         r.ox = o[0]; r.oy = o[1]; r.oz = o[2]; r.rx = d[0]; r.ry = d[1]; r.rz = d[2];
-        quad_ray_setup<kL>(instances, N, r, coef_own, rays + rl.row * 8, rl);
+        quad_ray_setup<kL>(instances, N, N, r, coef_own, rays + rl.row * 8, rl);
     }
     quad_stage_samples<kL, kRoundsS>(rowbase, c, S, ray, u_coarse, u_fine, sorted_input, rl);
     float w1[kRoundsS];
@@ -1024,7 +1081,7 @@ __device__ __forceinline__ bool rows_backward_body(const float* __restrict__ ins
         const float* d = directions + static_cast<size_t>(ray) * 3;
         Ray r;
         r.ox = o[0]; r.oy = o[1]; r.oz = o[2]; r.rx = d[0]; r.ry = d[1]; r.rz = d[2];
-        quad_ray_setup<kL>(instances, N, r, coef_own, rays + rl.row * 8, rl);       // (clears the label adjoints, syncs)
+        quad_ray_setup<kL>(instances, N, N, r, coef_own, rays + rl.row * 8, rl);       // (clears the label adjoints, syncs)
     }
     const float* src = distances + static_cast<size_t>(ray) * num_distances;
     float* own_merged = rowbase + quad_merged_offset(half, kL);
@@ -1133,14 +1190,14 @@ __global__ __launch_bounds__(kBlockThreads, 3) void render_backward_pair_kernel(
 #ifndef VSRD_PAIR_WAVES_PER_EU
 #define VSRD_PAIR_WAVES_PER_EU 3
 #endif
-template <int kRoundsS>
+template <int kRoundsS, bool kHot, bool kFull>
 __global__ __launch_bounds__(kBlockThreads, VSRD_PAIR_WAVES_PER_EU) void render_silhouette_pair_kernel(
     FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
     const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
     const float* __restrict__ targets, const float* __restrict__ instance_weights, float loss_scale,
-    float* __restrict__ labels_out, float* __restrict__ partials, float* __restrict__ loss_partials) {
-    silhouette_rows_kernel_body<32, kRoundsS>(f, instances, c, origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, labels_out,
-                                              partials, loss_partials);
+    float* __restrict__ labels_out, float* __restrict__ partials, float* __restrict__ loss_partials, unsigned char* __restrict__ redo_flags) {
+    silhouette_rows_kernel_body<32, kRoundsS, kHot, kFull>(f, instances, c, origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, labels_out,
+                                                    partials, loss_partials, redo_flags);
 }
 
 }  // namespace vsrd

@@ -94,7 +94,7 @@ __device__ __forceinline__ UnionSums union_loop(const float* __restrict__ instan
         if (near == 0ull) { evaluated &= ~(1ull << i); continue; }
         best = fminf(best, e.d);
         box_gradient<kYaw>(e, in);
-        if (kResidual) add_residual<kYaw>(e, in, residual_forward(mlp + i * kMlpWeights, e.px, e.py, e.pz, rows_with(near & live) | sh.mlp_bits, sh.mlp_lds));
+        if (kResidual) add_residual<kYaw>(e, in, residual_forward_packed(mlp + i * kMlpWeights, e.px, e.py, e.pz, near & live, sh.mlp_bits, sh.mlp_lds));
         if (kCacheDistances) dcache[i * kWave + lane] = e.d;
         union_accumulate<kRunning>(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, sh.inv_t);
     }

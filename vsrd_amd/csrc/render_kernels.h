@@ -302,10 +302,9 @@ struct RayAdjoint {
     SampleAdjoint sa[kRounds];
     Opacity op[kRounds];
     float gx[kRounds], gy[kRounds], gz[kRounds], trans[kRounds], delta[kRounds];
-    // culling decisions of the forward sweep (wave-uniform, bit i = instance i): evaluated in the round at all / in 16-lane row q
-    // (residual fields).  The later phases read these instead of repeating the bound test per instance and round.
+    // culling decisions of the forward sweep (wave-uniform, bit i = instance i): evaluated in the round at all.  The later phases read
+    // these instead of repeating the bound test per instance and round.
     unsigned long long near_any[kRounds];
-    unsigned long long near_rows[kRounds][4];
     bool last_running;       // the last round's soft-min used the running minimum: its cache rows hold distances, not soft-min terms
 };
 
@@ -326,9 +325,7 @@ __device__ __forceinline__ UnionSums sweep_union_loop(RayAdjoint<kRounds>& st, i
         best = fminf(best, e.d);
         box_gradient<kYaw>(e, in);
         if (kResidual) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) st.near_rows[k][q] |= (((near & live) >> (16 * q)) & 0xFFFFull) ? (1ull << i) : 0ull;
-            const Residual res = residual_forward(mlp + i * kMlpWeights, e.px, e.py, e.pz, rows_with(near & live) | sh.mlp_bits, sh.mlp_lds);
+            const Residual res = residual_forward_packed(mlp + i * kMlpWeights, e.px, e.py, e.pz, near & live, sh.mlp_bits, sh.mlp_lds);
             add_residual<kYaw>(e, in, res);
             if (rcache) rcache[(k * N + i) * kWave + lane] = make_float4(res.value, res.gx, res.gy, res.gz);
         }
@@ -362,7 +359,6 @@ __device__ __forceinline__ float adjoint_forward_sweep(RayAdjoint<kRounds>& st, 
         // culling (field.h): which instances this round has to evaluate
         RoundCull cull;
         st.near_any[k] = cull_round_mask<kCacheD>(rc, N, mid, sh.cull, dcache, lane, &cull);
-        if (kResidual) st.near_rows[k][0] = st.near_rows[k][1] = st.near_rows[k][2] = st.near_rows[k][3] = 0ull;
         const unsigned long long live = __ballot(valid);                    // padding lanes repeat the last point: their tiles skip the MLP
         UnionSums sums;
         const float floor = cull.nearest_lo - sh.reach;
@@ -500,8 +496,8 @@ __device__ __forceinline__ void adjoint_label_mix(RayAdjoint<kRounds>& st, const
     }
 }
 
-// Where the per-instance phase leaves the seeds (kSeedFloats x 64 floats per (round, instance)) and the 4-bit tile masks of the MLP
-// adjoint.  Two layouts: wave-private batches (render_backward_kernel / render_residual_step_kernel: [round][instance], 32-bit masks
+// Where the per-instance phase leaves the seeds (kSeedFloats x 64 floats per (round, instance), the points that matter first) and
+// their COUNTS (0 .. 64 leading columns; "masks" for historical reasons: rounds 2 and 3 stored 4-bit tile masks) for the MLP adjoint.  Two layouts: wave-private batches (render_backward_kernel / render_residual_step_kernel: [round][instance], 32-bit masks
 // in LDS) and the launch-wide dense table of the split residual step ([instance][ray of chunk][round], byte masks in global memory).
 struct SeedSink {
     float* seeds;                    // base of this ray's seeds
@@ -521,33 +517,25 @@ __device__ __forceinline__ SeedSink batch_seed_sink(float* ray_seeds, unsigned* 
 template <int kRounds, bool kResidual, bool kYaw>
 __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, const float* __restrict__ instances, const float* __restrict__ mlp,
                                                 int N, float inv_t, int num_points, const float* lam, float* G, int lane,
-                                                const float4* rcache, const SeedSink& sink, int first_point = 0) {
+                                                const float4* rcache, const SeedSink& sink, float cull_margin = 3.0e38f, int first_point = 0) {
     unsigned long long todo = 0ull;                                           // instances evaluated in some round of this ray
 #pragma unroll
     for (int k = 0; k < kRounds; ++k) todo |= (first_point + k * kWave < num_points) ? st.near_any[k] : 0ull;
     for (; todo != 0ull; todo &= todo - 1ull) {
         const int i = __builtin_ctzll(todo);
         bool active[kRounds];
-        unsigned tiles[kRounds];
+        int counts[kRounds];                                                  // residual fields: leading seed columns that matter, per round
         bool any_active = false;
 #pragma unroll
         for (int k = 0; k < kRounds; ++k) {                                   // the forward sweep's culling decisions (scalar bit tests)
-            tiles[k] = static_cast<unsigned>((st.near_any[k] >> i) & 1ull);
-            if (kResidual) {
-                tiles[k] = 0u;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) tiles[k] |= static_cast<unsigned>((st.near_rows[k][q] >> i) & 1ull) << q;
-            }
-            active[k] = (first_point + k * kWave < num_points) && tiles[k] != 0u;
+            active[k] = (first_point + k * kWave < num_points) && ((st.near_any[k] >> i) & 1ull) != 0ull;
             any_active = any_active || active[k];
+            counts[k] = 0;
         }
-        if (kResidual && lane < kRounds) {                                    // which tiles of which rounds the MLP adjoint has to visit
-            unsigned mine = 0u;
-#pragma unroll
-            for (int k = 0; k < kRounds; ++k) mine = (lane == k && active[k]) ? tiles[k] : mine;
+        if (kResidual && !any_active && lane < kRounds) {                     // (an instance no round of this ray evaluated: nothing for the MLP adjoint)
             const long long at = lane * sink.mask_round_stride + i * sink.mask_instance_stride;
-            if (sink.masks32) sink.masks32[at] = mine;
-            else sink.masks8[at] = static_cast<unsigned char>(mine);
+            if (sink.masks32) sink.masks32[at] = 0u;
+            else sink.masks8[at] = 0;
         }
         if (!any_active) continue;                                            // negligible for this ray (field.h culling)
         const Instance in = load_instance_as<!kResidual>(instances, i);
@@ -558,7 +546,15 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
         for (int k = 0; k < kRounds; ++k) {
             if (!active[k]) continue;
             BoxEval e = eval_box<kYaw>(in, st.sa[k].x, st.sa[k].y, st.sa[k].z);
-            if (kResidual) {        // the residual jet of this (round, instance) was left by the forward sweep
+            unsigned long long need = ~0ull;
+            if (kResidual) {
+                // The lanes whose points the MLP adjoint must see: those on which the instance is not negligible -- box distance within the
+                // culling margin of the union value u >= min_j d_j, a superset of the exact criterion of the forward sweep (field.h) that
+                // needs no state of it; lanes without a point of their own (padding) never.  The rest (soft-min weight < exp(-18)) is
+                // what the forward sweep's tile masks dropped at tile granularity in rounds 2 and 3.
+                const bool own = first_point + k * kWave + lane < num_points;
+                need = __ballot(own && !(e.d - (st.sa[k].m + st.sa[k].us) > cull_margin));
+                // the residual jet of this (round, instance) was left by the forward sweep
                 const float4 res = rcache[(k * N + i) * kWave + lane];
                 add_residual<kYaw>(e, in, Residual{res.x, res.y, res.z, res.w});
             }
@@ -588,7 +584,8 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
             const float pbx = sx * qbx, pby = sy * qby, pbz = sz * qbz;
             ad0 -= qbx; ad1 -= qby; ad2 -= qbz;
             if (kResidual) {        // seeds of the residual adjoint (main.py:451-458): value adjoint d_bar, local-gradient adjoint gl_bar;
-                float* dst = sink.seeds + k * sink.round_stride + i * sink.instance_stride + lane;        // left for the MLP adjoint
+                // left for the MLP adjoint with the points that matter gathered into the leading columns (residual.h: packed_column)
+                float* dst = sink.seeds + k * sink.round_stride + i * sink.instance_stride + packed_column(need, lane, counts[k]);
                 dst[0 * kWave] = e.px; dst[1 * kWave] = e.py; dst[2 * kWave] = e.pz; dst[3 * kWave] = d_bar;
                 dst[4 * kWave] = glbx; dst[5 * kWave] = glby; dst[6 * kWave] = glbz;
                 dst[7 * kWave] = e.relx; dst[8 * kWave] = e.rely; dst[9 * kWave] = e.relz;
@@ -603,6 +600,14 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
                 at1 -= in.r10 * pbx + in.r11 * pby + in.r12 * pbz;
                 at2 -= in.r20 * pbx + in.r21 * pby + in.r22 * pbz;
             }
+        }
+        if (kResidual && lane < kRounds) {                                    // how many leading seed columns of which rounds the MLP adjoint has to visit
+            int mine_count = 0;
+#pragma unroll
+            for (int k = 0; k < kRounds; ++k) mine_count = (lane == k) ? counts[k] : mine_count;
+            const long long at = lane * sink.mask_round_stride + i * sink.mask_instance_stride;
+            if (sink.masks32) sink.masks32[at] = static_cast<unsigned>(mine_count);
+            else sink.masks8[at] = static_cast<unsigned char>(mine_count);
         }
         // one reduce-scatter butterfly: lane j (< 16) receives parameter j of instance i and keeps it in its LDS slot
         const float packed[16] = {at0, at1, at2, r00, r01, r02, r10, r11, r12, r20, r21, r22, ad0, ad1, ad2, 0.0f};
@@ -631,8 +636,9 @@ __device__ __forceinline__ void adjoint_phase_mlp(const float* __restrict__ inst
         float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
 #pragma unroll 1
         for (int slot = 0; slot < kBatch * kRounds; ++slot) {           // slot = ray-of-batch * kRounds + round
-            const unsigned rows = __builtin_amdgcn_readfirstlane(masks[slot * N + i]);
-            if (rows == 0u) continue;
+            const unsigned count = __builtin_amdgcn_readfirstlane(masks[slot * N + i]);
+            if (count == 0u) continue;
+            const unsigned rows = tiles_of_count(static_cast<int>(count));
             const float* src = seeds + static_cast<size_t>(slot * N + i) * (kSeedFloats * kWave) + lane;
             const float relx = src[7 * kWave], rely = src[8 * kWave], relz = src[9 * kWave];
             const ResidualAdjoint ra = residual_backward(mlp + i * kMlpWeights, src[0 * kWave], src[1 * kWave], src[2 * kWave], src[3 * kWave],
@@ -717,8 +723,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
             const float* gg_row = grad_gradients ? grad_gradients + static_cast<size_t>(ray) * num_points * 3 : nullptr;
             if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, gw_row, gg_row, lane)) continue;      // exact zero adjoint
             const SeedSink sink = batch_seed_sink(ray_seeds, ray_masks, N);
-            if (sh.yaw) adjoint_phase_b<kRounds, kResidual, true>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink);
-            else adjoint_phase_b<kRounds, kResidual, false>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink);
+            if (sh.yaw) adjoint_phase_b<kRounds, kResidual, true>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink, sh.cull);
+            else adjoint_phase_b<kRounds, kResidual, false>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink, sh.cull);
         }
         if (kResidual) {
             wave_lds_sync();                                                 // masks: written by lanes < kRounds, read by all
@@ -920,8 +926,8 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(V
             if (!adjoint_reverse_sweep<kRounds>(st, sh, r, num_points, nullptr, nullptr, lane, eikonal_scale)) continue;
             VSRD_PHASE(4);
             const SeedSink sink = batch_seed_sink(ray_seeds, ray_masks, N);
-            if (sh.yaw) adjoint_phase_b<kRounds, true, true>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink);
-            else adjoint_phase_b<kRounds, true, false>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink);
+            if (sh.yaw) adjoint_phase_b<kRounds, true, true>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink, sh.cull);
+            else adjoint_phase_b<kRounds, true, false>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink, sh.cull);
             VSRD_PHASE(5);
         }
         wave_lds_sync();                                                     // masks: written by lanes < kRounds, read by all
@@ -1024,8 +1030,8 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(k
         const long long slot0 = static_cast<long long>(local) * kRounds;
         const SeedSink sink = {seed_table + slot0 * (kSeedFloats * kWave), slots_per_instance * (kSeedFloats * kWave), static_cast<long long>(kSeedFloats) * kWave,
                                nullptr, mask_table + slot0, slots_per_instance, 1};
-        if (sh.yaw) adjoint_phase_b<kRounds, true, true>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink);
-        else adjoint_phase_b<kRounds, true, false>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink);
+        if (sh.yaw) adjoint_phase_b<kRounds, true, true>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink, sh.cull);
+        else adjoint_phase_b<kRounds, true, false>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink, sh.cull);
     }
     wave_lds_sync();
     for (int idx = lane; idx < N * kGradStride; idx += kWave) out[idx] = G[idx];
@@ -1094,8 +1100,8 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(k
         const long long slot0 = static_cast<long long>(local) * kRounds;
         const SeedSink sink = {seed_table + slot0 * (kSeedFloats * kWave), slots_per_instance * (kSeedFloats * kWave), static_cast<long long>(kSeedFloats) * kWave,
                                nullptr, mask_table + slot0, slots_per_instance, 1};
-        if (sh.yaw) adjoint_phase_b<kRounds, true, true>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink);
-        else adjoint_phase_b<kRounds, true, false>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink);
+        if (sh.yaw) adjoint_phase_b<kRounds, true, true>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink, sh.cull);
+        else adjoint_phase_b<kRounds, true, false>(st, instances, mlp, N, f.inv_t, num_points, lam, G, lane, rcache, sink, sh.cull);
     }
     wave_lds_sync();
     for (int idx = lane; idx < N * kGradStride; idx += kWave) out[idx] = G[idx];
@@ -1240,8 +1246,8 @@ __global__ __launch_bounds__(kPairWaves * kWave) __attribute__((amdgpu_waves_per
             const long long slot0 = static_cast<long long>(local) * kRounds + wave * kMine;
             const SeedSink sink = {seed_table + slot0 * (kSeedFloats * kWave), slots_per_instance * (kSeedFloats * kWave), static_cast<long long>(kSeedFloats) * kWave,
                                    nullptr, mask_table + slot0, slots_per_instance, 1};
-            if (sh.yaw) adjoint_phase_b<kMine, true, true>(st, instances, mlp, N, f.inv_t, my_points, lam, G, lane, rcache, sink, first_point);
-            else adjoint_phase_b<kMine, true, false>(st, instances, mlp, N, f.inv_t, my_points, lam, G, lane, rcache, sink, first_point);
+            if (sh.yaw) adjoint_phase_b<kMine, true, true>(st, instances, mlp, N, f.inv_t, my_points, lam, G, lane, rcache, sink, sh.cull, first_point);
+            else adjoint_phase_b<kMine, true, false>(st, instances, mlp, N, f.inv_t, my_points, lam, G, lane, rcache, sink, sh.cull, first_point);
         }
     }
     wave_lds_sync();
@@ -1378,8 +1384,8 @@ __global__ __launch_bounds__(kPairWaves * kWave) void render_silhouette_split_ke
         const float suffix = (wave == 0) ? xchg[5] : 0.0f;
         if (adjoint_reverse_sweep<kMine>(st, sh, r, my_points, nullptr, nullptr, lane, 0.0f, first_point, suffix)) {
             const SeedSink no_sink = {};
-            if (sh.yaw) adjoint_phase_b<kMine, false, true>(st, instances, nullptr, N, f.inv_t, my_points, lam, G, lane, nullptr, no_sink, first_point);
-            else adjoint_phase_b<kMine, false, false>(st, instances, nullptr, N, f.inv_t, my_points, lam, G, lane, nullptr, no_sink, first_point);
+            if (sh.yaw) adjoint_phase_b<kMine, false, true>(st, instances, nullptr, N, f.inv_t, my_points, lam, G, lane, nullptr, no_sink, sh.cull, first_point);
+            else adjoint_phase_b<kMine, false, false>(st, instances, nullptr, N, f.inv_t, my_points, lam, G, lane, nullptr, no_sink, sh.cull, first_point);
         }
     }
     wave_lds_sync();
@@ -1411,11 +1417,15 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         if (item >= num_items) break;
         const int i = item / items_per_instance;
         const long long first = static_cast<long long>(item - i * items_per_instance) * slots_per_item;
-        const unsigned char* item_masks = mask_table + static_cast<long long>(i) * slots_per_instance + first;
-        // anything to do?  (lane k looks at slot k of the item; slots_per_item <= 64)
-        const int my_mask = (lane < slots_per_item && first + lane < used_slots) ? static_cast<int>(item_masks[lane]) : 0;
-        const unsigned long long active = __ballot(my_mask != 0);
-        if (active == 0ull) {
+        const unsigned char* item_counts = mask_table + static_cast<long long>(i) * slots_per_instance + first;
+        // Lane k looks at slot k of the item (slots_per_item <= 64): the number of leading seed columns that matter (adjoint_phase_b).
+        // Round 4: the points of ALL the item's slots are taken as one stream and cut into 16-point tiles -- a slot of its own ends in a
+        // partly filled tile (half a tile per (ray, round, instance) on average: a fifth of the tiles of pass 2, tests/tile_statistics.py),
+        // the stream only once.  Element e of the stream = column e - begin_k of slot k, k = the first slot whose inclusive count exceeds e.
+        const int my_count = (lane < slots_per_item && first + lane < used_slots) ? static_cast<int>(item_counts[lane]) : 0;
+        const int inclusive = static_cast<int>(wave_inclusive_sum(static_cast<float>(my_count)));        // (exact: at most 64 x 64)
+        const int total = __builtin_amdgcn_readlane(inclusive, kWave - 1);
+        if (total == 0) {
             if (lane == 0) item_flags[item] = 0;
             continue;
         }
@@ -1430,14 +1440,27 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         s.clear();
         float at0 = 0, at1 = 0, at2 = 0;
         float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
+        const int begin = inclusive - my_count;
+        const float* item_seeds = seed_table + (static_cast<long long>(i) * slots_per_instance + first) * (kSeedFloats * kWave);
 #pragma unroll 1
-        for (unsigned long long todo = active; todo != 0ull; todo &= todo - 1ull) {
-            const int k = __builtin_ctzll(todo);
-            const unsigned rows = static_cast<unsigned>(__builtin_amdgcn_readlane(my_mask, k));      // (lane k read slot k's mask above: no second round trip)
-            const float* src = seed_table + (static_cast<long long>(i) * slots_per_instance + first + k) * (kSeedFloats * kWave) + lane;
-            const float relx = src[7 * kWave], rely = src[8 * kWave], relz = src[9 * kWave];
-            const ResidualAdjoint ra = mlp_adjoint_points<true>(s, wt, src[0 * kWave], src[1 * kWave], src[2 * kWave], src[3 * kWave],
-                                                                src[4 * kWave], src[5 * kWave], src[6 * kWave], scratch, lane, rows);
+        for (int base = 0; base < total; base += kWave) {
+            const int e = base + lane;
+            const bool valid = e < total;
+            int k = 0;                                                         // number of slots whose inclusive count is <= e (binary lifting over the lanes)
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                const int probe = __builtin_amdgcn_ds_bpermute((k + step - 1) << 2, inclusive);
+                k += (probe <= e) ? step : 0;
+            }
+            const int column = e - __builtin_amdgcn_ds_bpermute(k << 2, begin);
+            const float* src = item_seeds + (valid ? static_cast<long long>(k) * (kSeedFloats * kWave) + column : 0);
+            // lanes beyond the stream's end: zero seeds (the adjoint is linear in them) at the origin
+            const float px = valid ? src[0 * kWave] : 0.0f, py = valid ? src[1 * kWave] : 0.0f, pz = valid ? src[2 * kWave] : 0.0f;
+            const float res_bar = valid ? src[3 * kWave] : 0.0f;
+            const float glx = valid ? src[4 * kWave] : 0.0f, gly = valid ? src[5 * kWave] : 0.0f, glz = valid ? src[6 * kWave] : 0.0f;
+            const float relx = valid ? src[7 * kWave] : 0.0f, rely = valid ? src[8 * kWave] : 0.0f, relz = valid ? src[9 * kWave] : 0.0f;
+            const unsigned rows = tiles_of_count(min(total - base, kWave));
+            const ResidualAdjoint ra = mlp_adjoint_points<true>(s, wt, px, py, pz, res_bar, glx, gly, glz, scratch, lane, rows);
             r00 += relx * ra.px; r01 += relx * ra.py; r02 += relx * ra.pz;
             r10 += rely * ra.px; r11 += rely * ra.py; r12 += rely * ra.pz;
             r20 += relz * ra.px; r21 += relz * ra.py; r22 += relz * ra.pz;

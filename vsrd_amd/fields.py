@@ -19,7 +19,6 @@ A callable that cannot be flattened is rejected with ``UnsupportedFieldError``: 
 generic (per-op PyTorch) rendering path in this package.
 """
 import functools
-import threading
 from dataclasses import dataclass
 from typing import Optional
 
@@ -248,22 +247,41 @@ def flatten(field) -> FieldBlock:
     if len(members) > _lib.MAX_INSTANCES:
         raise UnsupportedFieldError(f"{len(members)} instances > VSRD_MAX_INSTANCES={_lib.MAX_INSTANCES}")
     parts = [_unwrap_instance(m) for m in members]
-    # main.py's hierarchical_wrapper (main.py:511-523) renders the SAME closure twice per step (pass 1 under no_grad, pass 2 with the
-    # samples of pass 1): the second call finds the block of the first, as long as every captured tensor is the same object at the
-    # same version (in-place updates bump the version that a view shares with its base).  The block is always built with autograd on,
-    # so that the call under no_grad leaves a block the differentiable call can use.
-    key = (hard, (id(temperature), temperature._version) if isinstance(temperature, torch.Tensor) else float(temperature),
-           tuple((id(t), t._version, t.requires_grad) if isinstance(t, torch.Tensor) else t for p in parts for t in p))
-    cached = getattr(_last_block, "entry", None)
-    if cached is not None and cached[0] == key:
-        return cached[1]
-    with torch.enable_grad():
-        block = _build_block(parts, temperature, hard)
-    _last_block.entry = (key, block, parts, temperature)          # (the parts stay referenced: their ids cannot be reused meanwhile)
-    return block
+    with torch.enable_grad():         # (also under no_grad: the block of main.py's pass 1 is handed to the differentiable pass 2, below)
+        return _build_block(parts, temperature, hard)
 
 
-_last_block = threading.local()
+class BlockHandOver:
+    """The block flattened for pass 1 of main.py's hierarchical_wrapper (main.py:511-523: the SAME closure rendered twice, pass 1 under
+    no_grad, pass 2 with pass 1's `sampled_distances` / `sampled_weights`), handed to pass 2 so that the closure tree is walked and the
+    block assembled once per step.  The reuse is scoped to exactly that hand-over: the renderer attaches this object to the
+    `sampled_distances` tensor it returns from pass 1, and pass 2 takes the block from the tensor it is given back -- only if it is
+    that very tensor, the closure is the same object, and every tensor the closure tree captures is the same object at the same
+    version.  Nothing is kept in module state (round 3's thread-local "last block" could outlive a parameter update written through
+    `.data` or a raw pointer, which no version counter sees: ADVICE r03); the entry dies with the tensor.
+    ``vsrd_amd.fields.BLOCK_HAND_OVER = False`` switches it off."""
+
+    def __init__(self, field, block):
+        self.field, self.block = field, block
+        self.key = _capture_key(field)
+
+    def take(self, field):
+        if not BLOCK_HAND_OVER or field is not self.field:
+            return None
+        try:
+            return self.block if _capture_key(field) == self.key else None
+        except UnsupportedFieldError:
+            return None
+
+
+BLOCK_HAND_OVER = True
+
+
+def _capture_key(field):
+    members, temperature, hard = _as_soft_union(field)
+    parts = [_unwrap_instance(m) for m in members]
+    return (hard, (id(temperature), temperature._version) if isinstance(temperature, torch.Tensor) else float(temperature),
+            tuple((id(t), t._version, t.requires_grad) if isinstance(t, torch.Tensor) else t for p in parts for t in p))
 
 
 def _build_block(parts, temperature, hard) -> FieldBlock:

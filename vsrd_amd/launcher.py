@@ -91,10 +91,13 @@ def run_frames(frames: Sequence, optimise: Callable, checkpoint_path: Callable[[
         return [one(item) for item in pending]
 
     from concurrent.futures import ThreadPoolExecutor
+    # a worker thread starts with device 0 current: it takes over this thread's device (the rank's GPU) before it makes its stream
+    device = torch.cuda.current_device() if torch.cuda.is_available() else None
 
     def on_own_stream(item):
         if torch.cuda.is_available():
-            with torch.cuda.stream(torch.cuda.Stream()):
+            torch.cuda.set_device(device)
+            with torch.cuda.stream(torch.cuda.Stream(device=device)):
                 frame = one(item)
                 torch.cuda.current_stream().synchronize()
                 return frame
@@ -102,3 +105,160 @@ def run_frames(frames: Sequence, optimise: Callable, checkpoint_path: Callable[[
 
     with ThreadPoolExecutor(max_workers=frames_in_flight) as pool:
         return list(pool.map(on_own_stream, pending))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# frames/s: the unit the reference shards (README.md:128 "about 15 minutes per frame"; main.py:106-136 one optimisation per frame)
+#   python -m vsrd_amd.launcher --gpus N --frames K      (or under torchrun; `python bench.py --native --gpus N ...` forwards here)
+# ---------------------------------------------------------------------------------------------------------------------------------
+
+def synthetic_frame_inputs(device, frame, views, instances, height=376, width=1408):
+    """FrameInputs of synthetic frame number `frame` (bench.synthetic_frame(seed = frame): KITTI-360 intrinsics, boxes in the
+    reference's ranges): soft masks rendered from the true boxes at the sharp end of the schedule, ground-truth 2-D boxes projected
+    from them, every instance visible in every view."""
+    import bench
+    from . import fields, models, operations, optimization, rendering
+    K, E, raw_loc, raw_dim, raw_ori = bench.synthetic_frame(int(frame), views, height, width, instances)
+    K, E = K.to(device), E.to(device)
+    det = models.BoxParameters3D(1, instances).to(device)
+    with torch.no_grad():
+        det.locations.copy_(raw_loc); det.dimensions.copy_(raw_dim); det.orientations.copy_(raw_ori)
+        out = det()
+        cam, dirs = rendering.ray_casting((height, width), K, E)
+        block = fields.FieldBlock(fields.pack_instances(out["locations"][0], out["orientations"][0], out["dimensions"][0]), 0.1, None, None)
+        origins = cam[:, None, None, :].expand(views, height, width, 3).reshape(-1, 3).contiguous()
+        soft = rendering.render_hierarchical(block, origins, dirs.reshape(-1, 3), (0.0, 100.0), 64, 0.1, 1.0, seed=1,
+                                             skip_exact_misses=True)["labels"].clamp(0, 1).reshape(views, height, width, instances).contiguous()
+        gt_boxes, _ = operations.project_boxes_multi_view(out["boxes_3d"][0], E, K, (height, width))
+    return optimization.FrameInputs((height, width), K, E, soft, gt_boxes, torch.ones(views, instances, dtype=torch.bool, device=device))
+
+
+def _spawn(argv, gpus, share_gpu):
+    """No launcher around us: start `gpus` copies of this module, one rank each, before anything here touches a GPU."""
+    import socket
+    import subprocess
+    import sys
+    if not share_gpu and torch.cuda.device_count() < gpus:
+        raise SystemExit(f"vsrd_amd.launcher --gpus {gpus}: this node has {torch.cuda.device_count()} visible GPU(s); one rank per GPU")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    children = []
+    for rank in range(gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(gpus), LOCAL_WORLD_SIZE=str(gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        children.append(subprocess.Popen([sys.executable, "-m", "vsrd_amd.launcher", *argv], env=env,
+                                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    return max(abs(child.wait()) for child in children)
+
+
+def main(argv=None):
+    """Optimise K synthetic frames, sharded over the ranks, each rank keeping `--frames-in-flight` frames on its GPU at a time with
+    ``FrameOptimizer(graph=True)``; checkpoints through formats.checkpoint_payload (atomic, restartable: a frame whose final checkpoint
+    exists is skipped, main.py:134-136).  Rank 0 broadcasts the manifest, the ranks start behind an ordered barrier, and rank 0 prints
+    ONE JSON line: whole-job frames/s (K over the slowest rank's barrier-to-barrier time), frames/s per GPU, every rank's own time."""
+    import argparse
+    import json
+    import sys
+    import tempfile
+    import time
+    parser = argparse.ArgumentParser(prog="python -m vsrd_amd.launcher")
+    parser.add_argument("--gpus", type=int, default=1)
+    parser.add_argument("--frames", type=int, default=0, help="frames of the whole job (default: 2 per rank)")
+    parser.add_argument("--frames-in-flight", type=int, default=2)
+    parser.add_argument("--views", type=int, default=17)
+    parser.add_argument("--instances", type=int, default=8)
+    parser.add_argument("--rays", type=int, default=1000)
+    parser.add_argument("--samples", type=int, default=100)
+    parser.add_argument("--num-steps", type=int, default=3000)
+    parser.add_argument("--warmup-steps", type=int, default=1000)
+    parser.add_argument("--height", type=int, default=376)
+    parser.add_argument("--width", type=int, default=1408)
+    parser.add_argument("--out", default="", help="checkpoint directory (default: a temporary one)")
+    parser.add_argument("--seed", type=int, default=0)
+    parser.add_argument("--ranks-share-gpu", action="store_true",
+                        help="TEST ONLY: every rank on cuda:0, gloo rendezvous (RCCL refuses two ranks on one device); the line says so")
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parser.parse_args(argv)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))          # bench.synthetic_frame, __graft_entry__.build live at the repo root
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    if "RANK" not in os.environ and args.gpus > 1:
+        return _spawn(argv, args.gpus, args.ranks_share_gpu)
+    if args.ranks_share_gpu:
+        os.environ["LOCAL_RANK"] = "0"
+    if not torch.cuda.is_available():
+        raise SystemExit("vsrd_amd.launcher optimises frames on HIP devices: no GPU visible, and vsrd_amd has no CPU fallback")
+    rank, world, device = init_process_group(backend="gloo" if args.ranks_share_gpu else None)
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    barrier()
+    from . import formats, optimization
+    total = args.frames or 2 * world
+    out_dir = args.out or (tempfile.mkdtemp(prefix="vsrd_frames_") if rank == 0 else None)
+    manifest = broadcast_manifest(dict(frames=list(range(total)), seed=args.seed, out=out_dir) if rank == 0 else None)
+    mine = shard_frames(manifest["frames"], rank, world, seed=manifest["seed"])
+    ordered(lambda r: print(f"[rank {r}/{world}] {device}: frames {mine}", file=sys.stderr, flush=True))
+    config = dict(num_steps=args.num_steps, warmup_steps=args.warmup_steps, num_rays=args.rays, num_samples=args.samples)
+    # inputs are resident before the clock starts (what main.py:106-316 prepares per frame is the dataset's work, not the loop's)
+    inputs = {frame: synthetic_frame_inputs(device, frame, args.views, args.instances, args.height, args.width) for frame in mine}
+    losses = {}
+
+    def optimise(frame):
+        loop = optimization.FrameOptimizer(inputs[frame], optimization.OptimizationConfig(seed=int(frame), **config), device, graph=True)
+        record = loop.run(args.num_steps)
+        torch.cuda.current_stream().synchronize()
+        losses[frame] = float(record["loss"])
+        payload = formats.checkpoint_payload(loop, step=args.num_steps - 1, metrics={})
+        loop.close()
+        return payload
+
+    def path_of(frame):
+        return os.path.join(manifest["out"], f"frame_{int(frame):06d}", f"step_{args.num_steps - 1}.pt")
+
+    def fence():
+        barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    done = run_frames(mine, optimise, path_of, frames_in_flight=args.frames_in_flight)
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0
+    fence()
+    elapsed = time.perf_counter() - t0
+    report = dict(rank=rank, own_seconds=own, elapsed_seconds=elapsed, frames=len(done), skipped=len(mine) - len(done),
+                  mean_final_loss=(sum(losses.values()) / len(losses)) if losses else None)
+    gathered = [report]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, report)
+    if rank == 0:
+        slowest = max(r["elapsed_seconds"] for r in gathered)
+        frames_done = sum(r["frames"] for r in gathered)
+        line = {
+            "metric": "optimised target frames/s, whole job (reference: about 15 minutes per frame on a V100, README.md:128)",
+            "value": frames_done / slowest, "unit": "frames/s", "n_gpus": len(gathered), "higher_is_better": True, "scaling": "weak",
+            "frames": frames_done, "frames_skipped_as_done": sum(r["skipped"] for r in gathered), "seconds": slowest,
+            "frames_per_s_per_gpu": frames_done / slowest / len(gathered),
+            "per_rank_seconds": [r["own_seconds"] for r in gathered], "per_rank_frames": [r["frames"] for r in gathered],
+            "seconds_per_frame_per_gpu": [r["own_seconds"] / r["frames"] if r["frames"] else None for r in gathered],
+            "mean_final_loss": [r["mean_final_loss"] for r in gathered], "data": "synthetic", "dtype": "f32",
+            "config": {"workload": f"{args.num_steps} optimisation steps per frame ({args.warmup_steps} box-only + {args.num_steps - args.warmup_steps} with the "
+                                   f"residual MLP), {args.rays} rays x {args.samples} samples per step, {args.views} views of {args.height}x{args.width}, "
+                                   f"{args.instances} instances, FrameOptimizer(graph=True), {args.frames_in_flight} frames in flight per GPU",
+                       "parallelism": f"frames sharded over {len(gathered)} rank(s), no data-path collective; RCCL: barriers, manifest broadcast, gather of the report",
+                       "checkpoints": manifest["out"]},
+        }
+        if args.ranks_share_gpu:
+            line["metric"] = "ranks share ONE GPU (--ranks-share-gpu): a test of the multi-rank path, NOT a scaling measurement; " + line["metric"]
+        print(json.dumps(line), flush=True)
+    barrier()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

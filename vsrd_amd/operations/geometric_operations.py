@@ -13,12 +13,23 @@ LINE_INDICES = [[0, 1], [1, 2], [2, 3], [3, 0], [4, 5], [5, 6], [6, 7], [7, 4], 
 _edge_cache = {}
 
 
+_edge_identity = {}
+
+
 def _edges(line_indices, device):
+    """The edge list as an int32 device tensor, cached: by the list OBJECT first (main.py passes its module-level LINE_INDICES on every
+    one of its V x N calls) with a C-speed equality check against a private copy of its contents (a list mutated in place misses),
+    then by value."""
+    hit = _edge_identity.get((id(line_indices), device))
+    if hit is not None and hit[0] is line_indices and line_indices == hit[1]:
+        return hit[2]
     key = (tuple(map(tuple, line_indices)), device)
     cached = _edge_cache.get(key)
     if cached is None:
         cached = torch.tensor(line_indices, dtype=torch.int32, device=device).contiguous()
         _edge_cache[key] = cached
+    if isinstance(line_indices, (list, tuple)):
+        _edge_identity[(id(line_indices), device)] = (line_indices, [list(edge) for edge in line_indices], cached)
     return cached
 
 
@@ -61,14 +72,61 @@ def project_boxes_multi_view(world_boxes_3d, extrinsic_matrices, intrinsic_matri
     return boxes.unflatten(-1, (2, 2)), camera
 
 
+_identity_cache = {}
+
+
+def _identity_extrinsic(device):
+    cached = _identity_cache.get(device)
+    if cached is None:
+        cached = torch.eye(4, dtype=torch.float32, device=device).reshape(1, 16).contiguous()
+        _identity_cache[device] = cached
+    return cached
+
+
+class _ProjectCameraBoxes(torch.autograd.Function):
+    """The single-view, camera-frame form behind `project_box_3d`: scripts/main.py:339-362 calls it V x N times per optimisation step
+    (136 calls at V = 17, N = 8), so a call is a kernel launch and as little host work as there can be around it -- the identity
+    extrinsic is cached per device, nothing is allocated but the box, the saved edge selection and (backward) the corner adjoint, and
+    the camera-frame corners are not written at all (they are the input)."""
+
+    @staticmethod
+    def forward(ctx, corners, intrinsic, edges, epsilon):
+        lib = _lib.load()
+        flat = corners.detach().reshape(-1, 8, 3)
+        if flat.dtype != torch.float32 or not flat.is_contiguous():
+            flat = flat.to(torch.float32).contiguous()
+        K = intrinsic.detach().reshape(1, 9)
+        if K.dtype != torch.float32 or not K.is_contiguous():
+            K = K.to(torch.float32).contiguous()
+        E = _identity_extrinsic(flat.device)
+        N = flat.shape[0]
+        boxes = torch.empty(1, N, 4, dtype=torch.float32, device=flat.device)
+        selection = torch.empty(1, N, 4, dtype=torch.int32, device=flat.device)
+        _lib.check(lib.vsrd_project_boxes_forward(_lib.ptr(flat), _lib.ptr(E), _lib.ptr(K), _lib.iptr(edges), edges.shape[0], 1, N,
+                                                  0, 0, epsilon, _lib.ptr(boxes), None, _lib.iptr(selection), _lib.stream()))   # height = width = 0: no image clamp
+        ctx.save_for_backward(flat, K, edges, selection)
+        ctx.epsilon = epsilon
+        ctx.shape = corners.shape
+        return boxes.reshape(*corners.shape[:-2], 2, 2)
+
+    @staticmethod
+    def backward(ctx, grad_boxes):
+        lib = _lib.load()
+        flat, K, edges, selection = ctx.saved_tensors
+        N = flat.shape[0]
+        grad = grad_boxes.reshape(1, N, 4)
+        if grad.dtype != torch.float32 or not grad.is_contiguous():
+            grad = grad.to(torch.float32).contiguous()
+        per_view = torch.empty(1, N, 8, 3, dtype=torch.float32, device=flat.device)
+        _lib.check(lib.vsrd_project_boxes_backward(_lib.ptr(flat), _lib.ptr(_identity_extrinsic(flat.device)), _lib.ptr(K), _lib.iptr(edges),
+                                                   edges.shape[0], 1, N, ctx.epsilon, _lib.ptr(grad), _lib.iptr(selection), _lib.ptr(per_view),
+                                                   _lib.stream()))
+        return per_view.reshape(ctx.shape), None, None, None
+
+
 def project_box_3d(box_3d, line_indices, intrinsic_matrix, epsilon=1e-6):
     """Reference signature (geometric_operations.py:368-389): camera-frame corners [...,8,3] -> [...,2,2], not clipped to an image."""
-    lead = box_3d.shape[:-2]
-    corners = box_3d.reshape(-1, 8, 3)
-    eye = torch.eye(4, device=box_3d.device).unsqueeze(0)
-    boxes, _ = _ProjectBoxes.apply(corners, eye, intrinsic_matrix.reshape(1, 3, 3), _edges(line_indices, box_3d.device),
-                                   0, 0, epsilon)      # height = width = 0: no image clamp
-    return boxes[0].reshape(*lead, 2, 2)
+    return _ProjectCameraBoxes.apply(box_3d, intrinsic_matrix, _edges(line_indices, box_3d.device), float(epsilon))
 
 
 def rotation_matrix_x(angles):

@@ -283,7 +283,8 @@ class FrameOptimizer:
         rays_branch, net_branch = self._branches
         fused_net = residual and self.fused_hypernetwork
         sampled = ray_indices is None
-        with_prologue = sampled and self.ray_table is not None      # the draw rides in the prologue's launch (a second workgroup): no branch, no join
+        # the draw rides in the prologue's launch (a second workgroup): no branch, no join
+        with_prologue = sampled and self.ray_table is not None and getattr(self, "_prologue_draws", True)
         if sampled and not with_prologue:   # branch 1: this step's rays (device sampler keyed by the step counter, ray_sampling.h)
             rays_branch.wait_stream(main)
             with torch.cuda.stream(rays_branch):
@@ -304,8 +305,16 @@ class FrameOptimizer:
                          _lib.ptr(b["instance_weights"]), _lib.ptr(self.schedule), _lib.ptr(b["projection_losses"]), _lib.ptr(b["grad_raw"]))
         if with_prologue:
             table = self.ray_table
-            _lib.check(lib.vsrd_frame_prologue_sample(*prologue_args, table.table.data_ptr(), table.count, cfg.num_rays, (cfg.seed + 1) & 0xFFFFFFFFFFFFFFFF,
-                                                      self.positive_pixels.data_ptr(), b["ray_indices"].data_ptr(), stream))
+            code = lib.vsrd_frame_prologue_sample(*prologue_args, table.table.data_ptr(), table.count, cfg.num_rays, (cfg.seed + 1) & 0xFFFFFFFFFFFFFFFF,
+                                                  self.positive_pixels.data_ptr(), b["ray_indices"].data_ptr(), stream)
+            if code == _lib.E_LAUNCH and not torch.cuda.is_current_stream_capturing():
+                # the combined launch needs ~125 KB of LDS in one workgroup (cost matrix + the sampler's hash table): where the opt-in or
+                # the launch fails, the frame keeps the bit-identical two-launch form (tests: test_frame_prologue_matches_the_torch_path)
+                self._prologue_draws = False
+                _lib.check(lib.vsrd_frame_prologue(*prologue_args, stream))
+                self._draw_rays(b["ray_indices"], b["picks"])
+            else:
+                _lib.check(code)
         else:
             _lib.check(lib.vsrd_frame_prologue(*prologue_args, stream))
         if sampled and not with_prologue:

@@ -21,7 +21,7 @@ import threading
 import torch
 
 from .. import _lib, profiling
-from ..fields import FieldBlock, SoftUnion, flatten, member_label, _closure_vars
+from ..fields import BlockHandOver, FieldBlock, SoftUnion, flatten, member_label, _closure_vars
 
 class Workspace:
     """Device scratch of one stream of work: the adjoint launches' per-wave gradient partials / residual jets and seeds
@@ -364,7 +364,11 @@ def hierarchical_volumetric_rendering(
     ray-major device buffers, just as the reference returns permuted views).
     """
     lib = _lib.load()
-    block = flatten(distance_field)
+    # pass 2 of main.py's hierarchical_wrapper is given back the very `sampled_distances` tensor pass 1 returned: it carries pass 1's block
+    hand_over = getattr(sampled_distances, "_vsrd_block_hand_over", None) if sampled_distances is not None else None
+    block = hand_over.take(distance_field) if hand_over is not None else None
+    if block is None:
+        block = flatten(distance_field)
     origins, directions, stride, lead = _prepare_rays(ray_positions, ray_directions)
     R = directions.shape[0]
     dev = directions.device
@@ -393,10 +397,13 @@ def hierarchical_volumetric_rendering(
                                                           block.temperature, scalars, stride)
     labels = _scatter_labels(labels, block)
     D = distances.shape[1]
+    distances_out = distances.reshape(*lead, D).movedim(-1, 0).unsqueeze(-1)
+    if sampled_distances is None and not isinstance(distance_field, FieldBlock):
+        distances_out._vsrd_block_hand_over = BlockHandOver(distance_field, block)      # (fields.BlockHandOver: pass 1 -> pass 2 only)
     return (
         labels.reshape(*lead, -1),
         gradients.reshape(*lead, D - 1, 3).movedim(-2, 0),
-        distances.reshape(*lead, D).movedim(-1, 0).unsqueeze(-1),
+        distances_out,
         weights.reshape(*lead, D - 1).movedim(-1, 0).unsqueeze(-1),
     )
 
