@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Register / scratch / LDS footprint of every kernel of the library, from the code object metadata of a device-only compile:
-    python tools/kernel_resources.py [extra hipcc flags...]
-(waves per SIMD on gfx950: floor(512 / (vgpr + agpr)) capped at 8)."""
+"""Register / scratch footprint of every kernel of the library AS SHIPPED: the code-object metadata inside vsrd_amd/lib/libvsrd_hip.so
+(what the loader sees -- a callee's registers and the AGPRs it parks callee-saved ones in count towards its callers here, which a
+one-kernel compile does not show: residual_step_pair_kernel<4> is 251 registers compiled alone and 256-260 in the library).
+    python tools/kernel_resources.py [path/to/lib.so]          -> table on stdout (profiles/<round>/kernel_resources.txt)
+(waves per SIMD on gfx950: floor(512 / unified registers), at most 8; kernels with an amdgpu_waves_per_eu attribute are listed as built)."""
 import os
 import re
 import subprocess
@@ -9,28 +11,36 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+
+
+def code_object_notes(library):
+    with tempfile.TemporaryDirectory() as tmp:
+        fatbin, device = os.path.join(tmp, "fatbin.bin"), os.path.join(tmp, "device.co")
+        subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", library, fatbin], check=True)
+        data = open(fatbin, "rb").read()
+        start = data.find(b"\x7fELF")                         # the gfx950 code object inside the clang offload bundle
+        if start < 0:
+            raise SystemExit(f"{library}: no device code object found")
+        open(device, "wb").write(data[start:])
+        return subprocess.run([READELF, "--notes", device], capture_output=True, text=True, check=True).stdout
 
 
 def main():
-    import __graft_entry__ as g
-    flags = [f for f in g.HIPCC_FLAGS if f not in ("-shared", "-fPIC")] + sys.argv[1:]
-    with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, "api.s")
-        subprocess.run([g.HIPCC, *flags, "--cuda-device-only", "-S", "-o", out, os.path.join(g.CSRC, "api.hip")], check=True, stderr=subprocess.DEVNULL)
-        text = open(out).read()
-    meta = text[text.index("amdhsa.kernels:"):]
+    library = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "vsrd_amd", "lib", "libvsrd_hip.so")
+    notes = code_object_notes(library)
     rows = []
-    for block in meta.split("\n  - .agpr_count:")[1:]:
-        block = ".agpr_count:" + block
+    for block in notes.split("  - .agpr_count:")[1:]:
+        agpr = int(block.split()[0])
         get = lambda key, block=block: re.search(r"\.%s:\s+(\S+)" % key, block)
         name = get("name").group(1)
         demangled = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().split("(")[0].replace("void ", "")
-        rows.append((demangled, int(get("vgpr_count").group(1)), int(get("agpr_count").group(1)), int(get("sgpr_count").group(1)),
-                     int(get("vgpr_spill_count").group(1)), int(get("sgpr_spill_count").group(1)), int(get("private_segment_fixed_size").group(1))))
-    print(f"{'kernel':58s} {'vgpr+agpr':>9s} {'agpr':>5s} {'sgpr':>5s} {'vspill':>6s} {'sspill':>6s} {'scratch':>7s} {'waves/SIMD':>10s}")
+        rows.append((demangled, int(get("vgpr_count").group(1)), agpr, int(get("sgpr_count").group(1)), int(get("vgpr_spill_count").group(1)),
+                     int(get("sgpr_spill_count").group(1)), int(get("private_segment_fixed_size").group(1))))
+    print(f"# {os.path.relpath(library, ROOT)}: code-object metadata (llvm-readelf --notes)")
+    print(f"{'kernel':62s} {'vgpr+agpr':>9s} {'agpr':>5s} {'sgpr':>5s} {'vspill':>6s} {'sspill':>6s} {'scratch':>7s} {'waves/SIMD':>10s}")
     for name, vgpr, agpr, sgpr, vs, ss, scratch in sorted(rows):
-        print(f"{name[:58]:58s} {vgpr:9d} {agpr:5d} {sgpr:5d} {vs:6d} {ss:6d} {scratch:7d} {min(8, 512 // max(vgpr, 1)):10d}")
+        print(f"{name[:62]:62s} {vgpr:9d} {agpr:5d} {sgpr:5d} {vs:6d} {ss:6d} {scratch:7d} {min(8, 512 // max(vgpr, 1)):10d}")
 
 
 if __name__ == "__main__":

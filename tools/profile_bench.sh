@@ -9,7 +9,9 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-extra-regimes $*"
+# the kernel-trace pass runs the driver's own step counts (bench.py --steps 20 --warmup 5 for config 2; PROFILE_STEPS / PROFILE_WARMUP for
+# the long regimes), so that the committed average duration is of the run the driver times
+ARGS="--steps ${PROFILE_STEPS:-20} --warmup ${PROFILE_WARMUP:-5} --no-cpu-baseline --no-extra-regimes $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python3 "$ROOT/bench.py" $ARGS > "$OUT/trace_stdout.log" 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY \
   --kernel-trace --output-format csv -d "$OUT/pmc_sq" -o bench -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-extra-regimes $* > "$OUT/pmc_sq_stdout.log" 2>&1

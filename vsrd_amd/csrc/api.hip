@@ -621,7 +621,7 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
     // the partial buffer holds one gradient row per wave; the loss partials live in the tail of the same row budget, and behind them
     // (multi-ray mappings) one byte per group of rays: "the hot kernel could not serve this group" (quad_step.h)
     const size_t num_groups = (quad || pair) ? (static_cast<size_t>(config->num_rays) + rays_per_wave - 1) / rays_per_wave : 0;
-    const size_t flag_bytes = (num_groups + 15) & ~static_cast<size_t>(15);
+    const size_t flag_bytes = (quad || pair) ? 16 + ((num_groups + 15) & ~static_cast<size_t>(15)) : 0;      // summary words + one byte per group
     if (flag_bytes + static_cast<size_t>(g.threads / kWave) * (row + 1) * sizeof(float) > vsrd_workspace_bytes(N, 0)) return VSRD_E_WORKSPACE;
     const int max_waves_for_loss = static_cast<int>((vsrd_workspace_bytes(N, 0) - flag_bytes) / sizeof(float) / (row + 1));
     if (g.blocks * (g.threads / kWave) > max_waves_for_loss) g.blocks = max_waves_for_loss / (g.threads / kWave);
@@ -643,6 +643,7 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
 #define VSRD_LAUNCH_ROWS(KERNEL, K, FULL)                                                                                         \
     do {                                                                                                                          \
         if (opt_in_lds(KERNEL<K, true, FULL>, g.lds_bytes) != VSRD_OK || opt_in_lds(KERNEL<K, false, false>, g.lds_bytes) != VSRD_OK) return VSRD_E_LAUNCH; \
+        if (hipMemsetAsync(redo_flags, 0, 16, s) != hipSuccess) return VSRD_E_LAUNCH;                                               \
         hipLaunchKernelGGL((KERNEL<K, true, FULL>), dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c,        \
                            origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, labels, partials,        \
                            loss_partials, redo_flags);                                                                           \

@@ -268,7 +268,8 @@ class FrameOptimizer:
                 or tuple(t.data_ptr() for t in current) != self._bound_signature):
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("a tensor bound to the captured step was replaced during stream capture")
-            torch.cuda.synchronize(self.device)          # replays that still write through the old addresses finish first
+            with _capture_lock:                          # (a device-wide synchronisation is refused while another frame's thread captures)
+                torch.cuda.synchronize(self.device)      # replays that still write through the old addresses finish first
             self.rebind()
 
     def _fused_step(self, ray_indices, count=True, joins=(True, True)):
@@ -449,13 +450,14 @@ class FrameOptimizer:
             return outputs
         static_rays = ray_indices.clone() if ray_indices is not None else None
         graph = torch.cuda.CUDAGraph()
-        torch.cuda.synchronize(self.device)
         # an own capture stream per loop: torch keys the rocBLAS / hipBLASLt workspaces by stream, and its default capture stream is
         # shared by every capture -- two loops replayed at the same time would then run their GEMMs in one workspace
         if self._capture_stream is None:
             self._capture_stream = torch.cuda.Stream(device=self.device)
         # stream capture is a process-wide mode: one capture at a time, and thread-local error checking so that another frame's
         # thread (launcher.run_frames(frames_in_flight=2)) may keep replaying its own graph meanwhile
+        # (no device-wide synchronisation out here: while ANOTHER frame's thread captures, HIP refuses it -- "operation not permitted when
+        #  stream is capturing"; torch.cuda.graph synchronises by itself once this thread holds the lock and nobody captures)
         with _capture_lock, torch.cuda.graph(graph, stream=self._capture_stream, capture_error_mode="thread_local"):
             outputs = self._step(static_rays, None, None, count=False)
         self._graphs[key] = (graph, static_rays, outputs)
@@ -491,7 +493,6 @@ class FrameOptimizer:
         key = (residual, False, k)
         if key not in self._graphs:
             graph = torch.cuda.CUDAGraph()
-            torch.cuda.synchronize(self.device)
             with _capture_lock, torch.cuda.graph(graph, stream=self._capture_stream, capture_error_mode="thread_local"):
                 for j in range(k):      # the hypernetwork's branch is joined to the step's stream only at the ends of the graph: between two
                     # steps the next prologue (which needs the epilogue only) overlaps the hypernetwork's backward and forward

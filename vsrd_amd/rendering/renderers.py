@@ -21,7 +21,8 @@ import threading
 import torch
 
 from .. import _lib, profiling
-from ..fields import BlockHandOver, FieldBlock, SoftUnion, flatten, member_label, _closure_vars
+from ..fields import BlockHandOver, FieldBlock, SoftUnion, UnsupportedFieldError, flatten, member_label, _closure_vars
+from . import generic
 
 class Workspace:
     """Device scratch of one stream of work: the adjoint launches' per-wave gradient partials / residual jets and seeds
@@ -368,7 +369,13 @@ def hierarchical_volumetric_rendering(
     hand_over = getattr(sampled_distances, "_vsrd_block_hand_over", None) if sampled_distances is not None else None
     block = hand_over.take(distance_field) if hand_over is not None else None
     if block is None:
-        block = flatten(distance_field)
+        try:
+            block = flatten(distance_field)
+        except UnsupportedFieldError as reason:
+            # a field the kernels do not know: the same algorithm with torch operations on the device (generic.py), not an exception
+            generic.warn_once(reason)
+            return generic.hierarchical_volumetric_rendering(distance_field, ray_positions, ray_directions, distance_range, num_samples,
+                                                             sdf_std_deviation, cosine_ratio, epsilon, sampled_distances, sampled_weights)
     origins, directions, stride, lead = _prepare_rays(ray_positions, ray_directions)
     R = directions.shape[0]
     dev = directions.device

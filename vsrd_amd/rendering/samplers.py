@@ -6,18 +6,20 @@ The renderer does not call these (sampling is fused into the render kernels); th
 import torch
 
 from .. import _lib
+from . import generic
 
 
 def quadrature_sampler(bins, deterministic=False):
-    """Stratified samples inside consecutive bins [..., S+1] -> [..., S].  Bins must be the linspace the
-    renderer uses (renderers.py:191-192): the kernel regenerates it from its two end points."""
+    """Stratified samples inside consecutive bins [..., S+1] -> [..., S] (samplers.py:5-8).  The renderer's own bins -- one linspace for
+    every ray (renderers.py:191-192), recognised by being an expanded 1-D tensor -- go through vsrd_sample_stratified, which regenerates
+    the linspace from its two end points; any other bins take the element-wise torch form on the device (generic.py)."""
     lib = _lib.load()
     S = bins.shape[-1] - 1
-    flat = bins.reshape(-1, S + 1)
-    near, far = float(flat[0, 0]), float(flat[0, -1])
-    expected = torch.linspace(near, far, S + 1, device=bins.device)
-    if not torch.equal(flat, expected.expand_as(flat)):
-        raise NotImplementedError("quadrature_sampler: only the renderer's linspace bins are supported")
+    shared = bins.dim() >= 1 and all(stride == 0 or size == 1 for stride, size in zip(bins.stride()[:-1], bins.shape[:-1]))
+    first = bins.reshape(-1, S + 1)[0] if shared else None
+    near, far = (float(first[0]), float(first[-1])) if shared else (0.0, 0.0)                     # (one host read of two numbers)
+    if not shared or S < 1 or S > 256 or not torch.equal(first, torch.linspace(near, far, S + 1, device=bins.device, dtype=bins.dtype)):
+        return generic.stratified_samples(bins, deterministic)
     u = torch.full(bins[..., :-1].shape, 0.5, device=bins.device) if deterministic else torch.rand_like(bins[..., :-1])
     u = u.reshape(-1, S).to(torch.float32).contiguous()
     out = torch.empty_like(u)
@@ -44,13 +46,14 @@ def importance_merge(bins, weights, uniforms=None, sorted_uniforms=False):
 
 
 def inverse_transform_sampler(bins, weights, num_samples, deterministic=False, uniforms=None):
-    """Drop-in for vsrd.rendering.samplers.inverse_transform_sampler (samplers.py:11-36): ``num_samples`` (= bins.shape[-1], the
-    only case the renderer uses, renderers.py:203) sorted samples of the piecewise-constant pdf ``weights`` [..., S-1] over the
-    points ``bins`` [..., S].  ``deterministic`` takes linspace(0, 1, S) as the uniforms; ``uniforms`` [..., S] (sorted) may be given."""
+    """Drop-in for vsrd.rendering.samplers.inverse_transform_sampler (samplers.py:11-36): sorted samples of the piecewise-constant pdf
+    ``weights`` [..., S-1] over the points ``bins`` [..., S].  ``num_samples`` = S (the renderer's case, renderers.py:203) runs
+    vsrd_sample_importance; any other count takes the torch form on the device.  ``deterministic`` takes linspace(0, 1, num_samples) as
+    the uniforms; ``uniforms`` [..., num_samples] (sorted) may be given."""
     lib = _lib.load()
     S = bins.shape[-1]
-    if num_samples != S:
-        raise NotImplementedError("inverse_transform_sampler: num_samples must equal the number of bins (the renderer's case)")
+    if num_samples != S or S > 256:          # not the renderer's case: the torch form on the device (generic.py)
+        return generic.inverse_transform_samples(bins, weights, num_samples, deterministic, uniforms)
     lead = bins.shape[:-1]
     b = bins.reshape(-1, S).to(torch.float32).contiguous()
     w = weights.reshape(-1, S - 1).to(torch.float32).contiguous()
