@@ -33,7 +33,7 @@ def run(cmd, timeout):
 
 def main():
     parser = argparse.ArgumentParser()
-    parser.add_argument("--tag", default="r03")
+    parser.add_argument("--tag", default="r04")
     parser.add_argument("--quick", action="store_true", help="skip the two multi-second-per-step full-size runs (C3, C5)")
     args = parser.parse_args()
     out_dir = os.path.join(ROOT, "gpurun_out", args.tag)
