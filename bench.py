@@ -172,8 +172,10 @@ def build_union(detector, temperature):
     sdfs.translation(sdfs.rotation(instance_field(sdfs.box(...)))) tree, built here in one cat)."""
     from vsrd_amd import fields
     out = detector()
+    # (the orientations are rotation_matrix_y(cos, sin) of the detector's parameters: yaw_gradients -- VSRD_FLAG_YAW_GRADIENTS -- lets
+    #  the kernels skip the adjoints of the five matrix entries that function keeps constant; every parameter gradient is unchanged)
     return fields.FieldBlock(fields.pack_instances(out["locations"][0], out["orientations"][0], out["dimensions"][0]),
-                             float(temperature), None, None)
+                             float(temperature), None, None, yaw_gradients=True)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

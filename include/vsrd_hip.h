@@ -133,6 +133,14 @@ typedef struct vsrd_render_config {
                                              is latency); the flag forces it for any launch, VSRD_FLAG_STEP_WAVE_PER_RAY forbids it; the
                                              results agree to rounding (A/B switch)                                                     */
 
+#define VSRD_FLAG_YAW_GRADIENTS 1024u       /* the caller differentiates the rotations only through rotation_matrix_y(cos, sin)
+                                             (box_parameters.py:5-13: what BoxParameters3D decodes to): grad_instances then carries the
+                                             adjoints of r00, r02, r20, r22 only -- the five entries that rotation_matrix_y keeps constant
+                                             (r01, r10, r11, r12, r21) get ZERO instead of their adjoint, which nobody would read.  Only
+                                             honoured when every rotation of the field IS of that form (checked on the device), by the
+                                             multi-ray kernels of vsrd_render_silhouette_step / vsrd_render_backward; never set it for
+                                             rotation matrices that are parameters themselves                                          */
+
 int32_t vsrd_abi_version(void);
 const char* vsrd_error_string(int32_t code);
 

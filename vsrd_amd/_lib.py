@@ -29,6 +29,7 @@ FLAG_RESIDUAL_SINGLE_KERNEL = 64
 FLAG_RESIDUAL_WAVE_PER_RAY = 128
 FLAG_STEP_WAVE_PER_RAY = 256
 FLAG_STEP_SPLIT_RAY = 512
+FLAG_YAW_GRADIENTS = 1024
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 

@@ -119,6 +119,7 @@ RenderArgs render_args(const vsrd_render_config* c) {
     a.sh.cull = 0.0f;   // computed in-kernel (field.h: field_bounds)
     a.sh.reach = -1.0f; // likewise
     a.sh.yaw = false;   // likewise
+    a.sh.yaw_gradients = false;
     a.sh.std = c->sdf_std_deviation;
     a.sh.inv_std = 1.0f / c->sdf_std_deviation;
     a.sh.ratio = c->cosine_ratio;
@@ -618,6 +619,9 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
     Geometry g;
     const size_t per_wave = (quad || pair) ? static_cast<size_t>(quad_lds_floats(S, full ? shape_instances : N, lanes)) : static_cast<size_t>(wave_lds_floats(S, N)) + N + row;
     if (!plan((quad || pair) ? (config->num_rays + rays_per_wave - 1) / rays_per_wave : config->num_rays, per_wave, &g)) return VSRD_E_UNSUPPORTED;
+#ifdef VSRD_INSTANCE_LDS
+    if (quad && full) g.lds_bytes += static_cast<size_t>(N) * kInstanceStride * sizeof(float);      // experiment: the instance block next to the waves' partitions
+#endif
     // the partial buffer holds one gradient row per wave; the loss partials live in the tail of the same row budget, and behind them
     // (multi-ray mappings) one byte per group of rays: "the hot kernel could not serve this group" (quad_step.h)
     const size_t num_groups = (quad || pair) ? (static_cast<size_t>(config->num_rays) + rays_per_wave - 1) / rays_per_wave : 0;

@@ -124,6 +124,25 @@ __device__ __forceinline__ int opaque_lane_id() {
     return lane;
 }
 
+// Experiment (-DVSRD_INSTANCE_LDS): the hot full-shape kernel stages the instance block in the workgroup's LDS and the instance loops read
+// it with four ds_read_b128 of one address (a broadcast): the parameters are VGPR operands then -- an FMA with an SGPR operand issues in
+// 4.4 cycles, on VGPRs in 2.8 (profiles/r01/op_rates.txt), and the instance loops have ~14 of them per (sample, instance).
+__device__ __forceinline__ Instance load_instance_block(const float* __restrict__ instances, int i) {
+#ifdef VSRD_INSTANCE_LDS
+    const float4* p = reinterpret_cast<const float4*>(instances + i * kInstanceStride);
+    const float4 a = p[0], b = p[1], c = p[2], d = p[3];
+    Instance v;
+    v.tx = a.x; v.ty = a.y; v.tz = a.z;
+    v.r00 = a.w; v.r01 = b.x; v.r02 = b.y;
+    v.r10 = b.z; v.r11 = b.w; v.r12 = c.x;
+    v.r20 = c.y; v.r21 = c.z; v.r22 = c.w;
+    v.dx = d.x; v.dy = d.y; v.dz = d.z;
+    return v;
+#else
+    return load_instance(instances, i);
+#endif
+}
+
 // ---- per-wave LDS ------------------------------------------------------------------------------------------------------------------
 //   4 x [ coarse S | fine S (first the sorted uniforms) | 16 pad | merged 2S (first: raw uniforms | cdf) | 16 + 4 pad ]   the first pad takes
 //       the tail of the per-point array below when 2S - 1 points are padded to whole rounds of 16, the second the tail of C2
@@ -377,7 +396,7 @@ __device__ __forceinline__ RoundCull quad_round_bounds(const RayCull& rc, int nu
 }
 // Step 2: bit i = instance i may matter on some lane (wave-uniform).  (NaN-safe: an undecidable comparison keeps the instance.)
 __device__ __forceinline__ unsigned long long quad_round_mask(const RayCull& rc, const RoundCull& cull, int num_instances, float t,
-                                                              unsigned long long real = ~0ull) {
+                                                              unsigned long long real = ~0ull, float widest = -1.0f) {
 #ifndef VSRD_CULL_PARTIAL
     const float shift = cull.err;
 #else
@@ -385,6 +404,27 @@ __device__ __forceinline__ unsigned long long quad_round_mask(const RayCull& rc,
 #endif
     unsigned long long mask = 0ull;
     int i = 0;
+#ifndef VSRD_CULL_PER_INSTANCE_RADIUS
+    // Round 4: one threshold per lane from the WIDEST instance's bounding radius (field_bounds: max |dim|) instead of one per (lane,
+    // instance): two instructions and an LDS read less per pair, a margin looser by at most max|dim| - min|dim| (1.1 m between the
+    // reference's smallest and largest box against 18 T + the nearest distance) -- conservative, so nothing the tests see changes (the
+    // benchmark's final loss is bit-identical); config 2: 218.3 -> 221.3 Mrays/s, config 5: 29.15 -> 29.50.  `widest` < 0: no such
+    // bound (field_bounds found rotations that are not orthonormal): the per-instance radii of the coefficient rows.
+    if (widest >= 0.0f) {
+        const float reach = cull.limit + widest;
+        const float threshold = fmaf(reach, reach, shift);
+#pragma unroll 4
+        for (; i + 4 <= num_instances; i += 4) {
+            float e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = centre_partial(rc, i + j, t);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mask |= (__ballot(!(e[j] > threshold)) != 0ull) ? (1ull << (i + j)) : 0ull;
+        }
+        for (; i < num_instances; ++i) mask |= (__ballot(!(centre_partial(rc, i, t) > threshold)) != 0ull) ? (1ull << i) : 0ull;
+        return mask & real;
+    }
+#endif
 #pragma unroll 4
     for (; i + 4 <= num_instances; i += 4) {
         float e[4], radius[4];
@@ -431,7 +471,7 @@ __device__ __forceinline__ UnionSums quad_union_loop(const float* __restrict__ i
     int slot = 0;
     for (unsigned long long todo = evaluated; todo != 0ull; todo &= todo - 1ull) {
         const int i = __builtin_ctzll(todo);
-        const Instance in = load_instance(instances, i);
+        const Instance in = load_instance_block(instances, i);
         BoxEval e = box_value<kYaw>(in, x, y, z);
         const unsigned long long near = __ballot(!(e.d - best > sh.cull));
         if (near == 0ull) { evaluated &= ~(1ull << i); continue; }
@@ -451,7 +491,7 @@ __device__ __forceinline__ float quad_cached_term(const float* __restrict__ inst
                                                   float m, float inv_t) {
     if (!kBySlot) return dcache[i * kWave + lane];
     if (slot < kCacheSlots) return dcache[slot * kWave + lane];
-    const float d = box_value<kYaw>(load_instance(instances, i), x, y, z).d;
+    const float d = box_value<kYaw>(load_instance_block(instances, i), x, y, z).d;
     return kRunning ? d : fast_exp(-(d - m) * inv_t);
 }
 
@@ -487,7 +527,7 @@ __device__ __forceinline__ bool quad_pass_one(const float* __restrict__ instance
         const QuadPoint p = quad_point<kL>(coarse, num_points, k, rr.ray, true, rl);
         const RoundCull cull = quad_round_bounds(rc, N, p.mid, sh.cull);
         if (quad_round_is_empty(rc, cull, sh, p.delta)) continue;                // alpha = 0 exactly: the transmittance passes unchanged
-        unsigned long long evaluated = quad_round_mask(rc, cull, N, p.mid, real);
+        unsigned long long evaluated = quad_round_mask(rc, cull, N, p.mid, real, sh.reach >= 0.0f ? sh.reach * (1.0f / (1.0f - kCullSlack)) : -1.0f);
         const float floor = cull.nearest_lo - sh.reach;
         if (!kRunning && wave_any(!((cull.nearest_hi + 1.0f - floor) * sh.inv_t <= kUnionFloorSpan))) return false;
         const UnionSums sums = quad_union_loop<false, false, kRunning, kYaw>(instances, evaluated, sh, cull, floor, p.x, p.y, p.z, nullptr, rl.lane);
@@ -546,7 +586,7 @@ __device__ __forceinline__ bool quad_forward_sweep(QuadAdjoint<kRounds>& st, con
             const QuadPoint p = quad_point<kL>(merged, num_points, q, rr.ray, live, rl);
             const RoundCull cull = quad_round_bounds(rc, N, p.mid, sh.cull);
             if (quad_round_is_empty(rc, cull, sh, p.delta)) continue;            // alpha = 0 exactly: no weight, no label, no adjoint
-            st.near[q] = quad_round_mask(rc, cull, N, p.mid, real);
+            st.near[q] = quad_round_mask(rc, cull, N, p.mid, real, sh.reach >= 0.0f ? sh.reach * (1.0f / (1.0f - kCullSlack)) : -1.0f);
             const float floor = cull.nearest_lo - sh.reach;
             if (!kRunning && wave_any(!((cull.nearest_hi + 1.0f - floor) * sh.inv_t <= kUnionFloorSpan))) return false;
             const UnionSums sums = quad_union_loop<true, (kL > kRowLanes), kRunning, kYaw>(instances, st.near[q], sh, cull, floor, p.x, p.y, p.z, dcache, rl.lane);
@@ -616,7 +656,7 @@ __device__ __forceinline__ unsigned quad_reverse_sweep(QuadAdjoint<kRounds>& st,
         } else {
             for (unsigned long long todo = st.near[q] & lam_any; todo != 0ull; todo &= todo - 1ull) {
                 const int i = __builtin_ctzll(todo);
-                const Instance in = load_instance(instances, i);
+                const Instance in = load_instance_block(instances, i);
                 acc += coef_own[kCullCoefs * i + 3] * fast_exp(-(box_value<kYaw>(in, p.x, p.y, p.z).d - st.m[q]) * sh.inv_t);
             }
         }
@@ -672,7 +712,7 @@ __device__ __forceinline__ void quad_phase_b(const QuadAdjoint<kRounds>& st, con
     for (int q = 0; q < kRounds; ++q) todo |= ((flow >> q) & 1u) ? st.near[q] : 0ull;
     for (; todo != 0ull; todo &= todo - 1ull) {
         const int i = __builtin_ctzll(todo);
-        const Instance in = load_instance(instances, i);
+        const Instance in = load_instance_block(instances, i);
         const float lam_i = coef_own[kCullCoefs * i + 3];
         float at0 = 0, at1 = 0, at2 = 0, ad0 = 0, ad1 = 0, ad2 = 0;
         float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
@@ -703,9 +743,13 @@ __device__ __forceinline__ void quad_phase_b(const QuadAdjoint<kRounds>& st, con
             const float qbz = d_bar * e.hz + ((e.qz > 0.0f) ? (vz - hz * hv) * inv_n : 0.0f);
             const float pbx = sx * qbx, pby = sy * qby, pbz = sz * qbz;
             ad0 -= qbx; ad1 -= qby; ad2 -= qbz;
-            r00 += e.relx * pbx + gwbx * e.glx; r01 += e.relx * pby + gwbx * e.gly; r02 += e.relx * pbz + gwbx * e.glz;
-            r10 += e.rely * pbx + gwby * e.glx; r11 += e.rely * pby + gwby * e.gly; r12 += e.rely * pbz + gwby * e.glz;
-            r20 += e.relz * pbx + gwbz * e.glx; r21 += e.relz * pby + gwbz * e.gly; r22 += e.relz * pbz + gwbz * e.glz;
+            r00 += e.relx * pbx + gwbx * e.glx; r02 += e.relx * pbz + gwbx * e.glz;
+            r20 += e.relz * pbx + gwbz * e.glx; r22 += e.relz * pbz + gwbz * e.glz;
+            if (!(kYaw && sh.yaw_gradients)) {           // (wave-uniform) the entries rotation_matrix_y keeps constant: nobody reads their adjoints
+                r01 += e.relx * pby + gwbx * e.gly;
+                r10 += e.rely * pbx + gwby * e.glx; r11 += e.rely * pby + gwby * e.gly; r12 += e.rely * pbz + gwby * e.glz;
+                r21 += e.relz * pby + gwbz * e.gly;
+            }
             if (kYaw) {
                 at0 -= in.r00 * pbx + in.r02 * pbz; at1 -= pby; at2 -= in.r20 * pbx + in.r22 * pbz;
             } else {
@@ -891,11 +935,20 @@ __device__ __forceinline__ void silhouette_rows_kernel_body(
     Shading sh = c.sh;
     const FieldBounds bounds = field_bounds(instances, N, f.inv_t, false, c.flags);
     sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
+    sh.yaw_gradients = sh.yaw && (c.flags & 1024u) != 0u;                       // VSRD_FLAG_YAW_GRADIENTS
     sh.mlp_bits = 0u;
     sh.mlp_lds = nullptr;
     const bool hot_runs = sh.reach >= 0.0f && sh.yaw;                          // (wave-uniform, the same in both kernels of the launch)
     if (kHot && !hot_runs) return;
     if (kHot && blockIdx.x == 0 && threadIdx.x == 0) redo_summary[1] = 1u;
+#ifdef VSRD_INSTANCE_LDS
+    if (kHot && kFull && kL == kRowLanes) {                                     // (the host adds N x 16 floats behind the waves' partitions)
+        float* block = lds + waves_per_block() * quad_lds_floats(S, NP, kL);
+        for (int idx = static_cast<int>(threadIdx.x); idx < N * kInstanceStride; idx += static_cast<int>(blockDim.x)) block[idx] = instances[idx];
+        __syncthreads();
+        instances = block;
+    }
+#endif
     float loss_acc = 0.0f;
     float G[kG];
 #pragma unroll
@@ -1157,6 +1210,7 @@ __device__ __forceinline__ void backward_rows_kernel_body(
     Shading sh = c.sh;
     const FieldBounds bounds = field_bounds(instances, N, f.inv_t, false, c.flags);
     sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
+    sh.yaw_gradients = sh.yaw && (c.flags & 1024u) != 0u;                       // VSRD_FLAG_YAW_GRADIENTS
     sh.mlp_bits = 0u;
     sh.mlp_lds = nullptr;
     float G[kG];

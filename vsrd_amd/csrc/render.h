@@ -20,6 +20,8 @@ struct Shading {
     float cull;     // culling margin (field.h), wave-uniform; +huge disables culling
     float reach;    // soft-min floor: every d_i >= nearest centre distance - reach (field.h: field_bounds); < 0: running minimum
     bool yaw;       // every rotation is exactly a rotation about y (field.h: box_value<true>)
+    bool yaw_gradients;  // ... and the caller differentiates only through rotation_matrix_y (VSRD_FLAG_YAW_GRADIENTS): the adjoints of the
+                         //     five constant entries of the rotation are not accumulated
     float std;      // sdf_std_deviation
     float inv_std;  // 1 / sdf_std_deviation
     float ratio;    // cosine_ratio

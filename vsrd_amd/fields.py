@@ -38,6 +38,10 @@ class FieldBlock:
     mlp_weights: Optional[torch.Tensor]      # [N,1617] or None
     label_indices: Optional[torch.Tensor]    # instance_label of every instance (None = 0..N-1 in order)
     hard: bool = False
+    # the rotations were built by rotation_matrix_y(cos, sin) (BoxParameters3D) and are differentiated only through it: the kernels may
+    # leave the adjoints of the five constant matrix entries out (VSRD_FLAG_YAW_GRADIENTS).  Set by the code that built the block from a
+    # detector (FrameOptimizer, bench.build_union); never inferred from the closure tree of a drop-in call.
+    yaw_gradients: bool = False
 
     @property
     def num_instances(self):

@@ -327,7 +327,7 @@ class FrameOptimizer:
         weights = cfg.loss_weights
         eikonal_ratio = weights["eikonal_loss"] / weights["silhouette_loss"] if residual else 0.0
         from .rendering import renderers
-        flags = renderers._base_flags()
+        flags = renderers._base_flags() | _lib.FLAG_YAW_GRADIENTS      # (the prologue decodes rotation_matrix_y; the epilogue reads r00, r02, r20, r22 only)
         mlp_weights = centred = None
         if fused_net:
             centred = b["mlp_centred"]
@@ -402,7 +402,7 @@ class FrameOptimizer:
 
     def field_block(self, outputs, temperature, mlp_weights=None):
         return fields.FieldBlock(fields.pack_instances(outputs["locations"][0], outputs["orientations"][0], outputs["dimensions"][0]),
-                                 float(temperature), mlp_weights, None)
+                                 float(temperature), mlp_weights, None, yaw_gradients=True)      # (BoxParameters3D: rotation_matrix_y)
 
     def step(self, ray_indices: Optional[torch.Tensor] = None, u_coarse=None, u_fine=None):
         """One optimisation step.  Steps < warmup_steps optimise the boxes only; later steps add the per-instance residual MLP

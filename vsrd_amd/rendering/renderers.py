@@ -669,7 +669,7 @@ def silhouette_step(distance_field, ray_positions, ray_directions, targets, dist
     if u_coarse is not None:
         u_coarse = u_coarse.reshape(-1, num_samples).to(torch.float32).contiguous()
         u_fine = u_fine.reshape(-1, num_samples).to(torch.float32).contiguous()
-    flags = (_lib.FLAG_SKIP_EXACT_MISSES if skip_exact_misses else 0) | _base_flags()
+    flags = (_lib.FLAG_SKIP_EXACT_MISSES if skip_exact_misses else 0) | _base_flags() | (_lib.FLAG_YAW_GRADIENTS if block.yaw_gradients else 0)
     scalars = (float(sdf_std_deviation), float(cosine_ratio), float(epsilon), float(distance_range[0]), float(distance_range[1]), int(num_samples), schedule)
     if residual:
         loss, terms, labels = _ResidualStep.apply(block.instances, block.mlp_weights, origins, directions, ordered, weights, u_coarse, u_fine,
