@@ -924,6 +924,7 @@ __device__ __forceinline__ void silhouette_rows_kernel_body(
     const int lane0 = lane_id();
     static_assert(kHot || !kFull, "only the hot kernel is instantiated for a full shape");
     if (kFull) c.num_samples = kL * kRoundsS;                                   // (the host launches kFull for exactly this S)
+    c.ray_indices = nullptr; c.target_columns = nullptr; c.rays_per_origin = 0;  // (these kernels take dense launches only: api.hip)
     const int S = c.num_samples;
     const int N = f.num_instances;
     const int NP = kFull ? (kL == kRowLanes ? kQuadMaxInstances : kPairMaxInstances) : N;      // rows of the instance tables
