@@ -154,10 +154,17 @@ def _check_render_case(name, tol_labels, tol_grad):
     torch.testing.assert_close(fine.labels, g["fine_labels"], rtol=1e-4, atol=tol_labels)
     torch.testing.assert_close(fine.weights, g["fine_weights"].t(), rtol=1e-3, atol=tol_labels)
     # (field gradients at samples the ill-conditioned division above displaced by ~1e-3 m differ visibly where instances overlap:
-    #  all but a handful of entries must agree tightly, the handful loosely)
+    #  every gradient at a sample that did NOT move must agree tightly; only the displaced ones -- a few percent of the samples --
+    #  get the loose bound, and at most 0.1 % of all entries may need it)
     got_g, want_g = fine.gradients[~miss], g["fine_gradients"].transpose(0, 1)[~miss]
-    off = (got_g - want_g).abs() > 1e-4 + 1e-3 * want_g.abs()
-    assert off.float().mean() <= 1e-3 and (got_g - want_g).abs().max() < 5e-3, (int(off.sum()), float((got_g - want_g).abs().max()))
+    got_d, want_d = fine.distances[~miss], g["fine_distances"].t()[~miss]
+    moved = (got_d - want_d).abs() > 1e-5 + 1e-6 * want_d.abs()                                          # samples the sampler displaced
+    moved = (moved[:, :-1] | moved[:, 1:]).unsqueeze(-1).expand_as(got_g)                                # (gradients live at the midpoints)
+    error = (got_g - want_g).abs().detach()
+    tight = error <= 1e-4 + 1e-3 * want_g.abs()
+    assert bool(tight[~moved].all()), (int((~tight & ~moved).sum()), float(error[~moved].max()))          # every sample that stayed: tight
+    assert moved.float().mean() <= 5e-2 and (~tight).float().mean() <= 1e-3 and float(error.max()) < 5e-3, \
+        (float(moved.float().mean()), int((~tight).sum()), float(error.max()))
     # losses and parameter gradients
     bce = losses.silhouette_loss(fine.labels, g["targets"])
     eik = losses.eikonal_loss(fine.gradients)
