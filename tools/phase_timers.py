@@ -92,6 +92,10 @@ def main():
     print(f"{report['workload']}: {ms:.2f} ms/step")
     for i, name in enumerate(PHASES):
         print(f"  {ticks[i] / total * 100:6.2f} %  ~{ticks[i] / total * ms:7.2f} ms  {name}")
+    if ticks[8]:
+        report["instance_loops"] = {"rounds": ticks[8], "past_the_bound_test_per_round": ticks[9] / ticks[8], "survivors_per_round": ticks[10] / ticks[8]}
+        print(f"  instance loops (multi-ray kernels): {ticks[8]} rounds, {ticks[9] / ticks[8]:.2f} instances past the bound test and "
+              f"{ticks[10] / ticks[8]:.2f} past the exact test per round")
     print(json.dumps(report))
 
 

@@ -62,6 +62,7 @@ struct BoxEval {
     float qx, qy, qz;         // |p| - half extents
     float hx, hy, hz;         // d d / d q
     float nrm;                // sqrt(sum relu(q)^2 + 1e-6)
+    float inv;                // 1 / nrm
     float qmax;               // max_j q_j
     float d;                  // signed distance
     float glx, gly, glz;      // local gradient  sign(p) * h
@@ -93,10 +94,26 @@ __device__ __forceinline__ BoxEval box_value(const Instance& in, float x, float 
     }
     e.qx = fabsf(e.px) - in.dx; e.qy = fabsf(e.py) - in.dy; e.qz = fabsf(e.pz) - in.dz;
     const float ax = fmaxf(e.qx, 0.0f), ay = fmaxf(e.qy, 0.0f), az = fmaxf(e.qz, 0.0f);
+    // |v| = s rsq(s) and 1 / |v| = rsq(s): ONE transcendental per evaluation instead of v_sqrt + v_rcp (a quarter-rate instruction costs
+    // three multiply-adds).  Both forms are within 1.5 ulp of the exact norm; round 4: config 2 229 -> 234 Mrays/s, config 5 30.1 -> 30.7.
+    // -DVSRD_BOX_SQRT_RCP: the form of rounds 1-3.
+#ifndef VSRD_BOX_SQRT_RCP
+    const float squares = ax * ax + ay * ay + az * az + kNormEpsilon;
+    e.inv = fast_rsq(squares);
+    e.nrm = squares * e.inv;
+    asm volatile("" : "+v"(e.nrm));      // (a rounded product in EVERY instantiation: without this some of them fuse it into the subtraction below,
+                                         //  and kernels that differ in the last bit of a distance differ by 1e-4 in summed gradients -- see above)
+#else
     e.nrm = fast_sqrt(ax * ax + ay * ay + az * az + kNormEpsilon);
+    e.inv = fast_rcp(e.nrm);
+#endif
     e.qmax = fmaxf(fmaxf(e.qx, e.qy), e.qz);                            // one v_max3_f32
     e.d = e.nrm - fmaxf(-e.qmax, 0.0f);
     return e;
+}
+
+__device__ __forceinline__ float box_inverse_norm(const BoxEval& e) {
+    return e.inv;
 }
 
 // gw_k = sum_j R_kj gl_j
@@ -122,7 +139,7 @@ __device__ __forceinline__ void rotate_to_world(BoxEval& e, const Instance& in) 
 // form, and no faster: the fused step kernel is bound by its multiply-add stream, tools/micro/op_rates.hip.)
 template <bool kYaw = false>
 __device__ __forceinline__ void box_gradient(BoxEval& e, const Instance& in) {
-    const float inv = fast_rcp(e.nrm);
+    const float inv = box_inverse_norm(e);
     const bool inside = e.qmax < 0.0f;
     const bool first_x = e.qx == e.qmax;
     const bool first_y = !first_x && (e.qy == e.qmax);

@@ -79,19 +79,27 @@ __device__ __forceinline__ float seg_inclusive_sum(float v) {          // prefix
 }
 template <int kL>
 __device__ __forceinline__ float seg_inclusive_product(float v) {
+#ifndef VSRD_NO_DPP_INPLACE
+    v = mul_shr8(mul_shr4(mul_shr2(mul_shr1(v))));
+#else
     v *= dpp_move<kDppRowShr1>(1.0f, v);
     v *= dpp_move<kDppRowShr2>(1.0f, v);
     v *= dpp_move<kDppRowShr4>(1.0f, v);
     v *= dpp_move<kDppRowShr8>(1.0f, v);
+#endif
     if (kL == 32) v *= dpp_move<kDppRowBcast15, 0xa>(1.0f, v);
     return v;
 }
 template <int kL>
 __device__ __forceinline__ float seg_inclusive_max(float v) {
+#ifndef VSRD_NO_DPP_INPLACE
+    v = max_shr8(max_shr4(max_shr2(max_shr1(v))));
+#else
     v = fmaxf(v, dpp_move<kDppRowShr1>(v, v));
     v = fmaxf(v, dpp_move<kDppRowShr2>(v, v));
     v = fmaxf(v, dpp_move<kDppRowShr4>(v, v));
     v = fmaxf(v, dpp_move<kDppRowShr8>(v, v));
+#endif
     if (kL == 32) v = fmaxf(v, dpp_move<kDppRowBcast15, 0xa>(v, v));
     return v;
 }
@@ -155,18 +163,22 @@ __device__ __forceinline__ Instance load_instance_block(const float* __restrict_
 // (the sorted distances are followed by `lanes` + 4 floats: the reverse sweep writes C2 of point s at merged[s + 1] for EVERY lane of a
 //  round, padding lanes included, i.e. up to index roundup(2S - 1, lanes) -- without the room a row's padding lanes overwrote the next
 //  row's transmittances of round 0 whenever 2S - 1 is not just below a multiple of `lanes`: found by the shape sweep of round 3)
+constexpr int kRowRayFloats = 8;           // a ray in LDS: ox oy oz rx | ry rz reach pad
 __host__ __device__ constexpr int quad_row_floats(int num_samples, int lanes = kRowLanes) { return 4 * num_samples + 2 * lanes + 4; }
 __host__ __device__ constexpr int quad_merged_offset(int num_samples, int lanes = kRowLanes) { return 2 * num_samples + lanes; }
 __host__ __device__ constexpr int quad_coef_floats(int num_instances) { return kCullCoefs * num_instances + 4; }
 __host__ __device__ constexpr int quad_rounds_s(int num_samples, int lanes = kRowLanes) {          // rounds of `lanes` coarse points: 1, 2 or 4
     return num_samples <= lanes ? 1 : (num_samples <= 2 * lanes ? 2 : 4);
 }
-constexpr int kCacheSlots = 16;          // shapes with more instances than lanes per ray: soft-min terms of the first 16 survivors of a round
+#ifndef VSRD_CACHE_SLOTS
+#define VSRD_CACHE_SLOTS 16
+#endif
+constexpr int kCacheSlots = VSRD_CACHE_SLOTS;   // (>= 16: the rows also hold C1 / C3 of the eight pass-2 rounds) shapes with more instances than lanes per ray: soft-min terms of the first 16 survivors of a round
 __host__ __device__ constexpr int quad_cache_rows(int num_samples, int num_instances, int lanes = kRowLanes) {   // [rows][64]: soft-min terms of a round, later C1 / C3 of every pass-2 round
     return lanes == kRowLanes ? (num_instances > 4 * quad_rounds_s(num_samples, lanes) ? num_instances : 4 * quad_rounds_s(num_samples, lanes)) : kCacheSlots;
 }
 __host__ __device__ constexpr int quad_lds_floats(int num_samples, int num_instances, int lanes = kRowLanes) {
-    return (kWave / lanes) * (quad_row_floats(num_samples, lanes) + quad_coef_floats(num_instances) + 8) + quad_cache_rows(num_samples, num_instances, lanes) * kWave;
+    return (kWave / lanes) * (quad_row_floats(num_samples, lanes) + quad_coef_floats(num_instances) + kRowRayFloats) + quad_cache_rows(num_samples, num_instances, lanes) * kWave;
 }
 
 // Stratified distances and sorted fine uniforms of the lane's ray (render_kernels.h: stage_ray_samples, per 16-lane row).
@@ -331,6 +343,7 @@ __device__ __forceinline__ RayCull row_cull(const float* coef, const RowRay& r) 
     rc.coef = coef;
     rc.c2 = r.ray.rx * r.ray.rx + r.ray.ry * r.ray.ry + r.ray.rz * r.ray.rz;
     rc.rnorm = fast_sqrt(rc.c2);
+    // (r.r, |r| and max(1, |r|) / 2 kept in the ray's LDS row instead of being re-derived by every round: tried in round 4, neutral)
     rc.reach = r.reach;
     return rc;
 }
@@ -469,18 +482,28 @@ __device__ __forceinline__ UnionSums quad_union_loop(const float* __restrict__ i
     UnionSums sums = union_init(kRunning, floor);
     float best = cull.nearest_hi;
     int slot = 0;
+#ifdef VSRD_PHASE_TIMERS
+    const int candidates = __builtin_popcountll(evaluated);       // (tools/phase_timers.py: rounds, instances past the bound test, survivors)
+#endif
+    // (a form with two nested loops -- the inner one looking for the next instance past the exact test -- lets the compiler update the sums
+    //  in place and drops the nine register copies this loop ends with, 12 of 70 vector instructions per instance: 1.5 % SLOWER on config 2;
+    //  the copies are nearly free and the longer scalar chain between the test and the branch is not)
     for (unsigned long long todo = evaluated; todo != 0ull; todo &= todo - 1ull) {
         const int i = __builtin_ctzll(todo);
         const Instance in = load_instance_block(instances, i);
         BoxEval e = box_value<kYaw>(in, x, y, z);
         const unsigned long long near = __ballot(!(e.d - best > sh.cull));
         if (near == 0ull) { evaluated &= ~(1ull << i); continue; }
-        best = fminf(best, e.d);
+        best = min_raw(best, e.d);
         box_gradient<kYaw>(e, in);
         const float term = union_accumulate<kRunning, false>(sums, e.d, e.gwx, e.gwy, e.gwz, 0.0f, sh.inv_t);
         if (kCache && (!kBySlot || slot < kCacheSlots)) dcache[(kBySlot ? slot : i) * kWave + lane] = term;
         ++slot;
     }
+#ifdef VSRD_PHASE_TIMERS
+    if (lane == 0) { atomicAdd(&g_phase_cycles[8], 1ull); atomicAdd(&g_phase_cycles[9], static_cast<unsigned long long>(candidates));
+                     atomicAdd(&g_phase_cycles[10], static_cast<unsigned long long>(slot)); }
+#endif
     return sums;
 }
 
@@ -735,7 +758,7 @@ __device__ __forceinline__ void quad_phase_b(const QuadAdjoint<kRounds>& st, con
             const float glbx = cc * rgx, glby = cc * rgy, glbz = cc * rgz;
             const float sx = sign_of(e.px), sy = sign_of(e.py), sz = sign_of(e.pz);
             const float vx = sx * glbx, vy = sy * glby, vz = sz * glbz;
-            const float inv_n = fast_rcp(e.nrm);
+            const float inv_n = box_inverse_norm(e);
             const float hx = fmaxf(e.qx, 0.0f) * inv_n, hy = fmaxf(e.qy, 0.0f) * inv_n, hz = fmaxf(e.qz, 0.0f) * inv_n;
             const float hv = hx * vx + hy * vy + hz * vz;
             const float qbx = d_bar * e.hx + ((e.qx > 0.0f) ? (vx - hx * hv) * inv_n : 0.0f);
@@ -814,13 +837,13 @@ __device__ __forceinline__ bool quad_step_body(const float* __restrict__ instanc
         const float* d = directions + src * 3;
         Ray r;
         r.ox = o[0]; r.oy = o[1]; r.oz = o[2]; r.rx = d[0]; r.ry = d[1]; r.rz = d[2];
-        quad_ray_setup<kL>(instances, N, NP, r, coef_own, rays + rl.row * 8, rl);
+        quad_ray_setup<kL>(instances, N, NP, r, coef_own, rays + rl.row * kRowRayFloats, rl);
     }
     quad_stage_samples<kL, kRoundsS>(rowbase, c, S, ray, u_coarse, u_fine, sorted_input, rl);
     VSRD_PHASE(0);
     // ---- pass 1 ----------------------------------------------------------------------------------------------------------------
     float w1[kRoundsS];
-    if (!quad_pass_one<kL, kRoundsS, kYaw, kRunning>(instances, NP, sh, rays + rl.row * 8, coef_own, rowbase, S, w1, rl, real)) return false;
+    if (!quad_pass_one<kL, kRoundsS, kYaw, kRunning>(instances, NP, sh, rays + rl.row * kRowRayFloats, coef_own, rowbase, S, w1, rl, real)) return false;
     VSRD_PHASE(1);
     float coarse_total = 0.0f;
 #pragma unroll
@@ -836,7 +859,7 @@ __device__ __forceinline__ bool quad_step_body(const float* __restrict__ instanc
     QuadAdjoint<kRounds> st;
     // rows that do not take part shadow the first live row (same points, same votes in the culling ballots, zero weight)
     const int data_row = live ? rl.row : (live_lanes != 0ull ? (__builtin_ctzll(live_lanes) / kL) : rl.row);
-    const float* rayp = rays + data_row * 8;
+    const float* rayp = rays + data_row * kRowRayFloats;
     const float* merged = stage + data_row * quad_row_floats(S, kL) + quad_merged_offset(S, kL);
     float* trans_mid = rowbase;                                              // (the row's own: a shadow row's transmittances are all 1)
     if (live_lanes != 0ull) {
@@ -1033,11 +1056,11 @@ __device__ __forceinline__ bool rows_forward_body(const float* __restrict__ inst
         const float* d = directions + static_cast<size_t>(ray) * 3;
         Ray r;
         r.ox = o[0]; r.oy = o[1]; r.oz = o[2]; r.rx = d[0]; r.ry = d[1]; r.rz = d[2];
-        quad_ray_setup<kL>(instances, N, N, r, coef_own, rays + rl.row * 8, rl);
+        quad_ray_setup<kL>(instances, N, N, r, coef_own, rays + rl.row * kRowRayFloats, rl);
     }
     quad_stage_samples<kL, kRoundsS>(rowbase, c, S, ray, u_coarse, u_fine, sorted_input, rl);
     float w1[kRoundsS];
-    if (!quad_pass_one<kL, kRoundsS, kYaw, kRunning>(instances, N, sh, rays + rl.row * 8, coef_own, rowbase, S, w1, rl)) return false;
+    if (!quad_pass_one<kL, kRoundsS, kYaw, kRunning>(instances, N, sh, rays + rl.row * kRowRayFloats, coef_own, rowbase, S, w1, rl)) return false;
     float coarse_total = 0.0f;
 #pragma unroll
     for (int k = 0; k < kRoundsS; ++k) coarse_total += seg_sum<kL>(w1[k]);
@@ -1052,7 +1075,7 @@ __device__ __forceinline__ bool rows_forward_body(const float* __restrict__ inst
         QuadAdjoint<kRounds> st;
         const int data_row = live ? rl.row : (__builtin_ctzll(live_lanes) / kL);
         quad_importance_merge<kL, kRoundsS>(rowbase, S, w1, rl);
-        if (!quad_forward_sweep<kL, kRounds, kYaw, kRunning>(st, instances, N, sh, rays + data_row * 8, coefs + data_row * quad_coef_floats(N),
+        if (!quad_forward_sweep<kL, kRounds, kYaw, kRunning>(st, instances, N, sh, rays + data_row * kRowRayFloats, coefs + data_row * quad_coef_floats(N),
                                                               stage + data_row * quad_row_floats(S, kL) + quad_merged_offset(S, kL), num_points, live, dcache,
                                                               rowbase, label, active, cached_round, rl)) return false;
     }
@@ -1146,7 +1169,7 @@ __device__ __forceinline__ bool rows_backward_body(const float* __restrict__ ins
         const float* d = directions + static_cast<size_t>(ray) * 3;
         Ray r;
         r.ox = o[0]; r.oy = o[1]; r.oz = o[2]; r.rx = d[0]; r.ry = d[1]; r.rz = d[2];
-        quad_ray_setup<kL>(instances, N, N, r, coef_own, rays + rl.row * 8, rl);       // (clears the label adjoints, syncs)
+        quad_ray_setup<kL>(instances, N, N, r, coef_own, rays + rl.row * kRowRayFloats, rl);       // (clears the label adjoints, syncs)
     }
     const float* src = distances + static_cast<size_t>(ray) * num_distances;
     float* own_merged = rowbase + quad_merged_offset(half, kL);
@@ -1176,7 +1199,7 @@ __device__ __forceinline__ bool rows_backward_body(const float* __restrict__ ins
     }
     wave_lds_sync();
     const int data_row = live ? rl.row : (__builtin_ctzll(live_lanes) / kL);
-    const float* rayp = rays + data_row * 8;
+    const float* rayp = rays + data_row * kRowRayFloats;
     const float* merged = stage + data_row * quad_row_floats(half, kL) + quad_merged_offset(half, kL);
     float label[kSlots];
     unsigned active = 0u;

@@ -575,7 +575,7 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
             const float glbx = cc * rgx, glby = cc * rgy, glbz = cc * rgz;       // gl_bar_j = sum_k R_kj gw_bar_k
             const float sx = sign_of(e.px), sy = sign_of(e.py), sz = sign_of(e.pz);
             const float vx = sx * glbx, vy = sy * glby, vz = sz * glbz;
-            const float inv_n = fast_rcp(e.nrm);
+            const float inv_n = box_inverse_norm(e);
             const float hx = fmaxf(e.qx, 0.0f) * inv_n, hy = fmaxf(e.qy, 0.0f) * inv_n, hz = fmaxf(e.qz, 0.0f) * inv_n;
             const float hv = hx * vx + hy * vy + hz * vz;
             const float qbx = d_bar * e.hx + ((e.qx > 0.0f) ? (vx - hx * hv) * inv_n : 0.0f);

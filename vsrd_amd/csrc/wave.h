@@ -44,6 +44,30 @@ __device__ __forceinline__ float dpp_move(float identity, float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v),
                                                                  kCtrl, kRowMask, kBankMask, false));
 }
+// In-place scan steps "v = v op v[lane - n]" inside a row of 16 as ONE DPP instruction: a lane whose source lies outside its row is
+// disabled by the instruction itself (no bound_ctrl) and keeps its value, so no identity register is needed -- the compiler's form of
+// `v *= dpp_move(1.0f, v)` is v_mov 1.0 + v_mov_dpp + v_mul (and for fmaxf two canonicalising v_max on top).  The wait states a VALU
+// write needs before a DPP read are in the string (-DVSRD_NO_DPP_INPLACE: the compiler's form).
+#ifndef VSRD_NO_DPP_INPLACE
+#define VSRD_DPP_STEP(NAME, OP, CTRL)                                                                              \
+    __device__ __forceinline__ float NAME(float v) {                                                               \
+        asm volatile("s_nop 1\n\t" OP " %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(v));                \
+        return v;                                                                                                  \
+    }
+VSRD_DPP_STEP(mul_shr1, "v_mul_f32_dpp", "row_shr:1") VSRD_DPP_STEP(mul_shr2, "v_mul_f32_dpp", "row_shr:2")
+VSRD_DPP_STEP(mul_shr4, "v_mul_f32_dpp", "row_shr:4") VSRD_DPP_STEP(mul_shr8, "v_mul_f32_dpp", "row_shr:8")
+VSRD_DPP_STEP(max_shr1, "v_max_f32_dpp", "row_shr:1") VSRD_DPP_STEP(max_shr2, "v_max_f32_dpp", "row_shr:2")
+VSRD_DPP_STEP(max_shr4, "v_max_f32_dpp", "row_shr:4") VSRD_DPP_STEP(max_shr8, "v_max_f32_dpp", "row_shr:8")
+#undef VSRD_DPP_STEP
+// min / max of two values that are known not to be signalling NaNs: one instruction (fminf / fmaxf canonicalise both operands first
+// whenever the compiler cannot prove them canonical, e.g. a value carried around a loop)
+__device__ __forceinline__ float min_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float max_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#else
+__device__ __forceinline__ float min_raw(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ float max_raw(float a, float b) { return fmaxf(a, b); }
+#endif
+
 constexpr int kDppQuadXor1 = 0xB1;       // quad_perm:[1,0,3,2]
 constexpr int kDppQuadXor2 = 0x4E;       // quad_perm:[2,3,0,1]
 constexpr int kDppRowHalfMirror = 0x141;
@@ -149,18 +173,20 @@ __device__ __forceinline__ float wave_shift_up(float v, float first, int lane) {
 __device__ __forceinline__ float wave_reverse(float v, int lane) { return __shfl(v, kWave - 1 - lane, kWave); }
 
 // ---- fast fp32 math -----------------------------------------------------------------------------------
-// One hardware transcendental each (v_rcp_f32 / v_sqrt_f32 / v_exp_f32, <= 1 ulp) instead of the
+// One hardware transcendental each (v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 / v_exp_f32, <= 1 ulp) instead of the
 // correctly-rounded expansions (~10 instructions for a division).  The reference tolerance is 1e-4 on the
 // silhouettes (BASELINE.json), five orders of magnitude above what these change; VSRD_PRECISE_MATH=1
 // restores the IEEE sequences for A/B runs.
 #ifndef VSRD_PRECISE_MATH
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
 #else
 __device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
 __device__ __forceinline__ float fast_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return 1.0f / sqrtf(x); }
 __device__ __forceinline__ float fast_exp(float x) { return expf(x); }
 __device__ __forceinline__ float fast_log(float x) { return logf(x); }
 #endif
