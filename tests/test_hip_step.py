@@ -622,6 +622,56 @@ def test_rebind_after_tensors_are_replaced_mid_frame(dev, how):
         assert torch.equal(plain[3][name], disturbed[3][name]), name
 
 
+def test_graphs_are_destroyed_only_while_nobody_captures(dev):
+    """On ROCm torch.cuda.CUDAGraph's destructor synchronises the device, which HIP refuses while any thread of the process captures: a
+    frame that ended during the other frame's capture took its rank down about once in five runs of the frames/s launcher ("operation not
+    permitted when stream is capturing", thrown from ~CUDAGraph).  close() / rebind() must wait for the capture; the garbage collector's
+    path must not wait (it may run inside the capturing thread) and parks the graphs for the next holder of the lock."""
+    import threading
+    import time
+    from vsrd_amd import optimization
+    inputs = _c1_inputs(dev, all_visible=True)
+    config = optimization.OptimizationConfig(num_samples=32, num_rays=128, warmup_steps=12, num_steps=20, seed=3)
+    loops = [optimization.FrameOptimizer(inputs, config, dev, graph=True) for _ in range(2)]
+    for loop in loops:
+        for _ in range(8):                 # (a phase's first steps run eagerly; then its graph is captured)
+            loop.step()
+        assert loop._graphs
+    torch.cuda.synchronize()
+    capturing, release, errors = threading.Event(), threading.Event(), []
+
+    def capture():
+        try:
+            torch.cuda.set_device(dev)
+            stream, graph, x = torch.cuda.Stream(), torch.cuda.CUDAGraph(), torch.zeros(16, device=dev)
+            with optimization._capture_lock, torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+                x.add_(1.0)
+                capturing.set()
+                release.wait(10.0)
+                x.mul_(2.0)
+            with optimization._capture_lock:
+                del graph
+        except Exception as error:          # pragma: no cover
+            errors.append(error)
+            capturing.set()
+
+    thread = threading.Thread(target=capture)
+    thread.start()
+    assert capturing.wait(30.0) and not errors
+    optimization._destroy_graphs(loops[1]._graphs, wait=False)              # the collector's path: returns at once, graphs parked
+    assert not loops[1]._graphs and optimization._graveyard
+    timer = threading.Timer(0.5, release.set)
+    timer.start()
+    start = time.perf_counter()
+    loops[0].close()                                                         # blocks until the capture has ended, then destroys
+    waited = time.perf_counter() - start
+    thread.join(30.0)
+    assert not errors, errors
+    assert waited > 0.3 and not loops[0]._graphs and not optimization._graveyard
+    loops[1].close()
+    torch.cuda.synchronize()
+
+
 def test_graph_mode_keeps_the_race_sampler_for_concentrated_weights(dev):
     """A frame whose importance weights sit in hardly more pixels than a step draws fails RayTable.suits: graph mode then keeps the
     per-step exponential race on its own branch of the graph (vsrd_sample_rays), and the loop runs -- warm-up and residual phase,

@@ -171,14 +171,23 @@ __host__ __device__ constexpr int quad_rounds_s(int num_samples, int lanes = kRo
     return num_samples <= lanes ? 1 : (num_samples <= 2 * lanes ? 2 : 4);
 }
 #ifndef VSRD_CACHE_SLOTS
-#define VSRD_CACHE_SLOTS 16
+#define VSRD_CACHE_SLOTS 22       // (what three workgroups per CU leave room for at S = 128, N = 64: 52 160 of 54 613 bytes)
 #endif
 constexpr int kCacheSlots = VSRD_CACHE_SLOTS;   // (>= 16: the rows also hold C1 / C3 of the eight pass-2 rounds) shapes with more instances than lanes per ray: soft-min terms of the first 16 survivors of a round
-__host__ __device__ constexpr int quad_cache_rows(int num_samples, int num_instances, int lanes = kRowLanes) {   // [rows][64]: soft-min terms of a round, later C1 / C3 of every pass-2 round
-    return lanes == kRowLanes ? (num_instances > 4 * quad_rounds_s(num_samples, lanes) ? num_instances : 4 * quad_rounds_s(num_samples, lanes)) : kCacheSlots;
+// Two rays per wave: the terms of survivor k of a round start at float k * kSlotStride (64 lanes + 4: rows stay 16-byte aligned and
+// sixteen lanes reading sixteen DIFFERENT rows with ds_read_b128 touch every bank once -- quad_label_sums), and one more row holds the
+// lanes' label scales.  The same floats hold C1 / C3 of the eight pass-2 rounds afterwards ([16][64]).
+#ifndef VSRD_LABEL_LOOP
+constexpr int kSlotStride = kWave + 4;
+#else
+constexpr int kSlotStride = kWave;
+#endif
+__host__ __device__ constexpr int quad_cache_floats(int num_samples, int num_instances, int lanes = kRowLanes) {   // soft-min terms of a round, later C1 / C3 of every pass-2 round ([rows][64])
+    return lanes == kRowLanes ? (num_instances > 4 * quad_rounds_s(num_samples, lanes) ? num_instances : 4 * quad_rounds_s(num_samples, lanes)) * kWave
+                              : (kCacheSlots + 1) * kSlotStride;
 }
 __host__ __device__ constexpr int quad_lds_floats(int num_samples, int num_instances, int lanes = kRowLanes) {
-    return (kWave / lanes) * (quad_row_floats(num_samples, lanes) + quad_coef_floats(num_instances) + kRowRayFloats) + quad_cache_rows(num_samples, num_instances, lanes) * kWave;
+    return (kWave / lanes) * (quad_row_floats(num_samples, lanes) + quad_coef_floats(num_instances) + kRowRayFloats) + quad_cache_floats(num_samples, num_instances, lanes);
 }
 
 // Stratified distances and sorted fine uniforms of the lane's ray (render_kernels.h: stage_ray_samples, per 16-lane row).
@@ -497,7 +506,7 @@ __device__ __forceinline__ UnionSums quad_union_loop(const float* __restrict__ i
         best = min_raw(best, e.d);
         box_gradient<kYaw>(e, in);
         const float term = union_accumulate<kRunning, false>(sums, e.d, e.gwx, e.gwy, e.gwz, 0.0f, sh.inv_t);
-        if (kCache && (!kBySlot || slot < kCacheSlots)) dcache[(kBySlot ? slot : i) * kWave + lane] = term;
+        if (kCache && (!kBySlot || slot < kCacheSlots)) dcache[(kBySlot ? slot * kSlotStride : i * kWave) + lane] = term;
         ++slot;
     }
 #ifdef VSRD_PHASE_TIMERS
@@ -513,9 +522,34 @@ template <bool kBySlot, bool kRunning, bool kYaw>
 __device__ __forceinline__ float quad_cached_term(const float* __restrict__ instances, int i, int slot, const float* dcache, int lane, float x, float y, float z,
                                                   float m, float inv_t) {
     if (!kBySlot) return dcache[i * kWave + lane];
-    if (slot < kCacheSlots) return dcache[slot * kWave + lane];
+    if (slot < kCacheSlots) return dcache[slot * kSlotStride + lane];
     const float d = box_value<kYaw>(load_instance_block(instances, i), x, y, z).d;
     return kRunning ? d : fast_exp(-(d - m) * inv_t);
+}
+
+// Two rays per wave, fixed shift: the label sums of one round, transposed.  The instance loop left the soft-min term of survivor k at
+// every point in row k of the cache; lane (ray, k) multiplies its survivor's row with the ray's label scales (t alpha / Z per point) --
+// 32 multiply-adds on eight pairs of ds_read_b128 for ALL cached survivors at once, where one reduction per survivor costs a row
+// reduction (seven instructions) and two selects for each of the ~20 survivors of a config-5 round -- and the lane that owns instance n
+// fetches the sum of slot rank(n) = popcount(near & below(n)).  Survivors beyond the cache take the per-survivor path in the caller.
+__device__ __forceinline__ void quad_label_sums(float* dcache, float scale, unsigned long long near, float (&label)[2], const RowLanes& rl) {
+    float* scales = dcache + kCacheSlots * kSlotStride;
+    scales[rl.lane] = scale;
+    wave_lds_sync();
+    const int first = rl.lane & ~31;                                              // the ray's first lane = its first point's column
+    const float4* terms = reinterpret_cast<const float4*>(dcache + min(rl.col, kCacheSlots - 1) * kSlotStride + first);
+    const float4* factors = reinterpret_cast<const float4*>(scales + first);
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float4 e = terms[k], f = factors[k];
+        sum = fmaf(e.x, f.x, sum); sum = fmaf(e.y, f.y, sum); sum = fmaf(e.z, f.z, sum); sum = fmaf(e.w, f.w, sum);
+    }
+    const unsigned lo = static_cast<unsigned>(near), hi = static_cast<unsigned>(near >> 32), below = (1u << rl.col) - 1u;
+    const int rank0 = __builtin_popcount(lo & below), rank1 = __builtin_popcount(lo) + __builtin_popcount(hi & below);
+    const float sum0 = lane_gather(sum, (first + min(rank0, 31)) << 2), sum1 = lane_gather(sum, (first + min(rank1, 31)) << 2);
+    label[0] += (((lo >> rl.col) & 1u) && rank0 < kCacheSlots) ? sum0 : 0.0f;
+    label[1] += (((hi >> rl.col) & 1u) && rank1 < kCacheSlots) ? sum1 : 0.0f;
 }
 
 // One point per lane: the interval [dist[s], dist[s + 1]] of the lane's ray.
@@ -638,7 +672,15 @@ __device__ __forceinline__ bool quad_forward_sweep(QuadAdjoint<kRounds>& st, con
         trans[q * kL + rl.col] = t;
         const float scale = t * alpha * v.inv_z;
         int slot = 0;
-        for (unsigned long long todo = st.near[q]; todo != 0ull; todo &= todo - 1ull, ++slot) {
+        unsigned long long todo = st.near[q];
+#ifndef VSRD_LABEL_LOOP
+        if constexpr (kL > kRowLanes && !kRunning) {                               // the cached survivors at once; the loop below: the others
+            quad_label_sums(dcache, scale, st.near[q], label, rl);
+            if (__builtin_popcountll(todo) <= kCacheSlots) todo = 0ull;
+            for (; slot < kCacheSlots && todo != 0ull; ++slot) todo &= todo - 1ull;
+        }
+#endif
+        for (; todo != 0ull; todo &= todo - 1ull, ++slot) {
             const int i = __builtin_ctzll(todo);
             const float cached = quad_cached_term<(kL > kRowLanes), kRunning, kYaw>(instances, i, slot, dcache, rl.lane, px, py, pz, v.m, sh.inv_t);
             const float e = kRunning ? fast_exp(-(cached - v.m) * sh.inv_t) : cached;
@@ -953,7 +995,7 @@ __device__ __forceinline__ void silhouette_rows_kernel_body(
     const int NP = kFull ? (kL == kRowLanes ? kQuadMaxInstances : kPairMaxInstances) : N;      // rows of the instance tables
     float* stage = lds + wave * quad_lds_floats(S, NP, kL);
     float* dcache = stage + kRays * quad_row_floats(S, kL);
-    float* coefs = dcache + quad_cache_rows(S, NP, kL) * kWave;
+    float* coefs = dcache + quad_cache_floats(S, NP, kL);
     float* rays = coefs + kRays * quad_coef_floats(NP);
     const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
     Shading sh = c.sh;
@@ -1108,7 +1150,7 @@ __device__ __forceinline__ void hierarchical_rows_kernel_body(
     const int N = f.num_instances;
     float* stage = lds + wave * quad_lds_floats(S, N, kL);
     float* dcache = stage + kRays * quad_row_floats(S, kL);
-    float* coefs = dcache + quad_cache_rows(S, N, kL) * kWave;
+    float* coefs = dcache + quad_cache_floats(S, N, kL);
     float* rays = coefs + kRays * quad_coef_floats(N);
     const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
     Shading sh = c.sh;
@@ -1229,7 +1271,7 @@ __device__ __forceinline__ void backward_rows_kernel_body(
     const int N = f.num_instances;
     float* stage = lds + wave * quad_lds_floats(half, N, kL);
     float* dcache = stage + kRays * quad_row_floats(half, kL);
-    float* coefs = dcache + quad_cache_rows(half, N, kL) * kWave;
+    float* coefs = dcache + quad_cache_floats(half, N, kL);
     float* rays = coefs + kRays * quad_coef_floats(N);
     Shading sh = c.sh;
     const FieldBounds bounds = field_bounds(instances, N, f.inv_t, false, c.flags);

@@ -24,6 +24,25 @@ from . import _lib, fields, losses, models, operations, rendering
 
 
 _capture_lock = threading.Lock()
+_graveyard = []          # graphs whose owner went away while somebody captured: destroyed by the next holder of the lock
+
+
+def _destroy_graphs(graphs, wait=True):
+    """Destroy captured graphs where nobody captures.  On ROCm ``torch.cuda.CUDAGraph``'s destructor synchronises the DEVICE, which HIP
+    refuses while any thread of the process is capturing ("operation not permitted when stream is capturing": the frames/s launcher
+    lost a rank about once in five runs when one frame ended during the other frame's capture).  ``wait=False`` (garbage collection:
+    the collector may run inside the capturing thread itself) parks the graphs instead of blocking."""
+    if not graphs and not _graveyard:
+        return
+    if _capture_lock.acquire(blocking=wait):
+        try:
+            graphs.clear()
+            _graveyard.clear()
+        finally:
+            _capture_lock.release()
+    else:
+        _graveyard.append(list(graphs.values()))
+        graphs.clear()
 
 
 @dataclass
@@ -251,7 +270,7 @@ class FrameOptimizer:
         # the hypernetwork and the embeddings (residual phase) run through csrc/hypernetwork.h on the same footing: torch's module
         # owns the parameters, torch.optim.Adam owns the moments and counters, the kernels update both in place
         self._hypernetwork = hypernetwork_tensors(self.hyper_distance_field, det.embeddings, self.optimizer, cfg.lr_gamma)
-        self._graphs.clear()
+        _destroy_graphs(self._graphs)
         # references keep every bound tensor alive until the next rebind: a replaced tensor's memory is not handed to somebody else
         # while a graph that writes through its address may still be replayed
         self._bound = self._bound_tensors()
@@ -585,9 +604,15 @@ class FrameOptimizer:
             import warnings
             warnings.warn("vsrd_sample_rays overflowed its candidate list in some step of this frame: those draws were incomplete "
                           "(many equal importance weights in one histogram bin); see csrc/ray_sampling.h", RuntimeWarning)
-        self._graphs.clear()
+        _destroy_graphs(self._graphs)
         self.ray_table = None                  # (43 MB per frame at the reference's size: the table and its guide)
         self.workspace.release()
+
+    def __del__(self):
+        try:
+            _destroy_graphs(self._graphs, wait=False)
+        except Exception:                      # (interpreter shutdown: module globals may be gone)
+            pass
 
     # ---- checkpoint views (scripts/main.py:1109-1121 saves optimizer.state_dict() and scheduler.state_dict()) ----------------
     def optimizer_state_dict(self):
