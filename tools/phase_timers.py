@@ -96,6 +96,10 @@ def main():
         report["instance_loops"] = {"rounds": ticks[8], "past_the_bound_test_per_round": ticks[9] / ticks[8], "survivors_per_round": ticks[10] / ticks[8]}
         print(f"  instance loops (multi-ray kernels): {ticks[8]} rounds, {ticks[9] / ticks[8]:.2f} instances past the bound test and "
               f"{ticks[10] / ticks[8]:.2f} past the exact test per round")
+    if ticks[11]:
+        report["pass2_rounds_behind_opaque_surface"] = ticks[12] / ticks[11]
+        print(f"  pass-2 rounds that start with a transmittance below 1e-9 / 1e-6 on every ray of the wave: {ticks[12] / ticks[11] * 100:.2f} % / "
+              f"{ticks[13] / ticks[11] * 100:.2f} % of {ticks[11]}")
     print(json.dumps(report))
 
 

@@ -633,6 +633,11 @@ __device__ __forceinline__ bool quad_forward_sweep(QuadAdjoint<kRounds>& st, con
     for (int q = 0; q < kRounds; ++q) {
         st.near[q] = 0ull;
         if (q * kL >= num_points) continue;
+#ifdef VSRD_PHASE_TIMERS
+        if (rl.lane == 0) atomicAdd(&g_phase_cycles[11], 1ull);                   // pass-2 rounds / of them: behind an opaque surface on every ray
+        if (!wave_any(!(carry < 1.0e-9f)) && rl.lane == 0) atomicAdd(&g_phase_cycles[12], 1ull);
+        if (!wave_any(!(carry < 1.0e-6f)) && rl.lane == 0) atomicAdd(&g_phase_cycles[13], 1ull);
+#endif
         float delta, bprime, px, py, pz;
         UnionValue v;
         Opacity op;
