@@ -283,3 +283,42 @@ def test_loss_library_rest_matches_reference_g18():
                  "gaussian_nll student_nll gaussian_energy_score student_energy_score logit_gaussian_nll logit_student_nll logit_gaussian_energy_score "
                  "logit_student_energy_score smoothness_loss motion_smoothness_loss motion_sparsity_loss").split():
         assert callable(getattr(L, name)), name
+
+
+def test_capture_gate_exclusive_against_shared():
+    """optimization._CaptureGate: replays (shared) run next to each other, never next to a capture / destruction / device-wide
+    synchronisation (exclusive); the garbage collector's non-blocking attempt fails while anybody is inside."""
+    import threading
+    import time
+    from vsrd_amd import optimization
+    gate = optimization._CaptureGate()
+    log, inside = [], threading.Event()
+
+    def replay(tag, hold):
+        with gate.replaying():
+            log.append(("in", tag))
+            inside.set()
+            time.sleep(hold)
+            log.append(("out", tag))
+
+    first, second = threading.Thread(target=replay, args=("a", 0.3)), threading.Thread(target=replay, args=("b", 0.05))
+    first.start()
+    assert inside.wait(5.0)
+    second.start()                                        # shared next to shared: does not wait for "a"
+    second.join(5.0)
+    assert ("out", "b") in log and ("out", "a") not in log
+    assert gate.acquire(blocking=False) is False          # exclusive, non-blocking: somebody replays
+    start = time.perf_counter()
+    with gate:                                            # exclusive, blocking: waits for "a"
+        waited = time.perf_counter() - start
+        assert ("out", "a") in log and waited > 0.1
+        assert gate.acquire(blocking=False) is False
+        late = threading.Thread(target=replay, args=("c", 0.0))
+        late.start()
+        time.sleep(0.1)
+        assert ("in", "c") not in log                     # shared waits for the exclusive holder
+    late.join(5.0)
+    first.join(5.0)
+    assert ("out", "c") in log
+    assert gate.acquire(blocking=False) is True
+    gate.release()

@@ -9,7 +9,6 @@ export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --pmc $COUNTERS --kernel-trace --output-format csv -d "$OUT" -o run -- python3 "$ROOT/$1" "${@:2}" > "$OUT/stdout.log" 2>&1
 tail -n 3 "$OUT/stdout.log" | cut -c1-400
-find "$OUT" -type f -size +8M -delete
 python3 - "$OUT" <<'PY'
 import csv, sys, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -22,3 +21,4 @@ for k, cs in acc.items():
     for c, v in sorted(cs.items()):
         print(f"   {c:32s} n={len(v):3d} last={v[-1]:.6g}")
 PY
+find "$OUT" -type f -size +8M -delete

@@ -14,12 +14,27 @@ import os
 import torch
 
 
-def checkpoint_payload(frame_optimizer, step, metrics=None):
+def to_host(value):
+    """A checkpoint payload with every tensor copied to host memory (containers rebuilt, everything else as it is)."""
+    if isinstance(value, torch.Tensor):
+        return value.detach().cpu()
+    if isinstance(value, dict):
+        return type(value)((k, to_host(v)) for k, v in value.items())
+    if isinstance(value, (list, tuple)):
+        return type(value)(to_host(v) for v in value)
+    return value
+
+
+def checkpoint_payload(frame_optimizer, step, metrics=None, host=False):
+    """``host=True``: the tensors already in host memory -- what a frame optimised next to others must hand to ``torch.save``: serialising
+    device tensors copies them with calls that HIP refuses while another frame's thread captures a graph (launcher.main takes the copies
+    under optimization.exclusive_device_access())."""
     models = {"detector": frame_optimizer.detector.state_dict(),
               "hyper_distance_field": frame_optimizer.hyper_distance_field.state_dict()}
     # eager and hipGraph mode write the same layout (FrameOptimizer.optimizer_state_dict / scheduler_state_dict)
-    return dict(step=step, models=models, optimizer=frame_optimizer.optimizer_state_dict(),
-                scheduler=frame_optimizer.scheduler_state_dict(), metrics=metrics or {})
+    payload = dict(step=step, models=models, optimizer=frame_optimizer.optimizer_state_dict(),
+                   scheduler=frame_optimizer.scheduler_state_dict(), metrics=metrics or {})
+    return to_host(payload) if host else payload
 
 
 def atomic_torch_save(payload, path):

@@ -70,8 +70,10 @@ def run_frames(frames: Sequence, optimise: Callable, checkpoint_path: Callable[[
 
     ``frames_in_flight`` > 1 runs that many frames at the same time on this rank's GPU, one host thread and one stream each: at the
     reference's 1000 rays per step the launch-bound box-only phase runs twice as fast with two frames, the compute-bound residual
-    phase about 10 % faster; more than two host threads lose to the GIL.  ``optimise`` is then called from worker threads, inside ``torch.cuda.stream(<own stream>)``; a
-    ``FrameOptimizer(graph=True)`` built there is safe (own scratch, own capture stream, captures serialised).
+    phase about 10 % faster; with several steps per hipGraph three frames are the optimum (round 4: 0.73 / 0.79 / 0.87 / 0.87
+    frames/s with one to four).  ``optimise`` is then called from worker threads, inside ``torch.cuda.stream(<own stream>)``; a
+    ``FrameOptimizer(graph=True)`` built there is safe (own scratch, own capture stream; captures, graph destruction and device-wide
+    synchronisations exclusive, replays shared: optimization._CaptureGate).
     The returned list keeps the order of ``frames``."""
     pending = []
     for frame in frames:
@@ -164,8 +166,9 @@ def main(argv=None):
     import time
     parser = argparse.ArgumentParser(prog="python -m vsrd_amd.launcher")
     parser.add_argument("--gpus", type=int, default=1)
-    parser.add_argument("--frames", type=int, default=0, help="frames of the whole job (default: 2 per rank)")
-    parser.add_argument("--frames-in-flight", type=int, default=2)
+    parser.add_argument("--frames", type=int, default=0, help="frames of the whole job (default: two rounds of --frames-in-flight per rank)")
+    parser.add_argument("--frames-in-flight", type=int, default=3,
+                        help="frames optimised at the same time on one GPU (one host thread and stream each): 0.73 / 0.75-0.79 / 0.85-0.87 / 0.84-0.87 frames/s with 1 / 2 / 3 / 4")
     parser.add_argument("--views", type=int, default=17)
     parser.add_argument("--instances", type=int, default=8)
     parser.add_argument("--rays", type=int, default=1000)
@@ -180,6 +183,10 @@ def main(argv=None):
                         help="TEST ONLY: every rank on cuda:0, gloo rendezvous (RCCL refuses two ranks on one device); the line says so")
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parser.parse_args(argv)
+    if not 1 <= args.frames_in_flight <= 4:
+        # (round 4: five and more frames on one device end in a memory fault or a segmentation fault inside torch / HIP within seconds --
+        #  construction and eager warm-up steps of that many threads next to a capture; two to four ran every test of the round)
+        raise SystemExit("--frames-in-flight must be 1..4")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))          # bench.synthetic_frame, __graft_entry__.build live at the repo root
     if root not in sys.path:
         sys.path.insert(0, root)
@@ -195,7 +202,7 @@ def main(argv=None):
         __graft_entry__.build()
     barrier()
     from . import formats, optimization
-    total = args.frames or 2 * world
+    total = args.frames or 2 * args.frames_in_flight * world
     out_dir = args.out or (tempfile.mkdtemp(prefix="vsrd_frames_") if rank == 0 else None)
     manifest = broadcast_manifest(dict(frames=list(range(total)), seed=args.seed, out=out_dir) if rank == 0 else None)
     mine = shard_frames(manifest["frames"], rank, world, seed=manifest["seed"])
@@ -209,8 +216,9 @@ def main(argv=None):
         loop = optimization.FrameOptimizer(inputs[frame], optimization.OptimizationConfig(seed=int(frame), **config), device, graph=True)
         record = loop.run(args.num_steps)
         torch.cuda.current_stream().synchronize()
-        losses[frame] = float(record["loss"])
-        payload = formats.checkpoint_payload(loop, step=args.num_steps - 1, metrics={})
+        with optimization.exclusive_device_access():       # (the copies to the host: refused while another frame's thread captures)
+            losses[frame] = float(record["loss"])
+            payload = formats.checkpoint_payload(loop, step=args.num_steps - 1, metrics={}, host=True)
         loop.close()
         return payload
 

@@ -23,7 +23,68 @@ import torch
 from . import _lib, fields, losses, models, operations, rendering
 
 
-_capture_lock = threading.Lock()
+class _CaptureGate:
+    """Who may touch hipGraphs when, over the frames that one rank optimises concurrently (launcher.run_frames): stream capture is a
+    process-wide mode.  EXCLUSIVE (``with gate:`` / ``acquire`` / ``release``): a capture, a device-wide synchronisation, the destruction
+    of graphs -- one at a time, and only while no replay is being launched.  SHARED (``with gate.replaying():``): the launch of a replay --
+    any number at once, never during a capture: torch refuses ("Cannot prepare for replay during capturing stage": every graph registers
+    the default generator, whose state is process-wide), and with five or more frames in flight that was a crash within seconds; with
+    two it is rare, not impossible."""
+
+    def __init__(self):
+        self._state = threading.Condition()
+        self._replays = 0
+        self._exclusive = False
+
+    def acquire(self, blocking=True):
+        with self._state:
+            while self._exclusive or self._replays:
+                if not blocking:
+                    return False
+                self._state.wait()
+            self._exclusive = True
+            return True
+
+    def release(self):
+        with self._state:
+            self._exclusive = False
+            self._state.notify_all()
+
+    def __enter__(self):
+        self.acquire()
+        return self
+
+    def __exit__(self, *exc):
+        self.release()
+
+    def replaying(self):
+        return _SharedGate(self)
+
+
+class _SharedGate:
+    def __init__(self, gate):
+        self.gate = gate
+
+    def __enter__(self):
+        with self.gate._state:
+            while self.gate._exclusive:
+                self.gate._state.wait()
+            self.gate._replays += 1
+
+    def __exit__(self, *exc):
+        with self.gate._state:
+            self.gate._replays -= 1
+            if not self.gate._replays:
+                self.gate._state.notify_all()
+
+
+_capture_lock = _CaptureGate()
+
+
+def exclusive_device_access():
+    """``with exclusive_device_access(): ...`` -- no frame of this process captures or launches a replay meanwhile: for device-wide
+    synchronisations and bulk device-to-host copies (checkpoints) of a frame that is optimised next to others."""
+    return _capture_lock
 _graveyard = []          # graphs whose owner went away while somebody captured: destroyed by the next holder of the lock
 
 
@@ -455,7 +516,8 @@ class FrameOptimizer:
             graph, static_rays, outputs = self._graphs[key]
             if static_rays is not None:
                 static_rays.copy_(ray_indices)
-            graph.replay()
+            with _capture_lock.replaying():
+                graph.replay()
             self.step_index += 1
             return outputs
         done = self._eager_graph_steps.get(key, 0)
@@ -480,7 +542,8 @@ class FrameOptimizer:
         with _capture_lock, torch.cuda.graph(graph, stream=self._capture_stream, capture_error_mode="thread_local"):
             outputs = self._step(static_rays, None, None, count=False)
         self._graphs[key] = (graph, static_rays, outputs)
-        graph.replay()                                   # capture does not execute: this replay IS the step
+        with _capture_lock.replaying():
+            graph.replay()                               # capture does not execute: this replay IS the step
         self.step_index += 1
         return outputs
 
@@ -518,7 +581,8 @@ class FrameOptimizer:
                     outputs = self._step(None, None, None, count=False, joins=(j == 0, j == k - 1))
             self._graphs[key] = (graph, None, outputs)
         graph, _, outputs = self._graphs[key]
-        graph.replay()
+        with _capture_lock.replaying():
+            graph.replay()
         self.step_index += k
         return outputs
 
