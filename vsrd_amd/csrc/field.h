@@ -101,8 +101,10 @@ __device__ __forceinline__ BoxEval box_value(const Instance& in, float x, float 
     const float squares = ax * ax + ay * ay + az * az + kNormEpsilon;
     e.inv = fast_rsq(squares);
     e.nrm = squares * e.inv;
+#ifndef VSRD_NO_NORM_PIN
     asm volatile("" : "+v"(e.nrm));      // (a rounded product in EVERY instantiation: without this some of them fuse it into the subtraction below,
                                          //  and kernels that differ in the last bit of a distance differ by 1e-4 in summed gradients -- see above)
+#endif
 #else
     e.nrm = fast_sqrt(ax * ax + ay * ay + az * az + kNormEpsilon);
     e.inv = fast_rcp(e.nrm);
