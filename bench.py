@@ -302,6 +302,10 @@ def executed_view(counters, launch_ms):
     return {"valu_tflops": valu_flop / seconds / 1e12, "mfma_tflops": mfma_flop / seconds / 1e12,
             "tflops": (valu_flop + mfma_flop) / seconds / 1e12, "frac": (valu_flop + mfma_flop) / seconds / 1e12 / FP32_PEAK_TF,
             "valu_issue_utilisation": 2.0 * valu_slots / (NUM_SIMDS * PEAK_CLOCK_HZ * seconds),
+            # what the SIMDs spent per vector instruction (MFMA time, 32 cycles each, taken off), next to what a stream of plain
+            # multiply-adds costs at four waves per SIMD on this part (profiles/r01/op_rates.txt: 2.7-3.0, not the nominal 2)
+            "cycles_per_valu_instruction": max(NUM_SIMDS * PEAK_CLOCK_HZ * seconds - 32.0 * mfma, 0.0) / max(valu_slots, 1.0),
+            "measured_cycles_per_plain_fma": 2.9,
             "mfma_utilisation": mfma_flop / seconds / 1e12 / FP32_PEAK_TF,
             "fma_share_of_fp32_ops": fma / max(fma + mul + add, 1.0),
             "valu_wave_instructions": counters["SQ_INSTS_VALU"], "mfma_wave_instructions": mfma,
