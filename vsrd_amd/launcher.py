@@ -99,9 +99,11 @@ def run_frames(frames: Sequence, optimise: Callable, checkpoint_path: Callable[[
     def on_own_stream(item):
         if torch.cuda.is_available():
             torch.cuda.set_device(device)
+            from . import optimization
             with torch.cuda.stream(torch.cuda.Stream(device=device)):
                 frame = one(item)
-                torch.cuda.current_stream().synchronize()
+                with optimization.exclusive_device_access():      # (a host synchronisation: not next to another frame's capture)
+                    torch.cuda.current_stream().synchronize()
                 return frame
         return one(item)
 
@@ -215,8 +217,8 @@ def main(argv=None):
     def optimise(frame):
         loop = optimization.FrameOptimizer(inputs[frame], optimization.OptimizationConfig(seed=int(frame), **config), device, graph=True)
         record = loop.run(args.num_steps)
-        torch.cuda.current_stream().synchronize()
-        with optimization.exclusive_device_access():       # (the copies to the host: refused while another frame's thread captures)
+        with optimization.exclusive_device_access():       # (host synchronisations and copies: refused now and then while another frame's thread captures)
+            torch.cuda.current_stream().synchronize()
             losses[frame] = float(record["loss"])
             payload = formats.checkpoint_payload(loop, step=args.num_steps - 1, metrics={}, host=True)
         loop.close()

@@ -24,31 +24,42 @@ from . import _lib, fields, losses, models, operations, rendering
 
 
 class _CaptureGate:
-    """Who may touch hipGraphs when, over the frames that one rank optimises concurrently (launcher.run_frames): stream capture is a
-    process-wide mode.  EXCLUSIVE (``with gate:`` / ``acquire`` / ``release``): a capture, a device-wide synchronisation, the destruction
-    of graphs -- one at a time, and only while no replay is being launched.  SHARED (``with gate.replaying():``): the launch of a replay --
-    any number at once, never during a capture: torch refuses ("Cannot prepare for replay during capturing stage": every graph registers
-    the default generator, whose state is process-wide), and with five or more frames in flight that was a crash within seconds; with
-    two it is rare, not impossible."""
+    """ONE holder at a time for everything that touches hipGraphs, over the frames that one rank optimises concurrently
+    (launcher.run_frames): a capture, the launch of a replay, the destruction of graphs, a device-wide synchronisation, a frame's bulk
+    copies to the host.  Stream capture is a process-wide mode and the runtime's graph code is not safe against itself across threads:
+    torch refuses a replay during another thread's capture ("Cannot prepare for replay during capturing stage": every graph registers the
+    process-wide default generator), ROCm's ~CUDAGraph synchronises the device (refused during a capture), and with replay LAUNCHES of
+    several threads merely excluded from captures but not from each other, about one run in ten of 36 frames at three in flight still
+    died inside hipGraphLaunch.  And HIP refuses even a STREAM synchronisation (`.item()`, `.cpu()`, `stream.synchronize()`, `torch.nonzero`)
+    of one thread while another captures, now and then: every host synchronisation of a frame belongs in here too.  A launch is ~30 us of
+    host time against 0.3-3 ms of GPU time per replay, so serialising them costs nothing measurable.  Re-entrant for its holder;
+    ``acquire(blocking=False)``: the garbage collector's path, which may run inside the holder's own thread and then must not enter."""
 
     def __init__(self):
-        self._state = threading.Condition()
-        self._replays = 0
-        self._exclusive = False
+        self._state = threading.Condition(threading.Lock())
+        self._owner, self._depth = None, 0
 
     def acquire(self, blocking=True):
+        me = threading.get_ident()
         with self._state:
-            while self._exclusive or self._replays:
+            if self._owner == me:
+                if not blocking:             # the collector inside the holder's own thread: not now
+                    return False
+                self._depth += 1             # the holder calls something that takes the gate itself (rebind inside a constructor)
+                return True
+            while self._owner is not None:
                 if not blocking:
                     return False
                 self._state.wait()
-            self._exclusive = True
+            self._owner, self._depth = me, 1
             return True
 
     def release(self):
         with self._state:
-            self._exclusive = False
-            self._state.notify_all()
+            self._depth -= 1
+            if self._depth == 0:
+                self._owner = None
+                self._state.notify()
 
     def __enter__(self):
         self.acquire()
@@ -58,24 +69,7 @@ class _CaptureGate:
         self.release()
 
     def replaying(self):
-        return _SharedGate(self)
-
-
-class _SharedGate:
-    def __init__(self, gate):
-        self.gate = gate
-
-    def __enter__(self):
-        with self.gate._state:
-            while self.gate._exclusive:
-                self.gate._state.wait()
-            self.gate._replays += 1
-
-    def __exit__(self, *exc):
-        with self.gate._state:
-            self.gate._replays -= 1
-            if not self.gate._replays:
-                self.gate._state.notify_all()
+        return self
 
 
 _capture_lock = _CaptureGate()
@@ -85,6 +79,8 @@ def exclusive_device_access():
     """``with exclusive_device_access(): ...`` -- no frame of this process captures or launches a replay meanwhile: for device-wide
     synchronisations and bulk device-to-host copies (checkpoints) of a frame that is optimised next to others."""
     return _capture_lock
+
+
 _graveyard = []          # graphs whose owner went away while somebody captured: destroyed by the next holder of the lock
 
 
@@ -211,6 +207,14 @@ class FrameOptimizer:
         self._graphs = {}
         self._capture_stream = None
         self._eager_graph_steps = {}
+        with _capture_lock:      # (host synchronisations below -- nonzero, the table's checks: not next to another frame's capture)
+            self._prepare_rays(inputs, config, H, W, N)
+        self.pixels_per_view = H * W
+        self.step_index = 0
+        if self.fused_glue:
+            self._init_fused_glue()
+
+    def _prepare_rays(self, inputs, config, H, W, N):
         # rays of every view, once per frame (main.py:267-296)
         cam, dirs = rendering.ray_casting((H, W), inputs.intrinsic_matrices, inputs.extrinsic_matrices)
         self.camera_positions = cam                                         # [V,3]
@@ -233,10 +237,6 @@ class FrameOptimizer:
             table = rendering.RayTable(self.positive_weights)
             if table.suits(config.num_rays):
                 self.ray_table = table
-        self.pixels_per_view = H * W
-        self.step_index = 0
-        if self.fused_glue:
-            self._init_fused_glue()
 
     # ---- fused glue (csrc/frame_step.h) ---------------------------------------------------------------------------------
     def _init_fused_glue(self):
@@ -660,11 +660,14 @@ class FrameOptimizer:
         """Drop the captured graphs and the scratch buffers (also happens when the optimizer is garbage-collected).  Once per frame
         this is also where the device ray sampler's sticky overflow flag is read back (a host synchronisation, so not per step): a
         draw whose threshold bin held more candidate keys than the sampler lists was incomplete and not reproducible."""
-        if self.graph and self.ray_table is not None and self.ray_table.incomplete():
+        with _capture_lock:
+            incomplete = bool(self.graph and self.ray_table is not None and self.ray_table.incomplete())
+            overflowed = bool(self.graph and self.workspace.sampler_overflowed(self.device))
+        if incomplete:
             import warnings
             warnings.warn("vsrd_sample_rays_table ran out of picks in some step of this frame: those draws repeat some rays "
                           "(see csrc/ray_sampling.h and RayTable.suits)", RuntimeWarning)
-        if self.graph and self.workspace.sampler_overflowed(self.device):
+        if overflowed:
             import warnings
             warnings.warn("vsrd_sample_rays overflowed its candidate list in some step of this frame: those draws were incomplete "
                           "(many equal importance weights in one histogram bin); see csrc/ray_sampling.h", RuntimeWarning)
