@@ -96,8 +96,9 @@ def main():
         with torch.cuda.stream(streams[slot]):
             start_line.wait()
             losses = loops[slot].run(args.steps, args.steps_per_graph)
-            streams[slot].synchronize()
-            results[slot] = float(losses["loss"])
+            with optimization.exclusive_device_access():       # (host synchronisations: not next to the other frame's capture)
+                streams[slot].synchronize()
+                results[slot] = float(losses["loss"])
 
     threads = [threading.Thread(target=worker, args=(slot,)) for slot in range(args.concurrent)]
     for t in threads:
