@@ -176,6 +176,14 @@ class FrameOptimizer:
     (``fused_hypernetwork = False`` keeps them with torch: the A/B reference)."""
 
     def __init__(self, inputs: FrameInputs, config: OptimizationConfig, device, graph=False, fused_glue=None):
+        self._graphs = {}
+        # the whole construction takes its turn at the gate: it copies modules to the device, reads ranges back (.item()), runs nonzero --
+        # host synchronisations that, next to ANOTHER frame's capture, fail now and then or break that capture ("capturing stream has
+        # unjoined work" in the other thread: one 36-frame run in fourteen)
+        with _capture_lock:
+            self._construct(inputs, config, device, graph, fused_glue)
+
+    def _construct(self, inputs, config, device, graph, fused_glue):
         self.inputs, self.config, self.device = inputs, config, torch.device(device)
         if self.device.type == "cuda" and self.device.index is None:      # the scratch buffers are keyed by device: one spelling of it
             self.device = torch.device("cuda", torch.cuda.current_device())
@@ -207,8 +215,7 @@ class FrameOptimizer:
         self._graphs = {}
         self._capture_stream = None
         self._eager_graph_steps = {}
-        with _capture_lock:      # (host synchronisations below -- nonzero, the table's checks: not next to another frame's capture)
-            self._prepare_rays(inputs, config, H, W, N)
+        self._prepare_rays(inputs, config, H, W, N)
         self.pixels_per_view = H * W
         self.step_index = 0
         if self.fused_glue:
@@ -522,11 +529,12 @@ class FrameOptimizer:
             return outputs
         done = self._eager_graph_steps.get(key, 0)
         if done < 3:
-            side = torch.cuda.Stream(device=self.device)
-            side.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(side):
-                outputs = self._step(ray_indices, None, None)
-            torch.cuda.current_stream(self.device).wait_stream(side)
+            with _capture_lock:          # (a phase's three eager steps take their turn as well: nothing of a frame calls into HIP next to a capture)
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):
+                    outputs = self._step(ray_indices, None, None)
+                torch.cuda.current_stream(self.device).wait_stream(side)
             self._eager_graph_steps[key] = done + 1
             return outputs
         static_rays = ray_indices.clone() if ray_indices is not None else None
