@@ -285,9 +285,10 @@ def test_loss_library_rest_matches_reference_g18():
         assert callable(getattr(L, name)), name
 
 
-def test_capture_gate_is_one_holder_at_a_time():
-    """optimization._CaptureGate: captures, replay launches, graph destruction and device-wide synchronisations of the frames optimised
-    concurrently by one rank take turns; the garbage collector's non-blocking attempt fails while anybody is inside."""
+def test_capture_gate_exclusive_against_shared():
+    """optimization._CaptureGate: replay launches (shared) run next to each other, never next to an exclusive section (construction, eager
+    steps, capture, destruction, host synchronisations); exclusive is re-entrant for its holder; the garbage collector's non-blocking
+    attempt fails while anybody is inside, the holder's own thread included."""
     import threading
     import time
     from vsrd_amd import optimization
@@ -301,21 +302,26 @@ def test_capture_gate_is_one_holder_at_a_time():
             time.sleep(hold)
             log.append(("out", tag))
 
-    first = threading.Thread(target=replay, args=("a", 0.3))
+    first, second = threading.Thread(target=replay, args=("a", 0.3)), threading.Thread(target=replay, args=("b", 0.05))
     first.start()
     assert inside.wait(5.0)
-    assert gate.acquire(blocking=False) is False          # non-blocking: somebody is inside
-    second = threading.Thread(target=replay, args=("b", 0.0))
-    second.start()
-    start = time.perf_counter()
-    with gate:                                            # blocking: waits for "a" (and takes its turn with "b")
-        assert ("out", "a") in log and time.perf_counter() - start > 0.1
-        inside_now = [entry for entry in log if entry[0] == "in"]
-        assert log.count(("in", "b")) == log.count(("out", "b"))       # "b" is not inside while we are
-        assert gate.acquire(blocking=False) is False
-        del inside_now
+    second.start()                                        # shared next to shared: does not wait for "a"
     second.join(5.0)
+    assert ("out", "b") in log and ("out", "a") not in log
+    assert gate.acquire(blocking=False) is False          # exclusive, non-blocking: somebody replays
+    start = time.perf_counter()
+    with gate:                                            # exclusive, blocking: waits for "a"
+        assert ("out", "a") in log and time.perf_counter() - start > 0.1
+        assert gate.acquire(blocking=False) is False      # the collector in the holder's own thread: not now
+        with gate:                                        # the holder re-enters
+            with gate.replaying():                        # ... and may launch a replay of its own
+                pass
+        late = threading.Thread(target=replay, args=("c", 0.0))
+        late.start()
+        time.sleep(0.1)
+        assert ("in", "c") not in log                     # shared waits for the exclusive holder
+    late.join(5.0)
     first.join(5.0)
-    assert ("out", "b") in log
+    assert ("out", "c") in log
     assert gate.acquire(blocking=False) is True
     gate.release()

@@ -70,10 +70,11 @@ def run_frames(frames: Sequence, optimise: Callable, checkpoint_path: Callable[[
 
     ``frames_in_flight`` > 1 runs that many frames at the same time on this rank's GPU, one host thread and one stream each: at the
     reference's 1000 rays per step the launch-bound box-only phase runs twice as fast with two frames, the compute-bound residual
-    phase about 10 % faster; with several steps per hipGraph three frames are the optimum (round 4: 0.73 / 0.79 / 0.87 / 0.87
-    frames/s with one to four).  ``optimise`` is then called from worker threads, inside ``torch.cuda.stream(<own stream>)``; a
-    ``FrameOptimizer(graph=True)`` built there is safe (own scratch, own capture stream; captures, graph destruction and device-wide
-    synchronisations exclusive, replays shared: optimization._CaptureGate).
+    phase about 10 % faster.  ``optimise`` is then called from worker threads, inside ``torch.cuda.stream(<own stream>)``; a
+    ``FrameOptimizer(graph=True)`` built there is safe because every call it makes into HIP -- construction, eager warm-up steps, captures,
+    graph destruction, host synchronisations -- takes its turn at optimization._CaptureGate and only replay launches overlap; that safety
+    costs most of the gain (round 4, one box: 0.749 frames/s with one frame, 0.757 with three; without the gate 0.73 -> 0.85 on another
+    box, and a dead rank about every tenth run of 36 frames).
     The returned list keeps the order of ``frames``."""
     pending = []
     for frame in frames:
@@ -168,9 +169,10 @@ def main(argv=None):
     import time
     parser = argparse.ArgumentParser(prog="python -m vsrd_amd.launcher")
     parser.add_argument("--gpus", type=int, default=1)
-    parser.add_argument("--frames", type=int, default=0, help="frames of the whole job (default: two rounds of --frames-in-flight per rank)")
-    parser.add_argument("--frames-in-flight", type=int, default=3,
-                        help="frames optimised at the same time on one GPU (one host thread and stream each): 0.73 / 0.75-0.79 / 0.85-0.87 / 0.84-0.87 frames/s with 1 / 2 / 3 / 4")
+    parser.add_argument("--frames", type=int, default=0, help="frames of the whole job (default: four per rank, or two rounds of --frames-in-flight)")
+    parser.add_argument("--frames-in-flight", type=int, default=1,
+                        help="frames optimised at the same time on one GPU (one host thread and stream each, every call into HIP but the replay "
+                             "launches taking turns: optimization._CaptureGate); with that gate 0.749 / 0.757 frames/s with 1 / 3 on one box")
     parser.add_argument("--views", type=int, default=17)
     parser.add_argument("--instances", type=int, default=8)
     parser.add_argument("--rays", type=int, default=1000)
@@ -204,7 +206,7 @@ def main(argv=None):
         __graft_entry__.build()
     barrier()
     from . import formats, optimization
-    total = args.frames or 2 * args.frames_in_flight * world
+    total = args.frames or 2 * max(args.frames_in_flight, 2) * world
     out_dir = args.out or (tempfile.mkdtemp(prefix="vsrd_frames_") if rank == 0 else None)
     manifest = broadcast_manifest(dict(frames=list(range(total)), seed=args.seed, out=out_dir) if rank == 0 else None)
     mine = shard_frames(manifest["frames"], rank, world, seed=manifest["seed"])

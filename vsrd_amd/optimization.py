@@ -24,20 +24,22 @@ from . import _lib, fields, losses, models, operations, rendering
 
 
 class _CaptureGate:
-    """ONE holder at a time for everything that touches hipGraphs, over the frames that one rank optimises concurrently
-    (launcher.run_frames): a capture, the launch of a replay, the destruction of graphs, a device-wide synchronisation, a frame's bulk
-    copies to the host.  Stream capture is a process-wide mode and the runtime's graph code is not safe against itself across threads:
-    torch refuses a replay during another thread's capture ("Cannot prepare for replay during capturing stage": every graph registers the
-    process-wide default generator), ROCm's ~CUDAGraph synchronises the device (refused during a capture), and with replay LAUNCHES of
-    several threads merely excluded from captures but not from each other, about one run in ten of 36 frames at three in flight still
-    died inside hipGraphLaunch.  And HIP refuses even a STREAM synchronisation (`.item()`, `.cpu()`, `stream.synchronize()`, `torch.nonzero`)
-    of one thread while another captures, now and then: every host synchronisation of a frame belongs in here too.  A launch is ~30 us of
-    host time against 0.3-3 ms of GPU time per replay, so serialising them costs nothing measurable.  Re-entrant for its holder;
-    ``acquire(blocking=False)``: the garbage collector's path, which may run inside the holder's own thread and then must not enter."""
+    """Who may call into HIP when, over the frames that one rank optimises concurrently (launcher.run_frames).  Stream capture is a
+    process-wide mode, and the runtime's graph code is not safe against itself across threads; every line here is a dead rank seen in
+    round 4: torch refuses a replay during another thread's capture ("Cannot prepare for replay during capturing stage": every graph
+    registers the process-wide default generator); ROCm's ~CUDAGraph synchronises the device, which HIP refuses during a capture; HIP
+    refuses, now and then, even a STREAM synchronisation (`.item()`, `.cpu()`, `stream.synchronize()`, `torch.nonzero`, a module's
+    `.to(device)`) of one thread while another captures -- or lets it through and breaks the capture instead ("capturing stream has
+    unjoined work"; a graph from such a capture is the likely cause of the one segmentation fault inside hipGraphLaunch).
+    EXCLUSIVE (``with gate:``; re-entrant for its holder): a frame's construction, a phase's eager warm-up steps, a capture, the
+    destruction of graphs, host synchronisations and copies -- one thread at a time and no replay launch meanwhile.  SHARED
+    (``with gate.replaying():``): the launch of a replay -- any number at once (a launch can block for milliseconds behind the previous
+    launch of the same graph: serialising launches as well took the whole gain of several frames in flight, 0.85 -> 0.75 frames/s).
+    ``acquire(blocking=False)``: the garbage collector's path, which may run inside any thread, the holder's included, and never waits."""
 
     def __init__(self):
         self._state = threading.Condition(threading.Lock())
-        self._owner, self._depth = None, 0
+        self._owner, self._depth, self._replays = None, 0, 0
 
     def acquire(self, blocking=True):
         me = threading.get_ident()
@@ -47,7 +49,7 @@ class _CaptureGate:
                     return False
                 self._depth += 1             # the holder calls something that takes the gate itself (rebind inside a constructor)
                 return True
-            while self._owner is not None:
+            while self._owner is not None or self._replays:
                 if not blocking:
                     return False
                 self._state.wait()
@@ -59,7 +61,7 @@ class _CaptureGate:
             self._depth -= 1
             if self._depth == 0:
                 self._owner = None
-                self._state.notify()
+                self._state.notify_all()
 
     def __enter__(self):
         self.acquire()
@@ -69,7 +71,29 @@ class _CaptureGate:
         self.release()
 
     def replaying(self):
-        return self
+        return _ReplayTurn(self)
+
+
+class _ReplayTurn:
+    def __init__(self, gate):
+        self.gate, self.counted = gate, False
+
+    def __enter__(self):
+        gate = self.gate
+        with gate._state:
+            if gate._owner == threading.get_ident():      # a replay inside the holder's own exclusive section: already alone
+                return
+            while gate._owner is not None:
+                gate._state.wait()
+            gate._replays += 1
+            self.counted = True
+
+    def __exit__(self, *exc):
+        if self.counted:
+            with self.gate._state:
+                self.gate._replays -= 1
+                if not self.gate._replays:
+                    self.gate._state.notify_all()
 
 
 _capture_lock = _CaptureGate()
