@@ -149,7 +149,8 @@ def test_native_frames_entry_point_two_ranks_on_one_gpu(tmp_path):
     bench = os.path.join(ROOT, "bench.py")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     command = [sys.executable, bench, "--native", "--gpus", "2", "--ranks-share-gpu", "--frames", "5", "--views", "3", "--instances", "4", "--height", "128",
-               "--width", "128", "--rays", "256", "--samples", "32", "--num-steps", "40", "--warmup-steps", "12", "--out", str(tmp_path)]
+               "--width", "128", "--rays", "256", "--samples", "32", "--num-steps", "40", "--warmup-steps", "12", "--frames-in-flight", "2",
+               "--out", str(tmp_path)]
     out = subprocess.run(command, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
