@@ -38,7 +38,9 @@ class _CaptureGate:
     ``acquire(blocking=False)``: the garbage collector's path, which may run inside any thread, the holder's included, and never waits."""
 
     def __init__(self):
-        self._state = threading.Condition(threading.Lock())
+        # (a re-entrant lock under the condition: the garbage collector may run a FrameOptimizer's __del__ -- which asks for the gate without
+        #  waiting -- in a thread that is inside one of these few-line critical sections itself)
+        self._state = threading.Condition(threading.RLock())
         self._owner, self._depth, self._replays = None, 0, 0
 
     def acquire(self, blocking=True):
