@@ -644,7 +644,7 @@ def test_graphs_are_destroyed_only_while_nobody_captures(dev):
         try:
             torch.cuda.set_device(dev)
             stream, graph, x = torch.cuda.Stream(), torch.cuda.CUDAGraph(), torch.zeros(16, device=dev)
-            with optimization._capture_lock, torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+            with optimization._capture_lock.capture(), torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
                 x.add_(1.0)
                 capturing.set()
                 release.wait(10.0)

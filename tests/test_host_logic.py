@@ -285,43 +285,56 @@ def test_loss_library_rest_matches_reference_g18():
         assert callable(getattr(L, name)), name
 
 
-def test_capture_gate_exclusive_against_shared():
-    """optimization._CaptureGate: replay launches (shared) run next to each other, never next to an exclusive section (construction, eager
-    steps, capture, destruction, host synchronisations); exclusive is re-entrant for its holder; the garbage collector's non-blocking
-    attempt fails while anybody is inside, the holder's own thread included."""
+def test_capture_gate_keeps_captures_alone():
+    """optimization._CaptureGate: a capture runs alone; everything else a frame's thread calls into HIP (construction, eager steps, replay
+    launches, graph destruction, host synchronisations) runs next to each other but never during a capture; a waiting capture goes before
+    newcomers but does not stop a thread that is already inside from nesting; the garbage collector's non-blocking attempt is refused
+    during a capture, inside the capturing thread too."""
     import threading
     import time
     from vsrd_amd import optimization
     gate = optimization._CaptureGate()
     log, inside = [], threading.Event()
 
-    def replay(tag, hold):
+    def other(tag, hold, nested=False):
         with gate.replaying():
             log.append(("in", tag))
             inside.set()
             time.sleep(hold)
+            if nested:
+                with gate:                                # nesting while a capture waits: must not deadlock
+                    log.append(("nested", tag))
             log.append(("out", tag))
 
-    first, second = threading.Thread(target=replay, args=("a", 0.3)), threading.Thread(target=replay, args=("b", 0.05))
+    first = threading.Thread(target=other, args=("a", 0.3, True))
+    second = threading.Thread(target=other, args=("b", 0.0))
     first.start()
     assert inside.wait(5.0)
-    second.start()                                        # shared next to shared: does not wait for "a"
+    second.start()                                        # next to "a": does not wait
     second.join(5.0)
     assert ("out", "b") in log and ("out", "a") not in log
-    assert gate.acquire(blocking=False) is False          # exclusive, non-blocking: somebody replays
+    assert gate.acquire(blocking=False) is True           # ... and so may anybody else, the collector included
+    gate.release()
     start = time.perf_counter()
-    with gate:                                            # exclusive, blocking: waits for "a"
-        assert ("out", "a") in log and time.perf_counter() - start > 0.1
-        assert gate.acquire(blocking=False) is False      # the collector in the holder's own thread: not now
-        with gate:                                        # the holder re-enters
-            with gate.replaying():                        # ... and may launch a replay of its own
-                pass
-        late = threading.Thread(target=replay, args=("c", 0.0))
+    with gate.capture():                                  # waits for "a", which nests once on its way out
+        assert ("nested", "a") in log and ("out", "a") in log and time.perf_counter() - start > 0.1
+        assert gate.acquire(blocking=False) is False      # the collector inside the capturing thread: not now
+        with gate:                                        # the capturing thread itself passes
+            pass
+        late = threading.Thread(target=other, args=("c", 0.0))
         late.start()
         time.sleep(0.1)
-        assert ("in", "c") not in log                     # shared waits for the exclusive holder
+        assert ("in", "c") not in log                     # everybody else waits for the capture
+        refused = []
+        probe = threading.Thread(target=lambda: refused.append(gate.acquire(blocking=False)))
+        probe.start(); probe.join(5.0)
+        assert refused == [False]
     late.join(5.0)
     first.join(5.0)
-    assert ("out", "c") in log
-    assert gate.acquire(blocking=False) is True
-    gate.release()
+    assert ("out", "c") in log and gate.capture_seconds > 0.0
+    with gate:
+        try:
+            with gate.capture():                          # a capture inside a held section would wait for itself
+                raise AssertionError("unreachable")
+        except RuntimeError:
+            pass

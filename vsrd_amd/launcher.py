@@ -71,10 +71,10 @@ def run_frames(frames: Sequence, optimise: Callable, checkpoint_path: Callable[[
     ``frames_in_flight`` > 1 runs that many frames at the same time on this rank's GPU, one host thread and one stream each: at the
     reference's 1000 rays per step the launch-bound box-only phase runs twice as fast with two frames, the compute-bound residual
     phase about 10 % faster.  ``optimise`` is then called from worker threads, inside ``torch.cuda.stream(<own stream>)``; a
-    ``FrameOptimizer(graph=True)`` built there is safe because every call it makes into HIP -- construction, eager warm-up steps, captures,
-    graph destruction, host synchronisations -- takes its turn at optimization._CaptureGate and only replay launches overlap; that safety
-    costs most of the gain (round 4, one box: 0.749 frames/s with one frame, 0.757 with three; without the gate 0.73 -> 0.85 on another
-    box, and a dead rank about every tenth run of 36 frames).
+    ``FrameOptimizer(graph=True)`` built there is safe because nothing it calls into HIP -- construction, eager warm-up steps, replay
+    launches, graph destruction, host synchronisations -- runs during ANOTHER frame's capture, and captures (with a graph's first launch)
+    run alone: optimization._CaptureGate (round 4, one box: 0.749 frames/s with one frame in flight, 0.91 with three; without the gate a
+    dead rank about every tenth run of 36 frames).
     The returned list keeps the order of ``frames``."""
     pending = []
     for frame in frames:
@@ -169,10 +169,11 @@ def main(argv=None):
     import time
     parser = argparse.ArgumentParser(prog="python -m vsrd_amd.launcher")
     parser.add_argument("--gpus", type=int, default=1)
-    parser.add_argument("--frames", type=int, default=0, help="frames of the whole job (default: four per rank, or two rounds of --frames-in-flight)")
-    parser.add_argument("--frames-in-flight", type=int, default=1,
-                        help="frames optimised at the same time on one GPU (one host thread and stream each, every call into HIP but the replay "
-                             "launches taking turns: optimization._CaptureGate); with that gate 0.749 / 0.757 frames/s with 1 / 3 on one box")
+    parser.add_argument("--frames", type=int, default=0, help="frames of the whole job (default: two rounds of --frames-in-flight per rank)")
+    parser.add_argument("--frames-in-flight", type=int, default=3,
+                        help="frames optimised at the same time on one GPU (one host thread and stream each; captures and a graph's first launch "
+                             "alone, everything else next to each other: optimization._CaptureGate): 0.75 / 0.74 / 0.91 frames/s with 1 / 2 / 3 "
+                             "on one box; 1 = no threads at all")
     parser.add_argument("--views", type=int, default=17)
     parser.add_argument("--instances", type=int, default=8)
     parser.add_argument("--rays", type=int, default=1000)
@@ -206,7 +207,7 @@ def main(argv=None):
         __graft_entry__.build()
     barrier()
     from . import formats, optimization
-    total = args.frames or 2 * max(args.frames_in_flight, 2) * world
+    total = args.frames or 2 * args.frames_in_flight * world
     out_dir = args.out or (tempfile.mkdtemp(prefix="vsrd_frames_") if rank == 0 else None)
     manifest = broadcast_manifest(dict(frames=list(range(total)), seed=args.seed, out=out_dir) if rank == 0 else None)
     mine = shard_frames(manifest["frames"], rank, world, seed=manifest["seed"])
@@ -241,6 +242,7 @@ def main(argv=None):
     fence()
     elapsed = time.perf_counter() - t0
     report = dict(rank=rank, own_seconds=own, elapsed_seconds=elapsed, frames=len(done), skipped=len(mine) - len(done),
+                  gate_capture_seconds=optimization.exclusive_device_access().capture_seconds,
                   mean_final_loss=(sum(losses.values()) / len(losses)) if losses else None)
     gathered = [report]
     if world > 1:
@@ -257,6 +259,8 @@ def main(argv=None):
             "per_rank_seconds": [r["own_seconds"] for r in gathered], "per_rank_frames": [r["frames"] for r in gathered],
             "seconds_per_frame_per_gpu": [r["own_seconds"] / r["frames"] if r["frames"] else None for r in gathered],
             "mean_final_loss": [r["mean_final_loss"] for r in gathered], "data": "synthetic", "dtype": "f32",
+            # host time per frame spent capturing hipGraphs (optimization._CaptureGate): what the other frames in flight wait for
+            "capture_seconds_per_frame": [r["gate_capture_seconds"] / r["frames"] if r["frames"] else None for r in gathered],
             "config": {"workload": f"{args.num_steps} optimisation steps per frame ({args.warmup_steps} box-only + {args.num_steps - args.warmup_steps} with the "
                                    f"residual MLP), {args.rays} rays x {args.samples} samples per step, {args.views} views of {args.height}x{args.width}, "
                                    f"{args.instances} instances, FrameOptimizer(graph=True), {args.frames_in_flight} frames in flight per GPU",

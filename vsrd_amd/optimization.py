@@ -17,6 +17,7 @@ from typing import Optional, Sequence
 
 import math
 import threading
+import time
 
 import torch
 
@@ -24,46 +25,59 @@ from . import _lib, fields, losses, models, operations, rendering
 
 
 class _CaptureGate:
-    """Who may call into HIP when, over the frames that one rank optimises concurrently (launcher.run_frames).  Stream capture is a
-    process-wide mode, and the runtime's graph code is not safe against itself across threads; every line here is a dead rank seen in
-    round 4: torch refuses a replay during another thread's capture ("Cannot prepare for replay during capturing stage": every graph
-    registers the process-wide default generator); ROCm's ~CUDAGraph synchronises the device, which HIP refuses during a capture; HIP
-    refuses, now and then, even a STREAM synchronisation (`.item()`, `.cpu()`, `stream.synchronize()`, `torch.nonzero`, a module's
-    `.to(device)`) of one thread while another captures -- or lets it through and breaks the capture instead ("capturing stream has
-    unjoined work"; a graph from such a capture is the likely cause of the one segmentation fault inside hipGraphLaunch).
-    EXCLUSIVE (``with gate:``; re-entrant for its holder): a frame's construction, a phase's eager warm-up steps, a capture, the
-    destruction of graphs, host synchronisations and copies -- one thread at a time and no replay launch meanwhile.  SHARED
-    (``with gate.replaying():``): the launch of a replay -- any number at once (a launch can block for milliseconds behind the previous
-    launch of the same graph: serialising launches as well took the whole gain of several frames in flight, 0.85 -> 0.75 frames/s).
-    ``acquire(blocking=False)``: the garbage collector's path, which may run inside any thread, the holder's included, and never waits."""
+    """Stream capture against everything else, over the frames that one rank optimises concurrently (launcher.run_frames).  Capture is a
+    process-wide mode, and every collision seen in round 4 -- each one a dead rank -- had a capture on one side: torch refuses a replay
+    during another thread's capture ("Cannot prepare for replay during capturing stage": every graph registers the process-wide default
+    generator); ROCm's ~CUDAGraph synchronises the device, which HIP refuses during a capture; HIP refuses, now and then, even a STREAM
+    synchronisation (`.item()`, `.cpu()`, `stream.synchronize()`, `torch.nonzero`, a module's `.to(device)`) of one thread while another
+    captures -- or lets it through and breaks the capture instead ("capturing stream has unjoined work"; a graph from such a capture is
+    the likely cause of the one segmentation fault inside hipGraphLaunch).  So:
+      ``with gate.capture():``  a capture -- alone: nothing else of any frame calls into HIP meanwhile (a waiting capture goes first);
+      ``with gate:`` / ``acquire`` / ``release`` / ``with gate.replaying():``  everything else that calls into HIP from a frame's thread --
+      construction, eager warm-up steps, replay launches, graph destruction, host synchronisations and copies: any number at once, never
+      during a capture.  Nestable, also inside the capturing thread's own capture.
+    ``acquire(blocking=False)``: the garbage collector's path; it never waits, and inside the capturing thread it is refused.
+    (Two stricter gates came first: with EVERY call taking turns, replay launches included, the gain of several frames in flight was
+    gone, 0.85 -> 0.75 frames/s -- a launch blocks for milliseconds behind the previous launch of the same graph; with only the launches
+    shared, a frame still held the gate exclusively for 0.22-0.25 s of its 1.33 s.)"""
 
     def __init__(self):
-        # (a re-entrant lock under the condition: the garbage collector may run a FrameOptimizer's __del__ -- which asks for the gate without
-        #  waiting -- in a thread that is inside one of these few-line critical sections itself)
+        # (a re-entrant lock under the condition: the collector may run a FrameOptimizer's __del__ in a thread that is inside one of these
+        #  few-line critical sections itself)
         self._state = threading.Condition(threading.RLock())
-        self._owner, self._depth, self._replays = None, 0, 0
+        self._capturer, self._capture_depth, self._waiting_captures, self._others = None, 0, 0, 0
+        self._local = threading.local()
+        self.capture_seconds, self._since = 0.0, 0.0            # total time spent capturing (launcher.main reports it per frame)
+
+    def _depth(self):
+        return getattr(self._local, "depth", 0)
 
     def acquire(self, blocking=True):
         me = threading.get_ident()
         with self._state:
-            if self._owner == me:
-                if not blocking:             # the collector inside the holder's own thread: not now
+            if self._capturer == me:
+                if not blocking:             # the collector inside the capturing thread: not now
                     return False
-                self._depth += 1             # the holder calls something that takes the gate itself (rebind inside a constructor)
+                self._local.depth = self._depth() + 1           # (inside its own capture the capturing thread passes)
                 return True
-            while self._owner is not None or self._replays:
+            if self._depth() > 0:            # nested: a capture that waits for THIS thread to leave must not stop it on the way out
+                self._local.depth += 1
+                return True
+            while self._capturer is not None or self._waiting_captures:
                 if not blocking:
                     return False
                 self._state.wait()
-            self._owner, self._depth = me, 1
+            self._others += 1
+            self._local.depth = 1
             return True
 
     def release(self):
         with self._state:
-            self._depth -= 1
-            if self._depth == 0:
-                self._owner = None
-                self._state.notify_all()
+            self._local.depth -= 1
+            if self._local.depth == 0 and self._capturer != threading.get_ident():
+                self._others -= 1
+                if not self._others:
+                    self._state.notify_all()
 
     def __enter__(self):
         self.acquire()
@@ -73,37 +87,49 @@ class _CaptureGate:
         self.release()
 
     def replaying(self):
-        return _ReplayTurn(self)
+        return self
+
+    def capture(self):
+        return _CaptureTurn(self)
 
 
-class _ReplayTurn:
+class _CaptureTurn:
     def __init__(self, gate):
-        self.gate, self.counted = gate, False
+        self.gate = gate
 
     def __enter__(self):
-        gate = self.gate
+        gate, me = self.gate, threading.get_ident()
         with gate._state:
-            if gate._owner == threading.get_ident():      # a replay inside the holder's own exclusive section: already alone
+            if gate._capturer == me:
+                gate._capture_depth += 1
                 return
-            while gate._owner is not None:
-                gate._state.wait()
-            gate._replays += 1
-            self.counted = True
+            if gate._depth() > 0:
+                raise RuntimeError("a capture cannot start inside a section that holds the capture gate (it would wait for itself)")
+            gate._waiting_captures += 1
+            try:
+                while gate._capturer is not None or gate._others:
+                    gate._state.wait()
+            finally:
+                gate._waiting_captures -= 1
+            gate._capturer, gate._capture_depth = me, 1
+            gate._since = time.perf_counter()
 
     def __exit__(self, *exc):
-        if self.counted:
-            with self.gate._state:
-                self.gate._replays -= 1
-                if not self.gate._replays:
-                    self.gate._state.notify_all()
+        gate = self.gate
+        with gate._state:
+            gate._capture_depth -= 1
+            if gate._capture_depth == 0:
+                gate.capture_seconds += time.perf_counter() - gate._since
+                gate._capturer = None
+                gate._state.notify_all()
 
 
 _capture_lock = _CaptureGate()
 
 
 def exclusive_device_access():
-    """``with exclusive_device_access(): ...`` -- no frame of this process captures or launches a replay meanwhile: for device-wide
-    synchronisations and bulk device-to-host copies (checkpoints) of a frame that is optimised next to others."""
+    """``with exclusive_device_access(): ...`` -- no frame of this process captures meanwhile: for the host synchronisations and
+    device-to-host copies (`.item()`, `stream.synchronize()`, checkpoints) of a frame that is optimised next to others."""
     return _capture_lock
 
 
@@ -203,9 +229,9 @@ class FrameOptimizer:
 
     def __init__(self, inputs: FrameInputs, config: OptimizationConfig, device, graph=False, fused_glue=None):
         self._graphs = {}
-        # the whole construction takes its turn at the gate: it copies modules to the device, reads ranges back (.item()), runs nonzero --
-        # host synchronisations that, next to ANOTHER frame's capture, fail now and then or break that capture ("capturing stream has
-        # unjoined work" in the other thread: one 36-frame run in fourteen)
+        # the whole construction stays out of other frames' captures: it copies modules to the device, reads ranges back (.item()), runs
+        # nonzero -- host synchronisations that, next to ANOTHER frame's capture, fail now and then or break that capture ("capturing
+        # stream has unjoined work" in the other thread: one 36-frame run in fourteen)
         with _capture_lock:
             self._construct(inputs, config, device, graph, fused_glue)
 
@@ -555,7 +581,7 @@ class FrameOptimizer:
             return outputs
         done = self._eager_graph_steps.get(key, 0)
         if done < 3:
-            with _capture_lock:          # (a phase's three eager steps take their turn as well: nothing of a frame calls into HIP next to a capture)
+            with _capture_lock:          # (a phase's three eager steps too: nothing of a frame calls into HIP next to another frame's capture)
                 side = torch.cuda.Stream(device=self.device)
                 side.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(side):
@@ -573,11 +599,13 @@ class FrameOptimizer:
         # thread (launcher.run_frames(frames_in_flight=2)) may keep replaying its own graph meanwhile
         # (no device-wide synchronisation out here: while ANOTHER frame's thread captures, HIP refuses it -- "operation not permitted when
         #  stream is capturing"; torch.cuda.graph synchronises by itself once this thread holds the lock and nobody captures)
-        with _capture_lock, torch.cuda.graph(graph, stream=self._capture_stream, capture_error_mode="thread_local"):
-            outputs = self._step(static_rays, None, None, count=False)
-        self._graphs[key] = (graph, static_rays, outputs)
-        with _capture_lock.replaying():
-            graph.replay()                               # capture does not execute: this replay IS the step
+        with _capture_lock.capture():
+            with torch.cuda.graph(graph, stream=self._capture_stream, capture_error_mode="thread_local"):
+                outputs = self._step(static_rays, None, None, count=False)
+            self._graphs[key] = (graph, static_rays, outputs)
+            # capture does not execute: this replay IS the step.  A graph's FIRST launch stays inside the capture's turn: next to another
+            # thread's launch it died inside hipGraphLaunch (one 36-frame run in twelve; later launches of an uploaded graph have not)
+            graph.replay()
         self.step_index += 1
         return outputs
 
@@ -609,11 +637,15 @@ class FrameOptimizer:
         key = (residual, False, k)
         if key not in self._graphs:
             graph = torch.cuda.CUDAGraph()
-            with _capture_lock, torch.cuda.graph(graph, stream=self._capture_stream, capture_error_mode="thread_local"):
-                for j in range(k):      # the hypernetwork's branch is joined to the step's stream only at the ends of the graph: between two
-                    # steps the next prologue (which needs the epilogue only) overlaps the hypernetwork's backward and forward
-                    outputs = self._step(None, None, None, count=False, joins=(j == 0, j == k - 1))
-            self._graphs[key] = (graph, None, outputs)
+            with _capture_lock.capture():
+                with torch.cuda.graph(graph, stream=self._capture_stream, capture_error_mode="thread_local"):
+                    for j in range(k):  # the hypernetwork's branch is joined to the step's stream only at the ends of the graph: between two
+                        # steps the next prologue (which needs the epilogue only) overlaps the hypernetwork's backward and forward
+                        outputs = self._step(None, None, None, count=False, joins=(j == 0, j == k - 1))
+                self._graphs[key] = (graph, None, outputs)
+                graph.replay()          # (the first launch inside the capture's turn: _graph_step)
+            self.step_index += k
+            return outputs
         graph, _, outputs = self._graphs[key]
         with _capture_lock.replaying():
             graph.replay()
