@@ -338,3 +338,18 @@ def test_capture_gate_keeps_captures_alone():
                 raise AssertionError("unreachable")
         except RuntimeError:
             pass
+
+
+def test_to_host_rebuilds_containers_and_leaves_the_rest():
+    """formats.to_host: what launcher.main hands to torch.save for a frame optimised next to others -- every tensor a host copy, dicts /
+    lists / tuples rebuilt with their types, everything else untouched."""
+    import collections
+    import torch
+    from vsrd_amd import formats
+    payload = collections.OrderedDict(step=7, models={"m": {"w": torch.arange(4.0).requires_grad_(True)}}, groups=[{"lr": 0.5, "params": (0, 1)}],
+                                      metrics={}, name="frame")
+    out = formats.to_host(payload)
+    assert type(out) is collections.OrderedDict and list(out) == list(payload)
+    assert out["step"] == 7 and out["name"] == "frame" and out["groups"] == [{"lr": 0.5, "params": (0, 1)}] and type(out["groups"][0]["params"]) is tuple
+    w = out["models"]["m"]["w"]
+    assert w.device.type == "cpu" and not w.requires_grad and torch.equal(w, torch.arange(4.0)) and w is not payload["models"]["m"]["w"]
