@@ -141,30 +141,15 @@ def spawn_ranks(args):
 # ---------------------------------------------------------------------------------------------------------------------
 
 def kitti_intrinsics(height, width):
-    import torch
-    sx, sy = width / 1408.0, height / 376.0
-    return torch.tensor([[552.554261 * sx, 0.0, 682.049453 * sx], [0.0, 552.554261 * sy, 238.769549 * sy], [0.0, 0.0, 1.0]])
+    from vsrd_amd import synthetic
+    return synthetic.kitti_intrinsics(height, width)
 
 
 def synthetic_frame(seed, num_views, height, width, num_instances):
-    """KITTI-360 intrinsics, target E = I, sources shifted along z with a small yaw; raw box parameters ~ N(0, 0.5^2) with depth
-    forced into 8-60 m."""
-    import torch
-    g = torch.Generator().manual_seed(seed)
-    K = kitti_intrinsics(height, width).expand(num_views, 3, 3).contiguous()
-    E = torch.eye(4).repeat(num_views, 1, 1)
-    half = (num_views - 1) // 2
-    offsets = [0] + [k for i in range(1, half + 1) for k in (i, -i)]
-    for v, k in enumerate(offsets[:num_views]):
-        yaw = math.radians(0.5 * k)
-        E[v, :3, :3] = torch.tensor([[math.cos(yaw), 0.0, math.sin(yaw)], [0.0, 1.0, 0.0], [-math.sin(yaw), 0.0, math.cos(yaw)]])
-        E[v, 2, 3] = 1.0 * k
-    raw_loc = torch.randn(1, num_instances, 3, generator=g) * 0.5
-    depth = torch.empty(num_instances).uniform_(8.0, 60.0, generator=g) / 100.0
-    raw_loc[0, :, 2] = torch.log(depth / (1.0 - depth))            # sigmoid^-1, decoded z = 100 * sigmoid(raw)
-    raw_dim = torch.randn(1, num_instances, 3, generator=g) * 0.5
-    raw_ori = torch.nn.functional.normalize(torch.randn(1, num_instances, 2, generator=g), dim=-1)
-    return K, E, raw_loc, raw_dim, raw_ori
+    """vsrd_amd.synthetic.synthetic_frame (the frame launcher of the package optimises the same frames): KITTI-360 intrinsics, target
+    E = I, sources shifted along z with a small yaw; raw box parameters ~ N(0, 0.5^2) with depth forced into 8-60 m."""
+    from vsrd_amd import synthetic
+    return synthetic.synthetic_frame(seed, num_views, height, width, num_instances)
 
 
 def build_union(detector, temperature):
@@ -587,6 +572,8 @@ def extra_regimes():
     dense = ["value", "unit", "ms_per_step", "steps", "warmup", "n_gpus"]
     native = ["phase", "graph", "steps_per_s", "ms_per_step", "seconds_per_3000_step_frame", "seconds_per_frame", "warmup_phase_seconds",
               "residual_phase_seconds", "steps", "rays_per_step", "samples_per_ray", "views", "instances", "final_loss"]
+    frames = ["value", "unit", "n_gpus", "frames", "seconds", "frames_per_s_per_gpu", "per_rank_seconds", "seconds_per_frame_per_gpu", "capture_seconds_per_frame",
+              "restarts", "max_restarts", "mean_final_loss"]
     base = ["bench.py", "--no-cpu-baseline", "--no-extra-regimes"]
     tool = os.path.join("tools", "native_mode_bench.py")
     return {
@@ -596,6 +583,9 @@ def extra_regimes():
         "native_graph_box_only": child([tool, "--graph", "--steps", "300", "--json"], native),
         "native_graph_residual": child([tool, "--graph", "--residual", "--steps", "300", "--json"], native),
         "native_graph_whole_frame": child([tool, "--graph", "--whole-frame", "--json"], native),
+        # frames/s, the unit the reference shards (README.md:128): twelve whole frames through the frame launcher with its default frames in
+        # flight, checkpoints included (python bench.py --native = python -m vsrd_amd.launcher; on a node: --gpus 8)
+        "native_frames_per_s": child(["bench.py", "--native", "--gpus", "1", "--frames", "12"], frames, timeout=1200),
     }
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VSRD_ABI_VERSION 6
+#define VSRD_ABI_VERSION 7
 
 #define VSRD_OK 0
 #define VSRD_E_INVALID_ARGUMENT (-1) /* null pointer, non-positive size, unsupported N / S */
@@ -284,11 +284,16 @@ int32_t vsrd_render_backward(const vsrd_field* field, const vsrd_render_config* 
  * u_coarse / u_fine [R,S]: recorded uniforms, or NULL -> Philox4x32-10 keyed by (seed, stream_offset, ray).
  * Outputs: labels [R,N]; distances [R,2S] (needed by vsrd_render_backward; may be NULL for
  * inference); gradients [R,2S-1,3] / weights [R,2S-1] may be NULL;
- * u_coarse_out / u_fine_out [R,S] (may be NULL) export the uniforms actually used. */
+ * coarse_weights [R,S-1] (may be NULL; ABI 7): pass 1's compositing weights, i.e. the `sampled_weights` pass 1 of
+ * main.py:511-523 returns and samplers.py:11-36 turns into the importance samples (its `sampled_distances` are
+ * torch.lerp(linspace bins, u_coarse), vsrd_sample_stratified);
+ * u_coarse_out / u_fine_out [R,S] (may be NULL) export the uniforms actually used (u_fine_out: SORTED when they
+ * were generated in the kernel).  Box-only launches that ask for neither `gradients` nor `weights` run in the
+ * fused step's own mappings (several rays per wave), so these outputs are the step kernels' own pass-1 state. */
 int32_t vsrd_render_hierarchical_forward(const vsrd_field* field, const vsrd_render_config* config,
                                          const float* origins, const float* directions,
                                          const float* u_coarse, const float* u_fine,
-                                         float* labels, float* distances, float* gradients, float* weights,
+                                         float* labels, float* distances, float* gradients, float* weights, float* coarse_weights,
                                          float* u_coarse_out, float* u_fine_out, void* stream);
 
 /* One fused optimisation-step launch for box-only fields: the two-pass render of vsrd_render_hierarchical_forward, the

@@ -227,7 +227,8 @@ def _fused_step_properties(dev, N, S, V, H, W, residual, seed):
 
 def test_config5_full_size_fused_step(dev):
     """BASELINE config 5 at its full size on one GPU: 17 views x 752 x 2816 = 36.0 M rays, 64 instances, 128 samples per ray
-    (render_silhouette_kernel<4>; its arithmetic is pinned by golden g17_render_n64_s128_mid in test_hip_render.py)."""
+    (render_silhouette_pair_kernel<4, true, true>; arithmetic pinned by golden g17_render_n64_s128_mid in test_hip_render.py and, at this
+    size, against the oracle by test_full_size_parity_against_the_oracle below)."""
     _fused_step_properties(dev, N=64, S=128, V=17, H=752, W=2816, residual=False, seed=2)
 
 
@@ -370,3 +371,141 @@ def test_multi_ray_step_culling_is_invisible(dev, shape, schedule):
     fixed_err = max(float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12) for a, b in zip(fixed["default"], fixed["no_culling"]))
     margin(tag, "gradients, same samples", fixed_err, 2e-4)
     assert all(float(g.abs().max()) > 0 for g in fixed["no_culling"]) and fixed_err < 2e-4
+
+
+# ---- round 5: the benched kernels against the ORACLE at full size ------------------------------------------------------------------
+def _oracle_union(det, temperature, dtype):
+    from oracle import fields as ofields, geometry as ogeometry
+    raw = [p.detach().to(dtype).cpu()[0] for p in (det.locations, det.dimensions, det.orientations)]
+    loc, dim, rot, _ = ogeometry.decode_box_parameters(*raw)
+    return ofields.InstanceUnion(loc, rot, dim, temperature)
+
+
+def _in_chunks(function, tensors, chunk):
+    """function(*rows of every tensor) over chunks of rows (bounded memory on the host), results concatenated."""
+    parts = [function(*(t[start:start + chunk] for t in tensors)) for start in range(0, tensors[0].shape[0], chunk)]
+    if isinstance(parts[0], tuple):
+        return tuple(torch.cat([p[k] for p in parts]) for k in range(len(parts[0])))
+    return torch.cat(parts)
+
+
+@pytest.mark.parametrize("config", ["config2", "config5"])
+def test_full_size_parity_against_the_oracle(dev, config):
+    """BASELINE configs 2 and 5 at their FULL size on one GPU, the fused step bench.py times (vsrd_render_silhouette_step:
+    render_silhouette_quad_kernel<4, true, true> / render_silhouette_pair_kernel<4, true, true>) pinned against the CPU oracle link by
+    link (scripts/main.py:511-523, vsrd/rendering/samplers.py:24-36, renderers.py:212-263).
+
+    Rays: a seeded random draw of the frame PLUS the rays on which the step's own culling A/B (default flags against
+    VSRD_FLAG_NO_CULLING) moves a label by more than 2e-6 -- the tail test_multi_ray_step_culling_is_invisible describes (the largest
+    first when there are more than the cap; config 2: 8192 + up to 8192; config 5, whose oracle costs 16x as much per ray: 2048 + up
+    to 2048; VSRD_PARITY_RAYS=<n> overrides both numbers for a patient run).
+
+    The step returns labels, not samples.  vsrd_render_hierarchical_forward runs the same pass 1 / sampler / forward sweep in the same
+    mapping with the same Philox keys and returns the state in between (ABI 7: pass 1's weights and the uniforms used, next to the sorted
+    pass-2 distances); its labels are asserted BIT-IDENTICAL to the step's on every selected ray, so that state is the step's.  Then
+      (pass 1)   oracle weights at the kernel's stratified distances (from its u_coarse)            vs the kernel's coarse weights: 1e-5
+      (sampler)  oracle.importance_distances(kernel coarse distances, KERNEL coarse weights, kernel sorted uniforms), merged and sorted,
+                 vs the kernel's pass-2 distances: test_hip_render.assert_sampled_distances_close
+      (pass 2)   oracle.render_given_distances at the KERNEL's distances, float32 and float64         vs the step's labels: 1e-5 on EVERY ray
+      (end to end, reported + bounded) the whole oracle pipeline on the kernel's uniforms, float32 and float64: the fraction of selected rays
+                 with |HIP - float32 oracle| > 1e-4 next to the same fraction for float32 oracle vs float64 oracle -- "the tail is the
+                 algorithm's own conditioning (the sampler's / (delta cdf + 1e-6), the box normal's jumps)" as two numbers in the margin
+                 table; the HIP fraction may not exceed the oracles' own by more than 1e-3 of the rays.
+    Exact misses among the selected rays (NaN sentinel): the float64 oracle's labels there are below 1e-6."""
+    import os
+    import bench
+    from oracle import rendering as orendering
+    from test_hip_render import assert_sampled_distances_close
+    from vsrd_amd import rendering
+    from vsrd_amd.rendering import renderers
+    N, S, V, H, W, seed, budget = (16, 64, 9, 376, 1408, 0, 8192) if config == "config2" else (64, 128, 17, 752, 2816, 2, 2048)
+    budget = int(os.environ.get("VSRD_PARITY_RAYS", budget))
+    sched = bench.schedule_values(bench.SCHEDULES["mid"])
+    T, std, ratio = sched["temperature"], sched["std"], sched["cosine_ratio"]
+    det, cam, dirs = scene(dev, N, V, H, W, seed=seed)
+    directions = dirs.reshape(-1, 3)
+    origins = cam[:, None, None, :].expand(V, H, W, 3).reshape(-1, 3).contiguous()
+    R = directions.shape[0]
+    tag = f"test_full_size_parity_against_the_oracle[{config}]"
+    with torch.no_grad():
+        targets = rendering.render_hierarchical(bench.build_union(det, 0.1), origins, directions, (0.0, 100.0), S, 0.1, 1.0, seed=99,
+                                                skip_exact_misses=True)["labels"].clamp(0.0, 1.0).contiguous()
+        det.locations.add_(0.02)
+        keys = dict(seed=5, stream_offset=11)
+        # (a) the fused step, default flags, and its culling A/B
+        _, step_labels = rendering.silhouette_step(bench.build_union(det, T), origins, directions, targets, (0.0, 100.0), S, std, ratio,
+                                                   return_labels=True, **keys)
+        renderers.CULLING = False
+        try:
+            _, unculled = rendering.silhouette_step(bench.build_union(det, T), origins, directions, targets, (0.0, 100.0), S, std, ratio,
+                                                    return_labels=True, **keys)
+        finally:
+            renderers.CULLING = True
+        del targets
+        moved_by = (step_labels - unculled).abs().max(-1).values
+        del unculled
+        moved = torch.nonzero(moved_by > 2e-6).flatten()
+        margin(tag, "rays the culling A/B moves", moved.numel() / R, 1e-3)
+        if moved.numel() > budget:
+            moved = moved[torch.topk(moved_by[moved], budget).indices]
+        # (b) the selection
+        draw = torch.randint(0, R, (budget,), generator=torch.Generator().manual_seed(1234)).to(dev)
+        selection = torch.unique(torch.cat([draw, moved]))
+        # the forward launch in the step's mapping with the step's keys: samples and pass-1 state (two launches: bounded memory at config 5)
+        out = rendering.render_hierarchical(bench.build_union(det, T), origins, directions, (0.0, 100.0), S, std, ratio, skip_exact_misses=True, **keys)
+        assert torch.equal(out["labels"][selection], step_labels[selection]), "the forward launch and the fused step disagree on a selected ray"
+        margin(tag, "step vs forward launch, all rays", float((out["labels"] - step_labels).abs().max()), 2e-6)
+        hip_labels, hip_distances = step_labels[selection].cpu(), out["distances"][selection].cpu()
+        del out, step_labels
+        out = rendering.render_hierarchical(bench.build_union(det, T), origins, directions, (0.0, 100.0), S, std, ratio, skip_exact_misses=True,
+                                            return_uniforms=True, return_coarse_weights=True, **keys)
+        u_coarse, u_fine, hip_coarse_weights = (out[k][selection].cpu() for k in ("u_coarse", "u_fine", "coarse_weights"))
+        assert torch.equal(out["labels"][selection].cpu(), hip_labels)
+        del out
+    o, d = origins[selection].cpu(), directions[selection].cpu()
+    missed = torch.isnan(hip_distances[:, 0])
+    hit = ~missed
+    assert torch.all(hip_labels[missed] == 0) and int(hit.sum()) > selection.numel() // 20
+    assert torch.all(u_fine[:, 1:] >= u_fine[:, :-1])                                        # (drawn in the kernel: exported sorted)
+    union32, union64 = _oracle_union(det, T, torch.float32), _oracle_union(det, T, torch.float64)
+    chunk = 1024 if N <= 16 else 256
+    with torch.no_grad():
+        # ---- pass 1 ----
+        coarse_distances = orendering.stratified_distances((0.0, 100.0), S, u_coarse)
+        oracle_coarse = _in_chunks(lambda a, b, c: orendering.render_given_distances(union32, a, b, c, std, ratio).weights, (o, d, coarse_distances), chunk)
+        margin(tag, "pass-1 weights vs oracle", float((oracle_coarse - hip_coarse_weights).abs().max()), 1e-5)
+        assert (oracle_coarse - hip_coarse_weights).abs().max() < 1e-5
+        assert torch.all(hip_coarse_weights[missed] == 0)
+        # ---- sampler, fed with the KERNEL's coarse weights ----
+        fine = orendering.importance_distances(coarse_distances[hit], hip_coarse_weights[hit], u_fine[hit])
+        merged = torch.sort(torch.cat([coarse_distances[hit], fine], dim=-1), dim=-1).values
+        displaced = (hip_distances[hit] - merged).abs()
+        margin(tag, "samples off by > 5e-3 m", float((displaced > 5e-3 + 1e-4 * merged.abs()).float().mean()), 2e-3)
+        margin(tag, "largest sample displacement", float(displaced.max()), 0.02 * 100.0 / S)
+        assert_sampled_distances_close(hip_distances[hit], merged, S)
+        # ---- pass 2 at the kernel's own samples ----
+        fixed32 = _in_chunks(lambda a, b, c: orendering.render_given_distances(union32, a, b, c, std, ratio).labels, (o[hit], d[hit], hip_distances[hit]), chunk)
+        fixed64 = _in_chunks(lambda a, b, c: orendering.render_given_distances(union64, a.double(), b.double(), c.double(), std, ratio).labels,
+                             (o[hit], d[hit], hip_distances[hit]), chunk)
+        worst64 = float((hip_labels[hit].double() - fixed64).abs().max())
+        margin(tag, "labels at fixed samples, f64", worst64, 1e-5)
+        margin(tag, "labels at fixed samples, f32", float((hip_labels[hit] - fixed32).abs().max()), 1e-5)
+        assert worst64 < 1e-5 and (hip_labels[hit] - fixed32).abs().max() < 1e-5
+        # ---- end to end on the kernel's uniforms: the tail, as numbers ----
+        whole32 = _in_chunks(lambda a, b, c, e: orendering.hierarchical_render(union32, a, b, (0.0, 100.0), S, std, ratio, c, e).labels, (o, d, u_coarse, u_fine), chunk)
+        whole64 = _in_chunks(lambda a, b, c, e: orendering.hierarchical_render(union64, a.double(), b.double(), (0.0, 100.0), S, std, ratio, c.double(), e.double()).labels,
+                             (o, d, u_coarse, u_fine), chunk)
+    hip_tail = float(((hip_labels - whole32).abs().max(-1).values > 1e-4).float().mean())
+    oracle_tail = float(((whole32.double() - whole64).abs().max(-1).values > 1e-4).float().mean())
+    hip_tail64 = float(((hip_labels.double() - whole64).abs().max(-1).values > 1e-4).float().mean())
+    margin(tag, "rays > 1e-4: HIP vs f32 oracle", hip_tail, max(oracle_tail, 0.0) + 1e-3)
+    margin(tag, "rays > 1e-4: f32 vs f64 oracle", oracle_tail, 1.0)
+    margin(tag, "rays > 1e-4: HIP vs f64 oracle", hip_tail64, max(oracle_tail, 0.0) + 1e-3)
+    margin(tag, "worst ray, HIP vs f32 oracle", float((hip_labels - whole32).abs().max()), 1.0)
+    margin(tag, "worst ray, f32 vs f64 oracle", float((whole32.double() - whole64).abs().max()), 1.0)
+    margin(tag, "median ray, HIP vs f32 oracle", float((hip_labels - whole32).abs().max(-1).values.median()), 1e-5)
+    assert hip_tail <= oracle_tail + 1e-3 and hip_tail64 <= oracle_tail + 1e-3
+    assert float((hip_labels - whole32).abs().max(-1).values.median()) < 1e-5
+    assert float(whole64[missed].abs().max()) < 1e-6 if bool(missed.any()) else True
+    print(f"{tag}: {selection.numel()} rays ({int(moved.numel())} from the culling A/B, {int(missed.sum())} exact misses); > 1e-4 end to end: "
+          f"HIP vs f32 oracle {hip_tail:.2e}, f32 vs f64 oracle {oracle_tail:.2e}, HIP vs f64 oracle {hip_tail64:.2e}")

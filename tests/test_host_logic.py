@@ -155,9 +155,12 @@ def test_block_hand_over_is_scoped_to_one_wrapper_call():
     with torch.no_grad():
         block = fields.flatten(field)
     assert block.instances.requires_grad                          # built with autograd on even under no_grad: pass 2 differentiates it
+    assert block.capture_key is not None                          # flatten's walk of the tree also serves the hand-over's comparison
     hand = fields.BlockHandOver(field, block)
-    assert hand.take(field) is block
-    assert hand.take(_main_py_style_field(loc, dim, rot, 0.5)) is None        # another closure object (the next step's): no reuse
+    assert hand.key == block.capture_key and hand.take(field) is block
+    assert hand.take(field) is None                               # single use: the block carries ONE autograd graph
+    assert fields.BlockHandOver(field, block).take(_main_py_style_field(loc, dim, rot, 0.5)) is None      # another closure object (the next step's): no reuse
+    hand = fields.BlockHandOver(field, block)
     with torch.no_grad():
         loc.add_(1.0)                                             # an in-place update bumps the version
     assert hand.take(field) is None

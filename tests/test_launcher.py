@@ -168,3 +168,40 @@ def test_native_frames_entry_point_two_ranks_on_one_gpu(tmp_path):
     assert again.returncode == 0, again.stderr[-3000:]
     second = json.loads([l for l in again.stdout.splitlines() if l.startswith("{")][0])
     assert second["frames"] == 0 and second["frames_skipped_as_done"] == 5
+
+
+def test_supervisor_restarts_a_dead_rank_and_every_frame_is_done_once(tmp_path):
+    """VERDICT r04 item 4 (README.md:146-155: the reference leans on `torchrun --max_restarts`; main.py:134-136: skip-if-done): a gloo rank
+    is killed mid-job -- os._exit from inside its second frame's slot, no clean-up, its peer left in the final barrier.  The supervisor
+    (launcher._supervise: a GPU-free parent polling its ranks) ends the attempt, starts BOTH ranks again as fresh processes on a new port,
+    and the second attempt skips what has a checkpoint: the job returns 0, every frame has exactly one checkpoint, the frame the dying rank
+    finished before it died is not optimised again, and the report counts done + skipped = all frames."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    command = [sys.executable, "-m", "vsrd_amd.launcher", "--selftest", "--gpus", "2", "--frames", "9", "--selftest-seconds", "0.2",
+               "--selftest-fail", "1:1", "--max-restarts", "2", "--out", str(tmp_path)]
+    out = subprocess.run(command, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "rank 1 exited with code 23" in out.stderr and "starting the ranks again" in out.stderr
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                              # the failed attempt printed nothing: its rank 0 never got to the report
+    line = lines[0]
+    assert line["restarts"] == 1 and line["n_gpus"] == 2 and line["frames"] + line["frames_skipped_as_done"] == 9 and line["frames_skipped_as_done"] >= 1
+    frames = sorted(os.listdir(tmp_path))
+    assert [f for f in frames if f.startswith("frame_")] == [f"frame_{k:06d}" for k in range(9)]
+    payloads = [torch.load(os.path.join(tmp_path, f"frame_{k:06d}", "step_final.pt"), weights_only=False) for k in range(9)]
+    assert [p["frame"] for p in payloads] == list(range(9))
+    assert all(len(os.listdir(os.path.join(tmp_path, f"frame_{k:06d}"))) == 1 for k in range(9))     # no temporary files, no second checkpoint
+    completed = [tuple(int(v) for v in row.split()) for row in open(os.path.join(tmp_path, "completed.log")).read().splitlines()]
+    from vsrd_amd import launcher
+    first_of_dying_rank = launcher.shard_frames(list(range(9)), 1, 2, seed=0)[0]
+    assert [row for row in completed if row[0] == first_of_dying_rank] == [(first_of_dying_rank, 0, 1)]      # done before the rank died: not repeated
+    assert {row[0] for row in completed} == set(range(9))
+    assert all(sum(1 for row in completed if row[0] == k) <= 2 for k in range(9))                      # (a frame in flight when the attempt ended runs again)
+    assert any(p["attempt"] == 1 for p in payloads) and payloads[first_of_dying_rank]["attempt"] == 0
+    # no restarts allowed: the job fails with the dead rank's code instead of hanging in the survivor's barrier
+    failing = subprocess.run([*command[:-1], str(tmp_path / "second"), "--max-restarts", "0"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert failing.returncode == 23 and "no restarts left" in failing.stderr

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VSRD_HIP_LIBRARY: an experiment build of the same ABI (tools/phase_timers.py, A/B macros); the product path is the in-tree default
 LIBRARY_PATH = os.environ.get("VSRD_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libvsrd_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_INSTANCES = 64
 MAX_SAMPLES = 256
 INSTANCE_STRIDE = 16
@@ -143,7 +143,7 @@ SIGNATURES = {
                                               ctypes.c_int32, c_float_p, c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_size_t,
                                               c_float_p, c_float_p, ctypes.c_void_p]),
     "vsrd_render_hierarchical_forward": (ctypes.c_int32, [ctypes.POINTER(Field), ctypes.POINTER(RenderConfig), c_float_p, c_float_p,
-                                                          c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
+                                                          c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
                                                           c_float_p, c_float_p, ctypes.c_void_p]),
     "vsrd_render_silhouette_step": (ctypes.c_int32, [ctypes.POINTER(Field), ctypes.POINTER(RenderConfig), c_float_p, c_float_p, c_float_p,
                                                      c_float_p, c_float_p, c_float_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,
@@ -268,11 +268,12 @@ def make_config(num_rays, num_samples, distance_range, sdf_std_deviation, cosine
         offset_ptr, stream_offset = stream_offset.data_ptr(), 0
     ray_indices = target_columns = None
     rays_per_origin = target_stride = 0
-    if gather is not None:        # (ray_indices int64 [R], rays_per_origin, target_columns int32 [N] or None, target_stride): vsrd_render_config gather
+    if gather is not None:        # (ray_indices int64 [R] or None, rays_per_origin, target_columns int32 [N] or None, target_stride): vsrd_render_config gather
         indices, rays_per_origin, columns, target_stride = gather
-        if indices.dtype != torch.int64 or not indices.is_cuda or not indices.is_contiguous() or indices.numel() != int(num_rays):
-            raise ValueError("ray_indices must be a contiguous int64 device tensor with one entry per ray")
-        ray_indices = indices.data_ptr()
+        if indices is not None:   # (None: a dense launch that only maps the target columns)
+            if indices.dtype != torch.int64 or not indices.is_cuda or not indices.is_contiguous() or indices.numel() != int(num_rays):
+                raise ValueError("ray_indices must be a contiguous int64 device tensor with one entry per ray")
+            ray_indices = indices.data_ptr()
         if columns is not None:
             target_columns = iptr(columns).value
     return RenderConfig(int(num_rays), int(num_samples), float(distance_range[0]), float(distance_range[1]),

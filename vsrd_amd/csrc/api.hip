@@ -1,5 +1,6 @@
 // C ABI of libvsrd_hip (include/vsrd_hip.h): argument validation, launch geometry, dispatch on the
-// number of 64-sample rounds.  No torch types, no global state, no allocation.
+// number of 64-sample rounds.  No torch types, no allocation, and no state beyond the experiment switches below, which are read from
+// the environment ONCE (first call) and frozen: no entry point calls getenv per launch.
 #include <cstdio>
 #include <cstdlib>
 #include "../../include/vsrd_hip.h"
@@ -17,14 +18,34 @@ using namespace vsrd;
 
 constexpr int kMaxBlocks = 16384;             // 256 CUs x 8 workgroups: many more workgroups than are resident: rays differ a lot in cost and the dispatcher is the load balancer (r01: 2048 -> 16384 workgroups = -12 % time); also sizes the partial buffer
 
-int grid_cap() {                              // experiment switch: VSRD_GRID_BLOCKS=<n> (<= kMaxBlocks)
-    static const int cap = [] {
-        const char* e = getenv("VSRD_GRID_BLOCKS");
-        const int v = e ? atoi(e) : 0;
-        return (v > 0 && v <= kMaxBlocks) ? v : kMaxBlocks;
+// Experiment / A-B switches of the library, all of them: read once, then constants of the process.
+struct Switches {
+    int grid_blocks;          // VSRD_GRID_BLOCKS=<n> (<= kMaxBlocks): cap of the render grids
+    bool cap_to_residency;    // VSRD_CAP_TO_RESIDENCY=1: fit_to_residency really caps
+    bool debug;               // VSRD_DEBUG: failed launches / LDS opt-ins are reported on stderr
+    int split_max_rays;       // VSRD_SPLIT_MAX_RAYS: box-only step, launches of at most this many rays split every ray over two waves (0: never)
+    bool no_full_shape;       // VSRD_NO_FULL_SHAPE: the step keeps the run-time-shape kernels (quad_step.h: kFull)
+    int pair_max_rays;        // VSRD_PAIR_MAX_RAYS: residual step, 0 turns the pair kernel off for two-round launches
+    int slots_per_item;       // VSRD_SLOTS_PER_ITEM: forced item size of the MLP adjoint (0: planned)
+};
+const Switches& switches() {
+    static const Switches frozen = [] {
+        auto number = [](const char* name, int fallback) { const char* e = getenv(name); return e ? atoi(e) : fallback; };
+        Switches w;
+        const int blocks = number("VSRD_GRID_BLOCKS", 0);
+        w.grid_blocks = (blocks > 0 && blocks <= kMaxBlocks) ? blocks : kMaxBlocks;
+        const char* cap = getenv("VSRD_CAP_TO_RESIDENCY");
+        w.cap_to_residency = cap != nullptr && cap[0] == '1';
+        w.debug = getenv("VSRD_DEBUG") != nullptr;
+        w.split_max_rays = number("VSRD_SPLIT_MAX_RAYS", 2048);
+        w.no_full_shape = getenv("VSRD_NO_FULL_SHAPE") != nullptr;
+        w.pair_max_rays = number("VSRD_PAIR_MAX_RAYS", 2048);
+        w.slots_per_item = number("VSRD_SLOTS_PER_ITEM", 0);
+        return w;
     }();
-    return cap;
+    return frozen;
 }
+int grid_cap() { return switches().grid_blocks; }
 constexpr size_t kLdsLimit = 160 * 1024;     // gfx950 LDS per CU
 constexpr size_t kLdsDefault = 64 * 1024;    // dynamic LDS without opting in
 
@@ -67,22 +88,21 @@ void fit_to_residency(Kernel kernel, Geometry* g) {
     // Measured on C2 (r01): capping the grid at `resident` (one phase) is 5 % SLOWER than 2048 workgroups -- rays differ a lot in
     // cost (culling, early outs) and the extra workgroups act as dynamic load balancing -- so the grid is left alone unless the
     // experiment switch asks for it.
-    static const char* cap = getenv("VSRD_CAP_TO_RESIDENCY");
-    if (cap && cap[0] == '1' && g->blocks > resident) g->blocks = resident;
+    if (switches().cap_to_residency && g->blocks > resident) g->blocks = resident;
 }
 
 template <typename Kernel>
 int opt_in_lds(Kernel kernel, size_t bytes) {
     if (bytes <= kLdsDefault) return VSRD_OK;
     const hipError_t error = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
-    if (error != hipSuccess && getenv("VSRD_DEBUG")) fprintf(stderr, "libvsrd_hip: LDS opt-in of %zu bytes failed: %s\n", bytes, hipGetErrorString(error));
+    if (error != hipSuccess && switches().debug) fprintf(stderr, "libvsrd_hip: LDS opt-in of %zu bytes failed: %s\n", bytes, hipGetErrorString(error));
     return error == hipSuccess ? VSRD_OK : VSRD_E_LAUNCH;
 }
 
 int launch_status() {
     const hipError_t error = hipGetLastError();
     if (error == hipSuccess) return VSRD_OK;
-    if (getenv("VSRD_DEBUG")) fprintf(stderr, "libvsrd_hip: launch failed: %s\n", hipGetErrorString(error));
+    if (switches().debug) fprintf(stderr, "libvsrd_hip: launch failed: %s\n", hipGetErrorString(error));
     return VSRD_E_LAUNCH;
 }
 
@@ -464,7 +484,7 @@ int32_t vsrd_render_backward(const vsrd_field* field, const vsrd_render_config* 
 int32_t vsrd_render_hierarchical_forward(const vsrd_field* field, const vsrd_render_config* config,
                                          const float* origins, const float* directions,
                                          const float* u_coarse, const float* u_fine,
-                                         float* labels, float* distances, float* gradients, float* weights,
+                                         float* labels, float* distances, float* gradients, float* weights, float* coarse_weights,
                                          float* u_coarse_out, float* u_fine_out, void* stream) {
     if (!valid_field(field) || !valid_config(config)) return VSRD_E_INVALID_ARGUMENT;
     if (config->num_rays == 0) return VSRD_OK;   // empty batch: buffers may be null
@@ -477,18 +497,18 @@ int32_t vsrd_render_hierarchical_forward(const vsrd_field* field, const vsrd_ren
     RenderArgs c = render_args(config);
     c.sh.inv_t = f.inv_t;
     const hipStream_t s = static_cast<hipStream_t>(stream);
-    // labels (and distances) only, box-only field: the forward in the mappings of the fused step (quad_step.h) -- four rays per wave for
-    // N <= 16 and S <= 64, two for N <= 64 and S <= 128
-    if (!residual && !gradients && !weights && !u_coarse_out && !u_fine_out && !(config->flags & VSRD_FLAG_STEP_WAVE_PER_RAY) &&
+    // labels, distances, pass 1's weights and the uniforms only (no per-sample gradients / weights of pass 2), box-only field: the forward
+    // in the mappings of the fused step (quad_step.h) -- four rays per wave for N <= 16 and S <= 64, two for N <= 64 and S <= 128
+    if (!residual && !gradients && !weights && !(config->flags & VSRD_FLAG_STEP_WAVE_PER_RAY) &&
         S <= kPairMaxSamples && field->num_instances <= kPairMaxInstances) {
         const bool quad = S <= kQuadMaxSamples && field->num_instances <= kQuadMaxInstances;
         const int lanes = quad ? kRowLanes : 32, rays_per_wave = kWave / lanes;
         if (!plan((config->num_rays + rays_per_wave - 1) / rays_per_wave, static_cast<size_t>(quad_lds_floats(S, field->num_instances, lanes)), &g))
             return VSRD_E_UNSUPPORTED;
         if (quad) hipLaunchKernelGGL(render_hierarchical_quad_kernel, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins,
-                                     directions, u_coarse, u_fine, labels, distances);
+                                     directions, u_coarse, u_fine, labels, distances, coarse_weights, u_coarse_out, u_fine_out);
         else hipLaunchKernelGGL(render_hierarchical_pair_kernel, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins,
-                                directions, u_coarse, u_fine, labels, distances);
+                                directions, u_coarse, u_fine, labels, distances, coarse_weights, u_coarse_out, u_fine_out);
         return launch_status();
     }
     if (!plan(config->num_rays, static_cast<size_t>(hierarchical_lds_floats(S, field->num_instances, residual)), &g)) return VSRD_E_UNSUPPORTED;
@@ -498,7 +518,7 @@ int32_t vsrd_render_hierarchical_forward(const vsrd_field* field, const vsrd_ren
         fit_to_residency(render_hierarchical_kernel<K, RES>, &g);                                                             \
         hipLaunchKernelGGL((render_hierarchical_kernel<K, RES>), dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f,            \
                            field->instances, field->mlp_weights, c, origins, directions, u_coarse, u_fine, labels, distances,   \
-                           gradients, weights, u_coarse_out, u_fine_out);                                                     \
+                           gradients, weights, coarse_weights, u_coarse_out, u_fine_out);                                                     \
     } while (0)
     const int rounds = rounds_for(2 * S - 1);
     if (residual) {
@@ -551,10 +571,7 @@ int32_t vsrd_project_boxes_backward(const float* world_corners, const float* ext
 
 namespace {
 constexpr int kSplitBlocks = 1024;                       // render_silhouette_split_kernel: x 2 waves = two waves on each of the 1024 SIMDs
-int split_max_rays() {                                   // box-only step: launches of at most this many rays split every ray over two waves (0: never)
-    static const int value = [] { const char* e = getenv("VSRD_SPLIT_MAX_RAYS"); return e ? atoi(e) : 2048; }();
-    return value;
-}
+int split_max_rays() { return switches().split_max_rays; }   // box-only step: launches of at most this many rays split every ray over two waves (0: never)
 }  // namespace
 
 int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_config* config,
@@ -579,7 +596,8 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
     // dense launches of the benchmark shapes: four neighbouring rays per wave (quad_step.h).  Gathered rays (the reference's 1000
     // importance-sampled rays per step) are neither neighbours nor enough to fill the chip four to a wave.
     const bool force_split = (config->flags & VSRD_FLAG_STEP_SPLIT_RAY) && !(config->flags & VSRD_FLAG_STEP_WAVE_PER_RAY);
-    const bool dense = config->ray_indices == nullptr && !(config->flags & VSRD_FLAG_STEP_WAVE_PER_RAY) && !force_split;
+    // (dense = rays AND targets read row by row: the multi-ray kernels know neither ray_indices nor the target column map)
+    const bool dense = config->ray_indices == nullptr && config->target_columns == nullptr && !(config->flags & VSRD_FLAG_STEP_WAVE_PER_RAY) && !force_split;
     const bool quad = dense && S <= kQuadMaxSamples && N <= kQuadMaxInstances;
     // ... and for more instances or samples than that (BASELINE config 5: N = 64, S = 128) two rays per wave, 32 lanes each
     const bool pair = dense && !quad && S <= kPairMaxSamples && N <= kPairMaxInstances;
@@ -614,8 +632,8 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
     // a launch that fills its shape (S = lanes x rounds of the shape, more than half of its instance slots: BASELINE configs 2 and 5)
     // runs the hot kernel instantiated for that S with the instance tables padded to the shape's count (quad_step.h: kFull)
     const int shape_instances = quad ? kQuadMaxInstances : kPairMaxInstances;
-    const bool full = (quad || pair) && S == lanes * quad_rounds_s(S, lanes) && S >= 2 * lanes && 2 * N > shape_instances &&
-                      !getenv("VSRD_NO_FULL_SHAPE");
+    // (exactly the launches the dispatch below gives a <4, true, true> kernel: S = 4 x lanes)
+    const bool full = (quad || pair) && S == 4 * lanes && 2 * N > shape_instances && !switches().no_full_shape;
     Geometry g;
     const size_t per_wave = (quad || pair) ? static_cast<size_t>(quad_lds_floats(S, full ? shape_instances : N, lanes)) : static_cast<size_t>(wave_lds_floats(S, N)) + N + row;
     if (!plan((quad || pair) ? (config->num_rays + rays_per_wave - 1) / rays_per_wave : config->num_rays, per_wave, &g)) return VSRD_E_UNSUPPORTED;
@@ -751,10 +769,7 @@ constexpr int kMlpAdjointBlocks = 4096;                  // single-wave workgrou
 constexpr int kPairBlocks = 1024;                        // residual_step_pair_kernel: x 2 waves = two waves on each of the 1024 SIMDs
 constexpr int kPairMaxRays = 2048;                       // two-round launches of at most this many rays split each ray over two waves
 
-int pair_max_rays() {                                    // experiment switch: 0 turns the pair kernel off
-    static const int value = [] { const char* e = getenv("VSRD_PAIR_MAX_RAYS"); return e ? atoi(e) : kPairMaxRays; }();
-    return value;
-}
+int pair_max_rays() { return switches().pair_max_rays; }    // experiment switch: 0 turns the pair kernel off
 
 struct ResidualStepPlan {
     int rounds, chunk, front_blocks, front_waves, slots_per_item, items_per_instance;
@@ -790,7 +805,7 @@ static bool plan_residual_step(int N, int S, int num_rays, bool allow_pair, Resi
     // items: enough of them to balance ~2000 waves, few enough that an item amortises its partial row (6.6 KB written and read once)
     long long per_item = (p->slots_per_instance * N) / 16384;
     per_item = per_item < 4 ? 4 : (per_item > 32 ? 32 : per_item);
-    static const int forced = [] { const char* e = getenv("VSRD_SLOTS_PER_ITEM"); return e ? atoi(e) : 0; }();     // experiment switch
+    const int forced = switches().slots_per_item;                        // experiment switch
     if (forced >= 1 && forced <= 64) per_item = forced;
     p->slots_per_item = static_cast<int>(per_item);
     p->items_per_instance = static_cast<int>((p->slots_per_instance + per_item - 1) / per_item);

@@ -173,6 +173,7 @@ __host__ __device__ constexpr int quad_rounds_s(int num_samples, int lanes = kRo
 #ifndef VSRD_CACHE_SLOTS
 #define VSRD_CACHE_SLOTS 22       // (what three workgroups per CU leave room for at S = 128, N = 64: 52 160 of 54 613 bytes)
 #endif
+static_assert(VSRD_CACHE_SLOTS >= 16 && VSRD_CACHE_SLOTS <= 32, "quad_label_sums gathers a survivor's rank within the 32 lanes of a ray, and the rows are reused as the [16][64] C1 / C3 area");
 constexpr int kCacheSlots = VSRD_CACHE_SLOTS;   // (>= 16: the rows also hold C1 / C3 of the eight pass-2 rounds) shapes with more instances than lanes per ray: soft-min terms of the first 16 survivors of a round
 // Two rays per wave: the terms of survivor k of a round start at float k * kSlotStride (64 lanes + 4: rows stay 16-byte aligned and
 // sixteen lanes reading sixteen DIFFERENT rows with ds_read_b128 touch every bank once -- quad_label_sums), and one more row holds the
@@ -193,7 +194,8 @@ __host__ __device__ constexpr int quad_lds_floats(int num_samples, int num_insta
 // Stratified distances and sorted fine uniforms of the lane's ray (render_kernels.h: stage_ray_samples, per 16-lane row).
 template <int kL, int kRoundsS>
 __device__ __forceinline__ void quad_stage_samples(float* rowbase, const RenderArgs& c, int S, int ray, const float* __restrict__ u_coarse,
-                                                   const float* __restrict__ u_fine, bool sorted_input, const RowLanes& rl) {
+                                                   const float* __restrict__ u_fine, bool sorted_input, const RowLanes& rl,
+                                                   float* __restrict__ u_coarse_out = nullptr, float* __restrict__ u_fine_out = nullptr, bool write = false) {
     float* coarse = rowbase;
     float* usorted = rowbase + S;
     float* uraw = rowbase + quad_merged_offset(S, kL);
@@ -222,6 +224,7 @@ __device__ __forceinline__ void quad_stage_samples(float* rowbase, const RenderA
             const float lo = torch_linspace(c.near, c.far, S + 1, idx);
             const float hi = torch_linspace(c.near, c.far, S + 1, idx + 1);
             coarse[idx] = torch_lerp(lo, hi, uc);
+            if (u_coarse_out != nullptr && write) u_coarse_out[urow + idx] = uc;
         }
         if (u_fine == nullptr) {
             const float e = valid ? -fast_log(1.0f - uf) : 0.0f;
@@ -230,6 +233,7 @@ __device__ __forceinline__ void quad_stage_samples(float* rowbase, const RenderA
             running = lane_gather(inclusive, rl.last);
         } else if (valid) {
             (sorted_input ? usorted : uraw)[idx] = uf;
+            if (u_fine_out != nullptr && write) u_fine_out[urow + idx] = uf;
         }
     }
     if (u_fine == nullptr) {
@@ -237,7 +241,11 @@ __device__ __forceinline__ void quad_stage_samples(float* rowbase, const RenderA
 #pragma unroll
         for (int k = 0; k < kRoundsS; ++k) {
             const int idx = k * kL + rl.col;
-            if (idx < S) usorted[idx] = fminf(spacing[k] * inv_total, 0.99999994f);
+            if (idx < S) {
+                const float sorted_u = fminf(spacing[k] * inv_total, 0.99999994f);
+                usorted[idx] = sorted_u;
+                if (u_fine_out != nullptr && write) u_fine_out[urow + idx] = sorted_u;      // (the uniforms actually used: already sorted)
+            }
         }
     }
     wave_lds_sync();
@@ -997,7 +1005,9 @@ __device__ __forceinline__ void silhouette_rows_kernel_body(
     const int lane0 = lane_id();
     static_assert(kHot || !kFull, "only the hot kernel is instantiated for a full shape");
     if (kFull) c.num_samples = kL * kRoundsS;                                   // (the host launches kFull for exactly this S)
-    c.ray_indices = nullptr; c.target_columns = nullptr; c.rays_per_origin = 0;  // (these kernels take dense launches only: api.hip)
+    // (these kernels take dense launches only -- no ray_indices, no target column map: vsrd_render_silhouette_step sends every other launch
+    //  to the one-ray kernels -- so the three fields are compile-time nothing here)
+    c.ray_indices = nullptr; c.target_columns = nullptr; c.rays_per_origin = 0;
     const int S = c.num_samples;
     const int N = f.num_instances;
     const int NP = kFull ? (kL == kRowLanes ? kQuadMaxInstances : kPairMaxInstances) : N;      // rows of the instance tables
@@ -1090,7 +1100,8 @@ template <int kL, int kRoundsS, bool kYaw, bool kRunning>
 __device__ __forceinline__ bool rows_forward_body(const float* __restrict__ instances, int N, const RenderArgs& c, const Shading& sh, int first_ray,
                                                   const float* __restrict__ origins, const float* __restrict__ directions,
                                                   const float* __restrict__ u_coarse, const float* __restrict__ u_fine, bool sorted_input,
-                                                  float* __restrict__ labels_out, float* __restrict__ distances_out,
+                                                  float* __restrict__ labels_out, float* __restrict__ distances_out, float* __restrict__ coarse_weights_out,
+                                                  float* __restrict__ u_coarse_out, float* __restrict__ u_fine_out,
                                                   float* stage, float* dcache, float* coefs, float* rays, const RowLanes& rl) {
     constexpr int kRounds = 2 * kRoundsS;
     constexpr int kSlots = kL == kRowLanes ? 1 : 2;
@@ -1108,9 +1119,14 @@ __device__ __forceinline__ bool rows_forward_body(const float* __restrict__ inst
         r.ox = o[0]; r.oy = o[1]; r.oz = o[2]; r.rx = d[0]; r.ry = d[1]; r.rz = d[2];
         quad_ray_setup<kL>(instances, N, N, r, coef_own, rays + rl.row * kRowRayFloats, rl);
     }
-    quad_stage_samples<kL, kRoundsS>(rowbase, c, S, ray, u_coarse, u_fine, sorted_input, rl);
+    quad_stage_samples<kL, kRoundsS>(rowbase, c, S, ray, u_coarse, u_fine, sorted_input, rl, u_coarse_out, u_fine_out, alive);
     float w1[kRoundsS];
     if (!quad_pass_one<kL, kRoundsS, kYaw, kRunning>(instances, N, sh, rays + rl.row * kRowRayFloats, coef_own, rowbase, S, w1, rl)) return false;
+    if (coarse_weights_out != nullptr && alive) {            // pass 1's compositing weights: what pass 1 of main.py:511-523 hands to pass 2
+#pragma unroll
+        for (int k = 0; k < kRoundsS; ++k)
+            if (k * kL + rl.col < S - 1) coarse_weights_out[static_cast<size_t>(my_ray) * (S - 1) + k * kL + rl.col] = w1[k];
+    }
     float coarse_total = 0.0f;
 #pragma unroll
     for (int k = 0; k < kRoundsS; ++k) coarse_total += seg_sum<kL>(w1[k]);
@@ -1149,7 +1165,8 @@ __device__ __forceinline__ bool rows_forward_body(const float* __restrict__ inst
 template <int kL, int kRoundsS>
 __device__ __forceinline__ void hierarchical_rows_kernel_body(
     FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
-    const float* __restrict__ u_coarse, const float* __restrict__ u_fine, float* __restrict__ labels_out, float* __restrict__ distances_out) {
+    const float* __restrict__ u_coarse, const float* __restrict__ u_fine, float* __restrict__ labels_out, float* __restrict__ distances_out,
+    float* __restrict__ coarse_weights_out, float* __restrict__ u_coarse_out, float* __restrict__ u_fine_out) {
     constexpr int kRays = kWave / kL;
     apply_device_schedule(f, c);
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1176,25 +1193,27 @@ __device__ __forceinline__ void hierarchical_rows_kernel_body(
         bool done = false;
         if (sh.reach >= 0.0f) {
             done = sh.yaw ? rows_forward_body<kL, kRoundsS, true, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input,
-                                                                         labels_out, distances_out, stage, dcache, coefs, rays, rl)
+                                                                         labels_out, distances_out, coarse_weights_out, u_coarse_out, u_fine_out, stage, dcache, coefs, rays, rl)
                           : rows_forward_body<kL, kRoundsS, false, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input,
-                                                                          labels_out, distances_out, stage, dcache, coefs, rays, rl);
+                                                                          labels_out, distances_out, coarse_weights_out, u_coarse_out, u_fine_out, stage, dcache, coefs, rays, rl);
             if (!done) wave_lds_sync();
         }
         if (!done) rows_forward_body<kL, kRoundsS, false, true>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input,
-                                                                labels_out, distances_out, stage, dcache, coefs, rays, rl);
+                                                                labels_out, distances_out, coarse_weights_out, u_coarse_out, u_fine_out, stage, dcache, coefs, rays, rl);
     }
 }
 
 __global__ __launch_bounds__(kBlockThreads, 4) void render_hierarchical_quad_kernel(
     FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
-    const float* __restrict__ u_coarse, const float* __restrict__ u_fine, float* __restrict__ labels_out, float* __restrict__ distances_out) {
-    hierarchical_rows_kernel_body<kRowLanes, 4>(f, instances, c, origins, directions, u_coarse, u_fine, labels_out, distances_out);
+    const float* __restrict__ u_coarse, const float* __restrict__ u_fine, float* __restrict__ labels_out, float* __restrict__ distances_out,
+    float* __restrict__ coarse_weights_out, float* __restrict__ u_coarse_out, float* __restrict__ u_fine_out) {
+    hierarchical_rows_kernel_body<kRowLanes, 4>(f, instances, c, origins, directions, u_coarse, u_fine, labels_out, distances_out, coarse_weights_out, u_coarse_out, u_fine_out);
 }
 __global__ __launch_bounds__(kBlockThreads, 4) void render_hierarchical_pair_kernel(
     FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
-    const float* __restrict__ u_coarse, const float* __restrict__ u_fine, float* __restrict__ labels_out, float* __restrict__ distances_out) {
-    hierarchical_rows_kernel_body<32, 4>(f, instances, c, origins, directions, u_coarse, u_fine, labels_out, distances_out);
+    const float* __restrict__ u_coarse, const float* __restrict__ u_fine, float* __restrict__ labels_out, float* __restrict__ distances_out,
+    float* __restrict__ coarse_weights_out, float* __restrict__ u_coarse_out, float* __restrict__ u_fine_out) {
+    hierarchical_rows_kernel_body<32, 4>(f, instances, c, origins, directions, u_coarse, u_fine, labels_out, distances_out, coarse_weights_out, u_coarse_out, u_fine_out);
 }
 
 // ---- the adjoint at saved distances (vsrd_render_backward, box-only fields, label adjoints only) in the same mappings ------------------

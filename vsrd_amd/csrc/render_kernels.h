@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
     FieldArgs f, const float* __restrict__ instances, const float* __restrict__ mlp, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
     const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
     float* __restrict__ labels, float* __restrict__ distances, float* __restrict__ gradients, float* __restrict__ weights,
-    float* __restrict__ u_coarse_out, float* __restrict__ u_fine_out) {
+    float* __restrict__ coarse_weights, float* __restrict__ u_coarse_out, float* __restrict__ u_fine_out) {
     apply_device_schedule(f, c);
     constexpr int kRoundsS = (kRounds + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -253,6 +253,11 @@ __global__ __launch_bounds__(kBlockThreads) void render_hierarchical_kernel(
         // ---- pass 1: coarse weights only (no labels, no outputs) ----------------------------------
         float w1[kRoundsS];
         render_pass<kRoundsS, false, kResidual>(instances, mlp, f.num_instances, sh, r, rc, l.coarse, S, l.dcache, w1, nullptr, nullptr);
+        if (coarse_weights != nullptr) {                             // pass 1's compositing weights (main.py:511-523: what pass 1 hands to pass 2)
+#pragma unroll
+            for (int k = 0; k < kRoundsS; ++k)
+                if (k * kWave + lane < S - 1) coarse_weights[static_cast<size_t>(ray) * (S - 1) + k * kWave + lane] = w1[k];
+        }
         if (c.flags & 2u) {
             float total = 0.0f;
 #pragma unroll

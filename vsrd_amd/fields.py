@@ -42,6 +42,7 @@ class FieldBlock:
     # leave the adjoints of the five constant matrix entries out (VSRD_FLAG_YAW_GRADIENTS).  Set by the code that built the block from a
     # detector (FrameOptimizer, bench.build_union); never inferred from the closure tree of a drop-in call.
     yaw_gradients: bool = False
+    capture_key: Optional[tuple] = None      # flatten(): identity + version of every tensor the closure tree captured (BlockHandOver)
 
     @property
     def num_instances(self):
@@ -252,7 +253,9 @@ def flatten(field) -> FieldBlock:
         raise UnsupportedFieldError(f"{len(members)} instances > VSRD_MAX_INSTANCES={_lib.MAX_INSTANCES}")
     parts = [_unwrap_instance(m) for m in members]
     with torch.enable_grad():         # (also under no_grad: the block of main.py's pass 1 is handed to the differentiable pass 2, below)
-        return _build_block(parts, temperature, hard)
+        block = _build_block(parts, temperature, hard)
+    block.capture_key = _key_of(parts, temperature, hard)        # (what BlockHandOver compares: this walk of the tree serves it too)
+    return block
 
 
 class BlockHandOver:
@@ -263,17 +266,22 @@ class BlockHandOver:
     that very tensor, the closure is the same object, and every tensor the closure tree captures is the same object at the same
     version.  Nothing is kept in module state (round 3's thread-local "last block" could outlive a parameter update written through
     `.data` or a raw pointer, which no version counter sees: ADVICE r03); the entry dies with the tensor.
+    The handed-over block is SINGLE-USE: it carries one autograd graph from the parameters to `instances`, so a caller that renders
+    pass 2 twice from the same `sampled_distances` and calls backward on each would walk that graph twice ("backward through the graph
+    a second time"); the first take() empties the hand-over and a second pass 2 flattens the closure afresh.
+    The tree is walked twice per step: once by flatten() in pass 1 (which leaves its key on the block) and once here in pass 2.
     ``vsrd_amd.fields.BLOCK_HAND_OVER = False`` switches it off."""
 
     def __init__(self, field, block):
         self.field, self.block = field, block
-        self.key = _capture_key(field)
+        self.key = getattr(block, "capture_key", None) or _capture_key(field)
 
     def take(self, field):
-        if not BLOCK_HAND_OVER or field is not self.field:
+        block, self.block = self.block, None
+        if not BLOCK_HAND_OVER or block is None or field is not self.field:
             return None
         try:
-            return self.block if _capture_key(field) == self.key else None
+            return block if _capture_key(field) == self.key else None
         except UnsupportedFieldError:
             return None
 
@@ -281,11 +289,14 @@ class BlockHandOver:
 BLOCK_HAND_OVER = True
 
 
-def _capture_key(field):
-    members, temperature, hard = _as_soft_union(field)
-    parts = [_unwrap_instance(m) for m in members]
+def _key_of(parts, temperature, hard):
     return (hard, (id(temperature), temperature._version) if isinstance(temperature, torch.Tensor) else float(temperature),
             tuple((id(t), t._version, t.requires_grad) if isinstance(t, torch.Tensor) else t for p in parts for t in p))
+
+
+def _capture_key(field):
+    members, temperature, hard = _as_soft_union(field)
+    return _key_of([_unwrap_instance(m) for m in members], temperature, hard)
 
 
 def _build_block(parts, temperature, hard) -> FieldBlock:

@@ -118,12 +118,11 @@ def run_frames(frames: Sequence, optimise: Callable, checkpoint_path: Callable[[
 # ---------------------------------------------------------------------------------------------------------------------------------
 
 def synthetic_frame_inputs(device, frame, views, instances, height=376, width=1408):
-    """FrameInputs of synthetic frame number `frame` (bench.synthetic_frame(seed = frame): KITTI-360 intrinsics, boxes in the
+    """FrameInputs of synthetic frame number `frame` (synthetic.synthetic_frame(seed = frame): KITTI-360 intrinsics, boxes in the
     reference's ranges): soft masks rendered from the true boxes at the sharp end of the schedule, ground-truth 2-D boxes projected
     from them, every instance visible in every view."""
-    import bench
-    from . import fields, models, operations, optimization, rendering
-    K, E, raw_loc, raw_dim, raw_ori = bench.synthetic_frame(int(frame), views, height, width, instances)
+    from . import fields, models, operations, optimization, rendering, synthetic
+    K, E, raw_loc, raw_dim, raw_ori = synthetic.synthetic_frame(int(frame), views, height, width, instances)
     K, E = K.to(device), E.to(device)
     det = models.BoxParameters3D(1, instances).to(device)
     with torch.no_grad():
@@ -138,23 +137,69 @@ def synthetic_frame_inputs(device, frame, views, instances, height=376, width=14
     return optimization.FrameInputs((height, width), K, E, soft, gt_boxes, torch.ones(views, instances, dtype=torch.bool, device=device))
 
 
-def _spawn(argv, gpus, share_gpu):
-    """No launcher around us: start `gpus` copies of this module, one rank each, before anything here touches a GPU."""
+def _wait_for_ranks(children, grace_seconds=10.0):
+    """Poll the ranks until all have exited.  The first rank that exits non-zero takes the others with it (SIGTERM, SIGKILL after
+    `grace_seconds`): a rank whose peer died would otherwise sit in its final barrier until the collective's watchdog fires, tens of
+    minutes later.  Returns None when every rank exited 0, else (rank, exit code) of the first failure."""
+    import time
+    pending = dict(enumerate(children))
+    failed, deadline = None, None
+    while pending:
+        for rank, child in list(pending.items()):
+            code = child.poll()
+            if code is None:
+                continue
+            del pending[rank]
+            if code != 0 and failed is None:
+                failed, deadline = (rank, code), time.monotonic() + grace_seconds
+                for other in pending.values():
+                    other.terminate()
+        if failed is not None and pending and time.monotonic() > deadline:
+            for other in pending.values():
+                other.kill()
+            deadline = float("inf")
+        if pending:
+            time.sleep(0.05)
+    return failed
+
+
+def _supervise(argv, args):
+    """No launcher around us: this process stays GPU-free and supervises `--gpus` rank processes (README.md:146-155: the reference leans on
+    `torchrun --max_restarts` for the same thing, and on its skip-if-done guard, main.py:134-136, for what a restart repeats).
+
+    A rank that dies -- a segmentation fault inside the runtime, an out-of-memory kill -- strands its shard and leaves its peers in a
+    barrier.  The supervisor ends the attempt (see _wait_for_ranks) and starts ALL ranks again as FRESH child processes, up to
+    `--max-restarts` times: nothing that has initialised a GPU is ever re-executed, the rendezvous gets a new port, and every frame whose
+    final checkpoint exists is skipped, so a restart costs the frames that were in flight.  The checkpoint directory therefore has to
+    outlive an attempt: the supervisor fixes it (a temporary directory unless --out names one) and hands it to the ranks."""
     import socket
     import subprocess
     import sys
-    if not share_gpu and torch.cuda.device_count() < gpus:
-        raise SystemExit(f"vsrd_amd.launcher --gpus {gpus}: this node has {torch.cuda.device_count()} visible GPU(s); one rank per GPU")
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    children = []
-    for rank in range(gpus):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(gpus), LOCAL_WORLD_SIZE=str(gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        children.append(subprocess.Popen([sys.executable, "-m", "vsrd_amd.launcher", *argv], env=env,
-                                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-    return max(abs(child.wait()) for child in children)
+    import tempfile
+    # (counting devices does not initialise the runtime on this image; a selftest has no devices to count)
+    if not args.ranks_share_gpu and not args.selftest and torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"vsrd_amd.launcher --gpus {args.gpus}: this node has {torch.cuda.device_count()} visible GPU(s); one rank per GPU")
+    if not args.out:
+        argv = list(argv) + ["--out", tempfile.mkdtemp(prefix="vsrd_frames_")]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    failed = None
+    for attempt in range(args.max_restarts + 1):
+        with socket.socket() as s:                 # (a free port now; should somebody take it before rank 0 binds it, the attempt fails and the next one asks again)
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        children = []
+        for rank in range(args.gpus):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            children.append(subprocess.Popen([sys.executable, "-m", "vsrd_amd.launcher", *argv, "--attempt", str(attempt)], env=env, cwd=root))
+        failed = _wait_for_ranks(children)
+        if failed is None:
+            return 0
+        again = attempt < args.max_restarts
+        print(f"[vsrd_amd.launcher] attempt {attempt}: rank {failed[0]} exited with code {failed[1]}; "
+              + ("starting the ranks again as fresh processes (frames with a final checkpoint are skipped)" if again else "no restarts left"),
+              file=sys.stderr, flush=True)
+    return abs(failed[1]) or 1
 
 
 def main(argv=None):
@@ -186,6 +231,15 @@ def main(argv=None):
     parser.add_argument("--seed", type=int, default=0)
     parser.add_argument("--ranks-share-gpu", action="store_true",
                         help="TEST ONLY: every rank on cuda:0, gloo rendezvous (RCCL refuses two ranks on one device); the line says so")
+    parser.add_argument("--max-restarts", type=int, default=2,
+                        help="without torchrun around it, the launcher supervises its ranks: when one dies, all are started again as fresh "
+                             "processes, this many times at most; finished frames are skipped (0 with --gpus 1: no child processes at all)")
+    parser.add_argument("--attempt", type=int, default=0, help=argparse.SUPPRESS)          # set by the supervisor: restarts so far
+    parser.add_argument("--selftest", action="store_true",
+                        help="no rendering, no GPU: a frame is a sleep of --selftest-seconds and a small checkpoint (gloo, CPU) -- the supervisor, "
+                             "the sharding, the skip-if-done guard and the report, for tests/test_launcher.py; the line says so")
+    parser.add_argument("--selftest-seconds", type=float, default=0.05)
+    parser.add_argument("--selftest-fail", default="", help="RANK:FRAMES -- on attempt 0 that rank dies (exit code 23) once it has finished FRAMES frames")
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parser.parse_args(argv)
     if not 1 <= args.frames_in_flight <= 4:
@@ -195,10 +249,12 @@ def main(argv=None):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))          # bench.synthetic_frame, __graft_entry__.build live at the repo root
     if root not in sys.path:
         sys.path.insert(0, root)
-    if "RANK" not in os.environ and args.gpus > 1:
-        return _spawn(argv, args.gpus, args.ranks_share_gpu)
+    if "RANK" not in os.environ and (args.gpus > 1 or args.max_restarts > 0):
+        return _supervise(argv, args)
     if args.ranks_share_gpu:
         os.environ["LOCAL_RANK"] = "0"
+    if args.selftest:
+        return _selftest_rank(args)
     if not torch.cuda.is_available():
         raise SystemExit("vsrd_amd.launcher optimises frames on HIP devices: no GPU visible, and vsrd_amd has no CPU fallback")
     rank, world, device = init_process_group(backend="gloo" if args.ranks_share_gpu else None)
@@ -255,6 +311,7 @@ def main(argv=None):
             "metric": "optimised target frames/s, whole job (reference: about 15 minutes per frame on a V100, README.md:128)",
             "value": frames_done / slowest, "unit": "frames/s", "n_gpus": len(gathered), "higher_is_better": True, "scaling": "weak",
             "frames": frames_done, "frames_skipped_as_done": sum(r["skipped"] for r in gathered), "seconds": slowest,
+            "restarts": args.attempt, "max_restarts": args.max_restarts,     # (restarts > 0: `seconds` and `frames` are the last attempt's)
             "frames_per_s_per_gpu": frames_done / slowest / len(gathered),
             "per_rank_seconds": [r["own_seconds"] for r in gathered], "per_rank_frames": [r["frames"] for r in gathered],
             "seconds_per_frame_per_gpu": [r["own_seconds"] / r["frames"] if r["frames"] else None for r in gathered],
@@ -270,6 +327,61 @@ def main(argv=None):
         if args.ranks_share_gpu:
             line["metric"] = "ranks share ONE GPU (--ranks-share-gpu): a test of the multi-rank path, NOT a scaling measurement; " + line["metric"]
         print(json.dumps(line), flush=True)
+    barrier()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    return 0
+
+
+def _selftest_rank(args):
+    """One rank of `--selftest`: the launch / manifest / shard / skip-if-done / checkpoint / report path with a sleep for a frame, on gloo
+    without a GPU.  `--selftest-fail RANK:FRAMES` makes that rank die on attempt 0 once it has finished FRAMES frames."""
+    import json
+    import sys
+    import time
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    total = args.frames or 4 * world
+    manifest = broadcast_manifest(dict(frames=list(range(total)), seed=args.seed, out=args.out) if rank == 0 else None)
+    if not manifest["out"]:
+        raise SystemExit("--selftest needs --out (the supervisor supplies one)")
+    os.makedirs(manifest["out"], exist_ok=True)
+    mine = shard_frames(manifest["frames"], rank, world, seed=manifest["seed"])
+    ordered(lambda r: print(f"[rank {r}/{world}] selftest: frames {mine}", file=sys.stderr, flush=True))
+    fail_rank, fail_after = (int(v) for v in args.selftest_fail.split(":")) if args.selftest_fail else (-1, 0)
+    finished = []
+
+    def optimise(frame):
+        if args.attempt == 0 and rank == fail_rank and len(finished) >= fail_after:
+            os._exit(23)                                    # a dead rank: no clean-up, no goodbye to the process group
+        time.sleep(args.selftest_seconds)
+        finished.append(frame)
+        with open(os.path.join(manifest["out"], "completed.log"), "a") as log:      # (O_APPEND: one short line per frame, whole)
+            log.write(f"{int(frame)} {args.attempt} {rank}\n")
+        return dict(frame=int(frame), attempt=args.attempt, rank=rank)
+
+    def path_of(frame):
+        return os.path.join(manifest["out"], f"frame_{int(frame):06d}", "step_final.pt")
+
+    barrier()
+    t0 = time.perf_counter()
+    done = run_frames(mine, optimise, path_of, frames_in_flight=1)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    report = dict(rank=rank, frames=len(done), skipped=len(mine) - len(done), elapsed_seconds=elapsed)
+    gathered = [report]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, report)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher selftest: no rendering, NOT a measurement", "value": 0.0, "unit": "none", "n_gpus": len(gathered),
+                          "frames": sum(r["frames"] for r in gathered), "frames_skipped_as_done": sum(r["skipped"] for r in gathered),
+                          "per_rank_frames": [r["frames"] for r in gathered], "restarts": args.attempt, "max_restarts": args.max_restarts,
+                          "config": {"workload": f"sleep({args.selftest_seconds} s) per frame on gloo / CPU", "checkpoints": manifest["out"]}}), flush=True)
     barrier()
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -251,7 +251,7 @@ class _RenderHierarchical(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, instances, mlp_weights, origins, directions, u_coarse, u_fine, temperature, scalars, origin_stride,
-                seed, stream_offset, flags, want_gradients, want_weights, want_uniforms):
+                seed, stream_offset, flags, want_gradients, want_weights, want_uniforms, want_coarse_weights=False):
         lib = _lib.load()
         std, ratio, eps, near, far, S, schedule = _unpack(scalars)
         R = directions.shape[0]
@@ -264,6 +264,7 @@ class _RenderHierarchical(torch.autograd.Function):
         weights = torch.empty(R, 2 * S - 1, dtype=torch.float32, device=dev) if want_weights else None
         uc_out = torch.empty(R, S, dtype=torch.float32, device=dev) if want_uniforms else None
         uf_out = torch.empty(R, S, dtype=torch.float32, device=dev) if want_uniforms else None
+        coarse_weights = torch.empty(R, S - 1, dtype=torch.float32, device=dev) if want_coarse_weights else None
         mlp_weights = None if mlp_weights is None else _centre_mlp(mlp_weights)
         field = _lib.make_field(instances, temperature, mlp_weights)
         ctx.residual = mlp_weights is not None
@@ -273,18 +274,19 @@ class _RenderHierarchical(torch.autograd.Function):
         with profiling.timed("vsrd_render_hierarchical_forward"):
             _lib.check(lib.vsrd_render_hierarchical_forward(
                 field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(u_coarse), _lib.ptr(u_fine),
-                _lib.ptr(labels), _lib.ptr(distances), _lib.ptr(gradients), _lib.ptr(weights),
+                _lib.ptr(labels), _lib.ptr(distances), _lib.ptr(gradients), _lib.ptr(weights), _lib.ptr(coarse_weights),
                 _lib.ptr(uc_out), _lib.ptr(uf_out), _lib.stream()))
         ctx.save_for_backward(instances, origins, directions, distances)
         ctx.meta = (temperature, scalars, origin_stride)
         ctx.set_materialize_grads(False)
         outs = (labels, gradients if want_gradients else labels.new_empty(0), weights if want_weights else labels.new_empty(0),
-                distances, uc_out if want_uniforms else labels.new_empty(0), uf_out if want_uniforms else labels.new_empty(0))
-        ctx.mark_non_differentiable(outs[3], outs[4], outs[5])
+                distances, uc_out if want_uniforms else labels.new_empty(0), uf_out if want_uniforms else labels.new_empty(0),
+                coarse_weights if want_coarse_weights else labels.new_empty(0))
+        ctx.mark_non_differentiable(outs[3], outs[4], outs[5], outs[6])
         return outs
 
     @staticmethod
-    def backward(ctx, grad_labels, grad_gradients, grad_weights, _gd, _gu1, _gu2):
+    def backward(ctx, grad_labels, grad_gradients, grad_weights, _gd, _gu1, _gu2, _gcw):
         instances, origins, directions, distances = ctx.saved_tensors
         temperature, scalars, origin_stride = ctx.meta
         if grad_gradients is not None and grad_gradients.numel() == 0:
@@ -293,7 +295,7 @@ class _RenderHierarchical(torch.autograd.Function):
             grad_weights = None
         grad, grad_mlp = _backward(instances, ctx.mlp, origins, directions, distances, temperature, scalars, origin_stride,
                                    grad_labels, grad_gradients, grad_weights)
-        return (grad, grad_mlp) + (None,) * 13
+        return (grad, grad_mlp) + (None,) * 14
 
 
 def _scatter_labels(labels, block: FieldBlock):
@@ -318,9 +320,11 @@ def render_at_distances(distance_field, ray_positions, ray_directions, distances
 
 def render_hierarchical(distance_field, ray_positions, ray_directions, distance_range, num_samples, sdf_std_deviation,
                         cosine_ratio=1.0, epsilon=1.0e-6, u_coarse=None, u_fine=None, seed=0, stream_offset=0,
-                        return_gradients=False, return_weights=False, return_uniforms=False, skip_exact_misses=False, schedule=None):
+                        return_gradients=False, return_weights=False, return_uniforms=False, skip_exact_misses=False, schedule=None,
+                        return_coarse_weights=False):
     """Fused two-pass render.  Returns a dict: labels [R,N], distances [R,2S], optionally gradients
-    [R,2S-1,3], weights [R,2S-1], u_coarse/u_fine [R,S] (the uniforms actually used).
+    [R,2S-1,3], weights [R,2S-1], u_coarse/u_fine [R,S] (the uniforms actually used; u_fine sorted when drawn in the kernel),
+    coarse_weights [R,S-1] (pass 1's compositing weights: what pass 1 of main.py:511-523 hands to pass 2).
     ``schedule`` (device float32 [3] = temperature, sdf_std_deviation, cosine_ratio) and a tensor ``stream_offset`` are read on the
     device instead of the scalar arguments (hipGraph replay; see include/vsrd_hip.h)."""
     block = flatten(distance_field)
@@ -333,9 +337,9 @@ def render_hierarchical(distance_field, ray_positions, ray_directions, distance_
     flags = (_lib.FLAG_SKIP_EXACT_MISSES if skip_exact_misses else 0) | _base_flags()
     scalars = (float(sdf_std_deviation), float(cosine_ratio), float(epsilon), float(distance_range[0]),
                float(distance_range[1]), int(num_samples), schedule)
-    labels, gradients, weights, distances, uc, uf = _RenderHierarchical.apply(
+    labels, gradients, weights, distances, uc, uf, cw = _RenderHierarchical.apply(
         block.instances, block.mlp_weights, origins, directions, u_coarse, u_fine, block.temperature, scalars, stride,
-        int(seed), _offset(stream_offset), flags, bool(return_gradients), bool(return_weights), bool(return_uniforms))
+        int(seed), _offset(stream_offset), flags, bool(return_gradients), bool(return_weights), bool(return_uniforms), bool(return_coarse_weights))
     out = dict(labels=_scatter_labels(labels, block), distances=distances)
     if return_gradients:
         out["gradients"] = gradients
@@ -343,6 +347,8 @@ def render_hierarchical(distance_field, ray_positions, ray_directions, distance_
         out["weights"] = weights
     if return_uniforms:
         out["u_coarse"], out["u_fine"] = uc, uf
+    if return_coarse_weights:
+        out["coarse_weights"] = cw
     return out
 
 
