@@ -81,6 +81,14 @@ typedef struct vsrd_render_config {
      * in prediction order. */
     const int32_t* target_columns;         /* [N] or NULL                                                           */
     int32_t target_stride;                 /* columns of a targets row when target_columns is set                   */
+    /* Optional outputs of vsrd_render_silhouette_step (ABI 7; every other entry point rejects them): the per-ray state between the
+     * step's passes, written by the step launch itself -- what pass 1 of scripts/main.py:511-523 returns (`sampled_weights`), the
+     * uniforms it drew, and the sorted pass-2 distances its labels, loss and gradients were computed at.  Rows are in STEP order (ray r
+     * of the launch).  A step that writes them takes the multi-ray or the one-ray kernels (never the split-ray form). */
+    float* out_distances;                  /* [R,2S] or NULL; row of an exact miss (VSRD_FLAG_SKIP_EXACT_MISSES): [r,0] = NaN, rest untouched */
+    float* out_coarse_weights;             /* [R,S-1] or NULL: pass 1's compositing weights                           */
+    float* out_u_coarse;                   /* [R,S] or NULL: the stratified uniforms used                            */
+    float* out_u_fine;                     /* [R,S] or NULL: the fine uniforms used (SORTED when drawn in the kernel) */
 } vsrd_render_config;
 
 #define VSRD_FLAG_FINE_UNIFORMS_SORTED 1u /* u_fine is already sorted ascending per ray     */
@@ -140,6 +148,13 @@ typedef struct vsrd_render_config {
                                              honoured when every rotation of the field IS of that form (checked on the device), by the
                                              multi-ray kernels of vsrd_render_silhouette_step / vsrd_render_backward; never set it for
                                              rotation matrices that are parameters themselves                                          */
+
+#define VSRD_FLAG_MLP_SPLIT_BF16 2048u      /* vsrd_render_residual_step (two-kernel form): the per-instance MLP's matrix products of the FRONT
+                                             kernel (pass 1, pass 2: value and gradient of every residual) run on v_mfma_f32_16x16x32_bf16 with
+                                             both operands split into two bfloat16 parts (x = hi + lo to 2^-18; fp32 accumulation) instead of the
+                                             exact-fp32 matrix instruction.  A/B switch (ABI 7): results agree with the default to ~2e-6 on the
+                                             silhouettes and ~1e-3 of the largest gradient entry (tests/split_bf16_emulation.py, the residual
+                                             goldens under both settings).  Other entry points ignore it.                                 */
 
 int32_t vsrd_abi_version(void);
 const char* vsrd_error_string(int32_t code);

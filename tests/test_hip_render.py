@@ -724,9 +724,21 @@ def test_fused_residual_step_matches_two_launch_path(dev, name):
             assert (a - b).abs().max() <= 2e-4 * max(float(b.abs().max()), 1e-6)
 
 
+@pytest.fixture(params=["fp32_mfma", "split_bf16"])
+def mlp_products(request):
+    """How the front kernels of vsrd_render_residual_step multiply: the exact-fp32 matrix instruction (default) or the bf16 one with both
+    operands split into two bfloat16 parts (VSRD_FLAG_MLP_SPLIT_BF16; csrc/residual.h) -- VERDICT r04 item 2: the same tests, the same
+    tolerances, under both settings, with the margins of both in the record."""
+    from vsrd_amd.rendering import renderers
+    before = renderers.MLP_SPLIT_BF16
+    renderers.MLP_SPLIT_BF16 = request.param == "split_bf16"
+    yield request.param
+    renderers.MLP_SPLIT_BF16 = before
+
+
 @pytest.mark.parametrize("name", [n for n in RESIDUAL_CASES if n.startswith("g17")])
 @pytest.mark.parametrize("form", ["default", "wave_per_ray", "single_kernel"])
-def test_fused_residual_step_golden(dev, name, form):
+def test_fused_residual_step_golden(dev, name, form, mlp_products):
     """vsrd_render_residual_step at the shapes the benchmark times (BASELINE config 3: N = 16, S = 64; the reference's S = 100), in each
     of its three forms -- default: residual_step_pair_kernel<2 / 4> + residual_mlp_adjoint_kernel (launches of <= 2048 rays split a ray
     over two waves); wave_per_ray: residual_step_front_kernel<2 / 4> + residual_mlp_adjoint_kernel, WHAT DENSE LAUNCHES (bench.py's config
@@ -736,6 +748,9 @@ def test_fused_residual_step_golden(dev, name, form):
     the generator) combine to  (R / R_c) grad_bce + ratio * grad_eikonal  -- the dropped rays have clamped (zero) labels, whose
     BCE gradient is exactly zero."""
     from vsrd_amd import fields, rendering
+    if form == "single_kernel" and mlp_products == "split_bf16":
+        pytest.skip("the one-kernel form has no split-bf16 products (the flag is ignored there)")
+    tag = f"test_fused_residual_step_golden[{mlp_products}-{form}-{name}]"
     g = load_golden(name)
     S, N = int(g["num_samples"]), g["locations"].shape[0]
     std, ratio = float(g["sdf_std_deviation"]), float(g["cosine_ratio"])
@@ -757,15 +772,17 @@ def test_fused_residual_step_golden(dev, name, form):
         grads = torch.autograd.grad(loss, [loc, dim, rot, mlp])
     finally:
         renderers.RESIDUAL_SINGLE_KERNEL = renderers.RESIDUAL_WAVE_PER_RAY = False
-    assert (labels.cpu() - g["fine_labels"][keep]).abs().max() < LABEL_TOL
+    assert margin(tag, "labels vs golden", (labels.cpu() - g["fine_labels"][keep]).abs().max(), LABEL_TOL) < LABEL_TOL
     want_bce = torch.nn.functional.binary_cross_entropy(g["fine_labels"][keep].clamp(1.0e-6, 1.0 - 1.0e-6), g["targets"][keep], reduction="none").mean()
+    margin(tag, "silhouette loss (rel)", abs(float(terms[0]) - float(want_bce)) / max(abs(float(want_bce)), 1e-12), 1e-4)
+    margin(tag, "eikonal loss (rel)", abs(float(terms[1]) - float(g["eikonal_conditioned"])) / max(abs(float(g["eikonal_conditioned"])), 1e-12), 1e-2)
     torch.testing.assert_close(terms[0].cpu(), want_bce, rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(terms[1].cpu(), g["eikonal_conditioned"], rtol=1e-2, atol=5e-6)
     for got, key in zip(grads, ("locations", "dimensions", "orientations", "mlp_weights")):
         want = (R / Rc) * g["grad_bce_" + key] + eikonal_ratio * g["grad_eikonal_" + key]
         err = (got.cpu() - want).abs().max().item() / max(float(want.abs().max()), 1e-6)
-        print(f"[fused residual step vs reference] {name} {form} {key}: rel err {err:.3e}")
-        assert err < GRAD_TOL, f"{key}: relative error {err:.3e}"
+        print(f"[fused residual step vs reference] {name} {form} {mlp_products} {key}: rel err {err:.3e}")
+        assert margin(tag, f"grad {key} vs golden", err, GRAD_TOL) < GRAD_TOL, f"{key}: relative error {err:.3e}"
 
 
 @pytest.mark.parametrize("name", [n for n in RESIDUAL_CASES if n.startswith("g17")])
@@ -950,9 +967,13 @@ def test_quad_step_matches_wave_per_ray(dev, N, S, R, case):
     #  where it can be: at FIXED samples -- the distances one forward launch saved, the BCE label adjoints of its labels, pushed through
     #  render_backward_{quad,pair}_kernel (the step's own forward sweep / reverse sweep / per-instance phase) and through render_backward_kernel --
     #  within 2e-4 of the largest entry on EVERY scene; the moving-sample gradients keep their median bound and are reported.)
+    #  Two sets of label adjoints: seeded standard-normal ones (well conditioned: 2e-4 in EVERY case), and the step's own BCE ones, whose
+    #  1 / p reach 1e6 x loss_scale -- there the two mappings' culling (e^-18 terms dropped at different granularity) is visible in the sharp
+    #  cases (T = std = 0.1 / T = 0.02: observed 1.2e-3), so those are held to 5e-3 and the ordinary schedules to 2e-4.)
     loose_labels, fixed_gradient_tolerance = 1e-3, 2e-4
+    bce_fixed_tolerance = 5e-3 if case in ("misses", "tiny_temperature") else 2e-4
     tag = f"test_quad_step_matches_wave_per_ray[{N}-{S}-{R}-{case}]"
-    label_errors, gradient_errors, fixed_errors = [], [], []
+    label_errors, gradient_errors, fixed_errors, bce_fixed_errors = [], [], [], []
     for scene_seed in (31 + N + S, 1000, 1001, 1002, 1003):
         sc = _random_scene(scene_seed, N, R, S, general_rotations=(case == "general"))
         directions = sc["directions"].clone()
@@ -988,24 +1009,28 @@ def test_quad_step_matches_wave_per_ray(dev, N, S, R, case):
         chosen = probabilities if pd is None else probabilities[:, pd]
         wanted = targets.to(dev) if gt is None else targets.to(dev)[:, gt]
         bce = torch.nn.functional.binary_cross_entropy(chosen.clamp(1.0e-6, 1.0 - 1.0e-6), wanted)
-        lam = torch.autograd.grad(bce, probabilities)[0]
-        fixed = {}
-        for mode in ("quad", "wave"):
-            renderers.STEP_WAVE_PER_RAY = mode == "wave"
-            try:
-                fixed[mode] = torch.autograd.grad(out["labels"], inst, grad_outputs=lam, retain_graph=True)[0]
-            finally:
-                renderers.STEP_WAVE_PER_RAY = False
-        fixed_errors.append(float((fixed["quad"] - fixed["wave"]).abs().max()) / max(float(fixed["wave"].abs().max()), 1e-12))
+        lam_bce = torch.autograd.grad(bce, probabilities)[0]
+        lam_normal = torch.randn(out["labels"].shape, generator=torch.Generator().manual_seed(scene_seed)).to(dev)
+        for lam, errors in ((lam_normal, fixed_errors), (lam_bce, bce_fixed_errors)):
+            fixed = {}
+            for mode in ("quad", "wave"):
+                renderers.STEP_WAVE_PER_RAY = mode == "wave"
+                try:
+                    fixed[mode] = torch.autograd.grad(out["labels"], inst, grad_outputs=lam, retain_graph=True)[0]
+                finally:
+                    renderers.STEP_WAVE_PER_RAY = False
+            errors.append(float((fixed["quad"] - fixed["wave"]).abs().max()) / max(float(fixed["wave"].abs().max()), 1e-12))
     median = lambda values: sorted(values)[len(values) // 2]
     margin(tag, "labels, median of scenes", median(label_errors), label_tolerance)
     margin(tag, "labels, worst scene", max(label_errors), loose_labels)
     margin(tag, "gradients, median", median(gradient_errors), gradient_tolerance)
     margin(tag, "gradients, worst (informative)", max(gradient_errors), 1.0)
     margin(tag, "gradients, same samples", max(fixed_errors), fixed_gradient_tolerance)
+    margin(tag, "gradients, same samples, BCE", max(bce_fixed_errors), bce_fixed_tolerance)
     assert median(label_errors) < label_tolerance and max(label_errors) < loose_labels, label_errors
     assert median(gradient_errors) <= gradient_tolerance, gradient_errors
     assert max(fixed_errors) <= fixed_gradient_tolerance, fixed_errors
+    assert max(bce_fixed_errors) <= bce_fixed_tolerance, bce_fixed_errors
 
 
 @pytest.mark.parametrize("N,S,R", [(8, 32, 203), (16, 64, 64), (40, 100, 37)])
@@ -1042,12 +1067,15 @@ def test_dense_step_honours_the_target_column_map(dev, N, S, R):
                                                    _lib.ptr(loss), _lib.ptr(grad), _lib.ptr(labels), _lib.stream()))
         return float(loss), grad, labels
 
-    mapped = launch(raw.to(dev).contiguous(), columns.to(dev), M, 0)
+    mapped = launch(raw.to(dev).contiguous(), columns.to(dev), M, 0)                                 # whatever the dispatch picks (one ray per wave, or a ray split over two)
+    mapped_one_ray = launch(raw.to(dev).contiguous(), columns.to(dev), M, _lib.FLAG_STEP_WAVE_PER_RAY)
     one_ray = launch(ordered.to(dev).contiguous(), None, 0, _lib.FLAG_STEP_WAVE_PER_RAY)
-    default = launch(ordered.to(dev).contiguous(), None, 0, 0)
-    assert mapped[0] == one_ray[0] and torch.equal(mapped[1], one_ray[1]) and torch.equal(mapped[2], one_ray[2])
+    default = launch(ordered.to(dev).contiguous(), None, 0, 0)                                       # the multi-ray kernels
+    assert mapped_one_ray[0] == one_ray[0] and torch.equal(mapped_one_ray[1], one_ray[1]) and torch.equal(mapped_one_ray[2], one_ray[2])
     assert float(mapped[2].max()) > 0.05 and float(mapped[1].abs().max()) > 0
-    assert abs(mapped[0] - default[0]) <= 1e-4 * abs(default[0]) and (mapped[2] - default[2]).abs().max() < 1e-3
+    for got in (mapped, mapped_one_ray):
+        assert abs(got[0] - default[0]) <= 1e-4 * abs(default[0]) and (got[2] - default[2]).abs().max() < 1e-3
+        assert (got[1] - default[1]).abs().max() <= 5e-3 * float(default[1].abs().max())
 
 
 @pytest.mark.parametrize("N,S,R,case", [(8, 100, 250, "yaw"), (16, 64, 203, "yaw"), (4, 32, 64, "yaw"), (3, 20, 61, "general"), (64, 128, 37, "yaw"), (5, 64, 97, "tiny_temperature"),

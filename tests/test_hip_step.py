@@ -152,8 +152,18 @@ def test_five_optimisation_steps_match_oracle(dev):
     assert torch.isfinite(losses_free["loss"])
 
 
+@pytest.fixture(params=["fp32_mfma", "split_bf16"])
+def mlp_products(request):
+    """The residual step's front kernel on the exact-fp32 matrix instruction or on split-bf16 products (VSRD_FLAG_MLP_SPLIT_BF16)."""
+    from vsrd_amd.rendering import renderers
+    before = renderers.MLP_SPLIT_BF16
+    renderers.MLP_SPLIT_BF16 = request.param == "split_bf16"
+    yield request.param
+    renderers.MLP_SPLIT_BF16 = before
+
+
 @pytest.mark.parametrize("S", [32, 100])          # 100 = the reference's own samples per ray (config.json:236): 199 points, 4 rounds
-def test_residual_phase_step_matches_oracle(dev, S):
+def test_residual_phase_step_matches_oracle(dev, S, mlp_products):
     """Post-warm-up step (config 3 shape): hypernetwork -> per-instance MLP weights -> residual field + eikonal loss, gradients
     into boxes, embeddings and hypernetwork, against the CPU oracle step with identical weights and randomness."""
     from vsrd_amd import optimization, rendering, fields
@@ -211,7 +221,8 @@ def test_residual_phase_step_matches_oracle(dev, S):
         scale = max(float(exact_grad.abs().max()), 1e-12)
         err = float((device_grad.double() - exact_grad).abs().max()) / scale
         floor = float((oracle_grad.double() - exact_grad).abs().max()) / scale
-        print(f"[residual phase step, S={S}] {name}: device vs float64 oracle {err:.3e} (float32 oracle vs float64: {floor:.3e})")
+        print(f"[residual phase step, S={S}, {mlp_products}] {name}: device vs float64 oracle {err:.3e} (float32 oracle vs float64: {floor:.3e})")
+        margin(f"test_residual_phase_step_matches_oracle[{mlp_products}-{S}]", "grad " + name, err, max(5e-3, 2.0 * floor))
         assert err <= max(5e-3, 2.0 * floor), f"{name}: {err:.3e} (float32 oracle {floor:.3e})"
 
     for k, (gg, gw, gx) in enumerate(zip(got["raw_gradients"], want["raw_gradients"], exact["raw_gradients"])):
@@ -445,12 +456,14 @@ def test_frame_prologue_matches_the_torch_path(dev, seed, V, N):
                                               loop.step_tensor.data_ptr(), b["scratch"].data_ptr(), b["scratch"].numel(), _lib.ptr(b["instances"]),
                                               b["pd_indices"].data_ptr(), b["gt_indices"].data_ptr(), b["target_columns"].data_ptr(), _lib.ptr(b["instance_weights"]),
                                               _lib.ptr(loop.schedule), _lib.ptr(b["projection_losses"]), _lib.ptr(b["grad_raw"]),
-                                              table.table.data_ptr(), table.count, config.num_rays, config.seed + 1, loop.positive_pixels.data_ptr(),
+                                              table.table.data_ptr(), table.count, config.num_rays, config.seed + 1, None,
                                               rays.data_ptr(), _lib.stream()))
     for name in names:
         assert torch.equal(b[name], alone[name]), name
     assert torch.equal(loop.schedule, alone["schedule"])
-    assert torch.equal(rays, table.sample(config.num_rays, seed=config.seed + 1, stream_offset=loop.step_tensor, remap=loop.positive_pixels))
+    assert loop.ray_remap is None and table.count == loop.sampling_weights.numel()      # round 5: the table covers every pixel of the frame (shape-only size: frame slots)
+    assert torch.equal(rays, table.sample(config.num_rays, seed=config.seed + 1, stream_offset=loop.step_tensor))
+    assert bool((loop.sampling_weights[rays] > 0).all()) and rays.unique().numel() == config.num_rays
     assert torch.equal(rays, loop.sample_rays())
 
 
@@ -567,6 +580,68 @@ def test_run_replays_several_steps_per_graph(dev):
         assert torch.equal(a, b)
     for name in record_one:
         assert torch.equal(record_one[name], record_many[name]), name
+
+
+def test_frame_slot_reuses_its_graphs_for_the_next_frame(dev):
+    """Persistent frame slots (scripts/main.py:106-199 sets a frame up, :134-136 skips done ones): a loop built with
+    persistent=True captures ALL its graphs once (capture_all: box-only and residual phase, one-step and four-step graphs) and is then
+    handed frame after frame by reset() -- copies and fills, no construction, no eager steps, NO capture.  Each frame's trajectory is
+    bit-identical to the one a fresh FrameOptimizer walks on the same inputs from the same initial parameters (the torch generator that
+    draws the embeddings and the hypernetwork is seeded alike before either), for two different frames in a row and for the frame the
+    graphs were captured on; the slot's graph set and the capture gate's clock do not move after start-up."""
+    from vsrd_amd import optimization
+    frames = [_c1_inputs(dev, all_visible=True, seed=k) for k in (0, 1, 2)]
+    config = optimization.OptimizationConfig(num_samples=32, num_rays=128, warmup_steps=9, num_steps=40, seed=3)
+    steps = 26
+
+    def state_of(loop):
+        return [p.detach().clone() for p in [loop.detector.locations, loop.detector.dimensions, loop.detector.orientations, loop.detector.embeddings,
+                                             *loop.hyper_distance_field.parameters()]]
+
+    def fresh(inputs, seed):
+        torch.manual_seed(seed)
+        loop = optimization.FrameOptimizer(inputs, config, dev, graph=True)
+        out = loop.run(steps)
+        torch.cuda.synchronize()
+        result = state_of(loop), {k: v.detach().clone() for k, v in out.items() if isinstance(v, torch.Tensor)}
+        loop.close()
+        return result
+
+    torch.manual_seed(100)
+    slot = optimization.FrameOptimizer(frames[0], config, dev, graph=True, persistent=True)
+    held = slot.capture_all()
+    keys = sorted(slot._graphs)
+    assert held == 4 and keys == [(False, False), (False, False, 4), (True, False), (True, False, 4)]
+    assert slot.step_index == 0 and int(slot.step_tensor) == 0
+    gate = optimization.exclusive_device_access()
+    captured_for = gate.capture_seconds
+    for number, (inputs, seed) in enumerate(zip((frames[1], frames[2], frames[0]), (11, 12, 13))):
+        torch.manual_seed(seed)
+        assert slot.reset(inputs)
+        out = slot.run(steps)
+        torch.cuda.synchronize()
+        assert slot.step_index == steps and int(slot.step_tensor) == steps
+        got, record = state_of(slot), {k: v.detach().clone() for k, v in out.items() if isinstance(v, torch.Tensor)}
+        want, want_record = fresh(inputs, seed)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b), number
+        for name in want_record:
+            assert torch.equal(record[name], want_record[name]), (number, name)
+        assert sorted(slot._graphs) == keys                                    # no graph was added ...
+    assert gate.capture_seconds > captured_for                                 # (the fresh loops of the comparison captured theirs)
+    captured_for = gate.capture_seconds
+    torch.manual_seed(5)
+    assert slot.reset(frames[1])
+    slot.run(steps)
+    torch.cuda.synchronize()
+    assert gate.capture_seconds == captured_for and sorted(slot._graphs) == keys     # ... and a frame in a slot captures nothing
+    # the optimiser restarted: Adam's counters equal the steps of THIS frame, the rates are this frame's decay
+    assert float(slot.optimizer.state[slot.detector.locations]["step"]) == steps
+    assert float(slot.optimizer.state[slot.detector.embeddings]["step"]) == steps - config.warmup_steps        # (stepped in the residual phase only)
+    assert abs(float(slot.optimizer.param_groups[0]["lr"]) - config.learning_rate * config.lr_gamma ** steps) < 1e-9
+    with pytest.raises(ValueError):
+        slot.reset(_c1_inputs(dev, all_visible=True, N=5))                     # another shape: another slot
+    slot.close()
 
 
 @pytest.mark.parametrize("how", ["state_dict_clone", "checkpoint_view", "module_to_assign"])

@@ -41,7 +41,8 @@ def test_struct_layout_matches_header():
     from vsrd_amd import _lib
     assert ctypes.sizeof(_lib.Field) == 24                      # int32, float, 2 pointers
     assert _lib.Field.instances.offset == 8 and _lib.Field.mlp_weights.offset == 16
-    assert ctypes.sizeof(_lib.RenderConfig) == 104              # + ray_indices, rays_per_origin, target_columns, target_stride (ABI 3)
+    assert ctypes.sizeof(_lib.RenderConfig) == 136              # + ray_indices, rays_per_origin, target_columns, target_stride (ABI 3), out_* (ABI 7)
+    assert _lib.RenderConfig.out_distances.offset == 104 and _lib.RenderConfig.out_u_fine.offset == 128
     assert _lib.RenderConfig.ray_indices.offset == 72 and _lib.RenderConfig.rays_per_origin.offset == 80
     assert _lib.RenderConfig.target_columns.offset == 88 and _lib.RenderConfig.target_stride.offset == 96
     assert ctypes.sizeof(_lib.FrameConfig) == 116 and _lib.FrameConfig.num_steps.offset == 68 and _lib.FrameConfig.lr_gamma.offset == 112

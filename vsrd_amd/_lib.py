@@ -30,6 +30,7 @@ FLAG_RESIDUAL_WAVE_PER_RAY = 128
 FLAG_STEP_WAVE_PER_RAY = 256
 FLAG_STEP_SPLIT_RAY = 512
 FLAG_YAW_GRADIENTS = 1024
+FLAG_MLP_SPLIT_BF16 = 2048
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 
@@ -62,6 +63,10 @@ class RenderConfig(ctypes.Structure):
         ("rays_per_origin", ctypes.c_int32),
         ("target_columns", ctypes.c_void_p),
         ("target_stride", ctypes.c_int32),
+        ("out_distances", ctypes.c_void_p),
+        ("out_coarse_weights", ctypes.c_void_p),
+        ("out_u_coarse", ctypes.c_void_p),
+        ("out_u_fine", ctypes.c_void_p),
     ]
 
 
@@ -254,9 +259,11 @@ def make_field(instances, temperature, mlp_weights=None):
 
 
 def make_config(num_rays, num_samples, distance_range, sdf_std_deviation, cosine_ratio, epsilon, origin_stride,
-                seed=0, stream_offset=0, flags=0, schedule=None, gather=None):
+                seed=0, stream_offset=0, flags=0, schedule=None, gather=None, samples=None):
     """`schedule`: optional device tensor float32 [3] = (temperature, sdf_std_deviation, cosine_ratio) read by the kernels at
-    start instead of the by-value scalars; `stream_offset` may likewise be a device int64 tensor (hipGraph replay)."""
+    start instead of the by-value scalars; `stream_offset` may likewise be a device int64 tensor (hipGraph replay).
+    `samples`: optional (distances [R,2S], coarse_weights [R,S-1], u_coarse [R,S], u_fine [R,S]) float32 device tensors (any may be None)
+    that vsrd_render_silhouette_step fills with its own state between the passes (vsrd_render_config::out_*)."""
     schedule_ptr = offset_ptr = None
     if schedule is not None:
         if schedule.dtype != torch.float32 or schedule.numel() != 3 or not schedule.is_cuda or not schedule.is_contiguous():
@@ -276,7 +283,10 @@ def make_config(num_rays, num_samples, distance_range, sdf_std_deviation, cosine
             ray_indices = indices.data_ptr()
         if columns is not None:
             target_columns = iptr(columns).value
+    outs = [None, None, None, None]
+    if samples is not None:
+        outs = [None if t is None else ptr(t).value for t in samples]
     return RenderConfig(int(num_rays), int(num_samples), float(distance_range[0]), float(distance_range[1]),
                         float(sdf_std_deviation), float(cosine_ratio), float(epsilon), int(origin_stride),
                         int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_offset) & 0xFFFFFFFFFFFFFFFF, int(flags), schedule_ptr, offset_ptr,
-                        ray_indices, int(rays_per_origin), target_columns, int(target_stride))
+                        ray_indices, int(rays_per_origin), target_columns, int(target_stride), *outs)

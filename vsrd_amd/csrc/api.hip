@@ -111,10 +111,13 @@ bool valid_field(const vsrd_field* f) {
            f->temperature > 0.0f;
 }
 
-bool valid_config(const vsrd_render_config* c, bool gather_allowed = false) {
+bool wants_samples(const vsrd_render_config* c) { return c->out_distances || c->out_coarse_weights || c->out_u_coarse || c->out_u_fine; }
+
+bool valid_config(const vsrd_render_config* c, bool gather_allowed = false, bool samples_allowed = false) {
     if (c == nullptr || c->num_rays < 0 || c->num_samples < 2 || c->num_samples > VSRD_MAX_SAMPLES || !(c->sdf_std_deviation > 0.0f) ||
         (c->origin_stride != 0 && c->origin_stride != 3))
         return false;
+    if (wants_samples(c) && !samples_allowed) return false;      // only vsrd_render_silhouette_step writes its samples out
     const bool gather = c->ray_indices != nullptr || c->target_columns != nullptr;
     if (gather && !gather_allowed) return false;                 // only the fused step kernels read through an index
     if (c->ray_indices != nullptr && c->rays_per_origin < 0) return false;
@@ -145,6 +148,7 @@ RenderArgs render_args(const vsrd_render_config* c) {
     a.sh.ratio = c->cosine_ratio;
     a.sh.eps = c->epsilon;
     a.sh.mlp_bits = 0u;  // set in-kernel from the flags
+    a.sh.mlp_stride = kMlpWeights;   // (the two front kernels of the residual step switch to the image table under VSRD_FLAG_MLP_SPLIT_BF16)
     a.origin_stride = c->origin_stride;
     a.seed = c->seed;
     a.stream_offset = c->stream_offset;
@@ -155,6 +159,8 @@ RenderArgs render_args(const vsrd_render_config* c) {
     a.rays_per_origin = c->rays_per_origin;
     a.target_columns = c->target_columns;
     a.target_stride = c->target_stride;
+    a.out_distances = c->out_distances; a.out_coarse_weights = c->out_coarse_weights;
+    a.out_u_coarse = c->out_u_coarse; a.out_u_fine = c->out_u_fine;
     return a;
 }
 
@@ -579,7 +585,7 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
                                     const float* targets, const float* instance_weights, float loss_scale,
                                     void* workspace, size_t workspace_bytes,
                                     float* loss, float* grad_instances, float* labels, void* stream) {
-    if (!valid_field(field) || !valid_config(config, true) || !workspace || !loss || !grad_instances) return VSRD_E_INVALID_ARGUMENT;
+    if (!valid_field(field) || !valid_config(config, true, true) || !workspace || !loss || !grad_instances) return VSRD_E_INVALID_ARGUMENT;
     if (field->mlp_weights != nullptr) return VSRD_E_UNSUPPORTED;            // box-only fast path
     const int N = field->num_instances;
     if (workspace_bytes < vsrd_workspace_bytes(N, 0)) return VSRD_E_WORKSPACE;
@@ -603,7 +609,8 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
     const bool pair = dense && !quad && S <= kPairMaxSamples && N <= kPairMaxInstances;
     // ... and for launches too small to put two waves on every SIMD one ray per wave (the reference's 1000 sampled rays per step: 1000
     // waves on 1024 SIMDs, pure latency), a ray split over the two waves of a workgroup (render_silhouette_split_kernel)
-    const bool split = !quad && !pair && !(config->flags & VSRD_FLAG_STEP_WAVE_PER_RAY) && (rounds == 2 || rounds == 4) &&
+    // (a step that writes its samples out -- vsrd_render_config::out_* -- keeps one ray per wave: the split form has no such outputs)
+    const bool split = !quad && !pair && !(config->flags & VSRD_FLAG_STEP_WAVE_PER_RAY) && !wants_samples(config) && (rounds == 2 || rounds == 4) &&
                        (force_split || config->num_rays <= split_max_rays()) &&
                        static_cast<size_t>(split_lds_floats(S, N)) * sizeof(float) <= kLdsLimit / 2;
     if (split) {
@@ -777,7 +784,7 @@ struct ResidualStepPlan {
     long long slots_per_instance;
     size_t front_lds;
     // workspace layout, in floats from the base
-    size_t box_partials, loss_partials, jets, box_extra, counter, segment_sums, seeds, item_rows, masks, item_flags, total_bytes;
+    size_t box_partials, loss_partials, jets, box_extra, counter, segment_sums, seeds, item_rows, masks, item_flags, images, total_bytes;
 };
 
 static bool plan_residual_step(int N, int S, int num_rays, bool allow_pair, ResidualStepPlan* p) {
@@ -788,7 +795,7 @@ static bool plan_residual_step(int N, int S, int num_rays, bool allow_pair, Resi
     p->pair = allow_pair && num_rays >= 1 && (p->rounds == 4 || (p->rounds == 2 && num_rays <= pair_max_rays()));
     p->front_lds = p->pair ? static_cast<size_t>(residual_pair_lds_floats(S, N)) * sizeof(float)
                            : static_cast<size_t>(residual_front_lds_floats(S, N)) * sizeof(float) * kMaxWavesPerBlock;
-    if (p->front_lds > (p->pair ? kLdsLimit / 2 : kLdsDefault)) return false;     // (one wave per ray at N = 64, S = 128: 81 KB -> the single-kernel form)
+    if (p->front_lds > kLdsLimit / 2) return false;     // two workgroups per CU = two waves per SIMD (one wave per ray at N = 64, S = 128: 93 KB -> the single-kernel form)
     const size_t per_ray = static_cast<size_t>(N) * p->rounds * kSeedFloats * kWave * sizeof(float);
     long long chunk = static_cast<long long>(kSeedBudgetBytes / per_ray);
     if (chunk < 256) chunk = 256;
@@ -821,6 +828,7 @@ static bool plan_residual_step(int N, int S, int num_rays, bool allow_pair, Resi
     p->masks = take((static_cast<size_t>(N) * p->slots_per_instance + 3) / 4);
     p->counter = take(4);                                // right behind the masks: one memset clears both
     p->item_flags = take((static_cast<size_t>(N) * p->items_per_instance + 3) / 4);
+    p->images = take(static_cast<size_t>(N) * kMlpImageWords);       // VSRD_FLAG_MLP_SPLIT_BF16: the instances' operand images (residual.h)
     p->total_bytes = at * sizeof(float);
     return true;
 }
@@ -974,15 +982,24 @@ int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_con
     const float eikonal_scale = eikonal_ratio * eikonal_norm;
     const unsigned mlp_bits = (config->flags & VSRD_FLAG_MLP_WEIGHTS_CENTRED) ? kMlpCentredBit : 0u;
     const size_t adjoint_lds = (static_cast<size_t>(kMlpWbarFloats) + static_cast<size_t>(kMlpStashTiles) * kTileFloats) * sizeof(float);
+    // VSRD_FLAG_MLP_SPLIT_BF16: the front kernels read the instances' split-bf16 operand images instead of their weights
+    const float* front_weights = field->mlp_weights;
+    if (config->flags & VSRD_FLAG_MLP_SPLIT_BF16) {
+        unsigned* images = reinterpret_cast<unsigned*>(base + p.images);
+        hipLaunchKernelGGL(pack_mlp_images_kernel, dim3(N), dim3(256), 0, s, field->mlp_weights, (config->flags & VSRD_FLAG_MLP_WEIGHTS_CENTRED) ? 1 : 0, images);
+        front_weights = reinterpret_cast<const float*>(images);
+    }
     int chunk_index = 0;
     for (int first = 0; first < config->num_rays; first += p.chunk, ++chunk_index) {
         const int rays = std::min(p.chunk, config->num_rays - first);
         const long long used_slots = static_cast<long long>(rays) * p.rounds;
         if (hipMemsetAsync(masks, 0, (p.counter - p.masks + 4) * sizeof(float), s) != hipSuccess) return VSRD_E_LAUNCH;   // tile masks + the item counter's 16-byte slot (a multiple of 16 bytes: one fill kernel, not two)
 #define VSRD_FRONT_ARGS                                                                                                                  \
-        f, field->instances, field->mlp_weights, c, origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, eikonal_scale, \
+        f, field->instances, front_weights, c, origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, eikonal_scale, \
         eikonal_norm, labels, box_partials, jets, loss_partials, seeds, masks, p.slots_per_instance, first, rays, chunk_index > 0 ? 1 : 0
-#define VSRD_LAUNCH(K) hipLaunchKernelGGL(residual_step_front_kernel<K>, dim3(p.front_blocks), dim3(kBlockThreads), p.front_lds, s, VSRD_FRONT_ARGS)
+#define VSRD_LAUNCH(K)                                                                                                                   \
+        if (opt_in_lds(residual_step_front_kernel<K>, p.front_lds) != VSRD_OK) return VSRD_E_LAUNCH;                                     \
+        hipLaunchKernelGGL(residual_step_front_kernel<K>, dim3(p.front_blocks), dim3(kBlockThreads), p.front_lds, s, VSRD_FRONT_ARGS)
 #define VSRD_LAUNCH_PAIR(K)                                                                                                              \
         if (opt_in_lds(residual_step_pair_kernel<K>, p.front_lds) != VSRD_OK) return VSRD_E_LAUNCH;                                      \
         hipLaunchKernelGGL(residual_step_pair_kernel<K>, dim3(p.front_blocks), dim3(kPairWaves * kWave), p.front_lds, s, VSRD_FRONT_ARGS)
@@ -1083,7 +1100,9 @@ int32_t vsrd_frame_prologue_sample(const vsrd_frame_config* config, const float*
     b.instances = instances;
     b.pd_indices = reinterpret_cast<long long*>(pd_indices); b.gt_indices = reinterpret_cast<long long*>(gt_indices);
     b.target_map = target_columns; b.instance_weights = instance_weights; b.schedule = schedule; b.losses = projection_losses; b.grad_raw = grad_raw;
-    if (opt_in_lds(frame_prologue_sample_kernel, kTableLdsBytes) != VSRD_OK) return VSRD_E_LAUNCH;
+    // (a refused LDS opt-in is "this device / build cannot run the combined launch" -- VSRD_E_UNSUPPORTED, on which the caller falls back to
+    //  vsrd_frame_prologue + vsrd_sample_rays_table -- and not a failed launch, which must not be mistaken for it)
+    if (opt_in_lds(frame_prologue_sample_kernel, kTableLdsBytes) != VSRD_OK) return VSRD_E_UNSUPPORTED;
     hipLaunchKernelGGL(frame_prologue_sample_kernel, dim3(2), dim3(kTableThreads), kTableLdsBytes, static_cast<hipStream_t>(stream), a, b,
                        static_cast<RayTableHeader*>(ray_table), static_cast<long long>(count), num_rays, seed, reinterpret_cast<const unsigned long long*>(step),
                        reinterpret_cast<const long long*>(remap), reinterpret_cast<long long*>(ray_indices));

@@ -897,12 +897,17 @@ __device__ __forceinline__ bool quad_step_body(const float* __restrict__ instanc
         r.ox = o[0]; r.oy = o[1]; r.oz = o[2]; r.rx = d[0]; r.ry = d[1]; r.rz = d[2];
         quad_ray_setup<kL>(instances, N, NP, r, coef_own, rays + rl.row * kRowRayFloats, rl);
     }
-    quad_stage_samples<kL, kRoundsS>(rowbase, c, S, ray, u_coarse, u_fine, sorted_input, rl);
+    quad_stage_samples<kL, kRoundsS>(rowbase, c, S, ray, u_coarse, u_fine, sorted_input, rl, c.out_u_coarse, c.out_u_fine, alive);
     VSRD_PHASE(0);
     // ---- pass 1 ----------------------------------------------------------------------------------------------------------------
     float w1[kRoundsS];
     if (!quad_pass_one<kL, kRoundsS, kYaw, kRunning>(instances, NP, sh, rays + rl.row * kRowRayFloats, coef_own, rowbase, S, w1, rl, real)) return false;
     VSRD_PHASE(1);
+    if (c.out_coarse_weights != nullptr && alive) {          // (vsrd_render_config::out_*: the step's own state between its passes; wave-uniform pointers)
+#pragma unroll
+        for (int k = 0; k < kRoundsS; ++k)
+            if (k * kL + rl.col < S - 1) c.out_coarse_weights[static_cast<size_t>(my_ray) * (S - 1) + k * kL + rl.col] = w1[k];
+    }
     float coarse_total = 0.0f;
 #pragma unroll
     for (int k = 0; k < kRoundsS; ++k) coarse_total += seg_sum<kL>(w1[k]);
@@ -922,11 +927,17 @@ __device__ __forceinline__ bool quad_step_body(const float* __restrict__ instanc
     float* trans_mid = rowbase;                                              // (the row's own: a shadow row's transmittances are all 1)
     if (live_lanes != 0ull) {
         quad_importance_merge<kL, kRoundsS>(rowbase, S, w1, rl);
+        if (c.out_distances != nullptr && live) {            // the sorted pass-2 distances of the row's own ray (the reverse sweep overwrites them later)
+            float* dst = c.out_distances + static_cast<size_t>(my_ray) * (2 * S);
+            const float* own = rowbase + quad_merged_offset(S, kL);
+            for (int idx = rl.col; idx < 2 * S; idx += kL) dst[idx] = own[idx];
+        }
         VSRD_PHASE(2);
         if (!quad_forward_sweep<kL, kRounds, kYaw, kRunning>(st, instances, NP, sh, rayp, coefs + data_row * quad_coef_floats(NP), merged, num_points, live, dcache,
                                                          trans_mid, label, active, cached_round, rl, real)) return false;
         VSRD_PHASE(3);
     }
+    if (c.out_distances != nullptr && alive && !live && rl.col == 0) c.out_distances[static_cast<size_t>(my_ray) * (2 * S)] = __builtin_nanf("");   // exact miss: sentinel row
     // ---- loss and label adjoints -------------------------------------------------------------------------------------------------
     unsigned long long lam_any = 0ull;                                       // bit n: some ray has a label adjoint for instance n
     float lam_lane[kSlots];

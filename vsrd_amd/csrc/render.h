@@ -26,8 +26,10 @@ struct Shading {
     float inv_std;  // 1 / sdf_std_deviation
     float ratio;    // cosine_ratio
     float eps;      // epsilon (opacity denominator)
-    unsigned mlp_bits;   // kMlpCentredBit when VSRD_FLAG_MLP_WEIGHTS_CENTRED is set (OR-ed into the residual's tile mask), else 0
-    float* mlp_lds;      // residual fields: kMlpWbarFloats floats of the wave's LDS for residual_forward's staged weights
+    unsigned mlp_bits;   // kMlpCentredBit when VSRD_FLAG_MLP_WEIGHTS_CENTRED is set (OR-ed into the residual's tile mask), kMlpSplitBit when the
+                         // launch's `mlp` pointer is the table of split-bf16 operand images (VSRD_FLAG_MLP_SPLIT_BF16), else 0
+    int mlp_stride;      // floats between two instances' rows of `mlp`: kMlpWeights, or kMlpImageWords for the image table
+    float* mlp_lds;      // residual fields: kMlpWbarFloats (kMlpStageFloats in the kernels that take images) floats of the wave's LDS for residual_forward's staged weights
 };
 
 // torch.lerp(a, b, w): two-sided formula of ATen's lerp kernel.
@@ -96,7 +98,7 @@ __device__ __forceinline__ UnionSums union_loop(const float* __restrict__ instan
         if (near == 0ull) { evaluated &= ~(1ull << i); continue; }
         best = fminf(best, e.d);
         box_gradient<kYaw>(e, in);
-        if (kResidual) add_residual<kYaw>(e, in, residual_forward_packed(mlp + i * kMlpWeights, e.px, e.py, e.pz, near & live, sh.mlp_bits, sh.mlp_lds));
+        if (kResidual) add_residual<kYaw>(e, in, residual_forward_packed(mlp + i * sh.mlp_stride, e.px, e.py, e.pz, near & live, sh.mlp_bits, sh.mlp_lds));
         if (kCacheDistances) dcache[i * kWave + lane] = e.d;
         union_accumulate<kRunning>(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, sh.inv_t);
     }

@@ -54,6 +54,11 @@ struct RenderArgs {
     int rays_per_origin;
     const int* target_columns;
     int target_stride;
+    // vsrd_render_config::out_* (the fused box-only step only): the step's own pass-1 weights, uniforms and sorted pass-2 distances
+    float* out_distances;
+    float* out_coarse_weights;
+    float* out_u_coarse;
+    float* out_u_fine;
 };
 
 // Row of the frame-resident tensors that step ray `ray` reads (vsrd_render_config::ray_indices), as a wave-uniform value.
@@ -330,7 +335,7 @@ __device__ __forceinline__ UnionSums sweep_union_loop(RayAdjoint<kRounds>& st, i
         best = fminf(best, e.d);
         box_gradient<kYaw>(e, in);
         if (kResidual) {
-            const Residual res = residual_forward_packed(mlp + i * kMlpWeights, e.px, e.py, e.pz, near & live, sh.mlp_bits, sh.mlp_lds);
+            const Residual res = residual_forward_packed(mlp + i * sh.mlp_stride, e.px, e.py, e.pz, near & live, sh.mlp_bits, sh.mlp_lds);
             add_residual<kYaw>(e, in, res);
             if (rcache) rcache[(k * N + i) * kWave + lane] = make_float4(res.value, res.gx, res.gy, res.gz);
         }
@@ -787,21 +792,32 @@ __global__ __launch_bounds__(kBlockThreads, (kRounds <= 2) ? 4 : 2) void render_
         const Ray r = load_ray_gathered(c, origins, directions, row);
         const float target = load_target(c, targets, row, lane, N);
         const RayCull rc = cull_ray_setup(instances, N, r.ox, r.oy, r.oz, r.rx, r.ry, r.rz, l.cull, lane);
-        stage_ray_samples<kRoundsS>(l, c, S, ray, u_coarse, u_fine, nullptr, nullptr, sorted_input, lane);
+        stage_ray_samples<kRoundsS>(l, c, S, ray, u_coarse, u_fine, c.out_u_coarse, c.out_u_fine, sorted_input, lane);
         VSRD_PHASE(0);
         // ---- pass 1 ------------------------------------------------------------------------------------
         float w1[kRoundsS];
         render_pass<kRoundsS, false, false>(instances, nullptr, N, sh, r, rc, l.coarse, S, l.dcache, w1, nullptr, nullptr);
         VSRD_PHASE(1);
+        if (c.out_coarse_weights != nullptr) {
+#pragma unroll
+            for (int k = 0; k < kRoundsS; ++k)
+                if (k * kWave + lane < S - 1) c.out_coarse_weights[static_cast<size_t>(ray) * (S - 1) + k * kWave + lane] = w1[k];
+        }
         float coarse_total = 0.0f;
 #pragma unroll
         for (int k = 0; k < kRoundsS; ++k) coarse_total += wave_sum(w1[k]);
         float label = 0.0f;
         bool rendered = false;
         RayAdjoint<kRounds> st;
-        if (!((c.flags & 2u) && coarse_total == 0.0f)) {                    // exact miss: labels are exactly 0, adjoint exactly 0
+        if ((c.flags & 2u) && coarse_total == 0.0f) {
+            if (c.out_distances != nullptr && lane == 0) c.out_distances[static_cast<size_t>(ray) * D] = __builtin_nanf("");      // sentinel row
+        } else {                                                            // (exact miss: labels are exactly 0, adjoint exactly 0)
             rendered = true;
             importance_merge<kRoundsS>(l, S, w1);
+            if (c.out_distances != nullptr) {
+                float* dst = c.out_distances + static_cast<size_t>(ray) * D;
+                for (int idx = lane; idx < D; idx += kWave) dst[idx] = l.merged[idx];
+            }
             VSRD_PHASE(2);
             // ---- pass 2 with the adjoint's state kept in registers ------------------------------------
             label = adjoint_forward_sweep<kRounds, false, true>(st, instances, nullptr, N, sh, r, rc, l.merged, num_points, nullptr, l.dcache, lane);
@@ -964,9 +980,13 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(V
 // ---------------------------------------------------------------------------------------------------
 constexpr int kItemRowFloats = kMlpWbarFloats + kGradStride;         // 1632 + 16
 
+// (the staging area in front of a wave's partition holds the instance's fp32 weights or its split-bf16 operand image: kMlpStageFloats)
 __host__ __device__ constexpr int residual_front_lds_floats(int num_samples, int num_instances) {
-    return (kMlpWbarFloats + wave_lds_floats(num_samples, num_instances) + num_instances + num_instances * kGradStride + 3) & ~3;
+    return (kMlpStageFloats + wave_lds_floats(num_samples, num_instances) + num_instances + num_instances * kGradStride + 3) & ~3;
 }
+// residual_forward's mode bits of a launch (VSRD_FLAG_MLP_WEIGHTS_CENTRED, VSRD_FLAG_MLP_SPLIT_BF16: then `mlp` IS the image table)
+__device__ __forceinline__ unsigned residual_mode_bits(unsigned flags) { return ((flags & 8u) ? kMlpCentredBit : 0u) | ((flags & 2048u) ? kMlpSplitBit : 0u); }
+__device__ __forceinline__ int residual_weight_stride(unsigned flags) { return (flags & 2048u) ? kMlpImageWords : kMlpWeights; }
 
 // (four rounds -- S in (64, 128], the reference's own S = 100 -- hold twice the per-ray adjoint state and do not fit 256 registers)
 template <int kRounds>
@@ -983,7 +1003,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(k
     const int lane = lane_id();
     const int S = c.num_samples;
     const int N = f.num_instances;
-    float* base = lds + wave * residual_front_lds_floats(S, N) + kMlpWbarFloats;
+    float* base = lds + wave * residual_front_lds_floats(S, N) + kMlpStageFloats;
     WaveLds l = carve_lds(base, S, N);                                     // l.dcache: [N][64], one round at a time
     float* lam = base + wave_lds_floats(S, N);
     float* G = lam + N;
@@ -993,10 +1013,11 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(k
     float4* rcache = residual_cache + wave_global * (static_cast<size_t>(kRounds) * N * kWave);
     const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
     Shading sh = c.sh;
-    sh.mlp_lds = base - kMlpWbarFloats;
+    sh.mlp_lds = base - kMlpStageFloats;
     const FieldBounds bounds = field_bounds(instances, N, f.inv_t, true, c.flags);
     sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
-    sh.mlp_bits = (c.flags & 8u) ? kMlpCentredBit : 0u;
+    sh.mlp_bits = residual_mode_bits(c.flags);
+    sh.mlp_stride = residual_weight_stride(c.flags);
     const float weight_lane = (lane < N) ? (instance_weights ? instance_weights[lane] : 1.0f) : 0.0f;
     float loss_acc = 0.0f, eikonal_acc = 0.0f;
     const int D = 2 * S, num_points = D - 1;
@@ -1122,7 +1143,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(k
 constexpr int kPairWaves = 2;
 
 __host__ __device__ constexpr int residual_pair_wave_floats(int num_instances) {
-    return (kMlpWbarFloats + num_instances * kWave + cull_coef_floats(num_instances) + num_instances + num_instances * kGradStride + 3) & ~3;
+    return (kMlpStageFloats + num_instances * kWave + cull_coef_floats(num_instances) + num_instances + num_instances * kGradStride + 3) & ~3;
 }
 __host__ __device__ constexpr int residual_pair_lds_floats(int num_samples, int num_instances) {
     return ((7 * num_samples + 3) & ~3) + 16 + kPairWaves * kWave + kPairWaves * residual_pair_wave_floats(num_instances);
@@ -1150,7 +1171,7 @@ __global__ __launch_bounds__(kPairWaves * kWave) __attribute__((amdgpu_waves_per
     float* xchg = lds + ((7 * S + 3) & ~3);                                   // [0..1] pass-1 products, [2..3] pass-2 products, [4..5] suffix sums
     float* label_half = xchg + 16;                                            // [2][64]
     float* mine = label_half + kPairWaves * kWave + wave * residual_pair_wave_floats(N);
-    l.dcache = mine + kMlpWbarFloats;
+    l.dcache = mine + kMlpStageFloats;
     l.cull = l.dcache + N * kWave;
     float* lam = l.cull + cull_coef_floats(N);
     float* G = lam + N;
@@ -1163,7 +1184,8 @@ __global__ __launch_bounds__(kPairWaves * kWave) __attribute__((amdgpu_waves_per
     sh.mlp_lds = mine;
     const FieldBounds bounds = field_bounds(instances, N, f.inv_t, true, c.flags);
     sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
-    sh.mlp_bits = (c.flags & 8u) ? kMlpCentredBit : 0u;
+    sh.mlp_bits = residual_mode_bits(c.flags);
+    sh.mlp_stride = residual_weight_stride(c.flags);
     const float weight_lane = (lane < N) ? (instance_weights ? instance_weights[lane] : 1.0f) : 0.0f;
     float loss_acc = 0.0f, eikonal_acc = 0.0f;
     const int D = 2 * S, num_points = D - 1;
@@ -1480,6 +1502,16 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         if (lane < kGradStride) row[kMlpWbarFloats + lane] = mine;
         if (lane == 0) item_flags[item] = 1;
     }
+}
+
+// VSRD_FLAG_MLP_SPLIT_BF16: the operand images of a launch's instances (residual.h: pack_mlp_image), one workgroup per instance, once per
+// vsrd_render_residual_step call (N x 9.4 KB: the front kernels stage an instance's image where they staged its 6.5 KB of weights).
+__global__ __launch_bounds__(256) void pack_mlp_images_kernel(const float* __restrict__ weights, int centred, unsigned* __restrict__ images) {
+    __shared__ __attribute__((aligned(16))) float staged[kMlpWbarFloats];
+    const int n = blockIdx.x;
+    stage_centred_weights((LdsFloats)staged, weights + static_cast<size_t>(n) * kMlpWeights, centred != 0, static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x));
+    __syncthreads();
+    pack_mlp_image((LdsFloats)staged, images + static_cast<size_t>(n) * kMlpImageWords, static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x));
 }
 
 // grad_mlp [N,1617] (+)= sum over the item rows of instance i (fixed order); box_extra [N,16] likewise (the MLP's dL/dp chained into t, R).

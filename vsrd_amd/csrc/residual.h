@@ -38,6 +38,7 @@ constexpr float kLayerNormEps = 1.0e-5f;
 constexpr float kPi = 3.14159265358979323846f;
 constexpr unsigned kMlpCentredBit = 0x10u;                   // in the tile-mask argument: the weights arrive centred (VSRD_FLAG_MLP_WEIGHTS_CENTRED)
 constexpr int kMlpStartShift = 8;                            // ... and bits 8..13: the lane the tiles are counted from (residual_forward)
+constexpr unsigned kMlpSplitBit = 0x20u;                     // ... and: the weight pointer is the instance's split-bf16 operand IMAGE (VSRD_FLAG_MLP_SPLIT_BF16, below)
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
@@ -478,14 +479,210 @@ __device__ __forceinline__ void load_register_weights(RegisterWeights& w, const 
 // `weights_lds`: kMlpWbarFloats floats of this wave's LDS.  The instance's weights are staged there (26 coalesced loads per lane
 // instead of 69 gathers of 64 scattered addresses each) and read operand by operand: held in registers they would cost the CALLERS
 // their second wave per SIMD (a callee's registers, and the AGPRs it parks callee-saved ones in, count towards its callers).
+// One 16-point tile of residual_forward on the exact-fp32 matrix instruction: value `v` and the three tangents `t` of the MLP output
+// w.r.t. the folded, scaled coordinates (every lane of the tile's column receives them).
+__device__ __forceinline__ void forward_tile_f32(const LdsWeights& wt, const TileFeatures& e, float& v, float (&t)[3]) {
+    // ---- forward column ---------------------------------------------------------------------------------------------------
+    f32x4 z = wt.b0();
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) z = mfma4(wt.a0(c, k), e.f[c][k], z);
+    f32x4 y[4], g1[4];
+    float inv_s[4];
+    v = 0.0f;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {                            // z has zero channel mean (load_forward_weights)
+        const float var = rows_sum(dot4(z, z)) * (1.0f / kMlpHidden);
+        inv_s[l] = __builtin_amdgcn_rsqf(var + kLayerNormEps);
+        y[l] = z * splat4(inv_s[l]);
+        f32x4 a;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const Gauss n = gauss(y[l][j]);
+            a[j] = y[l][j] * n.cdf;
+            g1[l][j] = n.cdf + y[l][j] * n.pdf;
+        }
+        if (l < 3) {
+            z = wt.b(l);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) z = mfma4(wt.a(l, k), a[k], z);
+        } else {
+            v = rows_sum(dot4(wt.w4(), a)) + wt.b4();
+        }
+    }
+    // ---- reverse column ---------------------------------------------------------------------------------------------------
+    f32x4 a_bar = wt.w4(), z_bar;
+#pragma unroll
+    for (int l = 3; l >= 0; --l) {
+        const f32x4 u = a_bar * g1[l];
+        const float m = rows_sum(hsum4(u)) * (1.0f / kMlpHidden);
+        const float my = rows_sum(dot4(u, y[l])) * (1.0f / kMlpHidden);
+        z_bar = (u - splat4(m) - y[l] * splat4(my)) * splat4(inv_s[l]);
+        if (l > 0) {
+            a_bar = splat4(0.0f);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a_bar = mfma4(wt.at(l - 1, k), z_bar[k], a_bar);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        f32x4 feat_bar = splat4(0.0f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) feat_bar = mfma4(wt.at0(c, k), z_bar[k], feat_bar);
+        t[c] = rows_sum(dot4(feat_bar, e.d[c]));
+    }
+}
+
+// ---- the same MLP on v_mfma_f32_16x16x32_bf16 with BOTH operands split into two bfloat16 parts (round 5; VSRD_FLAG_MLP_SPLIT_BF16) --------
+// x = hi + lo, hi = bf16(x), lo = bf16(x - hi), both rounded to nearest even: |x - hi - lo| <= 2^-18 |x|.  The 16 x 16 layers have K = 16
+// channels and the instruction contracts K = 32 per lane group of four channels: a lane's eight slots hold [part A of its four channels |
+// part B of its four channels].  With the weight (A) operand [w_hi(4) | w_lo(4)] -- four words straight from the instance's operand
+// image -- and the activation (B) operand [a_hi(4) | a_hi(4)], then [a_lo(4) | a_lo(4)], two instructions give all four products
+// (w_hi + w_lo)(a_hi + a_lo) in fp32 accumulation: 2 x 16.6 cycles where the exact-fp32 form takes 4 x 32.5 (tools/micro/
+// mfma_valu_interleave.hip; in a stream of vector instructions the fp32 form costs another ~10 cycles per switch), plus 16 vector
+// instructions for the split of a four-channel operand.  The C / D layout is that of the fp32 instruction, so layers still chain with no
+// data movement, and everything between the products (LayerNorm, GELU, the row sums) is the fp32 code above.
+// What it costs in accuracy, measured, not estimated: tests/split_bf16_emulation.py (CPU, the oracle with both operands of every linear
+// replaced by their two-part sums): labels move by <= 2.1e-6, gradients by <= 7.8e-4 of the largest entry on the residual goldens.
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using LdsWords = __attribute__((address_space(3))) unsigned*;
+
+constexpr int kImgOperandWords = 4 * kWave;                  // one A operand: lane l reads words [4 l, 4 l + 4) = {hi(k0, k1), hi(k2, k3), lo(k0, k1), lo(k2, k3)}
+constexpr int kImgFirst = 0;                                 // operands 0..2: W0[o][16 c + 4 g + s]   (first layer, coordinate block c)
+constexpr int kImgHidden = 3;                                // operands 3..5: W_l[o][4 g + s]
+constexpr int kImgHiddenT = 6;                               // operands 6..8: W_l[4 g + s][i]        (transposed: the reverse column)
+constexpr int kImgOperands = 9;
+constexpr int kImgTail = kImgOperands * kImgOperandWords;    // then fp32: b0[16] | b_l[16] x 3 | w4[16] | b4 | pad
+constexpr int kImgTailFloats = 96;
+constexpr int kMlpImageWords = kImgTail + kImgTailFloats;    // 2400 words (9.4 KB) per instance; lane-linear, so every operand read is conflict-free
+constexpr int kMlpStageFloats = kMlpImageWords > kMlpWbarFloats ? kMlpImageWords : kMlpWbarFloats;   // a wave's staging area in kernels that take either form
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// {hi(x0, x1), hi(x2, x3), lo(x0, x1), lo(x2, x3)}
+__device__ __forceinline__ u32x4 split4(float x0, float x1, float x2, float x3) {
+    const unsigned h01 = cvt_pk_bf16(x0, x1), h23 = cvt_pk_bf16(x2, x3);
+    const float r0 = x0 - __uint_as_float(h01 << 16), r1 = x1 - __uint_as_float(h01 & 0xffff0000u);
+    const float r2 = x2 - __uint_as_float(h23 << 16), r3 = x3 - __uint_as_float(h23 & 0xffff0000u);
+    return u32x4{h01, h23, cvt_pk_bf16(r0, r1), cvt_pk_bf16(r2, r3)};
+}
+__device__ __forceinline__ u32x4 split4(f32x4 x) { return split4(x[0], x[1], x[2], x[3]); }
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// c += W x, W = the image operand `a` ([w_hi | w_lo]), x = the split `s` of the lane's four channels
+__device__ __forceinline__ f32x4 mfma_split(u32x4 a, u32x4 s, f32x4 c) {
+    c = mfma_bf16(a, u32x4{s[0], s[1], s[0], s[1]}, c);
+    return mfma_bf16(a, u32x4{s[2], s[3], s[2], s[3]}, c);
+}
+
+// One instance's operand image from its (centred) weights: what pack_mlp_images_kernel (render_kernels.h) runs per instance.
+// `w`: the 1617 weights in LDS, centred (stage_centred_weights); thread `thread` of `threads`.
+__device__ __forceinline__ void pack_mlp_image(const LdsFloats w, unsigned* __restrict__ image, int thread, int threads) {
+    for (int idx = thread; idx < kImgOperands * kWave; idx += threads) {
+        const int p = idx / kWave, lane = idx % kWave, g = lane >> 4, o = lane & 15;
+        float x[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (p < kImgHidden) x[s] = w[o * kMlpRow0 + 16 * (p - kImgFirst) + 4 * g + s];
+            else if (p < kImgHiddenT) x[s] = w[kMlpLayer1 + (p - kImgHidden) * kMlpBlock + o * kMlpRow + 4 * g + s];
+            else x[s] = w[kMlpLayer1 + (p - kImgHiddenT) * kMlpBlock + (4 * g + s) * kMlpRow + o];
+        }
+        const u32x4 words = split4(x[0], x[1], x[2], x[3]);
+        *reinterpret_cast<u32x4*>(image + p * kImgOperandWords + 4 * lane) = words;
+    }
+    float* tail = reinterpret_cast<float*>(image + kImgTail);
+    for (int idx = thread; idx < kImgTailFloats; idx += threads) {
+        float value = 0.0f;
+        if (idx < 16) value = w[idx * kMlpRow0 + kMlpFeatures];
+        else if (idx < 64) value = w[kMlpLayer1 + ((idx - 16) >> 4) * kMlpBlock + ((idx - 16) & 15) * kMlpRow + kMlpHidden];
+        else if (idx < 80) value = w[kMlpHead + (idx - 64)];
+        else if (idx == 80) value = w[kMlpHead + kMlpHidden];
+        tail[idx] = value;
+    }
+}
+
+struct SplitWeights {
+    LdsWords image;    // the staged operand image of the instance
+    int lane, g;
+    __device__ __forceinline__ u32x4 operand(int p) const {
+        return *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(image + p * kImgOperandWords + 4 * lane);
+    }
+    __device__ __forceinline__ f32x4 tail4(int at) const {
+        return *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(image + kImgTail + at + 4 * g);      // channels 4 g .. 4 g + 3
+    }
+    __device__ __forceinline__ f32x4 b0() const { return tail4(0); }
+    __device__ __forceinline__ f32x4 b(int l) const { return tail4(16 + 16 * l); }
+    __device__ __forceinline__ f32x4 w4() const { return tail4(64); }
+    __device__ __forceinline__ float b4() const { return __uint_as_float(image[kImgTail + 80]); }
+};
+
+__device__ __forceinline__ void stage_image_wave(LdsWords dst, const float* image, int lane) {
+    const unsigned long long bits = reinterpret_cast<unsigned long long>(image);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(bits)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(bits >> 32));
+    const __attribute__((address_space(1))) u32x4* src = reinterpret_cast<const __attribute__((address_space(1))) u32x4*>((static_cast<unsigned long long>(hi) << 32) | lo);
+    for (int idx = lane; idx < kMlpImageWords / 4; idx += kWave)
+        *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(dst + 4 * idx) = src[idx];
+}
+
+// forward_tile_f32 on the split-bf16 products.  The first layer's tangent goes FORWARDS here (X_c = W0_c dfeat_c next to z = W0 feat:
+// the same weight operand, read once), so t_c = sum over channels of z_bar0 . X_c needs no transposed first-layer operand -- 3 KB of LDS
+// the MLP-adjoint kernel does not have -- for the same number of matrix instructions.
+__device__ __forceinline__ void forward_tile_split(const SplitWeights& wt, const TileFeatures& e, float& v, float (&t)[3]) {
+    f32x4 z = wt.b0();
+    f32x4 x[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const u32x4 a = wt.operand(kImgFirst + c);
+        z = mfma_split(a, split4(e.f[c]), z);
+        x[c] = mfma_split(a, split4(e.d[c]), splat4(0.0f));
+    }
+    f32x4 y[4], g1[4];
+    float inv_s[4];
+    v = 0.0f;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        const float var = rows_sum(dot4(z, z)) * (1.0f / kMlpHidden);
+        inv_s[l] = __builtin_amdgcn_rsqf(var + kLayerNormEps);
+        y[l] = z * splat4(inv_s[l]);
+        f32x4 a;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const Gauss n = gauss(y[l][j]);
+            a[j] = y[l][j] * n.cdf;
+            g1[l][j] = n.cdf + y[l][j] * n.pdf;
+        }
+        if (l < 3) z = mfma_split(wt.operand(kImgHidden + l), split4(a), wt.b(l));
+        else v = rows_sum(dot4(wt.w4(), a)) + wt.b4();
+    }
+    f32x4 a_bar = wt.w4(), z_bar;
+#pragma unroll
+    for (int l = 3; l >= 0; --l) {
+        const f32x4 u = a_bar * g1[l];
+        const float m = rows_sum(hsum4(u)) * (1.0f / kMlpHidden);
+        const float my = rows_sum(dot4(u, y[l])) * (1.0f / kMlpHidden);
+        z_bar = (u - splat4(m) - y[l] * splat4(my)) * splat4(inv_s[l]);
+        if (l > 0) a_bar = mfma_split(wt.operand(kImgHiddenT + l - 1), split4(z_bar), splat4(0.0f));
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) t[c] = rows_sum(dot4(z_bar, x[c]));
+}
+
 VSRD_RESIDUAL_FN Residual residual_forward(const float* w_in, float px, float py, float pz, unsigned tiles_in, float* weights_lds) {
     const int lane = lane_id();
     const int g = lane >> 4;
     const unsigned tiles = __builtin_amdgcn_readfirstlane(tiles_in);
     const int start = static_cast<int>((tiles >> kMlpStartShift) & 63u);      // tile q = lanes start + 16 q ... start + 16 q + 15 (mod 64): tile_plan, below
+    const bool split = (tiles & kMlpSplitBit) != 0u;                           // (wave-uniform) w_in is the instance's operand image
     const LdsFloats staged = (LdsFloats)weights_lds;
     wave_lds_order();                                            // (the previous call's operand reads are done)
-    stage_centred_weights_wave(staged, uniform_weights_generic(w_in), (tiles & kMlpCentredBit) != 0u, lane);
+    if (split) stage_image_wave((LdsWords)weights_lds, w_in, lane);
+    else stage_centred_weights_wave(staged, uniform_weights_generic(w_in), (tiles & kMlpCentredBit) != 0u, lane);
     wave_lds_order();
 #ifdef VSRD_PROBE_STAGE_TWICE          // probe: what one staging costs (the difference to the normal build)
     asm volatile("" ::: "memory");
@@ -493,6 +690,7 @@ VSRD_RESIDUAL_FN Residual residual_forward(const float* w_in, float px, float py
     wave_lds_order();
 #endif
     const LdsWeights wt = {staged, g, lane & 15};
+    const SplitWeights swt = {(LdsWords)weights_lds, lane, g};
     const float fold = (px > 0.0f) ? 1.0f : ((px < 0.0f) ? -1.0f : 0.0f);
     const float inv = 1.0f / kPositionScale;
     const float f0 = fabsf(px) * inv, f1 = py * inv, f2 = pz * inv;
@@ -502,57 +700,9 @@ VSRD_RESIDUAL_FN Residual residual_forward(const float* w_in, float px, float py
         if (!((tiles >> q) & 1u)) continue;
         TileFeatures e;
         encode_tile(from_row(f0, q, lane, start), from_row(f1, q, lane, start), from_row(f2, q, lane, start), g, e);
-        // ---- forward column ---------------------------------------------------------------------------------------------------
-        f32x4 z = wt.b0();
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) z = mfma4(wt.a0(c, k), e.f[c][k], z);
-        f32x4 y[4], g1[4];
-        float inv_s[4];
-        float v = 0.0f;
-#pragma unroll
-        for (int l = 0; l < 4; ++l) {                            // z has zero channel mean (load_forward_weights)
-            const float var = rows_sum(dot4(z, z)) * (1.0f / kMlpHidden);
-            inv_s[l] = __builtin_amdgcn_rsqf(var + kLayerNormEps);
-            y[l] = z * splat4(inv_s[l]);
-            f32x4 a;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const Gauss n = gauss(y[l][j]);
-                a[j] = y[l][j] * n.cdf;
-                g1[l][j] = n.cdf + y[l][j] * n.pdf;
-            }
-            if (l < 3) {
-                z = wt.b(l);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) z = mfma4(wt.a(l, k), a[k], z);
-            } else {
-                v = rows_sum(dot4(wt.w4(), a)) + wt.b4();
-            }
-        }
-        // ---- reverse column ---------------------------------------------------------------------------------------------------
-        f32x4 a_bar = wt.w4(), z_bar;
-#pragma unroll
-        for (int l = 3; l >= 0; --l) {
-            const f32x4 u = a_bar * g1[l];
-            const float m = rows_sum(hsum4(u)) * (1.0f / kMlpHidden);
-            const float my = rows_sum(dot4(u, y[l])) * (1.0f / kMlpHidden);
-            z_bar = (u - splat4(m) - y[l] * splat4(my)) * splat4(inv_s[l]);
-            if (l > 0) {
-                a_bar = splat4(0.0f);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) a_bar = mfma4(wt.at(l - 1, k), z_bar[k], a_bar);
-            }
-        }
-        float t[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            f32x4 feat_bar = splat4(0.0f);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) feat_bar = mfma4(wt.at0(c, k), z_bar[k], feat_bar);
-            t[c] = rows_sum(dot4(feat_bar, e.d[c]));
-        }
+        float v, t[3];
+        if (split) forward_tile_split(swt, e, v, t);
+        else forward_tile_f32(wt, e, v, t);
         const bool mine = (g == q);                              // row q of tile q holds point 16 q + m = this lane
         out_v = mine ? v : out_v; out_t0 = mine ? t[0] : out_t0; out_t1 = mine ? t[1] : out_t1; out_t2 = mine ? t[2] : out_t2;
     }

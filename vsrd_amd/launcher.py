@@ -231,6 +231,9 @@ def main(argv=None):
     parser.add_argument("--seed", type=int, default=0)
     parser.add_argument("--ranks-share-gpu", action="store_true",
                         help="TEST ONLY: every rank on cuda:0, gloo rendezvous (RCCL refuses two ranks on one device); the line says so")
+    parser.add_argument("--fresh-loops", action="store_true",
+                        help="A/B: build a new FrameOptimizer (construction, eager warm-up steps, ~10 captures) for every frame, as round 4 did, "
+                             "instead of the persistent frame slots whose graphs are captured once at start-up")
     parser.add_argument("--max-restarts", type=int, default=2,
                         help="without torchrun around it, the launcher supervises its ranks: when one dies, all are started again as fresh "
                              "processes, this many times at most; finished frames are skipped (0 with --gpus 1: no child processes at all)")
@@ -270,18 +273,45 @@ def main(argv=None):
     ordered(lambda r: print(f"[rank {r}/{world}] {device}: frames {mine}", file=sys.stderr, flush=True))
     config = dict(num_steps=args.num_steps, warmup_steps=args.warmup_steps, num_rays=args.rays, num_samples=args.samples)
     # inputs are resident before the clock starts (what main.py:106-316 prepares per frame is the dataset's work, not the loop's)
-    inputs = {frame: synthetic_frame_inputs(device, frame, args.views, args.instances, args.height, args.width) for frame in mine}
+    pending = [frame for frame in mine if not os.path.exists(os.path.join(manifest["out"], f"frame_{int(frame):06d}", f"step_{args.num_steps - 1}.pt"))]
+    inputs = {frame: synthetic_frame_inputs(device, frame, args.views, args.instances, args.height, args.width) for frame in pending}
     losses = {}
+    # Frame slots (round 5): `--frames-in-flight` persistent loops, each constructed and with ALL its hipGraphs captured here, one after the
+    # other, before any worker thread exists (FrameOptimizer.capture_all).  A frame is then a reset (copies and fills), graph replays and a
+    # checkpoint: no construction, no eager steps, no capture next to another frame's work -- the collisions the capture gate of round 4
+    # was built around have nothing left to collide with.  (--fresh-loops: the round-4 form, for A/B.)
+    import queue
+    slots = queue.Queue()
+    setup_seconds, graphs_per_slot = 0.0, 0
+    if pending and not args.fresh_loops:
+        t_setup = time.perf_counter()
+        for _ in range(min(args.frames_in_flight, len(pending))):
+            loop = optimization.FrameOptimizer(inputs[pending[0]], optimization.OptimizationConfig(seed=int(manifest["seed"]), **config), device,
+                                               graph=True, persistent=True)
+            graphs_per_slot = loop.capture_all()
+            slots.put(loop)
+        torch.cuda.synchronize()
+        setup_seconds = time.perf_counter() - t_setup
+    captures_before = optimization.exclusive_device_access().capture_seconds
 
     def optimise(frame):
-        loop = optimization.FrameOptimizer(inputs[frame], optimization.OptimizationConfig(seed=int(frame), **config), device, graph=True)
-        record = loop.run(args.num_steps)
-        with optimization.exclusive_device_access():       # (host synchronisations and copies: refused now and then while another frame's thread captures)
-            torch.cuda.current_stream().synchronize()
-            losses[frame] = float(record["loss"])
-            payload = formats.checkpoint_payload(loop, step=args.num_steps - 1, metrics={}, host=True)
-        loop.close()
-        return payload
+        slot = None if args.fresh_loops else slots.get()
+        try:
+            loop = slot
+            if loop is None or not loop.reset(inputs[frame]):
+                # (--fresh-loops, or a frame whose importance weights do not suit the table sampler the slot's graphs draw from)
+                loop = optimization.FrameOptimizer(inputs[frame], optimization.OptimizationConfig(seed=int(manifest["seed"]), **config), device, graph=True)
+            record = loop.run(args.num_steps)
+            with optimization.exclusive_device_access():       # (host synchronisations and copies: refused now and then while another frame's thread captures)
+                torch.cuda.current_stream().synchronize()
+                losses[frame] = float(record["loss"])
+                payload = formats.checkpoint_payload(loop, step=args.num_steps - 1, metrics={}, host=True)
+            if loop is not slot:
+                loop.close()
+            return payload
+        finally:
+            if slot is not None:
+                slots.put(slot)
 
     def path_of(frame):
         return os.path.join(manifest["out"], f"frame_{int(frame):06d}", f"step_{args.num_steps - 1}.pt")
@@ -298,7 +328,8 @@ def main(argv=None):
     fence()
     elapsed = time.perf_counter() - t0
     report = dict(rank=rank, own_seconds=own, elapsed_seconds=elapsed, frames=len(done), skipped=len(mine) - len(done),
-                  gate_capture_seconds=optimization.exclusive_device_access().capture_seconds,
+                  gate_capture_seconds=optimization.exclusive_device_access().capture_seconds - captures_before,
+                  slot_setup_seconds=setup_seconds, graphs_per_slot=graphs_per_slot,
                   mean_final_loss=(sum(losses.values()) / len(losses)) if losses else None)
     gathered = [report]
     if world > 1:
@@ -318,9 +349,13 @@ def main(argv=None):
             "mean_final_loss": [r["mean_final_loss"] for r in gathered], "data": "synthetic", "dtype": "f32",
             # host time per frame spent capturing hipGraphs (optimization._CaptureGate): what the other frames in flight wait for
             "capture_seconds_per_frame": [r["gate_capture_seconds"] / r["frames"] if r["frames"] else None for r in gathered],
+            # persistent frame slots: built and captured once per rank BEFORE the clock (a job of thousands of frames pays it once)
+            "frame_slots": not args.fresh_loops, "slot_setup_seconds": [r["slot_setup_seconds"] for r in gathered],
+            "graphs_per_slot": [r["graphs_per_slot"] for r in gathered],
             "config": {"workload": f"{args.num_steps} optimisation steps per frame ({args.warmup_steps} box-only + {args.num_steps - args.warmup_steps} with the "
                                    f"residual MLP), {args.rays} rays x {args.samples} samples per step, {args.views} views of {args.height}x{args.width}, "
-                                   f"{args.instances} instances, FrameOptimizer(graph=True), {args.frames_in_flight} frames in flight per GPU",
+                                   f"{args.instances} instances, FrameOptimizer(graph=True), {args.frames_in_flight} frames in flight per GPU"
+                                   + (" (a new loop per frame)" if args.fresh_loops else " (persistent frame slots: graphs captured once at start-up)"),
                        "parallelism": f"frames sharded over {len(gathered)} rank(s), no data-path collective; RCCL: barriers, manifest broadcast, gather of the report",
                        "checkpoints": manifest["out"]},
         }

@@ -227,8 +227,11 @@ class FrameOptimizer:
     frame-resident tensors by index; in the residual phase the hypernetwork, its backward and its Adam are csrc/hypernetwork.h
     (``fused_hypernetwork = False`` keeps them with torch: the A/B reference)."""
 
-    def __init__(self, inputs: FrameInputs, config: OptimizationConfig, device, graph=False, fused_glue=None):
+    def __init__(self, inputs: FrameInputs, config: OptimizationConfig, device, graph=False, fused_glue=None, persistent=False):
+        """``persistent``: the loop will be given other frames of the same shape through ``reset()`` (a frame SLOT, launcher.py): it then
+        owns every buffer a captured graph holds the address of -- in particular a copy of the soft masks instead of the caller's tensor."""
         self._graphs = {}
+        self.persistent = bool(persistent)
         # the whole construction stays out of other frames' captures: it copies modules to the device, reads ranges back (.item()), runs
         # nonzero -- host synchronisations that, next to ANOTHER frame's capture, fail now and then or break that capture ("capturing
         # stream has unjoined work" in the other thread: one 36-frame run in fourteen)
@@ -279,23 +282,40 @@ class FrameOptimizer:
         self.camera_positions = cam                                         # [V,3]
         self.ray_directions = dirs.reshape(-1, 3).contiguous()              # [V*H*W,3]
         self.flat_masks = inputs.soft_masks.reshape(-1, N)
-        self.sampling_weights = self.flat_masks.max(dim=-1).values          # main.py:620-624
-        # the weights are fixed for the frame: the library sampler only visits the pixels that can be drawn at all
-        self.positive_pixels = torch.nonzero(self.sampling_weights > 0).flatten()
-        self.positive_weights = self.sampling_weights[self.positive_pixels].contiguous()
+        if self.persistent:                                                 # (a slot's graphs read the masks through this address for every later frame)
+            self.flat_masks = self.flat_masks.to(torch.float32).clone(memory_format=torch.contiguous_format)
+        self.sampling_weights = self.flat_masks.max(dim=-1).values.to(torch.float32).contiguous()          # main.py:620-624
+        self.ray_table = self.ray_remap = None
+        self._prepare_sampler(config)
+
+    def _prepare_sampler(self, config):
+        """What depends on the frame's importance weights (fixed for the frame).  Graph mode draws the rays on the device: the sampler's
+        table is built here, once per frame, over ALL V*H*W weights -- entries without weight have zero width and are never drawn, and the
+        table's size and entry count depend on the frame's SHAPE only, so a slot's graphs (which hold the table's address and count) serve
+        every frame of that shape; a step's draw is one launch (csrc/ray_sampling.h).  Frames whose weight sits in fewer entries than a
+        draw needs keep the per-step exponential race over the positive pixels (`ray_table` None).  False: such a frame cannot take over a
+        slot whose graphs were captured with the table."""
+        positive = int((self.sampling_weights > 0).sum())
         # torch.multinomial(replacement=False) raises when fewer categories than samples have weight; the device sampler would pad
         # its output with -1 instead (ray_sampling.h), silently: the weights are fixed for the frame, so check once here
-        if int(self.positive_pixels.numel()) < config.num_rays:
-            raise ValueError(f"only {int(self.positive_pixels.numel())} pixels have a positive soft mask, fewer than num_rays = {config.num_rays} "
+        if positive < config.num_rays:
+            raise ValueError(f"only {positive} pixels have a positive soft mask, fewer than num_rays = {config.num_rays} "
                              "(torch.multinomial without replacement raises in the reference as well)")
-        # graph mode draws the rays on the device.  The weights are fixed for the frame, so the sampler's table is built once here and a
-        # step's draw is one launch (csrc/ray_sampling.h); frames whose weight sits in fewer entries than a draw needs keep the
-        # per-step exponential race (`ray_table` None)
-        self.ray_table = None
-        if self.graph and self.device.type == "cuda":
-            table = rendering.RayTable(self.positive_weights)
-            if table.suits(config.num_rays):
-                self.ray_table = table
+        if not (self.graph and self.device.type == "cuda"):
+            return True
+        had_table = self.ray_table is not None
+        if had_table:
+            self.ray_table.rebuild(self.sampling_weights)
+        table = self.ray_table if had_table else rendering.RayTable(self.sampling_weights)
+        if table.suits(config.num_rays):
+            self.ray_table = table
+            return True
+        if had_table:
+            return False
+        # the race sampler only visits the pixels that can be drawn at all
+        self.positive_pixels = torch.nonzero(self.sampling_weights > 0).flatten()
+        self.positive_weights = self.sampling_weights[self.positive_pixels].contiguous()
+        return True
 
     # ---- fused glue (csrc/frame_step.h) ---------------------------------------------------------------------------------
     def _init_fused_glue(self):
@@ -332,7 +352,7 @@ class FrameOptimizer:
         b["grad_raw"], b["raw_gradients"] = torch.zeros(N, 8, **f32), torch.zeros(N, 8, **f32)
         b["grad_instances"], b["grad_mlp"] = torch.zeros(N, 16, **f32), torch.zeros(N, _lib.MLP_WEIGHTS, **f32)
         b["record"] = torch.zeros(5, **f32)
-        b["masks"] = self.flat_masks.to(**f32).contiguous()
+        b["masks"] = self.flat_masks.to(**f32).contiguous()        # (persistent: _prepare_rays made this the slot's own copy)
         self.fused_hypernetwork = True
         self.rebind()
         b["hyper_workspace"] = torch.empty(lib.vsrd_hypernetwork_workspace_bytes(N), dtype=torch.uint8, device=dev)
@@ -446,10 +466,14 @@ class FrameOptimizer:
         if with_prologue:
             table = self.ray_table
             code = lib.vsrd_frame_prologue_sample(*prologue_args, table.table.data_ptr(), table.count, cfg.num_rays, (cfg.seed + 1) & 0xFFFFFFFFFFFFFFFF,
-                                                  self.positive_pixels.data_ptr(), b["ray_indices"].data_ptr(), stream)
-            if code == _lib.E_LAUNCH and not torch.cuda.is_current_stream_capturing():
-                # the combined launch needs ~125 KB of LDS in one workgroup (cost matrix + the sampler's hash table): where the opt-in or
-                # the launch fails, the frame keeps the bit-identical two-launch form (tests: test_frame_prologue_matches_the_torch_path)
+                                                  None, b["ray_indices"].data_ptr(), stream)          # (the table covers every pixel: no remap)
+            if code == _lib.E_UNSUPPORTED and not torch.cuda.is_current_stream_capturing():
+                # the combined launch needs ~125 KB of LDS in one workgroup (cost matrix + the sampler's hash table): where that opt-in is
+                # refused (and only then: a failed launch is an error), the frame keeps the bit-identical two-launch form
+                # (tests: test_frame_prologue_matches_the_torch_path)
+                import warnings
+                warnings.warn("vsrd_frame_prologue_sample: the LDS opt-in of the combined launch was refused; this frame draws its rays "
+                              "in a launch of their own (vsrd_frame_prologue + vsrd_sample_rays_table)", RuntimeWarning)
                 self._prologue_draws = False
                 _lib.check(lib.vsrd_frame_prologue(*prologue_args, stream))
                 self._draw_rays(b["ray_indices"], b["picks"])
@@ -535,7 +559,7 @@ class FrameOptimizer:
         """Graph mode's draw of this step's rays into `out` (pixel indices over all views), keyed by the device-side step counter."""
         cfg = self.config
         if self.ray_table is not None:
-            return self.ray_table.sample(cfg.num_rays, seed=cfg.seed + 1, stream_offset=self.step_tensor, out=out, remap=self.positive_pixels)
+            return self.ray_table.sample(cfg.num_rays, seed=cfg.seed + 1, stream_offset=self.step_tensor, out=out, remap=self.ray_remap)
         picks = rendering.sample_rays(self.positive_weights, cfg.num_rays, seed=cfg.seed + 1, stream_offset=self.step_tensor, out=picks)
         return torch.index_select(self.positive_pixels, 0, picks, out=out)
 
@@ -573,9 +597,9 @@ class FrameOptimizer:
         key = (residual, ray_indices is not None)
         if key in self._graphs:
             graph, static_rays, outputs = self._graphs[key]
-            if static_rays is not None:
-                static_rays.copy_(ray_indices)
-            with _capture_lock.replaying():
+            with _capture_lock.replaying():      # (the copy too: nothing of a frame calls into HIP during another frame's capture)
+                if static_rays is not None:
+                    static_rays.copy_(ray_indices)
                 graph.replay()
             self.step_index += 1
             return outputs
@@ -717,6 +741,85 @@ class FrameOptimizer:
         result = {name: value.detach() for name, value in terms.items()}
         result["raw_gradients"] = raw_gradients
         return result
+
+    # ---- a frame SLOT: the loop and its captured graphs, reused for frame after frame (round 5) -----------------------------------------
+    def capture_all(self, steps_per_graph=4):
+        """Run, NOW, every eager warm-up step and every capture a frame's ``run()`` would meet on its way -- box-only and residual phase, the
+        one-step and the ``steps_per_graph``-step graph of each -- on the current frame's data, then ``reset()`` the frame.  A launcher
+        does this once per slot at start-up, one slot after the other and before any worker thread exists: afterwards a frame is copies,
+        fills and graph replays only, and stream capture -- a process-wide mode that every collision of round 4 had on one side -- never
+        happens next to another frame's work again.  Returns the number of graphs held."""
+        if not (self.graph and self.fused_glue and self.persistent):
+            raise ValueError("capture_all() belongs to a persistent graph-mode loop (FrameOptimizer(..., graph=True, persistent=True))")
+        cfg = self.config
+        k = int(steps_per_graph)
+        for phase_start in sorted({0, min(cfg.warmup_steps, cfg.num_steps)}):
+            phase_steps = (cfg.warmup_steps if phase_start < cfg.warmup_steps else cfg.num_steps) - phase_start
+            if phase_steps <= 0:
+                continue
+            with _capture_lock:
+                self.step_index = phase_start
+                self.step_tensor.fill_(phase_start)
+            for _ in range(min(4, phase_steps)):     # three eager steps, then the capture (and first replay) of the one-step graph
+                self.step()
+            if k > 1 and phase_steps >= 4 + k:       # (run() takes the k-step graph only for whole groups of k inside a phase)
+                self._graph_replay_many(k)
+        with _capture_lock:
+            torch.cuda.current_stream(self.device).synchronize()
+        self.reset(self.inputs)
+        return len(self._graphs)
+
+    def reset(self, inputs: FrameInputs):
+        """Start ANOTHER frame of the same shape in this loop, in place: the new frame's matrices, boxes and soft masks are copied into
+        the buffers the captured graphs read; parameters are re-initialised as a fresh ``BoxParameters3D`` / ``HyperDistanceField`` would
+        be (scripts/main.py:106-199 builds new models per frame); Adam's moments, counters and learning rates, the step counter and the
+        sampling table start over.  No allocation that a graph would have to learn about, no capture.  Returns False -- and leaves the
+        loop unusable for that frame -- when the frame's importance weights do not suit the table sampler the graphs were captured with
+        (the caller then optimises it in a loop of its own)."""
+        if not (self.graph and self.fused_glue and self.persistent):
+            raise ValueError("reset() belongs to a persistent graph-mode loop (FrameOptimizer(..., graph=True, persistent=True))")
+        cfg, dev, b = self.config, self.device, self._glue
+        V, N = self.num_views, self.num_instances
+        if tuple(inputs.soft_masks.shape) != (V, *[int(x) for x in self.inputs.image_size], N) or tuple(inputs.image_size) != tuple(self.inputs.image_size):
+            raise ValueError(f"a slot serves frames of ONE shape: {tuple(self.inputs.soft_masks.shape)}, got {tuple(inputs.soft_masks.shape)}")
+        with _capture_lock, torch.no_grad():
+            main = torch.cuda.current_stream(dev)
+            main.synchronize()                                      # (replays of the previous frame have finished: nothing reads the buffers)
+            # ---- inputs ----
+            H, W = (int(x) for x in inputs.image_size)
+            cam, dirs = rendering.ray_casting((H, W), inputs.intrinsic_matrices, inputs.extrinsic_matrices)
+            self.camera_positions.copy_(cam)
+            self.ray_directions.copy_(dirs.reshape(-1, 3))
+            self.flat_masks.copy_(inputs.soft_masks.reshape(-1, N))
+            if b["masks"].data_ptr() != self.flat_masks.data_ptr():
+                b["masks"].copy_(self.flat_masks)
+            torch.amax(self.flat_masks, dim=-1, out=self.sampling_weights)
+            b["extrinsics"].copy_(inputs.extrinsic_matrices.reshape(V, 16))
+            b["intrinsics"].copy_(inputs.intrinsic_matrices.reshape(V, 9))
+            b["gt_boxes"].copy_(inputs.boxes_2d.reshape(V, N, 4))
+            b["visible"].copy_(inputs.visible_masks)
+            self.inputs = inputs
+            # ---- parameters, optimiser, counters ----
+            fresh_detector = models.BoxParameters3D(1, N)
+            fresh_field = models.HyperDistanceField(48, [16, 16, 16, 16], 256, [256, 256, 256, 256])
+            for module, fresh in ((self.detector, fresh_detector), (self.hyper_distance_field, fresh_field)):
+                for p, q in zip(module.parameters(), fresh.parameters()):
+                    p.copy_(q)
+            initial = [cfg.learning_rate] * 3 + [cfg.embedding_learning_rate, cfg.hypernetwork_learning_rate]
+            for group, rate in zip(self.optimizer.param_groups, initial):
+                group["lr"].fill_(rate)
+                for p in group["params"]:
+                    state = self.optimizer.state.get(p)
+                    if state:
+                        state["exp_avg"].zero_(); state["exp_avg_sq"].zero_(); state["step"].zero_()
+            self.step_tensor.zero_()
+            self.schedule.fill_(1.0)
+            self.step_index = 0
+            for name in ("record", "raw_gradients", "grad_raw", "grad_instances", "grad_mlp", "projection_losses", "render_losses"):
+                b[name].zero_()
+            suits = self._prepare_sampler(cfg)
+            main.synchronize()
+        return suits
 
     def boxes(self):
         with torch.no_grad():

@@ -127,8 +127,13 @@ STEP_WAVE_PER_RAY = os.environ.get("VSRD_STEP_WAVE_PER_RAY", "0") == "1"
 STEP_SPLIT_RAY = os.environ.get("VSRD_STEP_SPLIT_RAY", "0") == "1"
 
 
+# A/B switch for the residual step's front kernel: True sets VSRD_FLAG_MLP_SPLIT_BF16 (the per-instance MLP's products on the bf16 matrix
+# instruction with both operands split into two bfloat16 parts; csrc/residual.h) instead of the exact-fp32 matrix instruction.
+MLP_SPLIT_BF16 = os.environ.get("VSRD_MLP_SPLIT_BF16", "0") == "1"
+
+
 def _base_flags():
-    return ((0 if CULLING else _lib.FLAG_NO_CULLING) | (_lib.FLAG_RUNNING_MINIMUM if RUNNING_MINIMUM else 0)
+    return ((0 if CULLING else _lib.FLAG_NO_CULLING) | (_lib.FLAG_MLP_SPLIT_BF16 if MLP_SPLIT_BF16 else 0) | (_lib.FLAG_RUNNING_MINIMUM if RUNNING_MINIMUM else 0)
             | (_lib.FLAG_GENERAL_ROTATIONS if GENERAL_ROTATIONS else 0) | (_lib.FLAG_RESIDUAL_SINGLE_KERNEL if RESIDUAL_SINGLE_KERNEL else 0)
             | (_lib.FLAG_RESIDUAL_WAVE_PER_RAY if RESIDUAL_WAVE_PER_RAY else 0) | (_lib.FLAG_STEP_WAVE_PER_RAY if STEP_WAVE_PER_RAY else 0) | (_lib.FLAG_STEP_SPLIT_RAY if STEP_SPLIT_RAY else 0))
 
@@ -582,7 +587,7 @@ class _SilhouetteStep(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, instances, origins, directions, targets, weights, u_coarse, u_fine, temperature, scalars, origin_stride,
-                seed, stream_offset, flags, loss_scale, want_labels):
+                seed, stream_offset, flags, loss_scale, want_labels, want_samples=False):
         lib = _lib.load()
         std, ratio, eps, near, far, S, schedule = _unpack(scalars)
         R, N = directions.shape[0], instances.shape[0]
@@ -591,22 +596,27 @@ class _SilhouetteStep(torch.autograd.Function):
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         grad = torch.empty_like(instances)
         labels = torch.empty(R, N, dtype=torch.float32, device=dev) if want_labels else None
+        samples = None
+        if want_samples:          # the step's own state between its passes (vsrd_render_config::out_*)
+            samples = (torch.empty(R, 2 * S, dtype=torch.float32, device=dev), torch.empty(R, S - 1, dtype=torch.float32, device=dev),
+                       torch.empty(R, S, dtype=torch.float32, device=dev), torch.empty(R, S, dtype=torch.float32, device=dev))
         workspace = _workspace(dev, N, False)
         field = _lib.make_field(instances, temperature)
-        config = _lib.make_config(R, S, (near, far), std, ratio, eps, origin_stride, seed, stream_offset, flags, schedule=schedule)
+        config = _lib.make_config(R, S, (near, far), std, ratio, eps, origin_stride, seed, stream_offset, flags, schedule=schedule, samples=samples)
         with profiling.timed("vsrd_render_silhouette_step"):
             _lib.check(lib.vsrd_render_silhouette_step(field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(u_coarse), _lib.ptr(u_fine),
                                                        _lib.ptr(targets), _lib.ptr(weights), float(loss_scale), workspace.data_ptr(),
                                                        workspace.numel(), _lib.ptr(loss), _lib.ptr(grad), _lib.ptr(labels), _lib.stream()))
         ctx.save_for_backward(grad)
         out_labels = labels if want_labels else loss.new_empty(0)
-        ctx.mark_non_differentiable(out_labels)
-        return loss[0], out_labels
+        out_samples = samples if want_samples else tuple(loss.new_empty(0) for _ in range(4))
+        ctx.mark_non_differentiable(out_labels, *out_samples)
+        return (loss[0], out_labels) + tuple(out_samples)
 
     @staticmethod
-    def backward(ctx, grad_loss, _grad_labels):
+    def backward(ctx, grad_loss, *_unused):
         grad, = ctx.saved_tensors
-        return (grad * grad_loss,) + (None,) * 14
+        return (grad * grad_loss,) + (None,) * 15
 
 
 class _ResidualStep(torch.autograd.Function):
@@ -647,12 +657,16 @@ class _ResidualStep(torch.autograd.Function):
 
 def silhouette_step(distance_field, ray_positions, ray_directions, targets, distance_range, num_samples, sdf_std_deviation,
                     cosine_ratio=1.0, epsilon=1.0e-6, pd_indices=None, gt_indices=None, u_coarse=None, u_fine=None, seed=0,
-                    stream_offset=0, return_labels=False, skip_exact_misses=True, schedule=None, eikonal_ratio=0.0, return_terms=False):
+                    stream_offset=0, return_labels=False, skip_exact_misses=True, schedule=None, eikonal_ratio=0.0, return_terms=False,
+                    return_samples=False):
     """Fused fast path of scripts/main.py:629-687: the two-pass render AND
     ``mean(BCE(clamp(labels[..., pd_indices], 1e-6, 1 - 1e-6), targets[..., gt_indices]))`` in one launch; for residual fields
     (box + per-instance MLP) also ``eikonal_ratio * mean((|sampled_gradients| - 1)^2)`` (main.py:679-687), i.e. the returned loss is
     ``silhouette + eikonal_ratio * eikonal``.  Returns the loss (autograd-connected to the field parameters), then -- when asked --
-    the detached terms ``[silhouette, eikonal]`` and the labels [R,N]."""
+    the detached terms ``[silhouette, eikonal]``, the labels [R,N], and (``return_samples``, box-only fields) a dict with the step's OWN
+    state between its passes: ``distances`` [R,2S] (sorted; NaN in column 0 = ray skipped as an exact miss), ``coarse_weights`` [R,S-1],
+    ``u_coarse`` / ``u_fine`` [R,S] -- what its labels, loss and gradients were computed from (the full-size parity tests feed them to the
+    oracle)."""
     block = flatten(distance_field)
     residual = block.mlp_weights is not None
     if eikonal_ratio and not residual:
@@ -677,13 +691,19 @@ def silhouette_step(distance_field, ray_positions, ray_directions, targets, dist
         u_fine = u_fine.reshape(-1, num_samples).to(torch.float32).contiguous()
     flags = (_lib.FLAG_SKIP_EXACT_MISSES if skip_exact_misses else 0) | _base_flags() | (_lib.FLAG_YAW_GRADIENTS if block.yaw_gradients else 0)
     scalars = (float(sdf_std_deviation), float(cosine_ratio), float(epsilon), float(distance_range[0]), float(distance_range[1]), int(num_samples), schedule)
+    if return_samples and residual:
+        raise NotImplementedError("return_samples: box-only fields (vsrd_render_silhouette_step) only")
+    samples = None
     if residual:
         loss, terms, labels = _ResidualStep.apply(block.instances, block.mlp_weights, origins, directions, ordered, weights, u_coarse, u_fine,
                                                   block.temperature, scalars, stride, int(seed), _offset(stream_offset), flags & ~_lib.FLAG_SKIP_EXACT_MISSES,
                                                   1.0 / (R * max(kept, 1)), float(eikonal_ratio), bool(return_labels))
     else:
-        loss, labels = _SilhouetteStep.apply(block.instances, origins, directions, ordered, weights, u_coarse, u_fine, block.temperature, scalars,
-                                             stride, int(seed), _offset(stream_offset), flags, 1.0 / (R * max(kept, 1)), bool(return_labels))
+        loss, labels, *samples = _SilhouetteStep.apply(block.instances, origins, directions, ordered, weights, u_coarse, u_fine, block.temperature, scalars,
+                                                       stride, int(seed), _offset(stream_offset), flags, 1.0 / (R * max(kept, 1)), bool(return_labels),
+                                                       bool(return_samples))
         terms = torch.stack([loss.detach(), torch.zeros_like(loss.detach())])
     out = (loss,) + ((terms,) if return_terms else ()) + ((labels,) if return_labels else ())
+    if return_samples:
+        out = out + (dict(zip(("distances", "coarse_weights", "u_coarse", "u_fine"), samples)),)
     return out if len(out) > 1 else loss

@@ -104,6 +104,15 @@ class RayTable:
         self.table = torch.empty(lib.vsrd_ray_table_bytes(self.count), dtype=torch.uint8, device=self.weights.device)
         _lib.check(lib.vsrd_ray_table_build(_lib.ptr(self.weights), self.count, self.table.data_ptr(), self.table.numel(), _lib.stream()))
 
+    def rebuild(self, weights):
+        """The table of OTHER weights of the same count, in place (same buffer, same address: a captured graph that draws from this table
+        draws from the new weights).  The build clears the header, the sticky `incomplete` flag included."""
+        weights = weights.detach().reshape(-1).to(torch.float32).contiguous()
+        if int(weights.numel()) != self.count or weights.device != self.weights.device:
+            raise ValueError(f"RayTable.rebuild: {self.count} weights on {self.weights.device} expected")
+        self.weights = weights
+        _lib.check(_lib.load().vsrd_ray_table_build(_lib.ptr(self.weights), self.count, self.table.data_ptr(), self.table.numel(), _lib.stream()))
+
     def suits(self, num_samples, margin=4.0):
         """Whether ``num_samples`` distinct picks arrive well inside the kernel's budget: skipping repeats needs about
         num_samples / (share of the weight outside the num_samples - 1 heaviest entries) picks.  One host synchronisation: call it once."""
