@@ -607,6 +607,7 @@ def test_frame_slot_reuses_its_graphs_for_the_next_frame(dev):
         loop.close()
         return result
 
+    untouched = [t.clone() for t in (frames[0].extrinsic_matrices, frames[0].intrinsic_matrices, frames[0].boxes_2d, frames[0].soft_masks)]
     torch.manual_seed(100)
     slot = optimization.FrameOptimizer(frames[0], config, dev, graph=True, persistent=True)
     held = slot.capture_all()
@@ -641,6 +642,9 @@ def test_frame_slot_reuses_its_graphs_for_the_next_frame(dev):
     assert abs(float(slot.optimizer.param_groups[0]["lr"]) - config.learning_rate * config.lr_gamma ** steps) < 1e-9
     with pytest.raises(ValueError):
         slot.reset(_c1_inputs(dev, all_visible=True, N=5))                     # another shape: another slot
+    # the slot owns what reset() overwrites: the frame it was built from is still the caller's (several slots are built from one frame)
+    for before, now in zip(untouched, (frames[0].extrinsic_matrices, frames[0].intrinsic_matrices, frames[0].boxes_2d, frames[0].soft_masks)):
+        assert torch.equal(before, now)
     slot.close()
 
 

@@ -15,15 +15,22 @@ READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 
 
 def code_object_notes(library):
+    """The notes of EVERY gfx950 code object in the library's fat binary (round 5: two translation units, api.hip and split_front.hip,
+    one clang offload bundle each)."""
     with tempfile.TemporaryDirectory() as tmp:
         fatbin, device = os.path.join(tmp, "fatbin.bin"), os.path.join(tmp, "device.co")
         subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", library, fatbin], check=True)
         data = open(fatbin, "rb").read()
-        start = data.find(b"\x7fELF")                         # the gfx950 code object inside the clang offload bundle
-        if start < 0:
+        starts = [m.start() for m in re.finditer(b"\x7fELF", data)]
+        if not starts:
             raise SystemExit(f"{library}: no device code object found")
-        open(device, "wb").write(data[start:])
-        return subprocess.run([READELF, "--notes", device], capture_output=True, text=True, check=True).stdout
+        notes = ""
+        for begin, end in zip(starts, starts[1:] + [len(data)]):
+            open(device, "wb").write(data[begin:end])
+            out = subprocess.run([READELF, "--notes", device], capture_output=True, text=True)
+            if out.returncode == 0:
+                notes += out.stdout
+        return notes
 
 
 def main():

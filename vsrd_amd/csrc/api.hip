@@ -11,6 +11,7 @@
 #include "projection.h"
 #include "frame_step.h"
 #include "hypernetwork.h"
+#include "split_front.h"
 
 namespace {
 
@@ -982,11 +983,13 @@ int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_con
     const float eikonal_scale = eikonal_ratio * eikonal_norm;
     const unsigned mlp_bits = (config->flags & VSRD_FLAG_MLP_WEIGHTS_CENTRED) ? kMlpCentredBit : 0u;
     const size_t adjoint_lds = (static_cast<size_t>(kMlpWbarFloats) + static_cast<size_t>(kMlpStashTiles) * kTileFloats) * sizeof(float);
-    // VSRD_FLAG_MLP_SPLIT_BF16: the front kernels read the instances' split-bf16 operand images instead of their weights
+    // VSRD_FLAG_MLP_SPLIT_BF16: the front kernels of the OTHER translation unit (split_front.hip), which read the instances' split-bf16
+    // operand images instead of their weights
+    const bool split = (config->flags & VSRD_FLAG_MLP_SPLIT_BF16) != 0u;
     const float* front_weights = field->mlp_weights;
-    if (config->flags & VSRD_FLAG_MLP_SPLIT_BF16) {
+    if (split) {
         unsigned* images = reinterpret_cast<unsigned*>(base + p.images);
-        hipLaunchKernelGGL(pack_mlp_images_kernel, dim3(N), dim3(256), 0, s, field->mlp_weights, (config->flags & VSRD_FLAG_MLP_WEIGHTS_CENTRED) ? 1 : 0, images);
+        if (vsrd_split_front::pack_images(field->mlp_weights, N, (config->flags & VSRD_FLAG_MLP_WEIGHTS_CENTRED) ? 1 : 0, images, s) != vsrd_split_front::kOk) return VSRD_E_LAUNCH;
         front_weights = reinterpret_cast<const float*>(images);
     }
     int chunk_index = 0;
@@ -1003,7 +1006,13 @@ int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_con
 #define VSRD_LAUNCH_PAIR(K)                                                                                                              \
         if (opt_in_lds(residual_step_pair_kernel<K>, p.front_lds) != VSRD_OK) return VSRD_E_LAUNCH;                                      \
         hipLaunchKernelGGL(residual_step_pair_kernel<K>, dim3(p.front_blocks), dim3(kPairWaves * kWave), p.front_lds, s, VSRD_FRONT_ARGS)
-        if (p.pair) {
+        if (split) {
+            vsrd_split_front::FrontLaunch launch = {&f, sizeof f, &c, sizeof c, field->instances, front_weights, origins, directions, u_coarse, u_fine, targets, instance_weights,
+                                                    loss_scale, eikonal_scale, eikonal_norm, labels, box_partials, jets, loss_partials, seeds, masks, p.slots_per_instance,
+                                                    first, rays, chunk_index > 0 ? 1 : 0, p.pair, p.rounds, p.front_blocks, p.front_lds};
+            const int code = vsrd_split_front::launch_front(launch, s);
+            if (code != vsrd_split_front::kOk) return code == vsrd_split_front::kUnsupported ? VSRD_E_UNSUPPORTED : VSRD_E_LAUNCH;
+        } else if (p.pair) {
             switch (p.rounds) {
                 case 2: VSRD_LAUNCH_PAIR(2); break;
                 case 4: VSRD_LAUNCH_PAIR(4); break;

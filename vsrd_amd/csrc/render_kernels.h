@@ -1506,6 +1506,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 
 // VSRD_FLAG_MLP_SPLIT_BF16: the operand images of a launch's instances (residual.h: pack_mlp_image), one workgroup per instance, once per
 // vsrd_render_residual_step call (N x 9.4 KB: the front kernels stage an instance's image where they staged its 6.5 KB of weights).
+#ifdef VSRD_SPLIT_BF16      // (csrc/split_front.hip only)
 __global__ __launch_bounds__(256) void pack_mlp_images_kernel(const float* __restrict__ weights, int centred, unsigned* __restrict__ images) {
     __shared__ __attribute__((aligned(16))) float staged[kMlpWbarFloats];
     const int n = blockIdx.x;
@@ -1513,6 +1514,7 @@ __global__ __launch_bounds__(256) void pack_mlp_images_kernel(const float* __res
     __syncthreads();
     pack_mlp_image((LdsFloats)staged, images + static_cast<size_t>(n) * kMlpImageWords, static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x));
 }
+#endif
 
 // grad_mlp [N,1617] (+)= sum over the item rows of instance i (fixed order); box_extra [N,16] likewise (the MLP's dL/dp chained into t, R).
 // Two deterministic stages: kItemSegments contiguous row ranges per instance are summed in parallel (grid N x 7 x segments), then the

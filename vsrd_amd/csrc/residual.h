@@ -50,9 +50,12 @@ __device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
 __device__ __forceinline__ float hsum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 __device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]); }
 
-// Sum over the four rows of 16 lanes: every lane (g, m) receives sum_g' v(g', m).  One MFMA with an all-ones A operand
-// (D[i][m] = sum_k 1 * B[k][m], k = row) instead of two row swaps: ~10 VALU issue slots become one matrix-pipe slot.
-#ifdef VSRD_ROWS_SUM_SWAP
+// Sum over the four rows of 16 lanes: every lane (g, m) receives sum_g' v(g', m): two row swaps (v_permlane16_swap / v_permlane32_swap).
+// Rounds 2-4 used ONE fp32 MFMA with an all-ones A operand instead (D[i][m] = sum_k 1 * B[k][m], k = row) on the assumption that the
+// matrix instruction runs beside the vector ones.  It does not (tools/micro/mfma_valu_interleave.hip: 32.5 cycles alone, ~42 in a stream
+// of vector instructions, nothing hidden), and the swaps cost ~18: round 5, same box, same build otherwise: config 3 3.05 -> 3.13 Mrays/s,
+// the native residual step 0.838 -> 0.820 ms.  -DVSRD_ROWS_SUM_MFMA: the matrix form.
+#ifndef VSRD_ROWS_SUM_MFMA
 __device__ __forceinline__ float rows_sum(float v) { return add_xor32(add_xor16(v)); }
 #else
 __device__ __forceinline__ float rows_sum(float v) { return mfma4(1.0f, v, f32x4{0.0f, 0.0f, 0.0f, 0.0f})[0]; }
@@ -559,6 +562,13 @@ constexpr int kImgTailFloats = 96;
 constexpr int kMlpImageWords = kImgTail + kImgTailFloats;    // 2400 words (9.4 KB) per instance; lane-linear, so every operand read is conflict-free
 constexpr int kMlpStageFloats = kMlpImageWords > kMlpWbarFloats ? kMlpImageWords : kMlpWbarFloats;   // a wave's staging area in kernels that take either form
 
+// The code below is compiled only in the translation unit that defines VSRD_SPLIT_BF16 (csrc/split_front.hip): under the library's
+// scheduler strategy (-amdgpu-sched-strategy=iterative-ilp) hipcc 7.2 crashes on it -- the iterative scheduler leaves the live intervals
+// of this function inconsistent and the register allocator's spill-weight pass (VirtRegAuxInfo::isRematerializable) follows a copy to a
+// value that is not there; which source shapes trigger it changes with every edit (the reverse column as a loop, the row sums as lane
+// swaps ...).  split_front.hip holds the residual step's front kernels with these products and is compiled with the default strategy;
+// api.hip (everything else, iterative-ilp) never sees this code.
+#ifdef VSRD_SPLIT_BF16
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
     unsigned r;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
@@ -673,6 +683,8 @@ __device__ __forceinline__ void forward_tile_split(const SplitWeights& wt, const
     for (int c = 0; c < 3; ++c) t[c] = rows_sum(dot4(z_bar, x[c]));
 }
 
+#endif  // VSRD_SPLIT_BF16
+
 VSRD_RESIDUAL_FN Residual residual_forward(const float* w_in, float px, float py, float pz, unsigned tiles_in, float* weights_lds) {
     const int lane = lane_id();
     const int g = lane >> 4;
@@ -681,8 +693,11 @@ VSRD_RESIDUAL_FN Residual residual_forward(const float* w_in, float px, float py
     const bool split = (tiles & kMlpSplitBit) != 0u;                           // (wave-uniform) w_in is the instance's operand image
     const LdsFloats staged = (LdsFloats)weights_lds;
     wave_lds_order();                                            // (the previous call's operand reads are done)
+#ifdef VSRD_SPLIT_BF16
     if (split) stage_image_wave((LdsWords)weights_lds, w_in, lane);
-    else stage_centred_weights_wave(staged, uniform_weights_generic(w_in), (tiles & kMlpCentredBit) != 0u, lane);
+    else
+#endif
+    stage_centred_weights_wave(staged, uniform_weights_generic(w_in), (tiles & kMlpCentredBit) != 0u, lane);
     wave_lds_order();
 #ifdef VSRD_PROBE_STAGE_TWICE          // probe: what one staging costs (the difference to the normal build)
     asm volatile("" ::: "memory");
@@ -690,7 +705,11 @@ VSRD_RESIDUAL_FN Residual residual_forward(const float* w_in, float px, float py
     wave_lds_order();
 #endif
     const LdsWeights wt = {staged, g, lane & 15};
+#ifdef VSRD_SPLIT_BF16
     const SplitWeights swt = {(LdsWords)weights_lds, lane, g};
+#else
+    (void)split;
+#endif
     const float fold = (px > 0.0f) ? 1.0f : ((px < 0.0f) ? -1.0f : 0.0f);
     const float inv = 1.0f / kPositionScale;
     const float f0 = fabsf(px) * inv, f1 = py * inv, f2 = pz * inv;
@@ -701,8 +720,11 @@ VSRD_RESIDUAL_FN Residual residual_forward(const float* w_in, float px, float py
         TileFeatures e;
         encode_tile(from_row(f0, q, lane, start), from_row(f1, q, lane, start), from_row(f2, q, lane, start), g, e);
         float v, t[3];
+#ifdef VSRD_SPLIT_BF16
         if (split) forward_tile_split(swt, e, v, t);
-        else forward_tile_f32(wt, e, v, t);
+        else
+#endif
+        forward_tile_f32(wt, e, v, t);
         const bool mine = (g == q);                              // row q of tile q holds point 16 q + m = this lane
         out_v = mine ? v : out_v; out_t0 = mine ? t[0] : out_t0; out_t1 = mine ? t[1] : out_t1; out_t2 = mine ? t[2] : out_t2;
     }

@@ -1,0 +1,66 @@
+// Second translation unit of libvsrd_hip: the front kernels of vsrd_render_residual_step with the per-instance MLP's products on
+// v_mfma_f32_16x16x32_bf16, both operands split into two bfloat16 parts (VSRD_FLAG_MLP_SPLIT_BF16; residual.h: forward_tile_split).
+// Compiled WITHOUT -amdgpu-sched-strategy=iterative-ilp (see residual.h and __graft_entry__.py) and with the headers' namespace renamed,
+// so that its copies of the kernels do not collide with api.hip's at link time.
+#define VSRD_SPLIT_BF16 1
+#define vsrd vsrd_split
+#include "render_kernels.h"
+#undef vsrd
+#include <cstring>
+#include "split_front.h"
+
+namespace vsrd_split_front {
+
+int pack_images(const float* weights, int num_instances, int centred, unsigned* images, hipStream_t stream) {
+    hipLaunchKernelGGL(vsrd_split::pack_mlp_images_kernel, dim3(num_instances), dim3(256), 0, stream, weights, centred, images);
+    return hipGetLastError() == hipSuccess ? kOk : kLaunchFailed;
+}
+
+namespace {
+template <typename Kernel>
+bool opt_in(Kernel kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return true;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)) == hipSuccess;
+}
+}  // namespace
+
+int launch_front(const FrontLaunch& a, hipStream_t stream) {
+    using namespace vsrd_split;
+    if (a.field_args_bytes != sizeof(FieldArgs) || a.render_args_bytes != sizeof(RenderArgs)) return kUnsupported;
+    FieldArgs f;
+    RenderArgs c;
+    std::memcpy(&f, a.field_args, sizeof f);
+    std::memcpy(&c, a.render_args, sizeof c);
+#define VSRD_ARGS f, a.instances, a.images, c, a.origins, a.directions, a.u_coarse, a.u_fine, a.targets, a.instance_weights, a.loss_scale, a.eikonal_scale, a.eikonal_norm, \
+                  a.labels, a.box_partials, static_cast<float4*>(a.jets), a.loss_partials, a.seeds, a.masks, a.slots_per_instance, a.first, a.rays, a.accumulate
+#define VSRD_FRONT(K)                                                                                                                         \
+    do {                                                                                                                                      \
+        if (!opt_in(residual_step_front_kernel<K>, a.lds_bytes)) return kLdsRefused;                                                          \
+        hipLaunchKernelGGL(residual_step_front_kernel<K>, dim3(a.blocks), dim3(kBlockThreads), a.lds_bytes, stream, VSRD_ARGS);               \
+    } while (0)
+#define VSRD_PAIR(K)                                                                                                                          \
+    do {                                                                                                                                      \
+        if (!opt_in(residual_step_pair_kernel<K>, a.lds_bytes)) return kLdsRefused;                                                           \
+        hipLaunchKernelGGL(residual_step_pair_kernel<K>, dim3(a.blocks), dim3(kPairWaves * kWave), a.lds_bytes, stream, VSRD_ARGS);           \
+    } while (0)
+    if (a.pair) {
+        switch (a.rounds) {
+            case 2: VSRD_PAIR(2); break;
+            case 4: VSRD_PAIR(4); break;
+            default: return kUnsupported;
+        }
+    } else {
+        switch (a.rounds) {
+            case 1: VSRD_FRONT(1); break;
+            case 2: VSRD_FRONT(2); break;
+            case 4: VSRD_FRONT(4); break;
+            default: return kUnsupported;
+        }
+    }
+#undef VSRD_FRONT
+#undef VSRD_PAIR
+#undef VSRD_ARGS
+    return hipGetLastError() == hipSuccess ? kOk : kLaunchFailed;
+}
+
+}  // namespace vsrd_split_front

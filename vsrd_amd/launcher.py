@@ -329,7 +329,7 @@ def main(argv=None):
     elapsed = time.perf_counter() - t0
     report = dict(rank=rank, own_seconds=own, elapsed_seconds=elapsed, frames=len(done), skipped=len(mine) - len(done),
                   gate_capture_seconds=optimization.exclusive_device_access().capture_seconds - captures_before,
-                  slot_setup_seconds=setup_seconds, graphs_per_slot=graphs_per_slot,
+                  slot_setup_seconds=setup_seconds, graphs_per_slot=graphs_per_slot, final_losses={int(f): losses[f] for f in sorted(losses)},
                   mean_final_loss=(sum(losses.values()) / len(losses)) if losses else None)
     gathered = [report]
     if world > 1:
@@ -347,6 +347,7 @@ def main(argv=None):
             "per_rank_seconds": [r["own_seconds"] for r in gathered], "per_rank_frames": [r["frames"] for r in gathered],
             "seconds_per_frame_per_gpu": [r["own_seconds"] / r["frames"] if r["frames"] else None for r in gathered],
             "mean_final_loss": [r["mean_final_loss"] for r in gathered], "data": "synthetic", "dtype": "f32",
+            "final_loss_per_frame": {str(f): v for r in gathered for f, v in r["final_losses"].items()},
             # host time per frame spent capturing hipGraphs (optimization._CaptureGate): what the other frames in flight wait for
             "capture_seconds_per_frame": [r["gate_capture_seconds"] / r["frames"] if r["frames"] else None for r in gathered],
             # persistent frame slots: built and captured once per rank BEFORE the clock (a job of thousands of frames pays it once)

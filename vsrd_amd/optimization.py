@@ -343,6 +343,9 @@ class FrameOptimizer:
         b["intrinsics"] = inp.intrinsic_matrices.to(**f32).reshape(V, 9).contiguous()
         b["gt_boxes"] = inp.boxes_2d.to(**f32).reshape(V, N, 4).contiguous()
         b["visible"] = inp.visible_masks.to(device=dev, dtype=torch.uint8).contiguous()
+        if self.persistent:       # a slot OWNS what reset() overwrites: float32 contiguous inputs would otherwise be these very tensors -- the
+            for name in ("extrinsics", "intrinsics", "gt_boxes", "visible"):      # caller's, and every other slot's built from the same frame
+                b[name] = b[name].clone()
         b["scratch"] = torch.empty(lib.vsrd_frame_scratch_bytes(V, N), dtype=torch.uint8, device=dev)
         b["instances"] = torch.zeros(N, 16, **f32)
         b["pd_indices"], b["gt_indices"] = torch.zeros(N, dtype=torch.int64, device=dev), torch.zeros(N, dtype=torch.int64, device=dev)
