@@ -639,7 +639,7 @@ def test_frame_slot_reuses_its_graphs_for_the_next_frame(dev):
     # the optimiser restarted: Adam's counters equal the steps of THIS frame, the rates are this frame's decay
     assert float(slot.optimizer.state[slot.detector.locations]["step"]) == steps
     assert float(slot.optimizer.state[slot.detector.embeddings]["step"]) == steps - config.warmup_steps        # (stepped in the residual phase only)
-    assert abs(float(slot.optimizer.param_groups[0]["lr"]) - config.learning_rate * config.lr_gamma ** steps) < 1e-9
+    assert abs(float(slot.optimizer.param_groups[0]["lr"]) / (config.learning_rate * config.lr_gamma ** steps) - 1.0) < 1e-5      # (float32, 26 in-place decays)
     with pytest.raises(ValueError):
         slot.reset(_c1_inputs(dev, all_visible=True, N=5))                     # another shape: another slot
     # the slot owns what reset() overwrites: the frame it was built from is still the caller's (several slots are built from one frame)

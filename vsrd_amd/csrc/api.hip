@@ -1029,9 +1029,14 @@ int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_con
 #undef VSRD_LAUNCH
 #undef VSRD_LAUNCH_PAIR
 #undef VSRD_FRONT_ARGS
-        hipLaunchKernelGGL(residual_mlp_adjoint_kernel, dim3(kMlpAdjointBlocks), dim3(kWave), adjoint_lds, s, field->instances,
-                           field->mlp_weights, N, mlp_bits, seeds, masks, p.slots_per_instance, used_slots, p.items_per_instance, p.slots_per_item,
-                           counter, item_rows, item_flags);
+        if (split) {
+            if (vsrd_split_front::launch_adjoint(kMlpAdjointBlocks, field->instances, front_weights, N, seeds, masks, p.slots_per_instance, used_slots,
+                                                 p.items_per_instance, p.slots_per_item, counter, item_rows, item_flags, s) != vsrd_split_front::kOk) return VSRD_E_LAUNCH;
+        } else {
+            hipLaunchKernelGGL(residual_mlp_adjoint_kernel, dim3(kMlpAdjointBlocks), dim3(kWave), adjoint_lds, s, field->instances,
+                               field->mlp_weights, N, mlp_bits, seeds, masks, p.slots_per_instance, used_slots, p.items_per_instance, p.slots_per_item,
+                               counter, item_rows, item_flags);
+        }
         hipLaunchKernelGGL(reduce_item_rows_kernel, dim3(N, (kItemRowFloats + 255) / 256, kItemSegments), dim3(256), 0, s, item_rows, item_flags,
                            p.items_per_instance, segment_sums);
         hipLaunchKernelGGL(reduce_item_segments_kernel, dim3(N, (kItemRowFloats + 255) / 256), dim3(256), 0, s, segment_sums, grad_mlp_weights, box_extra,

@@ -1504,6 +1504,94 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     }
 }
 
+#ifdef VSRD_SPLIT_BF16      // (csrc/split_front.hip only)
+constexpr int kMlpSplitScratchTiles = 4;
+// residual_mlp_adjoint_kernel on the split-bf16 products (VSRD_FLAG_MLP_SPLIT_BF16; residual.h: mlp_adjoint_points_split): the instance's
+// operand IMAGE is staged instead of its weights (9.4 KB) and the scratch is four tiles (the encoder features are recomputed, not
+// stashed): 14.5 KB of LDS per single-wave workgroup, eight per CU as before.  Same work items, same rows, same reductions.
+// One wave = one workgroup (its own staged image and transposition scratch), so waves
+// never wait for each other: the active fraction of an item varies from 0 to 1.  Work item = (instance, kSlotsPerItem consecutive
+// slots), fetched with one global atomic; ONE partial row per item and a flag whether it holds anything.
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void residual_mlp_adjoint_split_kernel(
+    const float* __restrict__ instances, const float* __restrict__ mlp, int N, unsigned mlp_bits, const float* __restrict__ seed_table,
+    const unsigned char* __restrict__ mask_table, long long slots_per_instance, long long used_slots, int items_per_instance, int slots_per_item,
+    unsigned* __restrict__ next_item, float* __restrict__ item_rows, unsigned char* __restrict__ item_flags) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = lane_id();
+    const LdsWords staged = (LdsWords)lds;                                     // [kMlpImageWords] this item's instance: the operand image
+    const LdsFloats scratch = (LdsFloats)lds + kMlpImageWords;                 // kMlpSplitScratchTiles tiles
+    const SplitWeights wt = {staged, lane, lane >> 4};
+    const int num_items = N * items_per_instance;
+    int staged_instance = -1;
+    while (true) {
+        int item = 0;
+        if (lane == 0) item = static_cast<int>(atomicAdd(next_item, 1u));
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= num_items) break;
+        const int i = item / items_per_instance;
+        const long long first = static_cast<long long>(item - i * items_per_instance) * slots_per_item;
+        const unsigned char* item_counts = mask_table + static_cast<long long>(i) * slots_per_instance + first;
+        // Lane k looks at slot k of the item (slots_per_item <= 64): the number of leading seed columns that matter (adjoint_phase_b).
+        // Round 4: the points of ALL the item's slots are taken as one stream and cut into 16-point tiles -- a slot of its own ends in a
+        // partly filled tile (half a tile per (ray, round, instance) on average: a fifth of the tiles of pass 2, tests/tile_statistics.py),
+        // the stream only once.  Element e of the stream = column e - begin_k of slot k, k = the first slot whose inclusive count exceeds e.
+        const int my_count = (lane < slots_per_item && first + lane < used_slots) ? static_cast<int>(item_counts[lane]) : 0;
+        const int inclusive = static_cast<int>(wave_inclusive_sum(static_cast<float>(my_count)));        // (exact: at most 64 x 64)
+        const int total = __builtin_amdgcn_readlane(inclusive, kWave - 1);
+        if (total == 0) {
+            if (lane == 0) item_flags[item] = 0;
+            continue;
+        }
+        if (i != staged_instance) {
+            wave_lds_sync();
+            stage_image_wave(staged, mlp + static_cast<size_t>(i) * kMlpImageWords, lane);      // (`mlp`: the image table of pack_mlp_images_kernel)
+            staged_instance = i;
+            wave_lds_sync();
+        }
+        const Instance in = load_instance(instances, i);
+        MlpAdjoint s;
+        s.clear();
+        float at0 = 0, at1 = 0, at2 = 0;
+        float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
+        const int begin = inclusive - my_count;
+        const float* item_seeds = seed_table + (static_cast<long long>(i) * slots_per_instance + first) * (kSeedFloats * kWave);
+#pragma unroll 1
+        for (int base = 0; base < total; base += kWave) {
+            const int e = base + lane;
+            const bool valid = e < total;
+            int k = 0;                                                         // number of slots whose inclusive count is <= e (binary lifting over the lanes)
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                const int probe = __builtin_amdgcn_ds_bpermute((k + step - 1) << 2, inclusive);
+                k += (probe <= e) ? step : 0;
+            }
+            const int column = e - __builtin_amdgcn_ds_bpermute(k << 2, begin);
+            const float* src = item_seeds + (valid ? static_cast<long long>(k) * (kSeedFloats * kWave) + column : 0);
+            // lanes beyond the stream's end: zero seeds (the adjoint is linear in them) at the origin
+            const float px = valid ? src[0 * kWave] : 0.0f, py = valid ? src[1 * kWave] : 0.0f, pz = valid ? src[2 * kWave] : 0.0f;
+            const float res_bar = valid ? src[3 * kWave] : 0.0f;
+            const float glx = valid ? src[4 * kWave] : 0.0f, gly = valid ? src[5 * kWave] : 0.0f, glz = valid ? src[6 * kWave] : 0.0f;
+            const float relx = valid ? src[7 * kWave] : 0.0f, rely = valid ? src[8 * kWave] : 0.0f, relz = valid ? src[9 * kWave] : 0.0f;
+            const unsigned rows = tiles_of_count(min(total - base, kWave));
+            const ResidualAdjoint ra = mlp_adjoint_points_split(s, wt, px, py, pz, res_bar, glx, gly, glz, scratch, lane, rows);
+            r00 += relx * ra.px; r01 += relx * ra.py; r02 += relx * ra.pz;
+            r10 += rely * ra.px; r11 += rely * ra.py; r12 += rely * ra.pz;
+            r20 += relz * ra.px; r21 += relz * ra.py; r22 += relz * ra.pz;
+            at0 -= in.r00 * ra.px + in.r01 * ra.py + in.r02 * ra.pz;
+            at1 -= in.r10 * ra.px + in.r11 * ra.py + in.r12 * ra.pz;
+            at2 -= in.r20 * ra.px + in.r21 * ra.py + in.r22 * ra.pz;
+        }
+        float* row = item_rows + static_cast<size_t>(item) * kItemRowFloats;
+        mlp_adjoint_flush<true>(s, row, lane);
+        const float packed[16] = {at0, at1, at2, r00, r01, r02, r10, r11, r12, r20, r21, r22, 0.0f, 0.0f, 0.0f, 0.0f};
+        const float mine = wave_reduce16_scatter(packed, lane);
+        if (lane < kGradStride) row[kMlpWbarFloats + lane] = mine;
+        if (lane == 0) item_flags[item] = 1;
+    }
+}
+
+#endif
+
 // VSRD_FLAG_MLP_SPLIT_BF16: the operand images of a launch's instances (residual.h: pack_mlp_image), one workgroup per instance, once per
 // vsrd_render_residual_step call (N x 9.4 KB: the front kernels stage an instance's image where they staged its 6.5 KB of weights).
 #ifdef VSRD_SPLIT_BF16      // (csrc/split_front.hip only)

@@ -982,4 +982,135 @@ __device__ __forceinline__ ResidualAdjoint residual_backward(const float* w_in, 
     return mine;
 }
 
+#ifdef VSRD_SPLIT_BF16
+// ---- mlp_adjoint_points on the split-bf16 products (csrc/split_front.hip only) ---------------------------------------------------------------
+// Same algebra and tile layout as mlp_adjoint_points; what changes:
+//   * every product W x / W^T z_bar is mfma_split on an operand of the instance's image (2 bf16 instructions for 4 fp32 ones);
+//   * the weight adjoints  W_bar += z_bar a^T + dz_bar da^T  contract over the tile's 16 points AND the two columns: K = 32 is ONE bf16
+//     instruction per pair of parts -- hi.hi, hi.lo, lo.hi, lo.lo: four instructions where the fp32 form takes eight; the operands are the
+//     transposed tiles (fetch_tile, as before) split in registers;
+//   * the first layer's input adjoint goes FORWARDS:  f_bar_c = z_bar . (W0_c dfeat_c) + dz_bar . (W0_c d(tangent_c)/df)  needs the forward
+//     operand of the image only -- no transposed first-layer image, 3 KB of LDS the kernel does not have;
+//   * the encoder features are recomputed where the first layer's adjoint needs them instead of waiting in six LDS tiles (or 36
+//     registers): with the 9.4 KB image the kernel's LDS is image + four scratch tiles = 14.5 KB, eight workgroups per CU as before.
+struct SplitPair { u32x4 hi, lo; };            // two columns of one transposed tile: {v_hi(4 points), t_hi(4 points)}, {v_lo, t_lo}
+__device__ __forceinline__ SplitPair split_pair(f32x4 v, f32x4 t) {
+    const u32x4 sv = split4(v), st = split4(t);
+    return {u32x4{sv[0], sv[1], st[0], st[1]}, u32x4{sv[2], sv[3], st[2], st[3]}};
+}
+// acc[o][i] += sum over the tile's points p of  xv[o][p] yv[i][p] + xt[o][p] yt[i][p]
+__device__ __forceinline__ f32x4 mfma_outer(const SplitPair& x, const SplitPair& y, f32x4 acc) {
+    acc = mfma_bf16(x.hi, y.hi, acc);
+    acc = mfma_bf16(x.hi, y.lo, acc);
+    acc = mfma_bf16(x.lo, y.hi, acc);
+    return mfma_bf16(x.lo, y.lo, acc);
+}
+
+__device__ __forceinline__ ResidualAdjoint mlp_adjoint_points_split(MlpAdjoint& s, const SplitWeights& wt, float px, float py, float pz, float res_bar,
+                                                                    float gbx, float gby, float gbz, LdsFloats scratch, int lane, unsigned tiles_in) {
+    const int g = lane >> 4;
+    const unsigned tiles = __builtin_amdgcn_readfirstlane(tiles_in);
+    const float fold = (px > 0.0f) ? 1.0f : ((px < 0.0f) ? -1.0f : 0.0f);
+    const float inv = 1.0f / kPositionScale;
+    const float f0 = fabsf(px) * inv, f1 = py * inv, f2 = pz * inv;
+    const float d0 = gbx * fold * inv, d1 = gby * inv, d2 = gbz * inv;      // the direction of the single tangent (mlp_adjoint_points)
+    const float base = (g == 0) ? 1.0f : ((g == 1) ? 4.0f : ((g == 2) ? 16.0f : 64.0f));
+    const float omega[2] = {base * kPi, 2.0f * base * kPi};
+    ResidualAdjoint mine = {0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        if (!((tiles >> q) & 1u)) continue;
+        const float tfold = from_row(fold, q, lane);
+        const float delta[3] = {from_row(d0, q, lane), from_row(d1, q, lane), from_row(d2, q, lane)};
+        const float t_res_bar = from_row(res_bar, q, lane);
+        const float tf[3] = {from_row(f0, q, lane), from_row(f1, q, lane), from_row(f2, q, lane)};
+        // ---- forward, keeping the [LayerNorm -> GELU] state of every layer ----------------------------------------------------
+        TileState st[4];
+        {
+            TileFeatures e;
+            encode_tile(tf[0], tf[1], tf[2], g, e);
+            TileJet1 z;
+            z.v = wt.b0();
+            z.t = splat4(0.0f);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const u32x4 a = wt.operand(kImgFirst + c);
+                z.v = mfma_split(a, split4(e.f[c]), z.v);
+                z.t = mfma_split(a, split4(e.d[c] * splat4(delta[c])), z.t);
+            }
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                tile_state(z, st[l]);
+                const u32x4 a = wt.operand(kImgHidden + l);
+                z.v = mfma_split(a, split4(st[l].a), wt.b(l));
+                z.t = mfma_split(a, split4(st[l].da()), splat4(0.0f));
+            }
+            tile_state(z, st[3]);
+        }
+        const f32x4 w4 = wt.w4();
+        const float out_v = rows_sum(dot4(w4, st[3].a)) + wt.b4();
+        const float out_t = rows_sum(dot4(w4, st[3].da()));
+        const float res = fast_rcp(1.0f + fast_exp(-(out_v - 1.0f)));
+        const float kappa = res * (1.0f - res);
+        const float zb_t = kappa;
+        const float zb_v = (t_res_bar + out_t * (1.0f - 2.0f * res)) * kappa;
+        TileJet1 zb;
+        s.acc_w4 += splat4(zb_v) * st[3].a + splat4(zb_t) * st[3].da();
+        s.acc_b4 += zb_v;
+        gelu_norm_adjoint_tile(st[3], w4 * splat4(zb_v), w4 * splat4(zb_t), zb);
+        // ---- blocks 3..1 ----------------------------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int l = 2; l >= 0; --l) {
+            s.acc_b[l] += zb.v;
+            stage_tile(scratch + 0 * kTileFloats, zb.v, lane);
+            stage_tile(scratch + 1 * kTileFloats, st[l].a, lane);
+            stage_tile(scratch + 2 * kTileFloats, zb.t, lane);
+            stage_tile(scratch + 3 * kTileFloats, st[l].da(), lane);
+            wave_lds_order();
+            {
+                const SplitPair x = split_pair(fetch_tile(scratch + 0 * kTileFloats, lane), fetch_tile(scratch + 2 * kTileFloats, lane));
+                const SplitPair y = split_pair(fetch_tile(scratch + 1 * kTileFloats, lane), fetch_tile(scratch + 3 * kTileFloats, lane));
+                s.acc_w[l] = mfma_outer(x, y, s.acc_w[l]);
+            }
+            wave_lds_order();
+            const u32x4 at = wt.operand(kImgHiddenT + l);
+            const f32x4 a_bar = mfma_split(at, split4(zb.v), splat4(0.0f));
+            const f32x4 da_bar = mfma_split(at, split4(zb.t), splat4(0.0f));
+            TileJet1 zin_bar;
+            gelu_norm_adjoint_tile(st[l], a_bar, da_bar, zin_bar);
+            zb = zin_bar;
+        }
+        // ---- first layer + encoder; zb is the adjoint of z[0] -------------------------------------------------------------------------------
+        s.acc_b0 += zb.v;
+        stage_tile(scratch + 0 * kTileFloats, zb.v, lane);
+        stage_tile(scratch + 1 * kTileFloats, zb.t, lane);
+        TileFeatures e;
+        encode_tile(tf[0], tf[1], tf[2], g, e);                      // (recomputed: see the header comment)
+        wave_lds_order();
+        const SplitPair x = split_pair(fetch_tile(scratch + 0 * kTileFloats, lane), fetch_tile(scratch + 1 * kTileFloats, lane));
+        float f_bar[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            stage_tile(scratch + 2 * kTileFloats, e.f[c], lane);
+            stage_tile(scratch + 3 * kTileFloats, e.d[c] * splat4(delta[c]), lane);
+            wave_lds_order();
+            {
+                const SplitPair y = split_pair(fetch_tile(scratch + 2 * kTileFloats, lane), fetch_tile(scratch + 3 * kTileFloats, lane));
+                s.acc_w0[c] = mfma_outer(x, y, s.acc_w0[c]);
+            }
+            wave_lds_order();
+            // d feat / d f = e.d;  d (delta dfeat) / d f = -delta omega^2 feat
+            const f32x4 second = {-delta[c] * omega[0] * omega[0] * e.f[c][0], -delta[c] * omega[0] * omega[0] * e.f[c][1],
+                                  -delta[c] * omega[1] * omega[1] * e.f[c][2], -delta[c] * omega[1] * omega[1] * e.f[c][3]};
+            const u32x4 a = wt.operand(kImgFirst + c);
+            const f32x4 x1 = mfma_split(a, split4(e.d[c]), splat4(0.0f));
+            const f32x4 x2 = mfma_split(a, split4(second), splat4(0.0f));
+            f_bar[c] = rows_sum(dot4(zb.v, x1) + dot4(zb.t, x2));
+        }
+        if (g == q) { mine.px = f_bar[0] * tfold * inv; mine.py = f_bar[1] * inv; mine.pz = f_bar[2] * inv; }
+    }
+    return mine;
+}
+#endif  // VSRD_SPLIT_BF16
+
 }  // namespace vsrd

@@ -63,4 +63,14 @@ int launch_front(const FrontLaunch& a, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? kOk : kLaunchFailed;
 }
 
+int launch_adjoint(int blocks, const float* instances, const float* images, int num_instances, const float* seeds, const unsigned char* masks,
+                   long long slots_per_instance, long long used_slots, int items_per_instance, int slots_per_item, unsigned* next_item, float* item_rows,
+                   unsigned char* item_flags, hipStream_t stream) {
+    using namespace vsrd_split;
+    const size_t lds = (static_cast<size_t>(kMlpImageWords) + static_cast<size_t>(kMlpSplitScratchTiles) * kTileFloats) * sizeof(float);
+    hipLaunchKernelGGL(residual_mlp_adjoint_split_kernel, dim3(blocks), dim3(kWave), lds, stream, instances, images, num_instances, 0u, seeds, masks,
+                       slots_per_instance, used_slots, items_per_instance, slots_per_item, next_item, item_rows, item_flags);
+    return hipGetLastError() == hipSuccess ? kOk : kLaunchFailed;
+}
+
 }  // namespace vsrd_split_front

@@ -245,11 +245,12 @@ def main(argv=None):
     parser.add_argument("--selftest-fail", default="", help="RANK:FRAMES -- on attempt 0 that rank dies (exit code 23) once it has finished FRAMES frames")
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parser.parse_args(argv)
-    if not 1 <= args.frames_in_flight <= 4:
-        # (round 4: five and more frames on one device end in a memory fault or a segmentation fault inside torch / HIP within seconds --
-        #  construction and eager warm-up steps of that many threads next to a capture; two to four ran every test of the round)
-        raise SystemExit("--frames-in-flight must be 1..4")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))          # bench.synthetic_frame, __graft_entry__.build live at the repo root
+    if not 1 <= args.frames_in_flight <= (4 if args.fresh_loops else 8):
+        # (round 4, a new loop per frame: five and more frames on one device ended in a memory fault or a segmentation fault inside torch / HIP
+        #  within seconds -- construction and eager warm-up steps of that many threads next to a capture.  Frame slots capture nothing once
+        #  the workers run; eight is what was tried.)
+        raise SystemExit("--frames-in-flight must be 1..8 (1..4 with --fresh-loops)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))          # __graft_entry__.build lives at the repo root
     if root not in sys.path:
         sys.path.insert(0, root)
     if "RANK" not in os.environ and (args.gpus > 1 or args.max_restarts > 0):
