@@ -51,6 +51,9 @@ def parse_args(argv=None):
     parser.add_argument("--samples", type=int, default=64)
     parser.add_argument("--schedule", choices=sorted(SCHEDULES), default="mid")
     parser.add_argument("--residual", action="store_true", help="BASELINE config 3: per-instance residual MLP + eikonal loss")
+    parser.add_argument("--mlp-split-bf16", action="store_true",
+                        help="with --residual: VSRD_FLAG_MLP_SPLIT_BF16 -- the per-instance MLP's products on v_mfma_f32_16x16x32_bf16 with both operands "
+                             "split into two bfloat16 parts instead of the exact-fp32 matrix instruction (csrc/residual.h)")
     parser.add_argument("--two-launch", action="store_true",
                         help="render forward, torch loss, render backward as separate launches instead of the fused step kernel")
     parser.add_argument("--no-culling", action="store_true", help="VSRD_FLAG_NO_CULLING: every instance at every sample (worst case)")
@@ -85,7 +88,8 @@ def workload_key(args):
     """Identifies the per-launch work: a committed rocprof summary is only quoted for the workload it was measured on."""
     return (f"V{args.views}_H{args.height}_W{args.width}_N{args.instances}_S{args.samples}_{args.schedule}_"
             f"{'residual' if args.residual else 'box'}_{'twolaunch' if args.two_launch else 'fused'}"
-            f"{'_nocull' if args.no_culling else ''}{'_noskip' if args.no_skip_misses else ''}{'_waveperray' if args.wave_per_ray else ''}")
+            f"{'_nocull' if args.no_culling else ''}{'_noskip' if args.no_skip_misses else ''}{'_waveperray' if args.wave_per_ray else ''}"
+            f"{'_splitbf16' if args.residual and args.mlp_split_bf16 else ''}")
 
 
 def describe_workload(args):
@@ -104,6 +108,8 @@ def describe_workload(args):
         name = "custom sizes (not a BASELINE config)"
     metric = BASELINE_METRIC if c2 else f"rendered rays/sec (fwd+bwd) per GPU, {H}×{W}, {N} instances"
     field = "box + per-instance residual-MLP field, eikonal loss" if args.residual else "box-only field"
+    if args.residual and args.mlp_split_bf16:
+        field += " (MLP products on split-bf16 MFMA: VSRD_FLAG_MLP_SPLIT_BF16)"
     text = (f"{name}: dense frame, {V} views x {H}x{W} = {V * H * W} rays/step/GPU, {N} instances, {S} samples/ray "
             f"(pass 1: {S - 1}, pass 2: {2 * S - 1} points), {field}")
     return metric, text
@@ -349,6 +355,7 @@ def run_rank(args):
         from vsrd_amd import models, rendering, profiling
         from vsrd_amd.rendering import renderers
         renderers.CULLING = not args.no_culling
+        renderers.MLP_SPLIT_BF16 = renderers.MLP_SPLIT_BF16 or (args.residual and args.mlp_split_bf16)
         renderers.STEP_WAVE_PER_RAY = renderers.STEP_WAVE_PER_RAY or args.wave_per_ray
         # one frame per rank, and every rank a replica of the same synthetic frame (the scaling curve then isolates the
         # launcher; frames of a real shard differ in cost, which is load imbalance, not scaling); the Philox streams differ by rank
@@ -571,7 +578,7 @@ def extra_regimes():
         return small
     dense = ["value", "unit", "ms_per_step", "steps", "warmup", "n_gpus"]
     native = ["phase", "graph", "steps_per_s", "ms_per_step", "seconds_per_3000_step_frame", "seconds_per_frame", "warmup_phase_seconds",
-              "residual_phase_seconds", "steps", "rays_per_step", "samples_per_ray", "views", "instances", "final_loss"]
+              "residual_phase_seconds", "steps", "rays_per_step", "samples_per_ray", "views", "instances", "final_loss", "mlp_products"]
     frames = ["value", "unit", "n_gpus", "frames", "seconds", "frames_per_s_per_gpu", "per_rank_seconds", "seconds_per_frame_per_gpu", "capture_seconds_per_frame",
               "restarts", "max_restarts", "mean_final_loss"]
     base = ["bench.py", "--no-cpu-baseline", "--no-extra-regimes"]
@@ -579,10 +586,12 @@ def extra_regimes():
     return {
         "note": "measured after the headline's timed region, one child process each; config 2 above stays the metric's workload",
         "config3_full_size": child(base + ["--residual", "--steps", "3", "--warmup", "1"], dense),
+        "config3_full_size_split_bf16": child(base + ["--residual", "--mlp-split-bf16", "--steps", "3", "--warmup", "1"], dense),
         "config5_one_gpu": child(base + ["--views", "17", "--height", "752", "--width", "2816", "--instances", "64", "--samples", "128", "--steps", "2", "--warmup", "1"], dense),
         "native_graph_box_only": child([tool, "--graph", "--steps", "300", "--json"], native),
         "native_graph_residual": child([tool, "--graph", "--residual", "--steps", "300", "--json"], native),
         "native_graph_whole_frame": child([tool, "--graph", "--whole-frame", "--json"], native),
+        "native_graph_whole_frame_fp32_mlp": child([tool, "--graph", "--whole-frame", "--fp32-mlp", "--json"], native),
         # frames/s, the unit the reference shards (README.md:128): twelve whole frames through the frame launcher with its default frames in
         # flight, checkpoints included (python bench.py --native = python -m vsrd_amd.launcher; on a node: --gpus 8)
         "native_frames_per_s": child(["bench.py", "--native", "--gpus", "1", "--frames", "12"], frames, timeout=1200),

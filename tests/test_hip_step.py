@@ -175,7 +175,7 @@ def test_residual_phase_step_matches_oracle(dev, S, mlp_products):
     soft = rendering.render_hierarchical(block, origins, dirs.reshape(-1, 3), (0.0, 100.0), S, 0.1, 1.0, seed=5)["labels"].clamp(0, 1)
     soft = (soft.reshape(V, H, W, N) * visible.to(dev)[:, None, None, :]).contiguous()
     inputs = optimization.FrameInputs((H, W), K.to(dev), E.to(dev), soft, gt_boxes.to(dev), visible.to(dev))
-    config = optimization.OptimizationConfig(num_samples=S, num_rays=R, warmup_steps=0, num_steps=3000)
+    config = optimization.OptimizationConfig(num_samples=S, num_rays=R, warmup_steps=0, num_steps=3000, mlp_split_bf16=(mlp_products == "split_bf16"))
     torch.manual_seed(0)
     device_loop = optimization.FrameOptimizer(inputs, config, dev)
     device_loop.step_index = 1500                                     # mid schedule: T = std = 0.55

@@ -27,6 +27,8 @@ def main():
     parser.add_argument("--concurrent", type=int, default=1, help="frames optimised at the same time (one host thread and stream each)")
     parser.add_argument("--residual", action="store_true", help="post-warm-up phase: residual MLP + eikonal loss (steps 1000-3000)")
     parser.add_argument("--json", action="store_true", help="also print one JSON line (tools/regimes.py)")
+    parser.add_argument("--fp32-mlp", action="store_true", help="OptimizationConfig(mlp_split_bf16=False): the residual MLP on the exact-fp32 matrix "
+                        "instruction instead of the split-bf16 products that are the loop's default since round 5")
     parser.add_argument("--steps-per-graph", type=int, default=4, help="graph mode: consecutive steps replayed per hipGraph launch (FrameOptimizer.run); 1 = one launch per step")
     parser.add_argument("--whole-frame", action="store_true", help="time one whole frame as the reference runs it: steps 0..2999 with the real schedules "
                         "(1000 box-only warm-up steps, then 2000 residual steps), set-up and graph captures included")
@@ -51,7 +53,7 @@ def main():
     inputs = optimization.FrameInputs((H, W), K.to(dev), E.to(dev), soft, gt_boxes, torch.ones(V, N, dtype=torch.bool, device=dev))
     if args.whole_frame:
         def frame(slot):
-            loop = optimization.FrameOptimizer(inputs, optimization.OptimizationConfig(seed=slot, num_rays=args.rays), dev, graph=args.graph)
+            loop = optimization.FrameOptimizer(inputs, optimization.OptimizationConfig(seed=slot, num_rays=args.rays, mlp_split_bf16=not args.fp32_mlp), dev, graph=args.graph)
             marks = []
             loop.run(loop.config.warmup_steps, args.steps_per_graph)
             torch.cuda.synchronize(); marks.append(time.perf_counter())
@@ -72,7 +74,8 @@ def main():
             import json
             print(json.dumps(dict(mode="native", phase="whole frame", graph=bool(args.graph), seconds_per_frame=total, warmup_phase_seconds=warm,
                                   residual_phase_seconds=total - warm, steps=cfg.num_steps, rays_per_step=args.rays, samples_per_ray=cfg.num_samples,
-                                  views=V, instances=N, final_loss=loss, steps_per_graph=args.steps_per_graph if args.graph else None)))
+                                  views=V, instances=N, final_loss=loss, steps_per_graph=args.steps_per_graph if args.graph else None,
+                                  mlp_products="exact fp32 MFMA" if args.fp32_mlp else "split bf16 MFMA")))
         return
     import threading
     # Frames are independent (README.md:128: no exchange): several can be optimised at once, each on its own stream with its own
@@ -81,7 +84,7 @@ def main():
     for slot in range(args.concurrent):
         stream = torch.cuda.Stream(device=dev)
         with torch.cuda.stream(stream):
-            loop = optimization.FrameOptimizer(inputs, optimization.OptimizationConfig(seed=slot, num_rays=args.rays), dev, graph=args.graph)
+            loop = optimization.FrameOptimizer(inputs, optimization.OptimizationConfig(seed=slot, num_rays=args.rays, mlp_split_bf16=not args.fp32_mlp), dev, graph=args.graph)
             if args.residual:
                 loop.step_index = loop.config.warmup_steps
                 loop.step_tensor.fill_(loop.step_index)
@@ -119,7 +122,8 @@ def main():
         print(json.dumps(dict(mode="native", phase="residual" if args.residual else "box-only", graph=bool(args.graph), frames_at_once=args.concurrent,
                               steps_per_s=total / dt, ms_per_step=dt / total * 1e3, seconds_per_3000_step_frame=3000 * dt / total,
                               rays_per_step=args.rays, samples_per_ray=100, views=V, instances=N, final_loss=results[0],
-                              steps_per_graph=args.steps_per_graph if args.graph else None)))
+                              steps_per_graph=args.steps_per_graph if args.graph else None,
+                              mlp_products="exact fp32 MFMA" if args.fp32_mlp else "split bf16 MFMA")))
 
 
 if __name__ == "__main__":

@@ -33,7 +33,7 @@ def run(cmd, timeout):
 
 def main():
     parser = argparse.ArgumentParser()
-    parser.add_argument("--tag", default="r04")
+    parser.add_argument("--tag", default="r05")
     parser.add_argument("--quick", action="store_true", help="skip the two multi-second-per-step full-size runs (C3, C5)")
     args = parser.parse_args()
     out_dir = os.path.join(ROOT, "gpurun_out", args.tag)
@@ -51,6 +51,7 @@ def main():
              ("C3-shaped frame (1 view 188x704, residual)", ["--steps", "5", "--warmup", "1", "--residual", "--views", "1", "--height", "188", "--width", "704"])]
     if not args.quick:
         dense += [("C3 full size (residual)", ["--steps", "2", "--warmup", "1", "--residual"]),
+                  ("C3 full size (residual), MLP on split-bf16 MFMA", ["--steps", "2", "--warmup", "1", "--residual", "--mlp-split-bf16"]),
                   ("C3 full size, start", ["--steps", "2", "--warmup", "1", "--residual", "--schedule", "start"]),
                   ("C3 full size, end", ["--steps", "2", "--warmup", "1", "--residual", "--schedule", "end"]),
                   ("C5 on one GPU", ["--steps", "2", "--warmup", "1", "--views", "17", "--height", "752", "--width", "2816", "--instances", "64", "--samples", "128"])]
@@ -61,6 +62,8 @@ def main():
         table["dense"].append(record)
         print(f"{name}: {record.get('value', 0) / 1e6:.2f} Mrays/s, {record.get('ms_per_step', 0):.1f} ms/step {record.get('error', '')}", flush=True)
     native = [("box-only, eager", []), ("box-only, hipGraph", ["--graph"]), ("residual, eager", ["--residual"]), ("residual, hipGraph", ["--residual", "--graph"]),
+              ("residual, hipGraph, exact-fp32 MLP", ["--residual", "--graph", "--fp32-mlp"]),
+              ("whole frame (3000 steps, real schedules), hipGraph, exact-fp32 MLP", ["--graph", "--whole-frame", "--fp32-mlp"]),
               ("box-only, hipGraph, 2 frames at once", ["--graph", "--concurrent", "2"]), ("residual, hipGraph, 2 frames at once", ["--residual", "--graph", "--concurrent", "2"]),
               ("whole frame (3000 steps, real schedules), hipGraph", ["--graph", "--whole-frame"])]
     for name, flags in native:

@@ -184,6 +184,10 @@ class OptimizationConfig:
     loss_weights: dict = dataclass_field(default_factory=lambda: dict(losses.LOSS_WEIGHTS))
     seed: int = 0
     skip_exact_misses: bool = True
+    # the residual phase's per-instance MLP on split-bf16 matrix products (VSRD_FLAG_MLP_SPLIT_BF16; csrc/residual.h): the same tests within the
+    # same tolerances as the exact-fp32 products (labels ~1e-6, gradients ~4e-4 of the largest entry against the reference's goldens), the
+    # residual step 8 % faster.  False: the exact-fp32 matrix instruction.
+    mlp_split_bf16: bool = True
 
 
 def adam_state_tensors(optimizer, parameter, group):
@@ -493,7 +497,9 @@ class FrameOptimizer:
         weights = cfg.loss_weights
         eikonal_ratio = weights["eikonal_loss"] / weights["silhouette_loss"] if residual else 0.0
         from .rendering import renderers
-        flags = renderers._base_flags() | _lib.FLAG_YAW_GRADIENTS      # (the prologue decodes rotation_matrix_y; the epilogue reads r00, r02, r20, r22 only)
+        flags = (renderers._base_flags() & ~_lib.FLAG_MLP_SPLIT_BF16) | _lib.FLAG_YAW_GRADIENTS      # (the prologue decodes rotation_matrix_y; the epilogue reads r00, r02, r20, r22 only)
+        if residual and cfg.mlp_split_bf16:
+            flags |= _lib.FLAG_MLP_SPLIT_BF16
         mlp_weights = centred = None
         if fused_net:
             centred = b["mlp_centred"]
@@ -716,7 +722,8 @@ class FrameOptimizer:
             rendered, parts = rendering.silhouette_step(block, origins, directions, self.flat_masks[ray_indices], cfg.distance_range,
                                                         cfg.num_samples, std, ratio, pd_indices=pd_idx, gt_indices=gt_idx,
                                                         u_coarse=u_coarse, u_fine=u_fine, seed=cfg.seed, stream_offset=step if offset is None else offset,
-                                                        skip_exact_misses=False, schedule=schedule, eikonal_ratio=eikonal_ratio, return_terms=True)
+                                                        skip_exact_misses=False, schedule=schedule, eikonal_ratio=eikonal_ratio, return_terms=True,
+                                                        mlp_split_bf16=cfg.mlp_split_bf16)
             silhouette, eikonal = parts[0], parts[1]
         else:           # box-only phase: render + silhouette BCE + adjoint in one launch
             rendered = rendering.silhouette_step(block, origins, directions, self.flat_masks[ray_indices], cfg.distance_range,

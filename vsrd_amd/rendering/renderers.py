@@ -658,7 +658,7 @@ class _ResidualStep(torch.autograd.Function):
 def silhouette_step(distance_field, ray_positions, ray_directions, targets, distance_range, num_samples, sdf_std_deviation,
                     cosine_ratio=1.0, epsilon=1.0e-6, pd_indices=None, gt_indices=None, u_coarse=None, u_fine=None, seed=0,
                     stream_offset=0, return_labels=False, skip_exact_misses=True, schedule=None, eikonal_ratio=0.0, return_terms=False,
-                    return_samples=False):
+                    return_samples=False, mlp_split_bf16=None):
     """Fused fast path of scripts/main.py:629-687: the two-pass render AND
     ``mean(BCE(clamp(labels[..., pd_indices], 1e-6, 1 - 1e-6), targets[..., gt_indices]))`` in one launch; for residual fields
     (box + per-instance MLP) also ``eikonal_ratio * mean((|sampled_gradients| - 1)^2)`` (main.py:679-687), i.e. the returned loss is
@@ -690,6 +690,8 @@ def silhouette_step(distance_field, ray_positions, ray_directions, targets, dist
         u_coarse = u_coarse.reshape(-1, num_samples).to(torch.float32).contiguous()
         u_fine = u_fine.reshape(-1, num_samples).to(torch.float32).contiguous()
     flags = (_lib.FLAG_SKIP_EXACT_MISSES if skip_exact_misses else 0) | _base_flags() | (_lib.FLAG_YAW_GRADIENTS if block.yaw_gradients else 0)
+    if mlp_split_bf16 is not None:        # (residual fields: the MLP's products on split-bf16 MFMA or on the exact-fp32 one; None: the module switch)
+        flags = (flags | _lib.FLAG_MLP_SPLIT_BF16) if mlp_split_bf16 else (flags & ~_lib.FLAG_MLP_SPLIT_BF16)
     scalars = (float(sdf_std_deviation), float(cosine_ratio), float(epsilon), float(distance_range[0]), float(distance_range[1]), int(num_samples), schedule)
     if return_samples and residual:
         raise NotImplementedError("return_samples: box-only fields (vsrd_render_silhouette_step) only")
