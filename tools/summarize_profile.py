@@ -91,7 +91,7 @@ def counters_json(src, dst):
         sums = defaultdict(lambda: defaultdict(float))
         with open(path) as f:
             for r in csv.DictReader(f):
-                if "vsrd::" not in r["Kernel_Name"]:
+                if "vsrd::" not in r["Kernel_Name"] and "vsrd_split::" not in r["Kernel_Name"]:
                     continue
                 name, counter, value = short(r["Kernel_Name"]), r["Counter_Name"], float(r["Counter_Value"])
                 if counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -126,7 +126,7 @@ def traffic(src, dst):
         per = defaultdict(list)
         with open(path) as f:
             for r in csv.DictReader(f):
-                if r["Counter_Name"] == key and "vsrd::" in r["Kernel_Name"]:
+                if r["Counter_Name"] == key and ("vsrd::" in r["Kernel_Name"] or "vsrd_split::" in r["Kernel_Name"]):
                     per[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
         for name, values in per.items():
             out[name][key + "_bytes"] = values[-1] * 1024.0          # rocprofv3 reports KiB; last dispatch = a timed step
