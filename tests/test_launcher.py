@@ -150,7 +150,7 @@ def test_native_frames_entry_point_two_ranks_on_one_gpu(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     command = [sys.executable, bench, "--native", "--gpus", "2", "--ranks-share-gpu", "--frames", "5", "--views", "3", "--instances", "4", "--height", "128",
                "--width", "128", "--rays", "256", "--samples", "32", "--num-steps", "40", "--warmup-steps", "12", "--frames-in-flight", "2",
-               "--out", str(tmp_path)]
+               "--procs-per-gpu", "1", "--out", str(tmp_path)]
     out = subprocess.run(command, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -170,6 +170,33 @@ def test_native_frames_entry_point_two_ranks_on_one_gpu(tmp_path):
     assert second["frames"] == 0 and second["frames_skipped_as_done"] == 5
 
 
+@pytest.mark.gpu
+def test_native_frames_with_a_helper_process_on_the_gpu(tmp_path):
+    """`--procs-per-gpu 2` on the GPU: the rank and the helper it started before it touched the device optimise every second frame of the
+    shard each (one frame in flight per process), the line counts both processes' frames and names the split, every frame has its
+    checkpoint, and the final losses are those of the same frames optimised by ONE process (the trajectories do not depend on who runs them)."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    small = ["--frames", "4", "--views", "3", "--instances", "4", "--height", "128", "--width", "128", "--rays", "256", "--samples", "32", "--num-steps", "40",
+             "--warmup-steps", "12", "--frames-in-flight", "1"]
+    lines = {}
+    for procs in (2, 1):
+        out = subprocess.run([sys.executable, bench, "--native", "--gpus", "1", "--procs-per-gpu", str(procs), *small, "--out", str(tmp_path / str(procs))],
+                             capture_output=True, text=True, timeout=900, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines[procs] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    line = lines[2]
+    assert line["n_gpus"] == 1 and line["procs_per_gpu"] == 2 and line["frames"] == 4 and line["per_process_frames"] == [[2, 2]] and line["restarts"] == 0
+    assert len(line["per_process_seconds"][0]) == 2 and line["seconds"] >= max(line["per_process_seconds"][0]) - 1e-3
+    assert sorted(os.listdir(tmp_path / "2")) == [f"frame_{k:06d}" for k in range(4)]
+    assert set(line["final_loss_per_frame"]) == {"0", "1", "2", "3"}
+    for frame, loss in line["final_loss_per_frame"].items():
+        assert math.isfinite(loss) and abs(loss - lines[1]["final_loss_per_frame"][frame]) <= 1e-3 * max(abs(loss), 1.0), (frame, loss, lines[1]["final_loss_per_frame"][frame])
+
+
 def test_supervisor_restarts_a_dead_rank_and_every_frame_is_done_once(tmp_path):
     """VERDICT r04 item 4 (README.md:146-155: the reference leans on `torchrun --max_restarts`; main.py:134-136: skip-if-done): a gloo rank
     is killed mid-job -- os._exit from inside its second frame's slot, no clean-up, its peer left in the final barrier.  The supervisor
@@ -181,7 +208,7 @@ def test_supervisor_restarts_a_dead_rank_and_every_frame_is_done_once(tmp_path):
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
-    command = [sys.executable, "-m", "vsrd_amd.launcher", "--selftest", "--gpus", "2", "--frames", "9", "--selftest-seconds", "0.2",
+    command = [sys.executable, "-m", "vsrd_amd.launcher", "--selftest", "--gpus", "2", "--procs-per-gpu", "1", "--frames", "9", "--selftest-seconds", "0.2",
                "--selftest-fail", "1:1", "--max-restarts", "2", "--out", str(tmp_path)]
     out = subprocess.run(command, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -198,10 +225,47 @@ def test_supervisor_restarts_a_dead_rank_and_every_frame_is_done_once(tmp_path):
     completed = [tuple(int(v) for v in row.split()) for row in open(os.path.join(tmp_path, "completed.log")).read().splitlines()]
     from vsrd_amd import launcher
     first_of_dying_rank = launcher.shard_frames(list(range(9)), 1, 2, seed=0)[0]
-    assert [row for row in completed if row[0] == first_of_dying_rank] == [(first_of_dying_rank, 0, 1)]      # done before the rank died: not repeated
+    assert [row for row in completed if row[0] == first_of_dying_rank] == [(first_of_dying_rank, 0, 1, 0)]   # done before the rank died: not repeated
     assert {row[0] for row in completed} == set(range(9))
     assert all(sum(1 for row in completed if row[0] == k) <= 2 for k in range(9))                      # (a frame in flight when the attempt ended runs again)
     assert any(p["attempt"] == 1 for p in payloads) and payloads[first_of_dying_rank]["attempt"] == 0
     # no restarts allowed: the job fails with the dead rank's code instead of hanging in the survivor's barrier
     failing = subprocess.run([*command[:-1], str(tmp_path / "second"), "--max-restarts", "0"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert failing.returncode == 23 and "no restarts left" in failing.stderr
+
+
+def test_helper_processes_share_a_ranks_frames_and_a_dead_helper_restarts_the_job(tmp_path):
+    """`--procs-per-gpu 2` (round 5: two processes per GPU overlap their kernels better than the streams of one; the collective level stays
+    one rank per GPU): every rank starts one helper before it does anything else and hands it every second frame of its shard over the
+    helper's stdin; the report counts both.  Then a HELPER of rank 1 is killed after its first frame: its rank goes down with it at once
+    (launcher._watch_helpers), the supervisor restarts both ranks -- and their helpers -- as fresh processes, and every frame is there once."""
+    import json
+    import subprocess
+    import sys
+    from vsrd_amd import launcher
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    base = [sys.executable, "-m", "vsrd_amd.launcher", "--selftest", "--gpus", "2", "--procs-per-gpu", "2", "--frames", "10", "--selftest-seconds", "0.2"]
+    out = subprocess.run([*base, "--out", str(tmp_path / "plain")], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    assert line["frames"] == 10 and line["restarts"] == 0 and line["procs_per_gpu"] == 2 and line["n_gpus"] == 2
+    shards = [launcher.shard_frames(list(range(10)), r, 2, seed=0) for r in range(2)]
+    assert line["per_process_frames"] == [[len(shard[0::2]), len(shard[1::2])] for shard in shards]
+    completed = [tuple(int(v) for v in row.split()) for row in open(tmp_path / "plain" / "completed.log").read().splitlines()]
+    assert sorted(row[0] for row in completed) == list(range(10))
+    for frame, attempt, rank, process in completed:                     # frame j of a rank's shard went to process j mod 2 of that rank
+        assert attempt == 0 and shards[rank].index(frame) % 2 == process
+    # a helper dies
+    out = subprocess.run([*base, "--selftest-fail", "1:1:1", "--max-restarts", "2", "--out", str(tmp_path / "killed")], capture_output=True, text=True, timeout=300,
+                         env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "helper 1 of rank 1 exited with code 23" in out.stderr and "starting the ranks again" in out.stderr
+    line = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    assert line["restarts"] == 1 and line["frames"] + line["frames_skipped_as_done"] == 10 and line["frames_skipped_as_done"] >= 1
+    assert sorted(f for f in os.listdir(tmp_path / "killed") if f.startswith("frame_")) == [f"frame_{k:06d}" for k in range(10)]
+    assert all(len(os.listdir(tmp_path / "killed" / f"frame_{k:06d}")) == 1 for k in range(10))
+    completed = [tuple(int(v) for v in row.split()) for row in open(tmp_path / "killed" / "completed.log").read().splitlines()]
+    first_of_dying_helper = shards[1][1]
+    assert [row for row in completed if row[0] == first_of_dying_helper] == [(first_of_dying_helper, 0, 1, 1)]       # finished before it died: not repeated
+    assert {row[0] for row in completed} == set(range(10))

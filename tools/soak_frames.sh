@@ -21,7 +21,8 @@ for run in $(seq 1 "$RUNS"); do
 import json, sys
 d = json.loads(sys.argv[2])
 losses = d.get("final_loss_per_frame", {})
-print(f"run {sys.argv[1]}: {d['frames']} frames, {d['value']:.3f} frames/s, {d['seconds']:.2f} s, restarts {d['restarts']}, capture s/frame {d['capture_seconds_per_frame']}, "
+print(f"run {sys.argv[1]}: {d['frames']} frames, {d['value']:.3f} frames/s, {d['seconds']:.2f} s, restarts {d['restarts']}, processes {d.get('procs_per_gpu')} x {d.get('frames_in_flight_per_process')} in flight, "
+      f"capture s/frame {d['capture_seconds_per_frame']}, "
       f"worst final loss {max(losses.values()) if losses else None:.4f}")
 PY
     fi

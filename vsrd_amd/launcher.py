@@ -202,6 +202,203 @@ def _supervise(argv, args):
     return abs(failed[1]) or 1
 
 
+_PROTOCOL = "@vsrd "          # leader <-> helper lines on the helper's stdin / stdout (anything else a helper prints is passed over)
+
+
+class _RenderWork:
+    """What ONE PROCESS does with its share of a rank's frames on the rank's GPU: inputs and frame slots before the clock, then the frames."""
+
+    def __init__(self, args, manifest, device):
+        self.args, self.manifest, self.device = args, manifest, device
+        self.config = dict(num_steps=args.num_steps, warmup_steps=args.warmup_steps, num_rays=args.rays, num_samples=args.samples)
+
+    def path_of(self, frame):
+        return os.path.join(self.manifest["out"], f"frame_{int(frame):06d}", f"step_{self.args.num_steps - 1}.pt")
+
+    def prepare(self, frames):
+        """Inputs are resident before the clock starts (what main.py:106-316 prepares per frame is the dataset's work, not the loop's), and
+        so are the frame slots (round 5): `--frames-in-flight` persistent loops, each constructed and with ALL its hipGraphs captured here,
+        one after the other, before any worker thread exists (FrameOptimizer.capture_all).  A frame is then a reset (copies and fills), graph
+        replays and a checkpoint: no construction, no eager steps, no capture next to another frame's work -- the collisions the capture gate
+        of round 4 was built around have nothing left to collide with.  (--fresh-loops: the round-4 form, for A/B.)"""
+        import queue
+        import time
+        from . import optimization
+        args = self.args
+        self.frames = list(frames)
+        pending = [frame for frame in self.frames if not os.path.exists(self.path_of(frame))]
+        self.inputs = {frame: synthetic_frame_inputs(self.device, frame, args.views, args.instances, args.height, args.width) for frame in pending}
+        self.slots = queue.Queue()
+        self.setup_seconds, self.graphs_per_slot = 0.0, 0
+        if pending and not args.fresh_loops:
+            t_setup = time.perf_counter()
+            for _ in range(min(args.frames_in_flight, len(pending))):
+                loop = optimization.FrameOptimizer(self.inputs[pending[0]], optimization.OptimizationConfig(seed=int(self.manifest["seed"]), **self.config),
+                                                   self.device, graph=True, persistent=True)
+                self.graphs_per_slot = loop.capture_all()
+                self.slots.put(loop)
+            torch.cuda.synchronize()
+            self.setup_seconds = time.perf_counter() - t_setup
+        self.captures_before = optimization.exclusive_device_access().capture_seconds
+
+    def run(self):
+        from . import formats, optimization
+        args, losses = self.args, {}
+
+        def optimise(frame):
+            slot = None if args.fresh_loops else self.slots.get()
+            try:
+                loop = slot
+                if loop is None or not loop.reset(self.inputs[frame]):
+                    # (--fresh-loops, or a frame whose importance weights do not suit the table sampler the slot's graphs draw from)
+                    loop = optimization.FrameOptimizer(self.inputs[frame], optimization.OptimizationConfig(seed=int(self.manifest["seed"]), **self.config),
+                                                       self.device, graph=True)
+                record = loop.run(args.num_steps)
+                with optimization.exclusive_device_access():       # (host synchronisations and copies: refused now and then while another frame's thread captures)
+                    torch.cuda.current_stream().synchronize()
+                    losses[frame] = float(record["loss"])
+                    payload = formats.checkpoint_payload(loop, step=args.num_steps - 1, metrics={}, host=True)
+                if loop is not slot:
+                    loop.close()
+                return payload
+            finally:
+                if slot is not None:
+                    self.slots.put(slot)
+
+        done = run_frames(self.frames, optimise, self.path_of, frames_in_flight=args.frames_in_flight)
+        torch.cuda.synchronize()
+        return dict(frames=len(done), skipped=len(self.frames) - len(done),
+                    gate_capture_seconds=optimization.exclusive_device_access().capture_seconds - self.captures_before,
+                    slot_setup_seconds=self.setup_seconds, graphs_per_slot=self.graphs_per_slot, final_losses={int(f): losses[f] for f in sorted(losses)})
+
+
+class _SleepWork:
+    """`--selftest`: a frame is a sleep and a small checkpoint.  `--selftest-fail RANK:FRAMES[:PROCESS]` makes that process of that rank die
+    (exit code 23, no clean-up, no goodbye to the process group) on attempt 0 once it has finished FRAMES frames."""
+
+    def __init__(self, args, manifest, rank, process):
+        self.args, self.manifest, self.rank, self.process = args, manifest, rank, process
+        spec = [int(v) for v in args.selftest_fail.split(":")] if args.selftest_fail else [-1, 0]
+        self.fail_rank, self.fail_after, self.fail_process = spec[0], spec[1], (spec[2] if len(spec) > 2 else 0)
+
+    def path_of(self, frame):
+        return os.path.join(self.manifest["out"], f"frame_{int(frame):06d}", "step_final.pt")
+
+    def prepare(self, frames):
+        os.makedirs(self.manifest["out"], exist_ok=True)
+        self.frames = list(frames)
+
+    def run(self):
+        import time
+        args, finished = self.args, []
+
+        def optimise(frame):
+            if args.attempt == 0 and self.rank == self.fail_rank and self.process == self.fail_process and len(finished) >= self.fail_after:
+                os._exit(23)
+            time.sleep(args.selftest_seconds)
+            finished.append(frame)
+            with open(os.path.join(self.manifest["out"], "completed.log"), "a") as log:      # (O_APPEND: one short line per frame, whole)
+                log.write(f"{int(frame)} {args.attempt} {self.rank} {self.process}\n")
+            return dict(frame=int(frame), attempt=args.attempt, rank=self.rank)
+
+        done = run_frames(self.frames, optimise, self.path_of, frames_in_flight=1)
+        return dict(frames=len(done), skipped=len(self.frames) - len(done), gate_capture_seconds=0.0, slot_setup_seconds=0.0, graphs_per_slot=0, final_losses={})
+
+
+def _start_helpers(argv, args):
+    """`--procs-per-gpu K`: the K - 1 helper processes of this rank, started BEFORE this process touches its GPU (fresh children, never a
+    re-execution).  A helper is no member of the process group: it takes its frames from this rank over its stdin and hands its report back
+    over its stdout, so the collective level stays one rank per GPU on RCCL whatever K is."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                                                            "TORCHELASTIC_RUN_ID")}
+    env["VSRD_LEADER_RANK"] = os.environ.get("RANK", "0")
+    return [subprocess.Popen([sys.executable, "-m", "vsrd_amd.launcher", *argv, "--helper", str(j)], env=env, cwd=root, text=True, bufsize=1,
+                             stdin=subprocess.PIPE, stdout=subprocess.PIPE) for j in range(1, args.procs_per_gpu)]
+
+
+def _watch_helpers(helpers):
+    """A helper that dies takes its rank with it at once (exit code of the helper), instead of when the rank gets round to reading its
+    report: the supervisor -- or torchrun -- then restarts the ranks, and the finished frames are skipped."""
+    import sys
+    import threading
+    import time
+
+    def watch():
+        while True:
+            for j, helper in enumerate(helpers, start=1):
+                code = helper.poll()
+                if code not in (None, 0):
+                    print(f"[vsrd_amd.launcher] helper {j} of rank {os.environ.get('RANK', '0')} exited with code {code}", file=sys.stderr, flush=True)
+                    for other in helpers:
+                        if other.poll() is None:
+                            other.kill()
+                    os._exit(abs(code) or 1)
+            if all(helper.poll() is not None for helper in helpers):
+                return
+            time.sleep(0.1)
+
+    threading.Thread(target=watch, daemon=True).start()
+
+
+def _tell(stream, payload):
+    stream.write(_PROTOCOL + payload + "\n")
+    stream.flush()
+
+
+def _hear(stream, who):
+    """The next protocol line of `stream`; a closed stream (the other side died) ends this process non-zero, which is what the supervisor,
+    or torchrun, restarts the ranks for."""
+    while True:
+        text = stream.readline()
+        if text == "":
+            raise SystemExit(f"vsrd_amd.launcher: {who} went away")
+        if text.startswith(_PROTOCOL):
+            return text[len(_PROTOCOL):].strip()
+
+
+def _make_work(args, manifest, rank, process):
+    if args.selftest:
+        return _SleepWork(args, manifest, rank, process)
+    if not torch.cuda.is_available():
+        raise SystemExit("vsrd_amd.launcher optimises frames on HIP devices: no GPU visible, and vsrd_amd has no CPU fallback")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
+    torch.cuda.set_device(device)
+    return _RenderWork(args, manifest, device)
+
+
+def _helper_main(args):
+    """Process `--helper J` of a rank (see _start_helpers): frames in, "ready", "go", report out."""
+    import json
+    import sys
+    import time
+    rank = int(os.environ.get("VSRD_LEADER_RANK", "0"))
+    # a helper never outlives its rank: the kernel sends it SIGKILL when the rank's process ends, however that happens (a supervisor's
+    # SIGTERM runs no clean-up code in the rank), so no orphan keeps optimising frames next to the restarted ranks
+    try:
+        import ctypes
+        import signal
+        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)          # PR_SET_PDEATHSIG
+        if os.getppid() == 1:
+            return 1
+    except (OSError, AttributeError):
+        pass
+    spec = json.loads(_hear(sys.stdin, f"rank {rank}"))
+    work = _make_work(args, spec["manifest"], rank, args.helper)
+    work.prepare(spec["frames"])
+    _tell(sys.stdout, "ready")
+    if _hear(sys.stdin, f"rank {rank}") != "go":
+        return 1
+    t0 = time.perf_counter()
+    report = work.run()
+    report["seconds"] = time.perf_counter() - t0
+    _tell(sys.stdout, json.dumps(report))
+    return 0
+
+
 def main(argv=None):
     """Optimise K synthetic frames, sharded over the ranks, each rank keeping `--frames-in-flight` frames on its GPU at a time with
     ``FrameOptimizer(graph=True)``; checkpoints through formats.checkpoint_payload (atomic, restartable: a frame whose final checkpoint
@@ -214,11 +411,14 @@ def main(argv=None):
     import time
     parser = argparse.ArgumentParser(prog="python -m vsrd_amd.launcher")
     parser.add_argument("--gpus", type=int, default=1)
-    parser.add_argument("--frames", type=int, default=0, help="frames of the whole job (default: two rounds of --frames-in-flight per rank)")
-    parser.add_argument("--frames-in-flight", type=int, default=3,
-                        help="frames optimised at the same time on one GPU (one host thread and stream each; captures and a graph's first launch "
-                             "alone, everything else next to each other: optimization._CaptureGate): 0.75 / 0.74 / 0.91 frames/s with 1 / 2 / 3 "
-                             "on one box; 1 = no threads at all")
+    parser.add_argument("--frames", type=int, default=0, help="frames of the whole job (default: two rounds of --frames-in-flight per process)")
+    parser.add_argument("--frames-in-flight", type=int, default=2,
+                        help="frames optimised at the same time by ONE process (one host thread, one stream and one persistent frame slot each; "
+                             "1 = no threads at all).  Round 5, one box, split-bf16 MLP: 0.83 / 0.88 / 0.89 frames/s with 1 / 3 / 5 in one process")
+    parser.add_argument("--procs-per-gpu", type=int, default=2,
+                        help="processes per GPU: the rank (a member of the RCCL group) and K - 1 helpers it starts before it touches the GPU and feeds "
+                             "with a share of its frames.  Kernels of different processes overlap better than streams of one: 2 x 2 frames in flight "
+                             "1.04 frames/s, 3 x 1 1.06, against 0.89 for 5 in one process (profiles/r05/frames_per_s.txt)")
     parser.add_argument("--views", type=int, default=17)
     parser.add_argument("--instances", type=int, default=8)
     parser.add_argument("--rays", type=int, default=1000)
@@ -236,13 +436,15 @@ def main(argv=None):
                              "instead of the persistent frame slots whose graphs are captured once at start-up")
     parser.add_argument("--max-restarts", type=int, default=2,
                         help="without torchrun around it, the launcher supervises its ranks: when one dies, all are started again as fresh "
-                             "processes, this many times at most; finished frames are skipped (0 with --gpus 1: no child processes at all)")
+                             "processes, this many times at most; finished frames are skipped (0 with --gpus 1: no supervisor process)")
     parser.add_argument("--attempt", type=int, default=0, help=argparse.SUPPRESS)          # set by the supervisor: restarts so far
+    parser.add_argument("--helper", type=int, default=0, help=argparse.SUPPRESS)           # set by a rank for its helper processes (_start_helpers)
     parser.add_argument("--selftest", action="store_true",
                         help="no rendering, no GPU: a frame is a sleep of --selftest-seconds and a small checkpoint (gloo, CPU) -- the supervisor, "
-                             "the sharding, the skip-if-done guard and the report, for tests/test_launcher.py; the line says so")
+                             "the helpers, the sharding, the skip-if-done guard and the report, for tests/test_launcher.py; the line says so")
     parser.add_argument("--selftest-seconds", type=float, default=0.05)
-    parser.add_argument("--selftest-fail", default="", help="RANK:FRAMES -- on attempt 0 that rank dies (exit code 23) once it has finished FRAMES frames")
+    parser.add_argument("--selftest-fail", default="", help="RANK:FRAMES[:PROCESS] -- on attempt 0 that process (0 = the rank itself) of that rank dies "
+                                                            "(exit code 23) once it has finished FRAMES frames")
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parser.parse_args(argv)
     if not 1 <= args.frames_in_flight <= (4 if args.fresh_loops else 8):
@@ -250,88 +452,88 @@ def main(argv=None):
         #  within seconds -- construction and eager warm-up steps of that many threads next to a capture.  Frame slots capture nothing once
         #  the workers run; eight is what was tried.)
         raise SystemExit("--frames-in-flight must be 1..8 (1..4 with --fresh-loops)")
+    if not (1 <= args.procs_per_gpu <= 4 and (args.selftest or args.procs_per_gpu * args.frames_in_flight <= 6 or args.procs_per_gpu == 1)):
+        # (four processes with two frames each took 190 s for 32 frames where 4 x 1 and 2 x 3 take 16 and 26: profiles/r05/frames_per_s.txt)
+        raise SystemExit("--procs-per-gpu must be 1..4 with at most 6 frames in flight per GPU between them")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))          # __graft_entry__.build lives at the repo root
     if root not in sys.path:
         sys.path.insert(0, root)
-    if "RANK" not in os.environ and (args.gpus > 1 or args.max_restarts > 0):
-        return _supervise(argv, args)
     if args.ranks_share_gpu:
         os.environ["LOCAL_RANK"] = "0"
-    if args.selftest:
-        return _selftest_rank(args)
-    if not torch.cuda.is_available():
+    if args.helper:
+        return _helper_main(args)
+    if "RANK" not in os.environ and (args.gpus > 1 or args.max_restarts > 0):
+        return _supervise(argv, args)
+    helpers = _start_helpers(argv, args) if args.procs_per_gpu > 1 else []
+    if helpers:
+        _watch_helpers(helpers)
+    try:
+        return _rank_main(args, helpers)
+    finally:
+        for helper in helpers:
+            if helper.poll() is None:
+                helper.kill()
+
+
+def _rank_main(args, helpers):
+    import json
+    import sys
+    import tempfile
+    import time
+    use_gpu = not args.selftest
+    if use_gpu and not torch.cuda.is_available():
         raise SystemExit("vsrd_amd.launcher optimises frames on HIP devices: no GPU visible, and vsrd_amd has no CPU fallback")
-    rank, world, device = init_process_group(backend="gloo" if args.ranks_share_gpu else None)
-    import __graft_entry__
-    if rank == 0:
-        __graft_entry__.build()
-    barrier()
-    from . import formats, optimization
-    total = args.frames or 2 * args.frames_in_flight * world
+    if use_gpu:
+        rank, world, device = init_process_group(backend="gloo" if args.ranks_share_gpu else None)
+        import __graft_entry__
+        if rank == 0:
+            __graft_entry__.build()
+        barrier()
+    else:
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    procs = args.procs_per_gpu
+    total = args.frames or (2 * args.frames_in_flight * procs * world if use_gpu else 4 * world)
     out_dir = args.out or (tempfile.mkdtemp(prefix="vsrd_frames_") if rank == 0 else None)
     manifest = broadcast_manifest(dict(frames=list(range(total)), seed=args.seed, out=out_dir) if rank == 0 else None)
+    if not manifest["out"]:
+        raise SystemExit("no checkpoint directory (--out; the supervisor supplies one)")
     mine = shard_frames(manifest["frames"], rank, world, seed=manifest["seed"])
-    ordered(lambda r: print(f"[rank {r}/{world}] {device}: frames {mine}", file=sys.stderr, flush=True))
-    config = dict(num_steps=args.num_steps, warmup_steps=args.warmup_steps, num_rays=args.rays, num_samples=args.samples)
-    # inputs are resident before the clock starts (what main.py:106-316 prepares per frame is the dataset's work, not the loop's)
-    pending = [frame for frame in mine if not os.path.exists(os.path.join(manifest["out"], f"frame_{int(frame):06d}", f"step_{args.num_steps - 1}.pt"))]
-    inputs = {frame: synthetic_frame_inputs(device, frame, args.views, args.instances, args.height, args.width) for frame in pending}
-    losses = {}
-    # Frame slots (round 5): `--frames-in-flight` persistent loops, each constructed and with ALL its hipGraphs captured here, one after the
-    # other, before any worker thread exists (FrameOptimizer.capture_all).  A frame is then a reset (copies and fills), graph replays and a
-    # checkpoint: no construction, no eager steps, no capture next to another frame's work -- the collisions the capture gate of round 4
-    # was built around have nothing left to collide with.  (--fresh-loops: the round-4 form, for A/B.)
-    import queue
-    slots = queue.Queue()
-    setup_seconds, graphs_per_slot = 0.0, 0
-    if pending and not args.fresh_loops:
-        t_setup = time.perf_counter()
-        for _ in range(min(args.frames_in_flight, len(pending))):
-            loop = optimization.FrameOptimizer(inputs[pending[0]], optimization.OptimizationConfig(seed=int(manifest["seed"]), **config), device,
-                                               graph=True, persistent=True)
-            graphs_per_slot = loop.capture_all()
-            slots.put(loop)
-        torch.cuda.synchronize()
-        setup_seconds = time.perf_counter() - t_setup
-    captures_before = optimization.exclusive_device_access().capture_seconds
-
-    def optimise(frame):
-        slot = None if args.fresh_loops else slots.get()
-        try:
-            loop = slot
-            if loop is None or not loop.reset(inputs[frame]):
-                # (--fresh-loops, or a frame whose importance weights do not suit the table sampler the slot's graphs draw from)
-                loop = optimization.FrameOptimizer(inputs[frame], optimization.OptimizationConfig(seed=int(manifest["seed"]), **config), device, graph=True)
-            record = loop.run(args.num_steps)
-            with optimization.exclusive_device_access():       # (host synchronisations and copies: refused now and then while another frame's thread captures)
-                torch.cuda.current_stream().synchronize()
-                losses[frame] = float(record["loss"])
-                payload = formats.checkpoint_payload(loop, step=args.num_steps - 1, metrics={}, host=True)
-            if loop is not slot:
-                loop.close()
-            return payload
-        finally:
-            if slot is not None:
-                slots.put(slot)
-
-    def path_of(frame):
-        return os.path.join(manifest["out"], f"frame_{int(frame):06d}", f"step_{args.num_steps - 1}.pt")
+    shares = [mine[j::procs] for j in range(procs)]                # process j of the rank (0 = the rank itself): every procs-th frame of the shard
+    ordered(lambda r: print(f"[rank {r}/{world}] " + ("selftest" if args.selftest else str(device)) + f": frames {mine}"
+                            + (f" over {procs} processes" if procs > 1 else ""), file=sys.stderr, flush=True))
+    for j, helper in enumerate(helpers, start=1):
+        _tell(helper.stdin, json.dumps(dict(frames=shares[j], manifest=manifest)))
+    work = _make_work(args, manifest, rank, 0)
+    work.prepare(shares[0])
+    for j, helper in enumerate(helpers, start=1):
+        if _hear(helper.stdout, f"helper {j} of rank {rank}") != "ready":
+            raise SystemExit(f"vsrd_amd.launcher: helper {j} of rank {rank} is not ready")
 
     def fence():
         barrier()
-        torch.cuda.synchronize()
+        if use_gpu:
+            torch.cuda.synchronize()
 
     fence()
     t0 = time.perf_counter()
-    done = run_frames(mine, optimise, path_of, frames_in_flight=args.frames_in_flight)
-    torch.cuda.synchronize()
+    for helper in helpers:
+        _tell(helper.stdin, "go")
+    reports = [work.run()]
+    reports[0]["seconds"] = time.perf_counter() - t0
+    reports += [json.loads(_hear(helper.stdout, f"helper {j} of rank {rank}")) for j, helper in enumerate(helpers, start=1)]
     own = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
-    report = dict(rank=rank, own_seconds=own, elapsed_seconds=elapsed, frames=len(done), skipped=len(mine) - len(done),
-                  gate_capture_seconds=optimization.exclusive_device_access().capture_seconds - captures_before,
-                  slot_setup_seconds=setup_seconds, graphs_per_slot=graphs_per_slot, final_losses={int(f): losses[f] for f in sorted(losses)},
-                  mean_final_loss=(sum(losses.values()) / len(losses)) if losses else None)
+    losses = {int(f): v for r in reports for f, v in r["final_losses"].items()}
+    report = dict(rank=rank, own_seconds=own, elapsed_seconds=elapsed, frames=sum(r["frames"] for r in reports), skipped=sum(r["skipped"] for r in reports),
+                  gate_capture_seconds=sum(r["gate_capture_seconds"] for r in reports), slot_setup_seconds=max(r["slot_setup_seconds"] for r in reports),
+                  graphs_per_slot=reports[0]["graphs_per_slot"], final_losses={f: losses[f] for f in sorted(losses)},
+                  mean_final_loss=(sum(losses.values()) / len(losses)) if losses else None,
+                  process_seconds=[r["seconds"] for r in reports], process_frames=[r["frames"] for r in reports])
     gathered = [report]
     if world > 1:
         gathered = [None] * world
@@ -339,89 +541,48 @@ def main(argv=None):
     if rank == 0:
         slowest = max(r["elapsed_seconds"] for r in gathered)
         frames_done = sum(r["frames"] for r in gathered)
-        line = {
-            "metric": "optimised target frames/s, whole job (reference: about 15 minutes per frame on a V100, README.md:128)",
-            "value": frames_done / slowest, "unit": "frames/s", "n_gpus": len(gathered), "higher_is_better": True, "scaling": "weak",
-            "frames": frames_done, "frames_skipped_as_done": sum(r["skipped"] for r in gathered), "seconds": slowest,
-            "restarts": args.attempt, "max_restarts": args.max_restarts,     # (restarts > 0: `seconds` and `frames` are the last attempt's)
-            "frames_per_s_per_gpu": frames_done / slowest / len(gathered),
-            "per_rank_seconds": [r["own_seconds"] for r in gathered], "per_rank_frames": [r["frames"] for r in gathered],
-            "seconds_per_frame_per_gpu": [r["own_seconds"] / r["frames"] if r["frames"] else None for r in gathered],
-            "mean_final_loss": [r["mean_final_loss"] for r in gathered], "data": "synthetic", "dtype": "f32",
-            "final_loss_per_frame": {str(f): v for r in gathered for f, v in r["final_losses"].items()},
-            # host time per frame spent capturing hipGraphs (optimization._CaptureGate): what the other frames in flight wait for
-            "capture_seconds_per_frame": [r["gate_capture_seconds"] / r["frames"] if r["frames"] else None for r in gathered],
-            # persistent frame slots: built and captured once per rank BEFORE the clock (a job of thousands of frames pays it once)
-            "frame_slots": not args.fresh_loops, "slot_setup_seconds": [r["slot_setup_seconds"] for r in gathered],
-            "graphs_per_slot": [r["graphs_per_slot"] for r in gathered],
-            "config": {"workload": f"{args.num_steps} optimisation steps per frame ({args.warmup_steps} box-only + {args.num_steps - args.warmup_steps} with the "
-                                   f"residual MLP), {args.rays} rays x {args.samples} samples per step, {args.views} views of {args.height}x{args.width}, "
-                                   f"{args.instances} instances, FrameOptimizer(graph=True), {args.frames_in_flight} frames in flight per GPU"
-                                   + (" (a new loop per frame)" if args.fresh_loops else " (persistent frame slots: graphs captured once at start-up)"),
-                       "parallelism": f"frames sharded over {len(gathered)} rank(s), no data-path collective; RCCL: barriers, manifest broadcast, gather of the report",
-                       "checkpoints": manifest["out"]},
-        }
-        if args.ranks_share_gpu:
-            line["metric"] = "ranks share ONE GPU (--ranks-share-gpu): a test of the multi-rank path, NOT a scaling measurement; " + line["metric"]
-        print(json.dumps(line), flush=True)
+        if args.selftest:
+            line = {"metric": "launcher selftest: no rendering, NOT a measurement", "value": 0.0, "unit": "none", "n_gpus": len(gathered),
+                    "procs_per_gpu": procs, "frames": frames_done, "frames_skipped_as_done": sum(r["skipped"] for r in gathered),
+                    "per_rank_frames": [r["frames"] for r in gathered], "per_process_frames": [r["process_frames"] for r in gathered],
+                    "restarts": args.attempt, "max_restarts": args.max_restarts,
+                    "config": {"workload": f"sleep({args.selftest_seconds} s) per frame on gloo / CPU", "checkpoints": manifest["out"]}}
+            print(json.dumps(line), flush=True)
+        else:
+            line = {
+                "metric": "optimised target frames/s, whole job (reference: about 15 minutes per frame on a V100, README.md:128)",
+                "value": frames_done / slowest, "unit": "frames/s", "n_gpus": len(gathered), "higher_is_better": True, "scaling": "weak",
+                "frames": frames_done, "frames_skipped_as_done": sum(r["skipped"] for r in gathered), "seconds": slowest,
+                "restarts": args.attempt, "max_restarts": args.max_restarts,     # (restarts > 0: `seconds` and `frames` are the last attempt's)
+                "frames_per_s_per_gpu": frames_done / slowest / len(gathered),
+                "procs_per_gpu": procs, "frames_in_flight_per_process": args.frames_in_flight,
+                "per_rank_seconds": [r["own_seconds"] for r in gathered], "per_rank_frames": [r["frames"] for r in gathered],
+                "per_process_seconds": [r["process_seconds"] for r in gathered], "per_process_frames": [r["process_frames"] for r in gathered],
+                "seconds_per_frame_per_gpu": [r["own_seconds"] / r["frames"] if r["frames"] else None for r in gathered],
+                "mean_final_loss": [r["mean_final_loss"] for r in gathered], "data": "synthetic", "dtype": "f32",
+                "final_loss_per_frame": {str(f): v for r in gathered for f, v in r["final_losses"].items()},
+                # host time per frame spent capturing hipGraphs (optimization._CaptureGate): what the other frames in flight wait for
+                "capture_seconds_per_frame": [r["gate_capture_seconds"] / r["frames"] if r["frames"] else None for r in gathered],
+                # persistent frame slots: built and captured once per process BEFORE the clock (a job of thousands of frames pays it once)
+                "frame_slots": not args.fresh_loops, "slot_setup_seconds": [r["slot_setup_seconds"] for r in gathered],
+                "graphs_per_slot": [r["graphs_per_slot"] for r in gathered],
+                "config": {"workload": f"{args.num_steps} optimisation steps per frame ({args.warmup_steps} box-only + {args.num_steps - args.warmup_steps} with the "
+                                       f"residual MLP), {args.rays} rays x {args.samples} samples per step, {args.views} views of {args.height}x{args.width}, "
+                                       f"{args.instances} instances, FrameOptimizer(graph=True), {procs} process(es) per GPU x {args.frames_in_flight} frames in flight each"
+                                       + (" (a new loop per frame)" if args.fresh_loops else " (persistent frame slots: graphs captured once at start-up)"),
+                           "parallelism": f"frames sharded over {len(gathered)} rank(s), no data-path collective; "
+                                          + ("gloo" if args.ranks_share_gpu else "RCCL") + ": barriers, manifest broadcast, gather of the report"
+                                          + (f"; {procs - 1} helper process(es) per rank outside the group" if procs > 1 else ""),
+                           "checkpoints": manifest["out"]},
+            }
+            if args.ranks_share_gpu:
+                line["metric"] = "ranks share ONE GPU (--ranks-share-gpu): a test of the multi-rank path, NOT a scaling measurement; " + line["metric"]
+            print(json.dumps(line), flush=True)
     barrier()
     if dist.is_initialized():
         dist.destroy_process_group()
-    return 0
-
-
-def _selftest_rank(args):
-    """One rank of `--selftest`: the launch / manifest / shard / skip-if-done / checkpoint / report path with a sleep for a frame, on gloo
-    without a GPU.  `--selftest-fail RANK:FRAMES` makes that rank die on attempt 0 once it has finished FRAMES frames."""
-    import json
-    import sys
-    import time
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    total = args.frames or 4 * world
-    manifest = broadcast_manifest(dict(frames=list(range(total)), seed=args.seed, out=args.out) if rank == 0 else None)
-    if not manifest["out"]:
-        raise SystemExit("--selftest needs --out (the supervisor supplies one)")
-    os.makedirs(manifest["out"], exist_ok=True)
-    mine = shard_frames(manifest["frames"], rank, world, seed=manifest["seed"])
-    ordered(lambda r: print(f"[rank {r}/{world}] selftest: frames {mine}", file=sys.stderr, flush=True))
-    fail_rank, fail_after = (int(v) for v in args.selftest_fail.split(":")) if args.selftest_fail else (-1, 0)
-    finished = []
-
-    def optimise(frame):
-        if args.attempt == 0 and rank == fail_rank and len(finished) >= fail_after:
-            os._exit(23)                                    # a dead rank: no clean-up, no goodbye to the process group
-        time.sleep(args.selftest_seconds)
-        finished.append(frame)
-        with open(os.path.join(manifest["out"], "completed.log"), "a") as log:      # (O_APPEND: one short line per frame, whole)
-            log.write(f"{int(frame)} {args.attempt} {rank}\n")
-        return dict(frame=int(frame), attempt=args.attempt, rank=rank)
-
-    def path_of(frame):
-        return os.path.join(manifest["out"], f"frame_{int(frame):06d}", "step_final.pt")
-
-    barrier()
-    t0 = time.perf_counter()
-    done = run_frames(mine, optimise, path_of, frames_in_flight=1)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    report = dict(rank=rank, frames=len(done), skipped=len(mine) - len(done), elapsed_seconds=elapsed)
-    gathered = [report]
-    if world > 1:
-        gathered = [None] * world
-        dist.all_gather_object(gathered, report)
-    if rank == 0:
-        print(json.dumps({"metric": "launcher selftest: no rendering, NOT a measurement", "value": 0.0, "unit": "none", "n_gpus": len(gathered),
-                          "frames": sum(r["frames"] for r in gathered), "frames_skipped_as_done": sum(r["skipped"] for r in gathered),
-                          "per_rank_frames": [r["frames"] for r in gathered], "restarts": args.attempt, "max_restarts": args.max_restarts,
-                          "config": {"workload": f"sleep({args.selftest_seconds} s) per frame on gloo / CPU", "checkpoints": manifest["out"]}}), flush=True)
-    barrier()
-    if dist.is_initialized():
-        dist.destroy_process_group()
+    for helper in helpers:
+        helper.wait()
     return 0
 
 
