@@ -14,11 +14,12 @@ import torch
 import torch.distributed as dist
 
 
-def init_process_group(backend=None):
-    """env:// rendezvous as with torchrun (main.py:49).  Returns (rank, world_size, device)."""
+def init_process_group(backend=None, ranks_per_device=1):
+    """env:// rendezvous as with torchrun (main.py:49).  Returns (rank, world_size, device).  `ranks_per_device` consecutive local ranks
+    share a device (the launcher's --procs-per-gpu)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) // max(int(ranks_per_device), 1)
     use_gpu = torch.cuda.is_available()
     device = torch.device("cuda", local % max(torch.cuda.device_count(), 1)) if use_gpu else torch.device("cpu")
     if use_gpu:
@@ -178,7 +179,8 @@ def _supervise(argv, args):
     import tempfile
     # (counting devices does not initialise the runtime on this image; a selftest has no devices to count)
     if not args.ranks_share_gpu and not args.selftest and torch.cuda.device_count() < args.gpus:
-        raise SystemExit(f"vsrd_amd.launcher --gpus {args.gpus}: this node has {torch.cuda.device_count()} visible GPU(s); one rank per GPU")
+        raise SystemExit(f"vsrd_amd.launcher --gpus {args.gpus}: this node has {torch.cuda.device_count()} visible GPU(s)")
+    ranks = args.gpus * args.procs_per_gpu
     if not args.out:
         argv = list(argv) + ["--out", tempfile.mkdtemp(prefix="vsrd_frames_")]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -188,8 +190,8 @@ def _supervise(argv, args):
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
         children = []
-        for rank in range(args.gpus):
-            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+        for rank in range(ranks):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(ranks), LOCAL_WORLD_SIZE=str(ranks), MASTER_ADDR="127.0.0.1",
                        MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
             children.append(subprocess.Popen([sys.executable, "-m", "vsrd_amd.launcher", *argv, "--attempt", str(attempt)], env=env, cwd=root))
         failed = _wait_for_ranks(children)
@@ -200,9 +202,6 @@ def _supervise(argv, args):
               + ("starting the ranks again as fresh processes (frames with a final checkpoint are skipped)" if again else "no restarts left"),
               file=sys.stderr, flush=True)
     return abs(failed[1]) or 1
-
-
-_PROTOCOL = "@vsrd "          # leader <-> helper lines on the helper's stdin / stdout (anything else a helper prints is passed over)
 
 
 class _RenderWork:
@@ -273,13 +272,12 @@ class _RenderWork:
 
 
 class _SleepWork:
-    """`--selftest`: a frame is a sleep and a small checkpoint.  `--selftest-fail RANK:FRAMES[:PROCESS]` makes that process of that rank die
-    (exit code 23, no clean-up, no goodbye to the process group) on attempt 0 once it has finished FRAMES frames."""
+    """`--selftest`: a frame is a sleep and a small checkpoint.  `--selftest-fail RANK:FRAMES` makes that rank die (exit code 23, no
+    clean-up, no goodbye to the process group) on attempt 0 once it has finished FRAMES frames."""
 
-    def __init__(self, args, manifest, rank, process):
-        self.args, self.manifest, self.rank, self.process = args, manifest, rank, process
-        spec = [int(v) for v in args.selftest_fail.split(":")] if args.selftest_fail else [-1, 0]
-        self.fail_rank, self.fail_after, self.fail_process = spec[0], spec[1], (spec[2] if len(spec) > 2 else 0)
+    def __init__(self, args, manifest, rank):
+        self.args, self.manifest, self.rank = args, manifest, rank
+        self.fail_rank, self.fail_after = (int(v) for v in args.selftest_fail.split(":")) if args.selftest_fail else (-1, 0)
 
     def path_of(self, frame):
         return os.path.join(self.manifest["out"], f"frame_{int(frame):06d}", "step_final.pt")
@@ -293,110 +291,16 @@ class _SleepWork:
         args, finished = self.args, []
 
         def optimise(frame):
-            if args.attempt == 0 and self.rank == self.fail_rank and self.process == self.fail_process and len(finished) >= self.fail_after:
+            if args.attempt == 0 and self.rank == self.fail_rank and len(finished) >= self.fail_after:
                 os._exit(23)
             time.sleep(args.selftest_seconds)
             finished.append(frame)
             with open(os.path.join(self.manifest["out"], "completed.log"), "a") as log:      # (O_APPEND: one short line per frame, whole)
-                log.write(f"{int(frame)} {args.attempt} {self.rank} {self.process}\n")
+                log.write(f"{int(frame)} {args.attempt} {self.rank}\n")
             return dict(frame=int(frame), attempt=args.attempt, rank=self.rank)
 
         done = run_frames(self.frames, optimise, self.path_of, frames_in_flight=1)
         return dict(frames=len(done), skipped=len(self.frames) - len(done), gate_capture_seconds=0.0, slot_setup_seconds=0.0, graphs_per_slot=0, final_losses={})
-
-
-def _start_helpers(argv, args):
-    """`--procs-per-gpu K`: the K - 1 helper processes of this rank, started BEFORE this process touches its GPU (fresh children, never a
-    re-execution).  A helper is no member of the process group: it takes its frames from this rank over its stdin and hands its report back
-    over its stdout, so the collective level stays one rank per GPU on RCCL whatever K is."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
-                                                            "TORCHELASTIC_RUN_ID")}
-    env["VSRD_LEADER_RANK"] = os.environ.get("RANK", "0")
-    return [subprocess.Popen([sys.executable, "-m", "vsrd_amd.launcher", *argv, "--helper", str(j)], env=env, cwd=root, text=True, bufsize=1,
-                             stdin=subprocess.PIPE, stdout=subprocess.PIPE) for j in range(1, args.procs_per_gpu)]
-
-
-def _watch_helpers(helpers):
-    """A helper that dies takes its rank with it at once (exit code of the helper), instead of when the rank gets round to reading its
-    report: the supervisor -- or torchrun -- then restarts the ranks, and the finished frames are skipped."""
-    import sys
-    import threading
-    import time
-
-    def watch():
-        while True:
-            for j, helper in enumerate(helpers, start=1):
-                code = helper.poll()
-                if code not in (None, 0):
-                    print(f"[vsrd_amd.launcher] helper {j} of rank {os.environ.get('RANK', '0')} exited with code {code}", file=sys.stderr, flush=True)
-                    for other in helpers:
-                        if other.poll() is None:
-                            other.kill()
-                    os._exit(abs(code) or 1)
-            if all(helper.poll() is not None for helper in helpers):
-                return
-            time.sleep(0.1)
-
-    threading.Thread(target=watch, daemon=True).start()
-
-
-def _tell(stream, payload):
-    stream.write(_PROTOCOL + payload + "\n")
-    stream.flush()
-
-
-def _hear(stream, who):
-    """The next protocol line of `stream`; a closed stream (the other side died) ends this process non-zero, which is what the supervisor,
-    or torchrun, restarts the ranks for."""
-    while True:
-        text = stream.readline()
-        if text == "":
-            raise SystemExit(f"vsrd_amd.launcher: {who} went away")
-        if text.startswith(_PROTOCOL):
-            return text[len(_PROTOCOL):].strip()
-
-
-def _make_work(args, manifest, rank, process):
-    if args.selftest:
-        return _SleepWork(args, manifest, rank, process)
-    if not torch.cuda.is_available():
-        raise SystemExit("vsrd_amd.launcher optimises frames on HIP devices: no GPU visible, and vsrd_amd has no CPU fallback")
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    device = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
-    torch.cuda.set_device(device)
-    return _RenderWork(args, manifest, device)
-
-
-def _helper_main(args):
-    """Process `--helper J` of a rank (see _start_helpers): frames in, "ready", "go", report out."""
-    import json
-    import sys
-    import time
-    rank = int(os.environ.get("VSRD_LEADER_RANK", "0"))
-    # a helper never outlives its rank: the kernel sends it SIGKILL when the rank's process ends, however that happens (a supervisor's
-    # SIGTERM runs no clean-up code in the rank), so no orphan keeps optimising frames next to the restarted ranks
-    try:
-        import ctypes
-        import signal
-        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)          # PR_SET_PDEATHSIG
-        if os.getppid() == 1:
-            return 1
-    except (OSError, AttributeError):
-        pass
-    spec = json.loads(_hear(sys.stdin, f"rank {rank}"))
-    work = _make_work(args, spec["manifest"], rank, args.helper)
-    work.prepare(spec["frames"])
-    _tell(sys.stdout, "ready")
-    if _hear(sys.stdin, f"rank {rank}") != "go":
-        return 1
-    t0 = time.perf_counter()
-    report = work.run()
-    report["seconds"] = time.perf_counter() - t0
-    _tell(sys.stdout, json.dumps(report))
-    return 0
 
 
 def main(argv=None):
@@ -412,13 +316,15 @@ def main(argv=None):
     parser = argparse.ArgumentParser(prog="python -m vsrd_amd.launcher")
     parser.add_argument("--gpus", type=int, default=1)
     parser.add_argument("--frames", type=int, default=0, help="frames of the whole job (default: two rounds of --frames-in-flight per process)")
-    parser.add_argument("--frames-in-flight", type=int, default=2,
+    parser.add_argument("--frames-in-flight", type=int, default=1,
                         help="frames optimised at the same time by ONE process (one host thread, one stream and one persistent frame slot each; "
-                             "1 = no threads at all).  Round 5, one box, split-bf16 MLP: 0.83 / 0.88 / 0.89 frames/s with 1 / 3 / 5 in one process")
+                             "1 = no threads at all).  Round 5, one box, split-bf16 MLP: 0.82 / 0.86 / 0.89 frames/s with 1 / 3 / 5 in one process")
     parser.add_argument("--procs-per-gpu", type=int, default=2,
-                        help="processes per GPU: the rank (a member of the RCCL group) and K - 1 helpers it starts before it touches the GPU and feeds "
-                             "with a share of its frames.  Kernels of different processes overlap better than streams of one: 2 x 2 frames in flight "
-                             "1.04 frames/s, 3 x 1 1.06, against 0.89 for 5 in one process (profiles/r05/frames_per_s.txt)")
+                        help="rank processes per GPU (local ranks P g .. P g + P - 1 use GPU g).  The kernels of two processes overlap better than the "
+                             "streams of one: 2 x 1 frame in flight 1.02-1.11 frames/s against 0.82 for one process with one frame and 0.85-0.87 with "
+                             "three (profiles/r05/frames_per_s.txt).  RCCL refuses two ranks on one device, so with P > 1 the launcher's control plane -- "
+                             "barriers, manifest broadcast, gather of the report; nothing else crosses ranks -- is gloo; P = 1 keeps RCCL.  Under torchrun: "
+                             "--nproc-per-node = GPUs x P")
     parser.add_argument("--views", type=int, default=17)
     parser.add_argument("--instances", type=int, default=8)
     parser.add_argument("--rays", type=int, default=1000)
@@ -438,13 +344,11 @@ def main(argv=None):
                         help="without torchrun around it, the launcher supervises its ranks: when one dies, all are started again as fresh "
                              "processes, this many times at most; finished frames are skipped (0 with --gpus 1: no supervisor process)")
     parser.add_argument("--attempt", type=int, default=0, help=argparse.SUPPRESS)          # set by the supervisor: restarts so far
-    parser.add_argument("--helper", type=int, default=0, help=argparse.SUPPRESS)           # set by a rank for its helper processes (_start_helpers)
     parser.add_argument("--selftest", action="store_true",
                         help="no rendering, no GPU: a frame is a sleep of --selftest-seconds and a small checkpoint (gloo, CPU) -- the supervisor, "
-                             "the helpers, the sharding, the skip-if-done guard and the report, for tests/test_launcher.py; the line says so")
+                             "the sharding, the rank -> device map, the skip-if-done guard and the report, for tests/test_launcher.py; the line says so")
     parser.add_argument("--selftest-seconds", type=float, default=0.05)
-    parser.add_argument("--selftest-fail", default="", help="RANK:FRAMES[:PROCESS] -- on attempt 0 that process (0 = the rank itself) of that rank dies "
-                                                            "(exit code 23) once it has finished FRAMES frames")
+    parser.add_argument("--selftest-fail", default="", help="RANK:FRAMES -- on attempt 0 that rank dies (exit code 23) once it has finished FRAMES frames")
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parser.parse_args(argv)
     if not 1 <= args.frames_in_flight <= (4 if args.fresh_loops else 8):
@@ -455,63 +359,51 @@ def main(argv=None):
     if not (1 <= args.procs_per_gpu <= 4 and (args.selftest or args.procs_per_gpu * args.frames_in_flight <= 6 or args.procs_per_gpu == 1)):
         # (four processes with two frames each took 190 s for 32 frames where 4 x 1 and 2 x 3 take 16 and 26: profiles/r05/frames_per_s.txt)
         raise SystemExit("--procs-per-gpu must be 1..4 with at most 6 frames in flight per GPU between them")
+    if args.ranks_share_gpu:
+        args.procs_per_gpu = 1               # (the test flag puts every rank on cuda:0 by itself)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))          # __graft_entry__.build lives at the repo root
     if root not in sys.path:
         sys.path.insert(0, root)
-    if args.ranks_share_gpu:
-        os.environ["LOCAL_RANK"] = "0"
-    if args.helper:
-        return _helper_main(args)
-    if "RANK" not in os.environ and (args.gpus > 1 or args.max_restarts > 0):
+    if "RANK" not in os.environ and (args.gpus * args.procs_per_gpu > 1 or args.max_restarts > 0):
         return _supervise(argv, args)
-    helpers = _start_helpers(argv, args) if args.procs_per_gpu > 1 else []
-    if helpers:
-        _watch_helpers(helpers)
-    try:
-        return _rank_main(args, helpers)
-    finally:
-        for helper in helpers:
-            if helper.poll() is None:
-                helper.kill()
+    return _rank_main(args)
 
 
-def _rank_main(args, helpers):
+def _rank_main(args):
     import json
     import sys
     import tempfile
     import time
     use_gpu = not args.selftest
-    if use_gpu and not torch.cuda.is_available():
-        raise SystemExit("vsrd_amd.launcher optimises frames on HIP devices: no GPU visible, and vsrd_amd has no CPU fallback")
+    procs = args.procs_per_gpu
+    # RCCL only when every rank has a device of its own
+    share = args.ranks_share_gpu or procs > 1
+    if args.ranks_share_gpu:
+        os.environ["LOCAL_RANK"] = "0"
+    local_device = int(os.environ.get("LOCAL_RANK", "0")) // procs
     if use_gpu:
-        rank, world, device = init_process_group(backend="gloo" if args.ranks_share_gpu else None)
+        if not torch.cuda.is_available():
+            raise SystemExit("vsrd_amd.launcher optimises frames on HIP devices: no GPU visible, and vsrd_amd has no CPU fallback")
+        rank, world, device = init_process_group(backend="gloo" if share else None, ranks_per_device=procs)
         import __graft_entry__
         if rank == 0:
             __graft_entry__.build()
         barrier()
     else:
-        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        rank, world, device = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), None
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    procs = args.procs_per_gpu
-    total = args.frames or (2 * args.frames_in_flight * procs * world if use_gpu else 4 * world)
+    total = args.frames or (2 * args.frames_in_flight * world if use_gpu else 4 * world)
     out_dir = args.out or (tempfile.mkdtemp(prefix="vsrd_frames_") if rank == 0 else None)
     manifest = broadcast_manifest(dict(frames=list(range(total)), seed=args.seed, out=out_dir) if rank == 0 else None)
     if not manifest["out"]:
         raise SystemExit("no checkpoint directory (--out; the supervisor supplies one)")
     mine = shard_frames(manifest["frames"], rank, world, seed=manifest["seed"])
-    shares = [mine[j::procs] for j in range(procs)]                # process j of the rank (0 = the rank itself): every procs-th frame of the shard
-    ordered(lambda r: print(f"[rank {r}/{world}] " + ("selftest" if args.selftest else str(device)) + f": frames {mine}"
-                            + (f" over {procs} processes" if procs > 1 else ""), file=sys.stderr, flush=True))
-    for j, helper in enumerate(helpers, start=1):
-        _tell(helper.stdin, json.dumps(dict(frames=shares[j], manifest=manifest)))
-    work = _make_work(args, manifest, rank, 0)
-    work.prepare(shares[0])
-    for j, helper in enumerate(helpers, start=1):
-        if _hear(helper.stdout, f"helper {j} of rank {rank}") != "ready":
-            raise SystemExit(f"vsrd_amd.launcher: helper {j} of rank {rank} is not ready")
+    ordered(lambda r: print(f"[rank {r}/{world}] " + (f"selftest, device {local_device}" if args.selftest else str(device)) + f": frames {mine}", file=sys.stderr, flush=True))
+    work = _SleepWork(args, manifest, rank) if args.selftest else _RenderWork(args, manifest, device)
+    work.prepare(mine)
 
     def fence():
         barrier()
@@ -520,20 +412,12 @@ def _rank_main(args, helpers):
 
     fence()
     t0 = time.perf_counter()
-    for helper in helpers:
-        _tell(helper.stdin, "go")
-    reports = [work.run()]
-    reports[0]["seconds"] = time.perf_counter() - t0
-    reports += [json.loads(_hear(helper.stdout, f"helper {j} of rank {rank}")) for j, helper in enumerate(helpers, start=1)]
+    report = work.run()
     own = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
-    losses = {int(f): v for r in reports for f, v in r["final_losses"].items()}
-    report = dict(rank=rank, own_seconds=own, elapsed_seconds=elapsed, frames=sum(r["frames"] for r in reports), skipped=sum(r["skipped"] for r in reports),
-                  gate_capture_seconds=sum(r["gate_capture_seconds"] for r in reports), slot_setup_seconds=max(r["slot_setup_seconds"] for r in reports),
-                  graphs_per_slot=reports[0]["graphs_per_slot"], final_losses={f: losses[f] for f in sorted(losses)},
-                  mean_final_loss=(sum(losses.values()) / len(losses)) if losses else None,
-                  process_seconds=[r["seconds"] for r in reports], process_frames=[r["frames"] for r in reports])
+    losses = report["final_losses"]
+    report.update(rank=rank, device=local_device, own_seconds=own, elapsed_seconds=elapsed, mean_final_loss=(sum(losses.values()) / len(losses)) if losses else None)
     gathered = [report]
     if world > 1:
         gathered = [None] * world
@@ -541,24 +425,24 @@ def _rank_main(args, helpers):
     if rank == 0:
         slowest = max(r["elapsed_seconds"] for r in gathered)
         frames_done = sum(r["frames"] for r in gathered)
+        n_gpus = len(gathered) if args.ranks_share_gpu else max(len(gathered) // procs, 1)       # (--ranks-share-gpu: the test's line counts ranks, as before)
         if args.selftest:
-            line = {"metric": "launcher selftest: no rendering, NOT a measurement", "value": 0.0, "unit": "none", "n_gpus": len(gathered),
-                    "procs_per_gpu": procs, "frames": frames_done, "frames_skipped_as_done": sum(r["skipped"] for r in gathered),
-                    "per_rank_frames": [r["frames"] for r in gathered], "per_process_frames": [r["process_frames"] for r in gathered],
+            line = {"metric": "launcher selftest: no rendering, NOT a measurement", "value": 0.0, "unit": "none", "n_gpus": n_gpus, "ranks": len(gathered),
+                    "procs_per_gpu": procs, "rank_devices": [r["device"] for r in gathered], "frames": frames_done,
+                    "frames_skipped_as_done": sum(r["skipped"] for r in gathered), "per_rank_frames": [r["frames"] for r in gathered],
                     "restarts": args.attempt, "max_restarts": args.max_restarts,
                     "config": {"workload": f"sleep({args.selftest_seconds} s) per frame on gloo / CPU", "checkpoints": manifest["out"]}}
-            print(json.dumps(line), flush=True)
         else:
             line = {
                 "metric": "optimised target frames/s, whole job (reference: about 15 minutes per frame on a V100, README.md:128)",
-                "value": frames_done / slowest, "unit": "frames/s", "n_gpus": len(gathered), "higher_is_better": True, "scaling": "weak",
+                "value": frames_done / slowest, "unit": "frames/s", "n_gpus": n_gpus, "higher_is_better": True, "scaling": "weak",
                 "frames": frames_done, "frames_skipped_as_done": sum(r["skipped"] for r in gathered), "seconds": slowest,
                 "restarts": args.attempt, "max_restarts": args.max_restarts,     # (restarts > 0: `seconds` and `frames` are the last attempt's)
-                "frames_per_s_per_gpu": frames_done / slowest / len(gathered),
-                "procs_per_gpu": procs, "frames_in_flight_per_process": args.frames_in_flight,
+                "frames_per_s_per_gpu": frames_done / slowest / n_gpus,
+                "ranks": len(gathered), "procs_per_gpu": procs, "frames_in_flight_per_process": args.frames_in_flight, "rank_devices": [r["device"] for r in gathered],
+                "control_plane": "gloo" if share else "RCCL",
                 "per_rank_seconds": [r["own_seconds"] for r in gathered], "per_rank_frames": [r["frames"] for r in gathered],
-                "per_process_seconds": [r["process_seconds"] for r in gathered], "per_process_frames": [r["process_frames"] for r in gathered],
-                "seconds_per_frame_per_gpu": [r["own_seconds"] / r["frames"] if r["frames"] else None for r in gathered],
+                "seconds_per_frame_per_rank": [r["own_seconds"] / r["frames"] if r["frames"] else None for r in gathered],
                 "mean_final_loss": [r["mean_final_loss"] for r in gathered], "data": "synthetic", "dtype": "f32",
                 "final_loss_per_frame": {str(f): v for r in gathered for f, v in r["final_losses"].items()},
                 # host time per frame spent capturing hipGraphs (optimization._CaptureGate): what the other frames in flight wait for
@@ -568,21 +452,18 @@ def _rank_main(args, helpers):
                 "graphs_per_slot": [r["graphs_per_slot"] for r in gathered],
                 "config": {"workload": f"{args.num_steps} optimisation steps per frame ({args.warmup_steps} box-only + {args.num_steps - args.warmup_steps} with the "
                                        f"residual MLP), {args.rays} rays x {args.samples} samples per step, {args.views} views of {args.height}x{args.width}, "
-                                       f"{args.instances} instances, FrameOptimizer(graph=True), {procs} process(es) per GPU x {args.frames_in_flight} frames in flight each"
+                                       f"{args.instances} instances, FrameOptimizer(graph=True), {procs} rank process(es) per GPU x {args.frames_in_flight} frame(s) in flight each"
                                        + (" (a new loop per frame)" if args.fresh_loops else " (persistent frame slots: graphs captured once at start-up)"),
-                           "parallelism": f"frames sharded over {len(gathered)} rank(s), no data-path collective; "
-                                          + ("gloo" if args.ranks_share_gpu else "RCCL") + ": barriers, manifest broadcast, gather of the report"
-                                          + (f"; {procs - 1} helper process(es) per rank outside the group" if procs > 1 else ""),
+                           "parallelism": f"frames sharded over {len(gathered)} rank(s) on {n_gpus} GPU(s), no data-path collective; "
+                                          + ("gloo (RCCL refuses two ranks on one device)" if share else "RCCL") + ": barriers, manifest broadcast, gather of the report",
                            "checkpoints": manifest["out"]},
             }
             if args.ranks_share_gpu:
                 line["metric"] = "ranks share ONE GPU (--ranks-share-gpu): a test of the multi-rank path, NOT a scaling measurement; " + line["metric"]
-            print(json.dumps(line), flush=True)
+        print(json.dumps(line), flush=True)
     barrier()
     if dist.is_initialized():
         dist.destroy_process_group()
-    for helper in helpers:
-        helper.wait()
     return 0
 
 
