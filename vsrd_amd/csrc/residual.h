@@ -585,10 +585,28 @@ __device__ __forceinline__ u32x4 split4(f32x4 x) { return split4(x[0], x[1], x[2
 __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
-// c += W x, W = the image operand `a` ([w_hi | w_lo]), x = the split `s` of the lane's four channels
-__device__ __forceinline__ f32x4 mfma_split(u32x4 a, u32x4 s, f32x4 c) {
-    c = mfma_bf16(a, u32x4{s[0], s[1], s[0], s[1]}, c);
-    return mfma_bf16(a, u32x4{s[2], s[3], s[2], s[3]}, c);
+// c += W x, W = an image operand, x = the split `s` = [x_hi | x_lo] of the lane's four channels.  The operand comes in both orders of
+// its halves, a = [w_hi | w_lo] and swapped = [w_lo | w_hi] (the same 16 bytes of the image read a second time, half by half: no second
+// image): a . s = w_hi x_hi + w_lo x_lo, swapped . s = w_lo x_hi + w_hi x_lo -- all four partial products with the split used AS IT IS.
+// kDup: the first form, a . [x_hi | x_hi] + a . [x_lo | x_lo], whose two activation operands cost four register moves per product (144 of
+// the 1 930 vector instructions of an adjoint tile) but which needs four registers less per live operand.
+// -DVSRD_SPLIT_DUP: that form everywhere; -DVSRD_SPLIT_DUP_FORWARD: in the forward tiles of the front kernels only.
+struct SplitOperand { u32x4 a, swapped; };
+#ifdef VSRD_SPLIT_DUP
+constexpr bool kSplitDupForward = true, kSplitDupAdjoint = true;
+#elif defined(VSRD_SPLIT_DUP_FORWARD)
+constexpr bool kSplitDupForward = true, kSplitDupAdjoint = false;
+#else
+constexpr bool kSplitDupForward = false, kSplitDupAdjoint = false;
+#endif
+template <bool kDup>
+__device__ __forceinline__ f32x4 mfma_split(const SplitOperand& w, u32x4 s, f32x4 c) {
+    if (kDup) {
+        c = mfma_bf16(w.a, u32x4{s[0], s[1], s[0], s[1]}, c);
+        return mfma_bf16(w.a, u32x4{s[2], s[3], s[2], s[3]}, c);
+    }
+    c = mfma_bf16(w.a, s, c);
+    return mfma_bf16(w.swapped, s, c);
 }
 
 // One instance's operand image from its (centred) weights: what pack_mlp_images_kernel (render_kernels.h) runs per instance.
@@ -620,8 +638,21 @@ __device__ __forceinline__ void pack_mlp_image(const LdsFloats w, unsigned* __re
 struct SplitWeights {
     LdsWords image;    // the staged operand image of the instance
     int lane, g;
-    __device__ __forceinline__ u32x4 operand(int p) const {
-        return *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(image + p * kImgOperandWords + 4 * lane);
+    template <bool kDup>
+    __device__ __forceinline__ SplitOperand operand(int p) const {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const __attribute__((address_space(3))) u32x2* at = reinterpret_cast<const __attribute__((address_space(3))) u32x2*>(image + p * kImgOperandWords + 4 * lane);
+        const u32x2 hi = at[0], lo = at[1];
+        if (kDup) return {u32x4{hi[0], hi[1], lo[0], lo[1]}, u32x4{0u, 0u, 0u, 0u}};
+        // The swapped operand: a second pair of reads through addresses the optimiser cannot see through -- otherwise it keeps the first
+        // pair and builds the swapped operand with four register moves, the moves this form is there to avoid; each half through its
+        // own address, because a merged ds_read2_b64 returns the halves in address order and the moves are back.
+        unsigned again_lo = static_cast<unsigned>(reinterpret_cast<unsigned long>(at + 1)), again_hi = static_cast<unsigned>(reinterpret_cast<unsigned long>(at));
+        asm volatile("" : "+v"(again_lo));
+        asm volatile("" : "+v"(again_hi));
+        const u32x2 lo2 = *reinterpret_cast<const __attribute__((address_space(3))) u32x2*>(static_cast<unsigned long>(again_lo));
+        const u32x2 hi2 = *reinterpret_cast<const __attribute__((address_space(3))) u32x2*>(static_cast<unsigned long>(again_hi));
+        return {u32x4{hi[0], hi[1], lo[0], lo[1]}, u32x4{lo2[0], lo2[1], hi2[0], hi2[1]}};
     }
     __device__ __forceinline__ f32x4 tail4(int at) const {
         return *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(image + kImgTail + at + 4 * g);      // channels 4 g .. 4 g + 3
@@ -648,9 +679,9 @@ __device__ __forceinline__ void forward_tile_split(const SplitWeights& wt, const
     f32x4 x[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const u32x4 a = wt.operand(kImgFirst + c);
-        z = mfma_split(a, split4(e.f[c]), z);
-        x[c] = mfma_split(a, split4(e.d[c]), splat4(0.0f));
+        const SplitOperand a = wt.operand<kSplitDupForward>(kImgFirst + c);
+        z = mfma_split<kSplitDupForward>(a, split4(e.f[c]), z);
+        x[c] = mfma_split<kSplitDupForward>(a, split4(e.d[c]), splat4(0.0f));
     }
     f32x4 y[4], g1[4];
     float inv_s[4];
@@ -667,7 +698,7 @@ __device__ __forceinline__ void forward_tile_split(const SplitWeights& wt, const
             a[j] = y[l][j] * n.cdf;
             g1[l][j] = n.cdf + y[l][j] * n.pdf;
         }
-        if (l < 3) z = mfma_split(wt.operand(kImgHidden + l), split4(a), wt.b(l));
+        if (l < 3) z = mfma_split<kSplitDupForward>(wt.operand<kSplitDupForward>(kImgHidden + l), split4(a), wt.b(l));
         else v = rows_sum(dot4(wt.w4(), a)) + wt.b4();
     }
     f32x4 a_bar = wt.w4(), z_bar;
@@ -677,7 +708,7 @@ __device__ __forceinline__ void forward_tile_split(const SplitWeights& wt, const
         const float m = rows_sum(hsum4(u)) * (1.0f / kMlpHidden);
         const float my = rows_sum(dot4(u, y[l])) * (1.0f / kMlpHidden);
         z_bar = (u - splat4(m) - y[l] * splat4(my)) * splat4(inv_s[l]);
-        if (l > 0) a_bar = mfma_split(wt.operand(kImgHiddenT + l - 1), split4(z_bar), splat4(0.0f));
+        if (l > 0) a_bar = mfma_split<kSplitDupForward>(wt.operand<kSplitDupForward>(kImgHiddenT + l - 1), split4(z_bar), splat4(0.0f));
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) t[c] = rows_sum(dot4(z_bar, x[c]));
@@ -1034,16 +1065,16 @@ __device__ __forceinline__ ResidualAdjoint mlp_adjoint_points_split(MlpAdjoint& 
             z.t = splat4(0.0f);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const u32x4 a = wt.operand(kImgFirst + c);
-                z.v = mfma_split(a, split4(e.f[c]), z.v);
-                z.t = mfma_split(a, split4(e.d[c] * splat4(delta[c])), z.t);
+                const SplitOperand a = wt.operand<kSplitDupAdjoint>(kImgFirst + c);
+                z.v = mfma_split<kSplitDupAdjoint>(a, split4(e.f[c]), z.v);
+                z.t = mfma_split<kSplitDupAdjoint>(a, split4(e.d[c] * splat4(delta[c])), z.t);
             }
 #pragma unroll
             for (int l = 0; l < 3; ++l) {
                 tile_state(z, st[l]);
-                const u32x4 a = wt.operand(kImgHidden + l);
-                z.v = mfma_split(a, split4(st[l].a), wt.b(l));
-                z.t = mfma_split(a, split4(st[l].da()), splat4(0.0f));
+                const SplitOperand a = wt.operand<kSplitDupAdjoint>(kImgHidden + l);
+                z.v = mfma_split<kSplitDupAdjoint>(a, split4(st[l].a), wt.b(l));
+                z.t = mfma_split<kSplitDupAdjoint>(a, split4(st[l].da()), splat4(0.0f));
             }
             tile_state(z, st[3]);
         }
@@ -1073,9 +1104,9 @@ __device__ __forceinline__ ResidualAdjoint mlp_adjoint_points_split(MlpAdjoint& 
                 s.acc_w[l] = mfma_outer(x, y, s.acc_w[l]);
             }
             wave_lds_order();
-            const u32x4 at = wt.operand(kImgHiddenT + l);
-            const f32x4 a_bar = mfma_split(at, split4(zb.v), splat4(0.0f));
-            const f32x4 da_bar = mfma_split(at, split4(zb.t), splat4(0.0f));
+            const SplitOperand at = wt.operand<kSplitDupAdjoint>(kImgHiddenT + l);
+            const f32x4 a_bar = mfma_split<kSplitDupAdjoint>(at, split4(zb.v), splat4(0.0f));
+            const f32x4 da_bar = mfma_split<kSplitDupAdjoint>(at, split4(zb.t), splat4(0.0f));
             TileJet1 zin_bar;
             gelu_norm_adjoint_tile(st[l], a_bar, da_bar, zin_bar);
             zb = zin_bar;
@@ -1102,9 +1133,9 @@ __device__ __forceinline__ ResidualAdjoint mlp_adjoint_points_split(MlpAdjoint& 
             // d feat / d f = e.d;  d (delta dfeat) / d f = -delta omega^2 feat
             const f32x4 second = {-delta[c] * omega[0] * omega[0] * e.f[c][0], -delta[c] * omega[0] * omega[0] * e.f[c][1],
                                   -delta[c] * omega[1] * omega[1] * e.f[c][2], -delta[c] * omega[1] * omega[1] * e.f[c][3]};
-            const u32x4 a = wt.operand(kImgFirst + c);
-            const f32x4 x1 = mfma_split(a, split4(e.d[c]), splat4(0.0f));
-            const f32x4 x2 = mfma_split(a, split4(second), splat4(0.0f));
+            const SplitOperand a = wt.operand<kSplitDupAdjoint>(kImgFirst + c);
+            const f32x4 x1 = mfma_split<kSplitDupAdjoint>(a, split4(e.d[c]), splat4(0.0f));
+            const f32x4 x2 = mfma_split<kSplitDupAdjoint>(a, split4(second), splat4(0.0f));
             f_bar[c] = rows_sum(dot4(zb.v, x1) + dot4(zb.t, x2));
         }
         if (g == q) { mine.px = f_bar[0] * tfold * inv; mine.py = f_bar[1] * inv; mine.pz = f_bar[2] * inv; }
