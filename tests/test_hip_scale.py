@@ -553,13 +553,13 @@ def test_config3_full_size_parity_against_the_oracle(dev, mlp_products):
     the rays where a fine sample crosses a plateau of the importance sampler or a box normal flips, so the share of rays whose labels are
     beyond 1e-4 may exceed the float32 oracle's own share (vs float64) by at most 1e-3 of the rays, against either oracle; the median ray
     is within 1e-5; rays the kernel leaves at exactly zero are zero (< 1e-6) in the float64 oracle.  VSRD_PARITY_RAYS=<n> overrides the
-    1024 rays (each costs the oracle 190 points x 16 instances of a 48-16-16-16-16-1 MLP with tangents, twice)."""
+    640 rays (each costs the oracle 190 points x 16 instances of a 48-16-16-16-16-1 MLP with tangents, twice)."""
     import os
     import bench
     from oracle import fields as ofields, geometry as ogeometry, rendering as orendering
     from vsrd_amd import models, rendering
     N, S, V, H, W, seed = 16, 64, 9, 376, 1408, 3
-    budget = int(os.environ.get("VSRD_PARITY_RAYS", 1024))
+    budget = int(os.environ.get("VSRD_PARITY_RAYS", 640))
     sched = bench.schedule_values(bench.SCHEDULES["mid"])
     T, std, ratio = sched["temperature"], sched["std"], sched["cosine_ratio"]
     det, cam, dirs = scene(dev, N, V, H, W, seed=seed)
