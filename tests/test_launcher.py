@@ -200,6 +200,46 @@ def test_native_frames_with_two_rank_processes_per_gpu(tmp_path):
         assert math.isfinite(loss) and abs(loss - lines[1]["final_loss_per_frame"][frame]) <= 5e-2 * max(abs(loss), 1.0), (frame, loss, lines[1]["final_loss_per_frame"][frame])
 
 
+@pytest.mark.gpu
+def test_supervisor_restarts_gpu_ranks_after_a_kill(tmp_path):
+    """The restart path on the real stack: two rank processes on the GPU (the default layout), one of them is SIGKILLed from outside as soon
+    as the job's first checkpoint exists -- a rank dying inside the runtime looks like this to everybody else.  The supervisor ends the
+    attempt, starts both ranks again as fresh processes (which initialise the GPU next to whatever the dead process left behind), the second
+    attempt skips the finished frames: exit code 0, `restarts: 1`, every frame has exactly one checkpoint, done + skipped = all."""
+    import json
+    import signal
+    import subprocess
+    import sys
+    import time
+    import psutil
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    frames = 12
+    command = [sys.executable, "-m", "vsrd_amd.launcher", "--gpus", "1", "--procs-per-gpu", "2", "--frames", str(frames), "--views", "3", "--instances", "4", "--height", "128",
+               "--width", "128", "--rays", "256", "--samples", "32", "--num-steps", "900", "--warmup-steps", "300", "--max-restarts", "2", "--out", str(tmp_path)]
+    job = subprocess.Popen(command, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    killed = None
+    deadline = time.time() + 600
+    while time.time() < deadline and job.poll() is None and killed is None:
+        done = [d for d in os.listdir(tmp_path) if d.startswith("frame_") and any(f.endswith(".pt") for f in os.listdir(tmp_path / d))]
+        if done:
+            ranks = [p for p in psutil.Process(job.pid).children(recursive=False) if p.is_running()]
+            if len(ranks) == 2:
+                killed = ranks[1].pid
+                os.kill(killed, signal.SIGKILL)
+                break
+        time.sleep(0.02)
+    out, err = job.communicate(timeout=900)
+    assert killed is not None, "the job finished before a rank could be killed: " + err[-1000:]
+    assert job.returncode == 0, err[-3000:]
+    assert "exited with code" in err and "starting the ranks again" in err
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["restarts"] == 1 and line["ranks"] == 2 and line["frames"] + line["frames_skipped_as_done"] == frames and line["frames_skipped_as_done"] >= 1
+    assert sorted(d for d in os.listdir(tmp_path) if d.startswith("frame_")) == [f"frame_{k:06d}" for k in range(frames)]
+    assert all(os.listdir(tmp_path / f"frame_{k:06d}") == ["step_899.pt"] for k in range(frames))          # no temporary file of the killed rank left behind
+    assert all(math.isfinite(x) for x in line["final_loss_per_frame"].values())
+
+
 def test_supervisor_restarts_a_dead_rank_and_every_frame_is_done_once(tmp_path):
     """VERDICT r04 item 4 (README.md:146-155: the reference leans on `torchrun --max_restarts`; main.py:134-136: skip-if-done): a gloo rank
     is killed mid-job -- os._exit from inside its second frame's slot, no clean-up, its peer left in the final barrier.  The supervisor

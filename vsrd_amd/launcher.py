@@ -82,6 +82,12 @@ def run_frames(frames: Sequence, optimise: Callable, checkpoint_path: Callable[[
         path = checkpoint_path(frame) if checkpoint_path else None
         if not (path and os.path.exists(path)):
             pending.append((frame, path))
+            # what a rank that was killed inside formats.atomic_torch_save left behind (the frame is this rank's: nobody else writes here)
+            folder, stem = (os.path.dirname(path), os.path.basename(path) + ".tmp.") if path else (None, None)
+            if folder and os.path.isdir(folder):
+                for name in os.listdir(folder):
+                    if name.startswith(stem):
+                        os.remove(os.path.join(folder, name))
 
     def one(item):
         frame, path = item
