@@ -24,7 +24,7 @@ def build():
     import __graft_entry__ as g
     sources = [os.path.join(g.CSRC, f) for f in os.listdir(g.CSRC)]
     if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in sources):
-        subprocess.run([g.HIPCC, *g.HIPCC_FLAGS, "-DVSRD_PHASE_TIMERS", "-o", LIB, os.path.join(g.CSRC, "api.hip")], check=True, cwd=ROOT)
+        g.compile_library(LIB, ["-DVSRD_PHASE_TIMERS"])          # (both translation units, as __graft_entry__.build())
 
 
 def main():
