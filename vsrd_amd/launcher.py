@@ -1,4 +1,5 @@
-"""Frame-sharded multi-GPU launcher: one process per GPU, frames split across ranks, no data-path collective.
+"""Frame-sharded multi-GPU launcher: rank processes (one per GPU on RCCL, or -- `--procs-per-gpu P`, the default is 2 -- P per GPU with a gloo
+control plane), frames split across ranks, no data-path collective; persistent frame slots inside a rank; a supervisor that restarts dead ranks.
 
 Reference behaviour (scripts/main.py:45-57, vsrd/distributed/loader.py:4-9, README.md:128): ``torch.distributed`` is
 initialised, ranks print in order between barriers, a ``DistributedSampler`` hands every rank its share of the target
