@@ -26,6 +26,18 @@ def golden():
     return load_golden
 
 
+@pytest.fixture(autouse=True)
+def seeded_generators():
+    """Every test starts from the same state of torch's global generators, run alone or in the suite: modules draw their initial parameters
+    from them at construction (a detector's embeddings, a hypernetwork), and the renderer's conditioning -- one fine sample on the other side
+    of a plateau -- turns a different draw into a different set of rays in the 1e-4 tail (round 5: a full-size parity test passed alone and
+    failed in the suite on exactly that)."""
+    torch.manual_seed(20240229)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(20240229)
+    yield
+
+
 RENDER_CASES = [
     "g4_render_n4_s32_step0",
     "g4_render_n4_s32_mid",

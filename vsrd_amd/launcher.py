@@ -249,16 +249,20 @@ class _RenderWork:
 
     def run(self):
         from . import formats, optimization
-        args, losses = self.args, {}
+        args, losses, fallbacks = self.args, {}, []
 
         def optimise(frame):
             slot = None if args.fresh_loops else self.slots.get()
             try:
                 loop = slot
-                if loop is None or not loop.reset(self.inputs[frame]):
+                # a frame starts from parameters drawn for (seed, frame): the same optimisation whichever rank, process or slot runs it
+                # (the reference seeds once per rank, scripts/main.py:67-74)
+                init_seed = (int(self.manifest["seed"]) * 1000003 + int(frame)) & 0x7FFFFFFF
+                if loop is None or not loop.reset(self.inputs[frame], init_seed=init_seed):
+                    fallbacks.append(int(frame))
                     # (--fresh-loops, or a frame whose importance weights do not suit the table sampler the slot's graphs draw from)
-                    loop = optimization.FrameOptimizer(self.inputs[frame], optimization.OptimizationConfig(seed=int(self.manifest["seed"]), **self.config),
-                                                       self.device, graph=True)
+                    loop = optimization.FrameOptimizer(self.inputs[frame], optimization.OptimizationConfig(seed=int(self.manifest["seed"]), init_seed=init_seed,
+                                                                                                         **self.config), self.device, graph=True)
                 record = loop.run(args.num_steps)
                 with optimization.exclusive_device_access():       # (host synchronisations and copies: refused now and then while another frame's thread captures)
                     torch.cuda.current_stream().synchronize()
@@ -275,7 +279,8 @@ class _RenderWork:
         torch.cuda.synchronize()
         return dict(frames=len(done), skipped=len(self.frames) - len(done),
                     gate_capture_seconds=optimization.exclusive_device_access().capture_seconds - self.captures_before,
-                    slot_setup_seconds=self.setup_seconds, graphs_per_slot=self.graphs_per_slot, final_losses={int(f): losses[f] for f in sorted(losses)})
+                    slot_setup_seconds=self.setup_seconds, graphs_per_slot=self.graphs_per_slot, final_losses={int(f): losses[f] for f in sorted(losses)},
+                    frames_outside_slots=sorted(fallbacks))
 
 
 class _SleepWork:
@@ -307,7 +312,8 @@ class _SleepWork:
             return dict(frame=int(frame), attempt=args.attempt, rank=self.rank)
 
         done = run_frames(self.frames, optimise, self.path_of, frames_in_flight=1)
-        return dict(frames=len(done), skipped=len(self.frames) - len(done), gate_capture_seconds=0.0, slot_setup_seconds=0.0, graphs_per_slot=0, final_losses={})
+        return dict(frames=len(done), skipped=len(self.frames) - len(done), gate_capture_seconds=0.0, slot_setup_seconds=0.0, graphs_per_slot=0, final_losses={},
+                    frames_outside_slots=[])
 
 
 def main(argv=None):
@@ -457,6 +463,8 @@ def _rank_main(args):
                 # persistent frame slots: built and captured once per process BEFORE the clock (a job of thousands of frames pays it once)
                 "frame_slots": not args.fresh_loops, "slot_setup_seconds": [r["slot_setup_seconds"] for r in gathered],
                 "graphs_per_slot": [r["graphs_per_slot"] for r in gathered],
+                # frames a slot could not take (their importance weights do not suit the sampling table its graphs draw from: a loop of their own, race sampler)
+                "frames_outside_slots": sorted(f for r in gathered for f in r["frames_outside_slots"]),
                 "config": {"workload": f"{args.num_steps} optimisation steps per frame ({args.warmup_steps} box-only + {args.num_steps - args.warmup_steps} with the "
                                        f"residual MLP), {args.rays} rays x {args.samples} samples per step, {args.views} views of {args.height}x{args.width}, "
                                        f"{args.instances} instances, FrameOptimizer(graph=True), {procs} rank process(es) per GPU x {args.frames_in_flight} frame(s) in flight each"

@@ -125,6 +125,7 @@ class _CaptureTurn:
 
 
 _capture_lock = _CaptureGate()
+_initial_draw = threading.Lock()      # seeding torch's host generator and drawing a frame's initial parameters from it: one frame at a time
 
 
 def exclusive_device_access():
@@ -188,6 +189,11 @@ class OptimizationConfig:
     # same tolerances as the exact-fp32 products (labels ~1e-6, gradients ~4e-4 of the largest entry against the reference's goldens), the
     # residual step 8 % faster.  False: the exact-fp32 matrix instruction.
     mlp_split_bf16: bool = True
+    # The initial parameters (a detector's embeddings, the hypernetwork) are drawn from torch's global generator when a loop is built or reset.
+    # None: whatever state that generator is in (the reference seeds it once per rank, scripts/main.py:67-74, so a frame's start depends on the
+    # frames its rank optimised before).  An integer: the generator is seeded with it right before the draw -- a frame's result then depends on
+    # the frame alone, not on the rank, process or slot that runs it (vsrd_amd.launcher passes seed and frame number).
+    init_seed: Optional[int] = None
 
 
 def adam_state_tensors(optimizer, parameter, group):
@@ -252,9 +258,13 @@ class FrameOptimizer:
             raise ValueError("fused_glue keeps the learning rates and Adam's counters on the device: it needs graph=True")
         V, H, W, N = inputs.soft_masks.shape
         self.num_views, self.num_instances = V, N
-        self.detector = models.BoxParameters3D(1, N).to(self.device)
-        # config.json:143-156: per-instance residual MLP 48->16->16->16->16->1 generated from 256-d embeddings
-        self.hyper_distance_field = models.HyperDistanceField(48, [16, 16, 16, 16], 256, [256, 256, 256, 256]).to(self.device)
+        with _initial_draw:
+            if config.init_seed is not None:
+                torch.default_generator.manual_seed(int(config.init_seed))      # (the CPU generator: the modules are built on the host; the device generators, which captured graphs register, stay untouched)
+            detector = models.BoxParameters3D(1, N)
+            # config.json:143-156: per-instance residual MLP 48->16->16->16->16->1 generated from 256-d embeddings
+            field = models.HyperDistanceField(48, [16, 16, 16, 16], 256, [256, 256, 256, 256])
+        self.detector, self.hyper_distance_field = detector.to(self.device), field.to(self.device)
         def rate(value):   # graph mode: learning rates are device tensors decayed in place inside the captured step
             return torch.tensor(value, dtype=torch.float32, device=self.device) if self.graph else value
         groups = [dict(params=[p], lr=rate(config.learning_rate)) for p in (self.detector.locations, self.detector.dimensions, self.detector.orientations)]
@@ -779,7 +789,7 @@ class FrameOptimizer:
         self.reset(self.inputs)
         return len(self._graphs)
 
-    def reset(self, inputs: FrameInputs):
+    def reset(self, inputs: FrameInputs, init_seed=None):
         """Start ANOTHER frame of the same shape in this loop, in place: the new frame's matrices, boxes and soft masks are copied into
         the buffers the captured graphs read; parameters are re-initialised as a fresh ``BoxParameters3D`` / ``HyperDistanceField`` would
         be (scripts/main.py:106-199 builds new models per frame); Adam's moments, counters and learning rates, the step counter and the
@@ -810,8 +820,11 @@ class FrameOptimizer:
             b["visible"].copy_(inputs.visible_masks)
             self.inputs = inputs
             # ---- parameters, optimiser, counters ----
-            fresh_detector = models.BoxParameters3D(1, N)
-            fresh_field = models.HyperDistanceField(48, [16, 16, 16, 16], 256, [256, 256, 256, 256])
+            with _initial_draw:                                   # (OptimizationConfig.init_seed, for THIS frame: seed and draw as one step -- the generator is the process's,
+                if init_seed is not None:                         #  and the capture gate lets several frames' threads in here at once)
+                    torch.default_generator.manual_seed(int(init_seed))
+                fresh_detector = models.BoxParameters3D(1, N)
+                fresh_field = models.HyperDistanceField(48, [16, 16, 16, 16], 256, [256, 256, 256, 256])
             for module, fresh in ((self.detector, fresh_detector), (self.hyper_distance_field, fresh_field)):
                 for p, q in zip(module.parameters(), fresh.parameters()):
                     p.copy_(q)
