@@ -1,5 +1,8 @@
+"""Debug script (GPU box): BASELINE config 3 at full size through the fused residual step with the exact-fp32 and the split-bf16 products of the
+per-instance MLP in ONE process on the same uniforms -- losses, per-ray label differences (the share beyond 1e-4 is the conditioning tail the
+parity tests allow for) and parameter gradients side by side.  `VIEWS=1 python tools/compare_forms_debug.py` for a quick run."""
 import os, sys, torch
-ROOT = "/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bench
 from test_hip_scale import scene
