@@ -305,3 +305,22 @@ def test_procs_per_gpu_maps_consecutive_local_ranks_to_one_device(tmp_path):
     # the device a GPU rank would take
     for local, expected in ((0, 0), (1, 0), (2, 1), (3, 1)):
         assert local // 2 == expected
+
+
+def test_supervisor_ends_a_hung_attempt(tmp_path):
+    """`--stall-timeout`: a rank that HANGS (inside the runtime, on a dead GPU) exits with nothing and its peers wait in their barrier for ever;
+    the supervisor watches the checkpoint directory instead -- no new checkpoint for that long, and the attempt is ended and restarted like after
+    a dead rank.  Here rank 1 of two gloo ranks goes to sleep for ever after its first frame; the job still finishes every frame."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    command = [sys.executable, "-m", "vsrd_amd.launcher", "--selftest", "--gpus", "2", "--procs-per-gpu", "1", "--frames", "8", "--selftest-seconds", "0.1",
+               "--selftest-hang", "1:1", "--stall-timeout", "4", "--max-restarts", "1", "--out", str(tmp_path)]
+    out = subprocess.run(command, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "no checkpoint for 4 s" in out.stderr and "starting the ranks again" in out.stderr
+    line = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    assert line["restarts"] == 1 and line["frames"] + line["frames_skipped_as_done"] == 8 and line["frames_skipped_as_done"] >= 4
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("frame_")) == [f"frame_{k:06d}" for k in range(8)]

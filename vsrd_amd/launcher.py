@@ -145,13 +145,24 @@ def synthetic_frame_inputs(device, frame, views, instances, height=376, width=14
     return optimization.FrameInputs((height, width), K, E, soft, gt_boxes, torch.ones(views, instances, dtype=torch.bool, device=device))
 
 
-def _wait_for_ranks(children, grace_seconds=10.0):
+def _newest_change(folder):
+    """Modification time of the newest entry of the checkpoint directory: a frame's folder changes when its checkpoint is renamed into it."""
+    try:
+        return max((entry.stat().st_mtime for entry in os.scandir(folder)), default=0.0)
+    except OSError:
+        return 0.0
+
+
+def _wait_for_ranks(children, grace_seconds=10.0, progress_folder=None, stall_seconds=0.0):
     """Poll the ranks until all have exited.  The first rank that exits non-zero takes the others with it (SIGTERM, SIGKILL after
     `grace_seconds`): a rank whose peer died would otherwise sit in its final barrier until the collective's watchdog fires, tens of
-    minutes later.  Returns None when every rank exited 0, else (rank, exit code) of the first failure."""
+    minutes later.  `stall_seconds` > 0: an attempt during which NO checkpoint appears in `progress_folder` for that long (counted from the
+    attempt's start) ends the same way -- a rank that hangs inside the runtime exits with nothing, and its peers wait for it for ever.
+    Returns None when every rank exited 0, else (rank, exit code) of the first failure ((-1, 124) for a stall)."""
     import time
     pending = dict(enumerate(children))
     failed, deadline = None, None
+    started = time.time()
     while pending:
         for rank, child in list(pending.items()):
             code = child.poll()
@@ -162,6 +173,10 @@ def _wait_for_ranks(children, grace_seconds=10.0):
                 failed, deadline = (rank, code), time.monotonic() + grace_seconds
                 for other in pending.values():
                     other.terminate()
+        if failed is None and pending and stall_seconds > 0 and time.time() - max(started, _newest_change(progress_folder)) > stall_seconds:
+            failed, deadline = (-1, 124), time.monotonic() + grace_seconds
+            for other in pending.values():
+                other.terminate()
         if failed is not None and pending and time.monotonic() > deadline:
             for other in pending.values():
                 other.kill()
@@ -188,8 +203,9 @@ def _supervise(argv, args):
     if not args.ranks_share_gpu and not args.selftest and torch.cuda.device_count() < args.gpus:
         raise SystemExit(f"vsrd_amd.launcher --gpus {args.gpus}: this node has {torch.cuda.device_count()} visible GPU(s)")
     ranks = args.gpus * args.procs_per_gpu
+    out_dir = args.out or tempfile.mkdtemp(prefix="vsrd_frames_")
     if not args.out:
-        argv = list(argv) + ["--out", tempfile.mkdtemp(prefix="vsrd_frames_")]
+        argv = list(argv) + ["--out", out_dir]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     failed = None
     for attempt in range(args.max_restarts + 1):
@@ -201,11 +217,12 @@ def _supervise(argv, args):
             env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(ranks), LOCAL_WORLD_SIZE=str(ranks), MASTER_ADDR="127.0.0.1",
                        MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
             children.append(subprocess.Popen([sys.executable, "-m", "vsrd_amd.launcher", *argv, "--attempt", str(attempt)], env=env, cwd=root))
-        failed = _wait_for_ranks(children)
+        failed = _wait_for_ranks(children, progress_folder=out_dir, stall_seconds=args.stall_timeout)
         if failed is None:
             return 0
         again = attempt < args.max_restarts
-        print(f"[vsrd_amd.launcher] attempt {attempt}: rank {failed[0]} exited with code {failed[1]}; "
+        print(f"[vsrd_amd.launcher] attempt {attempt}: " + (f"no checkpoint for {args.stall_timeout:g} s (--stall-timeout): the ranks were ended; " if failed[0] < 0 else
+                                                           f"rank {failed[0]} exited with code {failed[1]}; ")
               + ("starting the ranks again as fresh processes (frames with a final checkpoint are skipped)" if again else "no restarts left"),
               file=sys.stderr, flush=True)
     return abs(failed[1]) or 1
@@ -290,6 +307,7 @@ class _SleepWork:
     def __init__(self, args, manifest, rank):
         self.args, self.manifest, self.rank = args, manifest, rank
         self.fail_rank, self.fail_after = (int(v) for v in args.selftest_fail.split(":")) if args.selftest_fail else (-1, 0)
+        self.hang_rank, self.hang_after = (int(v) for v in args.selftest_hang.split(":")) if args.selftest_hang else (-1, 0)
 
     def path_of(self, frame):
         return os.path.join(self.manifest["out"], f"frame_{int(frame):06d}", "step_final.pt")
@@ -305,6 +323,8 @@ class _SleepWork:
         def optimise(frame):
             if args.attempt == 0 and self.rank == self.fail_rank and len(finished) >= self.fail_after:
                 os._exit(23)
+            if args.attempt == 0 and self.rank == self.hang_rank and len(finished) >= self.hang_after:
+                time.sleep(1.0e6)
             time.sleep(args.selftest_seconds)
             finished.append(frame)
             with open(os.path.join(self.manifest["out"], "completed.log"), "a") as log:      # (O_APPEND: one short line per frame, whole)
@@ -356,12 +376,16 @@ def main(argv=None):
     parser.add_argument("--max-restarts", type=int, default=2,
                         help="without torchrun around it, the launcher supervises its ranks: when one dies, all are started again as fresh "
                              "processes, this many times at most; finished frames are skipped (0 with --gpus 1: no supervisor process)")
+    parser.add_argument("--stall-timeout", type=float, default=0.0,
+                        help="supervisor: seconds without a new checkpoint (from an attempt's start; start-up, input set-up and the first frame count) after "
+                             "which the ranks are taken for hung, ended and restarted like after a dead rank; 0 = never (the default)")
     parser.add_argument("--attempt", type=int, default=0, help=argparse.SUPPRESS)          # set by the supervisor: restarts so far
     parser.add_argument("--selftest", action="store_true",
                         help="no rendering, no GPU: a frame is a sleep of --selftest-seconds and a small checkpoint (gloo, CPU) -- the supervisor, "
                              "the sharding, the rank -> device map, the skip-if-done guard and the report, for tests/test_launcher.py; the line says so")
     parser.add_argument("--selftest-seconds", type=float, default=0.05)
     parser.add_argument("--selftest-fail", default="", help="RANK:FRAMES -- on attempt 0 that rank dies (exit code 23) once it has finished FRAMES frames")
+    parser.add_argument("--selftest-hang", default="", help="RANK:FRAMES -- on attempt 0 that rank hangs (sleeps for ever) once it has finished FRAMES frames")
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parser.parse_args(argv)
     if not 1 <= args.frames_in_flight <= (4 if args.fresh_loops else 8):
