@@ -111,6 +111,30 @@ def test_bench_spawns_its_own_ranks_and_reports_what_ran():
         assert not [l for l in refused.stdout.splitlines() if l.startswith("{")]
 
 
+def test_bench_under_the_drivers_torchrun_command():
+    """The driver's own launch line for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` -- with the render step replaced by a sleep (--launcher-selftest, gloo, CPU): the
+    script is a rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), nothing is spawned twice, rank 0 prints ONE line with
+    `n_gpus` = N ranks through the barriers, K steps, and the slowest rank's time."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--launcher-selftest"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and len(line["per_rank_ms_per_step"]) == 2
+    assert line["ms_per_step"] >= max(line["per_rank_ms_per_step"]) - 0.2 and "NOT a measurement" in line["metric"]
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_with_the_real_step_on_one_gpu():
     """The multi-rank path of bench.py with the REAL render step: two ranks spawned by bench.py itself, both on
