@@ -135,6 +135,29 @@ def test_bench_under_the_drivers_torchrun_command():
     assert line["ms_per_step"] >= max(line["per_rank_ms_per_step"]) - 0.2 and "NOT a measurement" in line["metric"]
 
 
+def test_frame_launcher_under_torchrun(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 4 bench.py --native --gpus 2 --procs-per-gpu 2 --selftest ...`: under a launcher the
+    frames/s entry point is a rank (no supervisor of its own: torchrun's --max-restarts plays that part), --nproc-per-node = GPUs x processes
+    per GPU, local ranks 0, 1 take device 0 and 2, 3 device 1, and rank 0 prints the one line."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "bench.py"), "--native", "--gpus", "2", "--procs-per-gpu", "2", "--selftest", "--frames", "9", "--selftest-seconds", "0.05",
+                          "--out", str(tmp_path)], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["ranks"] == 4 and line["rank_devices"] == [0, 0, 1, 1] and line["frames"] == 9 and line["restarts"] == 0
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("frame_")) == [f"frame_{k:06d}" for k in range(9)]
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_with_the_real_step_on_one_gpu():
     """The multi-rank path of bench.py with the REAL render step: two ranks spawned by bench.py itself, both on
