@@ -449,16 +449,7 @@ def _rank_main(args):
 
     fence()
     t0 = time.perf_counter()
-    # experiment switch: VSRD_RANK_STREAM="a,b,..." -- rank r runs its frames on the (list[r] + 1)-th stream it creates (0: the default stream)
-    pick = os.environ.get("VSRD_RANK_STREAM", "")
-    which = int(pick.split(",")[rank % len(pick.split(","))]) if (pick and use_gpu) else 0
-    if which > 0:
-        streams = [torch.cuda.Stream(device=device) for _ in range(which)]
-        with torch.cuda.stream(streams[-1]):
-            report = work.run()
-            streams[-1].synchronize()
-    else:
-        report = work.run()
+    report = work.run()
     own = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
