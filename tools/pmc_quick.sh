@@ -14,7 +14,7 @@ import csv, sys, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(path)):
-        if "vsrd::" in r["Kernel_Name"]:
+        if "vsrd::" in r["Kernel_Name"] or "vsrd_split::" in r["Kernel_Name"]:
             acc[r["Kernel_Name"].split("(")[0][:80]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in acc.items():
     print(k)
