@@ -34,6 +34,8 @@ FP32_PEAK_TF = 157.3        # MI355X_MICROARCH.md: peak FP32 vector = dense FP32
 PEAK_CLOCK_HZ = 2.4e9
 NUM_SIMDS = 1024
 MFMA_16X16X4_FLOP = 2048    # one v_mfma_f32_16x16x4_f32 wave instruction: 16 x 16 x 4 multiply-adds
+MFMA_16X16X32_BF16_FLOP = 16384   # one v_mfma_f32_16x16x32_bf16 wave instruction (the vsrd_split:: kernels of split_front.hip: every MFMA they issue)
+BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 
 SCHEDULES = {"start": 0.0, "mid": 0.5, "end": 1.0}   # fraction of the 3000 optimisation steps
 BASELINE_METRIC = "rendered rays/sec (fwd+bwd) per GPU, KITTI-360 376×1408, 16 instances"   # BASELINE.json:metric
@@ -274,34 +276,59 @@ def committed_counters(kernel_symbols, key):
                         total[counter] = total.get(counter, 0.0) + value
         if used:
             total["kernels"] = used
+            # the matrix instructions of a step by kind: the kernels of split_front.hip (namespace vsrd_split) execute v_mfma_f32_16x16x32_bf16
+            # only when launched with VSRD_FLAG_MLP_SPLIT_BF16 -- the only way they are launched (their residual_forward keeps the fp32 form
+            # behind a wave-uniform branch on kMlpSplitBit that is never taken; `hipcc -S --cuda-device-only split_front.hip | grep v_mfma`:
+            # residual_mlp_adjoint_split_kernel 72 bf16 / 0 fp32) -- every other kernel of the library v_mfma_f32_16x16x4_f32 only
+            per_kernel = {name: data["kernels"][name].get("SQ_INSTS_MFMA_per_step", data["kernels"][name].get("SQ_INSTS_MFMA", 0.0)) for name in used}
+            total["mfma_bf16_16x16x32"] = sum(v for name, v in per_kernel.items() if "vsrd_split::" in name)
+            total["mfma_f32_16x16x4"] = sum(v for name, v in per_kernel.items() if "vsrd_split::" not in name)
             return total, os.path.relpath(path, ROOT)
     return None, None
 
 
 def executed_view(counters, launch_ms):
-    """Hardware view of one launch from its PMC counters (wave-instruction counts) and the live launch duration."""
+    """Hardware view of one step from its PMC counters (wave-instruction counts summed over the step's kernels) and the live step duration.
+    Two pipes, two peaks: fp32 vector arithmetic against the 157.3 TFLOP/s vector peak, matrix instructions priced BY INSTRUCTION --
+    v_mfma_f32_16x16x4_f32 = 2 048 flop against the same 157.3 (it runs on the vector datapath), v_mfma_f32_16x16x32_bf16 = 16 384 flop
+    against the dense bf16 peak of 2.5 PFLOP/s."""
     if not counters or "SQ_INSTS_VALU" not in counters:
         return None
     seconds = launch_ms * 1e-3
     fma, mul, add = (counters.get(k, 0.0) for k in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32"))
     trans = counters.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
     mfma = counters.get("SQ_INSTS_MFMA", counters.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0))
+    mfma_bf16 = counters.get("mfma_bf16_16x16x32", 0.0)
+    mfma_f32 = counters.get("mfma_f32_16x16x4", mfma - mfma_bf16)
     valu_flop = (2.0 * fma + mul + add + trans) * 64.0
-    mfma_flop = mfma * MFMA_16X16X4_FLOP
-    # a wave64 fp32 VALU instruction occupies its SIMD's issue port for 2 cycles at peak (32 lanes/clk); MFMA 16x16x4 f32: 8 passes x 4 clk
+    f32_flop, bf16_flop = mfma_f32 * MFMA_16X16X4_FLOP, mfma_bf16 * MFMA_16X16X32_BF16_FLOP
+    simd_cycles = NUM_SIMDS * PEAK_CLOCK_HZ * seconds
+    # a wave64 fp32 VALU instruction occupies its SIMD's issue port for 2 cycles at peak (32 lanes/clk); MFMA 16x16x4 f32: 8 passes x 4 clk;
+    # MFMA 16x16x32 bf16: 17-19 cycles measured (profiles/r05/mfma_bf16_overlap.txt)
     valu_slots = counters["SQ_INSTS_VALU"] - mfma
-    return {"valu_tflops": valu_flop / seconds / 1e12, "mfma_tflops": mfma_flop / seconds / 1e12,
-            "tflops": (valu_flop + mfma_flop) / seconds / 1e12, "frac": (valu_flop + mfma_flop) / seconds / 1e12 / FP32_PEAK_TF,
-            "valu_issue_utilisation": 2.0 * valu_slots / (NUM_SIMDS * PEAK_CLOCK_HZ * seconds),
-            # what the SIMDs spent per vector instruction (MFMA time, 32 cycles each, taken off), next to what a stream of plain
+    matrix_cycles = 32.0 * mfma_f32 + 18.0 * mfma_bf16
+    view = {"valu_tflops": valu_flop / seconds / 1e12, "valu_frac_of_fp32_vector_peak": valu_flop / seconds / 1e12 / FP32_PEAK_TF,
+            "mfma_f32_tflops": f32_flop / seconds / 1e12, "mfma_bf16_tflops": bf16_flop / seconds / 1e12,
+            "mfma_bf16_frac_of_bf16_peak": bf16_flop / seconds / 1e12 / BF16_MFMA_PEAK_TF, "bf16_peak_tflops": BF16_MFMA_PEAK_TF,
+            "mfma_tflops": (f32_flop + bf16_flop) / seconds / 1e12,
+            # the fp32 datapath (vector arithmetic + the fp32 matrix instruction, which shares it) against its 157.3 TFLOP/s
+            "tflops": (valu_flop + f32_flop) / seconds / 1e12, "frac": (valu_flop + f32_flop) / seconds / 1e12 / FP32_PEAK_TF,
+            "valu_issue_utilisation": 2.0 * valu_slots / simd_cycles,
+            # what the SIMDs spent per vector instruction (matrix time taken off), next to what a stream of plain
             # multiply-adds costs at four waves per SIMD on this part (profiles/r01/op_rates.txt: 2.7-3.0, not the nominal 2)
-            "cycles_per_valu_instruction": max(NUM_SIMDS * PEAK_CLOCK_HZ * seconds - 32.0 * mfma, 0.0) / max(valu_slots, 1.0),
+            "cycles_per_valu_instruction": max(simd_cycles - matrix_cycles, 0.0) / max(valu_slots, 1.0),
             "measured_cycles_per_plain_fma": 2.9,
-            "mfma_utilisation": mfma_flop / seconds / 1e12 / FP32_PEAK_TF,
+            "mfma_utilisation": f32_flop / seconds / 1e12 / FP32_PEAK_TF,
             "fma_share_of_fp32_ops": fma / max(fma + mul + add, 1.0),
             "valu_wave_instructions": counters["SQ_INSTS_VALU"], "mfma_wave_instructions": mfma,
+            "mfma_f32_16x16x4_wave_instructions": mfma_f32, "mfma_bf16_16x16x32_wave_instructions": mfma_bf16,
             "lds_bank_conflict_share": (counters["SQ_LDS_BANK_CONFLICT"] / counters["SQ_LDS_IDX_ACTIVE"]
                                         if counters.get("SQ_LDS_IDX_ACTIVE") else None)}
+    if counters.get("SQ_ACTIVE_INST_VALU"):
+        # SQ_ACTIVE_INST_VALU counts, per SIMD, the quad-cycles in which a vector instruction (matrix ones included) is being issued:
+        # x 4 over the step's SIMD-cycles = the share of time the vector issue port is busy
+        view["valu_active_fraction"] = 4.0 * counters["SQ_ACTIVE_INST_VALU"] / simd_cycles
+    return view
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -487,8 +514,8 @@ def step_kernel_symbols(args, fused):
     if not fused:
         return None, None
     if args.residual:
-        return "vsrd_render_residual_step", ["residual_step_front_kernel", "residual_step_pair_kernel", "residual_mlp_adjoint_kernel",
-                                             "render_residual_step_kernel", "reduce_item_rows_kernel", "reduce_item_segments_kernel"]
+        return "vsrd_render_residual_step", ["residual_step_front_kernel", "residual_step_pair_kernel", "residual_mlp_adjoint",      # (..._kernel and vsrd_split::..._split_kernel)
+                                             "render_residual_step_kernel", "reduce_item_rows_kernel", "reduce_item_segments_kernel", "pack_mlp_images_kernel"]
     from vsrd_amd.rendering import renderers
     dense = not renderers.STEP_WAVE_PER_RAY                              # api.hip: vsrd_render_silhouette_step
     if dense and S <= 64 and N <= 16:
@@ -530,12 +557,19 @@ def rooflines(args, kernels, R, fused):
     mlp_flop = (3 * S - 2) * N * 2 * 1617 * 9 if args.residual else 0.0
     total_ms = fwd_ms + bwd_ms
     achieved_gbs = R * dom_bytes / (dom_ms * 1e-3) / 1e9
+    # SURVEY.md section 8d's API-faithful figure: B_api = 24 + 12 N for the two-launch path, + 24 (2S - 1) when the eikonal gradients cross the
+    # boundary (config 3: 3 264 B per ray at N = 16, S = 64); `traffic_over_api_bytes` is the PMC traffic of a step against it
+    api_bytes = 24 + 12 * N + (24 * (2 * S - 1) if args.residual else 0)
     hbm = {"bound": "hbm", "kernel": dominant, "kernels": counters.get("kernels") if counters else symbols, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
            "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source, "algorithmic_bytes_per_ray": dom_bytes,
            "launch_ms": dom_ms, "traffic_bytes_per_ray": traffic / R if traffic else None,
+           "api_faithful_bytes_per_ray": api_bytes, "traffic_over_api_bytes": traffic / (R * api_bytes) if traffic else None,
+           "traffic_over_algorithmic_bytes": traffic / (R * dom_bytes) if traffic else None,
            "note": "the fused path is compute bound (arithmetic intensity ~1e4 flop/B), not HBM bound (SURVEY.md §8d); see roofline_valu"}
     model_tf = R * (box_flop + mlp_flop) / (total_ms * 1e-3) / 1e12
-    valu = {"bound": "fp32 VALU + MFMA (one datapath, 157.3 TFLOP/s)" if args.residual else "fp32-valu",
+    valu = {"bound": ("fp32 VALU (157.3 TFLOP/s); the matrix products on bf16 MFMA are priced against the 2.5 PFLOP/s bf16 peak in `executed`"
+                      if args.residual and args.mlp_split_bf16 else
+                      "fp32 VALU + fp32 MFMA (one datapath, 157.3 TFLOP/s)" if args.residual else "fp32-valu"),
             "achieved": executed["tflops"] if executed else None, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": executed["frac"] if executed else None,
             "basis": ("executed flops: committed PMC counters of this workload (per step, all kernels of the step) / live step duration" if executed
                       else "no committed counters for this workload: no utilisation figure (see work_equivalent_tflops)"),
@@ -571,8 +605,14 @@ def extra_regimes():
             small["schedule"] = record["config"].get("schedule")
         for key in ("roofline", "roofline_valu"):
             if key in record:
-                small[key] = {k: record[key].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "work_equivalent_tflops", "launch_ms")
+                small[key] = {k: record[key].get(k) for k in ("bound", "kernel", "kernels", "achieved", "peak", "unit", "frac", "traffic", "work_equivalent_tflops",
+                                                              "launch_ms", "traffic_over_api_bytes", "api_faithful_bytes_per_ray", "executed_source")
                               if k in record[key]}
+                executed = record[key].get("executed")
+                if executed:       # the utilisation figures a reader recomputes from profiles/: both pipes against their own peaks
+                    small[key]["executed"] = {k: executed.get(k) for k in ("valu_tflops", "valu_frac_of_fp32_vector_peak", "mfma_f32_tflops", "mfma_bf16_tflops",
+                                                                           "mfma_bf16_frac_of_bf16_peak", "valu_active_fraction", "valu_issue_utilisation",
+                                                                           "mfma_f32_16x16x4_wave_instructions", "mfma_bf16_16x16x32_wave_instructions")}
         small["command"] = "python " + " ".join(cmd)
         small["wall_s"] = round(time.time() - t0, 1)
         return small

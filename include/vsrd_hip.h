@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VSRD_ABI_VERSION 7
+#define VSRD_ABI_VERSION 8
 
 #define VSRD_OK 0
 #define VSRD_E_INVALID_ARGUMENT (-1) /* null pointer, non-positive size, unsupported N / S */
@@ -39,6 +39,26 @@ extern "C" {
 #define VSRD_MAX_SAMPLES 256   /* S, num_samples of hierarchical_volumetric_rendering      */
 #define VSRD_INSTANCE_STRIDE 16 /* floats per packed instance: t[3] R[9] (row-major) dim[3] pad */
 #define VSRD_MLP_WEIGHTS 1617  /* per-instance residual MLP, hyper_distance_field.py:18-25 */
+
+/* ---- frame batches (ABI 8) --------------------------------------------------------------------------------------------------
+ * The reference's unit of work is one target frame optimised for 3000 steps of 1000 rays (scripts/main.py:323-865), and its loop carries
+ * a batch dimension: BoxParameters3D(batch_size, num_instances) (vsrd/models/detectors/box_parameters.py:34-49), lists over the batch
+ * of distance fields, camera positions, ray directions and soft masks (scripts/main.py:525-651).  One frame's launches leave most of the
+ * GPU idle (about one wave per SIMD), so the entry points of the per-frame step take a batch of INDEPENDENT frames in one launch each:
+ *
+ *     num_frames   B >= 2 (0 or 1: one frame, the meaning of every earlier ABI);
+ *     frame_stride bytes, a positive multiple of 256: EVERY device pointer of the call -- arguments, struct members, workspaces --
+ *                  addresses frame 0's buffer, and frame f's buffer lies f * frame_stride bytes behind it.
+ *
+ * The caller keeps each frame's buffers at the same offsets of one arena row per frame.  By-value arguments (sizes, seeds, flags, Adam's
+ * constants) are shared; per-frame state (parameters, Adam's moments and counters, learning rates, the step counter that keys the Philox
+ * streams, schedules, ray tables, scratch) lies behind the pointers and is therefore the frame's own.  There is no arithmetic across
+ * frames: frame f's results are BIT-IDENTICAL to those of the same call on frame f alone (the launch is B copies of the one-frame grid,
+ * tests/test_hip_step.py::test_frame_batch_walks_each_frames_own_trajectory).
+ * The fields sit at the end of vsrd_render_config, vsrd_frame_config and vsrd_hypernetwork.  Entry points that accept B >= 2:
+ * vsrd_frame_prologue, vsrd_frame_prologue_sample, vsrd_frame_epilogue, vsrd_hypernetwork_forward, vsrd_hypernetwork_backward_step,
+ * vsrd_render_silhouette_step (gathered launches in the split-ray form: at most 2048 rays per frame) and vsrd_render_residual_step
+ * (two-kernel form, one chunk of rays per frame); every other entry point returns VSRD_E_UNSUPPORTED for B >= 2. */
 
 /* Field = temperature soft-min union of N oriented boxes (+ optional residual MLP).
  * Replaces the closure tree scripts/main.py:525-618 builds from
@@ -89,6 +109,9 @@ typedef struct vsrd_render_config {
     float* out_coarse_weights;             /* [R,S-1] or NULL: pass 1's compositing weights                           */
     float* out_u_coarse;                   /* [R,S] or NULL: the stratified uniforms used                            */
     float* out_u_fine;                     /* [R,S] or NULL: the fine uniforms used (SORTED when drawn in the kernel) */
+    /* Frame batch (ABI 8, see "frame batches" above): num_rays etc. are PER FRAME. */
+    int32_t num_frames;                    /* 0 or 1: one frame                                                       */
+    int64_t frame_stride;                  /* bytes between the frames' copies of every buffer of the call            */
 } vsrd_render_config;
 
 #define VSRD_FLAG_FINE_UNIFORMS_SORTED 1u /* u_fine is already sorted ascending per ray     */
@@ -357,6 +380,8 @@ typedef struct vsrd_frame_config {
     float weight_iou, weight_l1, weight_silhouette;             /* config.json:120-127                                        */
     float beta1, beta2, adam_epsilon; /* torch.optim.Adam defaults 0.9, 0.999, 1e-8                                           */
     float lr_gamma;                 /* ExponentialLR gamma (config.json:209-215)                                              */
+    int32_t num_frames;             /* frame batch (ABI 8, "frame batches" above): 0 or 1 = one frame                         */
+    int64_t frame_stride;           /* bytes between the frames' copies of every buffer of the call                           */
 } vsrd_frame_config;
 
 size_t vsrd_frame_scratch_bytes(int32_t num_views, int32_t num_boxes);
@@ -424,6 +449,8 @@ typedef struct vsrd_hypernetwork {
     vsrd_adam_tensors bias[VSRD_HYPER_LAYERS];
     vsrd_adam_tensors norm_weight[VSRD_HYPER_LAYERS - 1];    /* LayerNorm gamma [256]                                         */
     vsrd_adam_tensors norm_bias[VSRD_HYPER_LAYERS - 1];
+    int32_t num_frames;                                      /* frame batch (ABI 8, "frame batches" above): every frame its OWN hypernetwork, */
+    int64_t frame_stride;                                    /* embeddings and Adam state, frame_stride bytes apart                           */
 } vsrd_hypernetwork;
 
 size_t vsrd_hypernetwork_workspace_bytes(int32_t num_instances);
@@ -443,6 +470,13 @@ int32_t vsrd_hypernetwork_backward_step(const vsrd_hypernetwork* net, void* work
  * LayerNorm (hyper_distance_field.py:57-73) every column, bias column included, has its mean over the 16 output channels removed.
  * LayerNorm makes the field invariant to it, and the adjoints w.r.t. the centred weights are the adjoints w.r.t. the originals. */
 int32_t vsrd_centre_mlp_weights(const float* mlp_weights, int32_t num_instances, float* centred, void* stream);
+
+/* ---- self-tests of device building blocks (used by tests/, not by the product path) --------------------------------------------
+ * vsrd_selftest_wave: the wave64 primitives of csrc/wave.h (sums, scans, the reduce-scatter butterflies) on one wave: in64 [64] ->
+ * out [576].  vsrd_selftest_gelu: erf_gelu / erf_gelu_derivative of csrc/hypernetwork.h at n points: out[0..n) values, out[n..2n)
+ * derivatives (the hypernetwork's exact GELU, hyper_distance_field.py:38-41). */
+int32_t vsrd_selftest_wave(const float* in64, float* out576, void* stream);
+int32_t vsrd_selftest_gelu(const float* x, int32_t n, float* out, void* stream);
 
 #ifdef __cplusplus
 }

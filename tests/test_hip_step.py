@@ -648,6 +648,95 @@ def test_frame_slot_reuses_its_graphs_for_the_next_frame(dev):
     slot.close()
 
 
+def test_frame_batch_walks_each_frames_own_trajectory(dev):
+    """Frame batches (the reference's batch dimension: scripts/main.py:525-651 builds its distance fields, camera
+    positions, ray directions and soft masks as lists over the batch, BoxParameters3D(batch_size, num_instances) -- box_parameters.py:34-49):
+    optimization.FrameBatch runs B frames in lock-step with ONE launch of every kernel of a step for all of them (include/vsrd_hip.h,
+    "frame batches": B copies of the one-frame grid, every pointer frame_stride bytes x f further).  Each frame keeps its own detector,
+    hypernetwork, Adam state, rates, step counter (= Philox key), sampling table and scratch, so each frame of a batch of four must walk,
+    BIT FOR BIT, the trajectory it walks alone in a frame slot -- over the phase switch, with the one-step and the four-step graphs, for
+    two groups of frames in a row (reset), and for a last group of three frames (active < B)."""
+    from vsrd_amd import optimization
+    frames = [_c1_inputs(dev, all_visible=True, seed=k) for k in range(7)]
+    config = optimization.OptimizationConfig(num_samples=32, num_rays=128, warmup_steps=9, num_steps=40, seed=3)
+    steps = 26
+
+    def state_of(loop):
+        tensors = [loop.detector.locations, loop.detector.dimensions, loop.detector.orientations, loop.detector.embeddings, *loop.hyper_distance_field.parameters()]
+        tensors += [loop.optimizer.state[loop.detector.locations]["exp_avg"], loop.optimizer.state[loop.detector.embeddings]["exp_avg_sq"],
+                    loop.optimizer.param_groups[0]["lr"], loop.optimizer.param_groups[4]["lr"], loop._glue["record"], loop._glue["raw_gradients"], loop._glue["ray_indices"]]
+        return [t.detach().clone() for t in tensors]
+
+    # every frame alone, in a frame slot (what the launcher ran before round 6)
+    slot = optimization.FrameOptimizer(frames[0], config, dev, graph=True, persistent=True)
+    slot.capture_all()
+    alone = []
+    for k, inputs in enumerate(frames):
+        assert slot.reset(inputs, init_seed=50 + k)
+        slot.run(steps)
+        torch.cuda.synchronize()
+        assert slot.step_index == steps
+        alone.append(state_of(slot))
+    slot.close()
+    assert not torch.equal(alone[0][0], alone[1][0])                          # (the frames ARE different problems)
+
+    batch = optimization.FrameBatch(frames[:4], config, dev, init_seeds=[50, 51, 52, 53])
+    assert batch.arena.stride % 256 == 0 and all(row.layout == batch.arena.rows[0].layout for row in batch.arena.rows)
+    held = batch.capture_all(actives=[4, 3])
+    assert held == 8 and sorted(batch._graphs) == sorted((phase, active, k) for phase in (False, True) for active in (3, 4) for k in (1, 4))
+    gate = optimization.exclusive_device_access()
+    captured_for = gate.capture_seconds
+    worst = 0
+    for group, active in (([0, 1, 2, 3], 4), ([4, 5, 6], 3)):
+        for row, k in enumerate(group):
+            assert batch.reset(row, frames[k], init_seed=50 + k)
+        batch.run(steps, active=active)
+        torch.cuda.synchronize()
+        for row, k in enumerate(group):
+            member = batch.frames[row]
+            assert member.step_index == steps and int(member.step_tensor) == steps
+            for index, (a, b) in enumerate(zip(state_of(member), alone[k])):
+                assert torch.equal(a, b), (k, index, float((a.double() - b.double()).abs().max()))
+            worst = max(worst, float(batch.outputs(row)["loss"]))
+    assert gate.capture_seconds == captured_for and len(batch._graphs) == 8   # a group of frames in a captured batch captures nothing
+    margin("test_frame_batch_walks_each_frames_own_trajectory", "batched frames vs each alone: differing tensors (7 frames, 26 steps)", 0.0, 0.0)
+    # the batch refuses what would silently break the layout: a replaced parameter tensor
+    member = batch.frames[1]
+    member.detector.locations.data = member.detector.locations.data.clone()
+    assert batch.reset(0, frames[0], init_seed=50) and batch.reset(1, frames[1], init_seed=51) and batch.reset(2, frames[2], init_seed=52) and batch.reset(3, frames[3], init_seed=53)
+    with pytest.raises(RuntimeError, match="REPLACED"):
+        batch._step(4)
+    batch.close()
+
+
+def test_frame_batch_entry_points_reject_what_they_do_not_batch(dev):
+    """include/vsrd_hip.h, "frame batches": only the per-frame step entry points take num_frames >= 2, and only with a stride that is a
+    positive multiple of 256 bytes; the others answer VSRD_E_UNSUPPORTED, a malformed stride VSRD_E_INVALID_ARGUMENT."""
+    from vsrd_amd import _lib
+    lib = _lib.load()
+    N, S, R = 4, 32, 64
+    instances = torch.zeros(N, 16, device=dev)
+    instances[:, 3] = instances[:, 7] = instances[:, 11] = 1.0
+    instances[:, 12:15] = 1.0
+    field = _lib.make_field(instances, 0.5)
+    rays = torch.zeros(R, 3, device=dev); rays[:, 2] = 1.0
+    labels = torch.zeros(R, N, device=dev)
+    distances = torch.zeros(R, 2 * S, device=dev)
+    batched = _lib.make_config(R, S, (0.0, 100.0), 0.5, 0.5, 1.0e-6, 3, frames=(2, 4096))
+    assert lib.vsrd_render_hierarchical_forward(field, batched, _lib.ptr(rays), _lib.ptr(rays), None, None, _lib.ptr(labels), _lib.ptr(distances), None, None, None,
+                                                None, None, _lib.stream()) == _lib.E_UNSUPPORTED
+    workspace = torch.empty(lib.vsrd_workspace_bytes(N, 0), dtype=torch.uint8, device=dev)
+    loss, grads = torch.zeros(1, device=dev), torch.zeros(N, 16, device=dev)
+    odd = _lib.make_config(R, S, (0.0, 100.0), 0.5, 0.5, 1.0e-6, 3, frames=(2, 1000))
+    assert lib.vsrd_render_silhouette_step(field, odd, _lib.ptr(rays), _lib.ptr(rays), None, None, _lib.ptr(labels), None, 1.0, workspace.data_ptr(), workspace.numel(),
+                                           _lib.ptr(loss), _lib.ptr(grads), None, _lib.stream()) == _lib.E_INVALID_ARGUMENT
+    # a dense launch (four rays per wave) is not a batched form
+    dense = _lib.make_config(R, S, (0.0, 100.0), 0.5, 0.5, 1.0e-6, 3, frames=(2, 1 << 30), flags=_lib.FLAG_STEP_WAVE_PER_RAY)
+    assert lib.vsrd_render_silhouette_step(field, dense, _lib.ptr(rays), _lib.ptr(rays), None, None, _lib.ptr(labels), None, 1.0, workspace.data_ptr(), workspace.numel(),
+                                           _lib.ptr(loss), _lib.ptr(grads), None, _lib.stream()) == _lib.E_UNSUPPORTED
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("how", ["state_dict_clone", "checkpoint_view", "module_to_assign"])
 def test_rebind_after_tensors_are_replaced_mid_frame(dev, how):
     """The captured graphs and the kernels' pointer blocks hold raw addresses of parameters, Adam's moments / counters and the learning

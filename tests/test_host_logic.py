@@ -29,6 +29,11 @@ def test_header_symbols_are_exported(lib):
     assert declared == set(_lib.SIGNATURES), "ctypes binding and header disagree"
     for name in declared:
         assert getattr(lib, name) is not None
+    # ... and the converse: the library exports no vsrd_* symbol the header does not declare (nm -D; the debug build's phase clocks aside)
+    import subprocess
+    exported = {line.split()[-1] for line in subprocess.run(["nm", "-D", "--defined-only", _lib.LIBRARY_PATH], capture_output=True, text=True, check=True).stdout.splitlines()
+                if line.split()[-1].startswith("vsrd_") and " T " in line}
+    assert exported - {"vsrd_debug_phase_cycles"} == declared, exported ^ declared
     assert lib.vsrd_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define VSRD_ABI_VERSION (\d+)", header).group(1))
     assert lib.vsrd_workspace_bytes(16, 0) == 16384 * 4 * 16 * 16 * 4
     # box partials + per-wave MLP partials (512 workgroups x 2 waves) + residual jets [wave][4 rounds][N][64] float4 + seeds [wave][8 rays][4][N][10][64]
@@ -37,19 +42,30 @@ def test_header_symbols_are_exported(lib):
     assert lib.vsrd_error_string(-1) == b"invalid argument"
 
 
-def test_struct_layout_matches_header():
+def test_struct_layout_matches_header(tmp_path):
+    """The ctypes structures against the C compiler's view of include/vsrd_hip.h itself (gcc: sizeof / offsetof of every member that
+    matters), not against numbers copied into the test."""
+    import subprocess
     from vsrd_amd import _lib
-    assert ctypes.sizeof(_lib.Field) == 24                      # int32, float, 2 pointers
-    assert _lib.Field.instances.offset == 8 and _lib.Field.mlp_weights.offset == 16
-    assert ctypes.sizeof(_lib.RenderConfig) == 136              # + ray_indices, rays_per_origin, target_columns, target_stride (ABI 3), out_* (ABI 7)
-    assert _lib.RenderConfig.out_distances.offset == 104 and _lib.RenderConfig.out_u_fine.offset == 128
-    assert _lib.RenderConfig.ray_indices.offset == 72 and _lib.RenderConfig.rays_per_origin.offset == 80
-    assert _lib.RenderConfig.target_columns.offset == 88 and _lib.RenderConfig.target_stride.offset == 96
-    assert ctypes.sizeof(_lib.FrameConfig) == 116 and _lib.FrameConfig.num_steps.offset == 68 and _lib.FrameConfig.lr_gamma.offset == 112
-    assert ctypes.sizeof(_lib.AdamTensors) == 40
-    assert ctypes.sizeof(_lib.Hypernetwork) == 24 + 24 * 40 and _lib.Hypernetwork.embeddings.offset == 24 and _lib.Hypernetwork.norm_bias.offset == 24 + 20 * 40   # ABI 4
-    assert _lib.RenderConfig.seed.offset == 32 and _lib.RenderConfig.stream_offset.offset == 40 and _lib.RenderConfig.flags.offset == 48
-    assert _lib.RenderConfig.device_schedule.offset == 56 and _lib.RenderConfig.device_stream_offset.offset == 64
+    members = {"vsrd_field": (_lib.Field, ["instances", "mlp_weights"]),
+               "vsrd_render_config": (_lib.RenderConfig, ["seed", "stream_offset", "flags", "device_schedule", "device_stream_offset", "ray_indices", "rays_per_origin",
+                                                          "target_columns", "target_stride", "out_distances", "out_u_fine", "num_frames", "frame_stride"]),
+               "vsrd_frame_config": (_lib.FrameConfig, ["num_steps", "lr_gamma", "num_frames", "frame_stride"]),
+               "vsrd_adam_tensors": (_lib.AdamTensors, ["learning_rate"]),
+               "vsrd_hypernetwork": (_lib.Hypernetwork, ["embeddings", "norm_bias", "num_frames", "frame_stride"])}
+    lines = []
+    for struct, (_, names) in members.items():
+        lines.append(f'printf("{struct} %zu\\n", sizeof({struct}));')
+        lines += [f'printf("{struct}.{name} %zu\\n", offsetof({struct}, {name}));' for name in names]
+    source = tmp_path / "layout.c"
+    source.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "vsrd_hip.h"\nint main(void) {\n' + "\n".join(lines) + "\nreturn 0;\n}\n")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(source), "-o", str(tmp_path / "layout")], check=True)
+    seen = dict(line.split() for line in subprocess.run([str(tmp_path / "layout")], capture_output=True, text=True, check=True).stdout.splitlines())
+    for struct, (binding, names) in members.items():
+        assert int(seen[struct]) == ctypes.sizeof(binding), struct
+        for name in names:
+            assert int(seen[f"{struct}.{name}"]) == getattr(binding, name).offset, (struct, name)
+    assert ctypes.sizeof(_lib.RenderConfig) == 152 and ctypes.sizeof(_lib.FrameConfig) == 128 and ctypes.sizeof(_lib.Hypernetwork) == 24 + 24 * 40 + 16      # ABI 8
 
 
 def test_cpu_tensors_are_rejected_not_emulated(lib):

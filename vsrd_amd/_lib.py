@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VSRD_HIP_LIBRARY: an experiment build of the same ABI (tools/phase_timers.py, A/B macros); the product path is the in-tree default
 LIBRARY_PATH = os.environ.get("VSRD_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libvsrd_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_INSTANCES = 64
 MAX_SAMPLES = 256
 INSTANCE_STRIDE = 16
@@ -67,6 +67,8 @@ class RenderConfig(ctypes.Structure):
         ("out_coarse_weights", ctypes.c_void_p),
         ("out_u_coarse", ctypes.c_void_p),
         ("out_u_fine", ctypes.c_void_p),
+        ("num_frames", ctypes.c_int32),          # frame batch (ABI 8): 0 or 1 = one frame
+        ("frame_stride", ctypes.c_int64),        # bytes between the frames' copies of every buffer of the call
     ]
 
 
@@ -93,6 +95,8 @@ class FrameConfig(ctypes.Structure):
         ("beta2", ctypes.c_float),
         ("adam_epsilon", ctypes.c_float),
         ("lr_gamma", ctypes.c_float),
+        ("num_frames", ctypes.c_int32),
+        ("frame_stride", ctypes.c_int64),
     ]
 
 
@@ -123,6 +127,8 @@ class Hypernetwork(ctypes.Structure):
         ("bias", AdamTensors * HYPER_LAYERS),
         ("norm_weight", AdamTensors * (HYPER_LAYERS - 1)),
         ("norm_bias", AdamTensors * (HYPER_LAYERS - 1)),
+        ("num_frames", ctypes.c_int32),
+        ("frame_stride", ctypes.c_int64),
     ]
 
 
@@ -190,6 +196,8 @@ SIGNATURES = {
     "vsrd_project_boxes_backward": (ctypes.c_int32, [c_float_p, c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                                      ctypes.c_int32, ctypes.c_float, c_float_p, ctypes.c_void_p, c_float_p,
                                                      ctypes.c_void_p]),
+    "vsrd_selftest_wave": (ctypes.c_int32, [c_float_p, c_float_p, ctypes.c_void_p]),
+    "vsrd_selftest_gelu": (ctypes.c_int32, [c_float_p, ctypes.c_int32, c_float_p, ctypes.c_void_p]),
 }
 
 E_INVALID_ARGUMENT, E_UNSUPPORTED, E_LAUNCH, E_WORKSPACE = -1, -2, -3, -4      # include/vsrd_hip.h: VSRD_E_*
@@ -259,11 +267,12 @@ def make_field(instances, temperature, mlp_weights=None):
 
 
 def make_config(num_rays, num_samples, distance_range, sdf_std_deviation, cosine_ratio, epsilon, origin_stride,
-                seed=0, stream_offset=0, flags=0, schedule=None, gather=None, samples=None):
+                seed=0, stream_offset=0, flags=0, schedule=None, gather=None, samples=None, frames=None):
     """`schedule`: optional device tensor float32 [3] = (temperature, sdf_std_deviation, cosine_ratio) read by the kernels at
     start instead of the by-value scalars; `stream_offset` may likewise be a device int64 tensor (hipGraph replay).
     `samples`: optional (distances [R,2S], coarse_weights [R,S-1], u_coarse [R,S], u_fine [R,S]) float32 device tensors (any may be None)
-    that vsrd_render_silhouette_step fills with its own state between the passes (vsrd_render_config::out_*)."""
+    that vsrd_render_silhouette_step fills with its own state between the passes (vsrd_render_config::out_*).
+    `frames`: optional (num_frames, frame_stride in bytes) -- a batch of independent frames in one launch (include/vsrd_hip.h, ABI 8)."""
     schedule_ptr = offset_ptr = None
     if schedule is not None:
         if schedule.dtype != torch.float32 or schedule.numel() != 3 or not schedule.is_cuda or not schedule.is_contiguous():
@@ -289,4 +298,5 @@ def make_config(num_rays, num_samples, distance_range, sdf_std_deviation, cosine
     return RenderConfig(int(num_rays), int(num_samples), float(distance_range[0]), float(distance_range[1]),
                         float(sdf_std_deviation), float(cosine_ratio), float(epsilon), int(origin_stride),
                         int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_offset) & 0xFFFFFFFFFFFFFFFF, int(flags), schedule_ptr, offset_ptr,
-                        ray_indices, int(rays_per_origin), target_columns, int(target_stride), *outs)
+                        ray_indices, int(rays_per_origin), target_columns, int(target_stride), *outs,
+                        *((1, 0) if frames is None else (int(frames[0]), int(frames[1]))))

@@ -112,12 +112,34 @@ bool valid_field(const vsrd_field* f) {
            f->temperature > 0.0f;
 }
 
+// Frame batches (include/vsrd_hip.h, ABI 8): B copies of the one-frame grid along blockIdx.y, every pointer moved by frame_stride bytes per frame.
+constexpr int kMaxFrames = 1024;
+struct Frames {
+    int count;              // B (1: one frame)
+    long long stride;       // bytes; 0 for one frame (the kernels test this, not the count)
+};
+bool frames_of(int32_t num_frames, int64_t frame_stride, Frames* f) {
+    f->count = num_frames <= 1 ? 1 : num_frames;
+    f->stride = 0;
+    if (f->count == 1) return true;
+    if (f->count > kMaxFrames || frame_stride <= 0 || (frame_stride & 255) != 0) return false;
+    f->stride = frame_stride;
+    return true;
+}
+// one fill for every frame's copy of a scratch region (masks, counters)
+bool clear_frames(void* first, size_t bytes, const Frames& frames, hipStream_t s) {
+    if (frames.count == 1) return hipMemsetAsync(first, 0, bytes, s) == hipSuccess;
+    return hipMemset2DAsync(first, static_cast<size_t>(frames.stride), 0, bytes, static_cast<size_t>(frames.count), s) == hipSuccess;
+}
+
 bool wants_samples(const vsrd_render_config* c) { return c->out_distances || c->out_coarse_weights || c->out_u_coarse || c->out_u_fine; }
 
 bool valid_config(const vsrd_render_config* c, bool gather_allowed = false, bool samples_allowed = false) {
     if (c == nullptr || c->num_rays < 0 || c->num_samples < 2 || c->num_samples > VSRD_MAX_SAMPLES || !(c->sdf_std_deviation > 0.0f) ||
         (c->origin_stride != 0 && c->origin_stride != 3))
         return false;
+    Frames frames;
+    if (!frames_of(c->num_frames, c->frame_stride, &frames)) return false;
     if (wants_samples(c) && !samples_allowed) return false;      // only vsrd_render_silhouette_step writes its samples out
     const bool gather = c->ray_indices != nullptr || c->target_columns != nullptr;
     if (gather && !gather_allowed) return false;                 // only the fused step kernels read through an index
@@ -162,6 +184,7 @@ RenderArgs render_args(const vsrd_render_config* c) {
     a.target_stride = c->target_stride;
     a.out_distances = c->out_distances; a.out_coarse_weights = c->out_coarse_weights;
     a.out_u_coarse = c->out_u_coarse; a.out_u_fine = c->out_u_fine;
+    a.frame_stride = (c->num_frames > 1) ? c->frame_stride : 0;      // (only the two fused step entry points launch batches; the others reject them)
     return a;
 }
 
@@ -314,6 +337,7 @@ int32_t vsrd_polygon_soft_masks(const float* polygons, const int32_t* counts, in
 }
 
 int32_t vsrd_sample_stratified(const vsrd_render_config* config, const float* u_coarse, float* distances, void* stream) {
+    if (config != nullptr && config->num_frames > 1) return VSRD_E_UNSUPPORTED;      // (frame batches: the per-frame step entry points only)
     if (!valid_config(config)) return VSRD_E_INVALID_ARGUMENT;
     if (config->num_rays == 0) return VSRD_OK;
     if (!u_coarse || !distances) return VSRD_E_INVALID_ARGUMENT;
@@ -326,6 +350,7 @@ int32_t vsrd_sample_stratified(const vsrd_render_config* config, const float* u_
 
 int32_t vsrd_sample_importance(const vsrd_render_config* config, const float* coarse_distances,
                                const float* coarse_weights, const float* u_fine, float* merged, float* fine, void* stream) {
+    if (config != nullptr && config->num_frames > 1) return VSRD_E_UNSUPPORTED;      // (frame batches: the per-frame step entry points only)
     if (!valid_config(config)) return VSRD_E_INVALID_ARGUMENT;
     if (config->num_rays == 0) return VSRD_OK;
     if (!coarse_distances || !coarse_weights || !u_fine || (!merged && !fine)) return VSRD_E_INVALID_ARGUMENT;
@@ -351,6 +376,7 @@ int32_t vsrd_render_forward(const vsrd_field* field, const vsrd_render_config* c
                             const float* origins, const float* directions,
                             const float* distances, int32_t num_distances,
                             float* labels, float* gradients, float* weights, void* stream) {
+    if (config != nullptr && config->num_frames > 1) return VSRD_E_UNSUPPORTED;      // (frame batches: the per-frame step entry points only)
     if (!valid_field(field) || !valid_config(config) || num_distances < 2 || num_distances > 2 * VSRD_MAX_SAMPLES)
         return VSRD_E_INVALID_ARGUMENT;
     if (config->num_rays == 0) return VSRD_OK;   // empty batch: buffers may be null
@@ -404,6 +430,7 @@ int32_t vsrd_render_backward(const vsrd_field* field, const vsrd_render_config* 
                              const float* grad_labels, const float* grad_gradients, const float* grad_weights,
                              void* workspace, size_t workspace_bytes,
                              float* grad_instances, float* grad_mlp_weights, void* stream) {
+    if (config != nullptr && config->num_frames > 1) return VSRD_E_UNSUPPORTED;      // (frame batches: the per-frame step entry points only)
     if (!valid_field(field) || !valid_config(config) || !grad_instances || !workspace || num_distances < 2 ||
         num_distances > 2 * VSRD_MAX_SAMPLES)
         return VSRD_E_INVALID_ARGUMENT;
@@ -493,6 +520,7 @@ int32_t vsrd_render_hierarchical_forward(const vsrd_field* field, const vsrd_ren
                                          const float* u_coarse, const float* u_fine,
                                          float* labels, float* distances, float* gradients, float* weights, float* coarse_weights,
                                          float* u_coarse_out, float* u_fine_out, void* stream) {
+    if (config != nullptr && config->num_frames > 1) return VSRD_E_UNSUPPORTED;      // (frame batches: the per-frame step entry points only)
     if (!valid_field(field) || !valid_config(config)) return VSRD_E_INVALID_ARGUMENT;
     if (config->num_rays == 0) return VSRD_OK;   // empty batch: buffers may be null
     if (!origins || !directions || !labels) return VSRD_E_INVALID_ARGUMENT;
@@ -592,6 +620,9 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
     if (workspace_bytes < vsrd_workspace_bytes(N, 0)) return VSRD_E_WORKSPACE;
     const hipStream_t s = static_cast<hipStream_t>(stream);
     const int row = N * kGradStride;
+    Frames frames;
+    frames_of(config->num_frames, config->frame_stride, &frames);           // (validated by valid_config)
+    if (frames.count > 1 && (config->num_rays == 0 || wants_samples(config))) return VSRD_E_UNSUPPORTED;
     if (config->num_rays == 0) {
         if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) return VSRD_E_LAUNCH;
         return hipMemsetAsync(grad_instances, 0, row * sizeof(float), s) == hipSuccess ? VSRD_OK : VSRD_E_LAUNCH;
@@ -618,24 +649,28 @@ int32_t vsrd_render_silhouette_step(const vsrd_field* field, const vsrd_render_c
         const int blocks = config->num_rays < kSplitBlocks ? config->num_rays : kSplitBlocks;
         const int num_waves = blocks * kPairWaves;
         if (static_cast<size_t>(num_waves) * (row + 1) * sizeof(float) > workspace_bytes) return VSRD_E_WORKSPACE;
+        if (frames.count > 1 && static_cast<long long>(workspace_bytes) > frames.stride) return VSRD_E_INVALID_ARGUMENT;      // (the frames' workspaces would overlap)
         const size_t lds_bytes = static_cast<size_t>(split_lds_floats(S, N)) * sizeof(float);
         const FieldArgs f = field_args(field);
         RenderArgs c = render_args(config);
         c.sh.inv_t = f.inv_t;
         float* partials = static_cast<float*>(workspace);
         float* loss_partials = partials + static_cast<size_t>(num_waves) * row;
-#define VSRD_LAUNCH_SPLIT(K)                                                                                                    \
+#define VSRD_LAUNCH_SPLIT(K, FRAMES)                                                                                            \
         do {                                                                                                                      \
-            if (opt_in_lds(render_silhouette_split_kernel<K>, lds_bytes) != VSRD_OK) return VSRD_E_LAUNCH;                       \
-            hipLaunchKernelGGL(render_silhouette_split_kernel<K>, dim3(blocks), dim3(kPairWaves * kWave), lds_bytes, s, f, field->instances, c, \
+            if (opt_in_lds(render_silhouette_split_kernel<K, FRAMES>, lds_bytes) != VSRD_OK) return VSRD_E_LAUNCH;               \
+            hipLaunchKernelGGL((render_silhouette_split_kernel<K, FRAMES>), dim3(blocks, frames.count), dim3(kPairWaves * kWave), lds_bytes, s, f, field->instances, c, \
                                origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, labels, partials, loss_partials); \
         } while (0)
-        if (rounds == 2) VSRD_LAUNCH_SPLIT(2); else VSRD_LAUNCH_SPLIT(4);
+        if (frames.count > 1) { if (rounds == 2) VSRD_LAUNCH_SPLIT(2, true); else VSRD_LAUNCH_SPLIT(4, true); }
+        else if (rounds == 2) VSRD_LAUNCH_SPLIT(2, false); else VSRD_LAUNCH_SPLIT(4, false);
 #undef VSRD_LAUNCH_SPLIT
         if (launch_status() != VSRD_OK) return VSRD_E_LAUNCH;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(row + 1), dim3(256), 0, s, partials, num_waves, row, grad_instances, nullptr, loss_partials, 1, loss);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(row + 1, frames.count), dim3(256), 0, s, partials, num_waves, row, grad_instances, nullptr, loss_partials, 1, loss,
+                           frames.stride);
         return launch_status();
     }
+    if (frames.count > 1) return VSRD_E_UNSUPPORTED;     // a batch of frames runs in the split-ray form only (gathered launches of at most 2048 rays per frame)
     const int lanes = quad ? kRowLanes : 32, rays_per_wave = kWave / lanes;
     // a launch that fills its shape (S = lanes x rounds of the shape, more than half of its instance slots: BASELINE configs 2 and 5)
     // runs the hot kernel instantiated for that S with the instance tables padded to the shape's count (quad_step.h: kFull)
@@ -917,11 +952,11 @@ int32_t render_backward_split(const vsrd_field* field, const vsrd_render_config*
 #undef VSRD_LAUNCH
         hipLaunchKernelGGL(residual_mlp_adjoint_kernel, dim3(kMlpAdjointBlocks), dim3(kWave), adjoint_lds, s, field->instances,
                            field->mlp_weights, N, mlp_bits, seeds, masks, p.slots_per_instance, used_slots, p.items_per_instance, p.slots_per_item,
-                           counter, item_rows, item_flags);
+                           counter, item_rows, item_flags, 0ll);
         hipLaunchKernelGGL(reduce_item_rows_kernel, dim3(N, (kItemRowFloats + 255) / 256, kItemSegments), dim3(256), 0, s, item_rows, item_flags,
-                           p.items_per_instance, segment_sums);
+                           p.items_per_instance, segment_sums, 0ll);
         hipLaunchKernelGGL(reduce_item_segments_kernel, dim3(N, (kItemRowFloats + 255) / 256), dim3(256), 0, s, segment_sums, grad_mlp_weights, box_extra,
-                           chunk_index > 0 ? 1 : 0);
+                           chunk_index > 0 ? 1 : 0, 0ll);
         if (launch_status() != VSRD_OK) return VSRD_E_LAUNCH;
     }
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(row), dim3(256), 0, s, box_partials, p.front_waves, row, grad_instances, box_extra);
@@ -957,7 +992,12 @@ int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_con
     const int N = field->num_instances, S = config->num_samples;
     ResidualStepPlan p;
     const bool allow_pair = !(config->flags & VSRD_FLAG_RESIDUAL_WAVE_PER_RAY);
-    if ((config->flags & VSRD_FLAG_RESIDUAL_SINGLE_KERNEL) || config->num_rays == 0 || !plan_residual_step(N, S, config->num_rays, allow_pair, &p))
+    Frames frames;
+    frames_of(config->num_frames, config->frame_stride, &frames);           // (validated by valid_config)
+    const bool one_kernel = (config->flags & VSRD_FLAG_RESIDUAL_SINGLE_KERNEL) || config->num_rays == 0 || !plan_residual_step(N, S, config->num_rays, allow_pair, &p);
+    // a batch of frames: the two-kernel form with every frame's rays in ONE chunk (each frame its own seeds, item counter and rows, frame_stride apart)
+    if (frames.count > 1 && (one_kernel || p.chunk < config->num_rays || static_cast<long long>(p.total_bytes) > frames.stride)) return VSRD_E_UNSUPPORTED;
+    if (one_kernel)
         return residual_step_single_kernel(field, config, origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, eikonal_ratio,
                                            workspace, workspace_bytes, losses, grad_instances, grad_mlp_weights, labels, stream);
     if (workspace_bytes < p.total_bytes) return VSRD_E_WORKSPACE;
@@ -989,27 +1029,34 @@ int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_con
     const float* front_weights = field->mlp_weights;
     if (split) {
         unsigned* images = reinterpret_cast<unsigned*>(base + p.images);
-        if (vsrd_split_front::pack_images(field->mlp_weights, N, (config->flags & VSRD_FLAG_MLP_WEIGHTS_CENTRED) ? 1 : 0, images, s) != vsrd_split_front::kOk) return VSRD_E_LAUNCH;
+        if (vsrd_split_front::pack_images(field->mlp_weights, N, (config->flags & VSRD_FLAG_MLP_WEIGHTS_CENTRED) ? 1 : 0, images, frames.count, frames.stride, s) != vsrd_split_front::kOk)
+            return VSRD_E_LAUNCH;
         front_weights = reinterpret_cast<const float*>(images);
     }
     int chunk_index = 0;
     for (int first = 0; first < config->num_rays; first += p.chunk, ++chunk_index) {
         const int rays = std::min(p.chunk, config->num_rays - first);
         const long long used_slots = static_cast<long long>(rays) * p.rounds;
-        if (hipMemsetAsync(masks, 0, (p.counter - p.masks + 4) * sizeof(float), s) != hipSuccess) return VSRD_E_LAUNCH;   // tile masks + the item counter's 16-byte slot (a multiple of 16 bytes: one fill kernel, not two)
+        if (!clear_frames(masks, (p.counter - p.masks + 4) * sizeof(float), frames, s)) return VSRD_E_LAUNCH;   // tile masks + the item counter's 16-byte slot (a multiple of 16 bytes: one fill kernel, not two)
 #define VSRD_FRONT_ARGS                                                                                                                  \
         f, field->instances, front_weights, c, origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, eikonal_scale, \
         eikonal_norm, labels, box_partials, jets, loss_partials, seeds, masks, p.slots_per_instance, first, rays, chunk_index > 0 ? 1 : 0
 #define VSRD_LAUNCH(K)                                                                                                                   \
         if (opt_in_lds(residual_step_front_kernel<K>, p.front_lds) != VSRD_OK) return VSRD_E_LAUNCH;                                     \
+        if (frames.count > 1) return VSRD_E_UNSUPPORTED;      /* (a batch's frames are launches of <= 2048 rays: the pair kernel) */                    \
         hipLaunchKernelGGL(residual_step_front_kernel<K>, dim3(p.front_blocks), dim3(kBlockThreads), p.front_lds, s, VSRD_FRONT_ARGS)
 #define VSRD_LAUNCH_PAIR(K)                                                                                                              \
-        if (opt_in_lds(residual_step_pair_kernel<K>, p.front_lds) != VSRD_OK) return VSRD_E_LAUNCH;                                      \
-        hipLaunchKernelGGL(residual_step_pair_kernel<K>, dim3(p.front_blocks), dim3(kPairWaves * kWave), p.front_lds, s, VSRD_FRONT_ARGS)
+        if (frames.count > 1) {                                                                                                          \
+            if (opt_in_lds(residual_step_pair_kernel<K, true>, p.front_lds) != VSRD_OK) return VSRD_E_LAUNCH;                            \
+            hipLaunchKernelGGL((residual_step_pair_kernel<K, true>), dim3(p.front_blocks, frames.count), dim3(kPairWaves * kWave), p.front_lds, s, VSRD_FRONT_ARGS); \
+        } else {                                                                                                                         \
+            if (opt_in_lds(residual_step_pair_kernel<K>, p.front_lds) != VSRD_OK) return VSRD_E_LAUNCH;                                  \
+            hipLaunchKernelGGL(residual_step_pair_kernel<K>, dim3(p.front_blocks), dim3(kPairWaves * kWave), p.front_lds, s, VSRD_FRONT_ARGS); \
+        }
         if (split) {
             vsrd_split_front::FrontLaunch launch = {&f, sizeof f, &c, sizeof c, field->instances, front_weights, origins, directions, u_coarse, u_fine, targets, instance_weights,
                                                     loss_scale, eikonal_scale, eikonal_norm, labels, box_partials, jets, loss_partials, seeds, masks, p.slots_per_instance,
-                                                    first, rays, chunk_index > 0 ? 1 : 0, p.pair, p.rounds, p.front_blocks, p.front_lds};
+                                                    first, rays, chunk_index > 0 ? 1 : 0, p.pair, p.rounds, p.front_blocks, p.front_lds, frames.count};
             const int code = vsrd_split_front::launch_front(launch, s);
             if (code != vsrd_split_front::kOk) return code == vsrd_split_front::kUnsupported ? VSRD_E_UNSUPPORTED : VSRD_E_LAUNCH;
         } else if (p.pair) {
@@ -1031,20 +1078,22 @@ int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_con
 #undef VSRD_FRONT_ARGS
         if (split) {
             if (vsrd_split_front::launch_adjoint(kMlpAdjointBlocks, field->instances, front_weights, N, seeds, masks, p.slots_per_instance, used_slots,
-                                                 p.items_per_instance, p.slots_per_item, counter, item_rows, item_flags, s) != vsrd_split_front::kOk) return VSRD_E_LAUNCH;
+                                                 p.items_per_instance, p.slots_per_item, counter, item_rows, item_flags, frames.count, frames.stride, s) != vsrd_split_front::kOk)
+                return VSRD_E_LAUNCH;
         } else {
-            hipLaunchKernelGGL(residual_mlp_adjoint_kernel, dim3(kMlpAdjointBlocks), dim3(kWave), adjoint_lds, s, field->instances,
+            hipLaunchKernelGGL(residual_mlp_adjoint_kernel, dim3(kMlpAdjointBlocks, frames.count), dim3(kWave), adjoint_lds, s, field->instances,
                                field->mlp_weights, N, mlp_bits, seeds, masks, p.slots_per_instance, used_slots, p.items_per_instance, p.slots_per_item,
-                               counter, item_rows, item_flags);
+                               counter, item_rows, item_flags, frames.stride);
         }
-        hipLaunchKernelGGL(reduce_item_rows_kernel, dim3(N, (kItemRowFloats + 255) / 256, kItemSegments), dim3(256), 0, s, item_rows, item_flags,
-                           p.items_per_instance, segment_sums);
-        hipLaunchKernelGGL(reduce_item_segments_kernel, dim3(N, (kItemRowFloats + 255) / 256), dim3(256), 0, s, segment_sums, grad_mlp_weights, box_extra,
-                           chunk_index > 0 ? 1 : 0);
+        hipLaunchKernelGGL(reduce_item_rows_kernel, dim3(N, (kItemRowFloats + 255) / 256, kItemSegments * frames.count), dim3(256), 0, s, item_rows, item_flags,
+                           p.items_per_instance, segment_sums, frames.stride);
+        hipLaunchKernelGGL(reduce_item_segments_kernel, dim3(N, (kItemRowFloats + 255) / 256, frames.count), dim3(256), 0, s, segment_sums, grad_mlp_weights, box_extra,
+                           chunk_index > 0 ? 1 : 0, frames.stride);
         if (launch_status() != VSRD_OK) return VSRD_E_LAUNCH;
     }
     (void)mlp_row;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(row + 2), dim3(256), 0, s, box_partials, p.front_waves, row, grad_instances, box_extra, loss_partials, 2, losses);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(row + 2, frames.count), dim3(256), 0, s, box_partials, p.front_waves, row, grad_instances, box_extra, loss_partials, 2, losses,
+                       frames.stride);
     return launch_status();
 }
 
@@ -1066,6 +1115,9 @@ static bool frame_args(const vsrd_frame_config* c, FrameStepArgs* a) {
     a->max_temperature = c->max_temperature; a->min_temperature = c->min_temperature; a->max_std = c->max_std; a->min_std = c->min_std;
     a->weight_iou = c->weight_iou; a->weight_l1 = c->weight_l1; a->weight_silhouette = c->weight_silhouette;
     a->beta1 = c->beta1; a->beta2 = c->beta2; a->adam_epsilon = c->adam_epsilon; a->lr_gamma = c->lr_gamma;
+    Frames frames;
+    if (!frames_of(c->num_frames, c->frame_stride, &frames)) return false;
+    a->frame_stride = frames.stride;
     return true;
 }
 }  // namespace
@@ -1089,7 +1141,7 @@ int32_t vsrd_frame_prologue(const vsrd_frame_config* config, const float* raw_lo
     b.instances = instances;
     b.pd_indices = reinterpret_cast<long long*>(pd_indices); b.gt_indices = reinterpret_cast<long long*>(gt_indices);
     b.target_map = target_columns; b.instance_weights = instance_weights; b.schedule = schedule; b.losses = projection_losses; b.grad_raw = grad_raw;
-    hipLaunchKernelGGL(frame_prologue_kernel, dim3(1), dim3(kFrameThreads), 0, static_cast<hipStream_t>(stream), a, b);
+    hipLaunchKernelGGL(frame_prologue_kernel, dim3(1, config->num_frames > 1 ? config->num_frames : 1), dim3(kFrameThreads), 0, static_cast<hipStream_t>(stream), a, b);
     return launch_status();
 }
 
@@ -1117,7 +1169,7 @@ int32_t vsrd_frame_prologue_sample(const vsrd_frame_config* config, const float*
     // (a refused LDS opt-in is "this device / build cannot run the combined launch" -- VSRD_E_UNSUPPORTED, on which the caller falls back to
     //  vsrd_frame_prologue + vsrd_sample_rays_table -- and not a failed launch, which must not be mistaken for it)
     if (opt_in_lds(frame_prologue_sample_kernel, kTableLdsBytes) != VSRD_OK) return VSRD_E_UNSUPPORTED;
-    hipLaunchKernelGGL(frame_prologue_sample_kernel, dim3(2), dim3(kTableThreads), kTableLdsBytes, static_cast<hipStream_t>(stream), a, b,
+    hipLaunchKernelGGL(frame_prologue_sample_kernel, dim3(2, config->num_frames > 1 ? config->num_frames : 1), dim3(kTableThreads), kTableLdsBytes, static_cast<hipStream_t>(stream), a, b,
                        static_cast<RayTableHeader*>(ray_table), static_cast<long long>(count), num_rays, seed, reinterpret_cast<const unsigned long long*>(step),
                        reinterpret_cast<const long long*>(remap), reinterpret_cast<long long*>(ray_indices));
     return launch_status();
@@ -1144,7 +1196,7 @@ int32_t vsrd_frame_epilogue(const vsrd_frame_config* config, const float* grad_i
     e.locations = tensors[0]; e.dimensions = tensors[1]; e.orientations = tensors[2];
     e.other_learning_rates[0] = other_learning_rate_0; e.other_learning_rates[1] = other_learning_rate_1;
     e.step = reinterpret_cast<long long*>(step); e.record = record; e.raw_gradients = raw_gradients;
-    hipLaunchKernelGGL(frame_epilogue_kernel, dim3(1), dim3(kFrameMaxBoxes), 0, static_cast<hipStream_t>(stream), a, e);
+    hipLaunchKernelGGL(frame_epilogue_kernel, dim3(1, config->num_frames > 1 ? config->num_frames : 1), dim3(kFrameMaxBoxes), 0, static_cast<hipStream_t>(stream), a, e);
     return launch_status();
 }
 
@@ -1191,6 +1243,8 @@ size_t vsrd_hypernetwork_workspace_bytes(int32_t num_instances) {
 int32_t vsrd_hypernetwork_forward(const vsrd_hypernetwork* net, void* workspace, size_t workspace_bytes,
                                   float* mlp_weights, float* centred, void* stream) {
     if (!valid_hypernetwork(net) || !mlp_weights) return VSRD_E_INVALID_ARGUMENT;
+    Frames frames;
+    if (!frames_of(net->num_frames, net->frame_stride, &frames)) return VSRD_E_INVALID_ARGUMENT;
     const int N = net->num_instances;
     const HyperPlan p = plan_hypernetwork(N);
     if (!workspace || workspace_bytes < p.total * sizeof(float)) return VSRD_E_WORKSPACE;
@@ -1207,12 +1261,12 @@ int32_t vsrd_hypernetwork_forward(const vsrd_hypernetwork* net, void* workspace,
         hidden.inv_norm[l] = ws + p.inv_norm + l * kHyperWidth;
         if (l + 1 < kLast) { hidden.gamma[l] = net->norm_weight[l].parameter; hidden.beta[l] = net->norm_bias[l].parameter; }
     }
-    hipLaunchKernelGGL(hyper_hidden_forward_kernel, dim3(N), dim3(kHyperChainThreads), 0, s, net->embeddings.parameter, hidden);
-    hipLaunchKernelGGL(hyper_linear_forward_kernel, dim3((kMlpWeights + kHyperWaves - 1) / kHyperWaves), dim3(kHyperThreads), lds, s,
+    hipLaunchKernelGGL(hyper_hidden_forward_kernel, dim3(N, frames.count), dim3(kHyperChainThreads), 0, s, net->embeddings.parameter, hidden, frames.stride);
+    hipLaunchKernelGGL(hyper_linear_forward_kernel, dim3((kMlpWeights + kHyperWaves - 1) / kHyperWaves, frames.count), dim3(kHyperThreads), lds, s,
                        ws + p.activations + (kLast - 1) * slab, net->norm_weight[kLast - 1].parameter, net->norm_bias[kLast - 1].parameter,
                        net->weight_v[kLast].parameter, net->weight_g[kLast].parameter, net->bias[kLast].parameter, kMlpWeights, N, mlp_weights,
-                       ws + p.inv_norm + kLast * kHyperWidth);
-    if (centred) hipLaunchKernelGGL(hyper_centre_kernel, dim3(N), dim3(128), 0, s, mlp_weights, N, centred);
+                       ws + p.inv_norm + kLast * kHyperWidth, frames.stride);
+    if (centred) hipLaunchKernelGGL(hyper_centre_kernel, dim3(N, frames.count), dim3(128), 0, s, mlp_weights, N, centred, frames.stride);
     return launch_status();
 }
 
@@ -1225,6 +1279,8 @@ int32_t vsrd_centre_mlp_weights(const float* mlp_weights, int32_t num_instances,
 int32_t vsrd_hypernetwork_backward_step(const vsrd_hypernetwork* net, void* workspace, size_t workspace_bytes,
                                         const float* grad_mlp_weights, float grad_scale, void* stream) {
     if (!valid_hypernetwork(net) || !grad_mlp_weights) return VSRD_E_INVALID_ARGUMENT;
+    Frames frames;
+    if (!frames_of(net->num_frames, net->frame_stride, &frames)) return VSRD_E_INVALID_ARGUMENT;
     const int N = net->num_instances;
     const HyperPlan p = plan_hypernetwork(N);
     if (!workspace || workspace_bytes < p.total * sizeof(float)) return VSRD_E_WORKSPACE;
@@ -1240,11 +1296,11 @@ int32_t vsrd_hypernetwork_backward_step(const vsrd_hypernetwork* net, void* work
     auto norm_shares = [&](int k) { return ws + p.norm_partials + k * 2 * slab; };
     // the final linear: its own update and its workgroups' shares of the input adjoint; their sum through the norm behind linear 3
     const int final_blocks = (kMlpWeights + kHyperWaves - 1) / kHyperWaves;
-    hipLaunchKernelGGL(hyper_linear_backward_kernel, dim3(final_blocks), dim3(kHyperThreads), lds, s, z(kLast - 1), net->norm_weight[kLast - 1].parameter,
+    hipLaunchKernelGGL(hyper_linear_backward_kernel, dim3(final_blocks, frames.count), dim3(kHyperThreads), lds, s, z(kLast - 1), net->norm_weight[kLast - 1].parameter,
                        net->norm_bias[kLast - 1].parameter, grad_mlp_weights, grad_scale, inv_norm(kLast), kMlpWeights, N, adam_tensors(net->weight_v[kLast]),
-                       adam_tensors(net->weight_g[kLast]), adam_tensors(net->bias[kLast]), adam, ws + p.partials);
-    hipLaunchKernelGGL(hyper_norm_backward_kernel, dim3(N), dim3(kHyperNormThreads * kHyperNormSplit), 0, s, ws + p.partials, final_blocks, z(kLast - 1), N,
-                       net->norm_weight[kLast - 1].parameter, net->norm_bias[kLast - 1].parameter, gz(kLast - 1), norm_shares(kLast - 1));
+                       adam_tensors(net->weight_g[kLast]), adam_tensors(net->bias[kLast]), adam, ws + p.partials, frames.stride);
+    hipLaunchKernelGGL(hyper_norm_backward_kernel, dim3(N, frames.count), dim3(kHyperNormThreads * kHyperNormSplit), 0, s, ws + p.partials, final_blocks, z(kLast - 1), N,
+                       net->norm_weight[kLast - 1].parameter, net->norm_bias[kLast - 1].parameter, gz(kLast - 1), norm_shares(kLast - 1), frames.stride);
     // the chain through the hidden blocks (one workgroup per instance), then every hidden linear's own update
     HyperHiddenBackward chain;
     HyperHiddenUpdate update;
@@ -1271,10 +1327,10 @@ int32_t vsrd_hypernetwork_backward_step(const vsrd_hypernetwork* net, void* work
         update.v[l] = adam_tensors(net->weight_v[l]); update.g[l] = adam_tensors(net->weight_g[l]); update.b[l] = adam_tensors(net->bias[l]);
     }
     chain.embedding_bar = gz(kLast);
-    hipLaunchKernelGGL(hyper_hidden_backward_kernel, dim3(N), dim3(kHyperChainThreads), 0, s, chain);
-    hipLaunchKernelGGL(hyper_hidden_update_kernel, dim3(kHyperHidden * (kHyperWidth / kHyperWaves)), dim3(kHyperThreads), lds, s, update, N, adam);
-    hipLaunchKernelGGL(hyper_finish_kernel, dim3(1), dim3(kHyperChainThreads), 0, s, norms, ws + p.norm_partials, adam_tensors(net->embeddings), gz(kLast), N, adam,
-                       counters, net->embeddings.learning_rate, net->weight_v[0].learning_rate, net->lr_gamma);
+    hipLaunchKernelGGL(hyper_hidden_backward_kernel, dim3(N, frames.count), dim3(kHyperChainThreads), 0, s, chain, frames.stride);
+    hipLaunchKernelGGL(hyper_hidden_update_kernel, dim3(kHyperHidden * (kHyperWidth / kHyperWaves), frames.count), dim3(kHyperThreads), lds, s, update, N, adam, frames.stride);
+    hipLaunchKernelGGL(hyper_finish_kernel, dim3(1, frames.count), dim3(kHyperChainThreads), 0, s, norms, ws + p.norm_partials, adam_tensors(net->embeddings), gz(kLast), N, adam,
+                       counters, net->embeddings.learning_rate, net->weight_v[0].learning_rate, net->lr_gamma, frames.stride);
     return launch_status();
 }
 

@@ -35,6 +35,7 @@ struct FrameStepArgs {
     float max_temperature, min_temperature, max_std, min_std;
     float weight_iou, weight_l1, weight_silhouette;
     float beta1, beta2, adam_epsilon, lr_gamma;
+    long long frame_stride;            // vsrd_frame_config::frame_stride (bytes; wave.h: frame batches), 0 for one frame
 };
 
 // scratch (global, one per frame): boxes_2d [V,N,4], selection [V,N,4] (int), grad_boxes [V,N,4], grad_world [V,N,8,3]
@@ -414,13 +415,31 @@ __device__ __forceinline__ void frame_prologue_body(const FrameStepArgs& a, cons
 }
 #undef VSRD_PROLOGUE_MARK
 
-__global__ __launch_bounds__(kFrameThreads) void frame_prologue_kernel(FrameStepArgs a, FrameBuffers b) { frame_prologue_body<kFrameThreads>(a, b); }
+// Frame f of a batch (wave.h): the pointer block moves as a whole.
+__device__ __forceinline__ void shift_frame(FrameBuffers& b, long long shift) {
+    b.raw_locations = of_frame(b.raw_locations, shift); b.raw_dimensions = of_frame(b.raw_dimensions, shift); b.raw_orientations = of_frame(b.raw_orientations, shift);
+    b.extrinsics = of_frame(b.extrinsics, shift); b.intrinsics = of_frame(b.intrinsics, shift); b.gt_boxes = of_frame(b.gt_boxes, shift);
+    b.visible = of_frame(b.visible, shift); b.step = of_frame(b.step, shift); b.scratch = of_frame(b.scratch, shift); b.instances = of_frame(b.instances, shift);
+    b.pd_indices = of_frame(b.pd_indices, shift); b.gt_indices = of_frame(b.gt_indices, shift); b.target_map = of_frame(b.target_map, shift);
+    b.instance_weights = of_frame(b.instance_weights, shift); b.schedule = of_frame(b.schedule, shift); b.losses = of_frame(b.losses, shift);
+    b.grad_raw = of_frame(b.grad_raw, shift);
+}
+
+__global__ __launch_bounds__(kFrameThreads) void frame_prologue_kernel(FrameStepArgs a, FrameBuffers b) {
+    if (a.frame_stride != 0) shift_frame(b, frame_shift(a.frame_stride, blockIdx.y));
+    frame_prologue_body<kFrameThreads>(a, b);
+}
 
 // The prologue and the draw of the step's rays from the frame's sampling table (ray_sampling.h) in ONE launch of two workgroups: neither
 // needs the other, and as two launches on two streams they met again through a cross-queue dependency of ~10 us.
 __global__ __launch_bounds__(kTableThreads) void frame_prologue_sample_kernel(FrameStepArgs a, FrameBuffers b, RayTableHeader* table, long long count, int num_rays,
                                                                               unsigned long long seed, const unsigned long long* __restrict__ device_step,
                                                                               const long long* __restrict__ remap, long long* __restrict__ ray_indices) {
+    if (a.frame_stride != 0) {             // a batch of frames (wave.h): two workgroups per frame, frame blockIdx.y
+        const long long shift = frame_shift(a.frame_stride, blockIdx.y);
+        shift_frame(b, shift);
+        VSRD_OF_FRAME(table, shift); VSRD_OF_FRAME(device_step, shift); VSRD_OF_FRAME(remap, shift); VSRD_OF_FRAME(ray_indices, shift);
+    }
     if (blockIdx.x == 0) frame_prologue_body<kTableThreads>(a, b);
     else sample_table_body(table, count, num_rays, seed, 0ull, device_step, remap, ray_indices);
 }
@@ -457,7 +476,20 @@ __device__ __forceinline__ void adam_update(const FrameStepArgs& a, const AdamTe
     t.parameter[index] = old_p - (lr / bc1) * m / (sqrtf(v) / sqrtf(bc2) + a.adam_epsilon);
 }
 
+__device__ __forceinline__ void shift_frame(AdamTensors& t, long long shift) {
+    t.parameter = of_frame(t.parameter, shift); t.exp_avg = of_frame(t.exp_avg, shift); t.exp_avg_sq = of_frame(t.exp_avg_sq, shift);
+    t.step = of_frame(t.step, shift); t.learning_rate = of_frame(t.learning_rate, shift);
+}
+__device__ __forceinline__ void shift_frame(EpilogueBuffers& e, long long shift) {
+    e.grad_instances = of_frame(e.grad_instances, shift); e.grad_raw_projection = of_frame(e.grad_raw_projection, shift);
+    e.projection_losses = of_frame(e.projection_losses, shift); e.render_losses = of_frame(e.render_losses, shift);
+    shift_frame(e.locations, shift); shift_frame(e.dimensions, shift); shift_frame(e.orientations, shift);
+    e.other_learning_rates[0] = of_frame(e.other_learning_rates[0], shift); e.other_learning_rates[1] = of_frame(e.other_learning_rates[1], shift);
+    e.step = of_frame(e.step, shift); e.record = of_frame(e.record, shift); e.raw_gradients = of_frame(e.raw_gradients, shift);
+}
+
 __global__ __launch_bounds__(kFrameMaxBoxes) void frame_epilogue_kernel(FrameStepArgs a, EpilogueBuffers e) {
+    if (a.frame_stride != 0) shift_frame(e, frame_shift(a.frame_stride, blockIdx.y));      // a batch of frames (wave.h): one workgroup per frame
     const int tid = static_cast<int>(threadIdx.x);
     const int N = a.num_boxes;
     // every thread reads the scalars before anyone updates them -- and with them everything else it will need (its box's raw

@@ -97,7 +97,13 @@ __device__ __forceinline__ void stage_hyper_input(const float* __restrict__ x, c
 // z[n, o] = g[o] (v[o, :] . h[n, :]) / |v[o, :]| + b[o];  inv_norm[o] = 1 / |v[o, :]| kept for the backward.
 __global__ __launch_bounds__(kHyperThreads) void hyper_linear_forward_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ v,
-    const float* __restrict__ g, const float* __restrict__ b, int num_rows, int num_instances, float* __restrict__ z, float* __restrict__ inv_norm) {
+    const float* __restrict__ g, const float* __restrict__ b, int num_rows, int num_instances, float* __restrict__ z, float* __restrict__ inv_norm,
+    long long frame_stride) {
+    if (frame_stride != 0) {               // a batch of frames (wave.h): frame blockIdx.y, every frame its own hypernetwork
+        const long long shift = frame_shift(frame_stride, blockIdx.y);
+        VSRD_OF_FRAME(x, shift); VSRD_OF_FRAME(gamma, shift); VSRD_OF_FRAME(beta, shift); VSRD_OF_FRAME(v, shift); VSRD_OF_FRAME(g, shift); VSRD_OF_FRAME(b, shift);
+        VSRD_OF_FRAME(z, shift); VSRD_OF_FRAME(inv_norm, shift);
+    }
     extern __shared__ __attribute__((aligned(16))) float h[];
     const int wave = static_cast<int>(threadIdx.x) >> 6, lane = lane_id();
     const int o = static_cast<int>(blockIdx.x) * kHyperWaves + wave;
@@ -129,7 +135,11 @@ struct HyperHiddenForward {
     float* z[kHyperHidden]; float* inv_norm[kHyperHidden];
 };
 
-__global__ __launch_bounds__(kHyperChainThreads) void hyper_hidden_forward_kernel(const float* __restrict__ embeddings, HyperHiddenForward net) {
+// (Frame batches, wave.h: the pointer tables of these kernels are indexed by run-time layer numbers and therefore stay where they are, in
+//  the kernel arguments -- a modified copy would live in scratch memory; every pointer is moved to the workgroup's frame where it is read.)
+__global__ __launch_bounds__(kHyperChainThreads) void hyper_hidden_forward_kernel(const float* __restrict__ embeddings, HyperHiddenForward net, long long frame_stride) {
+    const long long shift = frame_shift(frame_stride, blockIdx.y);      // this workgroup's frame (0 for one frame)
+    VSRD_OF_FRAME(embeddings, shift);
     __shared__ __attribute__((aligned(16))) float h[kHyperWidth];
     __shared__ __attribute__((aligned(16))) float out[kHyperWidth];
     const int n = blockIdx.x, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6), lane = lane_id();    // (wave: scalar row addresses)
@@ -148,15 +158,16 @@ __global__ __launch_bounds__(kHyperChainThreads) void hyper_hidden_forward_kerne
     float4 row[kRows];
     float g_row = 0.0f, b_row = 0.0f;
     auto request = [&](int l) {
+        const float* v_l = of_frame(net.v[l], shift);
 #pragma unroll
-        for (int r = 0; r < kRows; ++r) row[r] = *reinterpret_cast<const float4*>(net.v[l] + static_cast<size_t>(wave + kHyperChainWaves * r) * kHyperWidth + 4 * lane);
-        if (lane < kRows) { g_row = net.g[l][wave + kHyperChainWaves * lane]; b_row = net.b[l][wave + kHyperChainWaves * lane]; }
+        for (int r = 0; r < kRows; ++r) row[r] = *reinterpret_cast<const float4*>(v_l + static_cast<size_t>(wave + kHyperChainWaves * r) * kHyperWidth + 4 * lane);
+        if (lane < kRows) { g_row = of_frame(net.g[l], shift)[wave + kHyperChainWaves * lane]; b_row = of_frame(net.b[l], shift)[wave + kHyperChainWaves * lane]; }
     };
     request(0);
     __shared__ __attribute__((aligned(16))) float affine[kHyperHidden - 1][2][kHyperWidth];      // gamma, beta of the three norms in between
     if (wave < kHyperHidden - 1) {
-        *reinterpret_cast<float4*>(&affine[wave][0][4 * lane]) = *reinterpret_cast<const float4*>(net.gamma[wave] + 4 * lane);
-        *reinterpret_cast<float4*>(&affine[wave][1][4 * lane]) = *reinterpret_cast<const float4*>(net.beta[wave] + 4 * lane);
+        *reinterpret_cast<float4*>(&affine[wave][0][4 * lane]) = *reinterpret_cast<const float4*>(of_frame(net.gamma[wave], shift) + 4 * lane);
+        *reinterpret_cast<float4*>(&affine[wave][1][4 * lane]) = *reinterpret_cast<const float4*>(of_frame(net.beta[wave], shift) + 4 * lane);
     }
     if (wave == kHyperHidden - 1)
         *reinterpret_cast<float4*>(h + 4 * lane) = *reinterpret_cast<const float4*>(embeddings + static_cast<size_t>(n) * kHyperWidth + 4 * lane);
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(kHyperChainThreads) void hyper_hidden_forward_kerne
             if (lane < kRows) {
                 const int o = wave + kHyperChainWaves * lane;
                 out[o] = dot * g_row * inv + b_row;
-                if (n == 0) net.inv_norm[l][o] = inv;
+                if (n == 0) of_frame(net.inv_norm[l], shift)[o] = inv;
             }
             if (l + 1 < kHyperHidden) request(l + 1);
             VSRD_HYPER_AT(10, 64);
@@ -191,7 +202,7 @@ __global__ __launch_bounds__(kHyperChainThreads) void hyper_hidden_forward_kerne
         VSRD_HYPER_AT(11, 0);
         if (wave == 0) {
             const float4 zv = *reinterpret_cast<const float4*>(out + 4 * lane);
-            *reinterpret_cast<float4*>(net.z[l] + static_cast<size_t>(n) * kHyperWidth + 4 * lane) = zv;
+            *reinterpret_cast<float4*>(of_frame(net.z[l], shift) + static_cast<size_t>(n) * kHyperWidth + 4 * lane) = zv;
             if (l + 1 < kHyperHidden) {                            // (the norm behind the last hidden linear belongs to the final linear's staging)
                 const float4 gv = *reinterpret_cast<const float4*>(&affine[l][0][4 * lane]), bv = *reinterpret_cast<const float4*>(&affine[l][1][4 * lane]);
                 float y[4] = {zv.x, zv.y, zv.z, zv.w};
@@ -213,7 +224,8 @@ __global__ __launch_bounds__(kHyperChainThreads) void hyper_hidden_forward_kerne
 
 // Centre the generated weights for the render kernels (VSRD_FLAG_MLP_WEIGHTS_CENTRED; rendering/renderers.py::_centre_mlp): in the
 // four linears of the per-instance MLP that feed a LayerNorm, remove each column's mean over the 16 output channels.
-__global__ __launch_bounds__(128) void hyper_centre_kernel(const float* __restrict__ weights, int num_instances, float* __restrict__ centred) {
+__global__ __launch_bounds__(128) void hyper_centre_kernel(const float* __restrict__ weights, int num_instances, float* __restrict__ centred, long long frame_stride = 0) {
+    if (frame_stride != 0) { const long long shift = frame_shift(frame_stride, blockIdx.y); VSRD_OF_FRAME(weights, shift); VSRD_OF_FRAME(centred, shift); }
     const int n = blockIdx.x;
     const float* src = weights + static_cast<size_t>(n) * kMlpWeights;
     float* dst = centred + static_cast<size_t>(n) * kMlpWeights;
@@ -308,7 +320,12 @@ __device__ __forceinline__ void hyper_rows_backward(
 __global__ __launch_bounds__(kHyperThreads) void hyper_linear_backward_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ gz, float grad_scale,
     const float* __restrict__ inv_norm, int num_rows, int num_instances, AdamTensors v, AdamTensors g, AdamTensors b, HyperAdam adam,
-    float* __restrict__ partial_gh) {
+    float* __restrict__ partial_gh, long long frame_stride) {
+    if (frame_stride != 0) {
+        const long long shift = frame_shift(frame_stride, blockIdx.y);
+        VSRD_OF_FRAME(x, shift); VSRD_OF_FRAME(gamma, shift); VSRD_OF_FRAME(beta, shift); VSRD_OF_FRAME(gz, shift); VSRD_OF_FRAME(inv_norm, shift); VSRD_OF_FRAME(partial_gh, shift);
+        shift_frame(v, shift); shift_frame(g, shift); shift_frame(b, shift);
+    }
     extern __shared__ __attribute__((aligned(16))) float lds[];
     hyper_rows_backward(x, gamma, beta, gz, grad_scale, inv_norm, num_rows, num_instances, v, g, b, adam, partial_gh, static_cast<int>(blockIdx.x), lds);
 }
@@ -320,12 +337,15 @@ struct HyperHiddenUpdate {
     AdamTensors v[4], g[4], b[4];
 };
 
-__global__ __launch_bounds__(kHyperThreads) void hyper_hidden_update_kernel(HyperHiddenUpdate u, int num_instances, HyperAdam adam) {
+__global__ __launch_bounds__(kHyperThreads) void hyper_hidden_update_kernel(HyperHiddenUpdate u, int num_instances, HyperAdam adam, long long frame_stride) {
+    const long long shift = frame_shift(frame_stride, blockIdx.y);      // this workgroup's frame (0 for one frame)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int kBlocksPerLayer = kHyperWidth / kHyperWaves;
     const int l = static_cast<int>(blockIdx.x) / kBlocksPerLayer, block = static_cast<int>(blockIdx.x) % kBlocksPerLayer;
-    hyper_rows_backward(u.x[l], u.gamma[l], u.beta[l], u.gz[l], 1.0f, u.inv_norm[l], kHyperWidth, num_instances, u.v[l], u.g[l], u.b[l], adam,
-                        nullptr, block, lds);
+    AdamTensors v = u.v[l], g = u.g[l], b = u.b[l];
+    shift_frame(v, shift); shift_frame(g, shift); shift_frame(b, shift);
+    hyper_rows_backward(of_frame(u.x[l], shift), of_frame(u.gamma[l], shift), of_frame(u.beta[l], shift), of_frame(u.gz[l], shift), 1.0f, of_frame(u.inv_norm[l], shift),
+                        kHyperWidth, num_instances, v, g, b, adam, nullptr, block, lds);
 }
 
 __device__ __forceinline__ float block_sum_256(float value, float* scratch) {       // 4 waves; scratch [4]; fixed order
@@ -343,7 +363,12 @@ __device__ __forceinline__ float block_sum_256(float value, float* scratch) {   
 // them at the end of the step).  Used behind the final linear, whose 203 workgroups' shares have to be summed across workgroups.
 __global__ __launch_bounds__(kHyperNormThreads * kHyperNormSplit) void hyper_norm_backward_kernel(
     const float* __restrict__ partial_gh, int num_partials, const float* __restrict__ z_prev, int num_instances,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ gz_out, float* __restrict__ norm_partials) {
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ gz_out, float* __restrict__ norm_partials, long long frame_stride) {
+    if (frame_stride != 0) {
+        const long long shift = frame_shift(frame_stride, blockIdx.y);
+        VSRD_OF_FRAME(partial_gh, shift); VSRD_OF_FRAME(z_prev, shift); VSRD_OF_FRAME(gamma, shift); VSRD_OF_FRAME(beta, shift); VSRD_OF_FRAME(gz_out, shift);
+        VSRD_OF_FRAME(norm_partials, shift);
+    }
     __shared__ float scratch[4];
     __shared__ float quarter[kHyperNormSplit][kHyperWidth];
     const int n = blockIdx.x, c = static_cast<int>(threadIdx.x) & (kHyperWidth - 1), q = static_cast<int>(threadIdx.x) >> 8;
@@ -388,7 +413,8 @@ struct HyperHiddenBackward {
     float* embedding_bar;                     // [N][256]
 };
 
-__global__ __launch_bounds__(kHyperChainThreads) void hyper_hidden_backward_kernel(HyperHiddenBackward net) {
+__global__ __launch_bounds__(kHyperChainThreads) void hyper_hidden_backward_kernel(HyperHiddenBackward net, long long frame_stride) {
+    const long long shift = frame_shift(frame_stride, blockIdx.y);      // this workgroup's frame (0 for one frame)
     constexpr int kWorkers = kHyperChainWaves - kHyperHidden;      // waves 4 .. 15 hold the weights: rows o = (wave - 4) + 12 r, 4 input channels per lane
     constexpr int kRows = (kHyperWidth + kWorkers - 1) / kWorkers; // 22 (the last ones of some waves fall off the end)
     __shared__ __attribute__((aligned(16))) float scaled[kWorkers * kRows];         // gz[l][o] g[o] / |v[o]|, zero behind row 255
@@ -402,10 +428,11 @@ __global__ __launch_bounds__(kHyperChainThreads) void hyper_hidden_backward_kern
         const int first = __builtin_amdgcn_readfirstlane(wave) - kHyperHidden;      // (wave-uniform row addresses: scalar base, one lane offset)
         float4 row[kRows];
         auto request = [&](int l) {
+            const float* v_l = of_frame(net.v[l], shift);
 #pragma unroll
             for (int r = 0; r < kRows; ++r) {
                 const int o = first + kWorkers * r;
-                row[r] = o < kHyperWidth ? *reinterpret_cast<const float4*>(net.v[l] + static_cast<size_t>(o) * kHyperWidth + 4 * lane) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                row[r] = o < kHyperWidth ? *reinterpret_cast<const float4*>(v_l + static_cast<size_t>(o) * kHyperWidth + 4 * lane) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
         };
         request(kHyperHidden - 1);
@@ -429,13 +456,14 @@ __global__ __launch_bounds__(kHyperChainThreads) void hyper_hidden_backward_kern
     float4 zv = make_float4(0.0f, 0.0f, 0.0f, 0.0f), gam = zv, bet = zv, weight_scale = zv;
     if (wave >= 1) {                                               // wave l: the norm behind linear k = l - 1
         const int k = wave - 1;
-        zv = *reinterpret_cast<const float4*>(net.z[k] + static_cast<size_t>(n) * kHyperWidth + 4 * lane);
-        gam = *reinterpret_cast<const float4*>(net.gamma[k] + 4 * lane);
-        bet = *reinterpret_cast<const float4*>(net.beta[k] + 4 * lane);
-        const float4 g = *reinterpret_cast<const float4*>(net.g[k] + 4 * lane), inv = *reinterpret_cast<const float4*>(net.inv_norm[k] + 4 * lane);
+        zv = *reinterpret_cast<const float4*>(of_frame(net.z[k], shift) + static_cast<size_t>(n) * kHyperWidth + 4 * lane);
+        gam = *reinterpret_cast<const float4*>(of_frame(net.gamma[k], shift) + 4 * lane);
+        bet = *reinterpret_cast<const float4*>(of_frame(net.beta[k], shift) + 4 * lane);
+        const float4 g = *reinterpret_cast<const float4*>(of_frame(net.g[k], shift) + 4 * lane), inv = *reinterpret_cast<const float4*>(of_frame(net.inv_norm[k], shift) + 4 * lane);
         weight_scale = make_float4(g.x * inv.x, g.y * inv.y, g.z * inv.z, g.w * inv.w);
     }
-    scaled[tid] = net.gz[kHyperHidden - 1][static_cast<size_t>(n) * kHyperWidth + tid] * net.g[kHyperHidden - 1][tid] * net.inv_norm[kHyperHidden - 1][tid];
+    scaled[tid] = of_frame(net.gz[kHyperHidden - 1], shift)[static_cast<size_t>(n) * kHyperWidth + tid] * of_frame(net.g[kHyperHidden - 1], shift)[tid] *
+                  of_frame(net.inv_norm[kHyperHidden - 1], shift)[tid];
     if (tid < kWorkers * kRows - kHyperWidth) scaled[kHyperWidth + tid] = 0.0f;
 #pragma unroll
     for (int l = kHyperHidden - 1; l >= 0; --l) {
@@ -449,7 +477,7 @@ __global__ __launch_bounds__(kHyperChainThreads) void hyper_hidden_backward_kern
             hb[0] += share.x; hb[1] += share.y; hb[2] += share.z; hb[3] += share.w;
         }
         if (l == 0) {
-            *reinterpret_cast<float4*>(net.embedding_bar + static_cast<size_t>(n) * kHyperWidth + 4 * lane) = make_float4(hb[0], hb[1], hb[2], hb[3]);
+            *reinterpret_cast<float4*>(of_frame(net.embedding_bar, shift) + static_cast<size_t>(n) * kHyperWidth + 4 * lane) = make_float4(hb[0], hb[1], hb[2], hb[3]);
             continue;
         }
         const int k = l - 1;                                       // the norm behind linear k
@@ -473,8 +501,8 @@ __global__ __launch_bounds__(kHyperChainThreads) void hyper_hidden_backward_kern
         float out[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { out[j] = (y_bar[j] - m1 - y[j] * m2) * inv_std; scaled[4 * lane + j] = out[j] * next_scale[j]; }
-        *reinterpret_cast<float4*>(net.gz[k] + static_cast<size_t>(n) * kHyperWidth + 4 * lane) = make_float4(out[0], out[1], out[2], out[3]);
-        float* shares = net.norm_partials[k] + static_cast<size_t>(n) * 2 * kHyperWidth;
+        *reinterpret_cast<float4*>(of_frame(net.gz[k], shift) + static_cast<size_t>(n) * kHyperWidth + 4 * lane) = make_float4(out[0], out[1], out[2], out[3]);
+        float* shares = of_frame(net.norm_partials[k], shift) + static_cast<size_t>(n) * 2 * kHyperWidth;
         *reinterpret_cast<float4*>(shares + 4 * lane) = make_float4(a_bar[0] * y[0], a_bar[1] * y[1], a_bar[2] * y[2], a_bar[3] * y[3]);
         *reinterpret_cast<float4*>(shares + kHyperWidth + 4 * lane) = make_float4(a_bar[0], a_bar[1], a_bar[2], a_bar[3]);
     }
@@ -489,14 +517,20 @@ struct HyperStepCounters { float* step[32]; int count; };
 
 __global__ __launch_bounds__(kHyperChainThreads) void hyper_finish_kernel(HyperNorms norms, const float* __restrict__ norm_partials, AdamTensors embeddings,
                                                                           const float* __restrict__ embedding_bar, int num_instances, HyperAdam adam,
-                                                                          HyperStepCounters counters, float* embedding_lr, float* hyper_lr, float gamma) {
+                                                                          HyperStepCounters counters, float* embedding_lr, float* hyper_lr, float gamma,
+                                                                          long long frame_stride) {
+    const long long shift = frame_shift(frame_stride, blockIdx.y);      // a batch of frames (wave.h): one workgroup per frame (0 for one frame)
+    VSRD_OF_FRAME(norm_partials, shift); shift_frame(embeddings, shift); VSRD_OF_FRAME(embedding_bar, shift);
+    VSRD_OF_FRAME(embedding_lr, shift); VSRD_OF_FRAME(hyper_lr, shift);
     const int tid = threadIdx.x;
     const int k = tid >> 8, c = tid & (kHyperWidth - 1);          // 4 norms x 256 channels
+    AdamTensors norm_gamma = norms.gamma[k], norm_beta = norms.beta[k];      // (the table stays in the kernel arguments: k is a run-time index)
+    shift_frame(norm_gamma, shift); shift_frame(norm_beta, shift);
     // every operand is requested before anything is computed (one round trip of ~2 us instead of five)
     constexpr int kMaxPerThread = VSRD_MAX_INSTANCES * kHyperWidth / kHyperChainThreads;          // 16 embedding entries per thread at N = 64
-    const float counter = (tid < counters.count) ? *counters.step[tid] : 0.0f;
-    const float old_gamma[3] = {norms.gamma[k].exp_avg[c], norms.gamma[k].exp_avg_sq[c], norms.gamma[k].parameter[c]};
-    const float old_beta[3] = {norms.beta[k].exp_avg[c], norms.beta[k].exp_avg_sq[c], norms.beta[k].parameter[c]};
+    const float counter = (tid < counters.count) ? *of_frame(counters.step[tid], shift) : 0.0f;      // (the table itself stays in the kernel arguments)
+    const float old_gamma[3] = {norm_gamma.exp_avg[c], norm_gamma.exp_avg_sq[c], norm_gamma.parameter[c]};
+    const float old_beta[3] = {norm_beta.exp_avg[c], norm_beta.exp_avg_sq[c], norm_beta.parameter[c]};
     float e_grad[kMaxPerThread], e_m[kMaxPerThread], e_v[kMaxPerThread], e_p[kMaxPerThread];
 #pragma unroll
     for (int it = 0; it < kMaxPerThread; ++it) {
@@ -513,16 +547,16 @@ __global__ __launch_bounds__(kHyperChainThreads) void hyper_finish_kernel(HyperN
         dgamma += src[(static_cast<size_t>(n) * 2 + 0) * kHyperWidth + c];
         dbeta += src[(static_cast<size_t>(n) * 2 + 1) * kHyperWidth + c];
     }
-    const AdamStep step_gamma(norms.gamma[k], adam), step_beta(norms.beta[k], adam), step_embeddings(embeddings, adam);
-    step_gamma.apply(norms.gamma[k], c, dgamma, old_gamma[0], old_gamma[1], old_gamma[2]);
-    step_beta.apply(norms.beta[k], c, dbeta, old_beta[0], old_beta[1], old_beta[2]);
+    const AdamStep step_gamma(norm_gamma, adam), step_beta(norm_beta, adam), step_embeddings(embeddings, adam);
+    step_gamma.apply(norm_gamma, c, dgamma, old_gamma[0], old_gamma[1], old_gamma[2]);
+    step_beta.apply(norm_beta, c, dbeta, old_beta[0], old_beta[1], old_beta[2]);
 #pragma unroll
     for (int it = 0; it < kMaxPerThread; ++it) {
         const int idx = tid + it * kHyperChainThreads;
         if (idx < num_instances * kHyperWidth) step_embeddings.apply(embeddings, idx, e_grad[it], e_m[it], e_v[it], e_p[it]);
     }
     block_lds_barrier();          // every thread has used the counters and the rates it read (an execution barrier: no need to drain the stores above)
-    if (tid < counters.count) *counters.step[tid] = counter + 1.0f;
+    if (tid < counters.count) *of_frame(counters.step[tid], shift) = counter + 1.0f;
     if (tid == 0) { *embedding_lr *= gamma; *hyper_lr *= gamma; }
 }
 

@@ -59,7 +59,16 @@ struct RenderArgs {
     float* out_coarse_weights;
     float* out_u_coarse;
     float* out_u_fine;
+    long long frame_stride;                       // vsrd_render_config::frame_stride (bytes; wave.h: frame batches), 0 for one frame
 };
+
+// Frame f of a batch (wave.h): the pointers inside the argument block move with every other pointer of the launch.
+__device__ __forceinline__ void shift_frame(RenderArgs& c, long long shift) {
+    c.dynamic = of_frame(c.dynamic, shift); c.dynamic_offset = of_frame(c.dynamic_offset, shift);
+    c.ray_indices = of_frame(c.ray_indices, shift); c.target_columns = of_frame(c.target_columns, shift);
+    c.out_distances = of_frame(c.out_distances, shift); c.out_coarse_weights = of_frame(c.out_coarse_weights, shift);
+    c.out_u_coarse = of_frame(c.out_u_coarse, shift); c.out_u_fine = of_frame(c.out_u_fine, shift);
+}
 
 // Row of the frame-resident tensors that step ray `ray` reads (vsrd_render_config::ray_indices), as a wave-uniform value.
 __device__ __forceinline__ long long source_row(const RenderArgs& c, int ray) {
@@ -1149,7 +1158,9 @@ __host__ __device__ constexpr int residual_pair_lds_floats(int num_samples, int 
     return ((7 * num_samples + 3) & ~3) + 16 + kPairWaves * kWave + kPairWaves * residual_pair_wave_floats(num_instances);
 }
 
-template <int kRounds>
+// kFrames: the instantiation for a batch of frames (wave.h): the arguments are moved to the workgroup's frame.  The one-frame instantiation
+// is the code it always was -- both kernels sit at their register limits, and the pointer arithmetic costs the batched form spills.
+template <int kRounds, bool kFrames = false>
 __global__ __launch_bounds__(kPairWaves * kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void residual_step_pair_kernel(
     FieldArgs f, const float* __restrict__ instances, const float* __restrict__ mlp, RenderArgs c,
     const float* __restrict__ origins, const float* __restrict__ directions, const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
@@ -1157,6 +1168,14 @@ __global__ __launch_bounds__(kPairWaves * kWave) __attribute__((amdgpu_waves_per
     float* __restrict__ labels_out, float* __restrict__ partials, float4* __restrict__ residual_cache, float* __restrict__ loss_partials,
     float* __restrict__ seed_table, unsigned char* __restrict__ mask_table, long long slots_per_instance, int chunk_base, int chunk_rays, int accumulate) {
     static_assert(kRounds % kPairWaves == 0, "a wave takes kRounds / 2 rounds of pass 2");
+    if constexpr (kFrames) {               // a batch of frames (wave.h): this workgroup's frame is blockIdx.y
+        const long long shift = frame_shift(c.frame_stride, blockIdx.y);
+        shift_frame(c, shift);
+        VSRD_OF_FRAME_NONNULL(instances, shift); VSRD_OF_FRAME_NONNULL(mlp, shift); VSRD_OF_FRAME_NONNULL(origins, shift); VSRD_OF_FRAME_NONNULL(directions, shift);
+        VSRD_OF_FRAME(u_coarse, shift); VSRD_OF_FRAME(u_fine, shift); VSRD_OF_FRAME_NONNULL(targets, shift); VSRD_OF_FRAME(instance_weights, shift);
+        VSRD_OF_FRAME(labels_out, shift); VSRD_OF_FRAME_NONNULL(partials, shift); VSRD_OF_FRAME_NONNULL(residual_cache, shift); VSRD_OF_FRAME_NONNULL(loss_partials, shift);
+        VSRD_OF_FRAME_NONNULL(seed_table, shift); VSRD_OF_FRAME_NONNULL(mask_table, shift);
+    }
     apply_device_schedule(f, c);
     constexpr int kRoundsS = (kRounds + 1) / 2;                               // rounds of pass 1 (all of them staged and merged by wave 0)
     constexpr int kMine = kRounds / kPairWaves;                               // rounds of pass 2 per wave
@@ -1299,13 +1318,20 @@ __host__ __device__ constexpr int split_lds_floats(int num_samples, int num_inst
     return ((7 * num_samples + 3) & ~3) + 16 + kPairWaves * kWave + kPairWaves * split_wave_floats(num_instances);
 }
 
-template <int kRounds>
+template <int kRounds, bool kFrames = false>      // (kFrames: as residual_step_pair_kernel)
 __global__ __launch_bounds__(kPairWaves * kWave) void render_silhouette_split_kernel(
     FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
     const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
     const float* __restrict__ targets, const float* __restrict__ instance_weights, float loss_scale,
     float* __restrict__ labels_out, float* __restrict__ partials, float* __restrict__ loss_partials) {
     static_assert(kRounds % kPairWaves == 0, "a wave takes kRounds / 2 rounds of pass 2");
+    if constexpr (kFrames) {               // a batch of frames (wave.h): this workgroup's frame is blockIdx.y
+        const long long shift = frame_shift(c.frame_stride, blockIdx.y);
+        shift_frame(c, shift);
+        VSRD_OF_FRAME_NONNULL(instances, shift); VSRD_OF_FRAME_NONNULL(origins, shift); VSRD_OF_FRAME_NONNULL(directions, shift);
+        VSRD_OF_FRAME(u_coarse, shift); VSRD_OF_FRAME(u_fine, shift); VSRD_OF_FRAME_NONNULL(targets, shift); VSRD_OF_FRAME(instance_weights, shift);
+        VSRD_OF_FRAME(labels_out, shift); VSRD_OF_FRAME_NONNULL(partials, shift); VSRD_OF_FRAME_NONNULL(loss_partials, shift);
+    }
     apply_device_schedule(f, c);
     constexpr int kRoundsS = (kRounds + 1) / 2;                               // rounds of pass 1 (all of them staged and merged by wave 0)
     constexpr int kMine = kRounds / kPairWaves;                               // rounds of pass 2 per wave
@@ -1429,7 +1455,13 @@ __global__ __launch_bounds__(kPairWaves * kWave) void render_silhouette_split_ke
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void residual_mlp_adjoint_kernel(
     const float* __restrict__ instances, const float* __restrict__ mlp, int N, unsigned mlp_bits, const float* __restrict__ seed_table,
     const unsigned char* __restrict__ mask_table, long long slots_per_instance, long long used_slots, int items_per_instance, int slots_per_item,
-    unsigned* __restrict__ next_item, float* __restrict__ item_rows, unsigned char* __restrict__ item_flags) {
+    unsigned* __restrict__ next_item, float* __restrict__ item_rows, unsigned char* __restrict__ item_flags, long long frame_stride) {
+    {                                      // a batch of frames (wave.h): blockIdx.y's workgroups fetch the items of frame blockIdx.y, from its own counter
+        const long long shift = frame_shift(frame_stride, blockIdx.y);          // (0 for one frame; straight-line code: hipcc 7.2's register allocator
+        VSRD_OF_FRAME_NONNULL(instances, shift); VSRD_OF_FRAME_NONNULL(mlp, shift); VSRD_OF_FRAME_NONNULL(seed_table, shift);      //  crashed on the branchy form)
+        VSRD_OF_FRAME_NONNULL(mask_table, shift); VSRD_OF_FRAME_NONNULL(next_item, shift); VSRD_OF_FRAME_NONNULL(item_rows, shift);
+        VSRD_OF_FRAME_NONNULL(item_flags, shift);
+    }
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = lane_id();
     const LdsFloats staged = (LdsFloats)lds;                                   // [1632] this item's instance weights, centred
@@ -1515,7 +1547,13 @@ constexpr int kMlpSplitScratchTiles = 4;
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void residual_mlp_adjoint_split_kernel(
     const float* __restrict__ instances, const float* __restrict__ mlp, int N, unsigned mlp_bits, const float* __restrict__ seed_table,
     const unsigned char* __restrict__ mask_table, long long slots_per_instance, long long used_slots, int items_per_instance, int slots_per_item,
-    unsigned* __restrict__ next_item, float* __restrict__ item_rows, unsigned char* __restrict__ item_flags) {
+    unsigned* __restrict__ next_item, float* __restrict__ item_rows, unsigned char* __restrict__ item_flags, long long frame_stride) {
+    {                                      // a batch of frames (wave.h): blockIdx.y's workgroups fetch the items of frame blockIdx.y, from its own counter
+        const long long shift = frame_shift(frame_stride, blockIdx.y);          // (0 for one frame; straight-line code: hipcc 7.2's register allocator
+        VSRD_OF_FRAME_NONNULL(instances, shift); VSRD_OF_FRAME_NONNULL(mlp, shift); VSRD_OF_FRAME_NONNULL(seed_table, shift);      //  crashed on the branchy form)
+        VSRD_OF_FRAME_NONNULL(mask_table, shift); VSRD_OF_FRAME_NONNULL(next_item, shift); VSRD_OF_FRAME_NONNULL(item_rows, shift);
+        VSRD_OF_FRAME_NONNULL(item_flags, shift);
+    }
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = lane_id();
     const LdsWords staged = (LdsWords)lds;                                     // [kMlpImageWords] this item's instance: the operand image
@@ -1595,7 +1633,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 // VSRD_FLAG_MLP_SPLIT_BF16: the operand images of a launch's instances (residual.h: pack_mlp_image), one workgroup per instance, once per
 // vsrd_render_residual_step call (N x 9.4 KB: the front kernels stage an instance's image where they staged its 6.5 KB of weights).
 #ifdef VSRD_SPLIT_BF16      // (csrc/split_front.hip only)
-__global__ __launch_bounds__(256) void pack_mlp_images_kernel(const float* __restrict__ weights, int centred, unsigned* __restrict__ images) {
+__global__ __launch_bounds__(256) void pack_mlp_images_kernel(const float* __restrict__ weights, int centred, unsigned* __restrict__ images, long long frame_stride) {
+    if (frame_stride != 0) { const long long shift = frame_shift(frame_stride, blockIdx.y); VSRD_OF_FRAME(weights, shift); VSRD_OF_FRAME(images, shift); }
     __shared__ __attribute__((aligned(16))) float staged[kMlpWbarFloats];
     const int n = blockIdx.x;
     stage_centred_weights((LdsFloats)staged, weights + static_cast<size_t>(n) * kMlpWeights, centred != 0, static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x));
@@ -1610,8 +1649,12 @@ __global__ __launch_bounds__(256) void pack_mlp_images_kernel(const float* __res
 constexpr int kItemSegments = 32;
 
 __global__ __launch_bounds__(256) void reduce_item_rows_kernel(const float* __restrict__ item_rows, const unsigned char* __restrict__ item_flags,
-                                                               int rows_per_instance, float* __restrict__ segment_sums) {
-    const int i = blockIdx.x, segment = blockIdx.z;
+                                                               int rows_per_instance, float* __restrict__ segment_sums, long long frame_stride) {
+    const int i = blockIdx.x, segment = blockIdx.z % kItemSegments;
+    if (frame_stride != 0) {               // a batch of frames (wave.h): the grid's z extent is frames x segments
+        const long long shift = frame_shift(frame_stride, blockIdx.z / kItemSegments);
+        VSRD_OF_FRAME(item_rows, shift); VSRD_OF_FRAME(item_flags, shift); VSRD_OF_FRAME(segment_sums, shift);
+    }
     const int idx = blockIdx.y * blockDim.x + threadIdx.x;
     if (idx >= kItemRowFloats) return;
     const int per_segment = (rows_per_instance + kItemSegments - 1) / kItemSegments;
@@ -1633,7 +1676,8 @@ __global__ __launch_bounds__(256) void reduce_item_rows_kernel(const float* __re
 
 // grad_mlp [N,1617] (+)= the segment sums of instance i; box_extra [N,16] likewise (the MLP's dL/dp chained into t and R).
 __global__ __launch_bounds__(256) void reduce_item_segments_kernel(const float* __restrict__ segment_sums, float* __restrict__ grad_mlp,
-                                                                   float* __restrict__ box_extra, int accumulate) {
+                                                                   float* __restrict__ box_extra, int accumulate, long long frame_stride) {
+    if (frame_stride != 0) { const long long shift = frame_shift(frame_stride, blockIdx.z); VSRD_OF_FRAME(segment_sums, shift); VSRD_OF_FRAME(grad_mlp, shift); VSRD_OF_FRAME(box_extra, shift); }
     const int i = blockIdx.x;
     const int idx = blockIdx.y * blockDim.x + threadIdx.x;
     if (idx >= kItemRowFloats) return;
@@ -1652,7 +1696,12 @@ __global__ __launch_bounds__(256) void reduce_item_segments_kernel(const float* 
 // rows of `row2` numbers, summed into out2) rides in the same launch: workgroups row .. row + row2 - 1.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int num_waves, int row, float* __restrict__ out,
                                                               const float* __restrict__ extra = nullptr,
-                                                              const float* __restrict__ partials2 = nullptr, int row2 = 0, float* __restrict__ out2 = nullptr) {
+                                                              const float* __restrict__ partials2 = nullptr, int row2 = 0, float* __restrict__ out2 = nullptr,
+                                                              long long frame_stride = 0) {
+    if (frame_stride != 0) {               // a batch of frames (wave.h): frame blockIdx.y
+        const long long shift = frame_shift(frame_stride, blockIdx.y);
+        VSRD_OF_FRAME(partials, shift); VSRD_OF_FRAME(out, shift); VSRD_OF_FRAME(extra, shift); VSRD_OF_FRAME(partials2, shift); VSRD_OF_FRAME(out2, shift);
+    }
     __shared__ float scratch[256 / kWave];
     const bool second = static_cast<int>(blockIdx.x) >= row;
     const int idx = second ? static_cast<int>(blockIdx.x) - row : static_cast<int>(blockIdx.x);

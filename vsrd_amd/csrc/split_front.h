@@ -21,15 +21,16 @@ struct FrontLaunch {
     bool pair;                                             // residual_step_pair_kernel (a ray over two waves) or residual_step_front_kernel
     int rounds, blocks;
     size_t lds_bytes;
+    int frames;                                            // frame batch (include/vsrd_hip.h, ABI 8): the grid's y extent; the stride travels in RenderArgs
 };
 
 enum { kOk = 0, kLdsRefused = 1, kUnsupported = 2, kLaunchFailed = 3 };
 
-int pack_images(const float* weights, int num_instances, int centred, unsigned* images, hipStream_t stream);
+int pack_images(const float* weights, int num_instances, int centred, unsigned* images, int frames, long long frame_stride, hipStream_t stream);
 int launch_front(const FrontLaunch& launch, hipStream_t stream);
 // residual_mlp_adjoint_split_kernel: the arguments of residual_mlp_adjoint_kernel with the image table in the place of the weights
 int launch_adjoint(int blocks, const float* instances, const float* images, int num_instances, const float* seeds, const unsigned char* masks,
                    long long slots_per_instance, long long used_slots, int items_per_instance, int slots_per_item, unsigned* next_item, float* item_rows,
-                   unsigned char* item_flags, hipStream_t stream);
+                   unsigned char* item_flags, int frames, long long frame_stride, hipStream_t stream);
 
 }  // namespace vsrd_split_front

@@ -11,8 +11,8 @@
 
 namespace vsrd_split_front {
 
-int pack_images(const float* weights, int num_instances, int centred, unsigned* images, hipStream_t stream) {
-    hipLaunchKernelGGL(vsrd_split::pack_mlp_images_kernel, dim3(num_instances), dim3(256), 0, stream, weights, centred, images);
+int pack_images(const float* weights, int num_instances, int centred, unsigned* images, int frames, long long frame_stride, hipStream_t stream) {
+    hipLaunchKernelGGL(vsrd_split::pack_mlp_images_kernel, dim3(num_instances, frames), dim3(256), 0, stream, weights, centred, images, frame_stride);
     return hipGetLastError() == hipSuccess ? kOk : kLaunchFailed;
 }
 
@@ -36,12 +36,18 @@ int launch_front(const FrontLaunch& a, hipStream_t stream) {
 #define VSRD_FRONT(K)                                                                                                                         \
     do {                                                                                                                                      \
         if (!opt_in(residual_step_front_kernel<K>, a.lds_bytes)) return kLdsRefused;                                                          \
+        if (a.frames > 1) return kUnsupported;          /* (a batch's frames are launches of <= 2048 rays: the pair kernel) */                \
         hipLaunchKernelGGL(residual_step_front_kernel<K>, dim3(a.blocks), dim3(kBlockThreads), a.lds_bytes, stream, VSRD_ARGS);               \
     } while (0)
 #define VSRD_PAIR(K)                                                                                                                          \
     do {                                                                                                                                      \
-        if (!opt_in(residual_step_pair_kernel<K>, a.lds_bytes)) return kLdsRefused;                                                           \
-        hipLaunchKernelGGL(residual_step_pair_kernel<K>, dim3(a.blocks), dim3(kPairWaves * kWave), a.lds_bytes, stream, VSRD_ARGS);           \
+        if (a.frames > 1) {                                                                                                                   \
+            if (!opt_in(residual_step_pair_kernel<K, true>, a.lds_bytes)) return kLdsRefused;                                                 \
+            hipLaunchKernelGGL((residual_step_pair_kernel<K, true>), dim3(a.blocks, a.frames), dim3(kPairWaves * kWave), a.lds_bytes, stream, VSRD_ARGS); \
+        } else {                                                                                                                              \
+            if (!opt_in(residual_step_pair_kernel<K>, a.lds_bytes)) return kLdsRefused;                                                       \
+            hipLaunchKernelGGL(residual_step_pair_kernel<K>, dim3(a.blocks), dim3(kPairWaves * kWave), a.lds_bytes, stream, VSRD_ARGS);       \
+        }                                                                                                                                     \
     } while (0)
     if (a.pair) {
         switch (a.rounds) {
@@ -65,11 +71,11 @@ int launch_front(const FrontLaunch& a, hipStream_t stream) {
 
 int launch_adjoint(int blocks, const float* instances, const float* images, int num_instances, const float* seeds, const unsigned char* masks,
                    long long slots_per_instance, long long used_slots, int items_per_instance, int slots_per_item, unsigned* next_item, float* item_rows,
-                   unsigned char* item_flags, hipStream_t stream) {
+                   unsigned char* item_flags, int frames, long long frame_stride, hipStream_t stream) {
     using namespace vsrd_split;
     const size_t lds = (static_cast<size_t>(kMlpImageWords) + static_cast<size_t>(kMlpSplitScratchTiles) * kTileFloats) * sizeof(float);
-    hipLaunchKernelGGL(residual_mlp_adjoint_split_kernel, dim3(blocks), dim3(kWave), lds, stream, instances, images, num_instances, 0u, seeds, masks,
-                       slots_per_instance, used_slots, items_per_instance, slots_per_item, next_item, item_rows, item_flags);
+    hipLaunchKernelGGL(residual_mlp_adjoint_split_kernel, dim3(blocks, frames), dim3(kWave), lds, stream, instances, images, num_instances, 0u, seeds, masks,
+                       slots_per_instance, used_slots, items_per_instance, slots_per_item, next_item, item_rows, item_flags, frame_stride);
     return hipGetLastError() == hipSuccess ? kOk : kLaunchFailed;
 }
 

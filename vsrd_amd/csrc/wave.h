@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace vsrd {
 
@@ -15,6 +16,27 @@ __device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) 
 __device__ __forceinline__ int wave_in_block() {
     return __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
 }
+
+// ---- frame batches (include/vsrd_hip.h, ABI 8: vsrd_frame_batch) ---------------------------------------------------------------
+// A launch over B frames is B copies of the one-frame grid stacked along blockIdx.y (kernels whose own grid is 2-D or 3-D: along
+// blockIdx.z), and copy f works on frame f's buffers: EVERY device pointer of the launch addresses frame 0's buffer, and frame f's lies
+// `frame_stride` bytes x f behind it (the caller lays the frames' buffers out in one arena with one stride).  Nothing else differs
+// between the copies -- same blockIdx.x / gridDim.x, same by-value arguments -- so frame f's results are bit for bit those of a launch
+// on frame f alone.  `of_frame` keeps the argument's provenance (a byte offset on the same object, nullptr stays nullptr): the
+// compiler still selects scalar loads for the wave-uniform parameter reads.
+__device__ __forceinline__ long long frame_shift(long long frame_stride, unsigned frame) { return frame_stride * static_cast<long long>(frame); }
+template <typename T>
+__device__ __forceinline__ T* of_frame(T* p, long long shift) {
+    return p ? reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_cv<T>::type*>(p)) + shift) : p;
+}
+// for arguments declared `T* __restrict__ p`: VSRD_OF_FRAME(p, shift) re-points the argument itself
+#define VSRD_OF_FRAME(p, shift) p = of_frame(p, shift)
+// ... and for arguments that are never null (no select)
+template <typename T>
+__device__ __forceinline__ T* of_frame_nonnull(T* p, long long shift) {
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_cv<T>::type*>(p)) + shift);
+}
+#define VSRD_OF_FRAME_NONNULL(p, shift) p = of_frame_nonnull(p, shift)
 
 __device__ __forceinline__ float uniform(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));

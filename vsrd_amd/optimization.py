@@ -155,6 +155,10 @@ def _destroy_graphs(graphs, wait=True):
         graphs.clear()
 
 
+class UnsuitableFrameError(ValueError):
+    """A frame that cannot be served by a persistent frame slot (its importance weights do not suit the slot's table sampler)."""
+
+
 @dataclass
 class FrameInputs:
     """What scripts/main.py:106-316 prepares for one target frame; view 0 is the target view."""
@@ -196,18 +200,72 @@ class OptimizationConfig:
     init_seed: Optional[int] = None
 
 
-def adam_state_tensors(optimizer, parameter, group):
+class FrameArena:
+    """Device memory of a BATCH of frames (include/vsrd_hip.h, "frame batches"): one row of ``row_bytes`` per frame, and every buffer a
+    frame's kernels touch sits at the SAME offset of its frame's row -- frame f's copy of a buffer is ``stride`` bytes x f behind frame 0's,
+    which is all a batched launch needs to know.  The rows are filled by the frames' own constructors (``FrameRow.new``): same calls in the
+    same order give the same offsets, which ``FrameBatch`` verifies."""
+
+    ALIGNMENT = 256
+
+    def __init__(self, num_frames, row_bytes, device):
+        self.stride = (int(row_bytes) + self.ALIGNMENT - 1) // self.ALIGNMENT * self.ALIGNMENT
+        self.buffer = torch.empty(int(num_frames), self.stride, dtype=torch.uint8, device=device)
+        self.rows = [FrameRow(self, f) for f in range(int(num_frames))]
+
+
+class FrameRow:
+    """Bump allocator over one frame's row of a ``FrameArena``."""
+
+    def __init__(self, arena, index):
+        self.arena, self.index = arena, index
+        self.cursor = 0
+        self.layout = []                 # (offset, nbytes) of every buffer, in order: equal across the rows of an arena
+
+    def bytes(self, nbytes):
+        nbytes = int(nbytes)
+        offset = self.cursor
+        end = offset + nbytes
+        if end > self.arena.stride:
+            raise RuntimeError(f"frame arena row of {self.arena.stride} bytes exhausted ({end} needed): FrameBatch._row_bytes is too small")
+        self.cursor = (end + FrameArena.ALIGNMENT - 1) // FrameArena.ALIGNMENT * FrameArena.ALIGNMENT
+        self.layout.append((offset, nbytes))
+        return self.arena.buffer[self.index, offset:end]
+
+    def new(self, shape, dtype=torch.float32, fill=None):
+        shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)))
+        count = 1
+        for x in shape:
+            count *= x
+        view = self.bytes(count * torch.empty((), dtype=dtype).element_size()).view(dtype).view(shape)
+        if fill is not None:
+            view.fill_(fill)
+        return view
+
+    def adopt(self, tensor):
+        """A row-resident copy of `tensor` (same shape, dtype and values)."""
+        view = self.new(tensor.shape, tensor.dtype)
+        view.copy_(tensor)
+        return view
+
+
+def adam_state_tensors(optimizer, parameter, group, row=None):
     """`parameter`'s torch.optim.Adam(capturable=True) state as the C ABI's pointer block, created now if the optimiser has not
-    stepped yet (torch creates it lazily): the kernels update the moments, the counter and the parameter in place."""
+    stepped yet (torch creates it lazily): the kernels update the moments, the counter and the parameter in place.  `row`: the frame's
+    row of a batch's arena (FrameRow) -- the state is created there."""
     state = optimizer.state[parameter]
     if not state:
-        state["step"] = torch.zeros((), dtype=torch.float32, device=parameter.device)
-        state["exp_avg"], state["exp_avg_sq"] = torch.zeros_like(parameter), torch.zeros_like(parameter)
+        if row is not None:
+            state["step"] = row.new((), torch.float32, fill=0.0)
+            state["exp_avg"], state["exp_avg_sq"] = row.new(parameter.shape, torch.float32, fill=0.0), row.new(parameter.shape, torch.float32, fill=0.0)
+        else:
+            state["step"] = torch.zeros((), dtype=torch.float32, device=parameter.device)
+            state["exp_avg"], state["exp_avg_sq"] = torch.zeros_like(parameter), torch.zeros_like(parameter)
     return _lib.AdamTensors(parameter.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(), state["step"].data_ptr(),
                             group["lr"].data_ptr())
 
 
-def hypernetwork_tensors(hyper_distance_field, embeddings, optimizer, lr_gamma):
+def hypernetwork_tensors(hyper_distance_field, embeddings, optimizer, lr_gamma, row=None):
     """include/vsrd_hip.h::vsrd_hypernetwork over the torch module's own parameters and the optimiser's own state.  `optimizer`'s
     groups: the one holding `embeddings` and the one holding the hypernetwork, learning rates as device tensors."""
     def group_of(p):
@@ -216,16 +274,16 @@ def hypernetwork_tensors(hyper_distance_field, embeddings, optimizer, lr_gamma):
     net.num_instances, net.num_outputs = int(embeddings.shape[-2]), _lib.MLP_WEIGHTS
     betas = group_of(embeddings)["betas"]
     net.beta1, net.beta2, net.adam_epsilon, net.lr_gamma = float(betas[0]), float(betas[1]), float(group_of(embeddings)["eps"]), float(lr_gamma)
-    net.embeddings = adam_state_tensors(optimizer, embeddings, group_of(embeddings))
+    net.embeddings = adam_state_tensors(optimizer, embeddings, group_of(embeddings), row)
     blocks = list(hyper_distance_field.hypernetwork)
     if len(blocks) != _lib.HYPER_LAYERS or embeddings.shape[-1] != 256 or not all(p.is_contiguous() for p in hyper_distance_field.parameters()):
         raise ValueError("csrc/hypernetwork.h is built for config.json:143-156: 256-d embeddings, four hidden blocks of 256")
     for l, block in enumerate(blocks):
         linear = block[0]
-        net.weight_v[l], net.weight_g[l], net.bias[l] = (adam_state_tensors(optimizer, p, group_of(p)) for p in (linear.weight_v, linear.weight_g, linear.bias))
+        net.weight_v[l], net.weight_g[l], net.bias[l] = (adam_state_tensors(optimizer, p, group_of(p), row) for p in (linear.weight_v, linear.weight_g, linear.bias))
         if l + 1 < len(blocks):
-            net.norm_weight[l] = adam_state_tensors(optimizer, block[1].weight, group_of(block[1].weight))
-            net.norm_bias[l] = adam_state_tensors(optimizer, block[1].bias, group_of(block[1].bias))
+            net.norm_weight[l] = adam_state_tensors(optimizer, block[1].weight, group_of(block[1].weight), row)
+            net.norm_bias[l] = adam_state_tensors(optimizer, block[1].bias, group_of(block[1].bias), row)
     return net
 
 
@@ -237,11 +295,16 @@ class FrameOptimizer:
     frame-resident tensors by index; in the residual phase the hypernetwork, its backward and its Adam are csrc/hypernetwork.h
     (``fused_hypernetwork = False`` keeps them with torch: the A/B reference)."""
 
-    def __init__(self, inputs: FrameInputs, config: OptimizationConfig, device, graph=False, fused_glue=None, persistent=False):
+    def __init__(self, inputs: FrameInputs, config: OptimizationConfig, device, graph=False, fused_glue=None, persistent=False, row=None):
         """``persistent``: the loop will be given other frames of the same shape through ``reset()`` (a frame SLOT, launcher.py): it then
-        owns every buffer a captured graph holds the address of -- in particular a copy of the soft masks instead of the caller's tensor."""
+        owns every buffer a captured graph holds the address of -- in particular a copy of the soft masks instead of the caller's tensor.
+        ``row`` (a ``FrameRow``): the loop is one frame of a ``FrameBatch`` and keeps EVERY device buffer its kernels touch -- parameters,
+        Adam's state, rates, counters, rays, masks, sampling table, scratch -- in that row of the batch's arena."""
         self._graphs = {}
         self.persistent = bool(persistent)
+        self._row = row
+        if row is not None and not (graph and persistent and fused_glue in (None, True)):
+            raise ValueError("a frame of a batch is a persistent graph-mode loop with the fused glue")
         # the whole construction stays out of other frames' captures: it copies modules to the device, reads ranges back (.item()), runs
         # nonzero -- host synchronisations that, next to ANOTHER frame's capture, fail now and then or break that capture ("capturing
         # stream has unjoined work" in the other thread: one 36-frame run in fourteen)
@@ -265,7 +328,12 @@ class FrameOptimizer:
             # config.json:143-156: per-instance residual MLP 48->16->16->16->16->1 generated from 256-d embeddings
             field = models.HyperDistanceField(48, [16, 16, 16, 16], 256, [256, 256, 256, 256])
         self.detector, self.hyper_distance_field = detector.to(self.device), field.to(self.device)
+        if self._row is not None:          # the parameters move into the frame's row (module order: the same in every frame of the batch)
+            for p in [*self.detector.parameters(), *self.hyper_distance_field.parameters()]:
+                p.data = self._row.adopt(p.data)
         def rate(value):   # graph mode: learning rates are device tensors decayed in place inside the captured step
+            if self._row is not None:
+                return self._row.new((), torch.float32, fill=value)
             return torch.tensor(value, dtype=torch.float32, device=self.device) if self.graph else value
         groups = [dict(params=[p], lr=rate(config.learning_rate)) for p in (self.detector.locations, self.detector.dimensions, self.detector.orientations)]
         groups.append(dict(params=[self.detector.embeddings], lr=rate(config.embedding_learning_rate)))
@@ -273,11 +341,11 @@ class FrameOptimizer:
         self.optimizer = torch.optim.Adam(groups, lr=rate(config.learning_rate), capturable=self.graph)
         self.scheduler = None if self.graph else torch.optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=config.lr_gamma)
         # per-step scalars on the device (graph mode): step index = Philox counter, (temperature, std, cosine_ratio)
-        self.step_tensor = torch.zeros(1, dtype=torch.int64, device=self.device)
-        self.schedule = torch.ones(3, dtype=torch.float32, device=self.device)
+        self.step_tensor = self._new(1, torch.int64, fill=0)
+        self.schedule = self._new(3, torch.float32, fill=1.0)
         # this frame's own scratch (frames may be optimised concurrently on other streams); freed with the optimizer.  Graph mode
         # sizes it for the residual phase up front: a captured graph holds the buffer's address
-        self.workspace = rendering.Workspace()
+        self.workspace = rendering.Workspace(allocate=None if self._row is None else self._row.bytes)
         if self.graph:
             self.workspace.keep_outgrown = True          # a captured graph holds the buffer's address: an outgrown buffer must outlive it
             self.workspace.reserve(self.device, N, residual=True, step_shape=(config.num_samples, config.num_rays))
@@ -290,17 +358,34 @@ class FrameOptimizer:
         if self.fused_glue:
             self._init_fused_glue()
 
+    def _new(self, shape, dtype=torch.float32, fill=None):
+        """A device buffer of this loop: in the frame's row of the batch's arena when there is one."""
+        if self._row is not None:
+            return self._row.new(shape, dtype, fill)
+        if fill is None:
+            return torch.empty(shape, dtype=dtype, device=self.device)
+        return torch.full(shape if isinstance(shape, (tuple, list)) else (shape,), fill, dtype=dtype, device=self.device)
+
+    def _own(self, tensor):
+        """`tensor` as a buffer of this loop: a copy in the frame's row of the batch's arena, or the tensor itself."""
+        return tensor if self._row is None else self._row.adopt(tensor)
+
     def _prepare_rays(self, inputs, config, H, W, N):
         # rays of every view, once per frame (main.py:267-296)
         cam, dirs = rendering.ray_casting((H, W), inputs.intrinsic_matrices, inputs.extrinsic_matrices)
-        self.camera_positions = cam                                         # [V,3]
-        self.ray_directions = dirs.reshape(-1, 3).contiguous()              # [V*H*W,3]
+        self.camera_positions = self._own(cam)                              # [V,3]
+        self.ray_directions = self._own(dirs.reshape(-1, 3).contiguous())   # [V*H*W,3]
         self.flat_masks = inputs.soft_masks.reshape(-1, N)
-        if self.persistent:                                                 # (a slot's graphs read the masks through this address for every later frame)
+        if self._row is not None:
+            self.flat_masks = self._row.adopt(self.flat_masks.to(torch.float32))
+        elif self.persistent:                                               # (a slot's graphs read the masks through this address for every later frame)
             self.flat_masks = self.flat_masks.to(torch.float32).clone(memory_format=torch.contiguous_format)
-        self.sampling_weights = self.flat_masks.max(dim=-1).values.to(torch.float32).contiguous()          # main.py:620-624
+        self.sampling_weights = self._own(self.flat_masks.max(dim=-1).values.to(torch.float32).contiguous())          # main.py:620-624
         self.ray_table = self.ray_remap = None
-        self._prepare_sampler(config)
+        if not self._prepare_sampler(config):
+            raise UnsuitableFrameError("this frame's importance weights do not suit the table sampler (too much of the weight in fewer pixels "
+                                       "than a draw needs; rendering.RayTable.suits): it cannot found a frame slot -- optimise it in a loop of "
+                                       "its own (persistent=False), which keeps the per-step race sampler")
 
     def _prepare_sampler(self, config):
         """What depends on the frame's importance weights (fixed for the frame).  Graph mode draws the rays on the device: the sampler's
@@ -320,11 +405,13 @@ class FrameOptimizer:
         had_table = self.ray_table is not None
         if had_table:
             self.ray_table.rebuild(self.sampling_weights)
-        table = self.ray_table if had_table else rendering.RayTable(self.sampling_weights)
+        table = self.ray_table if had_table else rendering.RayTable(self.sampling_weights, allocate=None if self._row is None else self._row.bytes)
         if table.suits(config.num_rays):
             self.ray_table = table
             return True
-        if had_table:
+        if had_table or self.persistent:
+            # a slot's graphs are captured with ONE sampler: a frame that does not suit the table cannot take over a slot (nor found one:
+            # __init__ raises UnsuitableFrameError) -- the caller optimises it in a loop of its own, with the race sampler
             return False
         # the race sampler only visits the pixels that can be drawn at all
         self.positive_pixels = torch.nonzero(self.sampling_weights > 0).flatten()
@@ -359,27 +446,28 @@ class FrameOptimizer:
         b["visible"] = inp.visible_masks.to(device=dev, dtype=torch.uint8).contiguous()
         if self.persistent:       # a slot OWNS what reset() overwrites: float32 contiguous inputs would otherwise be these very tensors -- the
             for name in ("extrinsics", "intrinsics", "gt_boxes", "visible"):      # caller's, and every other slot's built from the same frame
-                b[name] = b[name].clone()
-        b["scratch"] = torch.empty(lib.vsrd_frame_scratch_bytes(V, N), dtype=torch.uint8, device=dev)
-        b["instances"] = torch.zeros(N, 16, **f32)
-        b["pd_indices"], b["gt_indices"] = torch.zeros(N, dtype=torch.int64, device=dev), torch.zeros(N, dtype=torch.int64, device=dev)
-        b["target_columns"] = torch.zeros(N, dtype=torch.int32, device=dev)
-        b["instance_weights"] = torch.ones(N, **f32)
-        b["projection_losses"], b["render_losses"] = torch.zeros(2, **f32), torch.zeros(2, **f32)
-        b["grad_raw"], b["raw_gradients"] = torch.zeros(N, 8, **f32), torch.zeros(N, 8, **f32)
-        b["grad_instances"], b["grad_mlp"] = torch.zeros(N, 16, **f32), torch.zeros(N, _lib.MLP_WEIGHTS, **f32)
-        b["record"] = torch.zeros(5, **f32)
+                b[name] = b[name].clone() if self._row is None else self._row.adopt(b[name])
+        new = self._new            # (a frame of a batch: everything below lives in the frame's row of the arena)
+        b["scratch"] = new(lib.vsrd_frame_scratch_bytes(V, N), torch.uint8)
+        b["instances"] = new((N, 16), fill=0.0)
+        b["pd_indices"], b["gt_indices"] = new(N, torch.int64, fill=0), new(N, torch.int64, fill=0)
+        b["target_columns"] = new(N, torch.int32, fill=0)
+        b["instance_weights"] = new(N, fill=1.0)
+        b["projection_losses"], b["render_losses"] = new(2, fill=0.0), new(2, fill=0.0)
+        b["grad_raw"], b["raw_gradients"] = new((N, 8), fill=0.0), new((N, 8), fill=0.0)
+        b["grad_instances"], b["grad_mlp"] = new((N, 16), fill=0.0), new((N, _lib.MLP_WEIGHTS), fill=0.0)
+        b["record"] = new(5, fill=0.0)
         b["masks"] = self.flat_masks.to(**f32).contiguous()        # (persistent: _prepare_rays made this the slot's own copy)
         self.fused_hypernetwork = True
         self.rebind()
-        b["hyper_workspace"] = torch.empty(lib.vsrd_hypernetwork_workspace_bytes(N), dtype=torch.uint8, device=dev)
+        b["hyper_workspace"] = new(lib.vsrd_hypernetwork_workspace_bytes(N), torch.uint8)
         # the three things a step needs before its render launch -- its rays, the boxes' side (prologue) and the generated MLP weights --
         # do not depend on each other: they run as three branches (two side streams, forked from and joined to the step's stream), and
         # so do the two things after it (epilogue, hypernetwork backward).  Captured, they become parallel branches of the hipGraph
         self._branches = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
-        b["picks"] = torch.zeros(cfg.num_rays, dtype=torch.int64, device=dev)
-        b["ray_indices"] = torch.zeros(cfg.num_rays, dtype=torch.int64, device=dev)
-        b["mlp_weights"], b["mlp_centred"] = torch.zeros(N, _lib.MLP_WEIGHTS, **f32), torch.zeros(N, _lib.MLP_WEIGHTS, **f32)
+        b["picks"] = new(cfg.num_rays, torch.int64, fill=0)
+        b["ray_indices"] = new(cfg.num_rays, torch.int64, fill=0)
+        b["mlp_weights"], b["mlp_centred"] = new((N, _lib.MLP_WEIGHTS), fill=0.0), new((N, _lib.MLP_WEIGHTS), fill=0.0)
 
     # ---- the tensors whose addresses the kernels and the captured graphs hold ----------------------------------------------------
     def _bound_tensors(self):
@@ -422,11 +510,11 @@ class FrameOptimizer:
                 state = self.optimizer.state.get(p)
                 if state and not (isinstance(state.get("step"), torch.Tensor) and state["step"].device == self.device and state["step"].dtype == torch.float32):
                     state["step"] = torch.as_tensor(float(state["step"]), dtype=torch.float32, device=self.device).clone()
-        self._adam = [adam_state_tensors(self.optimizer, p, group)
+        self._adam = [adam_state_tensors(self.optimizer, p, group, self._row)
                       for group, p in zip(self.optimizer.param_groups[:3], (det.locations, det.dimensions, det.orientations))]
         # the hypernetwork and the embeddings (residual phase) run through csrc/hypernetwork.h on the same footing: torch's module
         # owns the parameters, torch.optim.Adam owns the moments and counters, the kernels update both in place
-        self._hypernetwork = hypernetwork_tensors(self.hyper_distance_field, det.embeddings, self.optimizer, cfg.lr_gamma)
+        self._hypernetwork = hypernetwork_tensors(self.hyper_distance_field, det.embeddings, self.optimizer, cfg.lr_gamma, self._row)
         _destroy_graphs(self._graphs)
         # references keep every bound tensor alive until the next rebind: a replaced tensor's memory is not handed to somebody else
         # while a graph that writes through its address may still be replayed
@@ -444,14 +532,21 @@ class FrameOptimizer:
                 or tuple(t.data_ptr() for t in current) != self._bound_signature):
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("a tensor bound to the captured step was replaced during stream capture")
+            if self._row is not None:
+                raise RuntimeError("a parameter, moment, counter or rate of a batch frame was REPLACED (load_state_dict, module.to, assign=True): "
+                                   "the frames of a FrameBatch keep them at fixed offsets of the batch's arena -- copy_ into the existing tensors")
             with _capture_lock:                          # (a device-wide synchronisation is refused while another frame's thread captures)
                 torch.cuda.synchronize(self.device)      # replays that still write through the old addresses finish first
             self.rebind()
 
-    def _fused_step(self, ray_indices, count=True, joins=(True, True)):
+    def _fused_step(self, ray_indices, count=True, joins=(True, True), frames=None):
         """One step with the box-side glue in frame_step.h.  Same arithmetic as `_step_in_scope` (the eager torch path is its
-        parity reference: tests/test_hip_step.py)."""
+        parity reference: tests/test_hip_step.py).  ``frames = (B, stride)``: this loop is frame 0 of a batch (``FrameBatch``) and
+        every launch of the step covers the B frames whose buffers lie ``stride`` bytes apart (include/vsrd_hip.h, "frame batches")."""
         cfg, b, lib, frame = self.config, self._glue, _lib.load(), self._frame
+        batch = (1, 0) if frames is None else (int(frames[0]), int(frames[1]))
+        frame.num_frames, frame.frame_stride = batch
+        self._hypernetwork.num_frames, self._hypernetwork.frame_stride = batch
         det = self.detector
         N = self.num_instances
         residual = self.step_index >= cfg.warmup_steps
@@ -462,6 +557,9 @@ class FrameOptimizer:
         sampled = ray_indices is None
         # the draw rides in the prologue's launch (a second workgroup): no branch, no join
         with_prologue = sampled and self.ray_table is not None and getattr(self, "_prologue_draws", True)
+        if batch[0] > 1 and not (with_prologue and (fused_net or not residual)):
+            raise RuntimeError("a batch of frames draws its rays from the frames' sampling tables inside the prologue launch and runs the "
+                               "hypernetwork through csrc/hypernetwork.h")
         if sampled and not with_prologue:   # branch 1: this step's rays (device sampler keyed by the step counter, ray_sampling.h)
             rays_branch.wait_stream(main)
             with torch.cuda.stream(rays_branch):
@@ -484,7 +582,7 @@ class FrameOptimizer:
             table = self.ray_table
             code = lib.vsrd_frame_prologue_sample(*prologue_args, table.table.data_ptr(), table.count, cfg.num_rays, (cfg.seed + 1) & 0xFFFFFFFFFFFFFFFF,
                                                   None, b["ray_indices"].data_ptr(), stream)          # (the table covers every pixel: no remap)
-            if code == _lib.E_UNSUPPORTED and not torch.cuda.is_current_stream_capturing():
+            if code == _lib.E_UNSUPPORTED and batch[0] == 1 and not torch.cuda.is_current_stream_capturing():
                 # the combined launch needs ~125 KB of LDS in one workgroup (cost matrix + the sampler's hash table): where that opt-in is
                 # refused (and only then: a failed launch is an error), the frame keeps the bit-identical two-launch form
                 # (tests: test_frame_prologue_matches_the_torch_path)
@@ -524,7 +622,7 @@ class FrameOptimizer:
         workspace = self.workspace.adjoint(self.device, N, residual, step_shape=(cfg.num_samples, R))
         field = _lib.make_field(b["instances"], 1.0, centred)          # (the temperature comes from the device schedule)
         config = _lib.make_config(R, cfg.num_samples, cfg.distance_range, 1.0, 1.0, 1.0e-6, 3, seed=cfg.seed, stream_offset=self.step_tensor, flags=flags,
-                                  schedule=self.schedule, gather=(ray_indices, self.pixels_per_view, b["target_columns"], N))
+                                  schedule=self.schedule, gather=(ray_indices, self.pixels_per_view, b["target_columns"], N), frames=frames)
         loss_scale = 1.0 / (R * N)
         if residual:
             _lib.check(lib.vsrd_render_residual_step(field, config, _lib.ptr(self.camera_positions), _lib.ptr(self.ray_directions), None, None,
@@ -906,3 +1004,200 @@ class FrameOptimizer:
                 "base_lrs": [cfg.learning_rate] * 3 + [cfg.embedding_learning_rate, cfg.hypernetwork_learning_rate],
                 "last_epoch": self.step_index, "_step_count": self.step_index + 1, "_is_initial": False,
                 "_get_lr_called_within_step": False, "_last_lr": [float(group["lr"]) for group in self.optimizer.param_groups]}
+
+
+class FrameBatch:
+    """B frames of ONE shape optimised in lock-step: every launch of a step -- prologue + ray draw, hypernetwork forward, render +
+    losses + adjoint, MLP adjoint, reductions, hypernetwork backward + Adam, epilogue -- covers all B frames at once (include/vsrd_hip.h,
+    "frame batches").  The reference's loop carries the same batch dimension (scripts/main.py:525-651: lists over the batch of distance
+    fields, camera positions, ray directions, soft masks; BoxParameters3D(batch_size, num_instances), box_parameters.py:34-49); its
+    configs use batch_size = 1 because one V100 was full with one frame -- one MI355X is not (1000 rays = one wave per SIMD).
+
+    The frames stay INDEPENDENT problems: each has its own detector, hypernetwork, Adam state, learning rates, step counter (which keys its
+    Philox streams), sampling table and scratch, in its own row of ``self.arena``; nothing is summed across frames.  A frame of a batch
+    therefore walks, bit for bit, the trajectory it walks alone in a ``FrameOptimizer(graph=True, persistent=True)``
+    (tests/test_hip_step.py::test_frame_batch_walks_each_frames_own_trajectory).  Each member is such a loop whose buffers live in the
+    arena; the batch launches member 0's step with ``frames = (B, stride)``.
+
+    Like a frame slot, a batch is built and captured once (``capture_all``) and then serves group after group of frames through
+    ``reset(f, inputs, init_seed)``; a last group of fewer than B frames runs with ``active < B`` (the first ``active`` rows)."""
+
+    def __init__(self, inputs, config, device, init_seeds=None):
+        inputs = list(inputs)
+        if not inputs:
+            raise ValueError("FrameBatch needs at least one frame")
+        shape = tuple(inputs[0].soft_masks.shape)
+        if any(tuple(i.soft_masks.shape) != shape or tuple(i.image_size) != tuple(inputs[0].image_size) for i in inputs):
+            raise ValueError("the frames of a batch share ONE shape (views, height, width, instances)")
+        self.config, self.device = config, torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.size = len(inputs)
+        import dataclasses
+        with _capture_lock:
+            self.arena = FrameArena(self.size, self._row_bytes(shape, config), self.device)
+        self.frames = []
+        for f, frame_inputs in enumerate(inputs):
+            cfg = config if init_seeds is None else dataclasses.replace(config, init_seed=init_seeds[f])
+            self.frames.append(FrameOptimizer(frame_inputs, cfg, self.device, graph=True, persistent=True, row=self.arena.rows[f]))
+        lead = self.arena.rows[0].layout
+        for row in self.arena.rows[1:]:
+            if row.layout != lead:
+                raise RuntimeError("the frames of a batch laid their buffers out differently: frame batches need equal offsets in every row")
+        self._graphs = {}
+        self._eager = {}
+        self._capture_stream = None
+
+    @staticmethod
+    def _row_bytes(shape, config):
+        """Bytes of one frame's row: every device buffer a FrameOptimizer(row=...) creates (FrameRow.new raises if this is short)."""
+        V, H, W, N = (int(x) for x in shape)
+        lib = _lib.load()
+        pixels = V * H * W
+        with torch.device("meta"):               # (no memory, no random numbers drawn)
+            parameters = sum(p.numel() for p in models.BoxParameters3D(1, N).parameters()) + \
+                sum(p.numel() for p in models.HyperDistanceField(48, [16, 16, 16, 16], 256, [256, 256, 256, 256]).parameters())
+        workspace = max(lib.vsrd_workspace_bytes(N, 1), lib.vsrd_residual_step_workspace_bytes(N, int(config.num_samples), int(config.num_rays)))
+        total = 4 * 3 * parameters                                   # parameters, exp_avg, exp_avg_sq
+        total += pixels * (12 + 4 * N + 4) + 12 * V                  # ray directions, soft masks, importance weights, camera positions
+        total += lib.vsrd_ray_table_bytes(pixels)
+        total += workspace + lib.vsrd_hypernetwork_workspace_bytes(N) + lib.vsrd_frame_scratch_bytes(V, N)
+        total += 4 * (3 * N * _lib.MLP_WEIGHTS + 64 * N + 128 * V) + 16 * int(config.num_rays)          # the glue's tables
+        return total + (4 << 20)                                     # 256-byte alignment of ~400 buffers, step counters, rates, slack
+
+    # ---- one step of the first `active` frames -----------------------------------------------------------------------------------
+    def _members(self, active):
+        active = self.size if active is None else int(active)
+        if not 1 <= active <= self.size:
+            raise ValueError(f"active frames: 1..{self.size}, got {active}")
+        return active, self.frames[:active]
+
+    def _step(self, active, count=True, joins=(True, True)):
+        active, members = self._members(active)
+        lead = members[0]
+        if any(m.step_index != lead.step_index for m in members):
+            raise RuntimeError("the frames of a batch step together: reset() every active frame before running the batch")
+        with rendering.workspace_scope(lead.workspace):
+            if not torch.cuda.is_current_stream_capturing():
+                for m in members:
+                    m._check_bindings()
+            lead._fused_step(None, count=False, joins=joins, frames=(active, self.arena.stride))
+        if count:
+            for m in members:
+                m.step_index += 1
+
+    def outputs(self, f):
+        """Frame f's record of its last step: the dictionary ``FrameOptimizer.step`` returns (device tensors, rewritten by every step)."""
+        m = self.frames[f]
+        record, raw = m._glue["record"], m._glue["raw_gradients"]
+        result = dict(iou_projection_loss=record[0], l1_projection_loss=record[1], silhouette_loss=record[2], loss=record[4],
+                      raw_gradients=[raw[:, 0:3].unsqueeze(0), raw[:, 3:6].unsqueeze(0), raw[:, 6:8].unsqueeze(0)])
+        if m.step_index > self.config.warmup_steps:
+            result["eikonal_loss"] = record[3]
+        return result
+
+    def _phase(self, active):
+        _, members = self._members(active)
+        return members[0].step_index >= self.config.warmup_steps
+
+    def step(self, active=None):
+        """One optimisation step of the first ``active`` frames: three eager steps per (phase, active) warm the lazy initialisations, then the
+        step is captured once and replayed (the protocol of ``FrameOptimizer._graph_step``)."""
+        active, members = self._members(active)
+        key = (self._phase(active), active, 1)
+        if key in self._graphs:
+            with _capture_lock.replaying():
+                self._graphs[key].replay()
+            for m in members:
+                m.step_index += 1
+            return
+        done = self._eager.get(key, 0)
+        if done < 3:
+            with _capture_lock:
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):
+                    self._step(active)
+                torch.cuda.current_stream(self.device).wait_stream(side)
+            self._eager[key] = done + 1
+            return
+        self._capture(key, active, 1)
+
+    def _capture(self, key, active, k):
+        _, members = self._members(active)
+        graph = torch.cuda.CUDAGraph()
+        if self._capture_stream is None:
+            self._capture_stream = torch.cuda.Stream(device=self.device)
+        with _capture_lock.capture():
+            with torch.cuda.graph(graph, stream=self._capture_stream, capture_error_mode="thread_local"):
+                for j in range(k):      # (the hypernetwork's branch joins the step's stream at the ends of the graph only: FrameOptimizer._graph_replay_many)
+                    self._step(active, count=False, joins=(j == 0, j == k - 1))
+            self._graphs[key] = graph
+            graph.replay()              # capture does not execute: this replay IS the step(s); a graph's first launch stays inside the capture's turn
+        for m in members:
+            m.step_index += k
+
+    def run(self, num_steps, steps_per_graph=4, active=None):
+        """``num_steps`` steps of the first ``active`` frames; whole groups of ``steps_per_graph`` steps inside a phase replay ONE hipGraph
+        (``FrameOptimizer.run``)."""
+        active, members = self._members(active)
+        remaining = int(num_steps)
+        k_many = int(steps_per_graph)
+        while remaining > 0:
+            residual = self._phase(active)
+            to_boundary = remaining if residual else self.config.warmup_steps - members[0].step_index
+            k = k_many if k_many > 1 and min(remaining, to_boundary) >= k_many else 1
+            if (residual, active, 1) not in self._graphs:
+                k = 1                   # the phase's eager steps and its one-step graph come first
+            if k == 1:
+                self.step(active)
+            else:
+                key = (residual, active, k)
+                if key in self._graphs:
+                    with _capture_lock.replaying():
+                        self._graphs[key].replay()
+                    for m in members:
+                        m.step_index += k
+                else:
+                    self._capture(key, active, k)
+            remaining -= k
+
+    def capture_all(self, steps_per_graph=4, actives=None):
+        """Every eager warm-up step and every capture ``run()`` would meet -- both phases, the one-step and the ``steps_per_graph``-step graph,
+        for every frame count in ``actives`` (default: the full batch) -- now, then every frame is reset.  Returns the number of graphs."""
+        cfg = self.config
+        k = int(steps_per_graph)
+        for active in (actives or [self.size]):
+            _, members = self._members(active)
+            for phase_start in sorted({0, min(cfg.warmup_steps, cfg.num_steps)}):
+                phase_steps = (cfg.warmup_steps if phase_start < cfg.warmup_steps else cfg.num_steps) - phase_start
+                if phase_steps <= 0:
+                    continue
+                with _capture_lock:
+                    for m in members:
+                        m.step_index = phase_start
+                        m.step_tensor.fill_(phase_start)
+                for _ in range(min(4, phase_steps)):
+                    self.step(active)
+                if k > 1 and phase_steps >= 4 + k:
+                    self._capture((self._phase(active), active, k), active, k)
+        with _capture_lock:
+            torch.cuda.current_stream(self.device).synchronize()
+        for m in self.frames:
+            m.reset(m.inputs)
+        return len(self._graphs)
+
+    def reset(self, f, inputs, init_seed=None):
+        """Row f starts another frame (``FrameOptimizer.reset``).  False: the frame does not suit the table sampler -- optimise it in a loop of its own."""
+        return self.frames[f].reset(inputs, init_seed=init_seed)
+
+    def close(self):
+        _destroy_graphs(self._graphs)
+        for m in self.frames:
+            m.close()
+
+    def __del__(self):
+        try:
+            _destroy_graphs(self._graphs, wait=False)
+        except Exception:
+            pass

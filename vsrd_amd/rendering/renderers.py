@@ -33,7 +33,11 @@ class Workspace:
     so a rank working through its shard of frames returns the memory frame by frame (round 1 kept them in a module-global dict
     keyed by ``id(optimizer)``: ~1.7 GB leaked per frame at N = 16)."""
 
-    def __init__(self):
+    def __init__(self, allocate=None):
+        """``allocate(nbytes) -> uint8 device tensor``: where the buffers come from instead of ``torch.empty`` -- a frame of a batch keeps
+        its scratch in its row of the batch's arena (optimization.FrameArena: the kernels reach frame f's copy of every buffer at a fixed
+        stride from frame 0's)."""
+        self._allocate = allocate
         self._adjoint = {}      # device -> uint8 tensor
         self._sampler = {}      # device -> uint8 tensor
         self._retired = []      # outgrown buffers that captured graphs may still reference (only kept when asked to)
@@ -51,7 +55,9 @@ class Workspace:
         if buf is None or buf.numel() < need:
             if buf is not None and self.keep_outgrown:
                 self._retired.append(buf)
-            buf = self._adjoint[device] = torch.empty(need, dtype=torch.uint8, device=device)
+            if buf is not None and self._allocate is not None:
+                raise RuntimeError("a Workspace inside a frame arena is reserved once (Workspace.reserve): it cannot grow")
+            buf = self._adjoint[device] = torch.empty(need, dtype=torch.uint8, device=device) if self._allocate is None else self._allocate(need)
         return buf
 
     def reserve(self, device, num_instances, residual=True, step_shape=None):

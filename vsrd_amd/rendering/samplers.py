@@ -95,13 +95,16 @@ class RayTable:
 
     MAX_PICKS = 32768          # csrc/ray_sampling.h: kTableRounds x 2048 candidates per draw
 
-    def __init__(self, weights):
+    def __init__(self, weights, allocate=None):
+        """``allocate(nbytes) -> uint8 device tensor``: where the table lives instead of a ``torch.empty`` of its own (a frame of a batch:
+        its row of the batch's arena, optimization.FrameArena)."""
         lib = _lib.load()
         self.weights = weights.detach().reshape(-1).to(torch.float32).contiguous()
         if not self.weights.is_cuda:
             raise _lib.VsrdHipError("RayTable needs device weights (there is no CPU path)")
         self.count = int(self.weights.numel())
-        self.table = torch.empty(lib.vsrd_ray_table_bytes(self.count), dtype=torch.uint8, device=self.weights.device)
+        nbytes = lib.vsrd_ray_table_bytes(self.count)
+        self.table = torch.empty(nbytes, dtype=torch.uint8, device=self.weights.device) if allocate is None else allocate(nbytes)
         _lib.check(lib.vsrd_ray_table_build(_lib.ptr(self.weights), self.count, self.table.data_ptr(), self.table.numel(), _lib.stream()))
 
     def rebuild(self, weights):
