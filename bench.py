@@ -620,7 +620,8 @@ def extra_regimes():
     native = ["phase", "graph", "steps_per_s", "ms_per_step", "seconds_per_3000_step_frame", "seconds_per_frame", "warmup_phase_seconds",
               "residual_phase_seconds", "steps", "rays_per_step", "samples_per_ray", "views", "instances", "final_loss", "mlp_products"]
     frames = ["value", "unit", "n_gpus", "frames", "seconds", "frames_per_s_per_gpu", "per_rank_seconds", "seconds_per_frame_per_gpu", "capture_seconds_per_frame",
-              "restarts", "max_restarts", "mean_final_loss", "ranks", "procs_per_gpu", "frames_in_flight_per_process", "control_plane"]
+              "restarts", "max_restarts", "mean_final_loss", "ranks", "procs_per_gpu", "frames_in_flight_per_process", "control_plane", "frame_batch", "queue",
+              "mlp_products", "slot_setup_seconds", "graphs_per_slot", "frames_outside_slots", "frames_with_unhealthy_draws"]
     base = ["bench.py", "--no-cpu-baseline", "--no-extra-regimes"]
     tool = os.path.join("tools", "native_mode_bench.py")
     return {
@@ -632,11 +633,19 @@ def extra_regimes():
         "native_graph_residual": child([tool, "--graph", "--residual", "--steps", "300", "--json"], native),
         "native_graph_whole_frame": child([tool, "--graph", "--whole-frame", "--json"], native),
         "native_graph_whole_frame_fp32_mlp": child([tool, "--graph", "--whole-frame", "--fp32-mlp", "--json"], native),
-        # frames/s, the unit the reference shards (README.md:128): twelve whole frames through the frame launcher with its default processes per GPU and frames in
-        # flight, checkpoints included (python bench.py --native = python -m vsrd_amd.launcher; on a node: --gpus 8)
-        "native_frames_per_s": child(["bench.py", "--native", "--gpus", "1", "--frames", "12"], frames, timeout=1200),
-        "native_frames_per_s_one_process": child(["bench.py", "--native", "--gpus", "1", "--procs-per-gpu", "1", "--frames-in-flight", "3", "--frames", "12"], frames,
-                                                 timeout=1200),
+        "native_graph_whole_frame_batch16": child([tool, "--graph", "--whole-frame", "--batch", "16", "--json"], native + ["frame_batch", "seconds_per_batch", "setup_seconds"]),
+        # frames/s, the unit the reference shards (README.md:128): whole frames through the frame launcher with its default layout,
+        # checkpoints included (python bench.py --native = python -m vsrd_amd.launcher; on a node: --gpus 8).  Round 6: ONE rank process per GPU (RCCL
+        # control plane) that steps a batch of frames together (optimization.FrameBatch; --frame-batch, default 16); the slots' set-up before the clock is
+        # `slot_setup_seconds`
+        "native_frames_per_s": child(["bench.py", "--native", "--gpus", "1", "--frames", "32"], frames, timeout=1200),
+        "native_frames_per_s_one_process": child(["bench.py", "--native", "--gpus", "1", "--procs-per-gpu", "1", "--frames", "32"], frames, timeout=1200),
+        "native_frames_per_s_one_process_batch8": child(["bench.py", "--native", "--gpus", "1", "--procs-per-gpu", "1", "--frame-batch", "8", "--frames", "24"], frames, timeout=1200),
+        "native_frames_per_s_one_process_fp32_mlp": child(["bench.py", "--native", "--gpus", "1", "--procs-per-gpu", "1", "--frames", "32", "--fp32-mlp"], frames, timeout=1200),
+        # round 5's layouts, for comparison: two rank processes (gloo) with one frame each; one process with three frames in flight (threads, streams)
+        "native_frames_per_s_two_processes_r05": child(["bench.py", "--native", "--gpus", "1", "--procs-per-gpu", "2", "--frame-batch", "1", "--frames", "12"], frames, timeout=1200),
+        "native_frames_per_s_three_threads_r05": child(["bench.py", "--native", "--gpus", "1", "--procs-per-gpu", "1", "--frame-batch", "1", "--frames-in-flight", "3",
+                                                         "--frames", "12"], frames, timeout=1200),
     }
 
 

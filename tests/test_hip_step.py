@@ -658,7 +658,9 @@ def test_frame_batch_walks_each_frames_own_trajectory(dev):
     two groups of frames in a row (reset), and for a last group of three frames (active < B)."""
     from vsrd_amd import optimization
     frames = [_c1_inputs(dev, all_visible=True, seed=k) for k in range(7)]
-    config = optimization.OptimizationConfig(num_samples=32, num_rays=128, warmup_steps=9, num_steps=40, seed=3)
+    # (33..128 samples: the split-ray kernels a batch runs in; eight slots per work item of the MLP adjoint, alone and in the batch: the order of
+    #  summation of the weight adjoints depends on that number -- vsrd_render_config::adjoint_slots_per_item -- and on nothing else of the launch)
+    config = optimization.OptimizationConfig(num_samples=40, num_rays=128, warmup_steps=9, num_steps=40, seed=3, mlp_adjoint_item_slots=8)
     steps = 26
 
     def state_of(loop):
@@ -682,6 +684,7 @@ def test_frame_batch_walks_each_frames_own_trajectory(dev):
 
     batch = optimization.FrameBatch(frames[:4], config, dev, init_seeds=[50, 51, 52, 53])
     assert batch.arena.stride % 256 == 0 and all(row.layout == batch.arena.rows[0].layout for row in batch.arena.rows)
+    assert batch.config.mlp_adjoint_item_slots == 8 and optimization.FrameBatch.item_slots(8, optimization.OptimizationConfig(), 8) == 16
     held = batch.capture_all(actives=[4, 3])
     assert held == 8 and sorted(batch._graphs) == sorted((phase, active, k) for phase in (False, True) for active in (3, 4) for k in (1, 4))
     gate = optimization.exclusive_device_access()

@@ -49,7 +49,7 @@ def test_struct_layout_matches_header(tmp_path):
     from vsrd_amd import _lib
     members = {"vsrd_field": (_lib.Field, ["instances", "mlp_weights"]),
                "vsrd_render_config": (_lib.RenderConfig, ["seed", "stream_offset", "flags", "device_schedule", "device_stream_offset", "ray_indices", "rays_per_origin",
-                                                          "target_columns", "target_stride", "out_distances", "out_u_fine", "num_frames", "frame_stride"]),
+                                                          "target_columns", "target_stride", "out_distances", "out_u_fine", "num_frames", "frame_stride", "adjoint_slots_per_item"]),
                "vsrd_frame_config": (_lib.FrameConfig, ["num_steps", "lr_gamma", "num_frames", "frame_stride"]),
                "vsrd_adam_tensors": (_lib.AdamTensors, ["learning_rate"]),
                "vsrd_hypernetwork": (_lib.Hypernetwork, ["embeddings", "norm_bias", "num_frames", "frame_stride"])}
@@ -65,7 +65,7 @@ def test_struct_layout_matches_header(tmp_path):
         assert int(seen[struct]) == ctypes.sizeof(binding), struct
         for name in names:
             assert int(seen[f"{struct}.{name}"]) == getattr(binding, name).offset, (struct, name)
-    assert ctypes.sizeof(_lib.RenderConfig) == 152 and ctypes.sizeof(_lib.FrameConfig) == 128 and ctypes.sizeof(_lib.Hypernetwork) == 24 + 24 * 40 + 16      # ABI 8
+    assert ctypes.sizeof(_lib.RenderConfig) == 160 and ctypes.sizeof(_lib.FrameConfig) == 128 and ctypes.sizeof(_lib.Hypernetwork) == 24 + 24 * 40 + 16      # ABI 8
 
 
 def test_cpu_tensors_are_rejected_not_emulated(lib):

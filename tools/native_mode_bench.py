@@ -30,6 +30,8 @@ def main():
     parser.add_argument("--fp32-mlp", action="store_true", help="OptimizationConfig(mlp_split_bf16=False): the residual MLP on the exact-fp32 matrix "
                         "instruction instead of the split-bf16 products that are the loop's default since round 5")
     parser.add_argument("--steps-per-graph", type=int, default=4, help="graph mode: consecutive steps replayed per hipGraph launch (FrameOptimizer.run); 1 = one launch per step")
+    parser.add_argument("--batch", type=int, default=0, help="with --whole-frame: B frames in lock-step through optimization.FrameBatch (one launch of every kernel of a "
+                        "step for all of them); the time reported is per frame")
     parser.add_argument("--whole-frame", action="store_true", help="time one whole frame as the reference runs it: steps 0..2999 with the real schedules "
                         "(1000 box-only warm-up steps, then 2000 residual steps), set-up and graph captures included")
     args = parser.parse_args()
@@ -51,6 +53,38 @@ def main():
                                              skip_exact_misses=True)["labels"].clamp(0, 1).reshape(V, H, W, N).contiguous()
         gt_boxes, _ = operations.project_boxes_multi_view(out["boxes_3d"][0], E.to(dev), K.to(dev), (H, W))
     inputs = optimization.FrameInputs((H, W), K.to(dev), E.to(dev), soft, gt_boxes, torch.ones(V, N, dtype=torch.bool, device=dev))
+    if args.whole_frame and args.batch > 0:
+        cfg = optimization.OptimizationConfig(seed=0, num_rays=args.rays, mlp_split_bf16=not args.fp32_mlp)
+        t_setup = time.perf_counter()
+        batch = optimization.FrameBatch([inputs] * args.batch, cfg, dev, init_seeds=list(range(args.batch)))
+        batch.capture_all(args.steps_per_graph)
+        torch.cuda.synchronize()
+        setup = time.perf_counter() - t_setup
+        times = []
+        for turn in range(2):                                # the first turn warms; the second is reported
+            for row in range(args.batch):
+                batch.reset(row, inputs, init_seed=100 * turn + row)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            batch.run(cfg.warmup_steps, args.steps_per_graph)
+            torch.cuda.synchronize(); warm = time.perf_counter() - t0
+            batch.run(cfg.num_steps - cfg.warmup_steps, args.steps_per_graph)
+            torch.cuda.synchronize(); total = time.perf_counter() - t0
+            times.append((warm, total))
+        warm, total = times[-1]
+        losses = [float(batch.outputs(row)["loss"]) for row in range(args.batch)]
+        B = args.batch
+        print(f"native mode, whole frames in a batch of {B} ({cfg.num_steps} steps = {cfg.warmup_steps} box-only + {cfg.num_steps - cfg.warmup_steps} residual, real schedules, "
+              f"{args.rays} rays x {cfg.num_samples} samples per frame, V={V}, N={N}, hipGraph replay): {total:.2f} s for {B} frames = {total / B:.3f} s per frame "
+              f"({warm / B:.3f} s warm-up phase, {(total - warm) / B:.3f} s residual phase = {(total - warm) / B / (cfg.num_steps - cfg.warmup_steps) * 1e3:.3f} ms per frame-step); "
+              f"set-up (construction + captures) {setup:.2f} s; final losses {', '.join(f'{x:.4f}' for x in losses)}")
+        if args.json:
+            import json
+            print(json.dumps(dict(mode="native", phase="whole frame", graph=True, frame_batch=B, seconds_per_frame=total / B, seconds_per_batch=total,
+                                  warmup_phase_seconds=warm / B, residual_phase_seconds=(total - warm) / B, steps=cfg.num_steps, rays_per_step=args.rays,
+                                  samples_per_ray=cfg.num_samples, views=V, instances=N, final_loss=losses[0], final_losses=losses, setup_seconds=setup,
+                                  steps_per_graph=args.steps_per_graph, mlp_products="exact fp32 MFMA" if args.fp32_mlp else "split bf16 MFMA")))
+        return
     if args.whole_frame:
         def frame(slot):
             loop = optimization.FrameOptimizer(inputs, optimization.OptimizationConfig(seed=slot, num_rays=args.rays, mlp_split_bf16=not args.fp32_mlp), dev, graph=args.graph)

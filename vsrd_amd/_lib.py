@@ -69,6 +69,7 @@ class RenderConfig(ctypes.Structure):
         ("out_u_fine", ctypes.c_void_p),
         ("num_frames", ctypes.c_int32),          # frame batch (ABI 8): 0 or 1 = one frame
         ("frame_stride", ctypes.c_int64),        # bytes between the frames' copies of every buffer of the call
+        ("adjoint_slots_per_item", ctypes.c_int32),   # vsrd_render_residual_step: slots per work item of the MLP adjoint (0: planned)
     ]
 
 
@@ -267,7 +268,7 @@ def make_field(instances, temperature, mlp_weights=None):
 
 
 def make_config(num_rays, num_samples, distance_range, sdf_std_deviation, cosine_ratio, epsilon, origin_stride,
-                seed=0, stream_offset=0, flags=0, schedule=None, gather=None, samples=None, frames=None):
+                seed=0, stream_offset=0, flags=0, schedule=None, gather=None, samples=None, frames=None, adjoint_slots_per_item=0):
     """`schedule`: optional device tensor float32 [3] = (temperature, sdf_std_deviation, cosine_ratio) read by the kernels at
     start instead of the by-value scalars; `stream_offset` may likewise be a device int64 tensor (hipGraph replay).
     `samples`: optional (distances [R,2S], coarse_weights [R,S-1], u_coarse [R,S], u_fine [R,S]) float32 device tensors (any may be None)
@@ -299,4 +300,4 @@ def make_config(num_rays, num_samples, distance_range, sdf_std_deviation, cosine
                         float(sdf_std_deviation), float(cosine_ratio), float(epsilon), int(origin_stride),
                         int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_offset) & 0xFFFFFFFFFFFFFFFF, int(flags), schedule_ptr, offset_ptr,
                         ray_indices, int(rays_per_origin), target_columns, int(target_stride), *outs,
-                        *((1, 0) if frames is None else (int(frames[0]), int(frames[1]))))
+                        *((1, 0) if frames is None else (int(frames[0]), int(frames[1]))), int(adjoint_slots_per_item))

@@ -823,7 +823,7 @@ struct ResidualStepPlan {
     size_t box_partials, loss_partials, jets, box_extra, counter, segment_sums, seeds, item_rows, masks, item_flags, images, total_bytes;
 };
 
-static bool plan_residual_step(int N, int S, int num_rays, bool allow_pair, ResidualStepPlan* p) {
+static bool plan_residual_step(int N, int S, int num_rays, bool allow_pair, ResidualStepPlan* p, int slots_per_item = 0) {
     p->rounds = rounds_for(2 * S - 1);
     if (p->rounds < 1 || p->rounds > 4) return false;
     // four rounds (S in (64, 128]): the one-wave-per-ray kernel needs 308 registers (one wave per SIMD), the pair kernel 256 -- the pair
@@ -850,6 +850,7 @@ static bool plan_residual_step(int N, int S, int num_rays, bool allow_pair, Resi
     per_item = per_item < 4 ? 4 : (per_item > 32 ? 32 : per_item);
     const int forced = switches().slots_per_item;                        // experiment switch
     if (forced >= 1 && forced <= 64) per_item = forced;
+    if (slots_per_item >= 1 && slots_per_item <= 64) per_item = slots_per_item;      // vsrd_render_config::adjoint_slots_per_item
     p->slots_per_item = static_cast<int>(per_item);
     p->items_per_instance = static_cast<int>((p->slots_per_instance + per_item - 1) / per_item);
     size_t at = 0;
@@ -994,7 +995,9 @@ int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_con
     const bool allow_pair = !(config->flags & VSRD_FLAG_RESIDUAL_WAVE_PER_RAY);
     Frames frames;
     frames_of(config->num_frames, config->frame_stride, &frames);           // (validated by valid_config)
-    const bool one_kernel = (config->flags & VSRD_FLAG_RESIDUAL_SINGLE_KERNEL) || config->num_rays == 0 || !plan_residual_step(N, S, config->num_rays, allow_pair, &p);
+    if (config->adjoint_slots_per_item < 0 || config->adjoint_slots_per_item > 64) return VSRD_E_INVALID_ARGUMENT;
+    const bool one_kernel = (config->flags & VSRD_FLAG_RESIDUAL_SINGLE_KERNEL) || config->num_rays == 0 ||
+                            !plan_residual_step(N, S, config->num_rays, allow_pair, &p, config->adjoint_slots_per_item);
     // a batch of frames: the two-kernel form with every frame's rays in ONE chunk (each frame its own seeds, item counter and rows, frame_stride apart)
     if (frames.count > 1 && (one_kernel || p.chunk < config->num_rays || static_cast<long long>(p.total_bytes) > frames.stride)) return VSRD_E_UNSUPPORTED;
     if (one_kernel)

@@ -311,7 +311,7 @@ class _RenderWork:
     def __init__(self, args, manifest, device, queue):
         self.args, self.manifest, self.device, self.queue = args, manifest, device, queue
         self.config = dict(num_steps=args.num_steps, warmup_steps=args.warmup_steps, num_rays=args.rays, num_samples=args.samples,
-                           mlp_split_bf16=not args.fp32_mlp)
+                           mlp_split_bf16=not args.fp32_mlp, mlp_adjoint_item_slots=args.adjoint_item_slots)
 
     def path_of(self, frame):
         return os.path.join(self.manifest["out"], f"frame_{int(frame):06d}", f"step_{self.args.num_steps - 1}.pt")
@@ -425,13 +425,16 @@ class _RenderWork:
         return dict(frames=len(done), skipped=taken - len(done),
                     gate_capture_seconds=optimization.exclusive_device_access().capture_seconds - self.captures_before,
                     slot_setup_seconds=self.setup_seconds, graphs_per_slot=self.graphs_per_slot, final_losses={int(f): losses[f] for f in sorted(losses)},
-                    frames_outside_slots=sorted(fallbacks), unsuitable_founders=self.unsuitable_founders, frames_with_unhealthy_draws=sorted(unhealthy))
+                    frames_outside_slots=sorted(fallbacks), unsuitable_founders=self.unsuitable_founders, frames_with_unhealthy_draws=sorted(unhealthy),
+                    phase_seconds=getattr(self, "phase_seconds", None))
 
     def _run_batches(self, losses, fallbacks, health):
         """Groups of --frame-batch frames through the FrameBatch: reset row by row, ONE graph replay per (four) step(s) for the whole group,
         then the group's checkpoints.  Frames the batch cannot take (their weights do not suit its table sampler) run alone afterwards."""
+        import time
         from . import formats, optimization
         args, batch, done = self.args, self.batch, []
+        clock = self.phase_seconds = dict(inputs=0.0, reset=0.0, steps=0.0, checkpoint_copy=0.0, checkpoint_write=0.0)
         while True:
             group = pending_frames(self.queue.take(args.frame_batch), self.path_of)
             if not group:
@@ -440,19 +443,30 @@ class _RenderWork:
                 break
             rows, alone = [], []
             for frame, path in group:
-                (rows if batch.reset(len(rows), self.inputs_of(frame), init_seed=self.init_seed(frame)) else alone).append((frame, path))
+                t0 = time.perf_counter()
+                inputs = self.inputs_of(frame)
+                t1 = time.perf_counter()
+                (rows if batch.reset(len(rows), inputs, init_seed=self.init_seed(frame)) else alone).append((frame, path))
+                clock["inputs"] += t1 - t0
+                clock["reset"] += time.perf_counter() - t1
             if rows:
+                t0 = time.perf_counter()
                 batch.run(args.num_steps, active=len(rows))
                 with optimization.exclusive_device_access():
                     torch.cuda.current_stream().synchronize()
+                    t1 = time.perf_counter()
                     payloads = []
                     for row, (frame, path) in enumerate(rows):
                         losses[frame] = float(batch.outputs(row)["loss"])
                         health(frame, batch.frames[row])
                         payloads.append(formats.checkpoint_payload(batch.frames[row], step=args.num_steps - 1, metrics={}, host=True))
+                t2 = time.perf_counter()
                 for (frame, path), payload in zip(rows, payloads):
                     formats.atomic_torch_save(payload, path)
                     done.append(frame)
+                clock["steps"] += t1 - t0
+                clock["checkpoint_copy"] += t2 - t1
+                clock["checkpoint_write"] += time.perf_counter() - t2
             for frame, path in alone:
                 fallbacks.append(int(frame))
                 losses[frame], payload = self._own_loop(frame)
@@ -500,7 +514,7 @@ class _SleepWork:
                     frames_outside_slots=[], unsuitable_founders=[], frames_with_unhealthy_draws=[])
 
 
-DEFAULT_FRAME_BATCH = 4
+DEFAULT_FRAME_BATCH = 16
 
 
 def main(argv=None):
@@ -534,6 +548,9 @@ def main(argv=None):
                         help="static: frame j of the seeded permutation to rank j mod world, inputs resident before the clock.  dynamic: the ranks take "
                              "their next group of frames from ONE queue (an atomic counter on rank 0's TCPStore): frames of unequal cost leave no rank idle "
                              "for more than one group; inputs are built when a frame is taken.  auto: dynamic when the job has more than one rank")
+    parser.add_argument("--adjoint-item-slots", type=int, default=0,
+                        help="OptimizationConfig.mlp_adjoint_item_slots (vsrd_render_config::adjoint_slots_per_item): 0 = planned (4 for one frame of 1000 rays; "
+                             "a batch picks FrameBatch.item_slots).  A frame's trajectory is bit-identical alone and in a batch for equal numbers")
     parser.add_argument("--fp32-mlp", action="store_true", help="the residual MLP's products on the exact-fp32 matrix instruction instead of split bf16")
     parser.add_argument("--views", type=int, default=17)
     parser.add_argument("--instances", type=int, default=8)
@@ -712,6 +729,8 @@ def _rank_main(args):
                 "frame_slots": not args.fresh_loops, "slot_setup_seconds": [r["slot_setup_seconds"] for r in gathered],
                 "graphs_per_slot": [r["graphs_per_slot"] for r in gathered],
                 # frames a slot could not take (their importance weights do not suit the sampling table its graphs draw from: a loop of their own, race sampler)
+                # where a batched rank's time went, in seconds over its frames: building inputs (dynamic queue only), resetting rows, the steps, checkpoints
+                "phase_seconds": [r.get("phase_seconds") for r in gathered],
                 "frames_outside_slots": sorted(f for r in gathered for f in r["frames_outside_slots"]),
                 "unsuitable_founders": sorted(f for r in gathered for f in r["unsuitable_founders"]),
                 # frames in which some ray draw ran out of picks / overflowed (read at the end of each frame; RuntimeWarning on stderr)

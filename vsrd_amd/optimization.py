@@ -125,7 +125,31 @@ class _CaptureTurn:
 
 
 _capture_lock = _CaptureGate()
-_initial_draw = threading.Lock()      # seeding torch's host generator and drawing a frame's initial parameters from it: one frame at a time
+
+
+class _InitialDraw:
+    """Seeding torch's host generator and drawing a frame's initial parameters from it: one frame at a time, and on ONE host thread -- the
+    draw is a handful of tiny CPU operations (the largest: weight_norm over [1617, 256]), and on a 256-core box torch's intra-op pool takes
+    100-200 ms to run them on all cores where one thread takes 2 ms (tools/reset_timers.py: a frame slot's reset() 100 ms -> 4.4 ms; the
+    launcher lost 0.11 s per frame to it).  The values drawn do not depend on the thread count."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+
+    def __enter__(self):
+        self._lock.acquire()
+        self._threads = torch.get_num_threads()
+        if self._threads > 1:
+            torch.set_num_threads(1)
+        return self
+
+    def __exit__(self, *exc):
+        if self._threads > 1:
+            torch.set_num_threads(self._threads)
+        self._lock.release()
+
+
+_initial_draw = _InitialDraw()
 
 
 def exclusive_device_access():
@@ -193,6 +217,10 @@ class OptimizationConfig:
     # same tolerances as the exact-fp32 products (labels ~1e-6, gradients ~4e-4 of the largest entry against the reference's goldens), the
     # residual step 8 % faster.  False: the exact-fp32 matrix instruction.
     mlp_split_bf16: bool = True
+    # vsrd_render_config::adjoint_slots_per_item of the residual step (0: the library plans it from one frame's launch: 4 slots at 1000 rays).
+    # A FrameBatch whose config leaves this at 0 picks the number for its B-fold item count (FrameBatch.item_slots: 16 for 8 x 1000 rays);
+    # a frame walks bit-identical trajectories alone and in a batch when both use the same number.
+    mlp_adjoint_item_slots: int = 0
     # The initial parameters (a detector's embeddings, the hypernetwork) are drawn from torch's global generator when a loop is built or reset.
     # None: whatever state that generator is in (the reference seeds it once per rank, scripts/main.py:67-74, so a frame's start depends on the
     # frames its rank optimised before).  An integer: the generator is seeded with it right before the draw -- a frame's result then depends on
@@ -622,7 +650,8 @@ class FrameOptimizer:
         workspace = self.workspace.adjoint(self.device, N, residual, step_shape=(cfg.num_samples, R))
         field = _lib.make_field(b["instances"], 1.0, centred)          # (the temperature comes from the device schedule)
         config = _lib.make_config(R, cfg.num_samples, cfg.distance_range, 1.0, 1.0, 1.0e-6, 3, seed=cfg.seed, stream_offset=self.step_tensor, flags=flags,
-                                  schedule=self.schedule, gather=(ray_indices, self.pixels_per_view, b["target_columns"], N), frames=frames)
+                                  schedule=self.schedule, gather=(ray_indices, self.pixels_per_view, b["target_columns"], N), frames=frames,
+                                  adjoint_slots_per_item=cfg.mlp_adjoint_item_slots if residual else 0)
         loss_scale = 1.0 / (R * N)
         if residual:
             _lib.check(lib.vsrd_render_residual_step(field, config, _lib.ptr(self.camera_positions), _lib.ptr(self.ray_directions), None, None,
@@ -1029,11 +1058,13 @@ class FrameBatch:
         shape = tuple(inputs[0].soft_masks.shape)
         if any(tuple(i.soft_masks.shape) != shape or tuple(i.image_size) != tuple(inputs[0].image_size) for i in inputs):
             raise ValueError("the frames of a batch share ONE shape (views, height, width, instances)")
+        self.size = len(inputs)
+        import dataclasses
+        if config.mlp_adjoint_item_slots == 0:
+            config = dataclasses.replace(config, mlp_adjoint_item_slots=self.item_slots(self.size, config, shape[-1]))
         self.config, self.device = config, torch.device(device)
         if self.device.type == "cuda" and self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
-        self.size = len(inputs)
-        import dataclasses
         with _capture_lock:
             self.arena = FrameArena(self.size, self._row_bytes(shape, config), self.device)
         self.frames = []
@@ -1047,6 +1078,19 @@ class FrameBatch:
         self._graphs = {}
         self._eager = {}
         self._capture_stream = None
+
+    @staticmethod
+    def item_slots(num_frames, config, num_instances):
+        """Slots per work item of the MLP adjoint for a batch of `num_frames` frames (vsrd_render_config::adjoint_slots_per_item): the library
+        plans about 16384 items per LAUNCH from one frame's size; a batch has B times the items, so its items can be B times as large --
+        fewer partial rows to write and to sum (measured, 1000 rays x 100 samples, N = 8: 8 frames 0.392 -> 0.337 ms per frame-step with 16
+        slots, 4 frames 0.423 -> 0.379; profiles/r06_native).  The next power of two, 4..32."""
+        rounds = 2 if config.num_samples <= 64 else 4
+        wanted = num_frames * config.num_rays * rounds * num_instances / 16384.0
+        slots = 4
+        while slots < wanted and slots < 32:
+            slots *= 2
+        return slots
 
     @staticmethod
     def _row_bytes(shape, config):
