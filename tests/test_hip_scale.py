@@ -381,6 +381,23 @@ def _oracle_union(det, temperature, dtype):
     return ofields.InstanceUnion(loc, rot, dim, temperature)
 
 
+def _stable_under_float32_noise(evaluate, inputs, which, reference, bound=1.0e-5, trials=4, ulps=4.0, seed=99):
+    """Rays on which the EXACT (float64) evaluation does not move by more than `bound` when input number `which` (sample distances, or ray
+    directions) is perturbed by a few float32 units in the last place, `trials` random perturbations: the rays on which float32 ARITHMETIC
+    determines the result.  (A sample within an ulp of a box's medial plane takes the other face's normal, a fine uniform within an ulp of a
+    plateau of the importance sampler lands in another bin: on such rays any two float32 implementations of renderers.py:212-263 may differ by
+    1e-1, the reference's own with a different summation order included.  Agreement of ONE float32 and ONE float64 evaluation -- VERDICT r05's
+    definition -- is necessary, not sufficient: at config 5, 64 overlapping boxes, a ray in ten sits that close to a kink somewhere.)"""
+    generator = torch.Generator().manual_seed(seed)
+    stable = torch.ones(reference.shape[0], dtype=torch.bool)
+    for _ in range(trials):
+        noisy = list(inputs)
+        noise = (torch.rand(noisy[which].shape, generator=generator, dtype=torch.float64) * 2.0 - 1.0) * ulps * 2.0 ** -23
+        noisy[which] = noisy[which].double() * (1.0 + noise)
+        stable &= (evaluate(*noisy).double() - reference.double()).abs().flatten(1).max(-1).values <= bound
+    return stable
+
+
 def _in_chunks(function, tensors, chunk):
     """function(*rows of every tensor) over chunks of rows (bounded memory on the host), results concatenated."""
     parts = [function(*(t[start:start + chunk] for t in tensors)) for start in range(0, tensors[0].shape[0], chunk)]
@@ -397,8 +414,20 @@ def test_full_size_parity_against_the_oracle(dev, config):
 
     Rays: a seeded random draw of the frame PLUS the rays on which the step's own culling A/B (default flags against
     VSRD_FLAG_NO_CULLING) moves a label by more than 2e-6 -- the tail test_multi_ray_step_culling_is_invisible describes (the largest
-    first when there are more than the cap; config 2: 8192 + up to 8192; config 5, whose oracle costs 16x as much per ray: 2048 + up
-    to 2048; VSRD_PARITY_RAYS=<n> overrides both numbers for a patient run).
+    first when there are more than the cap; config 2: 4096 + up to 4096; config 5, whose oracle costs 16x as much per ray: 1024 + up
+    to 1024 -- round 6 halved both and spends the time on the float64 noise trials and the gradients below; VSRD_PARITY_RAYS=<n> overrides
+    both numbers for a patient run).
+
+    Round 6.  (a) HARD bounds on the rays where float32 arithmetic determines the result: the float32 and the float64
+    oracle agree to 1e-5 AND the float64 oracle does not move by more than 1e-5 under random perturbations of a few float32 ulps of the
+    sample distances (pass 2) / the ray directions (end to end) -- `_stable_under_float32_noise`; agreement of one float32 and one float64
+    evaluation alone is not enough at config 5 (a determinate-looking ray 4.4e-4 away, first attempt).  Pass 2 at the step's samples: EVERY
+    such ray within 2e-5 (observed 1.7e-5 / 9.2e-6 at configs 2 / 5, 99 % / 91 % of the rays); end to end: every such ray within 1e-4 at
+    config 2 (observed 2.6e-5, none beyond), at most 0.5 % of them at config 5 (observed none of 55 %, worst 1.9e-5).  (c) Loss and parameter
+    gradients at the step's own samples: vsrd_render_forward + vsrd_render_backward on the determinate rays at the exported distances with
+    the BCE's label adjoints against the oracle's autograd (double backward through the normal included): loss within 1e-5 relative
+    (observed 2.6e-7 / 6e-8), every parameter gradient within 5e-3 of the largest entry of the float64 oracle's, or three times the float32
+    oracle's own distance from it (config 5, orientations: the float32 oracle itself is 8e-3 away).
 
     Every link is checked on the STEP LAUNCH'S OWN state: vsrd_render_config::out_* (ABI 7) makes vsrd_render_silhouette_step write, next
     to its labels, pass 1's weights, the uniforms it drew and the sorted pass-2 distances its labels, loss and gradients were computed at.
@@ -428,7 +457,7 @@ def test_full_size_parity_against_the_oracle(dev, config):
     from oracle import rendering as orendering
     from vsrd_amd import rendering
     from vsrd_amd.rendering import renderers
-    N, S, V, H, W, seed, budget = (16, 64, 9, 376, 1408, 0, 8192) if config == "config2" else (64, 128, 17, 752, 2816, 2, 2048)
+    N, S, V, H, W, seed, budget = (16, 64, 9, 376, 1408, 0, 4096) if config == "config2" else (64, 128, 17, 752, 2816, 2, 1024)
     budget = int(os.environ.get("VSRD_PARITY_RAYS", budget))
     sched = bench.schedule_values(bench.SCHEDULES["mid"])
     T, std, ratio = sched["temperature"], sched["std"], sched["cosine_ratio"]
@@ -451,6 +480,7 @@ def test_full_size_parity_against_the_oracle(dev, config):
             renderers.CULLING = True
         _, step_labels, samples = rendering.silhouette_step(bench.build_union(det, T), origins, directions, targets, (0.0, 100.0), S, std, ratio,
                                                             return_labels=True, return_samples=True, **keys)
+        all_targets = targets
         del targets
         moved_by = (step_labels - unculled).abs().max(-1).values
         del unculled
@@ -461,6 +491,8 @@ def test_full_size_parity_against_the_oracle(dev, config):
         # (b) the selection
         draw = torch.randint(0, R, (budget,), generator=torch.Generator().manual_seed(1234)).to(dev)
         selection = torch.unique(torch.cat([draw, moved]))
+        selected_targets = all_targets[selection].cpu()
+        del all_targets
         hip_labels = step_labels[selection].cpu()
         hip_distances, hip_coarse_weights, u_coarse, u_fine = (samples[k][selection].cpu() for k in ("distances", "coarse_weights", "u_coarse", "u_fine"))
         del samples, step_labels
@@ -519,6 +551,61 @@ def test_full_size_parity_against_the_oracle(dev, config):
         at_samples = held("pass 2", hip_labels[hit], fixed32, fixed64)
         margin(tag, "pass 2: median ray", float(at_samples.median()), 2e-6)
         assert float(at_samples.median()) < 2e-6
+        # a HARD bound where the reference's arithmetic is determinate -- the rays on which the float32 and the float64
+        # oracle agree to 1e-5 at these samples: EVERY such ray within 2e-5 of the float32 oracle (= the reference's own arithmetic)
+        determinate = (fixed32.double() - fixed64).abs().max(-1).values <= 1.0e-5
+        determinate &= _stable_under_float32_noise(
+            lambda a, b, c: _in_chunks(lambda x, y, z: orendering.render_given_distances(union64, x.double(), y.double(), z.double(), std, ratio).labels, (a, b, c), chunk),
+            (o[hit], d[hit], hip_distances[hit]), 2, fixed64)
+        worst_determinate = float(at_samples[determinate].max())
+        margin(tag, "pass 2: share of determinate rays", float(determinate.float().mean()), 1.0)
+        margin(tag, "pass 2, determinate rays: worst", worst_determinate, 2e-5)
+        assert float(determinate.float().mean()) > 0.75 and worst_determinate <= 2e-5
+        # ---- loss and parameter gradients at the step's own samples (scripts/main.py:653-671 through renderers.py:212-263,
+        # autograd's double backward through the SDF normal included): vsrd_render_forward + vsrd_render_backward on the selected rays at the
+        # step's exported distances, BCE against the frame's own targets, against the float32 oracle's autograd on the same rays and samples
+    with torch.enable_grad():
+        # (over the DETERMINATE rays: a ray whose labels float32 arithmetic does not determine -- a sample on a medial plane -- has label adjoints
+        #  of 1 / p size and a Hessian that jumps; and next to the float32 oracle's own distance from the float64 oracle's gradient, as everywhere)
+        from oracle import fields as ofields, geometry as ogeometry
+        raw_names = ("locations", "dimensions", "orientations")
+        rows_index = torch.nonzero(hit).flatten()[determinate]
+        rows = int(rows_index.numel())
+        rows_dev = rows_index.to(dev)
+        rays_o, rays_d = origins[selection][rows_dev], directions[selection][rows_dev]
+        hip_params = [getattr(det, n) for n in raw_names]
+        at_labels, _, _ = rendering.render_at_distances(bench.build_union(det, T), rays_o, rays_d, hip_distances[rows_index].to(dev), std, ratio)
+        hip_loss = torch.nn.functional.binary_cross_entropy(at_labels.clamp(1.0e-6, 1.0 - 1.0e-6), selected_targets[rows_index].to(dev), reduction="none").mean()
+        hip_grads = [g.detach().cpu()[0] for g in torch.autograd.grad(hip_loss, hip_params)]
+
+        def oracle_gradients(dtype):
+            raws = [getattr(det, n).detach().cpu()[0].to(dtype).clone().requires_grad_(True) for n in raw_names]
+            grads, loss = [torch.zeros_like(r) for r in raws], 0.0
+            for start in range(0, rows, chunk):        # (autograd state of a chunk: rays x (2S - 1) points x N instances, twice differentiated)
+                index = rows_index[start:start + chunk]
+                loc, dim, rot, _ = ogeometry.decode_box_parameters(*raws)
+                out = orendering.render_given_distances(ofields.InstanceUnion(loc, rot, dim, T), o[index].to(dtype), d[index].to(dtype), hip_distances[index].to(dtype), std, ratio)
+                part = torch.nn.functional.binary_cross_entropy(out.labels.clamp(1.0e-6, 1.0 - 1.0e-6), selected_targets[index].to(dtype), reduction="none").sum() / (rows * N)
+                for total, g in zip(grads, torch.autograd.grad(part, raws)):
+                    total += g
+                loss += float(part.detach())
+            return grads, loss
+
+        (grads32, loss32), (grads64, loss64) = oracle_gradients(torch.float32), oracle_gradients(torch.float64)
+        loss_error = abs(float(hip_loss) - loss32) / max(abs(loss32), 1e-12)
+        margin(tag, "loss at the step's samples (relative)", loss_error, 1e-5)
+        margin(tag, "loss at the step's samples: f32 vs f64 oracle", abs(loss32 - loss64) / max(abs(loss64), 1e-12), 1.0)
+        assert loss_error <= 1e-5, (float(hip_loss), loss32, loss64)
+        for name, got, want, exact in zip(raw_names, hip_grads, grads32, grads64):
+            # against the EXACT gradient, next to the float32 oracle's own distance from it (config 5: the float32 oracle's orientation gradient is
+            # 8e-3 of the largest entry away from the float64 one -- 64 overlapping boxes, label adjoints of 1 / p size): within 5e-3, or 3 x that
+            scale = max(float(exact.abs().max()), 1e-12)
+            error, own = float((got.double() - exact).abs().max()) / scale, float((want.double() - exact).abs().max()) / scale
+            margin(tag, f"grad {name} at the step's samples vs f64 oracle / largest entry", error, max(5e-3, 3.0 * own))
+            margin(tag, f"grad {name}: HIP vs f32 oracle / largest entry", float((got - want).abs().max()) / scale, 1.0)
+            margin(tag, f"grad {name}: f32 vs f64 oracle / largest entry", own, 1.0)
+            assert scale > 0 and error <= max(5e-3, 3.0 * own), (name, error, own)
+    with torch.no_grad():
         # ---- end to end on the kernel's uniforms: the tail, as numbers ----
         whole32 = _in_chunks(lambda a, b, c, e: orendering.hierarchical_render(union32, a, b, (0.0, 100.0), S, std, ratio, c, e).labels, (o, d, u_coarse, u_fine), chunk)
         whole64 = _in_chunks(lambda a, b, c, e: orendering.hierarchical_render(union64, a.double(), b.double(), (0.0, 100.0), S, std, ratio, c.double(), e.double()).labels,
@@ -532,7 +619,27 @@ def test_full_size_parity_against_the_oracle(dev, config):
     margin(tag, "worst ray, HIP vs f32 oracle", float((hip_labels - whole32).abs().max()), 1.0)
     margin(tag, "worst ray, f32 vs f64 oracle", float((whole32.double() - whole64).abs().max()), 1.0)
     margin(tag, "median ray, HIP vs f32 oracle", float((hip_labels - whole32).abs().max(-1).values.median()), 1e-5)
+    # VERDICT r05 item 4a, end to end: the rays on which the float32 and the float64 oracle agree to 1e-5 THROUGH THE WHOLE PIPELINE (their fine
+    # samples fell on the same side of every plateau, no normal flipped): the north star's "silhouettes within 1e-4" asserted on EVERY such ray
+    determinate_whole = (whole32.double() - whole64).abs().max(-1).values <= 1.0e-5
+    with torch.no_grad():
+        determinate_whole &= _stable_under_float32_noise(
+            lambda a, b, c, e: _in_chunks(lambda x, y, z, w: orendering.hierarchical_render(union64, x.double(), y.double(), (0.0, 100.0), S, std, ratio, z.double(), w.double()).labels,
+                                          (a, b, c, e), chunk), (o, d, u_coarse, u_fine), 1, whole64, trials=4 if N <= 16 else 8, ulps=4.0 if N <= 16 else 16.0)
+    whole_errors = (hip_labels - whole32).abs().max(-1).values
+    margin(tag, "end to end: share of determinate rays", float(determinate_whole.float().mean()), 1.0)
+    margin(tag, "end to end, determinate rays: worst", float(whole_errors[determinate_whole].max()), 1e-4)
+    margin(tag, "end to end, determinate rays beyond 1e-4", float((whole_errors[determinate_whole] > 1e-4).sum()), 0.5)
     assert not failures, failures
+    # Config 2 (the metric's workload): EVERY determinate ray within 1e-4.  Config 5 (64 overlapping boxes, 255 points per ray: half of the rays
+    # have a sample or a fine uniform within float32 noise of a kink SOMEWHERE along the pipeline, and no finite number of noise trials certifies
+    # a ray): the rays that survive eight trials of 16 ulps, at most 0.5 % of them beyond 1e-4 (observed: 3 of 1130 with four trials of 4 ulps).
+    beyond = float((whole_errors[determinate_whole] > 1e-4).float().mean())
+    margin(tag, "end to end, determinate rays: share beyond 1e-4", beyond, 0.0 if N <= 16 else 5e-3)
+    if N <= 16:
+        assert float(determinate_whole.float().mean()) > 0.75 and float(whole_errors[determinate_whole].max()) <= 1e-4
+    else:
+        assert float(determinate_whole.float().mean()) > 0.25 and beyond <= 5e-3
     assert hip_tail <= oracle_tail + 1e-3 and hip_tail64 <= oracle_tail + 1e-3
     assert float((hip_labels - whole32).abs().max(-1).values.median()) < 1e-5
     assert float(whole64[missed].abs().max()) < 1e-6 if bool(missed.any()) else True
@@ -559,7 +666,10 @@ def test_config3_full_size_parity_against_the_oracle(dev, mlp_products):
     from oracle import fields as ofields, geometry as ogeometry, rendering as orendering
     from vsrd_amd import models, rendering
     N, S, V, H, W, seed = 16, 64, 9, 376, 1408, 3
-    budget = int(os.environ.get("VSRD_PARITY_RAYS", 640))
+    # (round 6: 768 rays by default -- every ray costs the oracle ten passes of 190 points x 16 MLPs with tangents; the round's patient run,
+    #  VSRD_PARITY_RAYS=4096, 19 minutes on a 256-core box, is profiles/r06/parity_config3_4096_rays.log: no determinate ray beyond 1.2e-5)
+    budget = int(os.environ.get("VSRD_PARITY_RAYS", 768))
+    noise_trials = 2 if budget >= 4096 else 1
     sched = bench.schedule_values(bench.SCHEDULES["mid"])
     T, std, ratio = sched["temperature"], sched["std"], sched["cosine_ratio"]
     torch.manual_seed(0)                 # (the detector's embeddings -- the hypernetwork's input -- are drawn at construction: the same field in every run)
@@ -579,8 +689,10 @@ def test_config3_full_size_parity_against_the_oracle(dev, mlp_products):
         union = bench.build_union(det, T)
         weights = hyper(det.embeddings)[0].contiguous()
         union.mlp_weights = weights
-        _, labels = rendering.silhouette_step(union, origins, directions, targets, (0.0, 100.0), S, std, ratio, u_coarse=u_coarse, u_fine=u_fine,
-                                              eikonal_ratio=0.01, return_labels=True, skip_exact_misses=False, mlp_split_bf16=mlp_products == "split_bf16")
+        _, labels, samples = rendering.silhouette_step(union, origins, directions, targets, (0.0, 100.0), S, std, ratio, u_coarse=u_coarse, u_fine=u_fine,
+                                                       eikonal_ratio=0.01, return_labels=True, return_samples=True, skip_exact_misses=False,
+                                                       mlp_split_bf16=mlp_products == "split_bf16")
+        all_targets = targets
         del targets
         # three quarters of the selection from the rays that see something (label > 1e-3: a uniform draw of this frame is mostly sky), a quarter from all
         assert torch.isfinite(labels).all() and float(labels.max()) > 0.5
@@ -590,8 +702,10 @@ def test_config3_full_size_parity_against_the_oracle(dev, mlp_products):
         selection = torch.unique(torch.cat([lit[torch.randint(0, lit.numel(), (3 * budget // 4,), generator=pick).to(dev)],
                                             torch.randint(0, R, (budget // 4,), generator=pick).to(dev)]))
         hip_labels = labels[selection].cpu()
+        selected_targets = all_targets[selection].cpu()
+        hip_distances, hip_coarse_weights, samples_u_coarse, samples_u_fine = (samples[k][selection].cpu() for k in ("distances", "coarse_weights", "u_coarse", "u_fine"))
         margin(tag, "selected rays that see something", float((hip_labels.max(-1).values > 1e-3).float().mean()), 1.0)
-        del labels
+        del labels, samples, all_targets
         o, d, uc, uf = origins[selection].cpu(), directions[selection].cpu(), u_coarse[selection].cpu(), u_fine[selection].cpu()
         del u_coarse, u_fine
 
@@ -603,15 +717,60 @@ def test_config3_full_size_parity_against_the_oracle(dev, mlp_products):
             return field
 
         union32, union64 = oracle_union(torch.float32), oracle_union(torch.float64)
-        whole32 = _in_chunks(lambda a, b, c, e: orendering.hierarchical_render(union32, a, b, (0.0, 100.0), S, std, ratio, c, e).labels, (o, d, uc, uf), 128)
+        chunk = 128
+        failures = []
+
+        def held(what, got, want, exact, tight=1.0e-5):
+            """As in test_full_size_parity_against_the_oracle: the kernel against the float32 oracle next to the float32 oracle against the float64 one."""
+            mine = (got.double() - want.double()).abs().flatten(1).max(-1).values
+            own = (want.double() - exact.double()).abs().flatten(1).max(-1).values
+            share_mine, share_own = float((mine > tight).float().mean()), float((own > tight).float().mean())
+            margin(tag, what + f": rays > {tight:g}", share_mine, share_own + 1.0e-3)
+            margin(tag, what + ": worst ray", float(mine.max()), max(2.0e-4, float(own.max())))
+            margin(tag, what + ": oracle f32/f64 share", share_own, 1.0)
+            margin(tag, what + ": oracle f32/f64 worst", float(own.max()), 1.0)
+            if not (share_mine <= share_own + 1.0e-3 and float(mine.max()) <= max(2.0e-4, float(own.max()))):
+                failures.append((what, share_mine, share_own, float(mine.max()), float(own.max())))
+            return mine
+
+        # ---- link by link on the STEP'S OWN samples (VERDICT r05 item 4b; vsrd_render_config::out_* of vsrd_render_residual_step, ABI 8) ----
+        # (the caller's own uniforms come back as they were given -- raw; the kernel sorts its copy, samplers.py:22)
+        sorted_fine = torch.sort(uf, dim=-1).values
+        assert torch.equal(samples_u_coarse, uc) and (torch.equal(samples_u_fine, uf) or torch.equal(samples_u_fine, sorted_fine))
+        coarse_distances = orendering.stratified_distances((0.0, 100.0), S, uc)
+        coarse32 = _in_chunks(lambda a, b, c: orendering.render_given_distances(union32, a, b, c, std, ratio).weights, (o, d, coarse_distances), chunk)
+        coarse64 = _in_chunks(lambda a, b, c: orendering.render_given_distances(union64, a.double(), b.double(), c.double(), std, ratio).weights, (o, d, coarse_distances), chunk)
+        first = held("pass 1", hip_coarse_weights, coarse32, coarse64)
+        margin(tag, "pass 1: median ray", float(first.median()), 2e-6)
+        assert float(first.median()) < 2e-6
+        fine = orendering.importance_distances(coarse_distances, hip_coarse_weights, sorted_fine)
+        merged = torch.sort(torch.cat([coarse_distances, fine], dim=-1), dim=-1).values
+        sees = hip_coarse_weights.sum(-1) > 0                                  # (rays without any coarse weight: their fine samples are extrapolated to 1e6 m, samplers.py:33)
+        displaced = (hip_distances[sees] - merged[sees]).abs()
+        off = float((displaced > 5e-3 + 1e-4 * merged[sees].abs()).float().mean())
+        margin(tag, "samples off by > 5e-3 m", off, 1e-4)
+        margin(tag, "rays with a sample off > 2 % bin", float((displaced.max(-1).values > 0.02 * 100.0 / S).float().mean()), 1e-3)
+        assert off <= 1e-4
+        fixed32 = _in_chunks(lambda a, b, c: orendering.render_given_distances(union32, a, b, c, std, ratio).labels, (o, d, hip_distances), chunk)
+        fixed64 = _in_chunks(lambda a, b, c: orendering.render_given_distances(union64, a.double(), b.double(), c.double(), std, ratio).labels, (o, d, hip_distances), chunk)
+        at_samples = held("pass 2", hip_labels, fixed32, fixed64)
+        margin(tag, "pass 2: median ray", float(at_samples.median()), 2e-6)
+        determinate = (fixed32.double() - fixed64).abs().max(-1).values <= 1.0e-5
+        determinate &= _stable_under_float32_noise(
+            lambda a, b, c: _in_chunks(lambda x, y, z: orendering.render_given_distances(union64, x.double(), y.double(), z.double(), std, ratio).labels, (a, b, c), chunk),
+            (o, d, hip_distances), 2, fixed64, trials=noise_trials)
+        margin(tag, "pass 2: share of determinate rays", float(determinate.float().mean()), 1.0)
+        margin(tag, "pass 2, determinate rays: worst", float(at_samples[determinate].max()), 2e-5)
+        assert float(at_samples.median()) < 2e-6 and float(determinate.float().mean()) > 0.75 and float(at_samples[determinate].max()) <= 2e-5
+        whole32 = _in_chunks(lambda a, b, c, e: orendering.hierarchical_render(union32, a, b, (0.0, 100.0), S, std, ratio, c, e).labels, (o, d, uc, uf), chunk)
         whole64 = _in_chunks(lambda a, b, c, e: orendering.hierarchical_render(union64, a.double(), b.double(), (0.0, 100.0), S, std, ratio, c.double(), e.double()).labels,
-                             (o, d, uc, uf), 128)
+                             (o, d, uc, uf), chunk)
     mine32 = (hip_labels - whole32).abs().max(-1).values
     mine64 = (hip_labels.double() - whole64).abs().max(-1).values
     own = (whole32.double() - whole64).abs().max(-1).values
     hip_tail, hip_tail64, oracle_tail = (float((e > 1e-4).float().mean()) for e in (mine32, mine64, own))
-    margin(tag, "rays > 1e-4: HIP vs f32 oracle", hip_tail, oracle_tail + max(1e-3, 2.5 / selection.numel()))
-    margin(tag, "rays > 1e-4: HIP vs f64 oracle", hip_tail64, oracle_tail + max(1e-3, 2.5 / selection.numel()))
+    margin(tag, "rays > 1e-4: HIP vs f32 oracle", hip_tail, oracle_tail + 1e-3)
+    margin(tag, "rays > 1e-4: HIP vs f64 oracle", hip_tail64, oracle_tail + 1e-3)
     margin(tag, "rays > 1e-4: f32 vs f64 oracle", oracle_tail, 1.0)
     margin(tag, "rays > 1e-5: HIP vs f32 oracle", float((mine32 > 1e-5).float().mean()), 1.0)
     margin(tag, "rays > 1e-5: f32 vs f64 oracle", float((own > 1e-5).float().mean()), 1.0)
@@ -619,12 +778,55 @@ def test_config3_full_size_parity_against_the_oracle(dev, mlp_products):
     margin(tag, "worst ray, f32 vs f64 oracle", float(own.max()), 1.0)
     margin(tag, "median ray, HIP vs f32 oracle", float(mine32.median()), 1e-5)
     margin(tag, "median ray, f32 vs f64 oracle", float(own.median()), 1.0)
+    determinate_whole = own <= 1.0e-5
+    with torch.no_grad():
+        determinate_whole &= _stable_under_float32_noise(
+            lambda a, b, c, e: _in_chunks(lambda x, y, z, w: orendering.hierarchical_render(union64, x.double(), y.double(), (0.0, 100.0), S, std, ratio, z.double(), w.double()).labels,
+                                          (a, b, c, e), chunk), (o, d, uc, uf), 1, whole64, trials=noise_trials)
+    margin(tag, "end to end: share of determinate rays", float(determinate_whole.float().mean()), 1.0)
+    margin(tag, "end to end, determinate rays: worst", float(mine32[determinate_whole].max()), 1e-4)
     print(f"{tag}: {selection.numel()} rays; > 1e-4 end to end: HIP vs f32 oracle {hip_tail:.2e}, f32 vs f64 oracle {oracle_tail:.2e}, HIP vs f64 oracle {hip_tail64:.2e}; "
           f"median {float(mine32.median()):.2e}, worst {float(mine32.max()):.2e} (oracle's own {float(own.max()):.2e})")
-    # (the two product forms of the kernel disagree with EACH OTHER by more than 1e-4 on 2.9e-4 of this frame's rays -- a fine sample on the other
-    #  side of a plateau, tools/compare_forms_debug.py -- so among a few hundred selected rays one or two such rays are expected against any oracle)
-    slack = max(1e-3, 2.5 / selection.numel())
-    assert hip_tail <= oracle_tail + slack and hip_tail64 <= oracle_tail + slack
+    assert not failures, failures
+    # (round 5 allowed 2.5 rays of 640 here; with 4096 rays the share is a share: the float32 oracle's own + 1e-3)
+    assert hip_tail <= oracle_tail + 1e-3 and hip_tail64 <= oracle_tail + 1e-3
     assert float(mine32.median()) < 1e-5
+    assert float(determinate_whole.float().mean()) > 0.75 and float(mine32[determinate_whole].max()) <= 1e-4
+    # ---- loss and gradients (boxes AND the MLPs' weights) at the step's own samples, on a subset the oracle's double backward
+    # through 16 MLPs affords: vsrd_render_forward + vsrd_render_backward against the float32 oracle's autograd
+    subset = torch.arange(0, selection.numel(), max(selection.numel() // int(os.environ.get("VSRD_PARITY_GRADIENT_RAYS", 384)), 1))
+    with torch.enable_grad():
+        raw_names = ("locations", "dimensions", "orientations")
+        hip_weights = weights.detach().clone().requires_grad_(True)
+        field = bench.build_union(det, T)
+        field.mlp_weights = hip_weights
+        sub_dev = selection[subset.to(dev)]
+        at_labels, _, _ = rendering.render_at_distances(field, origins[sub_dev], directions[sub_dev], hip_distances[subset].to(dev), std, ratio)
+        sub_targets = selected_targets[subset]
+        hip_loss = torch.nn.functional.binary_cross_entropy(at_labels.clamp(1.0e-6, 1.0 - 1.0e-6), sub_targets.to(dev), reduction="none").mean()
+        hip_grads = [g.detach().cpu() for g in torch.autograd.grad(hip_loss, [*(getattr(det, n) for n in raw_names), hip_weights])]
+        hip_grads = [g[0] for g in hip_grads[:3]] + [hip_grads[3]]
+        raws = [getattr(det, n).detach().cpu()[0].clone().requires_grad_(True) for n in raw_names]
+        oracle_weights = weights.detach().cpu().clone().requires_grad_(True)
+        leaves = [*raws, oracle_weights]
+        oracle_grads, oracle_loss, rows = [torch.zeros_like(t) for t in leaves], 0.0, int(subset.numel())
+        for start in range(0, rows, 64):
+            index = subset[start:start + 64]
+            loc, dim, rot, _ = ogeometry.decode_box_parameters(*raws)
+            union = ofields.InstanceUnion(loc, rot, dim, T)
+            union.mlp_weights = oracle_weights
+            out = orendering.render_given_distances(union, o[index], d[index], hip_distances[index], std, ratio)
+            part = torch.nn.functional.binary_cross_entropy(out.labels.clamp(1.0e-6, 1.0 - 1.0e-6), selected_targets[index], reduction="none").sum() / (rows * N)
+            for total, g in zip(oracle_grads, torch.autograd.grad(part, leaves)):
+                total += g
+            oracle_loss += float(part)
+        loss_error = abs(float(hip_loss) - oracle_loss) / max(abs(oracle_loss), 1e-12)
+        margin(tag, "loss at the step's samples (relative)", loss_error, 1e-5)
+        assert loss_error <= 1e-5, (float(hip_loss), oracle_loss)
+        for name, got, want in zip((*raw_names, "mlp weights"), hip_grads, oracle_grads):
+            scale = max(float(want.abs().max()), 1e-12)
+            error = float((got - want).abs().max()) / scale
+            margin(tag, f"grad {name} at the step's samples / largest entry", error, 5e-3)
+            assert error <= 5e-3, (name, error)
     dark = hip_labels.abs().max(-1).values == 0
     assert float(whole64[dark].abs().max()) < 1e-6 if bool(dark.any()) else True

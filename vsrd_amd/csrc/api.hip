@@ -988,11 +988,13 @@ int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_con
                                   const float* targets, const float* instance_weights, float loss_scale, float eikonal_ratio,
                                   void* workspace, size_t workspace_bytes,
                                   float* losses, float* grad_instances, float* grad_mlp_weights, float* labels, void* stream) {
-    if (!valid_field(field) || !valid_config(config, true) || !workspace || !losses || !grad_instances || !grad_mlp_weights) return VSRD_E_INVALID_ARGUMENT;
+    if (!valid_field(field) || !valid_config(config, true, true) || !workspace || !losses || !grad_instances || !grad_mlp_weights) return VSRD_E_INVALID_ARGUMENT;
     if (field->mlp_weights == nullptr) return VSRD_E_INVALID_ARGUMENT;       // box-only fields: vsrd_render_silhouette_step
     const int N = field->num_instances, S = config->num_samples;
     ResidualStepPlan p;
-    const bool allow_pair = !(config->flags & VSRD_FLAG_RESIDUAL_WAVE_PER_RAY);
+    // (a step that writes its samples out -- vsrd_render_config::out_* -- keeps one ray per wave: the split-ray and the one-kernel forms have no such outputs)
+    const bool allow_pair = !(config->flags & VSRD_FLAG_RESIDUAL_WAVE_PER_RAY) && !wants_samples(config);
+    if (wants_samples(config) && (config->flags & VSRD_FLAG_RESIDUAL_SINGLE_KERNEL)) return VSRD_E_UNSUPPORTED;
     Frames frames;
     frames_of(config->num_frames, config->frame_stride, &frames);           // (validated by valid_config)
     if (config->adjoint_slots_per_item < 0 || config->adjoint_slots_per_item > 64) return VSRD_E_INVALID_ARGUMENT;
@@ -1000,6 +1002,7 @@ int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_con
                             !plan_residual_step(N, S, config->num_rays, allow_pair, &p, config->adjoint_slots_per_item);
     // a batch of frames: the two-kernel form with every frame's rays in ONE chunk (each frame its own seeds, item counter and rows, frame_stride apart)
     if (frames.count > 1 && (one_kernel || p.chunk < config->num_rays || static_cast<long long>(p.total_bytes) > frames.stride)) return VSRD_E_UNSUPPORTED;
+    if (one_kernel && wants_samples(config)) return VSRD_E_UNSUPPORTED;
     if (one_kernel)
         return residual_step_single_kernel(field, config, origins, directions, u_coarse, u_fine, targets, instance_weights, loss_scale, eikonal_ratio,
                                            workspace, workspace_bytes, losses, grad_instances, grad_mlp_weights, labels, stream);

@@ -1038,10 +1038,19 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(k
         const Ray r = load_ray_gathered(c, origins, directions, row);
         const float target = load_target(c, targets, row, lane, N);
         const RayCull rc = cull_ray_setup(instances, N, r.ox, r.oy, r.oz, r.rx, r.ry, r.rz, l.cull, lane);
-        stage_ray_samples<kRoundsS>(l, c, S, ray, u_coarse, u_fine, nullptr, nullptr, sorted_input, lane);
+        stage_ray_samples<kRoundsS>(l, c, S, ray, u_coarse, u_fine, c.out_u_coarse, c.out_u_fine, sorted_input, lane);
         float w1[kRoundsS];
         render_pass<kRoundsS, false, true>(instances, mlp, N, sh, r, rc, l.coarse, S, l.dcache, w1, nullptr, nullptr);
+        if (c.out_coarse_weights != nullptr) {                             // vsrd_render_config::out_* (ABI 8: the residual step too): the step's own samples
+#pragma unroll
+            for (int k = 0; k < kRoundsS; ++k)
+                if (k * kWave + lane < S - 1) c.out_coarse_weights[static_cast<size_t>(ray) * (S - 1) + k * kWave + lane] = w1[k];
+        }
         importance_merge<kRoundsS>(l, S, w1);
+        if (c.out_distances != nullptr) {
+            float* dst = c.out_distances + static_cast<size_t>(ray) * D;
+            for (int idx = lane; idx < D; idx += kWave) dst[idx] = l.merged[idx];
+        }
         RayAdjoint<kRounds> st;
         const float label = adjoint_forward_sweep<kRounds, true, true>(st, instances, mlp, N, sh, r, rc, l.merged, num_points, nullptr, l.dcache, lane, rcache);
         if (labels_out != nullptr && lane < N) labels_out[static_cast<size_t>(ray) * N + lane] = label;

@@ -631,7 +631,7 @@ class _ResidualStep(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, instances, mlp_weights, origins, directions, targets, weights, u_coarse, u_fine, temperature, scalars, origin_stride,
-                seed, stream_offset, flags, loss_scale, eikonal_ratio, want_labels):
+                seed, stream_offset, flags, loss_scale, eikonal_ratio, want_labels, want_samples=False):
         lib = _lib.load()
         std, ratio, eps, near, far, S, schedule = _unpack(scalars)
         R, N = directions.shape[0], instances.shape[0]
@@ -641,9 +641,13 @@ class _ResidualStep(torch.autograd.Function):
         losses = torch.empty(2, dtype=torch.float32, device=dev)
         grad, grad_mlp = torch.empty_like(instances), torch.empty_like(centred)
         labels = torch.empty(R, N, dtype=torch.float32, device=dev) if want_labels else None
+        samples = None
+        if want_samples:          # the step's own state between its passes (vsrd_render_config::out_*; ABI 8: the residual step's one-ray-per-wave form too)
+            samples = (torch.empty(R, 2 * S, dtype=torch.float32, device=dev), torch.empty(R, S - 1, dtype=torch.float32, device=dev),
+                       torch.empty(R, S, dtype=torch.float32, device=dev), torch.empty(R, S, dtype=torch.float32, device=dev))
         workspace = _workspace(dev, N, True, step_shape=(S, R))
         field = _lib.make_field(instances, temperature, centred)
-        config = _lib.make_config(R, S, (near, far), std, ratio, eps, origin_stride, seed, stream_offset, flags | _mlp_flag(centred), schedule=schedule)
+        config = _lib.make_config(R, S, (near, far), std, ratio, eps, origin_stride, seed, stream_offset, flags | _mlp_flag(centred), schedule=schedule, samples=samples)
         with profiling.timed("vsrd_render_residual_step"):
             _lib.check(lib.vsrd_render_residual_step(field, config, _lib.ptr(origins), _lib.ptr(directions), _lib.ptr(u_coarse), _lib.ptr(u_fine),
                                                      _lib.ptr(targets), _lib.ptr(weights), float(loss_scale), float(eikonal_ratio),
@@ -651,14 +655,15 @@ class _ResidualStep(torch.autograd.Function):
                                                      _lib.ptr(labels), _lib.stream()))
         ctx.save_for_backward(grad, grad_mlp)
         out_labels = labels if want_labels else losses.new_empty(0)
+        out_samples = samples if want_samples else tuple(losses.new_empty(0) for _ in range(4))
         terms = losses.clone()
-        ctx.mark_non_differentiable(out_labels, terms)
-        return losses[0] + eikonal_ratio * losses[1], terms, out_labels
+        ctx.mark_non_differentiable(out_labels, terms, *out_samples)
+        return (losses[0] + eikonal_ratio * losses[1], terms, out_labels) + tuple(out_samples)
 
     @staticmethod
-    def backward(ctx, grad_loss, _grad_terms, _grad_labels):
+    def backward(ctx, grad_loss, _grad_terms, _grad_labels, *_unused):
         grad, grad_mlp = ctx.saved_tensors
-        return (grad * grad_loss, grad_mlp * grad_loss) + (None,) * 15
+        return (grad * grad_loss, grad_mlp * grad_loss) + (None,) * 16
 
 
 def silhouette_step(distance_field, ray_positions, ray_directions, targets, distance_range, num_samples, sdf_std_deviation,
@@ -669,7 +674,7 @@ def silhouette_step(distance_field, ray_positions, ray_directions, targets, dist
     ``mean(BCE(clamp(labels[..., pd_indices], 1e-6, 1 - 1e-6), targets[..., gt_indices]))`` in one launch; for residual fields
     (box + per-instance MLP) also ``eikonal_ratio * mean((|sampled_gradients| - 1)^2)`` (main.py:679-687), i.e. the returned loss is
     ``silhouette + eikonal_ratio * eikonal``.  Returns the loss (autograd-connected to the field parameters), then -- when asked --
-    the detached terms ``[silhouette, eikonal]``, the labels [R,N], and (``return_samples``, box-only fields) a dict with the step's OWN
+    the detached terms ``[silhouette, eikonal]``, the labels [R,N], and (``return_samples``) a dict with the step's OWN
     state between its passes: ``distances`` [R,2S] (sorted; NaN in column 0 = ray skipped as an exact miss), ``coarse_weights`` [R,S-1],
     ``u_coarse`` / ``u_fine`` [R,S] -- what its labels, loss and gradients were computed from (the full-size parity tests feed them to the
     oracle)."""
@@ -699,13 +704,11 @@ def silhouette_step(distance_field, ray_positions, ray_directions, targets, dist
     if mlp_split_bf16 is not None:        # (residual fields: the MLP's products on split-bf16 MFMA or on the exact-fp32 one; None: the module switch)
         flags = (flags | _lib.FLAG_MLP_SPLIT_BF16) if mlp_split_bf16 else (flags & ~_lib.FLAG_MLP_SPLIT_BF16)
     scalars = (float(sdf_std_deviation), float(cosine_ratio), float(epsilon), float(distance_range[0]), float(distance_range[1]), int(num_samples), schedule)
-    if return_samples and residual:
-        raise NotImplementedError("return_samples: box-only fields (vsrd_render_silhouette_step) only")
     samples = None
     if residual:
-        loss, terms, labels = _ResidualStep.apply(block.instances, block.mlp_weights, origins, directions, ordered, weights, u_coarse, u_fine,
-                                                  block.temperature, scalars, stride, int(seed), _offset(stream_offset), flags & ~_lib.FLAG_SKIP_EXACT_MISSES,
-                                                  1.0 / (R * max(kept, 1)), float(eikonal_ratio), bool(return_labels))
+        loss, terms, labels, *samples = _ResidualStep.apply(block.instances, block.mlp_weights, origins, directions, ordered, weights, u_coarse, u_fine,
+                                                            block.temperature, scalars, stride, int(seed), _offset(stream_offset), flags & ~_lib.FLAG_SKIP_EXACT_MISSES,
+                                                            1.0 / (R * max(kept, 1)), float(eikonal_ratio), bool(return_labels), bool(return_samples))
     else:
         loss, labels, *samples = _SilhouetteStep.apply(block.instances, origins, directions, ordered, weights, u_coarse, u_fine, block.temperature, scalars,
                                                        stride, int(seed), _offset(stream_offset), flags, 1.0 / (R * max(kept, 1)), bool(return_labels),
