@@ -101,9 +101,10 @@ typedef struct vsrd_render_config {
      * in prediction order. */
     const int32_t* target_columns;         /* [N] or NULL                                                           */
     int32_t target_stride;                 /* columns of a targets row when target_columns is set                   */
-    /* Optional outputs of vsrd_render_silhouette_step (ABI 7; every other entry point rejects them): the per-ray state between the
+    /* Optional outputs of vsrd_render_silhouette_step (ABI 7) and vsrd_render_residual_step (ABI 8: two-kernel form, num_samples in
+     * (32, 64], one ray per wave; VSRD_E_UNSUPPORTED otherwise); every other entry point rejects them: the per-ray state between the
      * step's passes, written by the step launch itself -- what pass 1 of scripts/main.py:511-523 returns (`sampled_weights`), the
-     * uniforms it drew, and the sorted pass-2 distances its labels, loss and gradients were computed at.  Rows are in STEP order (ray r
+     * uniforms it used, and the sorted pass-2 distances its labels, loss and gradients were computed at.  Rows are in STEP order (ray r
      * of the launch).  A step that writes them takes the multi-ray or the one-ray kernels (never the split-ray form). */
     float* out_distances;                  /* [R,2S] or NULL; row of an exact miss (VSRD_FLAG_SKIP_EXACT_MISSES): [r,0] = NaN, rest untouched */
     float* out_coarse_weights;             /* [R,S-1] or NULL: pass 1's compositing weights                           */

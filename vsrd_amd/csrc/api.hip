@@ -465,10 +465,23 @@ int32_t vsrd_render_backward(const vsrd_field* field, const vsrd_render_config* 
         RenderArgs c = render_args(config);
         c.sh.inv_t = f.inv_t;
         float* partials = static_cast<float*>(workspace);
-        if (quad) hipLaunchKernelGGL(render_backward_quad_kernel, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins, directions,
-                                     distances, num_distances, grad_labels, partials);
-        else hipLaunchKernelGGL(render_backward_pair_kernel, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins, directions,
-                                distances, num_distances, grad_labels, partials);
+        // two kernels on one grid (quad_step.h: backward_rows_kernel_body): behind the waves' partial rows, two summary words and one byte per group of rays
+        const size_t num_groups = (static_cast<size_t>(config->num_rays) + rays_per_wave - 1) / rays_per_wave;
+        const size_t flag_bytes = 16 + ((num_groups + 15) & ~static_cast<size_t>(15));
+        const int waves_per_block = g.threads / kWave;
+        if (flag_bytes + static_cast<size_t>(waves_per_block) * row * sizeof(float) > workspace_bytes) return VSRD_E_WORKSPACE;
+        const int max_waves = static_cast<int>((workspace_bytes - flag_bytes) / sizeof(float) / row);
+        if (g.blocks * waves_per_block > max_waves) g.blocks = max_waves / waves_per_block;
+        unsigned char* redo_flags = reinterpret_cast<unsigned char*>(partials + static_cast<size_t>(g.blocks) * waves_per_block * row);
+        if (hipMemsetAsync(redo_flags, 0, 16, s) != hipSuccess) return VSRD_E_LAUNCH;
+#define VSRD_LAUNCH_BACKWARD_ROWS(KERNEL)                                                                                                 \
+        hipLaunchKernelGGL(KERNEL<true>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins, directions,   \
+                           distances, num_distances, grad_labels, partials, redo_flags);                                                \
+        hipLaunchKernelGGL(KERNEL<false>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins, directions,  \
+                           distances, num_distances, grad_labels, partials, redo_flags)
+        if (quad) { VSRD_LAUNCH_BACKWARD_ROWS(render_backward_quad_kernel); }
+        else { VSRD_LAUNCH_BACKWARD_ROWS(render_backward_pair_kernel); }
+#undef VSRD_LAUNCH_BACKWARD_ROWS
         if (launch_status() != VSRD_OK) return VSRD_E_LAUNCH;
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(row), dim3(256), 0, s, partials, g.blocks * (g.threads / kWave), row, grad_instances);
         return launch_status();
@@ -1050,6 +1063,7 @@ int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_con
 #define VSRD_LAUNCH(K)                                                                                                                   \
         if (opt_in_lds(residual_step_front_kernel<K>, p.front_lds) != VSRD_OK) return VSRD_E_LAUNCH;                                     \
         if (frames.count > 1) return VSRD_E_UNSUPPORTED;      /* (a batch's frames are launches of <= 2048 rays: the pair kernel) */                    \
+        if (wants_samples(config)) return VSRD_E_UNSUPPORTED; /* (the samples are written by the two-round instantiation below) */                      \
         hipLaunchKernelGGL(residual_step_front_kernel<K>, dim3(p.front_blocks), dim3(kBlockThreads), p.front_lds, s, VSRD_FRONT_ARGS)
 #define VSRD_LAUNCH_PAIR(K)                                                                                                              \
         if (frames.count > 1) {                                                                                                          \
@@ -1062,7 +1076,7 @@ int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_con
         if (split) {
             vsrd_split_front::FrontLaunch launch = {&f, sizeof f, &c, sizeof c, field->instances, front_weights, origins, directions, u_coarse, u_fine, targets, instance_weights,
                                                     loss_scale, eikonal_scale, eikonal_norm, labels, box_partials, jets, loss_partials, seeds, masks, p.slots_per_instance,
-                                                    first, rays, chunk_index > 0 ? 1 : 0, p.pair, p.rounds, p.front_blocks, p.front_lds, frames.count};
+                                                    first, rays, chunk_index > 0 ? 1 : 0, p.pair, p.rounds, p.front_blocks, p.front_lds, wants_samples(config), frames.count};
             const int code = vsrd_split_front::launch_front(launch, s);
             if (code != vsrd_split_front::kOk) return code == vsrd_split_front::kUnsupported ? VSRD_E_UNSUPPORTED : VSRD_E_LAUNCH;
         } else if (p.pair) {
@@ -1072,7 +1086,10 @@ int32_t vsrd_render_residual_step(const vsrd_field* field, const vsrd_render_con
                 default: return VSRD_E_UNSUPPORTED;
             }
         } else {
-            switch (p.rounds) {
+            if (p.rounds == 2 && wants_samples(config) && frames.count == 1) {         // vsrd_render_config::out_*: num_samples in (32, 64]
+                if (opt_in_lds(residual_step_front_kernel<2, true>, p.front_lds) != VSRD_OK) return VSRD_E_LAUNCH;
+                hipLaunchKernelGGL((residual_step_front_kernel<2, true>), dim3(p.front_blocks), dim3(kBlockThreads), p.front_lds, s, VSRD_FRONT_ARGS);
+            } else switch (p.rounds) {
                 case 1: VSRD_LAUNCH(1); break;
                 case 2: VSRD_LAUNCH(2); break;
                 case 4: VSRD_LAUNCH(4); break;

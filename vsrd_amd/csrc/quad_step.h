@@ -1294,13 +1294,24 @@ __device__ __forceinline__ bool rows_backward_body(const float* __restrict__ ins
     return true;
 }
 
-template <int kL>
+// Round 6: the adjoint launch is TWO kernels on one grid, like the fused step (silhouette_rows_kernel_body above).
+// With its three bodies inlined into one loop render_backward_quad_kernel held 128 registers with 135 of them spilled (160 bytes of scratch per
+// lane: the registers of the bodies it was not running) -- and this is the backward every `loss.backward()` of the recommended one-launch
+// render_hierarchical path takes.
+//   kHot   rotations about y + fixed soft-min shift (what BoxParameters3D decodes to); records per group whether that body served it
+//   !kHot  everything else: all groups when the hot kernel did not run, else only the groups it flagged, adding to the same partial rows
+template <int kL, bool kHot>
 __device__ __forceinline__ void backward_rows_kernel_body(
     FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
-    const float* __restrict__ distances, int num_distances, const float* __restrict__ grad_labels, float* __restrict__ partials) {
+    const float* __restrict__ distances, int num_distances, const float* __restrict__ grad_labels, float* __restrict__ partials,
+    unsigned char* __restrict__ redo_flags) {
     constexpr int kRays = kWave / kL;
     constexpr int kG = kL == kRowLanes ? 4 : 16;
     constexpr int kRounds = 8;                                               // up to 8 kL points
+    unsigned* redo_summary = reinterpret_cast<unsigned*>(redo_flags);        // [0] groups flagged, [1] the hot kernel ran (zeroed by the host)
+    redo_flags += 16;
+    if (!kHot && __builtin_amdgcn_readfirstlane(static_cast<int>(redo_summary[1])) != 0 &&
+        __builtin_amdgcn_readfirstlane(static_cast<int>(redo_summary[0])) == 0) return;
     apply_device_schedule(f, c);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = wave_in_block();
@@ -1317,42 +1328,61 @@ __device__ __forceinline__ void backward_rows_kernel_body(
     sh.yaw_gradients = sh.yaw && (c.flags & 1024u) != 0u;                       // VSRD_FLAG_YAW_GRADIENTS
     sh.mlp_bits = 0u;
     sh.mlp_lds = nullptr;
+    const bool hot_runs = sh.reach >= 0.0f && sh.yaw;                          // (wave-uniform, the same in both kernels of the launch)
+    if (kHot && !hot_runs) return;
+    if (kHot && blockIdx.x == 0 && threadIdx.x == 0) redo_summary[1] = 1u;
     float G[kG];
 #pragma unroll
     for (int s = 0; s < kG; ++s) G[s] = 0.0f;
     const int num_waves = static_cast<int>(gridDim.x) * waves_per_block();
     const int wave_global = static_cast<int>(blockIdx.x) * waves_per_block() + wave;
     const int num_groups = (c.num_rays + kRays - 1) / kRays;
+    bool touched = false;
     for (int group = wave_global; group < num_groups; group += num_waves) {
         const int first_ray = group * kRays;
+        if (!kHot && hot_runs) {
+            if (__builtin_amdgcn_readfirstlane(static_cast<int>(redo_flags[group])) == 0) continue;
+            touched = true;
+        }
         const RowLanes rl = row_lanes<kL>(opaque_lane_id());
         wave_lds_sync();
-        bool done = false;
-        if (sh.reach >= 0.0f) {
-            done = sh.yaw ? rows_backward_body<kL, kRounds, true, false>(instances, N, c, sh, first_ray, origins, directions, distances, num_distances, grad_labels,
-                                                                         stage, dcache, coefs, rays, G, rl)
-                          : rows_backward_body<kL, kRounds, false, false>(instances, N, c, sh, first_ray, origins, directions, distances, num_distances, grad_labels,
-                                                                          stage, dcache, coefs, rays, G, rl);
-            if (!done) wave_lds_sync();
+        if (kHot) {
+            const bool done = rows_backward_body<kL, kRounds, true, false>(instances, N, c, sh, first_ray, origins, directions, distances, num_distances, grad_labels,
+                                                                           stage, dcache, coefs, rays, G, rl);
+            if (lane0 == 0) {
+                redo_flags[group] = done ? 0 : 1;
+                if (!done) atomicAdd(redo_summary, 1u);
+            }
+        } else {
+            bool done = false;
+            if (sh.reach >= 0.0f && !hot_runs) {
+                done = rows_backward_body<kL, kRounds, false, false>(instances, N, c, sh, first_ray, origins, directions, distances, num_distances, grad_labels,
+                                                                     stage, dcache, coefs, rays, G, rl);
+                if (!done) wave_lds_sync();
+            }
+            if (!done) rows_backward_body<kL, kRounds, false, true>(instances, N, c, sh, first_ray, origins, directions, distances, num_distances, grad_labels,
+                                                                    stage, dcache, coefs, rays, G, rl);
         }
-        if (!done) rows_backward_body<kL, kRounds, false, true>(instances, N, c, sh, first_ray, origins, directions, distances, num_distances, grad_labels,
-                                                                stage, dcache, coefs, rays, G, rl);
     }
+    if (!kHot && hot_runs && !touched) return;                                  // (the usual case: nothing was left over)
+    const bool add = !kHot && hot_runs;
     float* out = partials + static_cast<size_t>(wave_global) * (N * kGradStride);
 #pragma unroll
     for (int s = 0; s < kG; ++s)
-        if (s * kWave + lane0 < N * kGradStride) out[s * kWave + lane0] = G[s];
+        if (s * kWave + lane0 < N * kGradStride) out[s * kWave + lane0] = add ? (out[s * kWave + lane0] + G[s]) : G[s];
 }
 
+template <bool kHot>
 __global__ __launch_bounds__(kBlockThreads, 4) void render_backward_quad_kernel(
     FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
-    const float* __restrict__ distances, int num_distances, const float* __restrict__ grad_labels, float* __restrict__ partials) {
-    backward_rows_kernel_body<kRowLanes>(f, instances, c, origins, directions, distances, num_distances, grad_labels, partials);
+    const float* __restrict__ distances, int num_distances, const float* __restrict__ grad_labels, float* __restrict__ partials, unsigned char* __restrict__ redo_flags) {
+    backward_rows_kernel_body<kRowLanes, kHot>(f, instances, c, origins, directions, distances, num_distances, grad_labels, partials, redo_flags);
 }
+template <bool kHot>
 __global__ __launch_bounds__(kBlockThreads, 3) void render_backward_pair_kernel(
     FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
-    const float* __restrict__ distances, int num_distances, const float* __restrict__ grad_labels, float* __restrict__ partials) {
-    backward_rows_kernel_body<32>(f, instances, c, origins, directions, distances, num_distances, grad_labels, partials);
+    const float* __restrict__ distances, int num_distances, const float* __restrict__ grad_labels, float* __restrict__ partials, unsigned char* __restrict__ redo_flags) {
+    backward_rows_kernel_body<32, kHot>(f, instances, c, origins, directions, distances, num_distances, grad_labels, partials, redo_flags);
 }
 
 // Two rays per wave, 32 lanes each (kRoundsS = 2: S <= 64; 4: S <= 128).

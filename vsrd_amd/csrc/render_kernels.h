@@ -998,7 +998,9 @@ __device__ __forceinline__ unsigned residual_mode_bits(unsigned flags) { return 
 __device__ __forceinline__ int residual_weight_stride(unsigned flags) { return (flags & 2048u) ? kMlpImageWords : kMlpWeights; }
 
 // (four rounds -- S in (64, 128], the reference's own S = 100 -- hold twice the per-ray adjoint state and do not fit 256 registers)
-template <int kRounds>
+// kExport (round 6): the instantiation that writes the step's own samples out (vsrd_render_config::out_*; launched only when a caller asks for them,
+// two-round launches only: in the kernel every launch runs, the few extra live values cost 6-12 registers and, in the split-bf16 unit, spills)
+template <int kRounds, bool kExport = false>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(kRounds <= 2 ? 2 : 1, 2))) void residual_step_front_kernel(
     FieldArgs f, const float* __restrict__ instances, const float* __restrict__ mlp, RenderArgs c,
     const float* __restrict__ origins, const float* __restrict__ directions, const float* __restrict__ u_coarse, const float* __restrict__ u_fine,
@@ -1038,16 +1040,16 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(k
         const Ray r = load_ray_gathered(c, origins, directions, row);
         const float target = load_target(c, targets, row, lane, N);
         const RayCull rc = cull_ray_setup(instances, N, r.ox, r.oy, r.oz, r.rx, r.ry, r.rz, l.cull, lane);
-        stage_ray_samples<kRoundsS>(l, c, S, ray, u_coarse, u_fine, c.out_u_coarse, c.out_u_fine, sorted_input, lane);
+        stage_ray_samples<kRoundsS>(l, c, S, ray, u_coarse, u_fine, kExport ? c.out_u_coarse : nullptr, kExport ? c.out_u_fine : nullptr, sorted_input, lane);
         float w1[kRoundsS];
         render_pass<kRoundsS, false, true>(instances, mlp, N, sh, r, rc, l.coarse, S, l.dcache, w1, nullptr, nullptr);
-        if (c.out_coarse_weights != nullptr) {                             // vsrd_render_config::out_* (ABI 8: the residual step too): the step's own samples
+        if (kExport && c.out_coarse_weights != nullptr) {                  // vsrd_render_config::out_* (ABI 8: the residual step too): the step's own samples
 #pragma unroll
             for (int k = 0; k < kRoundsS; ++k)
                 if (k * kWave + lane < S - 1) c.out_coarse_weights[static_cast<size_t>(ray) * (S - 1) + k * kWave + lane] = w1[k];
         }
         importance_merge<kRoundsS>(l, S, w1);
-        if (c.out_distances != nullptr) {
+        if (kExport && c.out_distances != nullptr) {
             float* dst = c.out_distances + static_cast<size_t>(ray) * D;
             for (int idx = lane; idx < D; idx += kWave) dst[idx] = l.merged[idx];
         }

@@ -21,6 +21,7 @@ struct FrontLaunch {
     bool pair;                                             // residual_step_pair_kernel (a ray over two waves) or residual_step_front_kernel
     int rounds, blocks;
     size_t lds_bytes;
+    bool export_samples;                                   // vsrd_render_config::out_* set: the instantiation that writes the step's samples (two rounds only)
     int frames;                                            // frame batch (include/vsrd_hip.h, ABI 8): the grid's y extent; the stride travels in RenderArgs
 };
 

@@ -35,6 +35,7 @@ int launch_front(const FrontLaunch& a, hipStream_t stream) {
                   a.labels, a.box_partials, static_cast<float4*>(a.jets), a.loss_partials, a.seeds, a.masks, a.slots_per_instance, a.first, a.rays, a.accumulate
 #define VSRD_FRONT(K)                                                                                                                         \
     do {                                                                                                                                      \
+        if (a.export_samples) return kUnsupported;      /* (the two-round instantiation below writes them) */                                 \
         if (!opt_in(residual_step_front_kernel<K>, a.lds_bytes)) return kLdsRefused;                                                          \
         if (a.frames > 1) return kUnsupported;          /* (a batch's frames are launches of <= 2048 rays: the pair kernel) */                \
         hipLaunchKernelGGL(residual_step_front_kernel<K>, dim3(a.blocks), dim3(kBlockThreads), a.lds_bytes, stream, VSRD_ARGS);               \
@@ -55,6 +56,9 @@ int launch_front(const FrontLaunch& a, hipStream_t stream) {
             case 4: VSRD_PAIR(4); break;
             default: return kUnsupported;
         }
+    } else if (a.rounds == 2 && a.export_samples && a.frames <= 1) {
+        if (!opt_in(residual_step_front_kernel<2, true>, a.lds_bytes)) return kLdsRefused;
+        hipLaunchKernelGGL((residual_step_front_kernel<2, true>), dim3(a.blocks), dim3(kBlockThreads), a.lds_bytes, stream, VSRD_ARGS);
     } else {
         switch (a.rounds) {
             case 1: VSRD_FRONT(1); break;
