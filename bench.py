@@ -624,7 +624,7 @@ def extra_regimes():
               "mlp_products", "slot_setup_seconds", "graphs_per_slot", "frames_outside_slots", "frames_with_unhealthy_draws"]
     base = ["bench.py", "--no-cpu-baseline", "--no-extra-regimes"]
     tool = os.path.join("tools", "native_mode_bench.py")
-    return {
+    regimes = {
         "note": "measured after the headline's timed region, one child process each; config 2 above stays the metric's workload",
         "config3_full_size": child(base + ["--residual", "--steps", "3", "--warmup", "1"], dense),
         "config3_full_size_split_bf16": child(base + ["--residual", "--mlp-split-bf16", "--steps", "3", "--warmup", "1"], dense),
@@ -638,15 +638,15 @@ def extra_regimes():
         # checkpoints included (python bench.py --native = python -m vsrd_amd.launcher; on a node: --gpus 8).  Round 6: ONE rank process per GPU (RCCL
         # control plane) that steps a batch of frames together (optimization.FrameBatch; --frame-batch, default 16); the slots' set-up before the clock is
         # `slot_setup_seconds`
-        "native_frames_per_s": child(["bench.py", "--native", "--gpus", "1", "--frames", "32"], frames, timeout=1200),
         "native_frames_per_s_one_process": child(["bench.py", "--native", "--gpus", "1", "--procs-per-gpu", "1", "--frames", "32"], frames, timeout=1200),
-        "native_frames_per_s_one_process_batch8": child(["bench.py", "--native", "--gpus", "1", "--procs-per-gpu", "1", "--frame-batch", "8", "--frames", "24"], frames, timeout=1200),
         "native_frames_per_s_one_process_fp32_mlp": child(["bench.py", "--native", "--gpus", "1", "--procs-per-gpu", "1", "--frames", "32", "--fp32-mlp"], frames, timeout=1200),
-        # round 5's layouts, for comparison: two rank processes (gloo) with one frame each; one process with three frames in flight (threads, streams)
-        "native_frames_per_s_two_processes_r05": child(["bench.py", "--native", "--gpus", "1", "--procs-per-gpu", "2", "--frame-batch", "1", "--frames", "12"], frames, timeout=1200),
-        "native_frames_per_s_three_threads_r05": child(["bench.py", "--native", "--gpus", "1", "--procs-per-gpu", "1", "--frame-batch", "1", "--frames-in-flight", "3",
-                                                         "--frames", "12"], frames, timeout=1200),
+        # round 5's default layout, for comparison: two rank processes (gloo) with one frame each
+        "native_frames_per_s_two_processes_r05": child(["bench.py", "--native", "--gpus", "1", "--procs-per-gpu", "2", "--frame-batch", "1", "--queue", "static", "--frames", "12"],
+                                                       frames, timeout=1200),
     }
+    # (`python bench.py --native --gpus 1` IS the one-process layout since round 6: the key of rounds 4-5 stays, it is the same record)
+    regimes["native_frames_per_s"] = dict(regimes["native_frames_per_s_one_process"], note="the launcher's default layout: the record of native_frames_per_s_one_process")
+    return regimes
 
 
 def main():

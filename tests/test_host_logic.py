@@ -373,3 +373,60 @@ def test_to_host_rebuilds_containers_and_leaves_the_rest():
     assert out["step"] == 7 and out["name"] == "frame" and out["groups"] == [{"lr": 0.5, "params": (0, 1)}] and type(out["groups"][0]["params"]) is tuple
     w = out["models"]["m"]["w"]
     assert w.device.type == "cpu" and not w.requires_grad and torch.equal(w, torch.arange(4.0)) and w is not payload["models"]["m"]["w"]
+
+
+def test_frame_arena_rows_share_one_layout():
+    """optimization.FrameArena / FrameRow (frame batches, include/vsrd_hip.h ABI 8): every frame's copy of a buffer sits at the same offset of its
+    row, rows are `stride` bytes apart, offsets are 256-byte aligned, views keep dtype and shape and alias the arena, and a row that runs out
+    raises instead of walking into its neighbour."""
+    from vsrd_amd import optimization
+    arena = optimization.FrameArena(3, 10_000, "cpu")
+    assert arena.stride % 256 == 0 and arena.stride >= 10_000 and arena.buffer.shape == (3, arena.stride)
+    views = []
+    for row in arena.rows:
+        a = row.new((5, 3), torch.float32, fill=1.5)
+        b = row.new(7, torch.int64, fill=2)
+        c = row.new((), torch.float32, fill=0.25)
+        d = row.adopt(torch.arange(6, dtype=torch.uint8).reshape(2, 3))
+        views.append((a, b, c, d))
+        assert a.shape == (5, 3) and a.dtype == torch.float32 and b.dtype == torch.int64 and c.shape == () and float(c) == 0.25
+        assert torch.equal(d, torch.arange(6, dtype=torch.uint8).reshape(2, 3)) and all(t.is_contiguous() for t in (a, b, c, d))
+    assert arena.rows[0].layout == arena.rows[1].layout == arena.rows[2].layout
+    assert all(offset % 256 == 0 for offset, _ in arena.rows[0].layout)
+    for k in range(4):           # frame f's buffer is exactly f * stride bytes behind frame 0's
+        assert views[1][k].data_ptr() - views[0][k].data_ptr() == arena.stride and views[2][k].data_ptr() - views[0][k].data_ptr() == 2 * arena.stride
+    views[1][0].fill_(9.0)       # rows do not overlap
+    assert float(views[0][0].max()) == 1.5 and float(views[2][0].max()) == 1.5
+    with pytest.raises(RuntimeError, match="exhausted"):
+        arena.rows[0].new(10_000, torch.float32)
+
+
+def test_frame_batch_item_slots_and_row_size(lib):
+    """FrameBatch.item_slots: the MLP adjoint's work items grow with the batch (about 16384 items per launch); FrameBatch._row_bytes covers what a
+    frame of the reference's size allocates (1.4 GB: directions, soft masks, the sampling table, and 0.8 GB of render workspace -- it is sized so that
+    every form of the residual step fits, the one-kernel fallback's per-wave caches included)."""
+    from vsrd_amd import optimization
+    config = optimization.OptimizationConfig()
+    assert [optimization.FrameBatch.item_slots(b, config, 8) for b in (1, 2, 4, 8, 16, 64)] == [4, 4, 8, 16, 32, 32]
+    assert optimization.FrameBatch.item_slots(8, optimization.OptimizationConfig(num_samples=64), 16) == 16      # two rounds per ray, twice the instances
+    row = optimization.FrameBatch._row_bytes((17, 376, 1408, 8), config)
+    pixels = 17 * 376 * 1408
+    assert row > pixels * (12 + 32 + 4) + lib.vsrd_ray_table_bytes(pixels) + lib.vsrd_residual_step_workspace_bytes(8, 100, 1000) and row < 3 << 29
+
+
+def test_initial_draw_runs_on_one_thread_and_draws_the_same_values():
+    """optimization._InitialDraw: the host-side draw of a frame's initial parameters runs on ONE intra-op thread (256 host cores made it 100 ms) and
+    restores the count; the values do not depend on it."""
+    from vsrd_amd import models, optimization
+    before = torch.get_num_threads()
+
+    def draw():
+        torch.default_generator.manual_seed(7)
+        return [p.detach().clone() for p in models.HyperDistanceField(48, [16, 16, 16, 16], 256, [256, 256, 256, 256]).parameters()]
+
+    with optimization._initial_draw:
+        assert torch.get_num_threads() == 1
+        single = draw()
+    assert torch.get_num_threads() == before
+    for a, b in zip(single, draw()):
+        assert torch.equal(a, b)

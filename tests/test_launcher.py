@@ -373,6 +373,50 @@ def test_supervisor_ends_a_hung_attempt(tmp_path):
     assert sorted(f for f in os.listdir(tmp_path) if f.startswith("frame_")) == [f"frame_{k:06d}" for k in range(8)]
 
 
+@pytest.mark.gpu
+def test_native_frames_in_a_batch_match_the_same_frames_alone(tmp_path):
+    """The launcher's default layout since round 6 -- ONE rank process per GPU (RCCL control plane) stepping `--frame-batch` frames together
+    (optimization.FrameBatch) -- against frame slots with one frame per launch chain: ten frames (two full groups of four and a last group of
+    two, captured at start-up because the static queue knows its tail), every frame with its checkpoint, and the final loss of EVERY frame equal
+    to the last digit to the loss of the same frame optimised alone with the same work-item size of the MLP adjoint (the one number of the launch
+    geometry its sums depend on: vsrd_render_config::adjoint_slots_per_item).  Also: the line says what ran (frame_batch, control plane, queue,
+    MLP products, where the time went), and a second run skips everything."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    small = ["--frames", "10", "--views", "3", "--instances", "4", "--height", "128", "--width", "128", "--rays", "256", "--samples", "40", "--num-steps", "40",
+             "--warmup-steps", "12", "--adjoint-item-slots", "8"]
+    lines = {}
+    for batch in (4, 1):
+        command = [sys.executable, bench, "--native", "--gpus", "1", *small, "--frame-batch", str(batch), "--out", str(tmp_path / str(batch))]
+        out = subprocess.run(command, capture_output=True, text=True, timeout=900, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines[batch] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    line = lines[4]
+    assert line["n_gpus"] == 1 and line["ranks"] == 1 and line["procs_per_gpu"] == 1 and line["control_plane"] == "RCCL" and line["frame_batch"] == 4
+    assert line["frames"] == 10 and line["queue"].startswith("static") and line["mlp_products"].startswith("split bf16") and line["restarts"] == 0
+    assert line["graphs_per_slot"] == [8] and line["frames_outside_slots"] == [] and line["frames_with_unhealthy_draws"] == []      # both phases x {1, 4 steps} x {4, 2 frames}
+    phases = line["phase_seconds"][0]
+    assert phases["steps"] > 0 and phases["reset"] > 0 and abs(sum(phases.values()) - line["per_rank_seconds"][0]) < 0.5 * line["per_rank_seconds"][0] + 0.5
+    assert sorted(os.listdir(tmp_path / "4")) == [f"frame_{k:06d}" for k in range(10)]
+    assert set(line["final_loss_per_frame"]) == {str(k) for k in range(10)} == set(lines[1]["final_loss_per_frame"])
+    for frame, loss in line["final_loss_per_frame"].items():
+        assert math.isfinite(loss) and loss == lines[1]["final_loss_per_frame"][frame], (frame, loss, lines[1]["final_loss_per_frame"][frame])
+    payload = torch.load(os.path.join(tmp_path, "4", "frame_000007", "step_39.pt"), weights_only=False)
+    alone = torch.load(os.path.join(tmp_path, "1", "frame_000007", "step_39.pt"), weights_only=False)
+    for name, value in payload["models"]["detector"].items():
+        assert torch.equal(value, alone["models"]["detector"][name]), name
+    for name, value in payload["models"]["hyper_distance_field"].items():
+        assert torch.equal(value, alone["models"]["hyper_distance_field"][name]), name
+    again = subprocess.run([sys.executable, bench, "--native", "--gpus", "1", *small, "--frame-batch", "4", "--out", str(tmp_path / "4")],
+                           capture_output=True, text=True, timeout=900, env=env)
+    assert again.returncode == 0, again.stderr[-3000:]
+    second = json.loads([l for l in again.stdout.splitlines() if l.startswith("{")][-1])
+    assert second["frames"] == 0 and second["frames_skipped_as_done"] == 10
+
+
 def test_dynamic_queue_bounds_the_tail_of_eight_ranks_with_unequal_frames(tmp_path):
     """VERDICT r05 item 8 (vsrd/distributed/loader.py:4-9 hands every rank a fixed share; scripts/main.py:134-136 is the only guard): real
     frames differ in instance count and cost, and with the static split `frame j -> rank j mod world` the job ends when the unluckiest rank

@@ -85,6 +85,29 @@ def main():
                                   samples_per_ray=cfg.num_samples, views=V, instances=N, final_loss=losses[0], final_losses=losses, setup_seconds=setup,
                                   steps_per_graph=args.steps_per_graph, mlp_products="exact fp32 MFMA" if args.fp32_mlp else "split bf16 MFMA")))
         return
+    if args.batch > 0:
+        # B frames in lock-step, `--steps` steps of one phase at its first step's schedule (what the PMC passes profile: tools/pmc_quick.sh)
+        cfg = optimization.OptimizationConfig(seed=0, num_rays=args.rays, mlp_split_bf16=not args.fp32_mlp)
+        batch = optimization.FrameBatch([inputs] * args.batch, cfg, dev, init_seeds=list(range(args.batch)))
+        start = cfg.warmup_steps if args.residual else 0
+        for member in batch.frames:
+            member.step_index = start
+            member.step_tensor.fill_(start)
+        for _ in range(4):
+            batch.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        batch.run(args.steps, args.steps_per_graph)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"native mode ({'residual' if args.residual else 'box-only'} phase, hipGraph replay, batch of {args.batch} frames): {dt / args.steps * 1e3:.3f} ms per step of the batch = "
+              f"{dt / args.steps / args.batch * 1e3:.4f} ms per frame-step ({args.rays} rays x 100 samples per frame, V={V}, N={N})")
+        if args.json:
+            import json
+            print(json.dumps(dict(mode="native", phase="residual" if args.residual else "box-only", graph=True, frame_batch=args.batch, ms_per_step=dt / args.steps * 1e3,
+                                  ms_per_frame_step=dt / args.steps / args.batch * 1e3, rays_per_step=args.rays, samples_per_ray=100, views=V, instances=N,
+                                  steps_per_graph=args.steps_per_graph, mlp_products="exact fp32 MFMA" if args.fp32_mlp else "split bf16 MFMA")))
+        return
     if args.whole_frame:
         def frame(slot):
             loop = optimization.FrameOptimizer(inputs, optimization.OptimizationConfig(seed=slot, num_rays=args.rays, mlp_split_bf16=not args.fp32_mlp), dev, graph=args.graph)

@@ -33,7 +33,7 @@ def run(cmd, timeout):
 
 def main():
     parser = argparse.ArgumentParser()
-    parser.add_argument("--tag", default="r05")
+    parser.add_argument("--tag", default="r06")
     parser.add_argument("--quick", action="store_true", help="skip the two multi-second-per-step full-size runs (C3, C5)")
     args = parser.parse_args()
     out_dir = os.path.join(ROOT, "gpurun_out", args.tag)
@@ -52,8 +52,8 @@ def main():
     if not args.quick:
         dense += [("C3 full size (residual)", ["--steps", "2", "--warmup", "1", "--residual"]),
                   ("C3 full size (residual), MLP on split-bf16 MFMA", ["--steps", "2", "--warmup", "1", "--residual", "--mlp-split-bf16"]),
-                  ("C3 full size, start", ["--steps", "2", "--warmup", "1", "--residual", "--schedule", "start"]),
-                  ("C3 full size, end", ["--steps", "2", "--warmup", "1", "--residual", "--schedule", "end"]),
+                  ("C3 full size, start", ["--steps", "1", "--warmup", "1", "--residual", "--schedule", "start"]),
+                  ("C3 full size, end", ["--steps", "1", "--warmup", "1", "--residual", "--schedule", "end"]),
                   ("C5 on one GPU", ["--steps", "2", "--warmup", "1", "--views", "17", "--height", "752", "--width", "2816", "--instances", "64", "--samples", "128"])]
     table = {"dense": [], "native": []}
     for name, flags in dense:
@@ -65,7 +65,14 @@ def main():
               ("residual, hipGraph, exact-fp32 MLP", ["--residual", "--graph", "--fp32-mlp"]),
               ("whole frame (3000 steps, real schedules), hipGraph, exact-fp32 MLP", ["--graph", "--whole-frame", "--fp32-mlp"]),
               ("box-only, hipGraph, 2 frames at once", ["--graph", "--concurrent", "2"]), ("residual, hipGraph, 2 frames at once", ["--residual", "--graph", "--concurrent", "2"]),
-              ("whole frame (3000 steps, real schedules), hipGraph", ["--graph", "--whole-frame"])]
+              ("whole frame (3000 steps, real schedules), hipGraph", ["--graph", "--whole-frame"]),
+              # round 6: B frames per launch chain (optimization.FrameBatch); seconds_per_frame is per frame of the batch
+              ("whole frames in a batch of 2, hipGraph", ["--graph", "--whole-frame", "--batch", "2"]),
+              ("whole frames in a batch of 4, hipGraph", ["--graph", "--whole-frame", "--batch", "4"]),
+              ("whole frames in a batch of 8, hipGraph", ["--graph", "--whole-frame", "--batch", "8"]),
+              ("whole frames in a batch of 16, hipGraph", ["--graph", "--whole-frame", "--batch", "16"]),
+              ("whole frames in a batch of 16, hipGraph, exact-fp32 MLP", ["--graph", "--whole-frame", "--batch", "16", "--fp32-mlp"]),
+              ("whole frames in a batch of 32, hipGraph", ["--graph", "--whole-frame", "--batch", "32"])]
     for name, flags in native:
         record = run(["tools/native_mode_bench.py", "--json", "--steps", "300", *flags], 1800)
         record["regime"] = name

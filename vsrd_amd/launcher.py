@@ -221,7 +221,7 @@ def synthetic_frame_inputs(device, frame, views, instances, height=376, width=14
 def _newest_change(folder):
     """Modification time of the newest entry of the checkpoint directory: a frame's folder changes when its checkpoint is renamed into it."""
     try:
-        return max((entry.stat().st_mtime for entry in os.scandir(folder)), default=0.0)
+        return max([os.stat(folder).st_mtime, *(entry.stat().st_mtime for entry in os.scandir(folder))])      # (the folder itself: rank 0 touches it when its set-up is done)
     except OSError:
         return 0.0
 
@@ -573,7 +573,7 @@ def main(argv=None):
     parser.add_argument("--stall-timeout", type=float, default=0.0,
                         help="supervisor: seconds without anything new in the checkpoint directory after which the ranks are taken for hung, ended and "
                              "restarted like after a dead rank; 0 = never (the default).  The clock starts with the attempt and starts over when rank 0 "
-                             "has finished its set-up (a marker file) and with every checkpoint, so the value must exceed both the start-up (library "
+                             "has finished its set-up (it touches the directory) and with every checkpoint, so the value must exceed both the start-up (library "
                              "build, inputs, graph capture: tens of seconds) and the time of one group of --frame-batch frames")
     parser.add_argument("--attempt", type=int, default=0, help=argparse.SUPPRESS)          # set by the supervisor: restarts so far
     parser.add_argument("--selftest", action="store_true",
@@ -670,10 +670,9 @@ def _rank_main(args):
                             (": frames from the job's queue" if dynamic else f": frames {queue.mine}"), file=sys.stderr, flush=True))
     work = _SleepWork(args, manifest, rank, queue) if args.selftest else _RenderWork(args, manifest, device, queue)
     work.prepare()
-    if rank == 0:                            # the supervisor's stall clock starts at the first fence, not at process start
+    if rank == 0:                            # the supervisor's stall clock starts over at the first fence: the directory's own time stamp
         os.makedirs(manifest["out"], exist_ok=True)
-        with open(os.path.join(manifest["out"], f".prepared_attempt_{args.attempt}"), "w") as marker:
-            marker.write("every rank is about to reach the first fence\n")
+        os.utime(manifest["out"], None)
 
     def fence():
         barrier()
