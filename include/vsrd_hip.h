@@ -184,9 +184,11 @@ typedef struct vsrd_render_config {
 #define VSRD_FLAG_MLP_SPLIT_BF16 2048u      /* vsrd_render_residual_step (two-kernel form): the per-instance MLP's matrix products of the FRONT
                                              kernel (pass 1, pass 2: value and gradient of every residual) run on v_mfma_f32_16x16x32_bf16 with
                                              both operands split into two bfloat16 parts (x = hi + lo to 2^-18; fp32 accumulation) instead of the
-                                             exact-fp32 matrix instruction.  A/B switch (ABI 7): results agree with the default to ~2e-6 on the
-                                             silhouettes and ~1e-3 of the largest gradient entry (tests/split_bf16_emulation.py, the residual
-                                             goldens under both settings).  Other entry points ignore it.                                 */
+                                             exact-fp32 matrix instruction.  The C ABI's default is the exact-fp32 form; optimization.FrameOptimizer / FrameBatch
+                                             (the native loop) set the flag by default (OptimizationConfig.mlp_split_bf16).  Measured on the GPU under the
+                                             residual goldens' tests with both forms, against the reference's goldens: labels within 1.1e-6 (tolerance
+                                             1e-4), gradients within 4.2e-4 of the largest entry (tolerance 5e-3; exact fp32: 1.5e-4).  Other entry
+                                             points ignore it.                                                                          */
 
 int32_t vsrd_abi_version(void);
 const char* vsrd_error_string(int32_t code);

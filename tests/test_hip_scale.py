@@ -663,16 +663,16 @@ def test_config3_full_size_parity_against_the_oracle(dev, mlp_products):
     2.5 rays of 640 on top); and the HARD bounds on the determinate rays (`_stable_under_float32_noise`): every one within 2e-5 at fixed samples
     and within 1e-4 end to end.  Then (item 4c) the loss and the gradients -- boxes and the 16 MLPs' weights -- of vsrd_render_forward +
     vsrd_render_backward at the step's samples against the oracle's autograd on determinate rays.
-    768 rays by default (three quarters of them rays that see something); VSRD_PARITY_RAYS=4096 is the round's patient run
+    1024 rays by default (three quarters of them rays that see something); VSRD_PARITY_RAYS=4096 is the round's patient run
     (profiles/r06/parity_config3_4096_rays.log: 97 % of the rays determinate end to end, none beyond 1.2e-5; gradients 1.8e-6 ... 7.6e-5)."""
     import os
     import bench
     from oracle import fields as ofields, geometry as ogeometry, rendering as orendering
     from vsrd_amd import models, rendering
     N, S, V, H, W, seed = 16, 64, 9, 376, 1408, 3
-    # (round 6: 768 rays by default -- every ray costs the oracle ten passes of 190 points x 16 MLPs with tangents; the round's patient run,
+    # (round 6: 1024 rays by default -- every ray costs the oracle ten passes of 190 points x 16 MLPs with tangents; the round's patient run,
     #  VSRD_PARITY_RAYS=4096, 19 minutes on a 256-core box, is profiles/r06/parity_config3_4096_rays.log: no determinate ray beyond 1.2e-5)
-    budget = int(os.environ.get("VSRD_PARITY_RAYS", 768))
+    budget = int(os.environ.get("VSRD_PARITY_RAYS", 1024))
     noise_trials = 2 if budget >= 4096 else 1
     sched = bench.schedule_values(bench.SCHEDULES["mid"])
     T, std, ratio = sched["temperature"], sched["std"], sched["cosine_ratio"]
@@ -773,8 +773,11 @@ def test_config3_full_size_parity_against_the_oracle(dev, mlp_products):
     mine64 = (hip_labels.double() - whole64).abs().max(-1).values
     own = (whole32.double() - whole64).abs().max(-1).values
     hip_tail, hip_tail64, oracle_tail = (float((e > 1e-4).float().mean()) for e in (mine32, mine64, own))
-    margin(tag, "rays > 1e-4: HIP vs f32 oracle", hip_tail, oracle_tail + 1e-3)
-    margin(tag, "rays > 1e-4: HIP vs f64 oracle", hip_tail64, oracle_tail + 1e-3)
+    # (a SHARE of 1e-3 needs a few thousand rays to mean anything: with the default 1024 one ray is 1e-3 -- a single non-determinate ray beyond 1e-4
+    #  is allowed there; the 4096-ray run holds the plain oracle's-own + 1e-3: 4.9e-4 against 4.9e-4 + 1e-3)
+    slack = max(1e-3, 1.5 / selection.numel())
+    margin(tag, "rays > 1e-4: HIP vs f32 oracle", hip_tail, oracle_tail + slack)
+    margin(tag, "rays > 1e-4: HIP vs f64 oracle", hip_tail64, oracle_tail + slack)
     margin(tag, "rays > 1e-4: f32 vs f64 oracle", oracle_tail, 1.0)
     margin(tag, "rays > 1e-5: HIP vs f32 oracle", float((mine32 > 1e-5).float().mean()), 1.0)
     margin(tag, "rays > 1e-5: f32 vs f64 oracle", float((own > 1e-5).float().mean()), 1.0)
@@ -792,8 +795,8 @@ def test_config3_full_size_parity_against_the_oracle(dev, mlp_products):
     print(f"{tag}: {selection.numel()} rays; > 1e-4 end to end: HIP vs f32 oracle {hip_tail:.2e}, f32 vs f64 oracle {oracle_tail:.2e}, HIP vs f64 oracle {hip_tail64:.2e}; "
           f"median {float(mine32.median()):.2e}, worst {float(mine32.max()):.2e} (oracle's own {float(own.max()):.2e})")
     assert not failures, failures
-    # (round 5 allowed 2.5 rays of 640 here; with 4096 rays the share is a share: the float32 oracle's own + 1e-3)
-    assert hip_tail <= oracle_tail + 1e-3 and hip_tail64 <= oracle_tail + 1e-3
+    # (round 5 allowed 2.5 rays of 640 here; now: the float32 oracle's own share + 1e-3, or ONE ray where the selection is too small for 1e-3 to be one)
+    assert hip_tail <= oracle_tail + slack and hip_tail64 <= oracle_tail + slack
     assert float(mine32.median()) < 1e-5
     assert float(determinate_whole.float().mean()) > 0.75 and float(mine32[determinate_whole].max()) <= 1e-4
     # ---- loss and gradients (boxes AND the MLPs' weights) at the step's own samples, on a subset the oracle's double backward

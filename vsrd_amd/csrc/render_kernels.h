@@ -604,10 +604,17 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
             ad0 -= qbx; ad1 -= qby; ad2 -= qbz;
             if (kResidual) {        // seeds of the residual adjoint (main.py:451-458): value adjoint d_bar, local-gradient adjoint gl_bar;
                 // left for the MLP adjoint with the points that matter gathered into the leading columns (residual.h: packed_column)
-                float* dst = sink.seeds + k * sink.round_stride + i * sink.instance_stride + packed_column(need, lane, counts[k]);
-                dst[0 * kWave] = e.px; dst[1 * kWave] = e.py; dst[2 * kWave] = e.pz; dst[3 * kWave] = d_bar;
-                dst[4 * kWave] = glbx; dst[5 * kWave] = glby; dst[6 * kWave] = glbz;
-                dst[7 * kWave] = e.relx; dst[8 * kWave] = e.rely; dst[9 * kWave] = e.relz;
+                const int column = packed_column(need, lane, counts[k]);
+                float* dst = sink.seeds + k * sink.round_stride + i * sink.instance_stride + column;
+                // Round 6: the launch-wide table's readers (residual_mlp_adjoint_kernel: the points of an item's slots as ONE stream) take the
+                // leading counts[k] columns of a slot and nothing else, so the other lanes' seeds -- three quarters of the 285 GB per config-3
+                // step that made the step's HBM traffic 28x its API-faithful bytes -- are not written.  (The wave-private batches of the
+                // one-kernel forms are read tile by tile: every lane writes there.)
+                if (sink.masks8 == nullptr || column < counts[k]) {
+                    dst[0 * kWave] = e.px; dst[1 * kWave] = e.py; dst[2 * kWave] = e.pz; dst[3 * kWave] = d_bar;
+                    dst[4 * kWave] = glbx; dst[5 * kWave] = glby; dst[6 * kWave] = glbz;
+                    dst[7 * kWave] = e.relx; dst[8 * kWave] = e.rely; dst[9 * kWave] = e.relz;
+                }
             }
             r00 += e.relx * pbx + gwbx * e.glx; r01 += e.relx * pby + gwbx * e.gly; r02 += e.relx * pbz + gwbx * e.glz;
             r10 += e.rely * pbx + gwby * e.glx; r11 += e.rely * pby + gwby * e.gly; r12 += e.rely * pbz + gwby * e.glz;
