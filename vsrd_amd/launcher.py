@@ -354,10 +354,11 @@ class _RenderWork:
                 founders += [founders[-1]] * (args.frame_batch - len(founders))           # (fewer frames than rows: the shape is what matters)
                 try:
                     self.batch = optimization.FrameBatch(founders, self.optimization_config(), self.device)
+                    self.unsuitable_founders += [int(candidates[min(f, len(candidates) - 1)]) for f in self.batch.unsuitable_founders]
                     tail = len(mine) % args.frame_batch if mine else 0                   # a static queue's last group is known now: capture it too
                     self.graphs_per_slot = self.batch.capture_all(actives=sorted({args.frame_batch, tail} - {0}, reverse=True))
-                except optimization.UnsuitableFrameError:
-                    self.batch = None                                                     # (every frame then runs in a loop of its own)
+                except optimization.UnsuitableFrameError:                                 # (not one of the founders suits the table sampler)
+                    self.batch = None                                                     # every frame then runs in a loop of its own
                     self.unsuitable_founders += [int(f) for f in candidates[:args.frame_batch]]
             else:
                 for _ in range(min(args.frames_in_flight, len(candidates))):

@@ -1067,10 +1067,29 @@ class FrameBatch:
             self.device = torch.device("cuda", torch.cuda.current_device())
         with _capture_lock:
             self.arena = FrameArena(self.size, self._row_bytes(shape, config), self.device)
-        self.frames = []
-        for f, frame_inputs in enumerate(inputs):
+        # A row is FOUNDED on a frame that suits the table sampler its graphs will draw from (the frames a row later serves come through reset(),
+        # which says so when one does not suit).  A founder that does not suit is replaced by the first one that does -- the shape is what a
+        # row needs from its founder -- and listed in `unsuitable_founders`; no suitable founder at all: UnsuitableFrameError.
+        self.frames, self.unsuitable_founders = [], []
+        stand_in = None
+        for f in range(self.size):
             cfg = config if init_seeds is None else dataclasses.replace(config, init_seed=init_seeds[f])
-            self.frames.append(FrameOptimizer(frame_inputs, cfg, self.device, graph=True, persistent=True, row=self.arena.rows[f]))
+            row = self.arena.rows[f]
+            candidates = [inputs[f]] + ([stand_in] if stand_in is not None else inputs[f + 1:])
+            for position, frame_inputs in enumerate(candidates):
+                row.cursor, row.layout = 0, []                           # (a founder that failed had begun to fill the row)
+                try:
+                    member = FrameOptimizer(frame_inputs, cfg, self.device, graph=True, persistent=True, row=row)
+                except UnsuitableFrameError:
+                    if position == 0:
+                        self.unsuitable_founders.append(f)
+                    if position + 1 == len(candidates):
+                        raise
+                    continue
+                if stand_in is None:
+                    stand_in = frame_inputs
+                self.frames.append(member)
+                break
         lead = self.arena.rows[0].layout
         for row in self.arena.rows[1:]:
             if row.layout != lead:
