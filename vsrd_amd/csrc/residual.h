@@ -577,12 +577,27 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
     return r;
 }
 // {hi(x0, x1), hi(x2, x3), lo(x0, x1), lo(x2, x3)}
+#ifdef VSRD_SPLIT_TRUNCATE
+// Experiment (round 6, VERDICT r05 item 3 "cut the VALU count"; profiles/r06_c3_bf16/variants.txt): both parts TRUNCATED to bfloat16 -- the high
+// half-words picked by v_perm_b32, no v_cvt_pk_bf16_f32 (a double-rate instruction: 5.6 cycles against 2.9, profiles/r05/split_rates.txt): six
+// full-rate instructions per pair of values instead of two conversions + four; |x - hi - lo| <= 2^-16 |x| instead of 2^-18.  Measured: +2.9 % on
+// config 3, +3.0 % on the batched native residual step, goldens inside their tolerances -- NOT the default: four times the product error for 3 %.
+__device__ __forceinline__ unsigned pack_high_halves(float lo, float hi) {        // {bits 31..16 of lo, bits 31..16 of hi} as one word, lo in the low half
+    return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+__device__ __forceinline__ u32x4 split4(float x0, float x1, float x2, float x3) {
+    const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u), r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+    const float r2 = x2 - __uint_as_float(__float_as_uint(x2) & 0xffff0000u), r3 = x3 - __uint_as_float(__float_as_uint(x3) & 0xffff0000u);
+    return u32x4{pack_high_halves(x0, x1), pack_high_halves(x2, x3), pack_high_halves(r0, r1), pack_high_halves(r2, r3)};
+}
+#else
 __device__ __forceinline__ u32x4 split4(float x0, float x1, float x2, float x3) {
     const unsigned h01 = cvt_pk_bf16(x0, x1), h23 = cvt_pk_bf16(x2, x3);
     const float r0 = x0 - __uint_as_float(h01 << 16), r1 = x1 - __uint_as_float(h01 & 0xffff0000u);
     const float r2 = x2 - __uint_as_float(h23 << 16), r3 = x3 - __uint_as_float(h23 & 0xffff0000u);
     return u32x4{h01, h23, cvt_pk_bf16(r0, r1), cvt_pk_bf16(r2, r3)};
 }
+#endif
 __device__ __forceinline__ u32x4 split4(f32x4 x) { return split4(x[0], x[1], x[2], x[3]); }
 __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -1036,7 +1051,11 @@ __device__ __forceinline__ f32x4 mfma_outer(const SplitPair& x, const SplitPair&
     acc = mfma_bf16(x.hi, y.hi, acc);
     acc = mfma_bf16(x.hi, y.lo, acc);
     acc = mfma_bf16(x.lo, y.hi, acc);
+#ifdef VSRD_SPLIT_OUTER_3        // experiment (round 6, profiles/r06_c3_bf16/variants.txt): without the lo.lo partial product (2^-16 of the term)
+    return acc;
+#else
     return mfma_bf16(x.lo, y.lo, acc);
+#endif
 }
 
 __device__ __forceinline__ ResidualAdjoint mlp_adjoint_points_split(MlpAdjoint& s, const SplitWeights& wt, float px, float py, float pz, float res_bar,
