@@ -301,3 +301,38 @@ def test_g16_rendering_helpers():
     colors = rendering.phong_shading(**{k[len("phong__"):]: v for k, v in g.items() if k.startswith("phong__")})
     torch.testing.assert_close(colors, g["colors"], rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(rendering.sdfs.norm(g["vectors"], dim=-1, keepdim=True), g["norms"], rtol=1e-7, atol=0)
+
+
+def test_diou_terms_against_an_independent_box_iou():
+    """torchvision 0.14 (distance_box_iou, distance_box_iou_loss: scripts/main.py:359-362, 375, 393) is not in the image, so the oracle's DIoU has
+    no reference output to be pinned by ("DIoU unpinned").  What CAN be cross-checked here: `transformers` ships DETR's
+    box_iou / generalized_box_iou, themselves taken from torchvision.ops.boxes -- an independent implementation of two of the three terms.  On
+    random boxes (overlapping, disjoint, nested, touching):  oracle DIoU + rho^2 / c^2  ==  transformers' IoU,  and the enclosing box whose
+    squared diagonal c^2 the oracle divides by has the area that generalized_box_iou's  IoU - (area_c - union) / area_c  implies.  The centre
+    distance rho^2 is the one term left to the hand cases above (test_diou_hand_cases)."""
+    import pytest
+    loss_module = pytest.importorskip("transformers.loss.loss_for_object_detection")
+    from oracle import geometry
+    g = torch.Generator().manual_seed(0)
+    lo = torch.rand(64, 2, generator=g, dtype=torch.float64) * 100.0
+    a = torch.cat([lo, lo + torch.rand(64, 2, generator=g, dtype=torch.float64) * 60.0 + 1.0], -1)
+    lo = torch.rand(48, 2, generator=g, dtype=torch.float64) * 100.0
+    b = torch.cat([lo, lo + torch.rand(48, 2, generator=g, dtype=torch.float64) * 60.0 + 1.0], -1)
+    b[0] = a[0]                                                        # identical
+    b[1] = torch.tensor([a[1, 0] + 1.0, a[1, 1] + 1.0, a[1, 2] - 1.0, a[1, 3] - 1.0]) if float((a[1, 2:] - a[1, :2]).min()) > 3 else b[1]     # nested
+    b[2] = torch.tensor([a[2, 2], a[2, 1], a[2, 2] + 10.0, a[2, 3]])  # touching along an edge
+    b[3] = a[3] + 500.0                                                # far apart
+    iou, union = loss_module.box_iou(a, b)
+    x1, y1, x2, y2 = (c[:, None] for c in a.unbind(-1))
+    x1g, y1g, x2g, y2g = (c[None, :] for c in b.unbind(-1))
+    centre = ((x1 + x2) / 2 - (x1g + x2g) / 2) ** 2 + ((y1 + y2) / 2 - (y1g + y2g) / 2) ** 2
+    width, height = torch.max(x2, x2g) - torch.min(x1, x1g), torch.max(y2, y2g) - torch.min(y1, y1g)
+    diou = geometry.distance_box_iou(a, b)
+    torch.testing.assert_close(diou + centre / (width ** 2 + height ** 2 + 1.0e-7), iou, rtol=1e-12, atol=1e-12)
+    giou = loss_module.generalized_box_iou(a, b)
+    torch.testing.assert_close(iou - (width * height - union) / (width * height), giou, rtol=1e-12, atol=1e-12)       # the same enclosing box
+    assert float(diou[0, 0]) == pytest.approx(1.0, abs=1e-9) and float(diou[3, 3]) < -0.5
+    # the element-wise loss form on matched pairs: 1 - DIoU of the pair (its IoU carries eps in the denominator: 1e-7 / union)
+    pairs = min(a.shape[0], b.shape[0])
+    loss = geometry.distance_box_iou_loss(a[:pairs], b[:pairs])
+    torch.testing.assert_close(loss, 1.0 - torch.diagonal(diou)[:pairs], rtol=1e-7, atol=1e-7)
