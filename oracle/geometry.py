@@ -8,8 +8,10 @@ Restates
   * torchvision==0.14.0 ``ops.distance_box_iou`` / ``distance_box_iou_loss`` /
     ``clip_boxes_to_image`` (called at ``scripts/main.py:359,375,393``).  torchvision is NOT
     in the build image: these three follow the published DIoU definition
-    (IoU - rho^2(centres)/c^2(enclosing diagonal), eps 1e-7) -- PARITY UNPINNED, checked
-    against hand-computed cases only.
+    (IoU - rho^2(centres)/c^2(enclosing diagonal), eps 1e-7) -- PARITY UNPINNED (no torchvision
+    output exists to pin them): checked against hand-computed cases, and (round 6) the IoU term and
+    the enclosing box against ``transformers``' DETR ``box_iou`` / ``generalized_box_iou`` -- taken
+    from torchvision.ops.boxes -- in tests/test_oracle_golden.py.
 """
 import torch
 import torch.nn.functional as F
