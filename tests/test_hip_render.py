@@ -1033,6 +1033,54 @@ def test_quad_step_matches_wave_per_ray(dev, N, S, R, case):
     assert max(bce_fixed_errors) <= bce_fixed_tolerance, bce_fixed_errors
 
 
+@pytest.mark.parametrize("N,S,R", [(16, 64, 203), (12, 48, 130), (40, 128, 37), (20, 100, 51)])
+def test_two_launch_rows_kernels_redo_the_groups_the_hot_kernel_marks(dev, N, S, R):
+    """Round 6: vsrd_render_hierarchical_forward and vsrd_render_backward on box-only fields are two kernels on one
+    grid each, like the fused step -- a hot kernel (rotations about y, fixed soft-min shift; instantiated for a full shape at S = 64 / 128
+    with more than half of the instance slots used) and a second one for what it could not serve.  The forward has no scratch: the hot
+    kernel marks such a group with NaN in its first label, the second kernel finds the mark and writes the group's real labels.  Here
+    every third ray looks away from the scene WITHOUT the exact-miss skip: its fine samples are extrapolated to 1e6 m (samplers.py:33),
+    the fixed shift cannot serve its group, and both launches take the redo path for a third of their groups -- labels finite and equal
+    to one ray per wave to the mappings' tolerance, the adjoint at the saved distances within 2e-4 of one ray per wave."""
+    from vsrd_amd import fields, rendering
+    from vsrd_amd.rendering import renderers
+    T, std, ratio = 0.4, 0.4, 0.4
+    sc = _random_scene(500 + N + S, N, R, S, general_rotations=False)
+    directions = sc["directions"].clone()
+    directions[::3] = torch.nn.functional.normalize(torch.tensor([[0.3, -0.9, -0.4]]), dim=-1)
+    uni = dict(u_coarse=sc["u_coarse"].to(dev), u_fine=sc["u_fine"].to(dev))
+    lam = torch.randn(R, N, generator=torch.Generator().manual_seed(N)).to(dev)
+    results = {}
+    for mode in ("rows", "wave"):
+        renderers.STEP_WAVE_PER_RAY = mode == "wave"
+        try:
+            inst = fields.pack_instances(sc["loc"], sc["rot"], sc["dim"]).to(dev).requires_grad_(True)
+            out = rendering.render_hierarchical(fields.FieldBlock(inst, T, None, None), sc["origins"].to(dev), directions.to(dev), (0.0, 100.0), S, std, ratio,
+                                                skip_exact_misses=False, **uni)
+            results[mode] = (out, inst, torch.autograd.grad(out["labels"], inst, grad_outputs=lam, retain_graph=True)[0])
+        finally:
+            renderers.STEP_WAVE_PER_RAY = False
+    rows, wave = results["rows"], results["wave"]
+    assert torch.isfinite(rows[0]["labels"]).all() and torch.isfinite(rows[0]["distances"]).all() and torch.isfinite(rows[2]).all()
+    assert float(rows[0]["distances"][::3].max()) > 1.0e4                                   # the rays that look away WERE extrapolated
+    assert float(rows[0]["labels"][::3].abs().max()) < 1e-6 and float(wave[0]["labels"].max()) > 0.05
+    tag = f"test_two_launch_rows_kernels_redo_the_groups_the_hot_kernel_marks[{N}-{S}-{R}]"
+    label_error = float((rows[0]["labels"] - wave[0]["labels"]).abs().max())
+    margin(tag, "labels vs one ray per wave", label_error, 1e-3)
+    assert label_error < 1e-3
+    # the adjoint of either mapping at the SAME saved distances (the rows mapping's), same label adjoints
+    fixed = {}
+    for mode in ("rows", "wave"):
+        renderers.STEP_WAVE_PER_RAY = mode == "wave"
+        try:
+            fixed[mode] = torch.autograd.grad(rows[0]["labels"], rows[1], grad_outputs=lam, retain_graph=True)[0]
+        finally:
+            renderers.STEP_WAVE_PER_RAY = False
+    error = float((fixed["rows"] - fixed["wave"]).abs().max()) / max(float(fixed["wave"].abs().max()), 1e-12)
+    margin(tag, "gradients at the same distances vs one ray per wave", error, 2e-4)
+    assert error <= 2e-4
+
+
 @pytest.mark.parametrize("N,S,R", [(8, 32, 203), (16, 64, 64), (40, 100, 37)])
 def test_dense_step_honours_the_target_column_map(dev, N, S, R):
     """include/vsrd_hip.h: vsrd_render_config.target_columns is a column map of the TARGETS, independent of ray_indices.  A dense launch

@@ -460,7 +460,10 @@ int32_t vsrd_render_backward(const vsrd_field* field, const vsrd_render_config* 
         num_distances <= 2 * kPairMaxSamples) {
         const bool quad = N <= kQuadMaxInstances && num_distances <= 2 * kQuadMaxSamples;
         const int lanes = quad ? kRowLanes : 32, rays_per_wave = kWave / lanes, half = (num_distances + 1) / 2;
-        if (!plan((config->num_rays + rays_per_wave - 1) / rays_per_wave, static_cast<size_t>(quad_lds_floats(half, N, lanes)), &g)) return VSRD_E_UNSUPPORTED;
+        const int shape_instances = quad ? kQuadMaxInstances : kPairMaxInstances;
+        const bool full = num_distances == 8 * lanes && 2 * N > shape_instances && !switches().no_full_shape;      // (2 S = 8 x lanes: BASELINE configs 2 and 5)
+        if (!plan((config->num_rays + rays_per_wave - 1) / rays_per_wave, static_cast<size_t>(quad_lds_floats(half, full ? shape_instances : N, lanes)), &g))
+            return VSRD_E_UNSUPPORTED;
         const FieldArgs f = field_args(field);
         RenderArgs c = render_args(config);
         c.sh.inv_t = f.inv_t;
@@ -474,13 +477,13 @@ int32_t vsrd_render_backward(const vsrd_field* field, const vsrd_render_config* 
         if (g.blocks * waves_per_block > max_waves) g.blocks = max_waves / waves_per_block;
         unsigned char* redo_flags = reinterpret_cast<unsigned char*>(partials + static_cast<size_t>(g.blocks) * waves_per_block * row);
         if (hipMemsetAsync(redo_flags, 0, 16, s) != hipSuccess) return VSRD_E_LAUNCH;
-#define VSRD_LAUNCH_BACKWARD_ROWS(KERNEL)                                                                                                 \
-        hipLaunchKernelGGL(KERNEL<true>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins, directions,   \
+#define VSRD_LAUNCH_BACKWARD_ROWS(KERNEL, FULL)                                                                                           \
+        hipLaunchKernelGGL((KERNEL<true, FULL>), dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins, directions,   \
                            distances, num_distances, grad_labels, partials, redo_flags);                                                \
-        hipLaunchKernelGGL(KERNEL<false>, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins, directions,  \
+        hipLaunchKernelGGL((KERNEL<false, false>), dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins, directions, \
                            distances, num_distances, grad_labels, partials, redo_flags)
-        if (quad) { VSRD_LAUNCH_BACKWARD_ROWS(render_backward_quad_kernel); }
-        else { VSRD_LAUNCH_BACKWARD_ROWS(render_backward_pair_kernel); }
+        if (quad) { if (full) { VSRD_LAUNCH_BACKWARD_ROWS(render_backward_quad_kernel, true); } else { VSRD_LAUNCH_BACKWARD_ROWS(render_backward_quad_kernel, false); } }
+        else { if (full) { VSRD_LAUNCH_BACKWARD_ROWS(render_backward_pair_kernel, true); } else { VSRD_LAUNCH_BACKWARD_ROWS(render_backward_pair_kernel, false); } }
 #undef VSRD_LAUNCH_BACKWARD_ROWS
         if (launch_status() != VSRD_OK) return VSRD_E_LAUNCH;
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(row), dim3(256), 0, s, partials, g.blocks * (g.threads / kWave), row, grad_instances);
@@ -551,12 +554,20 @@ int32_t vsrd_render_hierarchical_forward(const vsrd_field* field, const vsrd_ren
         S <= kPairMaxSamples && field->num_instances <= kPairMaxInstances) {
         const bool quad = S <= kQuadMaxSamples && field->num_instances <= kQuadMaxInstances;
         const int lanes = quad ? kRowLanes : 32, rays_per_wave = kWave / lanes;
-        if (!plan((config->num_rays + rays_per_wave - 1) / rays_per_wave, static_cast<size_t>(quad_lds_floats(S, field->num_instances, lanes)), &g))
+        // two kernels on one grid, the hot one instantiated for a full shape (quad_step.h: hierarchical_rows_kernel_body), as in vsrd_render_silhouette_step
+        const int shape_instances = quad ? kQuadMaxInstances : kPairMaxInstances;
+        const bool full = S == 4 * lanes && 2 * field->num_instances > shape_instances && !switches().no_full_shape;
+        if (!plan((config->num_rays + rays_per_wave - 1) / rays_per_wave,
+                  static_cast<size_t>(quad_lds_floats(S, full ? shape_instances : field->num_instances, lanes)), &g))
             return VSRD_E_UNSUPPORTED;
-        if (quad) hipLaunchKernelGGL(render_hierarchical_quad_kernel, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins,
-                                     directions, u_coarse, u_fine, labels, distances, coarse_weights, u_coarse_out, u_fine_out);
-        else hipLaunchKernelGGL(render_hierarchical_pair_kernel, dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins,
-                                directions, u_coarse, u_fine, labels, distances, coarse_weights, u_coarse_out, u_fine_out);
+#define VSRD_LAUNCH_FORWARD_ROWS(KERNEL, FULL)                                                                                            \
+        hipLaunchKernelGGL((KERNEL<true, FULL>), dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins,         \
+                           directions, u_coarse, u_fine, labels, distances, coarse_weights, u_coarse_out, u_fine_out);                   \
+        hipLaunchKernelGGL((KERNEL<false, false>), dim3(g.blocks), dim3(g.threads), g.lds_bytes, s, f, field->instances, c, origins,       \
+                           directions, u_coarse, u_fine, labels, distances, coarse_weights, u_coarse_out, u_fine_out)
+        if (quad) { if (full) { VSRD_LAUNCH_FORWARD_ROWS(render_hierarchical_quad_kernel, true); } else { VSRD_LAUNCH_FORWARD_ROWS(render_hierarchical_quad_kernel, false); } }
+        else { if (full) { VSRD_LAUNCH_FORWARD_ROWS(render_hierarchical_pair_kernel, true); } else { VSRD_LAUNCH_FORWARD_ROWS(render_hierarchical_pair_kernel, false); } }
+#undef VSRD_LAUNCH_FORWARD_ROWS
         return launch_status();
     }
     if (!plan(config->num_rays, static_cast<size_t>(hierarchical_lds_floats(S, field->num_instances, residual)), &g)) return VSRD_E_UNSUPPORTED;

@@ -1108,7 +1108,7 @@ __global__ __launch_bounds__(kBlockThreads, VSRD_QUAD_WAVES_PER_EU) void render_
 // NaN sentinel render_backward_kernel looks for).  Launches that also want the per-sample gradients / weights or the uniforms back keep
 // the one-ray kernel (render_hierarchical_kernel).
 template <int kL, int kRoundsS, bool kYaw, bool kRunning>
-__device__ __forceinline__ bool rows_forward_body(const float* __restrict__ instances, int N, const RenderArgs& c, const Shading& sh, int first_ray,
+__device__ __forceinline__ bool rows_forward_body(const float* __restrict__ instances, int N, int NP, const RenderArgs& c, const Shading& sh, int first_ray,
                                                   const float* __restrict__ origins, const float* __restrict__ directions,
                                                   const float* __restrict__ u_coarse, const float* __restrict__ u_fine, bool sorted_input,
                                                   float* __restrict__ labels_out, float* __restrict__ distances_out, float* __restrict__ coarse_weights_out,
@@ -1122,17 +1122,18 @@ __device__ __forceinline__ bool rows_forward_body(const float* __restrict__ inst
     const bool alive = my_ray < c.num_rays;
     const int ray = alive ? my_ray : (c.num_rays - 1);
     float* rowbase = stage + rl.row * quad_row_floats(S, kL);
-    float* coef_own = coefs + rl.row * quad_coef_floats(N);
+    float* coef_own = coefs + rl.row * quad_coef_floats(NP);
+    const unsigned long long real = NP > N ? ((1ull << N) - 1ull) : ~0ull;            // (NP > N: the full-shape instantiation's padded instance tables, quad_step_body)
     {
         const float* o = origins + static_cast<size_t>(ray) * c.origin_stride;
         const float* d = directions + static_cast<size_t>(ray) * 3;
         Ray r;
         r.ox = o[0]; r.oy = o[1]; r.oz = o[2]; r.rx = d[0]; r.ry = d[1]; r.rz = d[2];
-        quad_ray_setup<kL>(instances, N, N, r, coef_own, rays + rl.row * kRowRayFloats, rl);
+        quad_ray_setup<kL>(instances, N, NP, r, coef_own, rays + rl.row * kRowRayFloats, rl);
     }
     quad_stage_samples<kL, kRoundsS>(rowbase, c, S, ray, u_coarse, u_fine, sorted_input, rl, u_coarse_out, u_fine_out, alive);
     float w1[kRoundsS];
-    if (!quad_pass_one<kL, kRoundsS, kYaw, kRunning>(instances, N, sh, rays + rl.row * kRowRayFloats, coef_own, rowbase, S, w1, rl)) return false;
+    if (!quad_pass_one<kL, kRoundsS, kYaw, kRunning>(instances, NP, sh, rays + rl.row * kRowRayFloats, coef_own, rowbase, S, w1, rl, real)) return false;
     if (coarse_weights_out != nullptr && alive) {            // pass 1's compositing weights: what pass 1 of main.py:511-523 hands to pass 2
 #pragma unroll
         for (int k = 0; k < kRoundsS; ++k)
@@ -1152,9 +1153,9 @@ __device__ __forceinline__ bool rows_forward_body(const float* __restrict__ inst
         QuadAdjoint<kRounds> st;
         const int data_row = live ? rl.row : (__builtin_ctzll(live_lanes) / kL);
         quad_importance_merge<kL, kRoundsS>(rowbase, S, w1, rl);
-        if (!quad_forward_sweep<kL, kRounds, kYaw, kRunning>(st, instances, N, sh, rays + data_row * kRowRayFloats, coefs + data_row * quad_coef_floats(N),
+        if (!quad_forward_sweep<kL, kRounds, kYaw, kRunning>(st, instances, NP, sh, rays + data_row * kRowRayFloats, coefs + data_row * quad_coef_floats(NP),
                                                               stage + data_row * quad_row_floats(S, kL) + quad_merged_offset(S, kL), num_points, live, dcache,
-                                                              rowbase, label, active, cached_round, rl)) return false;
+                                                              rowbase, label, active, cached_round, rl, real)) return false;
     }
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) {
@@ -1173,58 +1174,86 @@ __device__ __forceinline__ bool rows_forward_body(const float* __restrict__ inst
     return true;
 }
 
-template <int kL, int kRoundsS>
+// Round 6: the two-launch path's forward is TWO kernels on one grid as well, and the hot one is instantiated for a full
+// shape like the fused step's (kFull: S and the instance count compile-time constants).  The forward has no scratch to keep flags in (the C
+// ABI gives vsrd_render_hierarchical_forward none), so a group the hot body cannot serve is marked IN ITS OUTPUT: NaN in the first label of
+// its first ray, which the second kernel looks for (one scalar load per group) and overwrites with the group's real labels.
+template <int kL, int kRoundsS, bool kHot, bool kFull>
 __device__ __forceinline__ void hierarchical_rows_kernel_body(
     FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
     const float* __restrict__ u_coarse, const float* __restrict__ u_fine, float* __restrict__ labels_out, float* __restrict__ distances_out,
     float* __restrict__ coarse_weights_out, float* __restrict__ u_coarse_out, float* __restrict__ u_fine_out) {
     constexpr int kRays = kWave / kL;
+    static_assert(kHot || !kFull, "only the hot kernel is instantiated for a full shape");
     apply_device_schedule(f, c);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = wave_in_block();
+    if (kFull) c.num_samples = kL * kRoundsS;                                   // (the host launches kFull for exactly this S)
     const int S = c.num_samples;
     const int N = f.num_instances;
-    float* stage = lds + wave * quad_lds_floats(S, N, kL);
+    const int NP = kFull ? (kL == kRowLanes ? kQuadMaxInstances : kPairMaxInstances) : N;      // rows of the instance tables
+    float* stage = lds + wave * quad_lds_floats(S, NP, kL);
     float* dcache = stage + kRays * quad_row_floats(S, kL);
-    float* coefs = dcache + quad_cache_floats(S, N, kL);
-    float* rays = coefs + kRays * quad_coef_floats(N);
+    float* coefs = dcache + quad_cache_floats(S, NP, kL);
+    float* rays = coefs + kRays * quad_coef_floats(NP);
     const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
     Shading sh = c.sh;
     const FieldBounds bounds = field_bounds(instances, N, f.inv_t, false, c.flags);
     sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
     sh.mlp_bits = 0u;
     sh.mlp_lds = nullptr;
+    const bool hot_runs = sh.reach >= 0.0f && sh.yaw;                          // (wave-uniform, the same in both kernels of the launch)
+    if (kHot && !hot_runs) return;
     const int num_waves = static_cast<int>(gridDim.x) * waves_per_block();
     const int wave_global = static_cast<int>(blockIdx.x) * waves_per_block() + wave;
     const int num_groups = (c.num_rays + kRays - 1) / kRays;
+    if (!kHot && hot_runs) {            // the usual case -- nothing marked -- costs this wave ONE vector load: lane k looks at the mark of the wave's k-th group
+        bool any = false;
+        for (int base = wave_global; base < num_groups; base += kWave * num_waves) {
+            const long long group = static_cast<long long>(base) + static_cast<long long>(lane_id()) * num_waves;
+            const float mark = group < num_groups ? labels_out[static_cast<size_t>(group) * kRays * N] : 0.0f;
+            any = any || __ballot(mark != mark) != 0ull;
+        }
+        if (!any) return;
+    }
     for (int group = wave_global; group < num_groups; group += num_waves) {
         const int first_ray = group * kRays;
+        if (!kHot && hot_runs) {                                                // behind the hot kernel: only the groups it marked
+            const float mark = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, labels_out[static_cast<size_t>(first_ray) * N])));
+            if (mark == mark) continue;
+        }
         const RowLanes rl = row_lanes<kL>(opaque_lane_id());
         wave_lds_sync();
-        bool done = false;
-        if (sh.reach >= 0.0f) {
-            done = sh.yaw ? rows_forward_body<kL, kRoundsS, true, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input,
-                                                                         labels_out, distances_out, coarse_weights_out, u_coarse_out, u_fine_out, stage, dcache, coefs, rays, rl)
-                          : rows_forward_body<kL, kRoundsS, false, false>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input,
-                                                                          labels_out, distances_out, coarse_weights_out, u_coarse_out, u_fine_out, stage, dcache, coefs, rays, rl);
-            if (!done) wave_lds_sync();
+        if (kHot) {
+            const bool done = rows_forward_body<kL, kRoundsS, true, false>(instances, N, NP, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input,
+                                                                           labels_out, distances_out, coarse_weights_out, u_coarse_out, u_fine_out, stage, dcache, coefs, rays, rl);
+            if (!done && lane_id() == 0) labels_out[static_cast<size_t>(first_ray) * N] = __builtin_nanf("");
+        } else {
+            bool done = false;
+            if (sh.reach >= 0.0f && !hot_runs) {
+                done = rows_forward_body<kL, kRoundsS, false, false>(instances, N, NP, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input,
+                                                                     labels_out, distances_out, coarse_weights_out, u_coarse_out, u_fine_out, stage, dcache, coefs, rays, rl);
+                if (!done) wave_lds_sync();
+            }
+            if (!done) rows_forward_body<kL, kRoundsS, false, true>(instances, N, NP, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input,
+                                                                    labels_out, distances_out, coarse_weights_out, u_coarse_out, u_fine_out, stage, dcache, coefs, rays, rl);
         }
-        if (!done) rows_forward_body<kL, kRoundsS, false, true>(instances, N, c, sh, first_ray, origins, directions, u_coarse, u_fine, sorted_input,
-                                                                labels_out, distances_out, coarse_weights_out, u_coarse_out, u_fine_out, stage, dcache, coefs, rays, rl);
     }
 }
 
+template <bool kHot, bool kFull>
 __global__ __launch_bounds__(kBlockThreads, 4) void render_hierarchical_quad_kernel(
     FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
     const float* __restrict__ u_coarse, const float* __restrict__ u_fine, float* __restrict__ labels_out, float* __restrict__ distances_out,
     float* __restrict__ coarse_weights_out, float* __restrict__ u_coarse_out, float* __restrict__ u_fine_out) {
-    hierarchical_rows_kernel_body<kRowLanes, 4>(f, instances, c, origins, directions, u_coarse, u_fine, labels_out, distances_out, coarse_weights_out, u_coarse_out, u_fine_out);
+    hierarchical_rows_kernel_body<kRowLanes, 4, kHot, kFull>(f, instances, c, origins, directions, u_coarse, u_fine, labels_out, distances_out, coarse_weights_out, u_coarse_out, u_fine_out);
 }
+template <bool kHot, bool kFull>
 __global__ __launch_bounds__(kBlockThreads, 4) void render_hierarchical_pair_kernel(
     FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
     const float* __restrict__ u_coarse, const float* __restrict__ u_fine, float* __restrict__ labels_out, float* __restrict__ distances_out,
     float* __restrict__ coarse_weights_out, float* __restrict__ u_coarse_out, float* __restrict__ u_fine_out) {
-    hierarchical_rows_kernel_body<32, 4>(f, instances, c, origins, directions, u_coarse, u_fine, labels_out, distances_out, coarse_weights_out, u_coarse_out, u_fine_out);
+    hierarchical_rows_kernel_body<32, 4, kHot, kFull>(f, instances, c, origins, directions, u_coarse, u_fine, labels_out, distances_out, coarse_weights_out, u_coarse_out, u_fine_out);
 }
 
 // ---- the adjoint at saved distances (vsrd_render_backward, box-only fields, label adjoints only) in the same mappings ------------------
@@ -1232,7 +1261,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void render_hierarchical_pair_ker
 // hierarchical_volumetric_rendering(...).backward() of the reference reaches for a box-only field (scripts/main.py:511-523, 629-671).
 // Launches that also carry adjoints of the per-sample gradients / weights keep the one-ray kernel (render_backward_kernel).
 template <int kL, int kRounds, bool kYaw, bool kRunning>
-__device__ __forceinline__ bool rows_backward_body(const float* __restrict__ instances, int N, const RenderArgs& c, const Shading& sh, int first_ray,
+__device__ __forceinline__ bool rows_backward_body(const float* __restrict__ instances, int N, int NP, const RenderArgs& c, const Shading& sh, int first_ray,
                                                    const float* __restrict__ origins, const float* __restrict__ directions,
                                                    const float* __restrict__ distances, int num_distances, const float* __restrict__ grad_labels,
                                                    float* stage, float* dcache, float* coefs, float* rays, float (&G)[kL == kRowLanes ? 4 : 16], const RowLanes& rl) {
@@ -1243,13 +1272,14 @@ __device__ __forceinline__ bool rows_backward_body(const float* __restrict__ ins
     const bool alive = my_ray < c.num_rays;
     const int ray = alive ? my_ray : (c.num_rays - 1);
     float* rowbase = stage + rl.row * quad_row_floats(half, kL);
-    float* coef_own = coefs + rl.row * quad_coef_floats(N);
+    float* coef_own = coefs + rl.row * quad_coef_floats(NP);
+    const unsigned long long real = NP > N ? ((1ull << N) - 1ull) : ~0ull;            // (NP > N: the full-shape instantiation's padded instance tables)
     {
         const float* o = origins + static_cast<size_t>(ray) * c.origin_stride;
         const float* d = directions + static_cast<size_t>(ray) * 3;
         Ray r;
         r.ox = o[0]; r.oy = o[1]; r.oz = o[2]; r.rx = d[0]; r.ry = d[1]; r.rz = d[2];
-        quad_ray_setup<kL>(instances, N, N, r, coef_own, rays + rl.row * kRowRayFloats, rl);       // (clears the label adjoints, syncs)
+        quad_ray_setup<kL>(instances, N, NP, r, coef_own, rays + rl.row * kRowRayFloats, rl);      // (clears the label adjoints, syncs)
     }
     const float* src = distances + static_cast<size_t>(ray) * num_distances;
     float* own_merged = rowbase + quad_merged_offset(half, kL);
@@ -1285,8 +1315,8 @@ __device__ __forceinline__ bool rows_backward_body(const float* __restrict__ ins
     unsigned active = 0u;
     int cached_round = -1;
     QuadAdjoint<kRounds> st;
-    if (!quad_forward_sweep<kL, kRounds, kYaw, kRunning>(st, instances, N, sh, rayp, coefs + data_row * quad_coef_floats(N), merged, num_points, live, dcache,
-                                                          rowbase, label, active, cached_round, rl)) return false;
+    if (!quad_forward_sweep<kL, kRounds, kYaw, kRunning>(st, instances, NP, sh, rayp, coefs + data_row * quad_coef_floats(NP), merged, num_points, live, dcache,
+                                                          rowbase, label, active, cached_round, rl, real)) return false;
     if (active == 0u) return true;
     const unsigned flow = quad_reverse_sweep<kL, kRounds, kYaw>(st, instances, sh, rayp, merged, num_points, live, active, lam_any, kRunning ? -1 : cached_round,
                                                                 coef_own, dcache, rowbase, own_merged, rl);
@@ -1300,7 +1330,7 @@ __device__ __forceinline__ bool rows_backward_body(const float* __restrict__ ins
 // render_hierarchical path takes.
 //   kHot   rotations about y + fixed soft-min shift (what BoxParameters3D decodes to); records per group whether that body served it
 //   !kHot  everything else: all groups when the hot kernel did not run, else only the groups it flagged, adding to the same partial rows
-template <int kL, bool kHot>
+template <int kL, bool kHot, bool kFull>
 __device__ __forceinline__ void backward_rows_kernel_body(
     FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
     const float* __restrict__ distances, int num_distances, const float* __restrict__ grad_labels, float* __restrict__ partials,
@@ -1308,6 +1338,8 @@ __device__ __forceinline__ void backward_rows_kernel_body(
     constexpr int kRays = kWave / kL;
     constexpr int kG = kL == kRowLanes ? 4 : 16;
     constexpr int kRounds = 8;                                               // up to 8 kL points
+    static_assert(kHot || !kFull, "only the hot kernel is instantiated for a full shape");
+    if (kFull) num_distances = 8 * kL;                                       // (the host launches kFull for exactly 2 S = 8 kL distances per ray: configs 2 and 5)
     unsigned* redo_summary = reinterpret_cast<unsigned*>(redo_flags);        // [0] groups flagged, [1] the hot kernel ran (zeroed by the host)
     redo_flags += 16;
     if (!kHot && __builtin_amdgcn_readfirstlane(static_cast<int>(redo_summary[1])) != 0 &&
@@ -1318,10 +1350,11 @@ __device__ __forceinline__ void backward_rows_kernel_body(
     const int lane0 = lane_id();
     const int half = (num_distances + 1) / 2;
     const int N = f.num_instances;
-    float* stage = lds + wave * quad_lds_floats(half, N, kL);
+    const int NP = kFull ? (kL == kRowLanes ? kQuadMaxInstances : kPairMaxInstances) : N;      // rows of the instance tables
+    float* stage = lds + wave * quad_lds_floats(half, NP, kL);
     float* dcache = stage + kRays * quad_row_floats(half, kL);
-    float* coefs = dcache + quad_cache_floats(half, N, kL);
-    float* rays = coefs + kRays * quad_coef_floats(N);
+    float* coefs = dcache + quad_cache_floats(half, NP, kL);
+    float* rays = coefs + kRays * quad_coef_floats(NP);
     Shading sh = c.sh;
     const FieldBounds bounds = field_bounds(instances, N, f.inv_t, false, c.flags);
     sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
@@ -1347,7 +1380,7 @@ __device__ __forceinline__ void backward_rows_kernel_body(
         const RowLanes rl = row_lanes<kL>(opaque_lane_id());
         wave_lds_sync();
         if (kHot) {
-            const bool done = rows_backward_body<kL, kRounds, true, false>(instances, N, c, sh, first_ray, origins, directions, distances, num_distances, grad_labels,
+            const bool done = rows_backward_body<kL, kRounds, true, false>(instances, N, NP, c, sh, first_ray, origins, directions, distances, num_distances, grad_labels,
                                                                            stage, dcache, coefs, rays, G, rl);
             if (lane0 == 0) {
                 redo_flags[group] = done ? 0 : 1;
@@ -1356,11 +1389,11 @@ __device__ __forceinline__ void backward_rows_kernel_body(
         } else {
             bool done = false;
             if (sh.reach >= 0.0f && !hot_runs) {
-                done = rows_backward_body<kL, kRounds, false, false>(instances, N, c, sh, first_ray, origins, directions, distances, num_distances, grad_labels,
+                done = rows_backward_body<kL, kRounds, false, false>(instances, N, NP, c, sh, first_ray, origins, directions, distances, num_distances, grad_labels,
                                                                      stage, dcache, coefs, rays, G, rl);
                 if (!done) wave_lds_sync();
             }
-            if (!done) rows_backward_body<kL, kRounds, false, true>(instances, N, c, sh, first_ray, origins, directions, distances, num_distances, grad_labels,
+            if (!done) rows_backward_body<kL, kRounds, false, true>(instances, N, NP, c, sh, first_ray, origins, directions, distances, num_distances, grad_labels,
                                                                     stage, dcache, coefs, rays, G, rl);
         }
     }
@@ -1372,17 +1405,17 @@ __device__ __forceinline__ void backward_rows_kernel_body(
         if (s * kWave + lane0 < N * kGradStride) out[s * kWave + lane0] = add ? (out[s * kWave + lane0] + G[s]) : G[s];
 }
 
-template <bool kHot>
+template <bool kHot, bool kFull>
 __global__ __launch_bounds__(kBlockThreads, 4) void render_backward_quad_kernel(
     FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
     const float* __restrict__ distances, int num_distances, const float* __restrict__ grad_labels, float* __restrict__ partials, unsigned char* __restrict__ redo_flags) {
-    backward_rows_kernel_body<kRowLanes, kHot>(f, instances, c, origins, directions, distances, num_distances, grad_labels, partials, redo_flags);
+    backward_rows_kernel_body<kRowLanes, kHot, kFull>(f, instances, c, origins, directions, distances, num_distances, grad_labels, partials, redo_flags);
 }
-template <bool kHot>
+template <bool kHot, bool kFull>
 __global__ __launch_bounds__(kBlockThreads, 3) void render_backward_pair_kernel(
     FieldArgs f, const float* __restrict__ instances, RenderArgs c, const float* __restrict__ origins, const float* __restrict__ directions,
     const float* __restrict__ distances, int num_distances, const float* __restrict__ grad_labels, float* __restrict__ partials, unsigned char* __restrict__ redo_flags) {
-    backward_rows_kernel_body<32, kHot>(f, instances, c, origins, directions, distances, num_distances, grad_labels, partials, redo_flags);
+    backward_rows_kernel_body<32, kHot, kFull>(f, instances, c, origins, directions, distances, num_distances, grad_labels, partials, redo_flags);
 }
 
 // Two rays per wave, 32 lanes each (kRoundsS = 2: S <= 64; 4: S <= 128).
