@@ -203,7 +203,7 @@ constexpr int kResidualWaves = 2;
 constexpr int kMaxBlocksResidual = 512;     // residual adjoint: one wave per SIMD resident; more workgroups than CUs = load balancing (each wave owns N x 1617 partials)
 
 // Residual adjoint, per wave: the residual jets (value + local gradient) the forward sweep leaves for the per-instance phase
-// [round <= 4][N][64] float4, and the seeds that phase leaves for the MLP adjoint [ray of batch][round <= 4][N][10][64].
+// [round <= 4][N][64] float4, and the seeds that phase leaves for the MLP adjoint [ray of batch][round <= 4][N][7][64].
 size_t residual_jet_floats(int num_instances, bool residual) {
     return residual ? static_cast<size_t>(kMaxBlocksResidual) * kResidualWaves * 4 * num_instances * kWave * 4 : 0;
 }

@@ -10,7 +10,7 @@ constexpr int kBlockThreads = kMaxWavesPerBlock * kWave;   // launch bound; the 
 
 __device__ __forceinline__ int waves_per_block() { return static_cast<int>(blockDim.x) >> 6; }
 constexpr int kGradStride = kInstanceStride;   // grad_instances rows are [t(3) R(9) dim(3) pad]
-constexpr int kSeedFloats = 10;                // per sample: local position (3), d_bar, gl_bar (3), x - t (3)
+constexpr int kSeedFloats = 7;                 // per sample: local position p (3), d_bar, gl_bar (3); x - t = R p is rebuilt by the reader (round 6; 10 before)
 constexpr int kMlpBatch = 8;                   // rays whose MLP adjoints are run together, instance-major (adjoint_phase_mlp)
 
 // residual fields: every wave also owns kMlpWbarFloats floats for residual_forward's staged weight operands (Shading::mlp_lds)
@@ -515,6 +515,14 @@ __device__ __forceinline__ void adjoint_label_mix(RayAdjoint<kRounds>& st, const
     }
 }
 
+// x - t of a sample from its position p in the instance's frame: p = R^T (x - t), so x - t = R p.  The seeds carried it as three more
+// floats until round 6 (write only what the adjoint cannot rebuild); nine multiply-adds per point where the MLP
+// adjoint spends thousands, and three tenths of the seed traffic.
+struct SeedOffset { float x, y, z; };
+__device__ __forceinline__ SeedOffset seed_offset(const Instance& in, float px, float py, float pz) {
+    return {fmaf(in.r02, pz, fmaf(in.r01, py, in.r00 * px)), fmaf(in.r12, pz, fmaf(in.r11, py, in.r10 * px)), fmaf(in.r22, pz, fmaf(in.r21, py, in.r20 * px))};
+}
+
 // Where the per-instance phase leaves the seeds (kSeedFloats x 64 floats per (round, instance), the points that matter first) and
 // their COUNTS (0 .. 64 leading columns; "masks" for historical reasons: rounds 2 and 3 stored 4-bit tile masks) for the MLP adjoint.  Two layouts: wave-private batches (render_backward_kernel / render_residual_step_kernel: [round][instance], 32-bit masks
 // in LDS) and the launch-wide dense table of the split residual step ([instance][ray of chunk][round], byte masks in global memory).
@@ -613,7 +621,6 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
                 if (sink.masks8 == nullptr || column < counts[k]) {
                     dst[0 * kWave] = e.px; dst[1 * kWave] = e.py; dst[2 * kWave] = e.pz; dst[3 * kWave] = d_bar;
                     dst[4 * kWave] = glbx; dst[5 * kWave] = glby; dst[6 * kWave] = glbz;
-                    dst[7 * kWave] = e.relx; dst[8 * kWave] = e.rely; dst[9 * kWave] = e.relz;
                 }
             }
             r00 += e.relx * pbx + gwbx * e.glx; r01 += e.relx * pby + gwbx * e.gly; r02 += e.relx * pbz + gwbx * e.glz;
@@ -645,7 +652,7 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
 // Phase B, residual part: the MLP adjoint of every (ray of the batch, instance, round) the box phase left seeds for.
 // * It runs AFTER the box phases, when no per-ray adjoint state is live: residual_backward (inlined here, its only call site) needs
 //   ~400 registers, and as a function called from inside the box phase it saved and restored 217 of them per call -- 200 GB of
-//   scratch traffic per launch on the C3-shaped bench.  The seeds (10 floats per sample) go through the workspace instead.
+//   scratch traffic per launch on the C3-shaped bench.  The seeds (7 floats per sample) go through the workspace instead.
 // * It is instance-major over a batch of kBatch rays: the 1617 weight adjoints of an instance are accumulated in LDS over the whole
 //   batch and flushed into the wave's global partial row once per (batch, instance) instead of once per (ray, instance) (that
 //   read-modify-write was 27 of the remaining 30 GB), the weight operands are loaded once, and one butterfly serves the batch.
@@ -666,8 +673,10 @@ __device__ __forceinline__ void adjoint_phase_mlp(const float* __restrict__ inst
             if (count == 0u) continue;
             const unsigned rows = tiles_of_count(static_cast<int>(count));
             const float* src = seeds + static_cast<size_t>(slot * N + i) * (kSeedFloats * kWave) + lane;
-            const float relx = src[7 * kWave], rely = src[8 * kWave], relz = src[9 * kWave];
-            const ResidualAdjoint ra = residual_backward(mlp + i * kMlpWeights, src[0 * kWave], src[1 * kWave], src[2 * kWave], src[3 * kWave],
+            const float px = src[0 * kWave], py = src[1 * kWave], pz = src[2 * kWave];
+            const SeedOffset rel = seed_offset(in, px, py, pz);
+            const float relx = rel.x, rely = rel.y, relz = rel.z;
+            const ResidualAdjoint ra = residual_backward(mlp + i * kMlpWeights, px, py, pz, src[3 * kWave],
                                                          src[4 * kWave], src[5 * kWave], src[6 * kWave], wbar, lane, rows | mlp_bits);
             r00 += relx * ra.px; r01 += relx * ra.py; r02 += relx * ra.pz;
             r10 += rely * ra.px; r11 += rely * ra.py; r12 += rely * ra.pz;
@@ -710,7 +719,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
     for (int idx = lane; idx < N * kGradStride; idx += kWave) G[idx] = 0.0f;
     const size_t wave_global0 = static_cast<size_t>(blockIdx.x) * waves_per_block() + wave;
     float* my_mlp = kResidual ? mlp_partials + wave_global0 * (static_cast<size_t>(N) * kMlpWeights) : nullptr;
-    // per-wave workspace of the residual adjoint: [round][instance][lane] residual jets (float4); [ray of batch][round][instance][10][lane] seeds
+    // per-wave workspace of the residual adjoint: [round][instance][lane] residual jets (float4); [ray of batch][round][instance][7][lane] seeds
     float4* rcache = kResidual ? residual_cache + wave_global0 * (static_cast<size_t>(kRounds) * N * kWave) : nullptr;
     float* seeds = kResidual ? seed_cache + wave_global0 * (static_cast<size_t>(kMlpBatch) * kRounds * N * kSeedFloats * kWave) : nullptr;
     if (kResidual) {
@@ -989,7 +998,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(V
 // are live, each half fits 256 registers (two waves per SIMD), and the MLP adjoint can be distributed by INSTANCE over the whole
 // launch: weight operands and weight-adjoint accumulators stay in registers over ~32 point sets instead of one batch of 8 rays.
 //   residual_step_front_kernel     pass 1, sampling, pass 2, silhouette BCE, eikonal term, reverse sweep, per-instance box adjoint;
-//                                  leaves seeds [N][slot][10][64] and 4-bit tile masks [N][slot] (slot = ray of chunk * rounds + round)
+//                                  leaves seeds [N][slot][7][64] and 4-bit tile masks [N][slot] (slot = ray of chunk * rounds + round)
 //   residual_mlp_adjoint_kernel    work items (instance, <= 64 consecutive slots), fetched dynamically by single-wave workgroups;
 //                                  ONE partial row [1617 weight adjoints | 16 box adjoints] per item, so the result does not depend
 //                                  on which wave ran which item (reduce_item_rows_kernel sums the rows in a fixed order)
@@ -1535,7 +1544,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             const float px = valid ? src[0 * kWave] : 0.0f, py = valid ? src[1 * kWave] : 0.0f, pz = valid ? src[2 * kWave] : 0.0f;
             const float res_bar = valid ? src[3 * kWave] : 0.0f;
             const float glx = valid ? src[4 * kWave] : 0.0f, gly = valid ? src[5 * kWave] : 0.0f, glz = valid ? src[6 * kWave] : 0.0f;
-            const float relx = valid ? src[7 * kWave] : 0.0f, rely = valid ? src[8 * kWave] : 0.0f, relz = valid ? src[9 * kWave] : 0.0f;
+            const SeedOffset rel = seed_offset(in, px, py, pz);               // (0 at the origin: lanes beyond the stream's end)
+            const float relx = rel.x, rely = rel.y, relz = rel.z;
             const unsigned rows = tiles_of_count(min(total - base, kWave));
             const ResidualAdjoint ra = mlp_adjoint_points<true>(s, wt, px, py, pz, res_bar, glx, gly, glz, scratch, lane, rows);
             r00 += relx * ra.px; r01 += relx * ra.py; r02 += relx * ra.pz;
@@ -1627,7 +1637,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             const float px = valid ? src[0 * kWave] : 0.0f, py = valid ? src[1 * kWave] : 0.0f, pz = valid ? src[2 * kWave] : 0.0f;
             const float res_bar = valid ? src[3 * kWave] : 0.0f;
             const float glx = valid ? src[4 * kWave] : 0.0f, gly = valid ? src[5 * kWave] : 0.0f, glz = valid ? src[6 * kWave] : 0.0f;
-            const float relx = valid ? src[7 * kWave] : 0.0f, rely = valid ? src[8 * kWave] : 0.0f, relz = valid ? src[9 * kWave] : 0.0f;
+            const SeedOffset rel = seed_offset(in, px, py, pz);               // (0 at the origin: lanes beyond the stream's end)
+            const float relx = rel.x, rely = rel.y, relz = rel.z;
             const unsigned rows = tiles_of_count(min(total - base, kWave));
             const ResidualAdjoint ra = mlp_adjoint_points_split(s, wt, px, py, pz, res_bar, glx, gly, glz, scratch, lane, rows);
             r00 += relx * ra.px; r01 += relx * ra.py; r02 += relx * ra.pz;
