@@ -596,6 +596,10 @@ __device__ __forceinline__ bool quad_pass_one(const float* __restrict__ instance
         const RoundCull cull = quad_round_bounds(rc, N, p.mid, sh.cull);
         if (quad_round_is_empty(rc, cull, sh, p.delta)) continue;                // alpha = 0 exactly: the transmittance passes unchanged
         unsigned long long evaluated = quad_round_mask(rc, cull, N, p.mid, real, sh.reach >= 0.0f ? sh.reach * (1.0f / (1.0f - kCullSlack)) : -1.0f);
+#ifdef VSRD_BOUND_FINER_CULLING         // (see quad_forward_sweep)
+        for (int drop = 0; drop < VSRD_BOUND_FINER_CULLING; ++drop)
+            if (__builtin_popcountll(evaluated) >= 5) evaluated &= ~(1ull << (63 - __builtin_clzll(evaluated)));
+#endif
         const float floor = cull.nearest_lo - sh.reach;
         if (!kRunning && wave_any(!((cull.nearest_hi + 1.0f - floor) * sh.inv_t <= kUnionFloorSpan))) return false;
         const UnionSums sums = quad_union_loop<false, false, kRunning, kYaw>(instances, evaluated, sh, cull, floor, p.x, p.y, p.z, nullptr, rl.lane);
@@ -660,6 +664,11 @@ __device__ __forceinline__ bool quad_forward_sweep(QuadAdjoint<kRounds>& st, con
             const RoundCull cull = quad_round_bounds(rc, N, p.mid, sh.cull);
             if (quad_round_is_empty(rc, cull, sh, p.delta)) continue;            // alpha = 0 exactly: no weight, no label, no adjoint
             st.near[q] = quad_round_mask(rc, cull, N, p.mid, real, sh.reach >= 0.0f ? sh.reach * (1.0f / (1.0f - kCullSlack)) : -1.0f);
+#ifdef VSRD_BOUND_FINER_CULLING         // TIMING BOUND ONLY (profiles/r06/variants.txt; wrong results): what a mapping with a finer culling granularity could
+            // buy at no cost of its own -- every pass-2 round with five or more candidate instances loses VSRD_BOUND_FINER_CULLING of them
+            for (int drop = 0; drop < VSRD_BOUND_FINER_CULLING; ++drop)
+                if (__builtin_popcountll(st.near[q]) >= 5) st.near[q] &= ~(1ull << (63 - __builtin_clzll(st.near[q])));
+#endif
             const float floor = cull.nearest_lo - sh.reach;
             if (!kRunning && wave_any(!((cull.nearest_hi + 1.0f - floor) * sh.inv_t <= kUnionFloorSpan))) return false;
             const UnionSums sums = quad_union_loop<true, (kL > kRowLanes), kRunning, kYaw>(instances, st.near[q], sh, cull, floor, p.x, p.y, p.z, dcache, rl.lane);
@@ -727,7 +736,11 @@ __device__ __forceinline__ unsigned quad_reverse_sweep(QuadAdjoint<kRounds>& st,
         const QuadPoint p = quad_point<kL>(merged, num_points, q, rr.ray, live, rl);
         // Lambda_s / Z_s = sum_n lambda_n w_{s,n} over the instances the forward sweep evaluated (culled ones: weight < exp(-18))
         float acc = 0.0f;
+#ifdef VSRD_BOUND_CACHED_LABEL_MIX      // TIMING BOUND ONLY (profiles/r06/variants.txt; wrong results): every round's label mix at the price of the cached round's
+        if (cached_round >= 0) {
+#else
         if (q == cached_round) {                                                   // wave-uniform: the soft-min terms are still in the distance cache
+#endif
             int slot = 0;
             for (unsigned long long todo = st.near[q]; todo != 0ull; todo &= todo - 1ull, ++slot) {
                 const int i = __builtin_ctzll(todo);
@@ -802,7 +815,14 @@ __device__ __forceinline__ void quad_phase_b(const QuadAdjoint<kRounds>& st, con
             if (!(((st.near[q] >> i) & 1ull) && ((flow >> q) & 1u))) continue;       // wave-uniform
             const float mid = mids[q * kL + rl.col];
             const float c1 = cbuf[(2 * q) * kWave + rl.lane], c3 = cbuf[(2 * q + 1) * kWave + rl.lane], c2 = c2buf[q * kL + rl.col + 1];
+#ifndef VSRD_BOUND_FREE_SELECTORS
             const BoxEval e = eval_box<kYaw>(in, ray.ox + ray.rx * mid, ray.oy + ray.ry * mid, ray.oz + ray.rz * mid);
+#else       // TIMING BOUND ONLY (profiles/r06/variants.txt; results are wrong inside boxes): the per-instance phase as if the seven selectors of a
+            // (sample, instance) pair -- inside, first-x, first-y, three p != 0, three q > 0 -- cost nothing at all
+            BoxEval e = box_value<kYaw>(in, ray.ox + ray.rx * mid, ray.oy + ray.ry * mid, ray.oz + ray.rz * mid);
+            e.hx = fmaxf(e.qx, 0.0f) * e.inv; e.hy = fmaxf(e.qy, 0.0f) * e.inv; e.hz = fmaxf(e.qz, 0.0f) * e.inv;
+            e.glx = __builtin_copysignf(e.hx, e.px); e.gly = __builtin_copysignf(e.hy, e.py); e.glz = __builtin_copysignf(e.hz, e.pz);
+#endif
             const float ds = e.d - st.m[q];
             const float w = fast_exp(-ds * inv_t) * st.inv_z[q];
             const float cc = w * (st.s[q] - ds * inv_t);
@@ -814,14 +834,24 @@ __device__ __forceinline__ void quad_phase_b(const QuadAdjoint<kRounds>& st, con
             const float d_bar = cc * (c1 - tb) + w * (c2 - tb - c3 * lam_i);
             const float gwbx = cc * gx_, gwby = cc * gy_, gwbz = cc * gz_;
             const float glbx = cc * rgx, glby = cc * rgy, glbz = cc * rgz;
+#ifndef VSRD_BOUND_FREE_SELECTORS
             const float sx = sign_of(e.px), sy = sign_of(e.py), sz = sign_of(e.pz);
+#else
+            const float sx = __builtin_copysignf(1.0f, e.px), sy = __builtin_copysignf(1.0f, e.py), sz = __builtin_copysignf(1.0f, e.pz);
+#endif
             const float vx = sx * glbx, vy = sy * glby, vz = sz * glbz;
             const float inv_n = box_inverse_norm(e);
             const float hx = fmaxf(e.qx, 0.0f) * inv_n, hy = fmaxf(e.qy, 0.0f) * inv_n, hz = fmaxf(e.qz, 0.0f) * inv_n;
             const float hv = hx * vx + hy * vy + hz * vz;
+#ifndef VSRD_BOUND_FREE_SELECTORS
             const float qbx = d_bar * e.hx + ((e.qx > 0.0f) ? (vx - hx * hv) * inv_n : 0.0f);
             const float qby = d_bar * e.hy + ((e.qy > 0.0f) ? (vy - hy * hv) * inv_n : 0.0f);
             const float qbz = d_bar * e.hz + ((e.qz > 0.0f) ? (vz - hz * hv) * inv_n : 0.0f);
+#else
+            const float qbx = d_bar * e.hx + (vx - hx * hv) * inv_n;
+            const float qby = d_bar * e.hy + (vy - hy * hv) * inv_n;
+            const float qbz = d_bar * e.hz + (vz - hz * hv) * inv_n;
+#endif
             const float pbx = sx * qbx, pby = sy * qby, pbz = sz * qbz;
             ad0 -= qbx; ad1 -= qby; ad2 -= qbz;
             r00 += e.relx * pbx + gwbx * e.glx; r02 += e.relx * pbz + gwbx * e.glz;
