@@ -37,7 +37,7 @@ def test_header_symbols_are_exported(lib):
     assert lib.vsrd_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define VSRD_ABI_VERSION (\d+)", header).group(1))
     assert lib.vsrd_workspace_bytes(16, 0) == 16384 * 4 * 16 * 16 * 4
     # box partials + per-wave MLP partials (512 workgroups x 2 waves) + residual jets [wave][4 rounds][N][64] float4 + seeds [wave][8 rays][4][N][10][64]
-    assert lib.vsrd_workspace_bytes(16, 1) == 16384 * 4 * 16 * 16 * 4 + 512 * 2 * 16 * 1617 * 4 + 512 * 2 * 4 * 16 * 64 * (16 + 8 * 28)
+    assert lib.vsrd_workspace_bytes(16, 1) == 16384 * 4 * 16 * 16 * 4 + 512 * 2 * 16 * 1617 * 4 + 512 * 2 * 4 * 16 * 64 * (16 + 8 * 28) + 512 * 2 * 16 * 16
     assert lib.vsrd_workspace_bytes(0, 0) == 0 and lib.vsrd_workspace_bytes(65, 0) == 0
     assert lib.vsrd_error_string(-1) == b"invalid argument"
 

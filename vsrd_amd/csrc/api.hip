@@ -203,9 +203,9 @@ constexpr int kResidualWaves = 2;
 constexpr int kMaxBlocksResidual = 512;     // residual adjoint: one wave per SIMD resident; more workgroups than CUs = load balancing (each wave owns N x 1617 partials)
 
 // Residual adjoint, per wave: the residual jets (value + local gradient) the forward sweep leaves for the per-instance phase
-// [round <= 4][N][64] float4, and the seeds that phase leaves for the MLP adjoint [ray of batch][round <= 4][N][7][64].
+// [round <= 4][N][64] float4 + a word per (round, instance) (render_kernels.h: jet_wave_float4s), and the seeds that phase leaves for the MLP adjoint [ray of batch][round <= 4][N][7][64].
 size_t residual_jet_floats(int num_instances, bool residual) {
-    return residual ? static_cast<size_t>(kMaxBlocksResidual) * kResidualWaves * 4 * num_instances * kWave * 4 : 0;
+    return residual ? static_cast<size_t>(kMaxBlocksResidual) * kResidualWaves * jet_wave_float4s(4, num_instances) * 4 : 0;
 }
 size_t residual_cache_floats(int num_instances, bool residual) {
     return residual_jet_floats(num_instances, residual) +
@@ -871,7 +871,9 @@ static bool plan_residual_step(int N, int S, int num_rays, bool allow_pair, Resi
     p->slots_per_instance = chunk * p->rounds;
     // items: enough of them to balance ~2000 waves, few enough that an item amortises its partial row (6.6 KB written and read once)
     long long per_item = (p->slots_per_instance * N) / 16384;
-    per_item = per_item < 4 ? 4 : (per_item > 32 ? 32 : per_item);
+    // (round 6: launches that leave >= 32 k items even at the largest item -- config 3's chunks of 110 k rays -- take 64 slots per item: same
+    //  speed as 32 or 48 (3.66-3.70 Mrays/s, tools/gpu_r06q.sh), half the partial rows written and reduced: 35 -> 17 GB per config-3 step)
+    per_item = per_item < 4 ? 4 : (per_item >= 128 ? 64 : (per_item > 32 ? 32 : per_item));
     const int forced = switches().slots_per_item;                        // experiment switch
     if (forced >= 1 && forced <= 64) per_item = forced;
     if (slots_per_item >= 1 && slots_per_item <= 64) per_item = slots_per_item;      // vsrd_render_config::adjoint_slots_per_item
@@ -881,7 +883,7 @@ static bool plan_residual_step(int N, int S, int num_rays, bool allow_pair, Resi
     auto take = [&](size_t floats) { const size_t here = at; at += (floats + 3) & ~size_t(3); return here; };
     p->box_partials = take(static_cast<size_t>(p->front_waves) * N * kGradStride);
     p->loss_partials = take(static_cast<size_t>(p->front_waves) * 2);
-    p->jets = take(static_cast<size_t>(p->front_waves) * p->rounds * N * kWave * 4);
+    p->jets = take(static_cast<size_t>(p->front_waves) * jet_wave_float4s(p->rounds, N) * 4);
     p->box_extra = take(static_cast<size_t>(N) * kGradStride);
     p->segment_sums = take(static_cast<size_t>(N) * kItemSegments * kItemRowFloats);
     p->seeds = take(static_cast<size_t>(N) * p->slots_per_instance * kSeedFloats * kWave);
@@ -920,7 +922,7 @@ bool plan_backward_split(int N, int num_distances, int num_rays, size_t budget_b
         auto take = [&](size_t floats) { const size_t here = at; at += (floats + 3) & ~size_t(3); return here; };
         p->box_partials = take(static_cast<size_t>(p->front_waves) * N * kGradStride);
         p->loss_partials = take(4);
-        p->jets = take(static_cast<size_t>(p->front_waves) * p->rounds * N * kWave * 4);
+        p->jets = take(static_cast<size_t>(p->front_waves) * jet_wave_float4s(p->rounds, N) * 4);
         p->box_extra = take(static_cast<size_t>(N) * kGradStride);
         p->segment_sums = take(static_cast<size_t>(N) * kItemSegments * kItemRowFloats);
         p->seeds = take(static_cast<size_t>(N) * p->slots_per_instance * kSeedFloats * kWave);

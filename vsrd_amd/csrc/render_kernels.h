@@ -327,6 +327,30 @@ struct RayAdjoint {
     bool last_running;       // the last round's soft-min used the running minimum: its cache rows hold distances, not soft-min terms
 };
 
+// The residual jets of one wave: [round][instance][lane] float4 (value, local gradient) followed by one word per (round, instance) that
+// says WHICH lanes hold one.  residual_forward evaluates 16-point tiles (residual.h: tile_plan); lanes of tiles it skipped have a zero jet
+// and -- round 6 -- no store: on config 3 three quarters of the float4s were zeros, written through the L2s (the waves' jets are 64 MB,
+// beyond them) and read back by the label mix and the per-instance phase: 84 of the step's 288 GB.  The word is the tile plan
+// (bits 0..3: tiles evaluated, bits 4..9: the lane the tiles are counted from); readers take zero where no jet was stored.
+__host__ __device__ constexpr size_t jet_wave_float4s(int rounds, int num_instances) {
+    return static_cast<size_t>(rounds) * num_instances * kWave + (static_cast<size_t>(rounds) * num_instances + 3) / 4;
+}
+template <int kRounds>
+__device__ __forceinline__ unsigned* jet_codes(float4* rcache, int N) { return reinterpret_cast<unsigned*>(rcache + static_cast<size_t>(kRounds) * N * kWave); }
+template <int kRounds>
+__device__ __forceinline__ const unsigned* jet_codes(const float4* rcache, int N) { return reinterpret_cast<const unsigned*>(rcache + static_cast<size_t>(kRounds) * N * kWave); }
+__device__ __forceinline__ unsigned jet_code(unsigned long long need) {
+    const TilePlan plan = tile_plan(need);
+    return plan.tiles | (static_cast<unsigned>(plan.start) << 4);
+}
+__device__ __forceinline__ bool jet_stored(unsigned code, int lane) { return (((code & 15u) >> (((lane - static_cast<int>(code >> 4)) & 63) >> 4)) & 1u) != 0u; }
+// The jet of (round k, instance i) at this lane; `code` is wave-uniform (one load of one address, made scalar).
+template <int kRounds>
+__device__ __forceinline__ float4 load_jet(const float4* rcache, int N, int k, int i, int lane) {
+    const unsigned code = __builtin_amdgcn_readfirstlane(jet_codes<kRounds>(rcache, N)[k * N + i]);
+    return jet_stored(code, lane) ? rcache[(k * N + i) * kWave + lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
 // The instance loop of the forward sweep for round k (render.h: union_loop, plus what the adjoint keeps: the 16-lane row masks and
 // the residual jets).  Instances that fail the exact test are cleared from st.near_any[k]: the later phases never see them.
 template <int kRounds, bool kResidual, bool kCacheD, bool kRunning, bool kYaw>
@@ -346,7 +370,11 @@ __device__ __forceinline__ UnionSums sweep_union_loop(RayAdjoint<kRounds>& st, i
         if (kResidual) {
             const Residual res = residual_forward_packed(mlp + i * sh.mlp_stride, e.px, e.py, e.pz, near & live, sh.mlp_bits, sh.mlp_lds);
             add_residual<kYaw>(e, in, res);
-            if (rcache) rcache[(k * N + i) * kWave + lane] = make_float4(res.value, res.gx, res.gy, res.gz);
+            if (rcache) {
+                const unsigned code = jet_code(near & live);                      // (the plan residual_forward_packed just ran)
+                if (jet_stored(code, lane)) rcache[(k * N + i) * kWave + lane] = make_float4(res.value, res.gx, res.gy, res.gz);
+                if (lane == 0) jet_codes<kRounds>(rcache, N)[k * N + i] = code;
+            }
         }
         // the distance cache feeds the label sums of the round: with a fixed shift it can hold the soft-min term itself
         const float term = union_accumulate<kRunning>(sums, e.d, e.gwx, e.gwy, e.gwz, lam ? lam[i] : 0.0f, sh.inv_t);
@@ -507,7 +535,7 @@ __device__ __forceinline__ void adjoint_label_mix(RayAdjoint<kRounds>& st, const
                 if (lam[i] == 0.0f) continue;                               // wave-uniform
                 const Instance in = load_instance_as<!kResidual>(instances, i);
                 float d = box_value<kYaw>(in, st.sa[k].x, st.sa[k].y, st.sa[k].z).d;
-                if (kResidual) d += rcache[(k * N + i) * kWave + lane].x;
+                if (kResidual) d += load_jet<kRounds>(rcache, N, k, i, lane).x;
                 acc += lam[i] * fast_exp(-(d - st.sa[k].m) * inv_t);
             }
         }
@@ -582,7 +610,7 @@ __device__ __forceinline__ void adjoint_phase_b(const RayAdjoint<kRounds>& st, c
                 const bool own = first_point + k * kWave + lane < num_points;
                 need = __ballot(own && !(e.d - (st.sa[k].m + st.sa[k].us) > cull_margin));
                 // the residual jet of this (round, instance) was left by the forward sweep
-                const float4 res = rcache[(k * N + i) * kWave + lane];
+                const float4 res = load_jet<kRounds>(rcache, N, k, i, lane);
                 add_residual<kYaw>(e, in, Residual{res.x, res.y, res.z, res.w});
             }
             const float ds = e.d - st.sa[k].m;
@@ -720,7 +748,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_backward_kernel(
     const size_t wave_global0 = static_cast<size_t>(blockIdx.x) * waves_per_block() + wave;
     float* my_mlp = kResidual ? mlp_partials + wave_global0 * (static_cast<size_t>(N) * kMlpWeights) : nullptr;
     // per-wave workspace of the residual adjoint: [round][instance][lane] residual jets (float4); [ray of batch][round][instance][7][lane] seeds
-    float4* rcache = kResidual ? residual_cache + wave_global0 * (static_cast<size_t>(kRounds) * N * kWave) : nullptr;
+    float4* rcache = kResidual ? residual_cache + wave_global0 * jet_wave_float4s(kRounds, N) : nullptr;
     float* seeds = kResidual ? seed_cache + wave_global0 * (static_cast<size_t>(kMlpBatch) * kRounds * N * kSeedFloats * kWave) : nullptr;
     if (kResidual) {
         for (int idx = lane; idx < N * kMlpWeights; idx += kWave) my_mlp[idx] = 0.0f;
@@ -913,7 +941,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(V
     for (int idx = lane; idx < N * kGradStride; idx += kWave) G[idx] = 0.0f;
     const size_t wave_global = static_cast<size_t>(blockIdx.x) * waves_per_block() + wave;
     float* my_mlp = mlp_partials + wave_global * (static_cast<size_t>(N) * kMlpWeights);
-    float4* rcache = residual_cache + wave_global * (static_cast<size_t>(kRounds) * N * kWave);
+    float4* rcache = residual_cache + wave_global * jet_wave_float4s(kRounds, N);
     float* seeds = seed_cache + wave_global * (static_cast<size_t>(kMlpBatch) * kRounds * N * kSeedFloats * kWave);
     for (int idx = lane; idx < N * kMlpWeights; idx += kWave) my_mlp[idx] = 0.0f;
     for (int idx = lane; idx < kMlpWeights; idx += kWave) wbar[idx] = 0.0f;
@@ -1037,7 +1065,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(k
     const size_t wave_global = static_cast<size_t>(blockIdx.x) * waves_per_block() + wave;
     float* out = partials + wave_global * (N * kGradStride);
     for (int idx = lane; idx < N * kGradStride; idx += kWave) G[idx] = accumulate ? out[idx] : 0.0f;      // chunks of one call add up
-    float4* rcache = residual_cache + wave_global * (static_cast<size_t>(kRounds) * N * kWave);
+    float4* rcache = residual_cache + wave_global * jet_wave_float4s(kRounds, N);
     const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
     Shading sh = c.sh;
     sh.mlp_lds = base - kMlpStageFloats;
@@ -1136,7 +1164,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(k
     const size_t wave_global = static_cast<size_t>(blockIdx.x) * waves_per_block() + wave;
     float* out = partials + wave_global * (N * kGradStride);
     for (int idx = lane; idx < N * kGradStride; idx += kWave) G[idx] = accumulate ? out[idx] : 0.0f;      // chunks of one call add up
-    float4* rcache = residual_cache + wave_global * (static_cast<size_t>(kRounds) * N * kWave);
+    float4* rcache = residual_cache + wave_global * jet_wave_float4s(kRounds, N);
     Shading sh = c.sh;
     sh.mlp_lds = mine;
     const FieldBounds bounds = field_bounds(instances, N, f.inv_t, true, c.flags);
@@ -1224,7 +1252,7 @@ __global__ __launch_bounds__(kPairWaves * kWave) __attribute__((amdgpu_waves_per
     const size_t wave_global = static_cast<size_t>(blockIdx.x) * kPairWaves + wave;
     float* out = partials + wave_global * (N * kGradStride);
     for (int idx = lane; idx < N * kGradStride; idx += kWave) G[idx] = accumulate ? out[idx] : 0.0f;
-    float4* rcache = residual_cache + wave_global * (static_cast<size_t>(kRounds) * N * kWave);
+    float4* rcache = residual_cache + wave_global * jet_wave_float4s(kRounds, N);
     const bool sorted_input = (u_fine != nullptr) && (c.flags & 1u);
     Shading sh = c.sh;
     sh.mlp_lds = mine;
