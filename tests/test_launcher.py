@@ -506,3 +506,19 @@ def test_frame_queue_hands_every_frame_out_once():
         assert len(group) <= 4
         seen += group
     assert sorted(seen) == frames and seen == queues[0].order and all(q.take(4) == [] for q in queues)
+
+
+def test_frame_batch_never_exceeds_a_ranks_share():
+    """Groups are handed out whole: a batch larger than total / world would leave ranks without work (32 frames, 8 ranks, batches of 16)."""
+    from vsrd_amd import launcher
+    assert launcher.effective_frame_batch(16, 32, 1) == 16
+    assert launcher.effective_frame_batch(16, 32, 8) == 4
+    assert launcher.effective_frame_batch(16, 33, 8) == 5
+    assert launcher.effective_frame_batch(16, 3, 8) == 1
+    assert launcher.effective_frame_batch(1, 1000, 8) == 1
+    assert launcher.effective_frame_batch(16, 10000, 8) == 16
+    for total in (1, 7, 32, 100):
+        for world in (1, 2, 8):
+            batch = launcher.effective_frame_batch(16, total, world)
+            groups = -(-total // batch)
+            assert groups >= min(world, total)                      # every rank (or every frame) gets a group

@@ -518,6 +518,15 @@ class _SleepWork:
 DEFAULT_FRAME_BATCH = 16
 
 
+def effective_frame_batch(requested: int, total_frames: int, world_size: int) -> int:
+    """Frames one rank steps together: what was asked for, but never more than a rank's share of the job -- groups are handed out whole
+    (FrameQueue.take), so 32 frames in batches of 16 would occupy two of eight ranks.  Every rank computes the same number."""
+    if requested <= 1:
+        return 1
+    share = -(-max(int(total_frames), 1) // max(int(world_size), 1))
+    return max(1, min(int(requested), share))
+
+
 def main(argv=None):
     """Optimise K synthetic frames, sharded over the ranks, each rank keeping `--frames-in-flight` frames on its GPU at a time with
     ``FrameOptimizer(graph=True)``; checkpoints through formats.checkpoint_payload (atomic, restartable: a frame whose final checkpoint
@@ -652,6 +661,7 @@ def _rank_main(args):
             os.environ.setdefault("MASTER_PORT", "29500")
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     total = args.frames or (2 * max(args.frames_in_flight, args.frame_batch) * world if use_gpu else 4 * world)
+    args.frame_batch = effective_frame_batch(args.frame_batch, total, world)
     out_dir = args.out or (tempfile.mkdtemp(prefix="vsrd_frames_") if rank == 0 else None)
     dynamic = args.queue == "dynamic" or (args.queue == "auto" and world > 1)
     store = None
