@@ -556,11 +556,15 @@ def test_full_size_parity_against_the_oracle(dev, config):
         determinate = (fixed32.double() - fixed64).abs().max(-1).values <= 1.0e-5
         determinate &= _stable_under_float32_noise(
             lambda a, b, c: _in_chunks(lambda x, y, z: orendering.render_given_distances(union64, x.double(), y.double(), z.double(), std, ratio).labels, (a, b, c), chunk),
-            (o[hit], d[hit], hip_distances[hit]), 2, fixed64)
+            (o[hit], d[hit], hip_distances[hit]), 2, fixed64, **(dict() if N <= 16 else dict(trials=8, ulps=16.0)))
+        # (config 5: eight trials of 16 ulps, as end to end below.  Four trials of 4 ulps -- 2e-5 m at 45 m -- certified a ray whose sample 184 has
+        #  its mid-point 5e-5 m from a face of the box it is inside of, where the reference's box SDF jumps from a unit normal to |q| / 1e-3:
+        #  a kernel whose pass 1 dropped one more negligible instance drew that fine sample a few ulps away and was 1.2e-3 off on that ray
+        #  while the float64 oracle with the sample moved by 1e-4 m reproduces its labels to 5e-5 -- tools/inner_debug.py, round 6)
         worst_determinate = float(at_samples[determinate].max())
         margin(tag, "pass 2: share of determinate rays", float(determinate.float().mean()), 1.0)
         margin(tag, "pass 2, determinate rays: worst", worst_determinate, 2e-5)
-        assert float(determinate.float().mean()) > (0.75 if N <= 16 else 0.5) and worst_determinate <= 2e-5       # (config 5: half of its selection are the culling A/B's outliers)
+        assert float(determinate.float().mean()) > (0.75 if N <= 16 else 0.4) and worst_determinate <= 2e-5       # (config 5: half of its selection are the culling A/B's outliers)
         # ---- loss and parameter gradients at the step's own samples (scripts/main.py:653-671 through renderers.py:212-263,
         # autograd's double backward through the SDF normal included): vsrd_render_forward + vsrd_render_backward on the selected rays at the
         # step's exported distances, BCE against the frame's own targets, against the float32 oracle's autograd on the same rays and samples

@@ -259,12 +259,18 @@ __device__ __forceinline__ float centre_distance2(const RayCull& rc, int i, floa
 }
 
 // After the minimum of the squared centre distances over the instances is known.
-__device__ __forceinline__ RoundCull cull_round(const RayCull& rc, float t, float nearest2, float margin) {
+// `inner` (field_bounds; 0: unknown): a radius every box contains around its centre.  A point at distance c from the centre of box j has
+// d_j <= c - inner (outside: the inscribed ball is no farther than that; inside: every face is at least inner - c away), so the smallest box
+// distance is at most (nearest centre distance) - inner: a tighter start for the exact test's running minimum and a tighter bound test.
+// Round 6, the kernels of quad_step.h: a round of the benchmark scene carried 0.7 candidates that fail the exact test and 0.3-0.4 survivors no
+// point of it needs (tests/survivor_statistics.py), because the minimum started from the nearest CENTRE; 0.8 m less of a 1.2-1.6 m slack:
+// config 2 232.4 -> 239.2 Mrays/s, config 5 31.4 -> 32.5, two-launch config 2 169.6 -> 171.7 (same box, tools/gpu_r06t.sh).
+__device__ __forceinline__ RoundCull cull_round(const RayCull& rc, float t, float nearest2, float margin, float inner = 0.0f) {
     RoundCull c;
     const float s = rc.reach + rc.rnorm * fabsf(t);
     c.err = kCullQuadSlack * s * s;
     const float nearest = fast_sqrt(fmaxf(nearest2, 0.0f) + c.err);
-    c.nearest_hi = nearest * (1.0f + kCullSlack);
+    c.nearest_hi = nearest * (1.0f + kCullSlack) - inner;
     c.limit = (c.nearest_hi + margin) * (1.0f / (1.0f - kCullSlack));
     c.nearest_lo = fast_sqrt(fmaxf(nearest2 - c.err, 0.0f)) * (1.0f - kCullSlack);
     return c;
@@ -328,10 +334,10 @@ __device__ __forceinline__ unsigned long long cull_round_mask(const RayCull& rc,
 //   reach   max_i |dim_i| + slack: every d_i(x) >= (nearest centre distance) (1 - k) - reach, which gives the soft-min a shift it
 //           knows BEFORE the instance loop (union_accumulate); < 0 when that bound is unavailable (non-orthonormal rotations) or
 //           reach / T is so large that exp(-(d - floor)/T) could underflow for the best instance.
-struct FieldBounds { float margin, reach; bool yaw; };   // yaw: every rotation is exactly of the form box_value<true> assumes
+struct FieldBounds { float margin, reach; bool yaw; float inner; };   // yaw: every rotation is exactly of the form box_value<true> assumes
 
 __device__ __forceinline__ FieldBounds field_bounds(const float* __restrict__ instances, int num_instances, float inv_t, bool residual, unsigned flags) {
-    float worst = 0.0f, rmax = 0.0f;
+    float worst = 0.0f, rmax = 0.0f, rmin = 3.0e38f;
     bool yaw = true;
     for (int i = 0; i < num_instances; ++i) {
         const Instance in = load_instance(instances, i);
@@ -341,6 +347,7 @@ __device__ __forceinline__ FieldBounds field_bounds(const float* __restrict__ in
         const float g02 = in.r00 * in.r02 + in.r10 * in.r12 + in.r20 * in.r22, g12 = in.r01 * in.r02 + in.r11 * in.r12 + in.r21 * in.r22;
         worst = fmaxf(worst, fmaxf(fmaxf(fabsf(g00 - 1.0f), fabsf(g11 - 1.0f)), fmaxf(fabsf(g22 - 1.0f), fmaxf(fabsf(g01), fmaxf(fabsf(g02), fabsf(g12))))));
         rmax = fmaxf(rmax, fast_sqrt(in.dx * in.dx + in.dy * in.dy + in.dz * in.dz));
+        rmin = fminf(rmin, fminf(in.dx, fminf(in.dy, in.dz)));
     }
     const bool orthonormal = worst < 1.0e-4f;                      // (a NaN parameter fails the test: no culling, running minimum)
     FieldBounds b;
@@ -349,6 +356,8 @@ __device__ __forceinline__ FieldBounds field_bounds(const float* __restrict__ in
     const float reach = rmax + 2.0e-3f;
     b.reach = (orthonormal && !(flags & 16u) && (reach + 1.0f) * inv_t <= 50.0f) ? reach : -1.0f;
     b.yaw = yaw && !(flags & 32u);
+    // the ball every box contains around its centre (cull_round); box-only fields with orthonormal rotations and positive extents only
+    b.inner = (orthonormal && !residual && num_instances > 0 && rmin > 4.0e-3f) ? rmin * (1.0f - 1.0e-4f) - 2.0e-3f : 0.0f;
     return b;
 }
 

@@ -409,7 +409,7 @@ __device__ __forceinline__ float centre_partial(const RayCull& rc, int i, float 
     return fmaf(t, rc.coef[kCullCoefs * i + 1], rc.coef[kCullCoefs * i + 0]);
 #endif
 }
-__device__ __forceinline__ RoundCull quad_round_bounds(const RayCull& rc, int num_instances, float t, float margin) {
+__device__ __forceinline__ RoundCull quad_round_bounds(const RayCull& rc, int num_instances, float t, float margin, float inner = 0.0f) {
     float nearest = 3.0e38f;
     int i = 0;
 #pragma unroll 4                                     // (sixteen instances in flight at most, also where the count is a compile-time 64)
@@ -419,9 +419,9 @@ __device__ __forceinline__ RoundCull quad_round_bounds(const RayCull& rc, int nu
     }
     for (; i < num_instances; ++i) nearest = fminf(nearest, centre_partial(rc, i, t));
 #ifndef VSRD_CULL_PARTIAL
-    return cull_round(rc, t, nearest, margin);
+    return cull_round(rc, t, nearest, margin, inner);
 #else
-    return cull_round(rc, t, fmaf(rc.c2 * t, t, nearest), margin);
+    return cull_round(rc, t, fmaf(rc.c2 * t, t, nearest), margin, inner);
 #endif
 }
 // Step 2: bit i = instance i may matter on some lane (wave-uniform).  (NaN-safe: an undecidable comparison keeps the instance.)
@@ -593,7 +593,7 @@ __device__ __forceinline__ bool quad_pass_one(const float* __restrict__ instance
         const RowRay rr = load_row_ray(rayp);
         const RayCull rc = row_cull(coef, rr);
         const QuadPoint p = quad_point<kL>(coarse, num_points, k, rr.ray, true, rl);
-        const RoundCull cull = quad_round_bounds(rc, N, p.mid, sh.cull);
+        const RoundCull cull = quad_round_bounds(rc, N, p.mid, sh.cull, sh.inner);
         if (quad_round_is_empty(rc, cull, sh, p.delta)) continue;                // alpha = 0 exactly: the transmittance passes unchanged
         unsigned long long evaluated = quad_round_mask(rc, cull, N, p.mid, real, sh.reach >= 0.0f ? sh.reach * (1.0f / (1.0f - kCullSlack)) : -1.0f);
 #ifdef VSRD_BOUND_FINER_CULLING         // (see quad_forward_sweep)
@@ -661,7 +661,7 @@ __device__ __forceinline__ bool quad_forward_sweep(QuadAdjoint<kRounds>& st, con
             const RowRay rr = load_row_ray(rayp);
             const RayCull rc = row_cull(coef, rr);
             const QuadPoint p = quad_point<kL>(merged, num_points, q, rr.ray, live, rl);
-            const RoundCull cull = quad_round_bounds(rc, N, p.mid, sh.cull);
+            const RoundCull cull = quad_round_bounds(rc, N, p.mid, sh.cull, sh.inner);
             if (quad_round_is_empty(rc, cull, sh, p.delta)) continue;            // alpha = 0 exactly: no weight, no label, no adjoint
             st.near[q] = quad_round_mask(rc, cull, N, p.mid, real, sh.reach >= 0.0f ? sh.reach * (1.0f / (1.0f - kCullSlack)) : -1.0f);
 #ifdef VSRD_BOUND_FINER_CULLING         // TIMING BOUND ONLY (profiles/r06/variants.txt; wrong results): what a mapping with a finer culling granularity could
@@ -1060,6 +1060,11 @@ __device__ __forceinline__ void silhouette_rows_kernel_body(
     Shading sh = c.sh;
     const FieldBounds bounds = field_bounds(instances, N, f.inv_t, false, c.flags);
     sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
+#ifndef VSRD_NO_CULL_INNER        // (A/B: the culling bounds without the boxes' inscribed ball, field.h: cull_round)
+    sh.inner = bounds.inner;
+#else
+    sh.inner = 0.0f;
+#endif
     sh.yaw_gradients = sh.yaw && (c.flags & 1024u) != 0u;                       // VSRD_FLAG_YAW_GRADIENTS
     sh.mlp_bits = 0u;
     sh.mlp_lds = nullptr;
@@ -1230,6 +1235,11 @@ __device__ __forceinline__ void hierarchical_rows_kernel_body(
     Shading sh = c.sh;
     const FieldBounds bounds = field_bounds(instances, N, f.inv_t, false, c.flags);
     sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
+#ifndef VSRD_NO_CULL_INNER        // (A/B: the culling bounds without the boxes' inscribed ball, field.h: cull_round)
+    sh.inner = bounds.inner;
+#else
+    sh.inner = 0.0f;
+#endif
     sh.mlp_bits = 0u;
     sh.mlp_lds = nullptr;
     const bool hot_runs = sh.reach >= 0.0f && sh.yaw;                          // (wave-uniform, the same in both kernels of the launch)
@@ -1388,6 +1398,11 @@ __device__ __forceinline__ void backward_rows_kernel_body(
     Shading sh = c.sh;
     const FieldBounds bounds = field_bounds(instances, N, f.inv_t, false, c.flags);
     sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
+#ifndef VSRD_NO_CULL_INNER        // (A/B: the culling bounds without the boxes' inscribed ball, field.h: cull_round)
+    sh.inner = bounds.inner;
+#else
+    sh.inner = 0.0f;
+#endif
     sh.yaw_gradients = sh.yaw && (c.flags & 1024u) != 0u;                       // VSRD_FLAG_YAW_GRADIENTS
     sh.mlp_bits = 0u;
     sh.mlp_lds = nullptr;

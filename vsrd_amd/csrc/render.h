@@ -19,6 +19,7 @@ struct Shading {
     float inv_t;    // 1 / soft-union temperature
     float cull;     // culling margin (field.h), wave-uniform; +huge disables culling
     float reach;    // soft-min floor: every d_i >= nearest centre distance - reach (field.h: field_bounds); < 0: running minimum
+    float inner;    // radius of the ball every box contains around its centre (field.h: cull_round), 0: not used (only the kernels of quad_step.h set it)
     bool yaw;       // every rotation is exactly a rotation about y (field.h: box_value<true>)
     bool yaw_gradients;  // ... and the caller differentiates only through rotation_matrix_y (VSRD_FLAG_YAW_GRADIENTS): the adjoints of the
                          //     five constant entries of the rotation are not accumulated
