@@ -553,23 +553,14 @@ def test_full_size_parity_against_the_oracle(dev, config):
         assert float(at_samples.median()) < 2e-6
         # a HARD bound where the reference's arithmetic is determinate -- the rays on which the float32 and the float64
         # oracle agree to 1e-5 at these samples: EVERY such ray within 2e-5 of the float32 oracle (= the reference's own arithmetic)
-        agree = (fixed32.double() - fixed64).abs().max(-1).values <= 1.0e-5
-        at_fixed_samples = lambda a, b, c: _in_chunks(
-            lambda x, y, z: orendering.render_given_distances(union64, x.double(), y.double(), z.double(), std, ratio).labels, (a, b, c), chunk)
-        gradient_rays = agree & _stable_under_float32_noise(at_fixed_samples, (o[hit], d[hit], hip_distances[hit]), 2, fixed64)    # (item 4c below)
-        determinate = gradient_rays if N <= 16 else \
-            gradient_rays & _stable_under_float32_noise(at_fixed_samples, (o[hit], d[hit], hip_distances[hit]), 2, fixed64, trials=8, ulps=16.0, seed=100)
-        # (config 5: eight trials of 16 ulps, as end to end below.  Four trials of 4 ulps -- 2e-5 m at 45 m -- certified a ray whose sample 184 has
-        #  its mid-point 5e-5 m from a face of the box it is inside of, where the reference's box SDF jumps from a unit normal to |q| / 1e-3:
-        #  a kernel whose pass 1 dropped one more negligible instance drew that fine sample a few ulps away and was 1.2e-3 off on that ray
-        #  while the float64 oracle with the sample moved by 1e-4 m reproduces its labels to 5e-5 -- tools/inner_debug.py, round 6.  The gradient
-        #  comparison below keeps the rays of the four 4-ulp trials: its criterion is relative to the float32 oracle's own distance from the
-        #  float64 one ON THE SAME RAYS, and that distance is what a handful of near-kink rays make it -- 4.6e-2 of the largest orientation
-        #  entry on that set, 1.0e-2 on the stricter one, with the kernel at 3.5e-2 / 3.6e-2 on either)
+        determinate = (fixed32.double() - fixed64).abs().max(-1).values <= 1.0e-5
+        determinate &= _stable_under_float32_noise(
+            lambda a, b, c: _in_chunks(lambda x, y, z: orendering.render_given_distances(union64, x.double(), y.double(), z.double(), std, ratio).labels, (a, b, c), chunk),
+            (o[hit], d[hit], hip_distances[hit]), 2, fixed64)
         worst_determinate = float(at_samples[determinate].max())
         margin(tag, "pass 2: share of determinate rays", float(determinate.float().mean()), 1.0)
         margin(tag, "pass 2, determinate rays: worst", worst_determinate, 2e-5)
-        assert float(determinate.float().mean()) > (0.75 if N <= 16 else 0.4) and worst_determinate <= 2e-5       # (config 5: half of its selection are the culling A/B's outliers)
+        assert float(determinate.float().mean()) > (0.75 if N <= 16 else 0.5) and worst_determinate <= 2e-5       # (config 5: half of its selection are the culling A/B's outliers)
         # ---- loss and parameter gradients at the step's own samples (scripts/main.py:653-671 through renderers.py:212-263,
         # autograd's double backward through the SDF normal included): vsrd_render_forward + vsrd_render_backward on the selected rays at the
         # step's exported distances, BCE against the frame's own targets, against the float32 oracle's autograd on the same rays and samples
@@ -578,7 +569,7 @@ def test_full_size_parity_against_the_oracle(dev, config):
         #  of 1 / p size and a Hessian that jumps; and next to the float32 oracle's own distance from the float64 oracle's gradient, as everywhere)
         from oracle import fields as ofields, geometry as ogeometry
         raw_names = ("locations", "dimensions", "orientations")
-        rows_index = torch.nonzero(hit).flatten()[gradient_rays]
+        rows_index = torch.nonzero(hit).flatten()[determinate]
         rows = int(rows_index.numel())
         rows_dev = rows_index.to(dev)
         rays_o, rays_d = origins[selection][rows_dev], directions[selection][rows_dev]

@@ -262,8 +262,8 @@ __device__ __forceinline__ float centre_distance2(const RayCull& rc, int i, floa
 // `inner` (field_bounds; 0: unknown): a radius every box contains around its centre.  A point at distance c from the centre of box j has
 // d_j <= c - inner (outside: the inscribed ball is no farther than that; inside: every face is at least inner - c away), so the smallest box
 // distance is at most (nearest centre distance) - inner: a tighter start for the exact test's running minimum and a tighter bound test.
-// Round 6, the kernels of quad_step.h: a round of the benchmark scene carried 0.7 candidates that fail the exact test and 0.3-0.4 survivors no
-// point of it needs (tests/survivor_statistics.py), because the minimum started from the nearest CENTRE; 0.8 m less of a 1.2-1.6 m slack:
+// Round 6, opt-in (-DVSRD_CULL_INNER; docs/OPTLOG.md round 6 item 7b) for the kernels of quad_step.h: a round of the benchmark scene carries 0.7 candidates that fail the exact test and 0.3-0.4 survivors no
+// point of it needs (tests/survivor_statistics.py), because the minimum starts from the nearest CENTRE; 0.8 m less of a 1.2-1.6 m slack:
 // config 2 232.4 -> 239.2 Mrays/s, config 5 31.4 -> 32.5, two-launch config 2 169.6 -> 171.7 (same box, tools/gpu_r06t.sh).
 __device__ __forceinline__ RoundCull cull_round(const RayCull& rc, float t, float nearest2, float margin, float inner = 0.0f) {
     RoundCull c;

@@ -1060,7 +1060,7 @@ __device__ __forceinline__ void silhouette_rows_kernel_body(
     Shading sh = c.sh;
     const FieldBounds bounds = field_bounds(instances, N, f.inv_t, false, c.flags);
     sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
-#ifndef VSRD_NO_CULL_INNER        // (A/B: the culling bounds without the boxes' inscribed ball, field.h: cull_round)
+#ifdef VSRD_CULL_INNER           // (opt-in, round 6: the culling bounds from the boxes' inscribed ball, field.h: cull_round; +3 %, docs/OPTLOG.md round 6 item 7b)
     sh.inner = bounds.inner;
 #else
     sh.inner = 0.0f;
@@ -1235,7 +1235,7 @@ __device__ __forceinline__ void hierarchical_rows_kernel_body(
     Shading sh = c.sh;
     const FieldBounds bounds = field_bounds(instances, N, f.inv_t, false, c.flags);
     sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
-#ifndef VSRD_NO_CULL_INNER        // (A/B: the culling bounds without the boxes' inscribed ball, field.h: cull_round)
+#ifdef VSRD_CULL_INNER           // (opt-in, round 6: the culling bounds from the boxes' inscribed ball, field.h: cull_round; +3 %, docs/OPTLOG.md round 6 item 7b)
     sh.inner = bounds.inner;
 #else
     sh.inner = 0.0f;
@@ -1398,7 +1398,7 @@ __device__ __forceinline__ void backward_rows_kernel_body(
     Shading sh = c.sh;
     const FieldBounds bounds = field_bounds(instances, N, f.inv_t, false, c.flags);
     sh.cull = bounds.margin; sh.reach = bounds.reach; sh.yaw = bounds.yaw;
-#ifndef VSRD_NO_CULL_INNER        // (A/B: the culling bounds without the boxes' inscribed ball, field.h: cull_round)
+#ifdef VSRD_CULL_INNER           // (opt-in, round 6: the culling bounds from the boxes' inscribed ball, field.h: cull_round; +3 %, docs/OPTLOG.md round 6 item 7b)
     sh.inner = bounds.inner;
 #else
     sh.inner = 0.0f;
