@@ -114,7 +114,8 @@ typedef struct vsrd_render_config {
     int32_t num_frames;                    /* 0 or 1: one frame                                                       */
     int64_t frame_stride;                  /* bytes between the frames' copies of every buffer of the call            */
     /* vsrd_render_residual_step, two-kernel form (ABI 8): slots (= 64-sample rounds of a ray) per work item of the MLP-adjoint kernel,
-     * 1..64; 0: planned from the launch's own size (about 16384 items per frame: 4 slots at 1000 rays).  An item keeps its instance's
+     * 1..64; 0: planned from the launch's own size (about 16384 items per frame: 4 slots at 1000 rays, at most 32 -- and 64 for launches that
+     * leave 32 k items even then: config 3's chunks of 110 k rays).  An item keeps its instance's
      * weight adjoints in registers and leaves ONE partial row of 6.6 KB, so larger items mean fewer rows to write and to sum -- what a
      * batch of frames wants, whose items are B times as many (8 frames x 1000 rays: 16 slots, -14 % per frame-step) -- and coarser load
      * balance.  The order of summation, and with it the last bits of grad_mlp_weights, depends on this number and on nothing else of the
