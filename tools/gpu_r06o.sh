@@ -4,6 +4,7 @@
 #   freesel    -DVSRD_BOUND_FREE_SELECTORS      per-instance phase as if the seven selectors of a pair cost nothing (selector bits carried from the forward sweep)
 #   finer1/2   -DVSRD_BOUND_FINER_CULLING=1|2   every round with >= 5 candidate instances loses 1 | 2 of them (an 8 x 8 mapping's finer culling granularity)
 #   cachedmix  -DVSRD_BOUND_CACHED_LABEL_MIX    the reverse sweep's label mix of EVERY round at the price of the cached round's (C5)
+#   first: bash tools/build_variant.sh freesel -DVSRD_BOUND_FREE_SELECTORS; ... finer1 -DVSRD_BOUND_FINER_CULLING=1; finer2 -DVSRD_BOUND_FINER_CULLING=2; cachedmix -DVSRD_BOUND_CACHED_LABEL_MIX
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r06o
 line() { python3 -c "

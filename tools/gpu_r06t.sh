@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 6: -DVSRD_CULL_INNER (the ball every box contains around its centre tightens the exact test's running minimum and the bound test) against the shipped
 # library, config 2 / config 5 / two-launch config 2, two turns; then the box-only GPU tests under the variant.
+#   first (here, no GPU needed): bash tools/build_variant.sh inner -DVSRD_CULL_INNER
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r06t
 line() { python3 -c "

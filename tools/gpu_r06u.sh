@@ -1,5 +1,7 @@
 #!/bin/bash
 # Which half of -DVSRD_CULL_INNER breaks config 5's hard bound: the bound test's limit or the exact test's starting minimum?
+#   first: bash tools/build_variant.sh innerlimit -DVSRD_CULL_INNER -DVSRD_CULL_INNER_LIMIT_ONLY; bash tools/build_variant.sh innerbest -DVSRD_CULL_INNER -DVSRD_CULL_INNER_BEST_ONLY
+#   (the two halves were macros of field.h: cull_round during the experiment; see docs/OPTLOG.md round 6 item 7b -- they are not in the tree any more)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r06u
 for v in innerlimit innerbest; do

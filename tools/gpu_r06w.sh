@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 6, last session on the final library (culling bounds with the inscribed radius): the whole GPU suite, counters of configs 2 and 5,
+# Round 6, a full session (as run on the -DVSRD_CULL_INNER library before it became opt-in; works on any build): the whole GPU suite, counters of configs 2 and 5,
 # the regime table, the driver's line.     gpurun --timeout 3000 -- 'bash tools/gpu_r06w.sh'
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r06
